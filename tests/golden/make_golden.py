@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ from the REFERENCE implementation.
+
+Run in the build container only (needs /root/reference; the GPU box has no copy):
+
+    python tests/golden/make_golden.py
+
+It imports the reference's ``models`` / ``diffusion`` / ``positional_embedding`` modules,
+(1) asserts the CPU oracle (oracle/*.py) matches them on the same inputs and
+(2) freezes inputs + expected outputs as small ``.npz`` files.  Only data is written —
+no reference source or bytecode.  Weights are not stored: they are rebuilt from
+``oracle.dit_oracle.seeded_state_dict(shape, seed)`` and pinned by a checksum.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("OSUD_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+
+import models as ref_models  # noqa: E402  (reference)
+import positional_embedding as ref_pe  # noqa: E402
+from diffusion import create_diffusion as ref_create_diffusion  # noqa: E402
+
+from oracle import diffusion_oracle as do  # noqa: E402
+from oracle import dit_oracle as mo  # noqa: E402
+from osu_diffusion_amd.synthetic import banded_attn_mask, synthetic_windows  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.set_num_threads(8)
+
+TINY = mo.DitShape(depth=2, hidden=128, heads=2, num_classes=10)
+SMALL = mo.shape_of("DiT-S", num_classes=10)
+
+
+def ref_model_for(shape: mo.DitShape, sd, dropout=0.2):
+    m = ref_models.DiT(depth=shape.depth, hidden_size=shape.hidden, num_heads=shape.heads,
+                       context_size=shape.context, num_classes=shape.num_classes,
+                       class_dropout_prob=dropout)
+    m.load_state_dict(sd, strict=True)
+    return m.eval()
+
+
+def checksum(sd) -> float:
+    return float(sum(v.double().abs().sum() for v in sd.values()))
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        out[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def close(a, b, tol, what):
+    err = (a.double() - b.double()).abs().max().item()
+    print(f"  oracle vs reference [{what}]: max|d| = {err:.3e}")
+    assert err <= tol, (what, err)
+
+
+# ------------------------------------------------------------------ G1 schedules
+def g1_schedules():
+    print("G1 schedules")
+    names = ["betas", "alphas_cumprod", "alphas_cumprod_prev", "alphas_cumprod_next", "sqrt_alphas_cumprod",
+             "sqrt_one_minus_alphas_cumprod", "log_one_minus_alphas_cumprod", "sqrt_recip_alphas_cumprod",
+             "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+             "posterior_mean_coef1", "posterior_mean_coef2"]
+    for tag, resp, sched in [("1000_cos", "1000", "squaredcos_cap_v2"), ("250_cos", "250", "squaredcos_cap_v2"),
+                             ("ddim50_cos", "ddim50", "squaredcos_cap_v2"), ("train_linear", "", "linear"),
+                             ("20_cos", "20", "squaredcos_cap_v2"), ("train_cos", "", "squaredcos_cap_v2")]:
+        ref = ref_create_diffusion(resp, noise_schedule=sched)
+        ora = do.create_schedule(resp, sched)
+        arrs = {}
+        for n in names:
+            r = getattr(ref, n)
+            assert np.array_equal(r, getattr(ora, n)), (tag, n)
+            arrs[n] = r
+        assert list(ora.timestep_map) == list(ref.timestep_map)
+        arrs["timestep_map"] = np.array(ref.timestep_map, dtype=np.int64)
+        save(f"g1_schedule_{tag}", respacing=resp, noise_schedule=sched, **arrs)
+
+
+# ------------------------------------------------------------------ G2 embeddings
+def g2_embeddings():
+    print("G2 embeddings")
+    v = torch.tensor([0.0, 1.0, 0.5, 511.99, 383.5, 999.0, 500.0, 14000.25, 1.4e5 / 10, 3.14159], dtype=torch.float32)
+    e128 = ref_pe.timestep_embedding(v, 128)
+    e256 = ref_pe.timestep_embedding(v, 256)
+    close(mo.sincos_embedding(v, 128), e128, 0.0, "emb128")
+    close(mo.sincos_embedding(v, 256), e256, 0.0, "emb256")
+    save("g2_embeddings", v=v, emb128=e128, emb256=e256)
+
+
+# ------------------------------------------------------------------ G3/G4 forward
+def inputs(n, T, shape, seed, ts, null_last=True):
+    (x, o, c), y = synthetic_windows(n, T, shape.num_classes, seed=seed, train_offsets=True)
+    if null_last:
+        y[-1] = shape.num_classes
+    t = torch.tensor([ts[i % len(ts)] for i in range(n)], dtype=torch.long)
+    return x, t, o, c, y
+
+
+def g3_forward():
+    print("G3/G4 forward")
+    for tag, shape, wseed, n, T, mask in [
+        ("tiny_T64", TINY, 11, 4, 64, None),
+        ("tiny_T128", TINY, 11, 4, 128, None),
+        ("tiny_T200_band", TINY, 11, 2, 200, banded_attn_mask(200, 128)),
+        ("tiny_T128_allfalse", TINY, 11, 2, 128, torch.zeros(128, 128, dtype=torch.bool)),
+        ("small_T128", SMALL, 12, 2, 128, None),
+        ("tiny_T128_rough", TINY, 13, 2, 128, None),
+    ]:
+        rough = tag.endswith("rough")
+        sd = mo.seeded_state_dict(shape, wseed, pos_gain=1.0, mod_std=0.2) if rough else mo.seeded_state_dict(shape, wseed)
+        ref = ref_model_for(shape, sd)
+        x, t, o, c, y = inputs(n, T, shape, seed=100 + T, ts=[0, 1, 500, 999])
+        out_ref = ref(x, t, o, c, y, attn_mask=mask)
+        out_ora = mo.forward(sd, shape, x, t, o, c, y, attn_mask=mask)
+        close(out_ora, out_ref, 5e-5 if rough else 2e-5, tag)
+        cfg4 = ref.forward_with_cfg(x, t, o, c, y, 4.0, attn_mask=mask)
+        cfg1 = ref.forward_with_cfg(x, t, o, c, y, 1.0, attn_mask=mask)
+        close(mo.forward_with_cfg(sd, shape, x, t, o, c, y, 4.0, attn_mask=mask), cfg4, 1e-4, tag + " cfg4")
+        extra = {} if mask is None else {"attn_mask": mask}
+        save(f"g3_forward_{tag}", shape=np.array([shape.depth, shape.hidden, shape.heads, shape.num_classes]),
+             wseed=wseed, wsum=checksum(sd), rough=rough, x=x, t=t, o=o, c=c, y=y, out=out_ref, out_cfg4=cfg4,
+             out_cfg1=cfg1, **extra)
+
+
+# ------------------------------------------------------------------ G5 sampler step
+def g5_step():
+    print("G5 sampler steps")
+    g = torch.Generator().manual_seed(5)
+    N, T = 6, 64
+    for tag, resp in [("1000", "1000"), ("250", "250")]:
+        ref = ref_create_diffusion(resp, noise_schedule="squaredcos_cap_v2")
+        ora = do.create_schedule(resp, "squaredcos_cap_v2")
+        nt = ref.num_timesteps
+        t = torch.tensor([0, 1, nt // 2, nt - 1, 0, nt - 2], dtype=torch.long)
+        x = torch.randn(N, 2, T, generator=g) * torch.tensor([0.3, 1.0, 1.0, 1.0, 3.0, 1.0]).view(-1, 1, 1) + 0.5
+        mout = torch.randn(N, 4, T, generator=g)
+        mout[:, 2:] = mout[:, 2:].clamp(-1.5, 1.5)
+        noise = torch.randn(N, 2, T, generator=g)
+        model = lambda *_a, **_k: mout  # noqa: E731
+
+        outs = {}
+        for name, fn, kw in [("p", ref.p_sample, {}), ("ddim0", ref.ddim_sample, {"eta": 0.0}),
+                             ("ddim1", ref.ddim_sample, {"eta": 1.0})]:
+            torch.manual_seed(77)
+            r = fn(model, x, t, clip_denoised=True, **kw)
+            torch.manual_seed(77)
+            nz = torch.randn_like(x)
+            if name == "p":
+                o = do.p_sample_step(ora, mout, x, t, nz)
+            else:
+                o = do.ddim_step(ora, mout, x, t, nz, eta=kw["eta"])
+            close(o["sample"], r["sample"], 0.0, f"{tag} {name} sample")
+            close(o["pred_xstart"], r["pred_xstart"], 0.0, f"{tag} {name} x0")
+            outs[name + "_sample"] = r["sample"]
+            outs[name + "_x0"] = r["pred_xstart"]
+            outs[name + "_noise"] = nz
+        torch.manual_seed(77)
+        r = ref.p_sample(model, x, t, clip_denoised=False)
+        outs["p_noclip_sample"] = r["sample"]
+        save(f"g5_step_{tag}", x=x, t=t, model_out=mout, **outs)
+
+
+# ------------------------------------------------------------------ G6 chained loop
+def g6_loop():
+    print("G6 chained sampling loops")
+    shape, wseed = TINY, 11
+    sd = mo.seeded_state_dict(shape, wseed)
+    ref = ref_model_for(shape, sd)
+    n, T = 2, 64
+    (x0, o, c), y = synthetic_windows(n, T, shape.num_classes, seed=7, train_offsets=False)
+    o = torch.cat([o, o])
+    c = torch.cat([c, c])
+    y = torch.cat([y, torch.full_like(y, shape.num_classes)])
+    for tag, resp, ddim in [("p20", "20", None), ("ddim20_eta1", "20", 1.0), ("ddim20_eta05", "20", 0.5)]:
+        dref = ref_create_diffusion(resp, noise_schedule="squaredcos_cap_v2")
+        ora = do.create_schedule(resp, "squaredcos_cap_v2")
+        torch.manual_seed(3)
+        z = torch.randn(n, 2, T)
+        z = torch.cat([z, z])
+        kw = dict(o=o, c=c, y=y, cfg_scale=4.0, attn_mask=None)
+        torch.manual_seed(4)
+        if ddim is None:
+            final = dref.p_sample_loop(ref.forward_with_cfg, z.shape, z, clip_denoised=True, model_kwargs=kw, device="cpu")
+        else:
+            final = dref.ddim_sample_loop(ref.forward_with_cfg, z.shape, z, clip_denoised=True, model_kwargs=kw,
+                                          device="cpu", eta=ddim)
+        torch.manual_seed(4)
+        noises = torch.stack([torch.randn_like(z) for _ in range(ora.num_timesteps)])
+        fn = lambda xx, tt: mo.forward_with_cfg(sd, shape, xx, tt, o, c, y, 4.0)  # noqa: E731
+        mine = do.sample_loop(ora, fn, z, noises, ddim_eta=ddim)
+        close(mine, final, 5e-4, tag)
+        save(f"g6_loop_{tag}", shape=np.array([shape.depth, shape.hidden, shape.heads, shape.num_classes]),
+             wseed=wseed, wsum=checksum(sd), z=z, o=o, c=c, y=y, noises=noises, final=final, respacing=resp,
+             eta=-1.0 if ddim is None else ddim)
+
+
+# ------------------------------------------------------------------ G7 training
+def g7_training():
+    print("G7 training losses + grads + AdamW/EMA step")
+    torch.set_grad_enabled(True)
+    shape, wseed = TINY, 11
+    B, T = 4, 64
+    (x, o, c), y = synthetic_windows(B, T, shape.num_classes, seed=21, train_offsets=True)
+    t = torch.tensor([0, 3, 500, 999], dtype=torch.long)
+    g = torch.Generator().manual_seed(22)
+    noise = torch.randn(B, 2, T, generator=g)
+    drop = torch.tensor([False, True, False, False])
+    y_eff = torch.where(drop, torch.full_like(y, shape.num_classes), y)
+    for loss_name, use_l1 in [("l1", True), ("mse", False)]:
+        sd = mo.seeded_state_dict(shape, wseed)
+        ref = ref_model_for(shape, sd)  # eval(): labels pre-dropped == train-mode dropout with that mask
+        for p in ref.parameters():
+            p.grad = None
+        dref = ref_create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=use_l1)
+        terms = dref.training_losses(ref, x, t, dict(o=o, c=c, y=y_eff), noise=noise)
+        loss = terms["loss"].mean()
+        loss.backward()
+        grads = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
+        # oracle
+        osd = {k: v.clone().requires_grad_(k != "xoc_embedder.playfield_size") for k, v in sd.items()}
+        ora = do.create_schedule("", "squaredcos_cap_v2")
+        fn = lambda xx, tt: mo.forward(osd, shape, xx, tt, o, c, y, drop_mask=drop)  # noqa: E731
+        ot = do.training_losses(ora, fn, x, t, noise, loss=loss_name)
+        ot["loss"].mean().backward()
+        for k in ("loss", "vb", loss_name):
+            close(ot[k].detach(), terms[k].detach(), 2e-5, f"{loss_name} term {k}")
+        worst = max((osd[k].grad - grads[k]).abs().max().item() for k in grads)
+        print(f"  oracle vs reference [{loss_name} grads]: max|d| = {worst:.3e}")
+        assert worst < 1e-4
+        keep = ["xoc_embedder.mlp.0.weight", "t_embedder.mlp.2.bias", "y_embedder.embedding_table.weight",
+                "blocks.0.attn.in_proj_weight", "blocks.0.attn.in_proj_bias", "blocks.1.attn.out_proj.weight",
+                "blocks.0.mlp.fc1.weight", "blocks.1.mlp.fc2.bias", "blocks.1.adaLN_modulation.1.weight",
+                "final_layer.linear.weight", "final_layer.adaLN_modulation.1.bias"]
+        gsave = {"grad:" + k: grads[k] for k in keep}
+        gnorm = {k: float(v.double().norm()) for k, v in grads.items()}
+        # one AdamW + EMA step (train.py:161,258-261; update_ema :36-45)
+        import copy
+        ema = copy.deepcopy(ref)
+        opt = torch.optim.AdamW(ref.parameters(), lr=1e-4, weight_decay=0)
+        opt.step()
+        with torch.no_grad():
+            for (k, pe), (_, pm) in zip(ema.named_parameters(), ref.named_parameters()):
+                pe.mul_(0.9999).add_(pm.data, alpha=1 - 0.9999)
+        after = {"after:" + k: dict(ref.named_parameters())[k].detach() for k in keep}
+        ema_after = {"ema:" + k: dict(ema.named_parameters())[k].detach() for k in keep[:3]}
+        save(f"g7_train_{loss_name}", shape=np.array([shape.depth, shape.hidden, shape.heads, shape.num_classes]),
+             wseed=wseed, wsum=checksum(sd), x=x, o=o, c=c, y=y, t=t, noise=noise, drop=drop,
+             loss=terms["loss"].detach(), vb=terms["vb"].detach(), main=terms[loss_name].detach(),
+             grad_keys=np.array(sorted(gnorm)), grad_norms=np.array([gnorm[k] for k in sorted(gnorm)]),
+             **gsave, **after, **ema_after)
+    torch.set_grad_enabled(False)
+
+
+# ------------------------------------------------------------------ G9 windows / init
+def g9_init_and_keys():
+    print("G9 registry: state-dict keys, shapes, init statistics")
+    torch.manual_seed(0)
+    m = ref_models.DiT_models["DiT-S"](num_classes=10, context_size=144, class_dropout_prob=0.2)
+    keys = [k for k, _ in m.named_parameters()]
+    shapes = [tuple(p.shape) for _, p in m.named_parameters()]
+    assert keys == list(mo.param_shapes(SMALL).keys()), "oracle key order differs from reference"
+    assert shapes == list(mo.param_shapes(SMALL).values())
+    sd = m.state_dict()
+    probe = {k: sd[k].flatten()[:8].clone() for k in ["xoc_embedder.mlp.0.weight", "blocks.0.attn.in_proj_weight",
+                                                      "blocks.3.mlp.fc1.weight", "y_embedder.embedding_table.weight",
+                                                      "t_embedder.mlp.2.weight", "blocks.11.attn.out_proj.weight"]}
+    save("g9_registry_dit_s", keys=np.array(keys), shapes=np.array([str(s) for s in shapes]),
+         state_keys=np.array(list(sd.keys())), **{"probe:" + k: v for k, v in probe.items()})
+
+
+if __name__ == "__main__":
+    g1_schedules()
+    g2_embeddings()
+    g3_forward()
+    g5_step()
+    g6_loop()
+    g7_training()
+    g9_init_and_keys()
+    print("all golden fixtures written; oracle pinned against the reference")
