@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the native DiT path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--mode sample|train]
+
+N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
+(one rank per GPU).  Prints ONE JSON line on rank 0 (contract in the task description; DESIGN.md §5
+says how each number is obtained).
+
+mode sample (BASELINE.json configs[3]): DiT-B, 64 synthetic beatmap windows of 128 tokens doubled
+  for classifier-free guidance (batch 128), cfg-scale 4.0, the 1000-step squaredcos schedule.  A
+  "step" is one sampling step = forward_with_cfg + the p_sample update; K steps starting at t=999
+  are timed, per-step Gaussian noise for the K steps is generated inside the timed region.
+  Sampling shards by rows with no collective: every rank runs its own 64 windows (weak scaling).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+FLOP_PER_TOKEN_FWD = 176.10e6  # DiT-B, T=128
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--mode", choices=["sample", "train"], default=os.environ.get("OSUD_BENCH_MODE", "sample"))
+    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--maps", type=int, default=64, help="beatmap windows per GPU (CFG doubles the batch)")
+    ap.add_argument("--seq-len", type=int, default=128)
+    ap.add_argument("--model", default="DiT-B")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def dist_setup(args):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl")  # RCCL on ROCm
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    return world, rank, local
+
+
+def barrier(world):
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(value, world, dev):
+    if world == 1:
+        return value
+    import torch.distributed as dist
+
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gemm_roofline(M, N, K, dev, iters=50):
+    """Live HIP-event timing of the dominant kernel — the fc1 GEMM (bias + GELU epilogue) at the
+    bench shape — on the current stream, random operands."""
+    from osu_diffusion_amd import _lib
+
+    L = _lib.lib()
+    Yf = torch.randn(M, K, device=dev)
+    Xf = torch.randn(N, K, device=dev) / K ** 0.5
+    bias = torch.randn(N, device=dev) * 0.02
+    Y = torch.empty(M, K, dtype=torch.bfloat16, device=dev)
+    X = torch.empty(N, K, dtype=torch.bfloat16, device=dev)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    _lib.check(L.osud_op_convert(0, _lib.ptr(Yf), _lib.ptr(Y), Yf.numel(), _lib.stream_ptr(dev)))
+    _lib.check(L.osud_op_convert(0, _lib.ptr(Xf), _lib.ptr(X), Xf.numel(), _lib.stream_ptr(dev)))
+
+    def launch():
+        _lib.check(L.osud_op_gemm(0, _lib.EPI_BIAS_GELU_TE, _lib.ptr(Y), K, _lib.ptr(X), K, M, N, K, _lib.ptr(out), N,
+                                  _lib.ptr(bias), None, 0, 0, 0, _lib.stream_ptr(dev)))
+
+    for _ in range(5):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(iters):
+        launch()
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) / 1e3 / iters
+    flops = 2.0 * M * N * K
+    return {"bound": "mfma", "kernel": "gemm_kernel<bf16, EPI_BIAS_GELU_TE> (fc1 %dx%dx%d)" % (M, N, K),
+            "achieved": round(flops / sec / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(flops / sec / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "flop_per_launch": flops, "avg_launch_us": round(sec * 1e6, 2)}
+
+
+def cpu_baseline_sample(model, args, windows, steps=2):
+    """Oracle (CPU restatement of the reference) timed on this host's cores on a bounded sample:
+    `steps` p_sample steps at the SAME shapes (batch 128 x 128 tokens, DiT-B, cfg 4)."""
+    from oracle import diffusion_oracle as do
+    from oracle import dit_oracle as mo
+
+    (x, o, c), y = windows
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    shape = mo.shape_of(args.model, num_classes=model.y_embedder.num_classes)
+    sch = do.create_schedule("1000", "squaredcos_cap_v2")
+    cores = min(32, os.cpu_count() or 1)  # measured on the GPU host: 32 threads is the fastest setting (tools/cpu_threads_probe.py)
+    torch.set_num_threads(cores)
+    xx = torch.randn(x.shape)
+    t = torch.full((x.shape[0],), 999, dtype=torch.long)
+    tmap = torch.from_numpy(sch.timestep_map)
+    with torch.no_grad():
+        mo.forward_with_cfg(sd, shape, xx[:4], tmap[t[:4]], o[:4], c[:4], y[:4], 4.0)  # warm the allocator
+        t0 = time.perf_counter()
+        for k in range(steps):
+            out = mo.forward_with_cfg(sd, shape, xx, tmap[t - k], o, c, y, 4.0)
+            xx = do.p_sample_step(sch, out, xx, t - k, torch.randn(x.shape))["sample"]
+        dt = time.perf_counter() - t0
+    return {"value": round(steps / dt, 5), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} p_sample steps (t=999..) of the same workload, fp32 torch-CPU oracle, {dt:.1f} s"}
+
+
+def bench_sample(args, world, rank, dev):
+    from osu_diffusion_amd.diffusion import create_diffusion
+    from osu_diffusion_amd.models import DiT_models
+    from osu_diffusion_amd.synthetic import randomize_zero_init, synthetic_windows
+
+    K = args.steps if args.steps is not None else 1000
+    W = args.warmup if args.warmup is not None else 50
+    assert 1 <= K <= 1000 and 0 <= W <= 1000
+    num_classes = 52670
+    torch.manual_seed(rank)
+    model = DiT_models[args.model](num_classes=num_classes, context_size=19 - 3 + 128, precision=args.precision)
+    model = randomize_zero_init(model.to(dev), seed=0).eval()
+    n, T = args.maps, args.seq_len
+    (x, o, c), y = synthetic_windows(n, T, num_classes, seed=1000 + rank, train_offsets=False)
+    x, o, c = torch.cat([x, x]), torch.cat([o, o]), torch.cat([c, c])
+    y = torch.cat([y, torch.full_like(y, num_classes)])  # uncond half uses the null class (sample.py:106-107)
+    windows = ((x, o, c), y)
+    diffusion = create_diffusion("1000", noise_schedule="squaredcos_cap_v2")
+    kw = dict(o=o.to(dev), c=c.to(dev), y=y.to(dev), cfg_scale=4.0, attn_mask=None)
+    model.reserve(2 * n, T)
+    z = torch.randn(2 * n, 2, T, device=dev)
+
+    def run(k_steps, state):
+        noise = torch.randn(k_steps, *state.shape, device=dev)  # per-step noise, generated in the timed region
+        diffusion.run_steps(model.forward_with_cfg, state, kw, first_step=999, last_step=999 - k_steps + 1,
+                            step_noise=noise)
+
+    if W:
+        run(W, z.clone())
+    state = z.clone()
+    barrier(world)
+    t0 = time.perf_counter()
+    run(K, state)
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    assert torch.isfinite(state).all(), "non-finite samples"
+
+    steps_per_s = K / dt
+    M = 2 * n * T
+    flop_step = M * FLOP_PER_TOKEN_FWD if args.model == "DiT-B" and T == 128 else None
+    res = {
+        "metric": "1000-step CFG sample steps/sec (DiT-B seq128)", "value": round(world * steps_per_s, 3),
+        "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": f"sample.py path: {args.model} seq-len {T}, {n} synthetic beatmap windows x2 (CFG) per GPU, "
+                               f"cfg-scale 4.0, 1000-step squaredcos schedule, steps t=999..{999 - K + 1}",
+                   "rows_per_gpu": 2 * n, "seq_len": T, "sharding": "rows per rank, no collective"},
+    }
+    if flop_step:
+        res["end_to_end"] = {"flop_per_step": flop_step, "achieved_tflops": round(steps_per_s * flop_step / 1e12, 1),
+                             "mfma_frac": round(steps_per_s * flop_step / 1e12 / PEAK_BF16_TFLOPS, 4)}
+    if rank == 0 and not args.no_roofline and args.precision == "bf16":
+        D = model.hidden_size
+        res["roofline"] = gemm_roofline(M, 4 * D, D, dev)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_sample(model, args, windows)
+    return res
+
+
+def main():
+    args = parse()
+    world, rank, local = dist_setup(args)
+    dev = torch.device("cuda", local if world > 1 else 0)
+    if args.mode == "train":
+        from bench_train import bench_train  # added with the training milestone
+
+        res = bench_train(args, world, rank, dev)
+    else:
+        res = bench_sample(args, world, rank, dev)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,146 @@
+/*
+ * osud.h — C ABI of libosud.so, the MI355X-native (gfx950) DiT denoising path for
+ * osu-diffusion.  Plain pointers and sizes only; no torch / C++ types cross this
+ * boundary.  Every entry point returns 0 on success or an OSUD_ERR_* code;
+ * osud_last_error() gives the thread-local message.  Handles are bound to the device
+ * that was current at create time and are NOT thread-safe; all work is enqueued on the
+ * caller-supplied stream (a hipStream_t passed as void*; NULL = the default stream), so
+ * it is ordered with the caller's other work on that stream.  The caller owns every
+ * I/O buffer (device memory); the library owns its handles, its packed low-precision
+ * weight copies and its activation workspaces (allocated in osud_dit_reserve /
+ * first use of a new shape — no allocation in steady state, so steps are hipGraph-
+ * capturable).
+ *
+ * Reference interfaces replaced (paths relative to the osu-diffusion repository):
+ *   models.py:243-273   DiT.__init__            -> osud_dit_create / osud_dit_set_param
+ *   models.py:306-325   DiT.forward             -> osud_dit_forward
+ *   models.py:327-343   DiT.forward_with_cfg    -> osud_dit_forward (cfg_scale >= 0)
+ *   diffusion/gaussian_diffusion.py:167-211 + diffusion/respace.py:72-86
+ *                       schedule tables         -> osud_sched_create
+ *   diffusion/gaussian_diffusion.py:273-369,420-467  p_mean_variance + p_sample
+ *                                               -> osud_sampler_step (mode P)
+ *   diffusion/gaussian_diffusion.py:563-610     ddim_sample -> osud_sampler_step (mode DDIM)
+ *   diffusion/gaussian_diffusion.py:514-561,686-733  *_sample_loop_progressive
+ *                                               -> osud_sample_loop
+ *   diffusion/gaussian_diffusion.py:785-874 (+735-783, diffusion_utils.py:9-89)
+ *                       training_losses         -> osud_train_loss / osud_dit_backward
+ *   train.py:243-261    optimizer + EMA step    -> osud_adamw_ema_step
+ *   train.py:152,257    DDP gradient all-reduce -> done by the host over RCCL on the flat
+ *                                                  gradient arena
+ */
+#ifndef OSUD_H
+#define OSUD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OSUD_OK 0
+#define OSUD_ERR_ARG 1         /* bad argument / shape (reference: assert / IndexError) */
+#define OSUD_ERR_HIP 2         /* a HIP runtime call failed */
+#define OSUD_ERR_STATE 3       /* missing parameter, not reserved, wrong call order */
+#define OSUD_ERR_UNSUPPORTED 4 /* configuration not built (e.g. head_dim != 64 in bf16) */
+
+/* arithmetic tiers */
+#define OSUD_PREC_BF16 0 /* fast tier: bf16 MFMA operands, fp32 accumulate / residual / LN / softmax */
+#define OSUD_PREC_F32 1  /* parity tier: exact-f32 MFMA (v_mfma_f32_32x32x2_f32), fp32 everywhere */
+
+typedef struct osud_dit osud_dit;
+typedef struct osud_sched osud_sched;
+typedef void* osud_stream; /* hipStream_t */
+
+typedef struct osud_dit_cfg {
+  int32_t hidden;      /* D: 384 / 768 / 1024 / 1152      models.py:410-423 */
+  int32_t depth;       /* number of DiTBlocks */
+  int32_t heads;       /* D / heads = head_dim */
+  int32_t context;     /* E, rows of c (144) */
+  int32_t in_channels; /* 2 */
+  int32_t table_rows;  /* num_classes + 1 (null class last)   models.py:48-52 */
+  int32_t learn_sigma; /* 1 -> out channels = 2 * in_channels */
+  int32_t precision;   /* OSUD_PREC_* */
+} osud_dit_cfg;
+
+const char* osud_last_error(void);
+/* Library/ABI version and the gfx target it was built for ("gfx950"). */
+int osud_version(void);
+const char* osud_build_arch(void);
+
+/* ------------------------------------------------------------------ model */
+int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out);
+void osud_dit_destroy(osud_dit* m);
+
+/* Upload one parameter under its reference state-dict key (e.g.
+ * "blocks.3.attn.in_proj_weight").  `dev_f32` is fp32 device memory laid out as the
+ * reference tensor (row-major, shape given); the library makes its own packed copy in the
+ * handle's precision — the caller keeps the fp32 master. */
+int osud_dit_set_param(osud_dit* m, const char* key, const float* dev_f32, const int64_t* shape, int ndim,
+                       osud_stream stream);
+/* Number of parameters still missing before forward may run (0 = ready). */
+int osud_dit_missing_params(const osud_dit* m);
+
+/* Allocate workspaces for batches up to N rows of T tokens (training != 0 also keeps the
+ * per-layer activations the backward pass needs). */
+int osud_dit_reserve(osud_dit* m, int max_N, int max_T, int training);
+
+/* Noise-prediction forward.
+ *   x (N,2,T) f32 channel-major; t (N) i64; o (N,T) f32 ms; c (N,E,T) f32 channel-major;
+ *   y (N) i64 class index (already label-dropped in training); attn_mask (T,T) u8, 1 = masked,
+ *   or NULL; out (N,4,T) f32 channel-major.
+ *   cfg_scale < 0: plain forward (models.py:306-325).
+ *   cfg_scale >= 0: forward_with_cfg (models.py:327-343): rows N/2.. reuse x of rows 0..N/2-1,
+ *   eps channels of both halves become uncond + s*(cond - uncond), other channels untouched. */
+int osud_dit_forward(osud_dit* m, const float* x, const int64_t* t, const float* o, const float* c,
+                     const int64_t* y, const uint8_t* attn_mask, int N, int T, float cfg_scale, float* out,
+                     osud_stream stream);
+
+/* ------------------------------------------------------------------ diffusion schedule */
+/* `betas` are the BASE process's betas (fp64, n_base of them); `use_timesteps` the sorted kept
+ * indices (n_use).  Re-derives the spaced betas and every fp64 table exactly as
+ * SpacedDiffusion/GaussianDiffusion.__init__ do. */
+int osud_sched_create(const double* betas, int n_base, const int64_t* use_timesteps, int n_use, osud_sched** out);
+void osud_sched_destroy(osud_sched* s);
+int osud_sched_num_timesteps(const osud_sched* s);
+/* Copy one fp64 host table out (for parity checks).  Names: "betas", "alphas_cumprod",
+ * "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+ * "posterior_log_variance_clipped", "posterior_mean_coef1", "posterior_mean_coef2",
+ * "log_betas", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "posterior_variance". */
+int osud_sched_table(const osud_sched* s, const char* name, double* out, int n);
+int osud_sched_timestep_map(const osud_sched* s, int64_t* out, int n);
+
+#define OSUD_SAMPLER_P 0    /* ancestral p_sample */
+#define OSUD_SAMPLER_DDIM 1 /* ddim_sample with eta */
+
+/* One sampler update given the raw model output (N,4,T) (pre-CFG when cfg_scale >= 0):
+ *   x (N,2,T) in; t_index (N) i64 step indices into the (spaced) schedule; noise (N,2,T);
+ *   x_out (N,2,T) (may alias x); pred_xstart (N,2,T) or NULL.  clip != 0 clamps x0 to [-1, 2]. */
+int osud_sampler_step(const osud_sched* s, int mode, float eta, const float* model_out, const float* x,
+                      const int64_t* t_index, const float* noise, int N, int T, float cfg_scale, int clip,
+                      float* x_out, float* pred_xstart, osud_stream stream);
+
+/* Whole sampling loop for steps first_step, first_step-1, ..., last_step (inclusive; the full
+ * loop is first = num_timesteps-1, last = 0), each step = forward (model sees
+ * timestep_map[i]) + sampler update, replayed from one captured hipGraph.
+ *   x (N,2,T) in/out.  noise: (n_steps, N, 2, T) f32 used in execution order, or NULL to draw
+ *   N(0,1) in-kernel from Philox4x32-10 keyed by `seed` (own stream, not torch's). */
+int osud_sample_loop(osud_dit* m, const osud_sched* s, int mode, float eta, float* x, const float* o, const float* c,
+                     const int64_t* y, const uint8_t* attn_mask, int N, int T, float cfg_scale, int clip,
+                     int first_step, int last_step, const float* noise, uint64_t seed, osud_stream stream);
+
+/* ------------------------------------------------------------------ op-level entry points
+ * (the fused building blocks, exported so each can be parity-tested on its own) */
+/* out[y][x] = epilogue(sum_k Y[y][k] * X[x][k]); see csrc/gemm.h for the epilogue codes. */
+int osud_op_gemm(int precision, int epilogue, const void* Y, int ldy, const void* X, int ldx, int My, int Nx, int K,
+                 void* out, int ldo, const float* bias, const float* gate, int ld_gate, int rows_per_sample,
+                 int n_samples, osud_stream stream);
+/* Convert n fp32 values to the tier's element type (bf16 round-to-nearest-even or f32 copy). */
+int osud_op_convert(int precision, const float* src, void* dst, size_t n, osud_stream stream);
+int osud_op_attention(int precision, const void* qk, const void* vt, const uint8_t* mask, void* out, int N, int T,
+                      int Tp, int Mp, int heads, int head_dim, osud_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OSUD_H */

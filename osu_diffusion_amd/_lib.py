@@ -1,0 +1,103 @@
+"""ctypes binding of libosud.so (C ABI declared in include/osud.h).
+
+The shared library is the product; this module only loads it and converts status codes
+into Python exceptions.  There is deliberately NO fallback: if the library is missing or a
+symbol cannot be resolved, importing the native path fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("OSUD_LIB", os.path.join(_HERE, "libosud.so"))
+
+OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
+PREC_BF16, PREC_F32 = 0, 1
+SAMPLER_P, SAMPLER_DDIM = 0, 1
+PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32}
+
+# gemm epilogue codes (csrc/gemm.h)
+EPI_BIAS_F32, EPI_BIAS_TE, EPI_BIAS_SILU_TE, EPI_ROWBIAS_TE, EPI_BIAS_GELU_TE, EPI_GATE_RES = range(6)
+EPI_NONE_F32, EPI_NONE_TE, EPI_ACCUM_F32, EPI_GELUGRAD_TE = 6, 7, 8, 9
+
+
+class DitCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("hidden", "depth", "heads", "context", "in_channels", "table_rows",
+                                          "learn_sigma", "precision")]
+
+
+class NativeError(RuntimeError):
+    """A libosud call failed (HIP error, missing parameter, unsupported configuration)."""
+
+
+_lib = None
+
+_vp, _i, _f, _u64, _sz = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t
+_SIGNATURES = {
+    "osud_last_error": (C.c_char_p, []),
+    "osud_version": (_i, []),
+    "osud_build_arch": (C.c_char_p, []),
+    "osud_dit_create": (_i, [C.POINTER(DitCfg), C.POINTER(_vp)]),
+    "osud_dit_destroy": (None, [_vp]),
+    "osud_dit_set_param": (_i, [_vp, C.c_char_p, _vp, C.POINTER(C.c_int64), _i, _vp]),
+    "osud_dit_missing_params": (_i, [_vp]),
+    "osud_dit_reserve": (_i, [_vp, _i, _i, _i]),
+    "osud_dit_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
+    "osud_sched_create": (_i, [C.POINTER(C.c_double), _i, C.POINTER(C.c_int64), _i, C.POINTER(_vp)]),
+    "osud_sched_destroy": (None, [_vp]),
+    "osud_sched_num_timesteps": (_i, [_vp]),
+    "osud_sched_table": (_i, [_vp, C.c_char_p, C.POINTER(C.c_double), _i]),
+    "osud_sched_timestep_map": (_i, [_vp, C.POINTER(C.c_int64), _i]),
+    "osud_sampler_step": (_i, [_vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp]),
+    "osud_sample_loop": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp, _u64, _vp]),
+    "osud_op_gemm": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "osud_op_convert": (_i, [_i, _vp, _vp, _sz, _vp]),
+    "osud_op_attention": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+}
+
+
+def lib():
+    """Load libosud.so once; raise (never fall back) if it cannot be loaded."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch ships its own HIP runtime (libamdhip64.so.7); load it FIRST so libosud.so binds to the
+    # same runtime instance as the tensors and streams it is handed (two runtimes in one process
+    # see no common device state).
+    import torch  # noqa: F401
+    if not os.path.isfile(LIB_PATH):
+        raise NativeError(
+            f"libosud.so not found at {LIB_PATH}: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C osu_diffusion_amd/csrc`). There is no CPU/PyTorch fallback for the DiT path.")
+    handle = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError if the symbol is missing -> loud
+        fn.restype = res
+        fn.argtypes = args
+    _lib = handle
+    return _lib
+
+
+def last_error() -> str:
+    return (lib().osud_last_error() or b"").decode()
+
+
+def check(rc: int):
+    if rc == OK:
+        return
+    msg = last_error()
+    if rc == ERR_ARG:  # the reference raises AssertionError / IndexError on bad shapes
+        raise AssertionError(msg)
+    raise NativeError(f"libosud error {rc}: {msg}")
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / None."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

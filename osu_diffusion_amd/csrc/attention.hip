@@ -1,0 +1,253 @@
+// Self-attention core for the DiT blocks (reference: nn.MultiheadAttention inside
+// DiTBlock.forward, models.py:130-135,164-170): softmax(q k^T / sqrt(hd) + mask) v per
+// (sample, head), non-causal, optional (T,T) boolean mask shared by all samples/heads.
+//
+// Inputs come straight from the two projection GEMMs (no head-major reshuffle):
+//   qk  [Mp][2D]  row m = n*Tp + t : Q in columns [0,D), K in [D,2D); head h = 64 columns
+//   vt  [D][Mp]   V transposed (row = h*hd + d, column = m) — produced by running the V
+//                 projection with the operand roles swapped, so that the P.V product finds
+//                 its contraction index (the key) contiguous.
+// Output ao [Mp][D].  Tp (tokens per sample incl. padding) is a multiple of 64; keys >= T
+// are masked out.
+//
+// bf16 tier: one workgroup = 128 queries of one (n,h); 4 waves x 32 queries; K / V^T blocks of
+// 64 keys staged in LDS (XOR-swizzled 16-byte chunks); S^T = K.Q^T on MFMA 32x32x16 so every
+// lane owns ONE query (its 32 scores of the tile sit in its own registers + the partner lane
+// l^32) -> softmax needs one cross-lane exchange; P goes back into the MFMA as the B operand
+// without leaving registers (the key order inside a k-step is permuted identically on the
+// V^T side).  fp32 statistics, online softmax across key blocks.
+// f32 (parity) tier: plain one-thread-per-query VALU kernel, fp32 everywhere.
+#include "common.h"
+
+namespace osud {
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float fast_exp2(float v) { return __builtin_amdgcn_exp2f(v); }
+
+__global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
+                                                        const uint8_t* __restrict__ mask, bf16_t* __restrict__ out,
+                                                        int T, int Tp, int Mp, int D, float c1 /* scale*log2(e) */) {
+  __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
+  __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int n = blockIdx.z, h = blockIdx.y;
+  const int q = blockIdx.x * 128 + wave * 32 + frow;
+  const int qc = q < Tp ? q : Tp - 1;
+  const size_t ldq = 2 * (size_t)D;
+  const size_t mrow = (size_t)n * Tp + qc;
+
+  // Q fragments (B operand of S^T = K.Q^T): 8 consecutive d per lane and k-step
+  u32x4 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    qf[ks] = *reinterpret_cast<const u32x4*>(qk + mrow * ldq + h * 64 + ks * 16 + fhalf * 8);
+
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int qm = qc < T ? qc : T - 1;  // row of the mask this query reads
+
+  const int nkb = Tp / 64;
+  for (int kb = 0; kb < nkb; ++kb) {
+    if (kb * 64 >= T) break;  // whole block is padding
+    __syncthreads();          // previous block fully consumed
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, r = idx >> 3, cp = idx & 7;
+      const int pos = (cp ^ ((r >> 1) & 7)) << 4;
+      const u32x4 kv = *reinterpret_cast<const u32x4*>(qk + ((size_t)n * Tp + kb * 64 + r) * ldq + D + h * 64 + cp * 8);
+      *reinterpret_cast<u32x4*>(Ks + r * 128 + pos) = kv;
+      const u32x4 vv = *reinterpret_cast<const u32x4*>(vt + ((size_t)h * 64 + r) * Mp + (size_t)n * Tp + kb * 64 + cp * 8);
+      *reinterpret_cast<u32x4*>(Vs + r * 128 + pos) = vv;
+    }
+    __syncthreads();
+
+    // ---- S^T tiles: s[kt][4g+i] = score(key = kb*64 + kt*32 + 8g + 4*fhalf + i, query q)
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+      const int row = kt * 32 + frow;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + row * 128 + (((2 * ks + fhalf) ^ ((row >> 1) & 7)) << 4));
+        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
+                                                        __builtin_bit_cast(bf16x8, qf[ks]), s[kt], 0, 0, 0);
+      }
+    }
+    // ---- scale, mask, block max
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int key0 = kb * 64 + kt * 32 + 8 * g + 4 * fhalf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int key = key0 + i;
+          bool dead = key >= T;
+          if (mask != nullptr && !dead) dead = mask[(size_t)qm * T + key] != 0;
+          const float v = dead ? -INFINITY : s[kt][4 * g + i] * c1;
+          s[kt][4 * g + i] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = fast_exp2(m_run - m_use);  // m_run = -inf -> 0
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(s[kt][r] - m_use);
+        s[kt][r] = p;
+        psum += p;
+      }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+
+    // ---- O^T += V^T . P^T ; k-step (kt, ss) covers keys kt*32 + 16ss + {4*fhalf + 0..3, 8 + 4*fhalf + 0..3}
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        u32x4 pf;
+        pf[0] = pack_bf2(s[kt][8 * ss + 0], s[kt][8 * ss + 1]);
+        pf[1] = pack_bf2(s[kt][8 * ss + 2], s[kt][8 * ss + 3]);
+        pf[2] = pack_bf2(s[kt][8 * ss + 4], s[kt][8 * ss + 5]);
+        pf[3] = pack_bf2(s[kt][8 * ss + 6], s[kt][8 * ss + 7]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const int d = dt * 32 + frow;
+          const int sw = (d >> 1) & 7, c0 = kt * 4 + 2 * ss;
+          const u32x2 lo = *reinterpret_cast<const u32x2*>(Vs + d * 128 + ((c0 ^ sw) << 4) + 8 * fhalf);
+          const u32x2 hi = *reinterpret_cast<const u32x2*>(Vs + d * 128 + (((c0 + 1) ^ sw) << 4) + 8 * fhalf);
+          u32x4 vf;
+          vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = hi[0]; vf[3] = hi[1];
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
+                                                          __builtin_bit_cast(bf16x8, pf), o[dt], 0, 0, 0);
+        }
+      }
+  }
+
+  if (q < Tp) {
+    const float inv = 1.0f / l_run;
+    bf16_t* orow = out + ((size_t)n * Tp + q) * D + h * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        store4(orow + dt * 32 + 8 * g + 4 * fhalf, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv,
+               o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+  }
+}
+
+// ---------------------------------------------------------------- parity tier (fp32, VALU)
+template <int HD>
+__global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ qk, const float* __restrict__ vt,
+                                                      const uint8_t* __restrict__ mask, float* __restrict__ out, int T,
+                                                      int Tp, int Mp, int D, float scale) {
+  __shared__ float Ks[64][HD];
+  __shared__ float Vs[HD][64];
+  const int tid = threadIdx.x, n = blockIdx.z, h = blockIdx.y;
+  const int q = blockIdx.x * 64 + tid;  // Tp % 64 == 0 -> always < Tp
+  const size_t ldq = 2 * (size_t)D;
+  float qv[HD], o[HD];
+  const float* qrow = qk + ((size_t)n * Tp + q) * ldq + h * HD;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    qv[d] = qrow[d] * scale;  // reference scales q before the product (F.multi_head_attention_forward)
+    o[d] = 0.f;
+  }
+  float m_run = -INFINITY, l_run = 0.f;
+  const int qm = q < T ? q : T - 1;
+  for (int kb = 0; kb * 64 < T; ++kb) {
+    __syncthreads();
+    for (int idx = tid; idx < 64 * HD; idx += 64) {
+      const int r = idx / HD, d = idx % HD;
+      Ks[r][d] = qk[((size_t)n * Tp + kb * 64 + r) * ldq + D + h * HD + d];
+    }
+    for (int idx = tid; idx < 64 * HD; idx += 64) {
+      const int d = idx / 64, j = idx % 64;
+      Vs[d][j] = vt[((size_t)h * HD + d) * Mp + (size_t)n * Tp + kb * 64 + j];
+    }
+    __syncthreads();
+    for (int j = 0; j < 64; ++j) {
+      const int key = kb * 64 + j;
+      if (key >= T) break;
+      if (mask != nullptr && mask[(size_t)qm * T + key]) continue;
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) s = fmaf(qv[d], Ks[j][d], s);
+      float p;
+      if (s > m_run) {
+        const float a = expf(m_run - s);
+        l_run = l_run * a + 1.0f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) o[d] *= a;
+        m_run = s;
+        p = 1.0f;
+      } else {
+        p = expf(s - m_run);
+        l_run += p;
+      }
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] = fmaf(p, Vs[d][j], o[d]);
+    }
+  }
+  const float inv = 1.0f / l_run;
+  float* orow = out + ((size_t)n * Tp + q) * D + h * HD;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) orow[d] = o[d] * inv;
+}
+
+}  // namespace
+
+int launch_attention(int prec, const void* qk, const void* vt, const uint8_t* mask, void* out, int N, int T, int Tp,
+                     int Mp, int heads, int head_dim, hipStream_t st) {
+  OSUD_CHECK_ARG(N > 0 && T > 0 && Tp >= T && Tp % 64 == 0 && Mp >= N * Tp, "attention: bad sizes N=%d T=%d Tp=%d Mp=%d", N,
+                 T, Tp, Mp);
+  const int D = heads * head_dim;
+  const float scale = 1.0f / sqrtf((float)head_dim);
+  if (prec == OSUD_PREC_BF16) {
+    if (head_dim != 64) {
+      set_error("attention: the bf16 tier is built for head_dim 64 only (got %d); use the f32 tier", head_dim);
+      return OSUD_ERR_UNSUPPORTED;
+    }
+    dim3 grid((Tp + 127) / 128, heads, N);
+    hipLaunchKernelGGL(attn_bf16_kernel, grid, dim3(256), 0, st, (const bf16_t*)qk, (const bf16_t*)vt, mask,
+                       (bf16_t*)out, T, Tp, Mp, D, scale * 1.4426950408889634f);
+  } else {
+    dim3 grid(Tp / 64, heads, N);
+    if (head_dim == 64)
+      hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(64), 0, st, (const float*)qk, (const float*)vt, mask,
+                         (float*)out, T, Tp, Mp, D, scale);
+    else if (head_dim == 72)
+      hipLaunchKernelGGL(attn_f32_kernel<72>, grid, dim3(64), 0, st, (const float*)qk, (const float*)vt, mask,
+                         (float*)out, T, Tp, Mp, D, scale);
+    else {
+      set_error("attention: head_dim %d not built (64, 72)", head_dim);
+      return OSUD_ERR_UNSUPPORTED;
+    }
+  }
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+}  // namespace osud

@@ -1,0 +1,117 @@
+// Shared declarations for libosud.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/osud.h"
+
+namespace osud {
+
+// ---- error plumbing: no C++ exception crosses the ABI -------------------------------
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define OSUD_HIP(call)                                                      \
+  do {                                                                      \
+    hipError_t e__ = (call);                                                \
+    if (e__ != hipSuccess) return ::osud::hip_fail(e__, #call, __FILE__, __LINE__); \
+  } while (0)
+
+#define OSUD_CHECK_ARG(cond, ...)        \
+  do {                                   \
+    if (!(cond)) {                       \
+      ::osud::set_error(__VA_ARGS__);    \
+      return OSUD_ERR_ARG;               \
+    }                                    \
+  } while (0)
+
+#define OSUD_TRY(expr)            \
+  do {                            \
+    int rc__ = (expr);            \
+    if (rc__ != OSUD_OK) return rc__; \
+  } while (0)
+
+// ---- element types of the two arithmetic tiers ---------------------------------------
+typedef uint16_t bf16_t;  // storage only
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN kept quiet
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <typename TE> struct ElemTraits;
+template <> struct ElemTraits<bf16_t> {
+  static constexpr int kPerChunk = 8;  // elements per 16-byte chunk
+  static constexpr int kPrec = OSUD_PREC_BF16;
+};
+template <> struct ElemTraits<float> {
+  static constexpr int kPerChunk = 4;
+  static constexpr int kPrec = OSUD_PREC_F32;
+};
+
+__device__ __forceinline__ void store_elem(bf16_t* p, float v) { *p = f2bf(v); }
+__device__ __forceinline__ void store_elem(float* p, float v) { *p = v; }
+__device__ __forceinline__ float load_elem(const bf16_t* p) { return bf2f(*p); }
+__device__ __forceinline__ float load_elem(const float* p) { return *p; }
+
+// 4 consecutive elements (8 B bf16 / 16 B f32), pointer suitably aligned
+__device__ __forceinline__ void store4(bf16_t* p, float a, float b, float c, float d) {
+  uint2 v;
+  v.x = pack_bf2(a, b);
+  v.y = pack_bf2(c, d);
+  *reinterpret_cast<uint2*>(p) = v;
+}
+__device__ __forceinline__ void store4(float* p, float a, float b, float c, float d) {
+  *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+}
+
+// FAST = bf16 tier (hardware v_exp_f32 based), !FAST = parity tier (accurate expf / division)
+template <bool FAST> __device__ __forceinline__ float exp_t(float v) { return FAST ? __expf(v) : expf(v); }
+template <bool FAST> __device__ __forceinline__ float sigmoid_t(float v) {
+  if (FAST) return __frcp_rn(1.0f + __expf(-v));
+  return 1.0f / (1.0f + expf(-v));
+}
+template <bool FAST> __device__ __forceinline__ float silu_t(float v) { return v * sigmoid_t<FAST>(v); }
+// nn.GELU(approximate="tanh"): 0.5 z (1 + tanh(u)), u = sqrt(2/pi) (z + 0.044715 z^3)
+//   == z * sigmoid(2u)  (one exp instead of a tanh)
+template <bool FAST> __device__ __forceinline__ float gelu_tanh_t(float z) {
+  const float k2 = 2.0f * 0.7978845608028654f;
+  float u2 = k2 * (z + 0.044715f * z * z * z);
+  return z * sigmoid_t<FAST>(u2);
+}
+// d/dz of the above
+template <bool FAST> __device__ __forceinline__ float gelu_tanh_grad_t(float z) {
+  const float k2 = 2.0f * 0.7978845608028654f;
+  float u2 = k2 * (z + 0.044715f * z * z * z);
+  float s = sigmoid_t<FAST>(u2);
+  float du2 = k2 * (1.0f + 3.0f * 0.044715f * z * z);
+  return s + z * s * (1.0f - s) * du2;
+}
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+static inline size_t elem_size(int prec) { return prec == OSUD_PREC_BF16 ? 2 : 4; }
+
+// wave-level reductions (wave = 64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+}  // namespace osud

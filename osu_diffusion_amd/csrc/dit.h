@@ -1,0 +1,92 @@
+// The osud_dit handle: packed weights, activation workspaces, forward orchestration.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "gemm.h"
+#include "kernels.h"
+
+struct osud_sched;
+
+namespace osud {
+int sched_upload(osud_sched* s);
+const float* sched_coefs(const osud_sched* s);
+const int64_t* sched_tmap_dev(const osud_sched* s);
+}  // namespace osud
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+struct BlockWeights {
+  void *w_qk = nullptr, *w_v = nullptr, *w_o = nullptr, *w1 = nullptr, *w2 = nullptr;  // TE, [out][in]
+  float *b_qk = nullptr, *b_v = nullptr, *b_o = nullptr, *b1 = nullptr, *b2 = nullptr;
+  // transposed copies ([in][out]) for the data-gradient products; built by osud_dit_set_param when training
+  void *w_qk_t = nullptr, *w_v_t = nullptr, *w_o_t = nullptr, *w1_t = nullptr, *w2_t = nullptr;
+};
+
+// per-layer activations kept for the backward pass (training only)
+struct LayerSaved {
+  float* h_in = nullptr;     // [Mp][D] residual stream entering the block
+  float* h_mid = nullptr;    // [Mp][D] after the attention branch
+  float* stats1 = nullptr;   // [Mp][2] mean, rstd of LN1
+  float* stats2 = nullptr;   // [Mp][2]
+  void *u1 = nullptr, *qk = nullptr, *vt = nullptr, *ao = nullptr, *u2 = nullptr, *z1 = nullptr, *g = nullptr;
+};
+
+struct GraphKey {
+  int N, T, mode, clip, has_mask, has_noise;
+  float cfg, eta;
+  const void *o, *c, *y, *mask, *x, *noise;
+  const void* sched;
+  bool operator==(const GraphKey& r) const {
+    return N == r.N && T == r.T && mode == r.mode && clip == r.clip && has_mask == r.has_mask &&
+           has_noise == r.has_noise && cfg == r.cfg && eta == r.eta && o == r.o && c == r.c && y == r.y &&
+           mask == r.mask && x == r.x && noise == r.noise && sched == r.sched;
+  }
+};
+
+struct osud_dit {
+  osud_dit_cfg cfg{};
+  int D = 0, L = 0, H = 0, hd = 0, E = 0, C = 0, C2 = 0, Kp = 0, prec = 0, esz = 0, ada_cols = 0;
+  int device = -1;
+  bool training = false;
+
+  // weights
+  void* w_e = nullptr;  float* b_e = nullptr;
+  void* w_t0 = nullptr; float* b_t0 = nullptr;
+  void* w_t2 = nullptr; float* b_t2 = nullptr;
+  float* table = nullptr;
+  std::vector<BlockWeights> blk;
+  void* w_ada = nullptr; float* b_ada = nullptr;
+  float* w_f = nullptr;  float* b_f = nullptr;
+  float* freqs64 = nullptr; float* freqs128 = nullptr;
+  float pf[2] = {512.f, 384.f};
+  std::map<std::string, bool> have;
+  std::vector<void*> owned;  // everything hipMalloc'ed by this handle
+
+  // workspaces (reserve)
+  int cap_N = 0, cap_T = 0, cap_Mp = 0, cap_Np = 0, cap_Tp = 0;
+  void *e0 = nullptr, *u = nullptr, *qk = nullptr, *vt = nullptr, *ao = nullptr, *g = nullptr;
+  float *h = nullptr, *tvec = nullptr, *bvec = nullptr, *ada = nullptr, *out_ws = nullptr;
+  void *temb = nullptr, *th = nullptr, *sb = nullptr;
+  int64_t *t_model = nullptr, *t_index = nullptr;
+  int* step_state = nullptr;
+  std::vector<LayerSaved> saved;
+  std::vector<void*> ws_owned;
+
+  // sample-loop graph cache
+  hipStream_t cap_stream = nullptr;
+  hipGraphExec_t graph_exec = nullptr;
+  GraphKey graph_key{};
+  bool graph_valid = false;
+};
+
+namespace osud {
+int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float* o, const float* c, const int64_t* y,
+                     const uint8_t* mask, int N, int T, float cfg_scale, bool combine_cfg, float* out, bool save,
+                     hipStream_t st);
+int dit_ensure_ws(osud_dit* m, int N, int T, bool training);
+}

@@ -1,0 +1,448 @@
+// osud_dit: parameter packing, workspaces, the forward pass and the graph-replayed sampling
+// loop.  Reference behaviour: models.py (DiT.forward / forward_with_cfg) and
+// diffusion/gaussian_diffusion.py (p_sample_loop_progressive / ddim_sample_loop_progressive).
+#include "dit.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace osud {
+
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) in `%s` at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+  return OSUD_ERR_HIP;
+}
+
+namespace {
+
+template <typename P> int dev_alloc(std::vector<void*>& owner, P** out, size_t bytes, bool zero = true) {
+  void* p = nullptr;
+  OSUD_HIP(hipMalloc(&p, bytes ? bytes : 16));
+  if (zero) OSUD_HIP(hipMemset(p, 0, bytes ? bytes : 16));
+  owner.push_back(p);
+  *out = reinterpret_cast<P*>(p);
+  return OSUD_OK;
+}
+
+int gemm(osud_dit* m, int epi, const void* Y, int ldy, const void* X, int ldx, int My, int Nx, int K, void* out,
+         int ldo, const float* bias, hipStream_t st, const float* gate = nullptr, int ld_gate = 0, int Tp = 0, int N = 0,
+         void* out2 = nullptr, const float* res = nullptr) {
+  GemmP p{};
+  p.Y = Y; p.X = X; p.ldy = ldy; p.ldx = ldx; p.My = My; p.Nx = Nx; p.K = K;
+  p.out = out; p.out2 = out2; p.ldo = ldo; p.bias = bias; p.gate = gate; p.ld_gate = ld_gate;
+  p.rows_per_sample = Tp; p.n_samples = N; p.res = res;
+  return launch_gemm(m->prec, epi, p, st);
+}
+
+}  // namespace
+
+int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
+  if (N <= m->cap_N && T <= m->cap_T && (!training || m->training)) return OSUD_OK;
+  // grow: free the old set, allocate for the max of old/new
+  for (void* p : m->ws_owned) (void)hipFree(p);
+  m->ws_owned.clear();
+  m->saved.clear();
+  m->graph_valid = false;
+  const int nN = N > m->cap_N ? N : m->cap_N, nT = T > m->cap_T ? T : m->cap_T;
+  const int Tp = round_up(nT, 64), Mp = round_up(nN * Tp, 128), Np = round_up(nN, 128);
+  const size_t es = m->esz, D = m->D;
+  auto& W = m->ws_owned;
+  OSUD_TRY(dev_alloc(W, &m->e0, (size_t)Mp * m->Kp * es));
+  OSUD_TRY(dev_alloc(W, &m->temb, (size_t)Np * 256 * es));
+  OSUD_TRY(dev_alloc(W, &m->th, (size_t)Np * D * es));
+  OSUD_TRY(dev_alloc(W, &m->sb, (size_t)Np * D * es));
+  OSUD_TRY(dev_alloc(W, &m->tvec, (size_t)Np * D * 4));
+  OSUD_TRY(dev_alloc(W, &m->bvec, (size_t)Np * D * 4));
+  OSUD_TRY(dev_alloc(W, &m->ada, (size_t)Np * m->ada_cols * 4));
+  OSUD_TRY(dev_alloc(W, &m->out_ws, (size_t)nN * m->C2 * nT * 4));
+  OSUD_TRY(dev_alloc(W, &m->t_model, (size_t)nN * 8));
+  OSUD_TRY(dev_alloc(W, &m->t_index, (size_t)nN * 8));
+  OSUD_TRY(dev_alloc(W, &m->step_state, 16));
+  const bool tr = training || m->training;
+  if (!tr) {
+    OSUD_TRY(dev_alloc(W, &m->h, (size_t)Mp * D * 4));
+    OSUD_TRY(dev_alloc(W, &m->u, (size_t)Mp * D * es));
+    OSUD_TRY(dev_alloc(W, &m->qk, (size_t)Mp * 2 * D * es));
+    OSUD_TRY(dev_alloc(W, &m->vt, (size_t)Mp * D * es));
+    OSUD_TRY(dev_alloc(W, &m->ao, (size_t)Mp * D * es));
+    OSUD_TRY(dev_alloc(W, &m->g, (size_t)Mp * 4 * D * es));
+  } else {
+    m->saved.resize((size_t)m->L + 1);
+    for (int l = 0; l <= m->L; ++l) {
+      LayerSaved& s = m->saved[(size_t)l];
+      OSUD_TRY(dev_alloc(W, &s.h_in, (size_t)Mp * D * 4));  // saved[L].h_in = output of the last block
+      if (l == m->L) {
+        OSUD_TRY(dev_alloc(W, &s.stats1, (size_t)Mp * 2 * 4));  // final-layer LN statistics
+        break;
+      }
+      OSUD_TRY(dev_alloc(W, &s.h_mid, (size_t)Mp * D * 4));
+      OSUD_TRY(dev_alloc(W, &s.stats1, (size_t)Mp * 2 * 4));
+      OSUD_TRY(dev_alloc(W, &s.stats2, (size_t)Mp * 2 * 4));
+      OSUD_TRY(dev_alloc(W, &s.u1, (size_t)Mp * D * es));
+      OSUD_TRY(dev_alloc(W, &s.qk, (size_t)Mp * 2 * D * es));
+      OSUD_TRY(dev_alloc(W, &s.vt, (size_t)Mp * D * es));
+      OSUD_TRY(dev_alloc(W, &s.ao, (size_t)Mp * D * es));
+      OSUD_TRY(dev_alloc(W, &s.u2, (size_t)Mp * D * es));
+      OSUD_TRY(dev_alloc(W, &s.z1, (size_t)Mp * 4 * D * es));
+      OSUD_TRY(dev_alloc(W, &s.g, (size_t)Mp * 4 * D * es));
+    }
+    m->h = m->saved[0].h_in;
+    m->training = true;
+  }
+  m->cap_N = nN; m->cap_T = nT; m->cap_Tp = Tp; m->cap_Mp = Mp; m->cap_Np = Np;
+  return OSUD_OK;
+}
+
+int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float* o, const float* c, const int64_t* y,
+                     const uint8_t* mask, int N, int T, float cfg_scale, bool combine_cfg, float* out, bool save,
+                     hipStream_t st) {
+  OSUD_CHECK_ARG(m && x && t && o && c && y && out, "forward: null argument");
+  OSUD_CHECK_ARG(N > 0 && T > 0, "forward: empty batch (N=%d, T=%d)", N, T);
+  int missing = 0;
+  for (auto& kv : m->have) missing += kv.second ? 0 : 1;
+  if (missing) {
+    for (auto& kv : m->have)
+      if (!kv.second) {
+        set_error("forward: %d parameter(s) not set, first missing: %s", missing, kv.first.c_str());
+        break;
+      }
+    return OSUD_ERR_STATE;
+  }
+  const bool cfg = cfg_scale >= 0.f;
+  OSUD_CHECK_ARG(!cfg || N % 2 == 0, "forward_with_cfg: batch must be [cond; uncond] halves, got N=%d", N);
+  OSUD_CHECK_ARG(!save || m->training, "forward(save): workspaces were not reserved for training");
+  OSUD_TRY(dit_ensure_ws(m, N, T, m->training));
+
+  const int D = m->D, L = m->L, Tp = round_up(T, 64), M = N * Tp, Mp = round_up(M, 128), Np = round_up(N, 128);
+  const int prec = m->prec, AC = m->ada_cols;
+
+  // token embedding + first linear (models.py:315-317)
+  OSUD_TRY(launch_embed(prec, x, o, c, m->freqs64, m->pf[0], m->pf[1], m->e0, N, T, Tp, Mp, m->E, m->Kp, cfg ? N / 2 : 0, st));
+  float* h = m->training ? m->saved[0].h_in : m->h;
+  OSUD_TRY(gemm(m, EPI_BIAS_F32, m->e0, m->Kp, m->w_e, m->Kp, Mp, D, m->Kp, h, D, m->b_e, st));
+  // conditioning vector b = t_emb + y_emb (models.py:318-320) and ALL adaLN modulations in one GEMM:
+  // b is the same for every block, so the 12 x (D -> 6D) + (D -> 2D) linears are one (Np x D) x (D x AC) product.
+  OSUD_TRY(launch_temb(prec, t, m->freqs128, m->temb, N, Np, st));
+  OSUD_TRY(gemm(m, EPI_BIAS_SILU_TE, m->temb, 256, m->w_t0, 256, Np, D, 256, m->th, D, m->b_t0, st));
+  OSUD_TRY(gemm(m, EPI_BIAS_F32, m->th, D, m->w_t2, D, Np, D, D, m->tvec, D, m->b_t2, st));
+  OSUD_TRY(launch_cond(prec, m->tvec, m->table, y, m->cfg.table_rows, m->bvec, m->sb, N, Np, D, st));
+  OSUD_TRY(gemm(m, EPI_BIAS_F32, m->sb, D, m->w_ada, D, Np, AC, D, m->ada, AC, m->b_ada, st));
+
+  for (int l = 0; l < L; ++l) {  // DiTBlock.forward, models.py:151-175
+    const BlockWeights& w = m->blk[(size_t)l];
+    LayerSaved* sv = m->training ? &m->saved[(size_t)l] : nullptr;
+    void* u1 = sv ? sv->u1 : m->u;
+    void* qk = sv ? sv->qk : m->qk;
+    void* vt = sv ? sv->vt : m->vt;
+    void* ao = sv ? sv->ao : m->ao;
+    void* u2 = sv ? sv->u2 : m->u;
+    void* g = sv ? sv->g : m->g;
+    float* h_mid = sv ? sv->h_mid : h;
+    float* h_out = sv ? m->saved[(size_t)l + 1].h_in : h;
+    const int base = l * 6 * D;
+    OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base, base + D, u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st));
+    OSUD_TRY(gemm(m, EPI_BIAS_TE, u1, D, w.w_qk, D, Mp, 2 * D, D, qk, 2 * D, w.b_qk, st));
+    OSUD_TRY(gemm(m, EPI_ROWBIAS_TE, w.w_v, D, u1, D, D, Mp, D, vt, Mp, w.b_v, st));  // V^T = W_v . u^T
+    OSUD_TRY(launch_attention(prec, qk, vt, mask, ao, N, T, Tp, Mp, m->H, m->hd, st));
+    OSUD_TRY(gemm(m, EPI_GATE_RES, ao, D, w.w_o, D, Mp, D, D, h_mid, D, w.b_o, st, m->ada + base + 2 * D, AC, Tp, N,
+                  nullptr, h));
+    OSUD_TRY(launch_ln_mod(prec, h_mid, m->ada, AC, base + 3 * D, base + 4 * D, u2, sv ? sv->stats2 : nullptr, Mp, Tp, N,
+                           D, st));
+    OSUD_TRY(gemm(m, EPI_BIAS_GELU_TE, u2, D, w.w1, D, Mp, 4 * D, D, g, 4 * D, w.b1, st, nullptr, 0, 0, 0,
+                  sv ? sv->z1 : nullptr));
+    OSUD_TRY(gemm(m, EPI_GATE_RES, g, 4 * D, w.w2, 4 * D, Mp, D, 4 * D, h_out, D, w.b2, st, m->ada + base + 5 * D, AC, Tp,
+                  N, nullptr, h_mid));
+    h = h_out;
+  }
+  // FinalLayer (models.py:192-196) + swapaxes (:324)
+  OSUD_TRY(launch_final(h, m->ada, AC, L * 6 * D, L * 6 * D + D, m->w_f, m->b_f, out, nullptr,
+                        m->training ? m->saved[(size_t)L].stats1 : nullptr, N, T, Tp, D, m->C2, st));
+  if (cfg && combine_cfg) OSUD_TRY(launch_cfg_combine(out, N, m->C, m->C2, T, cfg_scale, st));
+  (void)save;
+  return OSUD_OK;
+}
+
+}  // namespace osud
+
+using namespace osud;
+
+// ------------------------------------------------------------------------------- C ABI
+extern "C" const char* osud_last_error(void) { return g_err.c_str(); }
+extern "C" int osud_version(void) { return 1; }
+extern "C" const char* osud_build_arch(void) { return "gfx950"; }
+
+static int upload_f32(osud_dit* m, float** dst, const float* src, size_t n, hipStream_t st) {
+  if (!*dst) OSUD_TRY(dev_alloc(m->owned, dst, n * 4, false));
+  OSUD_HIP(hipMemcpyAsync(*dst, src, n * 4, hipMemcpyDeviceToDevice, st));
+  return OSUD_OK;
+}
+
+extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
+  OSUD_CHECK_ARG(cfg && out, "dit_create: null argument");
+  OSUD_CHECK_ARG(cfg->hidden > 0 && cfg->hidden % 128 == 0, "dit_create: hidden size %d must be a multiple of 128",
+                 cfg->hidden);
+  OSUD_CHECK_ARG(cfg->heads > 0 && cfg->hidden % cfg->heads == 0, "dit_create: heads=%d does not divide hidden=%d",
+                 cfg->heads, cfg->hidden);
+  OSUD_CHECK_ARG(cfg->depth > 0 && cfg->context > 0 && cfg->in_channels == 2 && cfg->table_rows > 0,
+                 "dit_create: bad depth/context/in_channels/table_rows");
+  OSUD_CHECK_ARG(cfg->precision == OSUD_PREC_BF16 || cfg->precision == OSUD_PREC_F32, "dit_create: unknown precision %d",
+                 cfg->precision);
+  const int hd = cfg->hidden / cfg->heads;
+  if (cfg->precision == OSUD_PREC_BF16 && hd != 64) {
+    set_error("dit_create: bf16 tier needs head_dim 64 (got %d); use OSUD_PREC_F32", hd);
+    return OSUD_ERR_UNSUPPORTED;
+  }
+  if (hd != 64 && hd != 72) {
+    set_error("dit_create: head_dim %d not built (64, 72)", hd);
+    return OSUD_ERR_UNSUPPORTED;
+  }
+  osud_dit* m = new osud_dit();
+  m->cfg = *cfg;
+  m->D = cfg->hidden; m->L = cfg->depth; m->H = cfg->heads; m->hd = hd; m->E = cfg->context;
+  m->C = cfg->in_channels; m->C2 = cfg->learn_sigma ? 2 * cfg->in_channels : cfg->in_channels;
+  m->prec = cfg->precision; m->esz = (int)elem_size(cfg->precision);
+  m->Kp = round_up(cfg->in_channels * 128 + 128 + cfg->context, 64);
+  m->ada_cols = 6 * m->D * m->L + 2 * m->D;
+  if (hipGetDevice(&m->device) != hipSuccess) {
+    delete m;
+    return hip_fail(hipErrorNoDevice, "hipGetDevice", __FILE__, __LINE__);
+  }
+  const size_t D = m->D, es = m->esz;
+  int rc = OSUD_OK;
+  auto A = [&](auto** p, size_t bytes) { if (rc == OSUD_OK) rc = dev_alloc(m->owned, p, bytes); };
+  A(&m->w_e, D * m->Kp * es); A(&m->b_e, D * 4);
+  A(&m->w_t0, D * 256 * es);  A(&m->b_t0, D * 4);
+  A(&m->w_t2, D * D * es);    A(&m->b_t2, D * 4);
+  A(&m->table, (size_t)cfg->table_rows * D * 4);
+  A(&m->w_ada, (size_t)m->ada_cols * D * es); A(&m->b_ada, (size_t)m->ada_cols * 4);
+  A(&m->w_f, (size_t)m->C2 * D * 4); A(&m->b_f, 16);
+  A(&m->freqs64, 64 * 4); A(&m->freqs128, 128 * 4);
+  m->blk.resize((size_t)m->L);
+  for (auto& b : m->blk) {
+    A(&b.w_qk, 2 * D * D * es); A(&b.b_qk, 2 * D * 4);
+    A(&b.w_v, D * D * es);      A(&b.b_v, D * 4);
+    A(&b.w_o, D * D * es);      A(&b.b_o, D * 4);
+    A(&b.w1, 4 * D * D * es);   A(&b.b1, 4 * D * 4);
+    A(&b.w2, 4 * D * D * es);   A(&b.b2, D * 4);
+  }
+  if (rc == OSUD_OK && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = OSUD_ERR_HIP;
+  if (rc != OSUD_OK) {
+    osud_dit_destroy(m);
+    return rc;
+  }
+  // default frequency tables: exp(-ln(1e4) * k / half) in fp32 (positional_embedding.py:39-44).
+  // The host may overwrite them with torch's own values through the "const.freqs64/128" keys.
+  float f64[64], f128[128];
+  for (int k = 0; k < 64; ++k) f64[k] = expf((float)(-log(10000.0)) * (float)k / 64.0f);
+  for (int k = 0; k < 128; ++k) f128[k] = expf((float)(-log(10000.0)) * (float)k / 128.0f);
+  (void)hipMemcpy(m->freqs64, f64, sizeof f64, hipMemcpyHostToDevice);
+  (void)hipMemcpy(m->freqs128, f128, sizeof f128, hipMemcpyHostToDevice);
+  // expected state-dict keys
+  const char* top[] = {"xoc_embedder.playfield_size", "xoc_embedder.mlp.0.weight", "xoc_embedder.mlp.0.bias",
+                       "t_embedder.mlp.0.weight", "t_embedder.mlp.0.bias", "t_embedder.mlp.2.weight",
+                       "t_embedder.mlp.2.bias", "y_embedder.embedding_table.weight", "final_layer.linear.weight",
+                       "final_layer.linear.bias", "final_layer.adaLN_modulation.1.weight",
+                       "final_layer.adaLN_modulation.1.bias"};
+  for (const char* k : top) m->have[k] = false;
+  const char* per[] = {"attn.in_proj_weight", "attn.in_proj_bias", "attn.out_proj.weight", "attn.out_proj.bias",
+                       "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias",
+                       "adaLN_modulation.1.weight", "adaLN_modulation.1.bias"};
+  for (int l = 0; l < m->L; ++l)
+    for (const char* k : per) m->have["blocks." + std::to_string(l) + "." + k] = false;
+  *out = m;
+  return OSUD_OK;
+}
+
+extern "C" void osud_dit_destroy(osud_dit* m) {
+  if (!m) return;
+  if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
+  if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+  for (void* p : m->owned) (void)hipFree(p);
+  for (void* p : m->ws_owned) (void)hipFree(p);
+  delete m;
+}
+
+extern "C" int osud_dit_missing_params(const osud_dit* m) {
+  if (!m) return -1;
+  int n = 0;
+  for (auto& kv : m->have) n += kv.second ? 0 : 1;
+  return n;
+}
+
+static bool shape_is(const int64_t* s, int nd, int64_t a, int64_t b = -1) {
+  return b < 0 ? (nd == 1 && s[0] == a) : (nd == 2 && s[0] == a && s[1] == b);
+}
+
+extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src, const int64_t* shape, int ndim,
+                                  osud_stream stream) {
+  OSUD_CHECK_ARG(m && key && src && shape, "set_param: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const std::string k(key);
+  const int64_t D = m->D;
+  const int prec = m->prec;
+#define SHAPE(...) OSUD_CHECK_ARG(shape_is(shape, ndim, __VA_ARGS__), "set_param(%s): unexpected shape", key)
+  if (k == "const.freqs64") { SHAPE(64); return upload_f32(m, &m->freqs64, src, 64, st); }
+  if (k == "const.freqs128") { SHAPE(128); return upload_f32(m, &m->freqs128, src, 128, st); }
+  auto it = m->have.find(k);
+  if (it == m->have.end()) {
+    set_error("set_param: unexpected key '%s'", key);  // load_state_dict(strict=True): unexpected key
+    return OSUD_ERR_ARG;
+  }
+  int rc = OSUD_OK;
+  if (k == "xoc_embedder.playfield_size") {
+    SHAPE(2);
+    OSUD_HIP(hipStreamSynchronize(st));
+    OSUD_HIP(hipMemcpy(m->pf, src, 8, hipMemcpyDeviceToHost));
+  } else if (k == "xoc_embedder.mlp.0.weight") {
+    SHAPE(D, 384 + m->E);
+    rc = launch_pack_rows(prec, src, 384 + m->E, 384 + m->E, m->w_e, m->Kp, m->Kp, (int)D, st);
+  } else if (k == "xoc_embedder.mlp.0.bias") { SHAPE(D); rc = upload_f32(m, &m->b_e, src, D, st);
+  } else if (k == "t_embedder.mlp.0.weight") { SHAPE(D, 256); rc = launch_convert(prec, src, m->w_t0, D * 256, st);
+  } else if (k == "t_embedder.mlp.0.bias") { SHAPE(D); rc = upload_f32(m, &m->b_t0, src, D, st);
+  } else if (k == "t_embedder.mlp.2.weight") { SHAPE(D, D); rc = launch_convert(prec, src, m->w_t2, D * D, st);
+  } else if (k == "t_embedder.mlp.2.bias") { SHAPE(D); rc = upload_f32(m, &m->b_t2, src, D, st);
+  } else if (k == "y_embedder.embedding_table.weight") {
+    SHAPE(m->cfg.table_rows, D);
+    rc = upload_f32(m, &m->table, src, (size_t)m->cfg.table_rows * D, st);
+  } else if (k == "final_layer.linear.weight") { SHAPE(m->C2, D); rc = upload_f32(m, &m->w_f, src, (size_t)m->C2 * D, st);
+  } else if (k == "final_layer.linear.bias") { SHAPE(m->C2); rc = upload_f32(m, &m->b_f, src, m->C2, st);
+  } else if (k == "final_layer.adaLN_modulation.1.weight") {
+    SHAPE(2 * D, D);
+    rc = launch_convert(prec, src, (char*)m->w_ada + (size_t)m->L * 6 * D * D * m->esz, 2 * D * D, st);
+  } else if (k == "final_layer.adaLN_modulation.1.bias") {
+    SHAPE(2 * D);
+    float* dst = m->b_ada + (size_t)m->L * 6 * D;
+    rc = upload_f32(m, &dst, src, 2 * D, st);
+  } else {  // blocks.<l>.<name>
+    const size_t p1 = k.find('.', 7);
+    const int l = atoi(k.substr(7, p1 - 7).c_str());
+    const std::string name = k.substr(p1 + 1);
+    BlockWeights& b = m->blk[(size_t)l];
+    const size_t es = m->esz;
+    if (name == "attn.in_proj_weight") {
+      SHAPE(3 * D, D);  // rows [Wq; Wk; Wv]
+      rc = launch_convert(prec, src, b.w_qk, 2 * D * D, st);
+      if (rc == OSUD_OK) rc = launch_convert(prec, src + 2 * D * D, b.w_v, D * D, st);
+    } else if (name == "attn.in_proj_bias") {
+      SHAPE(3 * D);
+      rc = upload_f32(m, &b.b_qk, src, 2 * D, st);
+      if (rc == OSUD_OK) rc = upload_f32(m, &b.b_v, src + 2 * D, D, st);
+    } else if (name == "attn.out_proj.weight") { SHAPE(D, D); rc = launch_convert(prec, src, b.w_o, D * D, st);
+    } else if (name == "attn.out_proj.bias") { SHAPE(D); rc = upload_f32(m, &b.b_o, src, D, st);
+    } else if (name == "mlp.fc1.weight") { SHAPE(4 * D, D); rc = launch_convert(prec, src, b.w1, 4 * D * D, st);
+    } else if (name == "mlp.fc1.bias") { SHAPE(4 * D); rc = upload_f32(m, &b.b1, src, 4 * D, st);
+    } else if (name == "mlp.fc2.weight") { SHAPE(D, 4 * D); rc = launch_convert(prec, src, b.w2, 4 * D * D, st);
+    } else if (name == "mlp.fc2.bias") { SHAPE(D); rc = upload_f32(m, &b.b2, src, D, st);
+    } else if (name == "adaLN_modulation.1.weight") {
+      SHAPE(6 * D, D);
+      rc = launch_convert(prec, src, (char*)m->w_ada + (size_t)l * 6 * D * D * es, 6 * D * D, st);
+    } else if (name == "adaLN_modulation.1.bias") {
+      SHAPE(6 * D);
+      float* dst = m->b_ada + (size_t)l * 6 * D;
+      rc = upload_f32(m, &dst, src, 6 * D, st);
+    } else {
+      set_error("set_param: unexpected key '%s'", key);
+      return OSUD_ERR_ARG;
+    }
+  }
+#undef SHAPE
+  if (rc == OSUD_OK) it->second = true;
+  return rc;
+}
+
+extern "C" int osud_dit_reserve(osud_dit* m, int max_N, int max_T, int training) {
+  OSUD_CHECK_ARG(m && max_N > 0 && max_T > 0, "reserve: bad argument");
+  return dit_ensure_ws(m, max_N, max_T, training != 0);
+}
+
+extern "C" int osud_dit_forward(osud_dit* m, const float* x, const int64_t* t, const float* o, const float* c,
+                                const int64_t* y, const uint8_t* attn_mask, int N, int T, float cfg_scale, float* out,
+                                osud_stream stream) {
+  return dit_forward_impl(m, x, t, o, c, y, attn_mask, N, T, cfg_scale, true, out, false, (hipStream_t)stream);
+}
+
+// one loop iteration: timestep bookkeeping -> forward -> sampler update (x updated in place)
+static int loop_body(osud_dit* m, const osud_sched* s, int mode, float eta, float* x, const float* o, const float* c,
+                     const int64_t* y, const uint8_t* mask, int N, int T, float cfg_scale, int clip, const float* noise,
+                     uint64_t seed, hipStream_t st) {
+  OSUD_TRY(launch_step_begin(m->step_state, sched_tmap_dev(s), m->t_model, m->t_index, N, st));
+  OSUD_TRY(dit_forward_impl(m, x, m->t_model, o, c, y, mask, N, T, cfg_scale, false, m->out_ws, false, st));
+  OSUD_TRY(launch_sampler_step(sched_coefs(s), mode, eta, m->out_ws, x, nullptr, m->step_state, noise,
+                               (size_t)N * 2 * T, seed, N, T, cfg_scale, clip, x, nullptr, st));
+  return OSUD_OK;
+}
+
+extern "C" int osud_sample_loop(osud_dit* m, const osud_sched* s, int mode, float eta, float* x, const float* o,
+                                const float* c, const int64_t* y, const uint8_t* attn_mask, int N, int T,
+                                float cfg_scale, int clip, int first_step, int last_step, const float* noise,
+                                uint64_t seed, osud_stream stream) {
+  OSUD_CHECK_ARG(m && s && x && o && c && y, "sample_loop: null argument");
+  const int nt = osud_sched_num_timesteps(s);
+  OSUD_CHECK_ARG(first_step < nt && last_step >= 0 && first_step >= last_step,
+                 "sample_loop: steps %d..%d outside the schedule's %d steps", first_step, last_step, nt);
+  hipStream_t st = (hipStream_t)stream;
+  OSUD_TRY(sched_upload(const_cast<osud_sched*>(s)));
+  OSUD_TRY(dit_ensure_ws(m, N, T, m->training));
+  OSUD_TRY(launch_step_init(m->step_state, first_step, st));
+  const int n_steps = first_step - last_step + 1;
+  const char* ng = getenv("OSUD_NO_GRAPH");
+  if (ng && ng[0] == '1') {
+    for (int k = 0; k < n_steps; ++k)
+      OSUD_TRY(loop_body(m, s, mode, eta, x, o, c, y, attn_mask, N, T, cfg_scale, clip, noise, seed, st));
+    return OSUD_OK;
+  }
+  GraphKey key{N, T, mode, clip, attn_mask != nullptr, noise != nullptr, cfg_scale, eta, o, c, y, attn_mask, x, noise, s};
+  if (!(m->graph_valid && m->graph_key == key)) {
+    if (m->graph_exec) {
+      (void)hipGraphExecDestroy(m->graph_exec);
+      m->graph_exec = nullptr;
+    }
+    m->graph_valid = false;
+    hipGraph_t graph = nullptr;
+    OSUD_HIP(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
+    const int rc = loop_body(m, s, mode, eta, x, o, c, y, attn_mask, N, T, cfg_scale, clip, noise, seed, m->cap_stream);
+    const hipError_t e = hipStreamEndCapture(m->cap_stream, &graph);
+    if (rc != OSUD_OK) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc;
+    }
+    OSUD_HIP(e);
+    OSUD_HIP(hipGraphInstantiate(&m->graph_exec, graph, nullptr, nullptr, 0));
+    (void)hipGraphDestroy(graph);
+    m->graph_key = key;
+    m->graph_valid = true;
+  }
+  for (int k = 0; k < n_steps; ++k) OSUD_HIP(hipGraphLaunch(m->graph_exec, st));
+  return OSUD_OK;
+}
+
+// ---- op-level exports ---------------------------------------------------------------------
+extern "C" int osud_op_gemm(int precision, int epilogue, const void* Y, int ldy, const void* X, int ldx, int My, int Nx,
+                            int K, void* out, int ldo, const float* bias, const float* gate, int ld_gate,
+                            int rows_per_sample, int n_samples, osud_stream stream) {
+  OSUD_CHECK_ARG(precision == OSUD_PREC_BF16 || precision == OSUD_PREC_F32, "op_gemm: unknown precision");
+  GemmP p{};
+  p.Y = Y; p.X = X; p.ldy = ldy; p.ldx = ldx; p.My = My; p.Nx = Nx; p.K = K; p.out = out; p.ldo = ldo; p.bias = bias;
+  p.gate = gate; p.ld_gate = ld_gate; p.rows_per_sample = rows_per_sample; p.n_samples = n_samples;
+  return launch_gemm(precision, epilogue, p, (hipStream_t)stream);
+}
+extern "C" int osud_op_convert(int precision, const float* src, void* dst, size_t n, osud_stream stream) {
+  OSUD_CHECK_ARG(src && dst, "op_convert: null argument");
+  return launch_convert(precision, src, dst, n, (hipStream_t)stream);
+}
+extern "C" int osud_op_attention(int precision, const void* qk, const void* vt, const uint8_t* mask, void* out, int N,
+                                 int T, int Tp, int Mp, int heads, int head_dim, osud_stream stream) {
+  OSUD_CHECK_ARG(qk && vt && out, "op_attention: null argument");
+  return launch_attention(precision, qk, vt, mask, out, N, T, Tp, Mp, heads, head_dim, (hipStream_t)stream);
+}

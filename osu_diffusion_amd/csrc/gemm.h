@@ -1,0 +1,56 @@
+// MFMA tile GEMM for gfx950:  out[y][x] = epilogue( sum_k Y[y][k] * X[x][k] )
+//
+// Both operands are "row operands" with the contraction index contiguous (PyTorch Linear
+// weights are (out,in) = exactly that), so the forward (Y = activations, X = weights), the
+// transposed V projection (Y = W_v, X = activations -> V^T) and the backward dgrad/wgrad
+// products all run through this one kernel with the roles of Y and X chosen by the caller.
+//
+// Tile 128(y) x 128(x) per 256-thread workgroup, 4 waves as 2x2, each wave 64x64 = 2x2
+// MFMA 32x32 tiles.  K is walked in 128-BYTE slabs (64 bf16 or 32 f32) so the two tiers
+// share every address computation: a 16-byte chunk is one MFMA operand fragment in both
+// (bf16: v_mfma_f32_32x32x16_bf16 once; f32: v_mfma_f32_32x32x2_f32 four times, exact f32).
+// Slabs go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), double buffered,
+// one barrier per slab.  The LDS image is [row][8 chunks] with the chunk index XOR-swizzled
+// by (row>>1)&7 on the SOURCE address (the LDS side of an LDS-DMA is lane-linear), which
+// makes the ds_read_b128 fragment reads bank-conflict free for 128-byte rows.
+// The MFMA is issued as mfma(Xfrag, Yfrag): D[i=x][j=y], so each lane ends up with 4
+// consecutive x for one y -> 8/16-byte row-major stores.
+#pragma once
+#include "common.h"
+
+namespace osud {
+
+enum GemmEpilogue {
+  EPI_BIAS_F32 = 0,       // out f32 = acc + bias[x]
+  EPI_BIAS_TE = 1,        // out TE  = acc + bias[x]
+  EPI_BIAS_SILU_TE = 2,   // out TE  = silu(acc + bias[x])
+  EPI_ROWBIAS_TE = 3,     // out TE  = acc + bias[y]            (transposed products)
+  EPI_BIAS_GELU_TE = 4,   // out TE  = gelu_tanh(acc + bias[x]); out2 TE (optional) = acc + bias[x]
+  EPI_GATE_RES = 5,       // out f32 += gate[sample(y)][x] * (acc + bias[x])   (adaLN-Zero gated residual)
+  EPI_NONE_F32 = 6,       // out f32 = acc
+  EPI_NONE_TE = 7,        // out TE  = acc
+  EPI_ACCUM_F32 = 8,      // out f32 += acc                      (gradient accumulation)
+  EPI_GELUGRAD_TE = 9,    // out TE  = acc * gelu'(aux[y][x])    (dgrad through fc1's activation)
+  EPI_COUNT
+};
+
+struct GemmP {
+  const void* Y;
+  const void* X;
+  int ldy, ldx;  // elements
+  int My, Nx, K; // My, Nx multiples of 128; K multiple of the 128-byte slab
+  void* out;
+  void* out2;
+  int ldo;
+  const float* bias;
+  const float* gate;
+  int ld_gate;
+  int rows_per_sample;  // Tp
+  int n_samples;
+  const void* aux;   // TE [My][ldo] (EPI_GELUGRAD_TE: saved pre-activation)
+  const float* res;  // EPI_GATE_RES: residual input [My][ldo]; nullptr = update `out` in place
+};
+
+int launch_gemm(int prec, int epi, const GemmP& p, hipStream_t st);
+
+}  // namespace osud

@@ -1,0 +1,35 @@
+// Launchers of the non-GEMM kernels (definitions in kernels_fwd.hip, attention.hip,
+// sampler.hip, kernels_bwd.hip).  Every launcher enqueues on `st` and returns an OSUD_* code.
+#pragma once
+#include "common.h"
+
+namespace osud {
+
+int launch_embed(int prec, const float* x, const float* o, const float* c, const float* freqs64, float pf0, float pf1,
+                 void* out, int N, int T, int Tp, int Mp, int E, int Kp, int x_dup_half, hipStream_t st);
+int launch_temb(int prec, const int64_t* t, const float* freqs128, void* out, int N, int Np, hipStream_t st);
+int launch_cond(int prec, const float* tvec, const float* table, const int64_t* y, int table_rows, float* b_out,
+                void* sb_out, int N, int Np, int D, hipStream_t st);
+int launch_ln_mod(int prec, const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, void* out,
+                  float* stats, int M, int Tp, int N, int D, hipStream_t st);
+int launch_final(const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, const float* w,
+                 const float* bias, float* out, float* u_save, float* stats, int N, int T, int Tp, int D, int C,
+                 hipStream_t st);
+int launch_cfg_combine(float* out, int N, int C, int C2, int T, float s, hipStream_t st);
+int launch_convert(int prec, const float* src, void* dst, size_t n, hipStream_t st);
+int launch_pack_rows(int prec, const float* src, int ld_src, int cols_src, void* dst, int ld_dst, int cols_dst, int rows,
+                     hipStream_t st);
+int launch_attention(int prec, const void* qk, const void* vt, const uint8_t* mask, void* out, int N, int T, int Tp,
+                     int Mp, int heads, int head_dim, hipStream_t st);
+
+// sampler.hip
+struct StepCoefs;  // device table, 8 floats per step
+int launch_sampler_step(const float* coefs, int mode, float eta, const float* model_out, const float* x,
+                        const int64_t* t_index, const int* step_state, const float* noise, size_t noise_step_stride,
+                        uint64_t seed, int N, int T, float cfg_scale, int clip, float* x_out, float* pred_xstart,
+                        hipStream_t st);
+int launch_step_init(int* step_state, int first, hipStream_t st);
+int launch_step_begin(int* step_state, const int64_t* tmap_dev, int64_t* t_model, int64_t* t_index, int N,
+                      hipStream_t st);
+
+}  // namespace osud

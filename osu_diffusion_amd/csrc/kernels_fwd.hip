@@ -1,0 +1,363 @@
+// Memory-bound forward kernels of the DiT path (everything that is not a GEMM or the
+// attention core).  All are templated on the tier's element type TE (bf16 storage / f32).
+//
+// Activation row layout: row m = n * Tp + t, Tp = tokens per sample rounded up to 64, rows
+// with t >= T (and rows >= N*Tp up to Mp) are padding: finite, never read back by the caller.
+#include "kernels.h"
+
+namespace osud {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Token embedding features (reference FirstLayer.forward, models.py:227-235 with
+// positional_embedding.py:29-77): per token
+//   [cos,sin](512*x0*f) | [cos,sin](384*x1*f) | [cos,sin]((o/10)*f) | c[0..E)      f = 64 freqs
+// written as one TE row of Kp (>= 384+E, zero padded) — the A operand of the first GEMM.
+// x, c are channel-major (N,2,T) / (N,E,T): T is the contiguous axis, so each block takes 32
+// consecutive tokens (TOK = 16), reads along T coalesced, transposes through LDS and writes whole rows.
+// Accurate sincosf on purpose: arguments reach ~1.4e4 rad.
+template <typename TE>
+__global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x, const float* __restrict__ o,
+                                                    const float* __restrict__ c, const float* __restrict__ freqs64,
+                                                    float pf0, float pf1, TE* __restrict__ out, int N, int T, int Tp,
+                                                    int E, int Kp, int x_dup_half) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int TOK = 16;
+  TE* tile = reinterpret_cast<TE*>(smem_raw);  // [TOK][Kp]
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.x * TOK;
+  const int n = m0 / Tp, t0 = m0 % Tp;  // Tp % TOK == 0 -> one sample per block
+  if (n >= N) {                          // rows past the last sample: zero
+    for (int i = tid; i < TOK * Kp; i += 256) store_elem(out + (size_t)m0 * Kp + i, 0.f);
+    return;
+  }
+  const int nx = (x_dup_half > 0 && n >= x_dup_half) ? n - x_dup_half : n;  // forward_with_cfg: cat([half, half])
+  // (a) sin/cos features: TOK tokens x 3 scalars x 64 frequencies
+  for (int idx = tid; idx < TOK * 192; idx += 256) {
+    const int tok = idx / 192, rem = idx % 192, which = rem >> 6, k = rem & 63;
+    const int t = t0 + tok;
+    float cs = 0.f, sn = 0.f;
+    if (t < T) {
+      float v;
+      if (which == 0) v = x[((size_t)nx * 2 + 0) * T + t] * pf0;        // models.py:229
+      else if (which == 1) v = x[((size_t)nx * 2 + 1) * T + t] * pf1;
+      else v = o[(size_t)n * T + t] / 10.0f;                            // models.py:232
+      const float arg = v * freqs64[k];
+      sincosf(arg, &sn, &cs);
+    }
+    store_elem(tile + tok * Kp + which * 128 + k, cs);       // cos first (positional_embedding.py:46)
+    store_elem(tile + tok * Kp + which * 128 + 64 + k, sn);
+  }
+  // (b) context rows, read along T
+  for (int idx = tid; idx < TOK * E; idx += 256) {
+    const int e = idx / TOK, tok = idx % TOK;
+    const int t = t0 + tok;
+    const float v = t < T ? c[((size_t)n * E + e) * T + t] : 0.f;
+    store_elem(tile + tok * Kp + 384 + e, v);
+  }
+  for (int idx = tid; idx < TOK * (Kp - 384 - E); idx += 256) {
+    const int tok = idx / (Kp - 384 - E), k = idx % (Kp - 384 - E);
+    store_elem(tile + tok * Kp + 384 + E + k, 0.f);
+  }
+  __syncthreads();
+  // (c) whole rows out, 16 bytes per lane
+  const int n16 = TOK * Kp * (int)sizeof(TE) / 16;
+  const uint4* src = reinterpret_cast<const uint4*>(smem_raw);
+  uint4* dst = reinterpret_cast<uint4*>(out + (size_t)m0 * Kp);
+  for (int i = tid; i < n16; i += 256) dst[i] = src[i];
+}
+
+// Timestep frequency embedding (models.py:35-36): [cos,sin](t * f_k), 128 frequencies.
+template <typename TE>
+__global__ void temb_kernel(const int64_t* __restrict__ t, const float* __restrict__ freqs128, TE* __restrict__ out,
+                            int N) {
+  const int n = blockIdx.x, k = threadIdx.x;  // 128 threads
+  float cs = 0.f, sn = 0.f;
+  if (n < N) sincosf((float)t[n] * freqs128[k], &sn, &cs);
+  store_elem(out + (size_t)n * 256 + k, cs);
+  store_elem(out + (size_t)n * 256 + 128 + k, sn);
+}
+
+// b = t_emb + table[y]; keep b (fp32, for backward) and silu(b) (TE, operand of every adaLN GEMM).
+template <typename TE>
+__global__ void cond_kernel(const float* __restrict__ tvec, const float* __restrict__ table,
+                            const int64_t* __restrict__ y, int table_rows, float* __restrict__ b_out,
+                            TE* __restrict__ sb_out, int N, int D) {
+  constexpr bool FAST = sizeof(TE) == 2;
+  const int n = blockIdx.x;
+  if (n >= N) {
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+      b_out[(size_t)n * D + d] = 0.f;
+      store_elem(sb_out + (size_t)n * D + d, 0.f);
+    }
+    return;
+  }
+  int64_t cls = y[n];
+  cls = cls < 0 ? 0 : (cls >= table_rows ? table_rows - 1 : cls);
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    const float b = tvec[(size_t)n * D + d] + table[(size_t)cls * D + d];  // models.py:320
+    b_out[(size_t)n * D + d] = b;
+    store_elem(sb_out + (size_t)n * D + d, silu_t<FAST>(b));
+  }
+}
+
+// LayerNorm (eps 1e-6, no affine, biased variance) + adaLN modulate (models.py:12-13,160,173):
+//   u = LN(h) * (1 + scale[n]) + shift[n]        one wave per token row, D/64 values per lane
+template <typename TE, int VPL>
+__global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ h, const float* __restrict__ ada,
+                                                     int ld_ada, int off_shift, int off_scale, TE* __restrict__ out,
+                                                     float* __restrict__ stats, int M, int Tp, int N) {
+  constexpr int D = VPL * 64;
+  const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= M) return;
+  int n = m / Tp;
+  if (n >= N) n = N - 1;
+  const float* hr = h + (size_t)m * D;
+  float v[VPL];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL / 2; ++i) {
+    const float2 p = *reinterpret_cast<const float2*>(hr + 2 * lane + 128 * i);
+    v[2 * i] = p.x;
+    v[2 * i + 1] = p.y;
+    sum += p.x + p.y;
+  }
+  const float mu = wave_sum(sum) * (1.0f / D);
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const float d = v[i] - mu;
+    sq += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) * (1.0f / D) + 1e-6f);
+  if (stats != nullptr && lane == 0) {
+    stats[2 * (size_t)m] = mu;
+    stats[2 * (size_t)m + 1] = rstd;
+  }
+  const float* sh = ada + (size_t)n * ld_ada + off_shift;
+  const float* sc = ada + (size_t)n * ld_ada + off_scale;
+  TE* orow = out + (size_t)m * D;
+#pragma unroll
+  for (int i = 0; i < VPL / 2; ++i) {
+    const int d = 2 * lane + 128 * i;
+    const float2 s2 = *reinterpret_cast<const float2*>(sc + d);
+    const float2 h2 = *reinterpret_cast<const float2*>(sh + d);
+    const float a = (v[2 * i] - mu) * rstd * (1.0f + s2.x) + h2.x;
+    const float b = (v[2 * i + 1] - mu) * rstd * (1.0f + s2.y) + h2.y;
+    store_elem(orow + d, a);
+    store_elem(orow + d + 1, b);
+  }
+}
+
+// Final layer (models.py:192-196,324): LN -> modulate -> Linear(D -> C) -> channel-major (N,C,T).
+// Memory bound (one read of h); one wave per token, C (<= 4) dot products reduced in-wave.
+template <int VPL>
+__global__ __launch_bounds__(256) void final_kernel(const float* __restrict__ h, const float* __restrict__ ada,
+                                                    int ld_ada, int off_shift, int off_scale,
+                                                    const float* __restrict__ w, const float* __restrict__ bias,
+                                                    float* __restrict__ out, float* __restrict__ u_save,
+                                                    float* __restrict__ stats, int N, int T, int Tp, int C) {
+  constexpr int D = VPL * 64;
+  const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int n = m / Tp, t = m % Tp;
+  if (n >= N || t >= T) return;
+  const float* hr = h + (size_t)m * D;
+  float v[VPL];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL / 2; ++i) {
+    const float2 p = *reinterpret_cast<const float2*>(hr + 2 * lane + 128 * i);
+    v[2 * i] = p.x;
+    v[2 * i + 1] = p.y;
+    sum += p.x + p.y;
+  }
+  const float mu = wave_sum(sum) * (1.0f / D);
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const float d = v[i] - mu;
+    sq += d * d;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(sq) * (1.0f / D) + 1e-6f);
+  if (stats != nullptr && lane == 0) {
+    stats[2 * (size_t)m] = mu;
+    stats[2 * (size_t)m + 1] = rstd;
+  }
+  const float* sh = ada + (size_t)n * ld_ada + off_shift;
+  const float* sc = ada + (size_t)n * ld_ada + off_scale;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < VPL / 2; ++i) {
+    const int d = 2 * lane + 128 * i;
+    const float2 s2 = *reinterpret_cast<const float2*>(sc + d);
+    const float2 h2 = *reinterpret_cast<const float2*>(sh + d);
+    const float a = (v[2 * i] - mu) * rstd * (1.0f + s2.x) + h2.x;
+    const float b = (v[2 * i + 1] - mu) * rstd * (1.0f + s2.y) + h2.y;
+    if (u_save != nullptr) *reinterpret_cast<float2*>(u_save + (size_t)m * D + d) = make_float2(a, b);
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch)
+      if (ch < C) {
+        const float2 w2 = *reinterpret_cast<const float2*>(w + (size_t)ch * D + d);
+        acc[ch] = fmaf(a, w2.x, fmaf(b, w2.y, acc[ch]));
+      }
+  }
+#pragma unroll
+  for (int ch = 0; ch < 4; ++ch)
+    if (ch < C) {
+      const float r = wave_sum(acc[ch]);
+      if (lane == 0) out[((size_t)n * C + ch) * T + t] = r + bias[ch];
+    }
+}
+
+// forward_with_cfg tail (models.py:338-343), in place on (N, C2, T): eps channels [0,C) of both
+// halves become uncond + s * (cond - uncond); the remaining channels are untouched.
+__global__ void cfg_combine_kernel(float* __restrict__ out, int half, int C, int C2, int T, float s) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= half * C * T) return;
+  const int t = i % T, ch = (i / T) % C, n = i / (T * C);
+  float* pc = out + ((size_t)n * C2 + ch) * T + t;
+  float* pu = out + ((size_t)(n + half) * C2 + ch) * T + t;
+  const float ce = *pc, ue = *pu;
+  const float he = ue + s * (ce - ue);
+  *pc = he;
+  *pu = he;
+}
+
+template <typename TE> __global__ void convert_kernel(const float* __restrict__ src, TE* __restrict__ dst, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    store_elem(dst + i, src[i]);
+}
+
+// dst[r][c] (ld_dst, zero padded to cols_dst) = src[r][c] (ld_src) for r < rows — weight packing
+template <typename TE>
+__global__ void pack_rows_kernel(const float* __restrict__ src, int ld_src, int cols_src, TE* __restrict__ dst,
+                                 int ld_dst, int cols_dst, int rows) {
+  const size_t total = (size_t)rows * cols_dst;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols_dst), cc = (int)(i % cols_dst);
+    store_elem(dst + (size_t)r * ld_dst + cc, cc < cols_src ? src[(size_t)r * ld_src + cc] : 0.f);
+  }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------- launchers
+template <typename TE>
+static int embed_t(const float* x, const float* o, const float* c, const float* freqs64, float pf0, float pf1, void* out,
+                   int N, int T, int Tp, int Mp, int E, int Kp, int x_dup_half, hipStream_t st) {
+  const size_t lds = (size_t)16 * Kp * sizeof(TE);
+  hipLaunchKernelGGL((embed_kernel<TE>), dim3(Mp / 16), dim3(256), lds, st, x, o, c, freqs64, pf0, pf1, (TE*)out, N, T,
+                     Tp, E, Kp, x_dup_half);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+int launch_embed(int prec, const float* x, const float* o, const float* c, const float* freqs64, float pf0, float pf1,
+                 void* out, int N, int T, int Tp, int Mp, int E, int Kp, int x_dup_half, hipStream_t st) {
+  OSUD_CHECK_ARG(Tp % 16 == 0 && Mp % 16 == 0 && Kp >= 384 + E && (Kp * elem_size(prec)) % 16 == 0, "embed: bad sizes");
+  return prec == OSUD_PREC_BF16 ? embed_t<bf16_t>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st)
+                                : embed_t<float>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st);
+}
+
+int launch_temb(int prec, const int64_t* t, const float* freqs128, void* out, int N, int Np, hipStream_t st) {
+  if (prec == OSUD_PREC_BF16)
+    hipLaunchKernelGGL((temb_kernel<bf16_t>), dim3(Np), dim3(128), 0, st, t, freqs128, (bf16_t*)out, N);
+  else
+    hipLaunchKernelGGL((temb_kernel<float>), dim3(Np), dim3(128), 0, st, t, freqs128, (float*)out, N);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+int launch_cond(int prec, const float* tvec, const float* table, const int64_t* y, int table_rows, float* b_out,
+                void* sb_out, int N, int Np, int D, hipStream_t st) {
+  if (prec == OSUD_PREC_BF16)
+    hipLaunchKernelGGL((cond_kernel<bf16_t>), dim3(Np), dim3(256), 0, st, tvec, table, y, table_rows, b_out,
+                       (bf16_t*)sb_out, N, D);
+  else
+    hipLaunchKernelGGL((cond_kernel<float>), dim3(Np), dim3(256), 0, st, tvec, table, y, table_rows, b_out,
+                       (float*)sb_out, N, D);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+template <typename TE>
+static int ln_mod_t(const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, void* out, float* stats,
+                    int M, int Tp, int N, int D, hipStream_t st) {
+  const dim3 grid((M + 3) / 4), block(256);
+#define OSUD_LN(V)                                                                                                  \
+  hipLaunchKernelGGL((ln_mod_kernel<TE, V>), grid, block, 0, st, h, ada, ld_ada, off_shift, off_scale, (TE*)out, \
+                     stats, M, Tp, N)
+  switch (D) {
+    case 128: OSUD_LN(2); break;
+    case 384: OSUD_LN(6); break;
+    case 768: OSUD_LN(12); break;
+    case 1024: OSUD_LN(16); break;
+    case 1152: OSUD_LN(18); break;
+    default: set_error("ln_mod: hidden size %d not built (128, 384, 768, 1024, 1152)", D); return OSUD_ERR_UNSUPPORTED;
+  }
+#undef OSUD_LN
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+int launch_ln_mod(int prec, const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, void* out,
+                  float* stats, int M, int Tp, int N, int D, hipStream_t st) {
+  return prec == OSUD_PREC_BF16 ? ln_mod_t<bf16_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st)
+                                : ln_mod_t<float>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st);
+}
+
+int launch_final(const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, const float* w,
+                 const float* bias, float* out, float* u_save, float* stats, int N, int T, int Tp, int D, int C,
+                 hipStream_t st) {
+  OSUD_CHECK_ARG(C >= 1 && C <= 4, "final layer: out channels %d not in 1..4", C);
+  const dim3 grid((N * Tp + 3) / 4), block(256);
+#define OSUD_FIN(V)                                                                                                   \
+  hipLaunchKernelGGL((final_kernel<V>), grid, block, 0, st, h, ada, ld_ada, off_shift, off_scale, w, bias, out, \
+                     u_save, stats, N, T, Tp, C)
+  switch (D) {
+    case 128: OSUD_FIN(2); break;
+    case 384: OSUD_FIN(6); break;
+    case 768: OSUD_FIN(12); break;
+    case 1024: OSUD_FIN(16); break;
+    case 1152: OSUD_FIN(18); break;
+    default: set_error("final layer: hidden size %d not built", D); return OSUD_ERR_UNSUPPORTED;
+  }
+#undef OSUD_FIN
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+int launch_cfg_combine(float* out, int N, int C, int C2, int T, float s, hipStream_t st) {
+  OSUD_CHECK_ARG(N % 2 == 0, "forward_with_cfg needs an even batch (cond rows then uncond rows), got %d", N);
+  const int half = N / 2, total = half * C * T;
+  hipLaunchKernelGGL(cfg_combine_kernel, dim3((total + 255) / 256), dim3(256), 0, st, out, half, C, C2, T, s);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+int launch_convert(int prec, const float* src, void* dst, size_t n, hipStream_t st) {
+  if (n == 0) return OSUD_OK;
+  const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  if (prec == OSUD_PREC_BF16)
+    hipLaunchKernelGGL((convert_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, src, (bf16_t*)dst, n);
+  else
+    hipLaunchKernelGGL((convert_kernel<float>), dim3(grid), dim3(256), 0, st, src, (float*)dst, n);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+int launch_pack_rows(int prec, const float* src, int ld_src, int cols_src, void* dst, int ld_dst, int cols_dst, int rows,
+                     hipStream_t st) {
+  const size_t total = (size_t)rows * cols_dst;
+  if (total == 0) return OSUD_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  if (prec == OSUD_PREC_BF16)
+    hipLaunchKernelGGL((pack_rows_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, src, ld_src, cols_src, (bf16_t*)dst,
+                       ld_dst, cols_dst, rows);
+  else
+    hipLaunchKernelGGL((pack_rows_kernel<float>), dim3(grid), dim3(256), 0, st, src, ld_src, cols_src, (float*)dst,
+                       ld_dst, cols_dst, rows);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+}  // namespace osud

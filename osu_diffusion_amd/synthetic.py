@@ -51,3 +51,23 @@ def banded_attn_mask(seq_len: int, window: int) -> torch.Tensor:
     for i in range(seq_len):
         m[max(0, i - window): min(seq_len, i + window), i] = False
     return m
+
+
+def randomize_zero_init(model, seed: int = 0, std: float = 0.02, pos_gain: float = 0.1):
+    """Give a freshly initialised DiT non-degenerate weights for benches / smoke runs.
+
+    The reference zero-initialises every adaLN modulation and the output projection
+    (models.py:295-304), so a fresh model is the identity and outputs exactly 0.  This fills
+    those tensors (and all biases) with N(0, std) from a seeded generator on the parameters'
+    device and scales the position-feature columns of the first linear by `pos_gain`
+    (see oracle.dit_oracle.seeded_state_dict for why).  There are no checkpoints to download."""
+    dev = model.xoc_embedder.playfield_size.device
+    g = torch.Generator(device=dev).manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("playfield_size"):
+                continue
+            if "adaLN" in name or name.startswith("final_layer") or name.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=g, device=dev) * std)
+        model.xoc_embedder.mlp[0].weight[:, : model.in_channels * 128] *= pos_gain
+    return model

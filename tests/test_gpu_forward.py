@@ -1,0 +1,327 @@
+"""GPU (-m gpu): parity of the native gfx950 path (through the C ABI) against the CPU oracle and
+the golden vectors frozen from the reference.
+
+Tolerances (stated per north_star):
+  * parity tier (fp32, exact-f32 MFMA): |out - ref| <= 2e-4 on model outputs of O(1); final
+    sampled coordinates within 1e-3 of the reference after a chained CFG-4 loop.
+  * fast tier (bf16 MFMA operands, fp32 accumulate/residual/statistics): teacher-forced (same
+    inputs) |out - ref| <= 1e-2 * max|ref|; end-to-end drift is reported, not asserted to 1e-3.
+  * sampler update given the same model output: <= 1e-6 (differs only by expf's last ulp).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import diffusion_oracle as do
+from oracle import dit_oracle as mo
+from osu_diffusion_amd import _lib
+from osu_diffusion_amd.diffusion import create_diffusion
+from osu_diffusion_amd.models import DiT
+from osu_diffusion_amd.synthetic import banded_attn_mask, synthetic_windows
+from tests.helpers import T, load, maxdiff, weights_for
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def native_model(shape, sd, precision):
+    m = DiT(depth=shape.depth, hidden_size=shape.hidden, num_heads=shape.heads, context_size=shape.context,
+            num_classes=shape.num_classes, class_dropout_prob=0.2, precision=precision)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).eval()
+
+
+def to_elem(prec, t):
+    out = torch.empty(t.numel() * (2 if prec == 0 else 4), dtype=torch.uint8, device=DEV)
+    _lib.check(_lib.lib().osud_op_convert(prec, _lib.ptr(t.contiguous()), _lib.ptr(out), t.numel(), None))
+    return out
+
+
+def from_elem(prec, buf, shape):
+    return buf.view(torch.bfloat16).view(shape).float() if prec == 0 else buf.view(torch.float32).view(shape).clone()
+
+
+# ------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("prec", [_lib.PREC_BF16, _lib.PREC_F32])
+@pytest.mark.parametrize("shape", [(128, 128, 64), (256, 384, 576), (128, 3072, 768), (256, 768, 3072)])
+def test_gemm_bias(prec, shape):
+    My, Nx, K = shape
+    torch.manual_seed(My + Nx + K)
+    Y = torch.randn(My, K, device=DEV)
+    X = torch.randn(Nx, K, device=DEV) / K ** 0.5  # asymmetric operands: a transposed result cannot pass
+    bias = torch.randn(Nx, device=DEV)
+    Yc, Xc = to_elem(prec, Y), to_elem(prec, X)
+    ref = (from_elem(prec, Yc, (My, K)).double() @ from_elem(prec, Xc, (Nx, K)).double().T + bias.double()).float()
+    out = torch.zeros(My, Nx, device=DEV)
+    _lib.check(_lib.lib().osud_op_gemm(prec, _lib.EPI_BIAS_F32, _lib.ptr(Yc), K, _lib.ptr(Xc), K, My, Nx, K,
+                                       _lib.ptr(out), Nx, _lib.ptr(bias), None, 0, 0, 0, None))
+    assert maxdiff(out.cpu(), ref.cpu()) < 1e-4
+
+
+@pytest.mark.parametrize("prec", [_lib.PREC_BF16, _lib.PREC_F32])
+def test_gemm_fused_epilogues(prec):
+    My, Nx, K, Tp, NS = 256, 256, 128, 64, 3  # 3 real samples of 64 rows + 64 padding rows
+    torch.manual_seed(5)
+    Y = torch.randn(My, K, device=DEV)
+    X = torch.randn(Nx, K, device=DEV) / K ** 0.5
+    bias, rbias = torch.randn(Nx, device=DEV), torch.randn(My, device=DEV)
+    gate = torch.randn(NS, Nx, device=DEV)
+    Yc, Xc = to_elem(prec, Y), to_elem(prec, X)
+    acc = from_elem(prec, Yc, (My, K)).double() @ from_elem(prec, Xc, (Nx, K)).double().T
+    L = _lib.lib()
+    tol = 2e-2 if prec == _lib.PREC_BF16 else 1e-4  # bf16 outputs are rounded to bf16
+
+    def run(epi, out, b, g=None):
+        _lib.check(L.osud_op_gemm(prec, epi, _lib.ptr(Yc), K, _lib.ptr(Xc), K, My, Nx, K, _lib.ptr(out), Nx, _lib.ptr(b),
+                                  _lib.ptr(g), Nx if g is not None else 0, Tp, NS, None))
+        torch.cuda.synchronize()
+
+    esz = 2 if prec == 0 else 4
+    o = torch.zeros(My * Nx * esz, dtype=torch.uint8, device=DEV)
+    run(_lib.EPI_BIAS_TE, o, bias)
+    assert maxdiff(from_elem(prec, o, (My, Nx)).cpu(), (acc + bias.double()).cpu()) < tol * 4
+    run(_lib.EPI_BIAS_SILU_TE, o, bias)
+    assert maxdiff(from_elem(prec, o, (My, Nx)).cpu(), torch.nn.functional.silu(acc + bias.double()).cpu()) < tol * 4
+    run(_lib.EPI_BIAS_GELU_TE, o, bias)
+    ref = torch.nn.functional.gelu(acc + bias.double(), approximate="tanh")
+    assert maxdiff(from_elem(prec, o, (My, Nx)).cpu(), ref.cpu()) < tol * 4
+    run(_lib.EPI_ROWBIAS_TE, o, rbias)
+    assert maxdiff(from_elem(prec, o, (My, Nx)).cpu(), (acc + rbias.double()[:, None]).cpu()) < tol * 4
+    res = torch.randn(My, Nx, device=DEV)
+    want = res.double() + gate.double()[torch.clamp(torch.arange(My, device=DEV) // Tp, max=NS - 1)] * (acc + bias.double())
+    run(_lib.EPI_GATE_RES, res, bias, gate)
+    assert maxdiff(res.cpu(), want.cpu()) < 1e-4
+
+
+def test_gemm_rejects_bad_shapes():
+    a = torch.zeros(128 * 64 * 4, dtype=torch.uint8, device=DEV)
+    o = torch.zeros(128, 128, device=DEV)
+    rc = _lib.lib().osud_op_gemm(0, 0, _lib.ptr(a), 64, _lib.ptr(a), 64, 100, 128, 64, _lib.ptr(o), 128, _lib.ptr(o), None,
+                                 0, 0, 0, None)
+    assert rc == _lib.ERR_ARG and "multiples of 128" in _lib.last_error()
+
+
+# ------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("prec,tol", [(_lib.PREC_BF16, 2e-2), (_lib.PREC_F32, 2e-5)])
+@pytest.mark.parametrize("T_,masked", [(64, False), (128, False), (200, True), (77, False)])
+def test_attention_core(prec, tol, T_, masked):
+    N, H, hd = 2, 2, 64
+    D = H * hd
+    Tp = (T_ + 63) // 64 * 64
+    Mp = (N * Tp + 127) // 128 * 128
+    torch.manual_seed(T_)
+    qk = torch.randn(Mp, 2 * D, device=DEV)
+    v = torch.randn(Mp, D, device=DEV)
+    mask = banded_attn_mask(T_, 128).to(DEV) if masked else None
+    qkc, vtc = to_elem(prec, qk), to_elem(prec, v.T.contiguous())
+    qkr, vr = from_elem(prec, qkc, (Mp, 2 * D)), from_elem(prec, vtc, (D, Mp)).T
+    out = torch.zeros(Mp * D * (2 if prec == 0 else 4), dtype=torch.uint8, device=DEV)
+    m8 = None if mask is None else mask.to(torch.uint8).contiguous()
+    _lib.check(_lib.lib().osud_op_attention(prec, _lib.ptr(qkc), _lib.ptr(vtc), _lib.ptr(m8), _lib.ptr(out), N, T_, Tp, Mp, H,
+                                            hd, None))
+    got = from_elem(prec, out, (Mp, D))
+    for n in range(N):
+        rows = slice(n * Tp, n * Tp + T_)
+        q = qkr[rows, :D].reshape(T_, H, hd).transpose(0, 1).double()
+        k = qkr[rows, D:].reshape(T_, H, hd).transpose(0, 1).double()
+        vv = vr[rows].reshape(T_, H, hd).transpose(0, 1).double()
+        s = q @ k.transpose(-1, -2) / hd ** 0.5
+        if mask is not None:
+            s = s.masked_fill(mask, float("-inf"))
+        ref = (torch.softmax(s, -1) @ vv).transpose(0, 1).reshape(T_, D)
+        assert maxdiff(got[rows].cpu(), ref.cpu()) < tol, (n, T_)
+
+
+# ------------------------------------------------------------------------------------ forward
+FWD_TAGS = ["tiny_T64", "tiny_T128", "tiny_T200_band", "tiny_T128_allfalse", "small_T128", "tiny_T128_rough"]
+
+
+@pytest.mark.parametrize("tag", FWD_TAGS)
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_forward_matches_reference_golden(tag, precision):
+    fx = load("g3_forward_" + tag)
+    shape, sd = weights_for(fx)
+    m = native_model(shape, sd, precision)
+    mask = T(fx["attn_mask"]).to(DEV) if "attn_mask" in fx else None
+    args = [T(fx[k]).to(DEV) for k in ("x", "t", "o", "c", "y")]
+    with torch.no_grad():
+        out = m(*args, attn_mask=mask)
+        cfg4 = m.forward_with_cfg(*args, 4.0, attn_mask=mask)
+        cfg1 = m.forward_with_cfg(*args, 1.0, attn_mask=mask)
+    scale = float(np.abs(fx["out"]).max())
+    tol = 2e-4 * max(scale, 1.0) if precision == "fp32" else 1e-2 * scale
+    assert out.shape == (len(args[0]), 4, args[0].shape[2]) and out.dtype == torch.float32
+    assert maxdiff(out.cpu(), fx["out"]) < tol
+    assert maxdiff(cfg4.cpu(), fx["out_cfg4"]) < 7 * tol  # guidance amplifies cond-uncond differences by 4 (+3)
+    assert maxdiff(cfg1.cpu(), fx["out_cfg1"]) < tol
+    n = len(cfg4) // 2
+    assert torch.equal(cfg4[:n, :2], cfg4[n:, :2])  # same guided eps in both halves (models.py:342)
+
+
+def test_forward_validates_inputs_like_the_reference():
+    shape = mo.DitShape(depth=1, hidden=128, heads=2, num_classes=4)
+    m = native_model(shape, mo.seeded_state_dict(shape, 1), "bf16")
+    (x, o, c), y = synthetic_windows(2, 64, 4, seed=0)
+    t = torch.zeros(2, dtype=torch.long)
+    with torch.no_grad():
+        with pytest.raises(AssertionError):
+            m(x[:, :1], t, o, c, y)
+        with pytest.raises(AssertionError):
+            m(x, t, o[:, :10], c, y)
+        with pytest.raises(AssertionError):
+            m.forward_with_cfg(x[:1], t[:1], o[:1], c[:1], y[:1], 4.0)
+        out = m(x, t, o, c, y)  # CPU inputs are moved to the module's device
+    assert out.is_cuda and torch.isfinite(out).all()
+
+
+def test_parameter_updates_are_picked_up():
+    shape = mo.DitShape(depth=1, hidden=128, heads=2, num_classes=4)
+    sd = mo.seeded_state_dict(shape, 2)
+    m = native_model(shape, sd, "fp32")
+    (x, o, c), y = synthetic_windows(2, 64, 4, seed=1)
+    t = torch.tensor([3, 700])
+    with torch.no_grad():
+        a = m(x, t, o, c, y)
+        m.final_layer.linear.bias.add_(1.0)
+        b = m(x, t, o, c, y)
+    assert maxdiff((b - a).cpu(), torch.ones_like(a).cpu()) < 1e-5
+    with torch.no_grad():
+        ref = mo.forward({k: v.detach().cpu() for k, v in m.state_dict().items()}, shape, x, t, o, c, y)
+    assert maxdiff(b.cpu(), ref) < 2e-4
+
+
+# ------------------------------------------------------------------------------------ sampler
+@pytest.mark.parametrize("tag", ["1000", "250"])
+def test_sampler_step_against_reference_golden(tag):
+    fx = load("g5_step_" + tag)
+    d = create_diffusion(tag, noise_schedule="squaredcos_cap_v2")
+    x, t, mout = (T(fx[k]).to(DEV) for k in ("x", "t", "model_out"))
+    N, _, TT = x.shape
+    L = _lib.lib()
+    for mode, eta, key, clip in [(0, 0.0, "p", 1), (1, 0.0, "ddim0", 1), (1, 1.0, "ddim1", 1), (0, 0.0, "p_noclip", 0)]:
+        out, x0 = torch.empty_like(x), torch.empty_like(x)
+        nz = T(fx[("p" if key == "p_noclip" else key) + "_noise"]).to(DEV)
+        _lib.check(L.osud_sampler_step(d._sched.handle, mode, eta, _lib.ptr(mout), _lib.ptr(x), _lib.ptr(t), _lib.ptr(nz), N, TT,
+                                       -1.0, clip, _lib.ptr(out), _lib.ptr(x0), None))
+        assert maxdiff(out.cpu(), fx[key + "_sample"]) < 1e-6, key
+        if clip:
+            assert maxdiff(x0.cpu(), fx[key + "_x0"]) == 0.0, key
+
+
+def test_sampler_step_fuses_cfg():
+    """cfg inside the update == forward_with_cfg's combine followed by the plain update."""
+    sch = do.create_schedule("250", "squaredcos_cap_v2")
+    d = create_diffusion("250", noise_schedule="squaredcos_cap_v2")
+    g = torch.Generator().manual_seed(9)
+    N, TT = 6, 96
+    raw = torch.randn(N, 4, TT, generator=g)
+    x, nz = torch.randn(N, 2, TT, generator=g), torch.randn(N, 2, TT, generator=g)
+    t = torch.tensor([0, 5, 249, 0, 5, 249])
+    ce, ue = raw[:3, :2], raw[3:, :2]
+    he = ue + 4.0 * (ce - ue)
+    combined = torch.cat([torch.cat([he, he]), raw[:, 2:]], dim=1)
+    want = do.p_sample_step(sch, combined, x, t, nz)["sample"]
+    out = torch.empty(N, 2, TT, device=DEV)
+    a = [v.to(DEV) for v in (raw, x, t, nz)]
+    _lib.check(_lib.lib().osud_sampler_step(d._sched.handle, 0, 0.0, _lib.ptr(a[0]), _lib.ptr(a[1]), _lib.ptr(a[2]), _lib.ptr(a[3]),
+                                            N, TT, 4.0, 1, _lib.ptr(out), None, None))
+    assert maxdiff(out.cpu(), want) < 1e-6
+
+
+def test_p_sample_api_native_step_matches_oracle():
+    shape = mo.DitShape(depth=2, hidden=128, heads=2, num_classes=10)
+    sd = mo.seeded_state_dict(shape, 11)
+    m = native_model(shape, sd, "fp32")
+    d = create_diffusion("250", noise_schedule="squaredcos_cap_v2")
+    sch = do.create_schedule("250", "squaredcos_cap_v2")
+    (x, o, c), y = synthetic_windows(2, 64, 10, seed=3, train_offsets=False)
+    x = torch.cat([x, x]); o = torch.cat([o, o]); c = torch.cat([c, c]); y = torch.cat([y, torch.full_like(y, 10)])
+    t = torch.tensor([100, 100, 100, 100])
+    kw = dict(o=o.to(DEV), c=c.to(DEV), y=y.to(DEV), cfg_scale=4.0, attn_mask=None)
+    torch.manual_seed(1)
+    with torch.no_grad():
+        r = d.p_sample(m.forward_with_cfg, x.to(DEV), t.to(DEV), clip_denoised=True, model_kwargs=kw)
+    torch.manual_seed(1)
+    nz = torch.randn(x.shape, device=DEV).cpu()  # the native step draws randn_like(x) on the device
+    mout = mo.forward_with_cfg(sd, shape, x, torch.from_numpy(sch.timestep_map)[t], o, c, y, 4.0)
+    want = do.p_sample_step(sch, mout, x, t, nz)
+    assert maxdiff(r["sample"].cpu(), want["sample"]) < 5e-4
+    assert maxdiff(r["pred_xstart"].cpu(), want["pred_xstart"]) < 5e-4
+
+
+@pytest.mark.parametrize("tag", ["p20", "ddim20_eta1", "ddim20_eta05"])
+def test_chained_loop_final_coordinates_fp32(tag):
+    """identical (seed -> noise, window, num-sampling-steps): final (x, y) within 1e-3 of the reference."""
+    fx = load("g6_loop_" + tag)
+    shape, sd = weights_for(fx)
+    m = native_model(shape, sd, "fp32")
+    d = create_diffusion(str(fx["respacing"]), noise_schedule="squaredcos_cap_v2")
+    z = T(fx["z"]).to(DEV)
+    kw = dict(o=T(fx["o"]).to(DEV), c=T(fx["c"]).to(DEV), y=T(fx["y"]).to(DEV), cfg_scale=4.0, attn_mask=None)
+    eta = float(fx["eta"])
+    finals = {}
+    for graph in ("graph", "eager"):
+        os.environ["OSUD_NO_GRAPH"] = "0" if graph == "graph" else "1"
+        try:
+            if eta < 0:
+                fin = d.p_sample_loop(m.forward_with_cfg, z.shape, z, model_kwargs=kw, step_noise=T(fx["noises"]))
+            else:
+                fin = d.ddim_sample_loop(m.forward_with_cfg, z.shape, z, model_kwargs=kw, eta=eta, step_noise=T(fx["noises"]))
+        finally:
+            os.environ["OSUD_NO_GRAPH"] = "0"
+        finals[graph] = fin.cpu()
+        assert maxdiff(finals[graph], fx["final"]) < 1e-3, graph
+    assert torch.equal(finals["graph"], finals["eager"])  # graph replay == eager launches, bit for bit
+
+
+def test_chained_loop_bf16_drift_is_bounded():
+    fx = load("g6_loop_p20")
+    shape, sd = weights_for(fx)
+    m = native_model(shape, sd, "bf16")
+    d = create_diffusion("20", noise_schedule="squaredcos_cap_v2")
+    z = T(fx["z"]).to(DEV)
+    kw = dict(o=T(fx["o"]).to(DEV), c=T(fx["c"]).to(DEV), y=T(fx["y"]).to(DEV), cfg_scale=4.0, attn_mask=None)
+    fin = d.p_sample_loop(m.forward_with_cfg, z.shape, z, model_kwargs=kw, step_noise=T(fx["noises"])).cpu()
+    drift = maxdiff(fin, fx["final"])
+    print(f"bf16 tier end-to-end drift after 20 CFG-4 steps: {drift:.3e}")
+    assert drift < 5e-2
+
+
+def test_generic_path_with_denoised_fn_uses_native_forward():
+    """in-paint style hook (testing/test_toy.py:56-74): generic Python step around the native forward."""
+    shape = mo.DitShape(depth=2, hidden=128, heads=2, num_classes=10)
+    sd = mo.seeded_state_dict(shape, 11)
+    m = native_model(shape, sd, "fp32")
+    d = create_diffusion("20", noise_schedule="squaredcos_cap_v2")
+    sch = do.create_schedule("20", "squaredcos_cap_v2")
+    (x, o, c), y = synthetic_windows(2, 64, 10, seed=4, train_offsets=False)
+    keep = torch.zeros(2, 2, 64, dtype=torch.bool)
+    keep[:, :, :32] = True
+    fn_dev = lambda v: torch.where(keep.to(v.device), x.to(v.device), v)  # noqa: E731
+    fn_cpu = lambda v: torch.where(keep, x, v)  # noqa: E731
+    torch.manual_seed(2)
+    z = torch.randn(2, 2, 64)
+    kw = dict(o=o.to(DEV), c=c.to(DEV), y=y.to(DEV))
+    torch.manual_seed(5)
+    got = d.p_sample_loop(m.forward, z.shape, z.to(DEV), denoised_fn=fn_dev, model_kwargs=kw, device=DEV)
+    torch.manual_seed(5)
+    noises = torch.stack([torch.randn(z.shape, device=DEV).cpu() for _ in range(20)])
+    fn = lambda xx, tt: mo.forward(sd, shape, xx, tt, o, c, y)  # noqa: E731
+    want = do.sample_loop(sch, fn, z, noises, denoised_fn=fn_cpu)
+    assert maxdiff(got.cpu(), want) < 1e-3
+
+
+def test_in_kernel_philox_noise_is_standard_normal_and_reproducible():
+    shape = mo.DitShape(depth=1, hidden=128, heads=2, num_classes=4)
+    m = native_model(shape, mo.seeded_state_dict(shape, 3), "bf16")
+    d = create_diffusion("20", noise_schedule="squaredcos_cap_v2")
+    (x, o, c), y = synthetic_windows(8, 128, 4, seed=5, train_offsets=False)
+    kw = dict(o=o.to(DEV), c=c.to(DEV), y=y.to(DEV))
+    z = torch.randn(8, 2, 128, device=DEV)
+    a = d.p_sample_loop(m.forward, z.shape, z, model_kwargs=kw, seed=123)
+    b = d.p_sample_loop(m.forward, z.shape, z, model_kwargs=kw, seed=123)
+    c2 = d.p_sample_loop(m.forward, z.shape, z, model_kwargs=kw, seed=124)
+    assert torch.equal(a, b) and not torch.equal(a, c2) and torch.isfinite(a).all()
