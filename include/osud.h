@@ -129,6 +129,34 @@ int osud_sample_loop(osud_dit* m, const osud_sched* s, int mode, float eta, floa
                      const int64_t* y, const uint8_t* attn_mask, int N, int T, float cfg_scale, int clip,
                      int first_step, int last_step, const float* noise, uint64_t seed, osud_stream stream);
 
+/* ------------------------------------------------------------------ training
+ * Sizes must satisfy T % 64 == 0 and N*T % 128 == 0 (no padding rows in the gradient products). */
+/* Where the backward pass writes the gradient of parameter `key` (fp32, same shape as the
+ * parameter).  Backward OVERWRITES these buffers (it does not accumulate). */
+int osud_dit_bind_grad(osud_dit* m, const char* key, float* grad_f32);
+/* Re-pack every parameter from the fp32 master pointer last passed to osud_dit_set_param
+ * (call after the optimizer changed the masters in place). */
+int osud_dit_refresh(osud_dit* m, osud_stream stream);
+/* forward that keeps the per-layer activations (plain forward, no CFG, no mask) */
+int osud_dit_forward_train(osud_dit* m, const float* x, const int64_t* t, const float* o, const float* c,
+                           const int64_t* y, int N, int T, float* out, osud_stream stream);
+/* backward of the last osud_dit_forward_train: dout (N,4,T) = dLoss/d(out) */
+int osud_dit_backward(osud_dit* m, const float* dout, osud_stream stream);
+/* x_t = sqrt(ac_t) x_0 + sqrt(1-ac_t) noise   (gaussian_diffusion.py:231-247); t = step indices */
+int osud_q_sample(const osud_sched* s, const float* x_start, const int64_t* t, const float* noise, int N, int T,
+                  float* x_t, osud_stream stream);
+/* training_losses for EPSILON / LEARNED_RANGE (gaussian_diffusion.py:785-874): terms is (3,N) =
+ * [l1|mse ; vb ; loss]; dout (N,4,T) = d(mean_n loss_n)/d(model_out).  use_l1: 1 = L1, 0 = MSE. */
+int osud_train_loss(const osud_sched* s, int use_l1, const float* model_out, const float* x_start, const float* x_t,
+                    const float* noise, const int64_t* t, int N, int T, float* terms, float* dout, osud_stream stream);
+/* torch.optim.AdamW step (bias-corrected, decoupled weight decay) fused with the EMA update
+ * (train.py:36-45,258-261) over flat fp32 arenas of n elements; elements [skip_begin, skip_end)
+ * are frozen (EMA only); grads are multiplied by grad_scale first (1/world after a SUM all-reduce).
+ * ema may be NULL. */
+int osud_adamw_ema_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema, size_t n,
+                        float lr, float beta1, float beta2, float eps, float weight_decay, int step, float ema_decay,
+                        size_t skip_begin, size_t skip_end, float grad_scale, osud_stream stream);
+
 /* ------------------------------------------------------------------ op-level entry points
  * (the fused building blocks, exported so each can be parity-tested on its own) */
 /* out[y][x] = epilogue(sum_k Y[y][k] * X[x][k]); see csrc/gemm.h for the epilogue codes. */

@@ -51,6 +51,13 @@ _SIGNATURES = {
     "osud_sched_timestep_map": (_i, [_vp, C.POINTER(C.c_int64), _i]),
     "osud_sampler_step": (_i, [_vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp]),
     "osud_sample_loop": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp, _u64, _vp]),
+    "osud_dit_bind_grad": (_i, [_vp, C.c_char_p, _vp]),
+    "osud_dit_refresh": (_i, [_vp, _vp]),
+    "osud_dit_forward_train": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "osud_dit_backward": (_i, [_vp, _vp, _vp]),
+    "osud_q_sample": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "osud_train_loss": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "osud_adamw_ema_step": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _sz, _sz, _f, _vp]),
     "osud_op_gemm": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "osud_op_convert": (_i, [_i, _vp, _vp, _sz, _vp]),
     "osud_op_attention": (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

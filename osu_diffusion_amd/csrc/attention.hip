@@ -30,7 +30,8 @@ __device__ __forceinline__ float fast_exp2(float v) { return __builtin_amdgcn_ex
 
 __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
                                                         const uint8_t* __restrict__ mask, bf16_t* __restrict__ out,
-                                                        int T, int Tp, int Mp, int D, float c1 /* scale*log2(e) */) {
+                                                        float* __restrict__ lse, int T, int Tp, int Mp, int D,
+                                                        int ld_qk, float c1 /* scale*log2(e) */) {
   __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
   __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -38,7 +39,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
   const int n = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * 128 + wave * 32 + frow;
   const int qc = q < Tp ? q : Tp - 1;
-  const size_t ldq = 2 * (size_t)D;
+  const size_t ldq = (size_t)ld_qk;  // 2D (inference: Q|K) or 3D (training: Q|K|V)
   const size_t mrow = (size_t)n * Tp + qc;
 
   // Q fragments (B operand of S^T = K.Q^T): 8 consecutive d per lane and k-step
@@ -147,6 +148,8 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
   }
 
   if (q < Tp) {
+    if (lse != nullptr && fhalf == 0)  // log2-domain logsumexp of the scaled scores, for the backward pass
+      lse[((size_t)n * gridDim.y + h) * Tp + q] = m_run + __builtin_amdgcn_logf(l_run);
     const float inv = 1.0f / l_run;
     bf16_t* orow = out + ((size_t)n * Tp + q) * D + h * 64;
 #pragma unroll
@@ -161,13 +164,14 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
 // ---------------------------------------------------------------- parity tier (fp32, VALU)
 template <int HD>
 __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ qk, const float* __restrict__ vt,
-                                                      const uint8_t* __restrict__ mask, float* __restrict__ out, int T,
-                                                      int Tp, int Mp, int D, float scale) {
+                                                      const uint8_t* __restrict__ mask, float* __restrict__ out,
+                                                      float* __restrict__ lse, int T, int Tp, int Mp, int D, int ld_qk,
+                                                      float scale) {
   __shared__ float Ks[64][HD];
   __shared__ float Vs[HD][64];
   const int tid = threadIdx.x, n = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * 64 + tid;  // Tp % 64 == 0 -> always < Tp
-  const size_t ldq = 2 * (size_t)D;
+  const size_t ldq = (size_t)ld_qk;
   float qv[HD], o[HD];
   const float* qrow = qk + ((size_t)n * Tp + q) * ldq + h * HD;
 #pragma unroll
@@ -211,6 +215,7 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
       for (int d = 0; d < HD; ++d) o[d] = fmaf(p, Vs[d][j], o[d]);
     }
   }
+  if (lse != nullptr) lse[((size_t)n * gridDim.y + h) * Tp + q] = m_run + logf(l_run);
   const float inv = 1.0f / l_run;
   float* orow = out + ((size_t)n * Tp + q) * D + h * HD;
 #pragma unroll
@@ -219,8 +224,8 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 
 }  // namespace
 
-int launch_attention(int prec, const void* qk, const void* vt, const uint8_t* mask, void* out, int N, int T, int Tp,
-                     int Mp, int heads, int head_dim, hipStream_t st) {
+int launch_attention(int prec, const void* qk, int ld_qk, const void* vt, const uint8_t* mask, void* out, float* lse,
+                     int N, int T, int Tp, int Mp, int heads, int head_dim, hipStream_t st) {
   OSUD_CHECK_ARG(N > 0 && T > 0 && Tp >= T && Tp % 64 == 0 && Mp >= N * Tp, "attention: bad sizes N=%d T=%d Tp=%d Mp=%d", N,
                  T, Tp, Mp);
   const int D = heads * head_dim;
@@ -232,15 +237,15 @@ int launch_attention(int prec, const void* qk, const void* vt, const uint8_t* ma
     }
     dim3 grid((Tp + 127) / 128, heads, N);
     hipLaunchKernelGGL(attn_bf16_kernel, grid, dim3(256), 0, st, (const bf16_t*)qk, (const bf16_t*)vt, mask,
-                       (bf16_t*)out, T, Tp, Mp, D, scale * 1.4426950408889634f);
+                       (bf16_t*)out, lse, T, Tp, Mp, D, ld_qk, scale * 1.4426950408889634f);
   } else {
     dim3 grid(Tp / 64, heads, N);
     if (head_dim == 64)
       hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(64), 0, st, (const float*)qk, (const float*)vt, mask,
-                         (float*)out, T, Tp, Mp, D, scale);
+                         (float*)out, lse, T, Tp, Mp, D, ld_qk, scale);
     else if (head_dim == 72)
       hipLaunchKernelGGL(attn_f32_kernel<72>, grid, dim3(64), 0, st, (const float*)qk, (const float*)vt, mask,
-                         (float*)out, T, Tp, Mp, D, scale);
+                         (float*)out, lse, T, Tp, Mp, D, ld_qk, scale);
     else {
       set_error("attention: head_dim %d not built (64, 72)", head_dim);
       return OSUD_ERR_UNSUPPORTED;

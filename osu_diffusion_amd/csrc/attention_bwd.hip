@@ -1,0 +1,352 @@
+// Backward of the attention core (autograd of nn.MultiheadAttention's softmax(QK^T/sqrt(hd))V,
+// models.py:164-170, as used in training: no mask, T == Tp).
+//
+// Inputs (training layouts): qkv [M][3D] (Q | K | V row-major, head h = columns h*hd..),
+// dO = d(attention output) [M][D], O [M][D], lse [N][H][T] saved by the forward kernel
+// (log2 domain in the bf16 tier, natural log in the f32 tier).  Output dqkv [M][3D].
+//   P = exp(S - lse), delta = rowsum(dO * O), dS = P * (dO V^T - delta) * scale
+//   dQ = dS K, dK = dS^T Q, dV = P^T dO
+//
+// bf16 tier: one workgroup per (n, h), T <= 128.  Two register-resident passes so that no two
+// waves ever share an output: pass A — each wave owns 32 queries and walks the keys (dQ);
+// pass B — each wave owns 32 keys and walks the queries (dK, dV).  S and dO.V^T are recomputed
+// in the orientation each pass needs (lane = the owned index), which keeps P / dS in registers
+// as MFMA B operands exactly like the forward kernel; the A operands that need the contraction
+// index contiguous come from transposed LDS copies (K^T, Q^T, dO^T) built once per workgroup.
+// f32 tier: plain VALU kernels (one thread per query / per key).
+#include "kernels.h"
+
+namespace osud {
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ u32x4 rowfrag(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const u32x4*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+}
+__device__ __forceinline__ u32x4 tfrag(const char* tt, int ts, int d, int e0) {
+  const u32x2 lo = *reinterpret_cast<const u32x2*>(tt + d * ts + e0 * 2);
+  const u32x2 hi = *reinterpret_cast<const u32x2*>(tt + d * ts + (e0 + 8) * 2);
+  u32x4 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+  return v;
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ u32x4 pack8(const f32x16& v, int base) {
+  u32x4 r;
+  r[0] = pack_bf2(v[base + 0], v[base + 1]);
+  r[1] = pack_bf2(v[base + 2], v[base + 3]);
+  r[2] = pack_bf2(v[base + 4], v[base + 5]);
+  r[3] = pack_bf2(v[base + 6], v[base + 7]);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                            const bf16_t* __restrict__ O, const float* __restrict__ lse,
+                                                            bf16_t* __restrict__ dqkv, int T, int D, float c1,
+                                                            float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int TS = T * 2 + 8;  // padded row stride of the transposed tiles (bytes)
+  char* Qs = smem;
+  char* Ks = Qs + T * 128;
+  char* Vs = Ks + T * 128;
+  char* Os = Vs + T * 128;            // dO rows
+  char* Kt = Os + T * 128;            // [64 d][T] (+pad)
+  char* Qt = Kt + 64 * TS;
+  char* Ot = Qt + 64 * TS;            // dO^T
+  float* lse_s = reinterpret_cast<float*>(Ot + 64 * TS);
+  float* del_s = lse_s + T;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int h = blockIdx.x, n = blockIdx.y, H = gridDim.x;
+  const size_t ld3 = 3 * (size_t)D;
+  const size_t m0 = (size_t)n * T;
+
+  // ---- load row-major tiles (coalesced: 8 lanes per 128-byte row) + delta = rowsum(dO * O)
+  for (int idx = tid; idx < T * 8; idx += 256) {
+    const int r = idx >> 3, cp = idx & 7;
+    const int pos = (cp ^ ((r >> 1) & 7)) << 4;
+    const bf16_t* src = qkv + (m0 + r) * ld3 + h * 64 + cp * 8;
+    *reinterpret_cast<u32x4*>(Qs + r * 128 + pos) = *reinterpret_cast<const u32x4*>(src);
+    *reinterpret_cast<u32x4*>(Ks + r * 128 + pos) = *reinterpret_cast<const u32x4*>(src + D);
+    *reinterpret_cast<u32x4*>(Vs + r * 128 + pos) = *reinterpret_cast<const u32x4*>(src + 2 * D);
+    const u32x4 dov = *reinterpret_cast<const u32x4*>(dO + (m0 + r) * D + h * 64 + cp * 8);
+    const u32x4 ov = *reinterpret_cast<const u32x4*>(O + (m0 + r) * D + h * 64 + cp * 8);
+    *reinterpret_cast<u32x4*>(Os + r * 128 + pos) = dov;
+    float part = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      part += bf2f((bf16_t)(dov[e] & 0xffff)) * bf2f((bf16_t)(ov[e] & 0xffff));
+      part += bf2f((bf16_t)(dov[e] >> 16)) * bf2f((bf16_t)(ov[e] >> 16));
+    }
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    part += __shfl_xor(part, 4, 64);
+    if (cp == 0) del_s[r] = part;
+  }
+  for (int r = tid; r < T; r += 256) lse_s[r] = lse[((size_t)n * H + h) * T + r];
+  __syncthreads();
+  // ---- transposed copies: lanes take consecutive rows so the 2-byte LDS writes spread over banks
+  for (int idx = tid; idx < T * 8; idx += 256) {
+    const int r = idx % T, cp = idx / T;
+    const u32x4 kq = rowfrag(Ks, r, cp), qq = rowfrag(Qs, r, cp), oq = rowfrag(Os, r, cp);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int d = cp * 8 + e;
+      const int sh = (e & 1) * 16;
+      *reinterpret_cast<bf16_t*>(Kt + d * TS + r * 2) = (bf16_t)(kq[e >> 1] >> sh);
+      *reinterpret_cast<bf16_t*>(Qt + d * TS + r * 2) = (bf16_t)(qq[e >> 1] >> sh);
+      *reinterpret_cast<bf16_t*>(Ot + d * TS + r * 2) = (bf16_t)(oq[e >> 1] >> sh);
+    }
+  }
+  __syncthreads();
+
+  const int own = wave * 32;  // first query (pass A) / key (pass B) this wave owns
+  if (own < T) {
+    // =============================== pass A: dQ for queries own..own+31 ======================
+    {
+      u32x4 qf[4], of[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        qf[ks] = rowfrag(Qs, own + frow, 2 * ks + fhalf);
+        of[ks] = rowfrag(Os, own + frow, 2 * ks + fhalf);
+      }
+      const float my_lse = lse_s[own + frow], my_del = del_s[own + frow];
+      f32x16 dq[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+      for (int kt = 0; kt < T / 32; ++kt) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = mfma_bf16(rowfrag(Ks, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s);    // D[key][query]
+          dp = mfma_bf16(rowfrag(Vs, kt * 32 + frow, 2 * ks + fhalf), of[ks], dp);  // dO . V^T
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[r] * c1 - my_lse);
+          s[r] = p * (dp[r] - my_del) * scale;  // dS
+        }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const u32x4 dsf = pack8(s, 8 * ss);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)
+            dq[dt] = mfma_bf16(tfrag(Kt, TS, dt * 32 + frow, kt * 32 + 16 * ss + 4 * fhalf), dsf, dq[dt]);
+        }
+      }
+      bf16_t* orow = dqkv + (m0 + own + frow) * ld3 + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          store4(orow + dt * 32 + 8 * g + 4 * fhalf, dq[dt][4 * g], dq[dt][4 * g + 1], dq[dt][4 * g + 2], dq[dt][4 * g + 3]);
+    }
+    // =============================== pass B: dK, dV for keys own..own+31 =====================
+    {
+      u32x4 kf[4], vf[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = rowfrag(Ks, own + frow, 2 * ks + fhalf);
+        vf[ks] = rowfrag(Vs, own + frow, 2 * ks + fhalf);
+      }
+      f32x16 dk[2], dv[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[i][r] = dv[i][r] = 0.f;
+      for (int qt = 0; qt < T / 32; ++qt) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = mfma_bf16(rowfrag(Qs, qt * 32 + frow, 2 * ks + fhalf), kf[ks], s);    // D[query][key]
+          dp = mfma_bf16(rowfrag(Os, qt * 32 + frow, 2 * ks + fhalf), vf[ks], dp);
+        }
+        f32x16 p;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 32 + 8 * g + 4 * fhalf);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qt * 32 + 8 * g + 4 * fhalf);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float pv = __builtin_amdgcn_exp2f(s[4 * g + i] * c1 - l4[i]);
+            p[4 * g + i] = pv;
+            s[4 * g + i] = pv * (dp[4 * g + i] - d4[i]) * scale;
+          }
+        }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const u32x4 pf = pack8(p, 8 * ss), dsf = pack8(s, 8 * ss);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            dv[dt] = mfma_bf16(tfrag(Ot, TS, dt * 32 + frow, qt * 32 + 16 * ss + 4 * fhalf), pf, dv[dt]);
+            dk[dt] = mfma_bf16(tfrag(Qt, TS, dt * 32 + frow, qt * 32 + 16 * ss + 4 * fhalf), dsf, dk[dt]);
+          }
+        }
+      }
+      bf16_t* orow = dqkv + (m0 + own + frow) * ld3 + h * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = dt * 32 + 8 * g + 4 * fhalf;
+          store4(orow + D + d, dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]);
+          store4(orow + 2 * D + d, dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- f32 tier (VALU)
+template <int HD>
+__global__ __launch_bounds__(64) void attn_bwd_dq_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
+                                                             const float* __restrict__ O, const float* __restrict__ lse,
+                                                             float* __restrict__ dqkv, int T, int D, float scale) {
+  __shared__ float Ks[64][HD];
+  __shared__ float Vs[64][HD];
+  const int tid = threadIdx.x, n = blockIdx.z, h = blockIdx.y, H = gridDim.y;
+  const int q = blockIdx.x * 64 + tid;
+  const size_t ld3 = 3 * (size_t)D, m = (size_t)n * T + q;
+  float qv[HD], dov[HD], dq[HD];
+  float delta = 0.f;
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    qv[d] = qkv[m * ld3 + h * HD + d] * scale;
+    dov[d] = dO[m * D + h * HD + d];
+    delta += dov[d] * O[m * D + h * HD + d];
+    dq[d] = 0.f;
+  }
+  const float my_lse = lse[((size_t)n * H + h) * T + q];
+  for (int kb = 0; kb * 64 < T; ++kb) {
+    __syncthreads();
+    for (int idx = tid; idx < 64 * HD; idx += 64) {
+      const int r = idx / HD, d = idx % HD;
+      const size_t mk = (size_t)n * T + kb * 64 + r;
+      Ks[r][d] = qkv[mk * ld3 + D + h * HD + d];
+      Vs[r][d] = qkv[mk * ld3 + 2 * D + h * HD + d];
+    }
+    __syncthreads();
+    for (int j = 0; j < 64; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) {
+        s = fmaf(qv[d], Ks[j][d], s);
+        dp = fmaf(dov[d], Vs[j][d], dp);
+      }
+      const float ds = expf(s - my_lse) * (dp - delta) * scale;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) dq[d] = fmaf(ds, Ks[j][d], dq[d]);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < HD; ++d) dqkv[m * ld3 + h * HD + d] = dq[d];
+}
+
+template <int HD>
+__global__ __launch_bounds__(64) void attn_bwd_dkv_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
+                                                              const float* __restrict__ O, const float* __restrict__ lse,
+                                                              float* __restrict__ dqkv, int T, int D, float scale) {
+  __shared__ float Qs[64][HD];
+  __shared__ float Os[64][HD];
+  __shared__ float ls[64], dl[64];
+  const int tid = threadIdx.x, n = blockIdx.z, h = blockIdx.y, H = gridDim.y;
+  const int key = blockIdx.x * 64 + tid;
+  const size_t ld3 = 3 * (size_t)D, m = (size_t)n * T + key;
+  float kv[HD], vv[HD], dk[HD], dv[HD];
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    kv[d] = qkv[m * ld3 + D + h * HD + d];
+    vv[d] = qkv[m * ld3 + 2 * D + h * HD + d];
+    dk[d] = dv[d] = 0.f;
+  }
+  for (int qb = 0; qb * 64 < T; ++qb) {
+    __syncthreads();
+    for (int idx = tid; idx < 64 * HD; idx += 64) {
+      const int r = idx / HD, d = idx % HD;
+      const size_t mq = (size_t)n * T + qb * 64 + r;
+      Qs[r][d] = qkv[mq * ld3 + h * HD + d] * scale;
+      Os[r][d] = dO[mq * D + h * HD + d];
+    }
+    {
+      const size_t mq = (size_t)n * T + qb * 64 + tid;
+      float delta = 0.f;
+      for (int d = 0; d < HD; ++d) delta += dO[mq * D + h * HD + d] * O[mq * D + h * HD + d];
+      dl[tid] = delta;
+      ls[tid] = lse[((size_t)n * H + h) * T + qb * 64 + tid];
+    }
+    __syncthreads();
+    for (int j = 0; j < 64; ++j) {
+      float s = 0.f, dp = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) {
+        s = fmaf(Qs[j][d], kv[d], s);
+        dp = fmaf(Os[j][d], vv[d], dp);
+      }
+      const float p = expf(s - ls[j]);
+      const float ds = p * (dp - dl[j]);  // Qs already carries `scale`
+#pragma unroll
+      for (int d = 0; d < HD; ++d) {
+        dv[d] = fmaf(p, Os[j][d], dv[d]);
+        dk[d] = fmaf(ds, Qs[j][d], dk[d]);
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < HD; ++d) {
+    dqkv[m * ld3 + D + h * HD + d] = dk[d];
+    dqkv[m * ld3 + 2 * D + h * HD + d] = dv[d];
+  }
+}
+
+}  // namespace
+
+int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* O, const float* lse, void* dqkv, int N,
+                         int T, int heads, int head_dim, hipStream_t st) {
+  OSUD_CHECK_ARG(N > 0 && T > 0 && T % 64 == 0, "attention backward: T=%d must be a multiple of 64", T);
+  const int D = heads * head_dim;
+  const float scale = 1.0f / sqrtf((float)head_dim);
+  if (prec == OSUD_PREC_BF16) {
+    if (head_dim != 64 || T > 128) {
+      set_error("attention backward (bf16 tier) is built for head_dim 64 and T <= 128 (got hd=%d, T=%d)", head_dim, T);
+      return OSUD_ERR_UNSUPPORTED;
+    }
+    const size_t lds = (size_t)4 * T * 128 + (size_t)3 * 64 * (T * 2 + 8) + (size_t)2 * T * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bf16_kernel),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(attn_bwd_bf16_kernel, dim3(heads, N), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)dO,
+                       (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, scale * 1.4426950408889634f, scale);
+  } else {
+    const dim3 grid(T / 64, heads, N);
+#define OSUD_ABWD(HD)                                                                                                   \
+  hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<HD>), grid, dim3(64), 0, st, (const float*)qkv, (const float*)dO,       \
+                     (const float*)O, lse, (float*)dqkv, T, D, scale);                                                  \
+  hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<HD>), grid, dim3(64), 0, st, (const float*)qkv, (const float*)dO,      \
+                     (const float*)O, lse, (float*)dqkv, T, D, scale)
+    if (head_dim == 64) { OSUD_ABWD(64); }
+    else if (head_dim == 72) { OSUD_ABWD(72); }
+    else {
+      set_error("attention backward: head_dim %d not built (64, 72)", head_dim);
+      return OSUD_ERR_UNSUPPORTED;
+    }
+#undef OSUD_ABWD
+  }
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+}  // namespace osud

@@ -21,10 +21,11 @@ struct DevBuf {
 };
 
 struct BlockWeights {
-  void *w_qk = nullptr, *w_v = nullptr, *w_o = nullptr, *w1 = nullptr, *w2 = nullptr;  // TE, [out][in]
-  float *b_qk = nullptr, *b_v = nullptr, *b_o = nullptr, *b1 = nullptr, *b2 = nullptr;
-  // transposed copies ([in][out]) for the data-gradient products; built by osud_dit_set_param when training
-  void *w_qk_t = nullptr, *w_v_t = nullptr, *w_o_t = nullptr, *w1_t = nullptr, *w2_t = nullptr;
+  // TE, [out][in].  w_qkv is the packed in_proj ([Wq;Wk;Wv], 3D x D); w_qk / w_v alias its first 2D / last D rows.
+  void *w_qkv = nullptr, *w_qk = nullptr, *w_v = nullptr, *w_o = nullptr, *w1 = nullptr, *w2 = nullptr;
+  float *b_qkv = nullptr, *b_qk = nullptr, *b_v = nullptr, *b_o = nullptr, *b1 = nullptr, *b2 = nullptr;
+  // transposed copies ([in][out]) for the data-gradient products (training only)
+  void *w_qkv_t = nullptr, *w_o_t = nullptr, *w1_t = nullptr, *w2_t = nullptr;
 };
 
 // per-layer activations kept for the backward pass (training only)
@@ -33,7 +34,17 @@ struct LayerSaved {
   float* h_mid = nullptr;    // [Mp][D] after the attention branch
   float* stats1 = nullptr;   // [Mp][2] mean, rstd of LN1
   float* stats2 = nullptr;   // [Mp][2]
-  void *u1 = nullptr, *qk = nullptr, *vt = nullptr, *ao = nullptr, *u2 = nullptr, *z1 = nullptr, *g = nullptr;
+  void *u1 = nullptr, *qk = nullptr /* [Mp][3D] q|k|v */, *vt = nullptr, *ao = nullptr, *u2 = nullptr, *z1 = nullptr,
+       *g = nullptr, *br1 = nullptr /* attention branch output */, *br2 = nullptr /* MLP branch output */;
+  float* lse = nullptr;  // [N][H][Tp]
+};
+
+// workspaces of the backward pass
+struct BwdWs {
+  float *dhA = nullptr, *dhB = nullptr, *du = nullptr, *dada = nullptr, *dWada = nullptr, *dbada = nullptr, *dsb = nullptr,
+        *db = nullptr, *dth = nullptr, *dWe = nullptr;
+  void *dbr = nullptr, *dz1 = nullptr, *dqkv = nullptr, *dao = nullptr, *tA = nullptr, *tB = nullptr, *dada_te = nullptr,
+       *db_te = nullptr, *dz0 = nullptr, *small_t1 = nullptr, *small_t2 = nullptr;
 };
 
 struct GraphKey {
@@ -65,6 +76,15 @@ struct osud_dit {
   float* freqs64 = nullptr; float* freqs128 = nullptr;
   float pf[2] = {512.f, 384.f};
   std::map<std::string, bool> have;
+  std::map<std::string, const float*> master;  // caller's fp32 parameter (as last passed to set_param)
+  std::map<std::string, float*> grad;          // caller's fp32 gradient buffer (osud_dit_bind_grad)
+  void *w_ada_t = nullptr, *w_t2_t = nullptr;  // transposed copies (training)
+  bool transposed_ready = false;
+  BwdWs bw;
+  void* z0 = nullptr;  // [Np][D] TE: TimestepEmbedder pre-activation
+  // last training forward (inputs needed again by the backward pass)
+  const int64_t* last_y = nullptr;
+  int last_N = 0, last_T = 0;
   std::vector<void*> owned;  // everything hipMalloc'ed by this handle
 
   // workspaces (reserve)
@@ -85,6 +105,26 @@ struct osud_dit {
 };
 
 namespace osud {
+
+template <typename P> inline int dev_alloc(std::vector<void*>& owner, P** out, size_t bytes, bool zero = true) {
+  void* p = nullptr;
+  OSUD_HIP(hipMalloc(&p, bytes ? bytes : 16));
+  if (zero) OSUD_HIP(hipMemset(p, 0, bytes ? bytes : 16));
+  owner.push_back(p);
+  *out = reinterpret_cast<P*>(p);
+  return OSUD_OK;
+}
+
+inline int gemm(osud_dit* m, int epi, const void* Y, int ldy, const void* X, int ldx, int My, int Nx, int K, void* out,
+                int ldo, const float* bias, hipStream_t st, const float* gate = nullptr, int ld_gate = 0, int Tp = 0,
+                int N = 0, void* out2 = nullptr, const float* res = nullptr, const void* aux = nullptr) {
+  GemmP p{};
+  p.Y = Y; p.X = X; p.ldy = ldy; p.ldx = ldx; p.My = My; p.Nx = Nx; p.K = K;
+  p.out = out; p.out2 = out2; p.ldo = ldo; p.bias = bias; p.gate = gate; p.ld_gate = ld_gate;
+  p.rows_per_sample = Tp; p.n_samples = N; p.res = res; p.aux = aux;
+  return launch_gemm(m->prec, epi, p, st);
+}
+
 int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float* o, const float* c, const int64_t* y,
                      const uint8_t* mask, int N, int T, float cfg_scale, bool combine_cfg, float* out, bool save,
                      hipStream_t st);

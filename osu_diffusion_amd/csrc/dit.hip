@@ -24,29 +24,6 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
   return OSUD_ERR_HIP;
 }
 
-namespace {
-
-template <typename P> int dev_alloc(std::vector<void*>& owner, P** out, size_t bytes, bool zero = true) {
-  void* p = nullptr;
-  OSUD_HIP(hipMalloc(&p, bytes ? bytes : 16));
-  if (zero) OSUD_HIP(hipMemset(p, 0, bytes ? bytes : 16));
-  owner.push_back(p);
-  *out = reinterpret_cast<P*>(p);
-  return OSUD_OK;
-}
-
-int gemm(osud_dit* m, int epi, const void* Y, int ldy, const void* X, int ldx, int My, int Nx, int K, void* out,
-         int ldo, const float* bias, hipStream_t st, const float* gate = nullptr, int ld_gate = 0, int Tp = 0, int N = 0,
-         void* out2 = nullptr, const float* res = nullptr) {
-  GemmP p{};
-  p.Y = Y; p.X = X; p.ldy = ldy; p.ldx = ldx; p.My = My; p.Nx = Nx; p.K = K;
-  p.out = out; p.out2 = out2; p.ldo = ldo; p.bias = bias; p.gate = gate; p.ld_gate = ld_gate;
-  p.rows_per_sample = Tp; p.n_samples = N; p.res = res;
-  return launch_gemm(m->prec, epi, p, st);
-}
-
-}  // namespace
-
 int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
   if (N <= m->cap_N && T <= m->cap_T && (!training || m->training)) return OSUD_OK;
   // grow: free the old set, allocate for the max of old/new
@@ -90,15 +67,43 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
       OSUD_TRY(dev_alloc(W, &s.stats1, (size_t)Mp * 2 * 4));
       OSUD_TRY(dev_alloc(W, &s.stats2, (size_t)Mp * 2 * 4));
       OSUD_TRY(dev_alloc(W, &s.u1, (size_t)Mp * D * es));
-      OSUD_TRY(dev_alloc(W, &s.qk, (size_t)Mp * 2 * D * es));
+      OSUD_TRY(dev_alloc(W, &s.qk, (size_t)Mp * 3 * D * es));
       OSUD_TRY(dev_alloc(W, &s.vt, (size_t)Mp * D * es));
       OSUD_TRY(dev_alloc(W, &s.ao, (size_t)Mp * D * es));
       OSUD_TRY(dev_alloc(W, &s.u2, (size_t)Mp * D * es));
       OSUD_TRY(dev_alloc(W, &s.z1, (size_t)Mp * 4 * D * es));
       OSUD_TRY(dev_alloc(W, &s.g, (size_t)Mp * 4 * D * es));
+      OSUD_TRY(dev_alloc(W, &s.br1, (size_t)Mp * D * es));
+      OSUD_TRY(dev_alloc(W, &s.br2, (size_t)Mp * D * es));
+      OSUD_TRY(dev_alloc(W, &s.lse, (size_t)nN * m->H * Tp * 4));
     }
     m->h = m->saved[0].h_in;
     m->training = true;
+    OSUD_TRY(dev_alloc(W, &m->z0, (size_t)Np * D * es));
+    BwdWs& b = m->bw;
+    const size_t AC = m->ada_cols;
+    OSUD_TRY(dev_alloc(W, &b.dhA, (size_t)Mp * D * 4));
+    OSUD_TRY(dev_alloc(W, &b.dhB, (size_t)Mp * D * 4));
+    OSUD_TRY(dev_alloc(W, &b.du, (size_t)Mp * D * 4));
+    OSUD_TRY(dev_alloc(W, &b.dbr, (size_t)Mp * D * es));
+    OSUD_TRY(dev_alloc(W, &b.dz1, (size_t)Mp * 4 * D * es));
+    OSUD_TRY(dev_alloc(W, &b.dqkv, (size_t)Mp * 3 * D * es));
+    OSUD_TRY(dev_alloc(W, &b.dao, (size_t)Mp * D * es));
+    const size_t tcols = 4 * D > (size_t)m->Kp ? 4 * D : (size_t)m->Kp;  // widest matrix that gets transposed
+    OSUD_TRY(dev_alloc(W, &b.tA, (size_t)Mp * tcols * es));
+    OSUD_TRY(dev_alloc(W, &b.tB, (size_t)Mp * tcols * es));
+    OSUD_TRY(dev_alloc(W, &b.dada, (size_t)Np * AC * 4));
+    OSUD_TRY(dev_alloc(W, &b.dada_te, (size_t)Np * AC * es * 2));  // [Np][AC] + its transpose [AC][Np]
+    OSUD_TRY(dev_alloc(W, &b.dWada, AC * D * 4));
+    OSUD_TRY(dev_alloc(W, &b.dbada, AC * 4));
+    OSUD_TRY(dev_alloc(W, &b.dsb, (size_t)Np * D * 4));
+    OSUD_TRY(dev_alloc(W, &b.db, (size_t)Np * D * 4));
+    OSUD_TRY(dev_alloc(W, &b.dth, (size_t)Np * D * 4));
+    OSUD_TRY(dev_alloc(W, &b.db_te, (size_t)Np * D * es));
+    OSUD_TRY(dev_alloc(W, &b.dz0, (size_t)Np * D * es));
+    OSUD_TRY(dev_alloc(W, &b.small_t1, (size_t)Np * (D > 256 ? D : 256) * es));
+    OSUD_TRY(dev_alloc(W, &b.small_t2, (size_t)Np * (D > 256 ? D : 256) * es));
+    OSUD_TRY(dev_alloc(W, &b.dWe, (size_t)D * m->Kp * 4));
   }
   m->cap_N = nN; m->cap_T = nT; m->cap_Tp = Tp; m->cap_Mp = Mp; m->cap_Np = Np;
   return OSUD_OK;
@@ -134,7 +139,8 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
   // conditioning vector b = t_emb + y_emb (models.py:318-320) and ALL adaLN modulations in one GEMM:
   // b is the same for every block, so the 12 x (D -> 6D) + (D -> 2D) linears are one (Np x D) x (D x AC) product.
   OSUD_TRY(launch_temb(prec, t, m->freqs128, m->temb, N, Np, st));
-  OSUD_TRY(gemm(m, EPI_BIAS_SILU_TE, m->temb, 256, m->w_t0, 256, Np, D, 256, m->th, D, m->b_t0, st));
+  OSUD_TRY(gemm(m, EPI_BIAS_SILU_TE, m->temb, 256, m->w_t0, 256, Np, D, 256, m->th, D, m->b_t0, st, nullptr, 0, 0, 0,
+                m->training ? m->z0 : nullptr));
   OSUD_TRY(gemm(m, EPI_BIAS_F32, m->th, D, m->w_t2, D, Np, D, D, m->tvec, D, m->b_t2, st));
   OSUD_TRY(launch_cond(prec, m->tvec, m->table, y, m->cfg.table_rows, m->bvec, m->sb, N, Np, D, st));
   OSUD_TRY(gemm(m, EPI_BIAS_F32, m->sb, D, m->w_ada, D, Np, AC, D, m->ada, AC, m->b_ada, st));
@@ -152,24 +158,30 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
     float* h_out = sv ? m->saved[(size_t)l + 1].h_in : h;
     const int base = l * 6 * D;
     OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base, base + D, u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st));
-    OSUD_TRY(gemm(m, EPI_BIAS_TE, u1, D, w.w_qk, D, Mp, 2 * D, D, qk, 2 * D, w.b_qk, st));
+    // training keeps V row-major too (its backward contracts over d): one 3D-wide product instead of 2D
+    const int qcols = sv ? 3 * D : 2 * D;
+    OSUD_TRY(gemm(m, EPI_BIAS_TE, u1, D, w.w_qkv, D, Mp, qcols, D, qk, qcols, w.b_qkv, st));
     OSUD_TRY(gemm(m, EPI_ROWBIAS_TE, w.w_v, D, u1, D, D, Mp, D, vt, Mp, w.b_v, st));  // V^T = W_v . u^T
-    OSUD_TRY(launch_attention(prec, qk, vt, mask, ao, N, T, Tp, Mp, m->H, m->hd, st));
+    OSUD_TRY(launch_attention(prec, qk, qcols, vt, mask, ao, sv ? sv->lse : nullptr, N, T, Tp, Mp, m->H, m->hd, st));
     OSUD_TRY(gemm(m, EPI_GATE_RES, ao, D, w.w_o, D, Mp, D, D, h_mid, D, w.b_o, st, m->ada + base + 2 * D, AC, Tp, N,
-                  nullptr, h));
+                  sv ? sv->br1 : nullptr, h));
     OSUD_TRY(launch_ln_mod(prec, h_mid, m->ada, AC, base + 3 * D, base + 4 * D, u2, sv ? sv->stats2 : nullptr, Mp, Tp, N,
                            D, st));
     OSUD_TRY(gemm(m, EPI_BIAS_GELU_TE, u2, D, w.w1, D, Mp, 4 * D, D, g, 4 * D, w.b1, st, nullptr, 0, 0, 0,
                   sv ? sv->z1 : nullptr));
     OSUD_TRY(gemm(m, EPI_GATE_RES, g, 4 * D, w.w2, 4 * D, Mp, D, 4 * D, h_out, D, w.b2, st, m->ada + base + 5 * D, AC, Tp,
-                  N, nullptr, h_mid));
+                  N, sv ? sv->br2 : nullptr, h_mid));
     h = h_out;
   }
   // FinalLayer (models.py:192-196) + swapaxes (:324)
   OSUD_TRY(launch_final(h, m->ada, AC, L * 6 * D, L * 6 * D + D, m->w_f, m->b_f, out, nullptr,
                         m->training ? m->saved[(size_t)L].stats1 : nullptr, N, T, Tp, D, m->C2, st));
   if (cfg && combine_cfg) OSUD_TRY(launch_cfg_combine(out, N, m->C, m->C2, T, cfg_scale, st));
-  (void)save;
+  if (save) {
+    m->last_y = y;
+    m->last_N = N;
+    m->last_T = T;
+  }
   return OSUD_OK;
 }
 
@@ -212,7 +224,7 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   m->D = cfg->hidden; m->L = cfg->depth; m->H = cfg->heads; m->hd = hd; m->E = cfg->context;
   m->C = cfg->in_channels; m->C2 = cfg->learn_sigma ? 2 * cfg->in_channels : cfg->in_channels;
   m->prec = cfg->precision; m->esz = (int)elem_size(cfg->precision);
-  m->Kp = round_up(cfg->in_channels * 128 + 128 + cfg->context, 64);
+  m->Kp = round_up(cfg->in_channels * 128 + 128 + cfg->context, 128);  // 528 -> 640
   m->ada_cols = 6 * m->D * m->L + 2 * m->D;
   if (hipGetDevice(&m->device) != hipSuccess) {
     delete m;
@@ -230,8 +242,11 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   A(&m->freqs64, 64 * 4); A(&m->freqs128, 128 * 4);
   m->blk.resize((size_t)m->L);
   for (auto& b : m->blk) {
-    A(&b.w_qk, 2 * D * D * es); A(&b.b_qk, 2 * D * 4);
-    A(&b.w_v, D * D * es);      A(&b.b_v, D * 4);
+    A(&b.w_qkv, 3 * D * D * es); A(&b.b_qkv, 3 * D * 4);
+    if (rc == OSUD_OK) {
+      b.w_qk = b.w_qkv; b.w_v = (char*)b.w_qkv + 2 * D * D * es;
+      b.b_qk = b.b_qkv; b.b_v = b.b_qkv + 2 * D;
+    }
     A(&b.w_o, D * D * es);      A(&b.b_o, D * 4);
     A(&b.w1, 4 * D * D * es);   A(&b.b1, 4 * D * 4);
     A(&b.w2, 4 * D * D * es);   A(&b.b2, D * 4);
@@ -332,12 +347,10 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
     const size_t es = m->esz;
     if (name == "attn.in_proj_weight") {
       SHAPE(3 * D, D);  // rows [Wq; Wk; Wv]
-      rc = launch_convert(prec, src, b.w_qk, 2 * D * D, st);
-      if (rc == OSUD_OK) rc = launch_convert(prec, src + 2 * D * D, b.w_v, D * D, st);
+      rc = launch_convert(prec, src, b.w_qkv, 3 * D * D, st);
     } else if (name == "attn.in_proj_bias") {
       SHAPE(3 * D);
-      rc = upload_f32(m, &b.b_qk, src, 2 * D, st);
-      if (rc == OSUD_OK) rc = upload_f32(m, &b.b_v, src + 2 * D, D, st);
+      rc = upload_f32(m, &b.b_qkv, src, 3 * D, st);
     } else if (name == "attn.out_proj.weight") { SHAPE(D, D); rc = launch_convert(prec, src, b.w_o, D * D, st);
     } else if (name == "attn.out_proj.bias") { SHAPE(D); rc = upload_f32(m, &b.b_o, src, D, st);
     } else if (name == "mlp.fc1.weight") { SHAPE(4 * D, D); rc = launch_convert(prec, src, b.w1, 4 * D * D, st);
@@ -357,7 +370,11 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
     }
   }
 #undef SHAPE
-  if (rc == OSUD_OK) it->second = true;
+  if (rc == OSUD_OK) {
+    it->second = true;
+    m->master[k] = src;
+    m->transposed_ready = false;
+  }
   return rc;
 }
 
@@ -444,5 +461,6 @@ extern "C" int osud_op_convert(int precision, const float* src, void* dst, size_
 extern "C" int osud_op_attention(int precision, const void* qk, const void* vt, const uint8_t* mask, void* out, int N,
                                  int T, int Tp, int Mp, int heads, int head_dim, osud_stream stream) {
   OSUD_CHECK_ARG(qk && vt && out, "op_attention: null argument");
-  return launch_attention(precision, qk, vt, mask, out, N, T, Tp, Mp, heads, head_dim, (hipStream_t)stream);
+  return launch_attention(precision, qk, 2 * heads * head_dim, vt, mask, out, nullptr, N, T, Tp, Mp, heads, head_dim,
+                          (hipStream_t)stream);
 }

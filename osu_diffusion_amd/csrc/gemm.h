@@ -23,10 +23,10 @@ namespace osud {
 enum GemmEpilogue {
   EPI_BIAS_F32 = 0,       // out f32 = acc + bias[x]
   EPI_BIAS_TE = 1,        // out TE  = acc + bias[x]
-  EPI_BIAS_SILU_TE = 2,   // out TE  = silu(acc + bias[x])
+  EPI_BIAS_SILU_TE = 2,   // out TE  = silu(acc + bias[x]); out2 TE (optional) = acc + bias[x]
   EPI_ROWBIAS_TE = 3,     // out TE  = acc + bias[y]            (transposed products)
   EPI_BIAS_GELU_TE = 4,   // out TE  = gelu_tanh(acc + bias[x]); out2 TE (optional) = acc + bias[x]
-  EPI_GATE_RES = 5,       // out f32 += gate[sample(y)][x] * (acc + bias[x])   (adaLN-Zero gated residual)
+  EPI_GATE_RES = 5,       // out f32 = res + gate[sample(y)][x] * (acc + bias[x]); out2 TE (optional) = acc + bias[x]
   EPI_NONE_F32 = 6,       // out f32 = acc
   EPI_NONE_TE = 7,        // out TE  = acc
   EPI_ACCUM_F32 = 8,      // out f32 += acc                      (gradient accumulation)

@@ -217,9 +217,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
           store4(reinterpret_cast<float*>(p.out) + o, rv[j][g].x + v0, rv[j][g].y + v1, rv[j][g].z + v2,
                  rv[j][g].w + v3);
         } else if (EPI == EPI_GATE_RES) {
+          if (p.out2) store4(reinterpret_cast<TE*>(p.out2) + o, v0, v1, v2, v3);  // branch output (training)
           store4(reinterpret_cast<float*>(p.out) + o, rv[j][g].x + gv[j][g].x * v0, rv[j][g].y + gv[j][g].y * v1,
                  rv[j][g].z + gv[j][g].z * v2, rv[j][g].w + gv[j][g].w * v3);
         } else if (EPI == EPI_BIAS_SILU_TE) {
+          if (p.out2) store4(reinterpret_cast<TE*>(p.out2) + o, v0, v1, v2, v3);  // pre-activation (training)
           store4(reinterpret_cast<TE*>(p.out) + o, silu_t<FAST>(v0), silu_t<FAST>(v1), silu_t<FAST>(v2),
                  silu_t<FAST>(v3));
         } else if (EPI == EPI_BIAS_GELU_TE) {

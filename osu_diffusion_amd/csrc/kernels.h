@@ -19,8 +19,30 @@ int launch_cfg_combine(float* out, int N, int C, int C2, int T, float s, hipStre
 int launch_convert(int prec, const float* src, void* dst, size_t n, hipStream_t st);
 int launch_pack_rows(int prec, const float* src, int ld_src, int cols_src, void* dst, int ld_dst, int cols_dst, int rows,
                      hipStream_t st);
-int launch_attention(int prec, const void* qk, const void* vt, const uint8_t* mask, void* out, int N, int T, int Tp,
-                     int Mp, int heads, int head_dim, hipStream_t st);
+int launch_attention(int prec, const void* qk, int ld_qk, const void* vt, const uint8_t* mask, void* out, float* lse,
+                     int N, int T, int Tp, int Mp, int heads, int head_dim, hipStream_t st);
+int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* O, const float* lse, void* dqkv, int N,
+                         int T, int heads, int head_dim, hipStream_t st);
+
+// kernels_bwd.hip
+int launch_transpose(int prec, const void* in, int ld_in, void* out, int ld_out, int R, int C, float* colsum,
+                     hipStream_t st);
+int launch_transpose_f32(int prec, const float* in, int ld_in, void* out, int ld_out, int R, int C, float* colsum,
+                         hipStream_t st);
+int launch_gate_bwd(int prec, const float* dh, const void* br, const float* gate, int ld_ada, void* dbr, float* dgate,
+                    int M, int Tp, int D, hipStream_t st);
+int launch_ln_mod_bwd(const float* h, const float* stats, const float* du, const float* ada, int ld_ada, int off_shift,
+                      int off_scale, const float* dh_skip, float* dh_out, float* dada, int M, int Tp, int D,
+                      hipStream_t st);
+int launch_final_bwd(const float* h, const float* stats, const float* dout, const float* w, const float* ada, int ld_ada,
+                     int off_shift, int off_scale, float* dh_out, float* dada, float* dw, float* dbias, int N, int T, int Tp,
+                     int D, int C, hipStream_t st);
+int launch_cond_bwd(int prec, const float* dsb, const float* b, const int64_t* y, int table_rows, float* db_out,
+                    void* db_te, float* dtable, int N, int Np, int D, hipStream_t st);
+int launch_silu_bwd(int prec, const float* dth, const void* z, void* dz, size_t n, hipStream_t st);
+int launch_mask_rows(int prec, float* a, void* a_te, int N, int Np, int C, hipStream_t st);
+int launch_unpad_rows(const float* src, int ld_src, float* dst, int cols, int rows, hipStream_t st);
+int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_t st);
 
 // sampler.hip
 struct StepCoefs;  // device table, 8 floats per step

@@ -1,0 +1,473 @@
+// Backward-pass kernels of the DiT path that are not GEMMs (autograd of models.py:151-196,
+// 306-325 written by hand).  Gradients flow as fp32 through the residual stream / LayerNorm /
+// modulation and as TE (bf16 | f32) into the MFMA products.  Training layouts have no padding
+// rows (T % 64 == 0 and N*T % 128 == 0 are enforced by the caller).
+#include "kernels.h"
+
+namespace osud {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// out[c][r] = in[r][c] for a [R][C] TE matrix (R, C multiples of 64), plus optional column sums
+// colsum[c] += sum_r in[r][c] (bias gradients: one pass over dC feeds both the transposed
+// operand of the weight-gradient GEMM and db).  64x64 tile through LDS, padded rows.
+template <typename TE>
+__global__ __launch_bounds__(256) void transpose_kernel(const TE* __restrict__ in, int ld_in, TE* __restrict__ out,
+                                                        int ld_out, float* __restrict__ colsum) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 4 row-groups
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = ty + 4 * i;
+    const float v = load_elem(in + (size_t)(r0 + r) * ld_in + c0 + tx);
+    tile[r][tx] = v;
+    s += v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = ty + 4 * i;
+    store_elem(out + (size_t)(c0 + c) * ld_out + r0 + tx, tile[tx][c]);
+  }
+  if (colsum != nullptr) {
+    __shared__ float part[4][64];
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0) atomicAdd(colsum + c0 + tx, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+  }
+}
+
+// f32 [R][C] -> TE [C][R] (+ column sums): same, source fp32 (gradient of the residual stream)
+template <typename TE>
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ in, int ld_in,
+                                                            TE* __restrict__ out, int ld_out,
+                                                            float* __restrict__ colsum) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = ty + 4 * i;
+    const float v = in[(size_t)(r0 + r) * ld_in + c0 + tx];
+    tile[r][tx] = v;
+    s += v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = ty + 4 * i;
+    store_elem(out + (size_t)(c0 + c) * ld_out + r0 + tx, tile[tx][c]);
+  }
+  if (colsum != nullptr) {
+    __shared__ float part[4][64];
+    part[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0) atomicAdd(colsum + c0 + tx, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Gated residual branch backward:  h_out = h_in + gate[n] * br   (models.py:161-175)
+//   dbr[m][d]  = gate[n][d] * dh[m][d]                       (TE, operand of the next GEMMs)
+//   dgate[n][d] += sum_t dh[m][d] * br[m][d]
+// Block = 64 consecutive rows (one sample: Tp % 64 == 0), wave w takes rows w, w+4, ...
+template <typename TE, int VPL>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dh, const TE* __restrict__ br,
+                                                       const float* __restrict__ gate, int ld_ada,
+                                                       TE* __restrict__ dbr, float* __restrict__ dgate, int Tp) {
+  constexpr int D = VPL * 64;
+  __shared__ float red[4][D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = blockIdx.x * 64, n = m0 / Tp;
+  const float* g = gate + (size_t)n * ld_ada;
+  float gv[VPL], acc[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL / 2; ++i) {
+    const float2 t = *reinterpret_cast<const float2*>(g + 2 * lane + 128 * i);
+    gv[2 * i] = t.x; gv[2 * i + 1] = t.y;
+    acc[2 * i] = acc[2 * i + 1] = 0.f;
+  }
+  for (int r = wave; r < 64; r += 4) {
+    const size_t row = (size_t)(m0 + r) * D;
+#pragma unroll
+    for (int i = 0; i < VPL / 2; ++i) {
+      const int d = 2 * lane + 128 * i;
+      const float2 dv = *reinterpret_cast<const float2*>(dh + row + d);
+      const float b0 = load_elem(br + row + d), b1 = load_elem(br + row + d + 1);
+      acc[2 * i] += dv.x * b0;
+      acc[2 * i + 1] += dv.y * b1;
+      store_elem(dbr + row + d, gv[2 * i] * dv.x);
+      store_elem(dbr + row + d + 1, gv[2 * i + 1] * dv.y);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VPL / 2; ++i) {
+    red[wave][2 * lane + 128 * i] = acc[2 * i];
+    red[wave][2 * lane + 128 * i + 1] = acc[2 * i + 1];
+  }
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 256)
+    atomicAdd(dgate + (size_t)n * ld_ada + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm + modulate backward:  u = xhat * (1 + sc[n]) + sh[n],  xhat = (h - mu) * rstd
+//   dsh[n] += sum_t du ; dsc[n] += sum_t du * xhat ; dy = du * (1 + sc)
+//   dh_out = dh_skip + rstd * (dy - mean(dy) - xhat * mean(dy * xhat))
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict__ h, const float* __restrict__ stats,
+                                                         const float* __restrict__ du, const float* __restrict__ ada,
+                                                         int ld_ada, int off_shift, int off_scale,
+                                                         const float* __restrict__ dh_skip, float* __restrict__ dh_out,
+                                                         float* __restrict__ dada, int Tp) {
+  constexpr int D = VPL * 64;
+  __shared__ float red[2][4][D];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = blockIdx.x * 64, n = m0 / Tp;
+  const float* sc = ada + (size_t)n * ld_ada + off_scale;
+  float scv[VPL], a_sh[VPL], a_sc[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL / 2; ++i) {
+    const float2 t = *reinterpret_cast<const float2*>(sc + 2 * lane + 128 * i);
+    scv[2 * i] = 1.0f + t.x; scv[2 * i + 1] = 1.0f + t.y;
+    a_sh[2 * i] = a_sh[2 * i + 1] = a_sc[2 * i] = a_sc[2 * i + 1] = 0.f;
+  }
+  for (int r = wave; r < 64; r += 4) {
+    const int m = m0 + r;
+    const size_t row = (size_t)m * D;
+    const float mu = stats[2 * (size_t)m], rstd = stats[2 * (size_t)m + 1];
+    float xh[VPL], dy[VPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL / 2; ++i) {
+      const int d = 2 * lane + 128 * i;
+      const float2 hv = *reinterpret_cast<const float2*>(h + row + d);
+      const float2 dv = *reinterpret_cast<const float2*>(du + row + d);
+      xh[2 * i] = (hv.x - mu) * rstd; xh[2 * i + 1] = (hv.y - mu) * rstd;
+      a_sh[2 * i] += dv.x; a_sh[2 * i + 1] += dv.y;
+      a_sc[2 * i] += dv.x * xh[2 * i]; a_sc[2 * i + 1] += dv.y * xh[2 * i + 1];
+      dy[2 * i] = dv.x * scv[2 * i]; dy[2 * i + 1] = dv.y * scv[2 * i + 1];
+      s1 += dy[2 * i] + dy[2 * i + 1];
+      s2 += dy[2 * i] * xh[2 * i] + dy[2 * i + 1] * xh[2 * i + 1];
+    }
+    const float m1 = wave_sum(s1) * (1.0f / D), m2 = wave_sum(s2) * (1.0f / D);
+#pragma unroll
+    for (int i = 0; i < VPL / 2; ++i) {
+      const int d = 2 * lane + 128 * i;
+      float2 o = make_float2(rstd * (dy[2 * i] - m1 - xh[2 * i] * m2), rstd * (dy[2 * i + 1] - m1 - xh[2 * i + 1] * m2));
+      if (dh_skip != nullptr) {
+        const float2 sk = *reinterpret_cast<const float2*>(dh_skip + row + d);
+        o.x += sk.x; o.y += sk.y;
+      }
+      *reinterpret_cast<float2*>(dh_out + row + d) = o;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VPL / 2; ++i) {
+    const int d = 2 * lane + 128 * i;
+    red[0][wave][d] = a_sh[2 * i]; red[0][wave][d + 1] = a_sh[2 * i + 1];
+    red[1][wave][d] = a_sc[2 * i]; red[1][wave][d + 1] = a_sc[2 * i + 1];
+  }
+  __syncthreads();
+  float* dn = dada + (size_t)n * ld_ada;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    atomicAdd(dn + off_shift + d, red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d]);
+    atomicAdd(dn + off_scale + d, red[1][0][d] + red[1][1][d] + red[1][2][d] + red[1][3][d]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Final layer backward (models.py:192-196): out[n][ch][t] = sum_d uF[m][d] Wf[ch][d] + bf[ch]
+//   duF = sum_ch dout * Wf ; dWf[ch][d] += sum_m dout * uF ; dbf[ch] += sum_m dout
+// then the same LN+modulate backward as above (dh_skip = 0), all in one pass over h.
+template <int VPL>
+__global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict__ h, const float* __restrict__ stats,
+                                                        const float* __restrict__ dout, const float* __restrict__ w,
+                                                        const float* __restrict__ ada, int ld_ada, int off_shift,
+                                                        int off_scale, float* __restrict__ dh_out,
+                                                        float* __restrict__ dada, float* __restrict__ dw,
+                                                        float* __restrict__ dbias, int T, int Tp, int C) {
+  constexpr int D = VPL * 64;
+  __shared__ float red[4][D];  // one quantity at a time (6 of them) to stay inside 64 KiB
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = blockIdx.x * 64, n = m0 / Tp;
+  const float* sc = ada + (size_t)n * ld_ada + off_scale;
+  const float* sh = ada + (size_t)n * ld_ada + off_shift;
+  float scv[VPL], shv[VPL], a_sh[VPL], a_sc[VPL], wv[4][VPL], a_w[4][VPL];
+  float a_b[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < VPL / 2; ++i) {
+    const int d = 2 * lane + 128 * i;
+    const float2 t = *reinterpret_cast<const float2*>(sc + d);
+    const float2 u = *reinterpret_cast<const float2*>(sh + d);
+    scv[2 * i] = 1.0f + t.x; scv[2 * i + 1] = 1.0f + t.y;
+    shv[2 * i] = u.x; shv[2 * i + 1] = u.y;
+    a_sh[2 * i] = a_sh[2 * i + 1] = a_sc[2 * i] = a_sc[2 * i + 1] = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      float2 w2 = make_float2(0.f, 0.f);
+      if (ch < C) w2 = *reinterpret_cast<const float2*>(w + (size_t)ch * D + d);
+      wv[ch][2 * i] = w2.x; wv[ch][2 * i + 1] = w2.y;
+      a_w[ch][2 * i] = a_w[ch][2 * i + 1] = 0.f;
+    }
+  }
+  for (int r = wave; r < 64; r += 4) {
+    const int m = m0 + r, t = m % Tp;
+    const size_t row = (size_t)m * D;
+    float go[4] = {0.f, 0.f, 0.f, 0.f};
+    if (t < T) {
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch)
+        if (ch < C) go[ch] = dout[((size_t)n * C + ch) * T + t];
+    }
+    const float mu = stats[2 * (size_t)m], rstd = stats[2 * (size_t)m + 1];
+    float xh[VPL], dy[VPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) a_b[ch] += go[ch];
+#pragma unroll
+    for (int i = 0; i < VPL / 2; ++i) {
+      const int d = 2 * lane + 128 * i;
+      const float2 hv = *reinterpret_cast<const float2*>(h + row + d);
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int k = 2 * i + e;
+        xh[k] = ((e ? hv.y : hv.x) - mu) * rstd;
+        const float uF = xh[k] * scv[k] + shv[k];
+        float du = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+          du += go[ch] * wv[ch][k];
+          a_w[ch][k] += go[ch] * uF;
+        }
+        a_sh[k] += du;
+        a_sc[k] += du * xh[k];
+        dy[k] = du * scv[k];
+        s1 += dy[k];
+        s2 += dy[k] * xh[k];
+      }
+    }
+    const float m1 = wave_sum(s1) * (1.0f / D), m2 = wave_sum(s2) * (1.0f / D);
+#pragma unroll
+    for (int i = 0; i < VPL / 2; ++i) {
+      const int d = 2 * lane + 128 * i;
+      *reinterpret_cast<float2*>(dh_out + row + d) =
+          make_float2(rstd * (dy[2 * i] - m1 - xh[2 * i] * m2), rstd * (dy[2 * i + 1] - m1 - xh[2 * i + 1] * m2));
+    }
+  }
+  float* dn = dada + (size_t)n * ld_ada;
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {  // 0: dshift, 1: dscale, 2..5: dW rows
+    if (q >= 2 && q - 2 >= C) break;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int d = 2 * lane + 128 * (i >> 1) + (i & 1);
+      red[wave][d] = q == 0 ? a_sh[i] : (q == 1 ? a_sc[i] : a_w[q >= 2 ? q - 2 : 0][i]);
+    }
+    __syncthreads();
+    float* dst = q == 0 ? dn + off_shift : (q == 1 ? dn + off_scale : dw + (size_t)(q - 2) * D);
+    for (int d = threadIdx.x; d < D; d += 256) atomicAdd(dst + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
+    __syncthreads();
+  }
+  if (lane == 0)  // every lane of a wave carries the same a_b
+    for (int ch = 0; ch < C; ++ch) atomicAdd(dbias + ch, a_b[ch]);
+}
+
+// ------------------------------------------------------------------------------------------
+// Conditioning path backward.  sb = silu(b), b = tvec + table[y]  (models.py:318-320):
+//   db = dsb * silu'(b) ; dtvec = db (TE copy for the GEMMs + f32) ; dtable[y[n]] += db[n]
+template <typename TE>
+__global__ void cond_bwd_kernel(const float* __restrict__ dsb, const float* __restrict__ b, const int64_t* __restrict__ y,
+                                int table_rows, float* __restrict__ db_out, TE* __restrict__ db_te,
+                                float* __restrict__ dtable, int N, int D) {
+  const int n = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float g = 0.f;
+    if (n < N) {
+      const float bv = b[(size_t)n * D + d];
+      const float s = 1.0f / (1.0f + expf(-bv));
+      g = dsb[(size_t)n * D + d] * (s + bv * s * (1.0f - s));
+      int64_t cls = y[n];
+      cls = cls < 0 ? 0 : (cls >= table_rows ? table_rows - 1 : cls);
+      atomicAdd(dtable + (size_t)cls * D + d, g);
+    }
+    db_out[(size_t)n * D + d] = g;
+    store_elem(db_te + (size_t)n * D + d, g);
+  }
+}
+
+// dz = dth * silu'(z)  (TimestepEmbedder's SiLU, models.py:29-31); z is the saved pre-activation
+template <typename TE>
+__global__ void silu_bwd_kernel(const float* __restrict__ dth, const TE* __restrict__ z, TE* __restrict__ dz, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float zv = load_elem(z + i);
+    const float s = 1.0f / (1.0f + expf(-zv));
+    store_elem(dz + i, dth[i] * (s + zv * s * (1.0f - s)));
+  }
+}
+
+// zero rows >= N of an f32 [Np][C] matrix and emit the TE copy (padding samples carry no gradient)
+template <typename TE>
+__global__ void mask_rows_kernel(float* __restrict__ a, TE* __restrict__ a_te, int N, int Np, int C) {
+  const size_t total = (size_t)Np * C;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / C);
+    float v = a[i];
+    if (n >= N) {
+      v = 0.f;
+      a[i] = 0.f;
+    }
+    store_elem(a_te + i, v);
+  }
+}
+
+// dst[r][0..cols) = src[r][0..cols) from a padded f32 [rows][ld_src] (first-layer weight gradient)
+__global__ void unpad_rows_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst, int cols, int rows) {
+  const size_t total = (size_t)rows * cols;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    dst[i] = src[(size_t)r * ld_src + c];
+  }
+}
+
+// column sums of an f32 [R][C] matrix over rows < R_valid (bias grads of the conditioning path)
+__global__ void colsum_f32_kernel(const float* __restrict__ a, int R_valid, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < R_valid; ++r) s += a[(size_t)r * C + c];
+  out[c] = s;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------- launchers
+int launch_transpose(int prec, const void* in, int ld_in, void* out, int ld_out, int R, int C, float* colsum,
+                     hipStream_t st) {
+  OSUD_CHECK_ARG(R % 64 == 0 && C % 64 == 0, "transpose: %dx%d must be multiples of 64", R, C);
+  const dim3 grid(C / 64, R / 64);
+  if (prec == OSUD_PREC_BF16)
+    hipLaunchKernelGGL((transpose_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out,
+                       colsum);
+  else
+    hipLaunchKernelGGL((transpose_kernel<float>), grid, dim3(256), 0, st, (const float*)in, ld_in, (float*)out, ld_out,
+                       colsum);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+int launch_transpose_f32(int prec, const float* in, int ld_in, void* out, int ld_out, int R, int C, float* colsum,
+                         hipStream_t st) {
+  OSUD_CHECK_ARG(R % 64 == 0 && C % 64 == 0, "transpose: %dx%d must be multiples of 64", R, C);
+  const dim3 grid(C / 64, R / 64);
+  if (prec == OSUD_PREC_BF16)
+    hipLaunchKernelGGL((transpose_f32_kernel<bf16_t>), grid, dim3(256), 0, st, in, ld_in, (bf16_t*)out, ld_out, colsum);
+  else
+    hipLaunchKernelGGL((transpose_f32_kernel<float>), grid, dim3(256), 0, st, in, ld_in, (float*)out, ld_out, colsum);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+#define OSUD_BY_D(D, CALL)                                                              \
+  switch (D) {                                                                          \
+    case 128: CALL(2); break;                                                           \
+    case 384: CALL(6); break;                                                           \
+    case 768: CALL(12); break;                                                          \
+    case 1024: CALL(16); break;                                                         \
+    case 1152: CALL(18); break;                                                         \
+    default: set_error("hidden size %d not built", D); return OSUD_ERR_UNSUPPORTED;    \
+  }
+
+int launch_gate_bwd(int prec, const float* dh, const void* br, const float* gate, int ld_ada, void* dbr, float* dgate,
+                    int M, int Tp, int D, hipStream_t st) {
+  OSUD_CHECK_ARG(M % 64 == 0 && Tp % 64 == 0, "gate_bwd: rows must come in blocks of 64");
+  const dim3 grid(M / 64), block(256);
+  if (prec == OSUD_PREC_BF16) {
+#define CALL(V) hipLaunchKernelGGL((gate_bwd_kernel<bf16_t, V>), grid, block, 0, st, dh, (const bf16_t*)br, gate, ld_ada, (bf16_t*)dbr, dgate, Tp)
+    OSUD_BY_D(D, CALL)
+#undef CALL
+  } else {
+#define CALL(V) hipLaunchKernelGGL((gate_bwd_kernel<float, V>), grid, block, 0, st, dh, (const float*)br, gate, ld_ada, (float*)dbr, dgate, Tp)
+    OSUD_BY_D(D, CALL)
+#undef CALL
+  }
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+int launch_ln_mod_bwd(const float* h, const float* stats, const float* du, const float* ada, int ld_ada, int off_shift,
+                      int off_scale, const float* dh_skip, float* dh_out, float* dada, int M, int Tp, int D,
+                      hipStream_t st) {
+  OSUD_CHECK_ARG(M % 64 == 0 && Tp % 64 == 0, "ln_mod_bwd: rows must come in blocks of 64");
+  const dim3 grid(M / 64), block(256);
+#define CALL(V) hipLaunchKernelGGL((ln_mod_bwd_kernel<V>), grid, block, 0, st, h, stats, du, ada, ld_ada, off_shift, off_scale, dh_skip, dh_out, dada, Tp)
+  OSUD_BY_D(D, CALL)
+#undef CALL
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+int launch_final_bwd(const float* h, const float* stats, const float* dout, const float* w, const float* ada, int ld_ada,
+                     int off_shift, int off_scale, float* dh_out, float* dada, float* dw, float* dbias, int N, int T, int Tp,
+                     int D, int C, hipStream_t st) {
+  OSUD_CHECK_ARG(Tp % 64 == 0 && C <= 4, "final_bwd: bad sizes");
+  const dim3 grid(N * Tp / 64), block(256);
+#define CALL(V) hipLaunchKernelGGL((final_bwd_kernel<V>), grid, block, 0, st, h, stats, dout, w, ada, ld_ada, off_shift, off_scale, dh_out, dada, dw, dbias, T, Tp, C)
+  OSUD_BY_D(D, CALL)
+#undef CALL
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+int launch_cond_bwd(int prec, const float* dsb, const float* b, const int64_t* y, int table_rows, float* db_out,
+                    void* db_te, float* dtable, int N, int Np, int D, hipStream_t st) {
+  if (prec == OSUD_PREC_BF16)
+    hipLaunchKernelGGL((cond_bwd_kernel<bf16_t>), dim3(Np), dim3(256), 0, st, dsb, b, y, table_rows, db_out,
+                       (bf16_t*)db_te, dtable, N, D);
+  else
+    hipLaunchKernelGGL((cond_bwd_kernel<float>), dim3(Np), dim3(256), 0, st, dsb, b, y, table_rows, db_out,
+                       (float*)db_te, dtable, N, D);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+int launch_silu_bwd(int prec, const float* dth, const void* z, void* dz, size_t n, hipStream_t st) {
+  const int grid = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  if (prec == OSUD_PREC_BF16)
+    hipLaunchKernelGGL((silu_bwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, dth, (const bf16_t*)z, (bf16_t*)dz, n);
+  else
+    hipLaunchKernelGGL((silu_bwd_kernel<float>), dim3(grid), dim3(256), 0, st, dth, (const float*)z, (float*)dz, n);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+int launch_mask_rows(int prec, float* a, void* a_te, int N, int Np, int C, hipStream_t st) {
+  const size_t total = (size_t)Np * C;
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  if (prec == OSUD_PREC_BF16)
+    hipLaunchKernelGGL((mask_rows_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a, (bf16_t*)a_te, N, Np, C);
+  else
+    hipLaunchKernelGGL((mask_rows_kernel<float>), dim3(grid), dim3(256), 0, st, a, (float*)a_te, N, Np, C);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+int launch_unpad_rows(const float* src, int ld_src, float* dst, int cols, int rows, hipStream_t st) {
+  const size_t total = (size_t)rows * cols;
+  const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  hipLaunchKernelGGL(unpad_rows_kernel, dim3(grid), dim3(256), 0, st, src, ld_src, dst, cols, rows);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(colsum_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, st, a, R_valid, C, out);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+}  // namespace osud

@@ -25,6 +25,7 @@ struct osud_sched {
       coef1, coef2, log_betas;
   std::vector<int64_t> tmap;
   float* d_coefs = nullptr;  // [n][8]
+  float* d_train = nullptr;  // [n][8] sqrt_ac, sqrt_1m_ac, sqrt_recip, sqrt_recipm1, coef1, coef2, post_logvar, log_beta
   int64_t* d_tmap = nullptr;
   int device = -1;
 };
@@ -53,6 +54,25 @@ int sched_upload(osud_sched* s) {
   return OSUD_OK;
 }
 const float* sched_coefs(const osud_sched* s) { return s->d_coefs; }
+const float* sched_train_coefs(const osud_sched* s) { return s->d_train; }
+int sched_upload_train(osud_sched* s) {
+  if (s->d_train) return OSUD_OK;
+  std::vector<float> h((size_t)s->n * 8);
+  for (int i = 0; i < s->n; ++i) {
+    float* r = &h[(size_t)i * 8];
+    r[0] = (float)s->sqrt_ac[i];
+    r[1] = (float)s->sqrt_1m_ac[i];
+    r[2] = (float)s->sqrt_recip[i];
+    r[3] = (float)s->sqrt_recipm1[i];
+    r[4] = (float)s->coef1[i];
+    r[5] = (float)s->coef2[i];
+    r[6] = (float)s->post_logvar[i];
+    r[7] = (float)s->log_betas[i];
+  }
+  OSUD_HIP(hipMalloc(&s->d_train, h.size() * sizeof(float)));
+  OSUD_HIP(hipMemcpy(s->d_train, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+  return OSUD_OK;
+}
 const int64_t* sched_tmap_dev(const osud_sched* s) { return s->d_tmap; }
 
 namespace {
@@ -244,6 +264,7 @@ extern "C" void osud_sched_destroy(osud_sched* s) {
   if (!s) return;
   if (s->d_coefs) (void)hipFree(s->d_coefs);
   if (s->d_tmap) (void)hipFree(s->d_tmap);
+  if (s->d_train) (void)hipFree(s->d_train);
   delete s;
 }
 

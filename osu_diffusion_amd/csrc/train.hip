@@ -1,0 +1,424 @@
+// Training path: backward of the DiT forward (hand-written autograd of models.py:306-325),
+// the fused diffusion loss (gaussian_diffusion.py:785-874 + :735-783, diffusion_utils.py:9-89),
+// q_sample (:231-247) and the AdamW + EMA update (train.py:161,258-261, update_ema :36-45).
+//
+// Every matrix product of the backward pass runs through the same MFMA tile kernel as the
+// forward (gemm.hip): data gradients use transposed weight copies made at pack time, weight
+// gradients use transposed activation / gradient copies produced by one fused
+// transpose+column-sum pass (the column sums are the bias gradients).
+#include <math.h>
+#include <stdlib.h>
+
+#include "dit.h"
+
+#pragma clang fp contract(off)
+
+struct osud_sched;
+namespace osud {
+const float* sched_train_coefs(const osud_sched* s);
+int sched_upload_train(osud_sched* s);
+}  // namespace osud
+
+namespace osud {
+
+namespace {
+
+// transposed weight copies ([in][out]) for the data-gradient products
+int build_transposed(osud_dit* m, hipStream_t st) {
+  if (m->transposed_ready) return OSUD_OK;
+  const int D = m->D, prec = m->prec;
+  const size_t es = m->esz;
+  auto T_ = [&](void* src, int R, int C, void** dst) -> int {
+    if (!*dst) OSUD_TRY(dev_alloc(m->owned, dst, (size_t)R * C * es, false));
+    return launch_transpose(prec, src, C, *dst, R, R, C, nullptr, st);
+  };
+  for (auto& b : m->blk) {
+    OSUD_TRY(T_(b.w_qkv, 3 * D, D, &b.w_qkv_t));
+    OSUD_TRY(T_(b.w_o, D, D, &b.w_o_t));
+    OSUD_TRY(T_(b.w1, 4 * D, D, &b.w1_t));
+    OSUD_TRY(T_(b.w2, D, 4 * D, &b.w2_t));
+  }
+  OSUD_TRY(T_(m->w_ada, m->ada_cols, D, &m->w_ada_t));
+  OSUD_TRY(T_(m->w_t2, D, D, &m->w_t2_t));
+  m->transposed_ready = true;
+  return OSUD_OK;
+}
+
+// OSUD_DEBUG_SYNC=1: synchronise after every stage of the backward pass and name it (fault triage)
+int dbg_sync(hipStream_t st, const char* stage) {
+  static const bool on = [] { const char* e = getenv("OSUD_DEBUG_SYNC"); return e && e[0] == '1'; }();
+  if (!on) return OSUD_OK;
+  fprintf(stderr, "[osud] %s ...", stage);
+  fflush(stderr);
+  const hipError_t e = hipStreamSynchronize(st);
+  fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e));
+  fflush(stderr);
+  return e == hipSuccess ? OSUD_OK : hip_fail(e, stage, __FILE__, __LINE__);
+}
+
+float* grad_of(osud_dit* m, const std::string& key) {
+  auto it = m->grad.find(key);
+  return it == m->grad.end() ? nullptr : it->second;
+}
+
+}  // namespace
+
+int dit_backward_impl(osud_dit* m, const float* dout, hipStream_t st) {
+  OSUD_CHECK_ARG(m && dout, "backward: null argument");
+  OSUD_CHECK_ARG(m->training && m->last_N > 0, "backward: no training forward to differentiate");
+  const int N = m->last_N, T = m->last_T, D = m->D, L = m->L, prec = m->prec, AC = m->ada_cols;
+  const int Tp = round_up(T, 64), M = N * Tp, Mp = round_up(M, 128), Np = round_up(N, 128);
+  OSUD_CHECK_ARG(T == Tp && M == Mp, "training needs seq_len %% 64 == 0 and batch*seq_len %% 128 == 0 (got N=%d, T=%d)", N, T);
+  for (auto& kv : m->have)
+    if (kv.first != "xoc_embedder.playfield_size" && !grad_of(m, kv.first)) {
+      set_error("backward: no gradient buffer bound for '%s'", kv.first.c_str());
+      return OSUD_ERR_STATE;
+    }
+  OSUD_TRY(build_transposed(m, st));
+  BwdWs& w = m->bw;
+  const size_t es = m->esz;
+  auto zero = [&](void* p, size_t bytes) -> int {
+    OSUD_HIP(hipMemsetAsync(p, 0, bytes, st));
+    return OSUD_OK;
+  };
+  auto G = [&](const std::string& k) { return grad_of(m, k); };
+
+  // ---- accumulators that are filled by atomics
+  OSUD_TRY(zero(w.dada, (size_t)Np * AC * 4));
+  OSUD_TRY(zero(G("final_layer.linear.weight"), (size_t)m->C2 * D * 4));
+  OSUD_TRY(zero(G("final_layer.linear.bias"), (size_t)m->C2 * 4));
+  OSUD_TRY(zero(G("y_embedder.embedding_table.weight"), (size_t)m->cfg.table_rows * D * 4));
+
+  // ---- final layer
+  const LayerSaved& fin = m->saved[(size_t)L];
+  float* dh = w.dhA;
+  float* dh_other = w.dhB;
+  OSUD_TRY(launch_final_bwd(fin.h_in, fin.stats1, dout, m->w_f, m->ada, AC, L * 6 * D, L * 6 * D + D, dh, w.dada,
+                            G("final_layer.linear.weight"), G("final_layer.linear.bias"), N, T, Tp, D, m->C2, st));
+    OSUD_TRY(dbg_sync(st, "final_bwd"));
+
+  // ---- blocks, last to first
+  for (int l = L - 1; l >= 0; --l) {
+    const BlockWeights& bw = m->blk[(size_t)l];
+    const LayerSaved& sv = m->saved[(size_t)l];
+    const std::string p = "blocks." + std::to_string(l) + ".";
+    const int base = l * 6 * D;
+    float *g_b2 = G(p + "mlp.fc2.bias"), *g_b1 = G(p + "mlp.fc1.bias"), *g_bo = G(p + "attn.out_proj.bias"),
+          *g_bqkv = G(p + "attn.in_proj_bias");
+    OSUD_TRY(zero(g_b2, (size_t)D * 4));
+    OSUD_TRY(zero(g_b1, (size_t)4 * D * 4));
+    OSUD_TRY(zero(g_bo, (size_t)D * 4));
+    OSUD_TRY(zero(g_bqkv, (size_t)3 * D * 4));
+    // MLP branch: h_out = h_mid + g2 * (gelu(u2 W1^T + b1) W2^T + b2)
+    OSUD_TRY(launch_gate_bwd(prec, dh, sv.br2, m->ada + base + 5 * D, AC, w.dbr, w.dada + base + 5 * D, M, Tp, D, st));
+    OSUD_TRY(dbg_sync(st, "gate_bwd mlp"));
+    OSUD_TRY(gemm(m, EPI_GELUGRAD_TE, w.dbr, D, bw.w2_t, D, Mp, 4 * D, D, w.dz1, 4 * D, nullptr, st, nullptr, 0, 0, 0,
+                  nullptr, nullptr, sv.z1));
+    OSUD_TRY(dbg_sync(st, "dgrad fc2 (gelu grad)"));
+    OSUD_TRY(launch_transpose(prec, w.dbr, D, w.tB, Mp, Mp, D, g_b2, st));
+    OSUD_TRY(launch_transpose(prec, sv.g, 4 * D, w.tA, Mp, Mp, 4 * D, nullptr, st));
+    OSUD_TRY(gemm(m, EPI_NONE_F32, w.tB, Mp, w.tA, Mp, D, 4 * D, Mp, G(p + "mlp.fc2.weight"), 4 * D, nullptr, st));
+    OSUD_TRY(dbg_sync(st, "wgrad fc2"));
+    OSUD_TRY(gemm(m, EPI_NONE_F32, w.dz1, 4 * D, bw.w1_t, 4 * D, Mp, D, 4 * D, w.du, D, nullptr, st));
+    OSUD_TRY(dbg_sync(st, "dgrad fc1"));
+    OSUD_TRY(launch_transpose(prec, w.dz1, 4 * D, w.tB, Mp, Mp, 4 * D, g_b1, st));
+    OSUD_TRY(launch_transpose(prec, sv.u2, D, w.tA, Mp, Mp, D, nullptr, st));
+    OSUD_TRY(gemm(m, EPI_NONE_F32, w.tB, Mp, w.tA, Mp, 4 * D, D, Mp, G(p + "mlp.fc1.weight"), D, nullptr, st));
+    OSUD_TRY(dbg_sync(st, "wgrad fc1"));
+    OSUD_TRY(launch_ln_mod_bwd(sv.h_mid, sv.stats2, w.du, m->ada, AC, base + 3 * D, base + 4 * D, dh, dh_other, w.dada, M,
+                               Tp, D, st));
+    OSUD_TRY(dbg_sync(st, "ln2 bwd"));
+    std::swap(dh, dh_other);  // dh = grad wrt h_mid
+    // attention branch: h_mid = h_in + g1 * (attn(u1) Wo^T + bo)
+    OSUD_TRY(launch_gate_bwd(prec, dh, sv.br1, m->ada + base + 2 * D, AC, w.dbr, w.dada + base + 2 * D, M, Tp, D, st));
+    OSUD_TRY(dbg_sync(st, "gate_bwd attn"));
+    OSUD_TRY(gemm(m, EPI_NONE_TE, w.dbr, D, bw.w_o_t, D, Mp, D, D, w.dao, D, nullptr, st));
+    OSUD_TRY(launch_transpose(prec, w.dbr, D, w.tB, Mp, Mp, D, g_bo, st));
+    OSUD_TRY(launch_transpose(prec, sv.ao, D, w.tA, Mp, Mp, D, nullptr, st));
+    OSUD_TRY(gemm(m, EPI_NONE_F32, w.tB, Mp, w.tA, Mp, D, D, Mp, G(p + "attn.out_proj.weight"), D, nullptr, st));
+    OSUD_TRY(dbg_sync(st, "wgrad out_proj"));
+    OSUD_TRY(launch_attention_bwd(prec, sv.qk, w.dao, sv.ao, sv.lse, w.dqkv, N, T, m->H, m->hd, st));
+    OSUD_TRY(dbg_sync(st, "attention bwd"));
+    OSUD_TRY(gemm(m, EPI_NONE_F32, w.dqkv, 3 * D, bw.w_qkv_t, 3 * D, Mp, D, 3 * D, w.du, D, nullptr, st));
+    OSUD_TRY(dbg_sync(st, "dgrad qkv"));
+    OSUD_TRY(launch_transpose(prec, w.dqkv, 3 * D, w.tB, Mp, Mp, 3 * D, g_bqkv, st));
+    OSUD_TRY(launch_transpose(prec, sv.u1, D, w.tA, Mp, Mp, D, nullptr, st));
+    OSUD_TRY(gemm(m, EPI_NONE_F32, w.tB, Mp, w.tA, Mp, 3 * D, D, Mp, G(p + "attn.in_proj_weight"), D, nullptr, st));
+    OSUD_TRY(dbg_sync(st, "wgrad qkv"));
+    OSUD_TRY(launch_ln_mod_bwd(sv.h_in, sv.stats1, w.du, m->ada, AC, base, base + D, dh, dh_other, w.dada, M, Tp, D, st));
+    OSUD_TRY(dbg_sync(st, "ln1 bwd"));
+    std::swap(dh, dh_other);  // dh = grad wrt h_in
+  }
+
+  // ---- token embedding linear: h0 = e0 We^T + be   (inputs need no gradient)
+  {
+    float* g_be = G("xoc_embedder.mlp.0.bias");
+    OSUD_TRY(zero(g_be, (size_t)D * 4));
+    OSUD_TRY(launch_transpose_f32(prec, dh, D, w.tB, Mp, Mp, D, g_be, st));
+    OSUD_TRY(launch_transpose(prec, m->e0, m->Kp, w.tA, Mp, Mp, m->Kp, nullptr, st));
+    OSUD_TRY(gemm(m, EPI_NONE_F32, w.tB, Mp, w.tA, Mp, D, m->Kp, Mp, w.dWe, m->Kp, nullptr, st));
+    OSUD_TRY(launch_unpad_rows(w.dWe, m->Kp, G("xoc_embedder.mlp.0.weight"), 384 + m->E, D, st));
+    OSUD_TRY(dbg_sync(st, "first layer"));
+  }
+
+  // ---- conditioning path: ada = silu(b) Wada^T + bada ; b = t_emb + table[y]
+  {
+    char* dada_te = (char*)w.dada_te;
+    char* dada_t = dada_te + (size_t)Np * AC * es;  // [AC][Np]
+    OSUD_TRY(launch_mask_rows(prec, w.dada, dada_te, N, Np, AC, st));
+    OSUD_TRY(zero(w.dbada, (size_t)AC * 4));
+    OSUD_TRY(launch_transpose(prec, dada_te, AC, dada_t, Np, Np, AC, w.dbada, st));
+    OSUD_TRY(launch_transpose(prec, m->sb, D, w.small_t1, Np, Np, D, nullptr, st));  // sb^T [D][Np]
+    OSUD_TRY(gemm(m, EPI_NONE_F32, dada_t, Np, w.small_t1, Np, AC, D, Np, w.dWada, D, nullptr, st));
+    OSUD_TRY(dbg_sync(st, "wgrad ada"));
+    for (int l = 0; l <= L; ++l) {
+      const std::string key = l < L ? "blocks." + std::to_string(l) + ".adaLN_modulation.1." : "final_layer.adaLN_modulation.1.";
+      const size_t rows = l < L ? 6 * (size_t)D : 2 * (size_t)D, off = (size_t)l * 6 * D;
+      OSUD_HIP(hipMemcpyAsync(G(key + "weight"), w.dWada + off * D, rows * D * 4, hipMemcpyDeviceToDevice, st));
+      OSUD_HIP(hipMemcpyAsync(G(key + "bias"), w.dbada + off, rows * 4, hipMemcpyDeviceToDevice, st));
+    }
+    OSUD_TRY(gemm(m, EPI_NONE_F32, dada_te, AC, m->w_ada_t, AC, Np, D, AC, w.dsb, D, nullptr, st));
+    OSUD_TRY(launch_cond_bwd(prec, w.dsb, m->bvec, m->last_y, m->cfg.table_rows, w.db, w.db_te,
+                             G("y_embedder.embedding_table.weight"), N, Np, D, st));
+    OSUD_TRY(dbg_sync(st, "cond bwd"));
+    // TimestepEmbedder: tvec = silu(temb W0^T + b0) W2^T + b2
+    float *g_bt2 = G("t_embedder.mlp.2.bias"), *g_bt0 = G("t_embedder.mlp.0.bias");
+    OSUD_TRY(zero(g_bt2, (size_t)D * 4));
+    OSUD_TRY(zero(g_bt0, (size_t)D * 4));
+    OSUD_TRY(launch_transpose(prec, w.db_te, D, w.small_t1, Np, Np, D, g_bt2, st));  // db^T [D][Np]
+    OSUD_TRY(launch_transpose(prec, m->th, D, w.small_t2, Np, Np, D, nullptr, st));  // th^T [D][Np]
+    OSUD_TRY(gemm(m, EPI_NONE_F32, w.small_t1, Np, w.small_t2, Np, D, D, Np, G("t_embedder.mlp.2.weight"), D, nullptr, st));
+    OSUD_TRY(gemm(m, EPI_NONE_F32, w.db_te, D, m->w_t2_t, D, Np, D, D, w.dth, D, nullptr, st));
+    OSUD_TRY(launch_silu_bwd(prec, w.dth, m->z0, w.dz0, (size_t)Np * D, st));
+    OSUD_TRY(launch_transpose(prec, w.dz0, D, w.small_t1, Np, Np, D, g_bt0, st));       // dz0^T [D][Np]
+    OSUD_TRY(launch_transpose(prec, m->temb, 256, w.small_t2, Np, Np, 256, nullptr, st));  // temb^T [256][Np]
+    OSUD_TRY(gemm(m, EPI_NONE_F32, w.small_t1, Np, w.small_t2, Np, D, 256, Np, G("t_embedder.mlp.0.weight"), 256, nullptr, st));
+    OSUD_TRY(dbg_sync(st, "t-embedder"));
+  }
+  return OSUD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+namespace {
+
+// x_t = sqrt(ac_t) x0 + sqrt(1 - ac_t) noise        (gaussian_diffusion.py:231-247)
+__global__ void q_sample_kernel(const float* __restrict__ tc, const float* __restrict__ x0, const int64_t* __restrict__ t,
+                                const float* __restrict__ noise, float* __restrict__ xt, int N, int CT) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * CT) return;
+  const float* c = tc + (size_t)t[i / CT] * 8;
+  xt[i] = c[0] * x0[i] + c[1] * noise[i];
+}
+
+__device__ __forceinline__ float approx_cdf(float v) {  // diffusion_utils.py:38-43
+  return 0.5f * (1.0f + tanhf(0.7978845608028654f * (v + 0.044715f * (v * v * v))));
+}
+__device__ __forceinline__ float approx_cdf_grad(float v) {
+  const float th = tanhf(0.7978845608028654f * (v + 0.044715f * (v * v * v)));
+  return 0.5f * (1.0f - th * th) * 0.7978845608028654f * (1.0f + 3.0f * 0.044715f * v * v);
+}
+
+// One block per sample.  terms[0][n] = main (l1 | mse), terms[1][n] = vb, terms[2][n] = loss;
+// dout[n] = d(mean_n loss)/d(model_out[n]).  The vb term sees eps DETACHED (gaussian_diffusion.py:833),
+// so channels 0:2 get only the l1/mse gradient and channels 2:4 only the vb gradient.
+__global__ __launch_bounds__(256) void train_loss_kernel(const float* __restrict__ tc, int use_l1,
+                                                         const float* __restrict__ out, const float* __restrict__ x0,
+                                                         const float* __restrict__ xt, const float* __restrict__ noise,
+                                                         const int64_t* __restrict__ t, float* __restrict__ terms,
+                                                         float* __restrict__ dout, int N, int T) {
+  __shared__ float red[2][4];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int CT = 2 * T;
+  const int step = (int)t[n];
+  const float* c = tc + (size_t)step * 8;
+  const float A = c[2], B = c[3], c1 = c[4], c2 = c[5], min_log = c[6], max_log = c[7];
+  const float inv_ln2 = 1.4426950408889634f;
+  const float wgt = 1.0f / ((float)CT * (float)N);  // d(mean over batch of mean_flat)
+  float s_main = 0.f, s_vb = 0.f;
+  for (int i = tid; i < CT; i += 256) {
+    const int ch = i / T, tt = i % T;
+    const size_t io = ((size_t)n * 4 + ch) * T + tt, iv = ((size_t)n * 4 + 2 + ch) * T + tt, ix = (size_t)n * CT + i;
+    const float eps = out[io], v = out[iv], x_start = x0[ix], x_t = xt[ix], nz = noise[ix];
+    // main term
+    const float diff = nz - eps;
+    float g_eps;
+    if (use_l1) {
+      s_main += fabsf(diff);
+      g_eps = diff > 0.f ? -1.0f : (diff < 0.f ? 1.0f : 0.0f);
+    } else {
+      s_main += diff * diff;
+      g_eps = -2.0f * diff;
+    }
+    dout[io] = g_eps * wgt;
+    // vb term (p_mean_variance with clip_denoised=False on the frozen eps)
+    const float frac = (v + 1.0f) / 2.0f;
+    const float lv = frac * max_log + (1.0f - frac) * min_log;
+    const float xs = A * x_t - B * eps;
+    const float mean = c1 * xs + c2 * x_t;
+    const float true_mean = c1 * x_start + c2 * x_t;
+    float term, g_lv;
+    if (step == 0) {  // decoder NLL, discretized Gaussian (diffusion_utils.py:63-89)
+      const float ls = 0.5f * lv;
+      const float cx = x_start - mean;
+      const float inv = expf(-ls);
+      const float pin = inv * (cx + 1.0f / 255.0f), nin = inv * (cx - 1.0f / 255.0f);
+      const float cp = approx_cdf(pin), cm = approx_cdf(nin);
+      float lp, g_ls;  // d lp / d ls ; d pin/d ls = -pin, d nin/d ls = -nin
+      if (x_start < -0.999f) {
+        lp = logf(fmaxf(cp, 1e-12f));
+        g_ls = cp > 1e-12f ? approx_cdf_grad(pin) * (-pin) / cp : 0.f;
+      } else if (x_start > 0.999f) {
+        const float om = 1.0f - cm;
+        lp = logf(fmaxf(om, 1e-12f));
+        g_ls = om > 1e-12f ? -approx_cdf_grad(nin) * (-nin) / om : 0.f;
+      } else {
+        const float dl = cp - cm;
+        lp = logf(fmaxf(dl, 1e-12f));
+        g_ls = dl > 1e-12f ? (approx_cdf_grad(pin) * (-pin) - approx_cdf_grad(nin) * (-nin)) / dl : 0.f;
+      }
+      term = -lp;
+      g_lv = -g_ls * 0.5f;
+    } else {  // KL(q(x_{t-1}|x_t,x_0) || p)   (diffusion_utils.py:9-35)
+      const float dm = true_mean - mean;
+      const float e1 = expf(min_log - lv), e2 = expf(-lv);
+      term = 0.5f * (-1.0f + lv - min_log + e1 + (dm * dm) * e2);
+      g_lv = 0.5f * (1.0f - e1 - (dm * dm) * e2);
+    }
+    s_vb += term;
+    dout[iv] = g_lv * 0.5f * (max_log - min_log) * inv_ln2 * wgt;
+  }
+  s_main = wave_sum(s_main);
+  s_vb = wave_sum(s_vb);
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = s_main;
+    red[1][tid >> 6] = s_vb;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const float mainv = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)CT;
+    const float vb = (red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)CT * inv_ln2;
+    terms[n] = mainv;
+    terms[N + n] = vb;
+    terms[2 * N + n] = mainv + vb;
+  }
+}
+
+// AdamW (torch.optim.AdamW semantics, decoupled weight decay) + EMA in one pass over flat arenas.
+// Elements in [skip_begin, skip_end) (the frozen playfield_size parameter) get only the EMA update.
+__global__ void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1,
+                                 float* __restrict__ m2, float* __restrict__ ema, size_t n, float lr, float beta1,
+                                 float beta2, float eps, float wd, float bc1, float bc2_sqrt, float decay,
+                                 size_t skip_begin, size_t skip_end, float grad_scale) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float pv = p[i];
+    if (i < skip_begin || i >= skip_end) {
+      const float gv = g[i] * grad_scale;
+      pv = pv * (1.0f - lr * wd);
+      const float a = m1[i] * beta1 + (1.0f - beta1) * gv;  // exp_avg.lerp_(grad, 1 - beta1)
+      const float b = m2[i] * beta2 + (1.0f - beta2) * gv * gv;
+      m1[i] = a;
+      m2[i] = b;
+      const float denom = sqrtf(b) / bc2_sqrt + eps;
+      pv = pv - (lr / bc1) * (a / denom);
+      p[i] = pv;
+    }
+    if (ema != nullptr) ema[i] = ema[i] * decay + pv * (1.0f - decay);  // update_ema, train.py:36-45
+  }
+}
+
+}  // namespace
+}  // namespace osud
+
+using namespace osud;
+
+// ------------------------------------------------------------------------------- C ABI
+extern "C" int osud_dit_bind_grad(osud_dit* m, const char* key, float* grad_f32) {
+  OSUD_CHECK_ARG(m && key && grad_f32, "bind_grad: null argument");
+  OSUD_CHECK_ARG(m->have.count(key) != 0, "bind_grad: unknown parameter '%s'", key);
+  m->grad[key] = grad_f32;
+  return OSUD_OK;
+}
+
+extern "C" int osud_dit_refresh(osud_dit* m, osud_stream stream) {
+  OSUD_CHECK_ARG(m, "refresh: null handle");
+  // re-pack every parameter from the caller's fp32 master (after an optimizer step)
+  std::vector<std::pair<std::string, const float*>> items(m->master.begin(), m->master.end());
+  for (auto& kv : items) {
+    int64_t shape[2];
+    int nd = 0;
+    const int64_t D = m->D;
+    const std::string& k = kv.first;
+    auto ends = [&](const char* s) { const std::string e(s); return k.size() >= e.size() && k.compare(k.size() - e.size(), e.size(), e) == 0; };
+    if (k == "xoc_embedder.playfield_size") continue;
+    else if (k == "xoc_embedder.mlp.0.weight") { shape[0] = D; shape[1] = 384 + m->E; nd = 2; }
+    else if (k == "t_embedder.mlp.0.weight") { shape[0] = D; shape[1] = 256; nd = 2; }
+    else if (k == "t_embedder.mlp.2.weight") { shape[0] = D; shape[1] = D; nd = 2; }
+    else if (k == "y_embedder.embedding_table.weight") { shape[0] = m->cfg.table_rows; shape[1] = D; nd = 2; }
+    else if (k == "final_layer.linear.weight") { shape[0] = m->C2; shape[1] = D; nd = 2; }
+    else if (k == "final_layer.linear.bias") { shape[0] = m->C2; nd = 1; }
+    else if (k == "final_layer.adaLN_modulation.1.weight") { shape[0] = 2 * D; shape[1] = D; nd = 2; }
+    else if (k == "final_layer.adaLN_modulation.1.bias") { shape[0] = 2 * D; nd = 1; }
+    else if (ends("attn.in_proj_weight")) { shape[0] = 3 * D; shape[1] = D; nd = 2; }
+    else if (ends("attn.in_proj_bias")) { shape[0] = 3 * D; nd = 1; }
+    else if (ends("attn.out_proj.weight")) { shape[0] = D; shape[1] = D; nd = 2; }
+    else if (ends("mlp.fc1.weight")) { shape[0] = 4 * D; shape[1] = D; nd = 2; }
+    else if (ends("mlp.fc1.bias")) { shape[0] = 4 * D; nd = 1; }
+    else if (ends("mlp.fc2.weight")) { shape[0] = D; shape[1] = 4 * D; nd = 2; }
+    else if (ends("adaLN_modulation.1.weight")) { shape[0] = 6 * D; shape[1] = D; nd = 2; }
+    else if (ends("adaLN_modulation.1.bias")) { shape[0] = 6 * D; nd = 1; }
+    else { shape[0] = D; nd = 1; }  // every remaining bias is (D,)
+    OSUD_TRY(osud_dit_set_param(m, k.c_str(), kv.second, shape, nd, stream));
+  }
+  if (m->training) OSUD_TRY(build_transposed(m, (hipStream_t)stream));
+  return OSUD_OK;
+}
+
+extern "C" int osud_dit_forward_train(osud_dit* m, const float* x, const int64_t* t, const float* o, const float* c,
+                                      const int64_t* y, int N, int T, float* out, osud_stream stream) {
+  OSUD_CHECK_ARG(m, "forward_train: null handle");
+  OSUD_CHECK_ARG(T % 64 == 0 && (N * T) % 128 == 0,
+                 "training needs seq_len %% 64 == 0 and batch*seq_len %% 128 == 0 (got N=%d, T=%d)", N, T);
+  OSUD_TRY(dit_ensure_ws(m, N, T, true));
+  return dit_forward_impl(m, x, t, o, c, y, nullptr, N, T, -1.0f, false, out, true, (hipStream_t)stream);
+}
+
+extern "C" int osud_dit_backward(osud_dit* m, const float* dout, osud_stream stream) {
+  return dit_backward_impl(m, dout, (hipStream_t)stream);
+}
+
+extern "C" int osud_q_sample(const osud_sched* s, const float* x_start, const int64_t* t, const float* noise, int N,
+                             int T, float* x_t, osud_stream stream) {
+  OSUD_CHECK_ARG(s && x_start && t && noise && x_t && N > 0 && T > 0, "q_sample: null/empty argument");
+  OSUD_TRY(sched_upload_train(const_cast<osud_sched*>(s)));
+  const int total = N * 2 * T;
+  hipLaunchKernelGGL(q_sample_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, sched_train_coefs(s),
+                     x_start, t, noise, x_t, N, 2 * T);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+extern "C" int osud_train_loss(const osud_sched* s, int use_l1, const float* model_out, const float* x_start,
+                               const float* x_t, const float* noise, const int64_t* t, int N, int T, float* terms,
+                               float* dout, osud_stream stream) {
+  OSUD_CHECK_ARG(s && model_out && x_start && x_t && noise && t && terms && dout && N > 0 && T > 0,
+                 "train_loss: null/empty argument");
+  OSUD_TRY(sched_upload_train(const_cast<osud_sched*>(s)));
+  hipLaunchKernelGGL(train_loss_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, sched_train_coefs(s), use_l1, model_out,
+                     x_start, x_t, noise, t, terms, dout, N, T);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+extern "C" int osud_adamw_ema_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema,
+                                   size_t n, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                   float ema_decay, size_t skip_begin, size_t skip_end, float grad_scale,
+                                   osud_stream stream) {
+  OSUD_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adamw_ema_step: bad argument");
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+  const int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
+                     ema, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, ema_decay, skip_begin, skip_end, grad_scale);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}

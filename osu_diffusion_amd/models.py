@@ -197,7 +197,8 @@ class DiT(nn.Module):
 
     def __getstate__(self):  # deepcopy (EMA copy, train.py:147) / pickling: never share a native handle
         state = self.__dict__.copy()
-        state.update(_handle=None, _handle_key=None, _uploaded={}, _grad_ctx=None)
+        state.update(_handle=None, _handle_key=None, _uploaded={}, _grad_ctx=None, _arena=None, _arena_bound=None,
+                     _train_keep=None)
         return state
 
     def _apply(self, fn, *a, **k):  # .to()/.cuda() moves storage: packed copies are stale

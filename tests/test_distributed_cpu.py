@@ -1,0 +1,62 @@
+"""CPU, world_size 2 over gloo: the N > 1 pieces of the training path that do not need a GPU — the
+per-rank data sharding rule (train.py:165-170, data_loading.py:366-376) and the flat-arena gradient
+averaging that replaces DDP's bucketed all-reduce (train.py:152,257)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from osu_diffusion_amd.training import allreduce_mean_, shard_range, worker_range
+
+
+def test_shard_rules():
+    assert [shard_range(0, 13402, r, 8) for r in (0, 1, 7)] == [(0, 1676), (1676, 3352), (11732, 13402)]
+    got = [shard_range(5, 105, r, 3) for r in range(3)]
+    assert got[0][0] == 5 and got[-1][1] == 105 and all(a[1] == b[0] for a, b in zip(got, got[1:]))
+    assert [worker_range(0, 10, w, 4) for w in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(100 + rank)  # ranks are seeded differently (train.py:113-114)
+        flat = torch.randn(1000)
+        local = flat.clone()
+        scale = allreduce_mean_(flat)
+        gathered = [torch.empty(1000) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        want = torch.stack(gathered).sum(0)
+        ok = bool(torch.allclose(flat, want)) and abs(scale - 1.0 / world) < 1e-12
+        # init broadcast (DDP ctor): rank 0's parameters win
+        params = torch.full((8,), float(rank))
+        dist.broadcast(params, 0)
+        ok = ok and bool((params == 0).all())
+        out[rank] = ok
+    finally:
+        dist.destroy_process_group()
+
+
+def test_allreduce_mean_two_ranks_gloo():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
+def test_allreduce_mean_without_process_group_is_identity():
+    t = torch.ones(4)
+    assert allreduce_mean_(t) == 1.0 and torch.equal(t, torch.ones(4))
