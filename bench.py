@@ -7,6 +7,13 @@ N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ... ben
 (one rank per GPU).  Prints ONE JSON line on rank 0 (contract in the task description; DESIGN.md §5
 says how each number is obtained).
 
+mode train (BASELINE.json configs[1], the configuration the headline metric is quoted on): DiT-B,
+  seq-len 128, per-GPU batch 256 synthetic windows, bf16 MFMA tier, one "step" = everything in the
+  reference's train.py:243-261 — randint t, randn noise, label dropout, q_sample, forward, L1+vb loss,
+  backward, gradient all-reduce (RCCL, N > 1), AdamW, EMA, re-pack of the bf16 weight copies.  Weak
+  scaling: the per-GPU batch is fixed, global batch = 256 * N.
+mode both (default): the train line above as the primary metric plus a "sampling" object holding the
+  sampling measurement below.
 mode sample (BASELINE.json configs[3]): DiT-B, 64 synthetic beatmap windows of 128 tokens doubled
   for classifier-free guidance (batch 128), cfg-scale 4.0, the 1000-step squaredcos schedule.  A
   "step" is one sampling step = forward_with_cfg + the p_sample update; K steps starting at t=999
@@ -14,8 +21,8 @@ mode sample (BASELINE.json configs[3]): DiT-B, 64 synthetic beatmap windows of 1
   Sampling shards by rows with no collective: every rank runs its own 64 windows (weak scaling).
 """
 import argparse
-import ctypes
 import json
+import math
 import os
 import sys
 import time
@@ -28,6 +35,7 @@ if ROOT not in sys.path:
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
 FLOP_PER_TOKEN_FWD = 176.10e6  # DiT-B, T=128
+FLOP_PER_TOKEN_TRAIN = 528.3e6  # forward + backward = 3x forward
 
 
 def parse():
@@ -35,7 +43,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--mode", choices=["sample", "train"], default=os.environ.get("OSUD_BENCH_MODE", "sample"))
+    ap.add_argument("--mode", choices=["both", "sample", "train"], default=os.environ.get("OSUD_BENCH_MODE", "both"))
+    ap.add_argument("--batch", type=int, default=256, help="training windows per GPU")
+    ap.add_argument("--sample-steps", type=int, default=None, help="timed sampling steps in mode both (default 1000)")
     ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--maps", type=int, default=64, help="beatmap windows per GPU (CFG doubles the batch)")
     ap.add_argument("--seq-len", type=int, default=128)
@@ -142,6 +152,102 @@ def cpu_baseline_sample(model, args, windows, steps=2):
             "sample": f"{steps} p_sample steps (t=999..) of the same workload, fp32 torch-CPU oracle, {dt:.1f} s"}
 
 
+def cpu_baseline_train(model, args, batch, steps=1, cpu_batch=32):
+    """Oracle training step (fp32 torch-CPU restatement + autograd + torch AdamW + EMA) on a bounded
+    sample: `steps` steps at batch `cpu_batch` x seq_len (the GPU step uses batch 256)."""
+    from oracle import diffusion_oracle as do
+    from oracle import dit_oracle as mo
+
+    (x, o, c), y = batch
+    x, o, c, y = x[:cpu_batch].cpu(), o[:cpu_batch].cpu(), c[:cpu_batch].cpu(), y[:cpu_batch].cpu()
+    cores = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    shape = mo.shape_of(args.model, num_classes=model.y_embedder.num_classes)
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(k != "xoc_embedder.playfield_size")
+          for k, v in model.state_dict().items()}
+    ema = {k: v.detach().clone() for k, v in sd.items()}
+    opt = torch.optim.AdamW([v for v in sd.values() if v.requires_grad], lr=1e-4, weight_decay=0)
+    sch = do.create_schedule("", "squaredcos_cap_v2")
+    T = x.shape[2]
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t = torch.randint(0, 1000, (cpu_batch,))
+        drop = torch.rand(cpu_batch) < 0.2
+        fn = lambda xx, tt: mo.forward(sd, shape, xx, tt, o, c, y, drop_mask=drop)  # noqa: E731
+        terms = do.training_losses(sch, fn, x, t, torch.randn_like(x), loss="l1")
+        terms["loss"].mean().backward()
+        opt.step()
+        opt.zero_grad(set_to_none=True)
+        with torch.no_grad():
+            for k in ema:
+                ema[k].mul_(0.9999).add_(sd[k].detach(), alpha=1e-4)
+    dt = time.perf_counter() - t0
+    return {"value": round(steps * cpu_batch * T / dt, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} full training step(s) at batch {cpu_batch} x {T} tokens (GPU: batch {len(batch[1])}), fp32 "
+                      f"torch-CPU oracle + autograd + AdamW + EMA, {dt:.1f} s"}
+
+
+def bench_train(args, world, rank, dev):
+    from osu_diffusion_amd.diffusion import create_diffusion
+    from osu_diffusion_amd.models import DiT_models
+    from osu_diffusion_amd.synthetic import randomize_zero_init, synthetic_windows
+    from osu_diffusion_amd.training import NativeTrainer
+
+    K = args.steps if args.steps is not None else 40
+    W = args.warmup if args.warmup is not None else 8
+    num_classes = 52670
+    seed = 0 * world + rank  # train.py:113: global_seed * world_size + rank
+    torch.manual_seed(seed)
+    model = DiT_models[args.model](num_classes=num_classes, context_size=19 - 3 + 128, class_dropout_prob=0.2,
+                                   precision=args.precision)
+    model = randomize_zero_init(model.to(dev), seed=0).train()  # train(): label dropout on (train.py:199)
+    diffusion = create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True)  # train.py defaults
+    B, T = args.batch, args.seq_len
+    batches = []
+    for i in range(4):  # a few distinct resident batches, cycled
+        (x, o, c), y = synthetic_windows(B, T, num_classes, seed=10_000 * rank + i, train_offsets=True)
+        batches.append(((x.to(dev), o.to(dev), c.to(dev)), y.to(dev)))
+    trainer = NativeTrainer(model, diffusion, lr=1e-4)
+    terms = None
+    for i in range(W):
+        (x, o, c), y = batches[i % 4]
+        terms = trainer.step(x, o, c, y)
+    barrier(world)
+    t0 = time.perf_counter()
+    for i in range(K):
+        (x, o, c), y = batches[i % 4]
+        terms = trainer.step(x, o, c, y)
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world, dev)
+    loss = float(terms[2].mean())
+    assert math.isfinite(loss), "non-finite training loss"
+    tokens_per_s = world * B * T * K / dt
+    res = {
+        "metric": "DiT-B seq128 train tokens/sec (whole job; per-GPU = value / n_gpus)", "value": round(tokens_per_s, 1),
+        "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
+        "config": {"workload": f"train.py step: {args.model} seq-len {T}, per-GPU batch {B} synthetic windows (global {B * world}), "
+                               f"L1+vb loss, AdamW lr 1e-4, EMA 0.9999, label dropout 0.2, squaredcos_cap_v2 1000 steps",
+                   "per_gpu_batch": B, "global_batch": B * world, "seq_len": T,
+                   "parallelism": f"dp{world}: flat fp32 gradient arena, one RCCL all-reduce per step" if world > 1 else "single GPU",
+                   "last_loss": round(loss, 4)},
+        "per_gpu_tokens_per_s": round(tokens_per_s / world, 1),
+    }
+    if args.model == "DiT-B" and T == 128:
+        per_gpu = tokens_per_s / world
+        res["end_to_end"] = {"flop_per_token": FLOP_PER_TOKEN_TRAIN, "achieved_tflops_per_gpu": round(per_gpu * FLOP_PER_TOKEN_TRAIN / 1e12, 1),
+                             "mfma_frac": round(per_gpu * FLOP_PER_TOKEN_TRAIN / 1e12 / PEAK_BF16_TFLOPS, 4)}
+    if rank == 0 and not args.no_roofline and args.precision == "bf16":
+        D = model.hidden_size
+        res["roofline"] = gemm_roofline(B * T, 4 * D, D, dev)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_train(model, args, batches[0])
+    del trainer, model
+    torch.cuda.empty_cache()
+    return res
+
+
 def bench_sample(args, world, rank, dev):
     from osu_diffusion_amd.diffusion import create_diffusion
     from osu_diffusion_amd.models import DiT_models
@@ -207,11 +313,16 @@ def main():
     world, rank, local = dist_setup(args)
     dev = torch.device("cuda", local if world > 1 else 0)
     if args.mode == "train":
-        from bench_train import bench_train  # added with the training milestone
-
         res = bench_train(args, world, rank, dev)
-    else:
+    elif args.mode == "sample":
         res = bench_sample(args, world, rank, dev)
+    else:
+        res = bench_train(args, world, rank, dev)
+        sargs = argparse.Namespace(**vars(args))
+        sargs.steps, sargs.warmup = args.sample_steps, None
+        samp = bench_sample(sargs, world, rank, dev)
+        res["sampling"] = {k: samp[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "end_to_end",
+                                                "roofline", "cpu_baseline") if k in samp}
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

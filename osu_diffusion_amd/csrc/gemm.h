@@ -49,8 +49,12 @@ struct GemmP {
   int n_samples;
   const void* aux;   // TE [My][ldo] (EPI_GELUGRAD_TE: saved pre-activation)
   const float* res;  // EPI_GATE_RES: residual input [My][ldo]; nullptr = update `out` in place
+  int split_k;       // > 1: blockIdx.y walks K in split_k equal ranges, range s writes out + s * split_stride (elements)
+  size_t split_stride;
 };
 
 int launch_gemm(int prec, int epi, const GemmP& p, hipStream_t st);
+// out[i] = sum_s part[s * stride + i], i < n (n % 4 == 0): deterministic split-K combine
+int launch_splitk_reduce(const float* part, int splits, size_t stride, float* out, size_t n, hipStream_t st);
 
 }  // namespace osud

@@ -1,35 +1,22 @@
 // See gemm.h for the design.  gfx950 only.
 #include "gemm.h"
 
+#include <stdlib.h>
+
 namespace osud {
 
 namespace {
 
-constexpr int BM = 128, BN = 128, SLAB = 128;  // SLAB in bytes along K
-constexpr int TILE_BYTES = BM * SLAB;          // 16 KiB per operand per buffer
+constexpr int SLAB = 128;  // bytes of K per pipeline stage row
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
-
-// HBM -> LDS, one 128-row x 128-byte operand slab, 4 x 1 KiB pieces per wave.
-__device__ __forceinline__ void stage_tile(const char* gsrc, size_t ld_bytes, char* lds_tile, int wave, int lane) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int r0 = 32 * wave + 8 * q;        // wave-uniform
-    const int R = r0 + (lane >> 3);          // this lane's row
-    const int c = (lane & 7) ^ ((R >> 1) & 7);  // source chunk for LDS position lane&7
-    const char* g = gsrc + (size_t)R * ld_bytes + c * 16;
-    char* dst = lds_tile + __builtin_amdgcn_readfirstlane(r0 * SLAB);
-    __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)dst, 16, 0, 0);
-  }
-}
-
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // Fragment reads are inline asm on purpose: hipcc cannot prove that a compiler-visible
-// ds_read does not alias the in-flight LDS-DMA of the NEXT slab and would put
+// ds_read does not alias the in-flight LDS-DMA of later slabs and would put
 // `s_waitcnt vmcnt(0)` in front of every read, serialising load and MFMA.  The asm reads are
-// ordered by the explicit vmcnt(0)+barrier at the top of each slab and by counted lgkmcnt.
+// ordered by the counted vmcnt + barrier at the top of each slab and by counted lgkmcnt.
 template <int OFF> __device__ __forceinline__ u32x4 ds_read16(uint32_t addr) {
   u32x4 v;
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
@@ -47,20 +34,24 @@ template <> __device__ __forceinline__ void mma<float>(f32x16& acc, const u32x4&
   for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[j], acc, 0, 0, 0);
 }
 
-struct FragSet {
-  u32x4 y[2], x[2];
+// Per-wave register block: (RY x 32) rows of Y by 64 rows of X -> RY x 2 MFMA 32x32 accumulators.
+template <int RY> struct FragSet {
+  u32x4 y[RY], x[2];
 };
-// ya/xa: this lane's LDS byte address of (first Y / X row of the wave, k-substep s) in buffer 0
-template <int BUF> __device__ __forceinline__ void read_set(FragSet& f, uint32_t ya, uint32_t xa) {
-  constexpr int B = BUF * 2 * TILE_BYTES;
-  f.y[0] = ds_read16<B>(ya);
-  f.y[1] = ds_read16<B + 32 * SLAB>(ya);
-  f.x[0] = ds_read16<B + TILE_BYTES>(xa);
-  f.x[1] = ds_read16<B + TILE_BYTES + 32 * SLAB>(xa);
+// ya/xa: this lane's LDS byte address of (first Y / X row of the wave, k-substep s) in the current stage
+template <int RY> __device__ __forceinline__ void read_set(FragSet<RY>& f, uint32_t ya, uint32_t xa) {
+  f.y[0] = ds_read16<0>(ya);
+  f.y[1] = ds_read16<32 * SLAB>(ya);
+  if constexpr (RY == 4) {
+    f.y[2] = ds_read16<64 * SLAB>(ya);
+    f.y[3] = ds_read16<96 * SLAB>(ya);
+  }
+  f.x[0] = ds_read16<0>(xa);
+  f.x[1] = ds_read16<32 * SLAB>(xa);
 }
-template <typename TE> __device__ __forceinline__ void mma_set(f32x16 (&acc)[2][2], const FragSet& f) {
+template <typename TE, int RY> __device__ __forceinline__ void mma_set(f32x16 (&acc)[RY][2], const FragSet<RY>& f) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RY; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) mma<TE>(acc[i][j], f.x[j], f.y[i]);
 }
@@ -68,183 +59,299 @@ template <typename TE> __device__ __forceinline__ void mma_set(f32x16 (&acc)[2][
   asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
   __builtin_amdgcn_sched_barrier(0)
 
-// One 128-byte K slab from LDS buffer BUF: 4 sub-steps, reads of sub-step s+1 in flight under
-// the MFMAs of sub-step s (LDS returns in order, so lgkmcnt(4) == "all but the newest 4").
-template <typename TE, int BUF>
-__device__ __forceinline__ void compute_slab(f32x16 (&acc)[2][2], const uint32_t (&ya)[4], const uint32_t (&xa)[4]) {
-  FragSet f0, f1;
-  read_set<BUF>(f0, ya[0], xa[0]);
-  read_set<BUF>(f1, ya[1], xa[1]);
-  OSUD_LGKM_WAIT(4);
-  mma_set<TE>(acc, f0);
-  read_set<BUF>(f0, ya[2], xa[2]);
-  OSUD_LGKM_WAIT(4);
-  mma_set<TE>(acc, f1);
-  read_set<BUF>(f1, ya[3], xa[3]);
-  OSUD_LGKM_WAIT(4);
-  mma_set<TE>(acc, f0);
+// One 128-byte K slab from the LDS stage at byte offset `so`: 4 sub-steps, reads of sub-step s+1 in
+// flight under the MFMAs of sub-step s (LDS returns in order, so lgkmcnt(R) == "all but the newest R").
+template <typename TE, int RY>
+__device__ __forceinline__ void compute_slab(f32x16 (&acc)[RY][2], const uint32_t (&ya)[4], const uint32_t (&xa)[4],
+                                             uint32_t so) {
+  FragSet<RY> f0, f1;
+  read_set<RY>(f0, ya[0] + so, xa[0] + so);
+  read_set<RY>(f1, ya[1] + so, xa[1] + so);
+  if constexpr (RY == 4) { OSUD_LGKM_WAIT(6); } else { OSUD_LGKM_WAIT(4); }
+  mma_set<TE, RY>(acc, f0);
+  read_set<RY>(f0, ya[2] + so, xa[2] + so);
+  if constexpr (RY == 4) { OSUD_LGKM_WAIT(6); } else { OSUD_LGKM_WAIT(4); }
+  mma_set<TE, RY>(acc, f1);
+  read_set<RY>(f1, ya[3] + so, xa[3] + so);
+  if constexpr (RY == 4) { OSUD_LGKM_WAIT(6); } else { OSUD_LGKM_WAIT(4); }
+  mma_set<TE, RY>(acc, f0);
   OSUD_LGKM_WAIT(0);
-  mma_set<TE>(acc, f1);
+  mma_set<TE, RY>(acc, f1);
 }
 
-template <typename TE, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];  // [buf][Y|X]
+// Tile geometry: WY x WX waves, each wave (RY*32) x 64 outputs: BM = WY*RY*32 rows of Y, BN = WX*64 rows of X.
+// A stage holds one K slab of both operands as ONE (BM+BN)-row x 128-byte image.
+template <int WY, int WX, int RY> struct Geo {
+  static constexpr int BM = WY * RY * 32, BN = WX * 64, NW = WY * WX, NT = 64 * NW;
+  static constexpr int STAGE = (BM + BN) * SLAB;
+  static constexpr int NSTAGE = STAGE * 4 <= 144 * 1024 ? 4 : (STAGE * 3 <= 160 * 1024 ? 3 : 2);
+  static constexpr int PIECES = (BM + BN) / 8, PPW = PIECES / NW;  // 1 KiB LDS-DMA pieces per slab, per wave
+  static_assert(PIECES % NW == 0, "pieces must divide evenly over the waves");
+};
+
+// HBM -> LDS: this wave's share of one K slab (PPW pieces of 8 rows x 128 bytes).  The 16-byte chunk index
+// is XOR-swizzled with (row>>1)&7 on the SOURCE side (the LDS side of an LDS-DMA is lane-linear).
+template <typename G>
+__device__ __forceinline__ void stage_slab(const char* gy, size_t ldy_b, const char* gx, size_t ldx_b, char* stage,
+                                           int wave, int lane) {
+#pragma unroll
+  for (int q = 0; q < G::PPW; ++q) {
+    const int piece = wave * G::PPW + q;  // wave-uniform
+    const int R = piece * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((R >> 1) & 7);
+    const char* g = (piece * 8 < G::BM) ? gy + (size_t)R * ldy_b : gx + (size_t)(R - G::BM) * ldx_b;
+    char* dst = stage + __builtin_amdgcn_readfirstlane(piece * 8 * SLAB);
+    __builtin_amdgcn_global_load_lds((glb_void*)(g + c * 16), (lds_void*)dst, 16, 0, 0);
+  }
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+  else static_assert(N < 0, "add the literal");
+}
+
+template <typename TE, int EPI, int WY, int WX, int RY>
+__global__ __launch_bounds__((Geo<WY, WX, RY>::NT)) void gemm_kernel(GemmP p) {
+  using G = Geo<WY, WX, RY>;
+  constexpr int BN = G::BN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool FAST = sizeof(TE) == 2;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wy = wave >> 1, wx = wave & 1;
-
-  // Workgroup -> tile.  Blocks are dispatched round-robin over the 8 XCDs (b % 8); give each
-  // XCD a contiguous run of tiles (x fastest) so its private L2 sees whole Y row-panels.
-  const int ntx = p.Nx / BN, nwg = gridDim.x;
-  int b = blockIdx.x;
-  {
-    const int q = nwg >> 3, r = nwg & 7, xcd = b & 7, idx = b >> 3;
-    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int ty = b / ntx, tx = b % ntx;
-
-  const size_t ldy_b = (size_t)p.ldy * sizeof(TE), ldx_b = (size_t)p.ldx * sizeof(TE);
-  const char* gy = reinterpret_cast<const char*>(p.Y) + (size_t)ty * BM * ldy_b;
-  const char* gx = reinterpret_cast<const char*>(p.X) + (size_t)tx * BN * ldx_b;
-  const int nk = (int)((size_t)p.K * sizeof(TE) / SLAB);
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // per-lane LDS byte addresses of the wave's first Y/X row for the 4 k-substeps (buffer 0)
+  const int wy = wave / WX, wx = wave % WX;
   const int frow = lane & 31, fhalf = lane >> 5;
+
+  const int ntx = p.Nx / BN, ntiles = (p.My / G::BM) * ntx;
+  int nk = (int)((size_t)p.K * sizeof(TE) / SLAB);
+  const size_t ldy_b = (size_t)p.ldy * sizeof(TE), ldx_b = (size_t)p.ldx * sizeof(TE);
+  const char* gy0 = reinterpret_cast<const char*>(p.Y);
+  const char* gx0 = reinterpret_cast<const char*>(p.X);
+  if (p.split_k > 1) {  // this workgroup's share of the contraction
+    nk /= p.split_k;
+    gy0 += (size_t)blockIdx.y * nk * SLAB;
+    gx0 += (size_t)blockIdx.y * nk * SLAB;
+    p.out = reinterpret_cast<char*>(p.out) + (size_t)blockIdx.y * p.split_stride * (EPI == EPI_NONE_F32 ? 4 : sizeof(TE));
+  }
+  // Persistent workgroups: gridDim.x <= #CUs.  Blocks are dispatched round-robin over the 8 XCDs (b % 8);
+  // in every round give each XCD a contiguous run of tiles (x fastest) so its private L2 sees whole panels.
+  const int G8 = gridDim.x;
+  int first;
+  {
+    const int b = blockIdx.x, q = G8 >> 3, r = G8 & 7, xcd = b & 7, idx = b >> 3;
+    first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  auto tile_ptrs = [&](int tile, int kt, const char*& gy, const char*& gx) {
+    const int ty = tile / ntx, tx = tile % ntx;
+    gy = gy0 + (size_t)ty * G::BM * ldy_b + (size_t)kt * SLAB;
+    gx = gx0 + (size_t)tx * BN * ldx_b + (size_t)kt * SLAB;
+  };
+
+  // per-lane LDS byte addresses of the wave's first Y/X row for the 4 k-substeps (stage 0)
   const uint32_t lds0 = (uint32_t)(size_t)(lds_void*)smem;
   uint32_t ya[4], xa[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const uint32_t sw = (uint32_t)(((2 * s + fhalf) ^ ((frow >> 1) & 7)) << 4);
-    ya[s] = lds0 + (wy * 64 + frow) * SLAB + sw;
-    xa[s] = lds0 + (wx * 64 + frow) * SLAB + sw;
+    ya[s] = lds0 + (wy * RY * 32 + frow) * SLAB + sw;
+    xa[s] = lds0 + (G::BM + wx * 64 + frow) * SLAB + sw;
   }
 
-  stage_tile(gy, ldy_b, smem, wave, lane);
-  stage_tile(gx, ldx_b, smem + TILE_BYTES, wave, lane);
-  int kt = 0;
-  for (; kt + 2 <= nk; kt += 2) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // slab kt landed for every wave; buffer 1 is free again
-    stage_tile(gy + (size_t)(kt + 1) * SLAB, ldy_b, smem + 2 * TILE_BYTES, wave, lane);
-    stage_tile(gx + (size_t)(kt + 1) * SLAB, ldx_b, smem + 3 * TILE_BYTES, wave, lane);
-    compute_slab<TE, 0>(acc, ya, xa);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) {
-      stage_tile(gy + (size_t)(kt + 2) * SLAB, ldy_b, smem, wave, lane);
-      stage_tile(gx + (size_t)(kt + 2) * SLAB, ldx_b, smem + TILE_BYTES, wave, lane);
+  // ---- prologue: fill NSTAGE-1 stages
+  int ic_tile = first, ic_kt = 0;  // issue cursor
+  int issued = 0, consumed = 0;
+  auto issue_next = [&]() {
+    if (ic_tile < ntiles) {
+      const char *gy, *gx;
+      tile_ptrs(ic_tile, ic_kt, gy, gx);
+      stage_slab<G>(gy, ldy_b, gx, ldx_b, smem + (issued % G::NSTAGE) * G::STAGE, wave, lane);
+      ++issued;
+      if (++ic_kt == nk) {
+        ic_kt = 0;
+        ic_tile += G8;
+      }
     }
-    compute_slab<TE, 1>(acc, ya, xa);
-  }
-  if (kt < nk) {  // odd slab count: the last slab sits in buffer 0
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    compute_slab<TE, 0>(acc, ya, xa);
-  }
+  };
+#pragma unroll
+  for (int i = 0; i < G::NSTAGE - 1; ++i) issue_next();
+  int landed = 0;  // slabs known to have landed already (waited for before the previous epilogue)
 
-  // ---- epilogue: lane holds, for y = ..+frow, x = xb + 8g + 4*fhalf + {0..3}, g = 0..3 -----
-  // All loads of a batch (bias / gate / residual / aux) are issued BEFORE its stores: on gfx950
-  // vmcnt counts stores too, so a load waited for between stores would drain every earlier store.
-  constexpr bool kBias = EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_TE || EPI == EPI_BIAS_SILU_TE ||
-                         EPI == EPI_BIAS_GELU_TE || EPI == EPI_GATE_RES;
-  float4 bv[2][4];
-  if (kBias) {
+  for (int tile = first; tile < ntiles; tile += G8) {
+    const int ty = tile / ntx, tx = tile % ntx;
+    f32x16 acc[RY][2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        bv[j][g] = *reinterpret_cast<const float4*>(p.bias + tx * BN + wx * 64 + j * 32 + 8 * g + 4 * fhalf);
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int y = ty * BM + wy * 64 + i * 32 + frow;
-    float rb = 0.f;
-    if (EPI == EPI_ROWBIAS_TE) rb = p.bias[y];
-    float4 gv[2][4], rv[2][4];
-    if (EPI == EPI_GATE_RES) {
-      int sample = y / p.rows_per_sample;
-      if (sample >= p.n_samples) sample = p.n_samples - 1;  // padding rows
-      const float* rsrc = p.res ? p.res : reinterpret_cast<const float*>(p.out);
+    for (int i = 0; i < RY; ++i)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+      // slab `consumed` must have landed; up to NSTAGE-2 later slabs may stay in flight (loads return in order)
+      // (stores of an epilogue may sit in the queue too; they only make the counted wait conservative)
+      const int ahead = issued - consumed - 1;
+      if (landed > 0) --landed;
+      else if (ahead <= 0 || G::NSTAGE == 2) wait_vm<0>();
+      else if (ahead == 1) wait_vm<G::PPW>();
+      else wait_vm<(G::NSTAGE > 3 ? 2 * G::PPW : 0)>();
+      __builtin_amdgcn_s_barrier();  // every wave's share landed; the stage consumed last round is free again
+      issue_next();
+      compute_slab<TE, RY>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
+      ++consumed;
+    }
+    // The next tile's first slabs are already in flight: make sure they landed NOW, while no store is
+    // queued behind them, so the next tile can start right after the epilogue without draining its stores.
+    wait_vm<0>();
+    landed = issued - consumed;
+
+    // ---- epilogue: lane holds, for y = ..+frow, x = xb + 8g + 4*fhalf + {0..3}, g = 0..3 -----
+    // All loads of a batch (bias / gate / residual / aux) are issued BEFORE its stores: on gfx950
+    // vmcnt counts stores too, so a load waited for between stores would drain every earlier store.
+    constexpr bool kBias = EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_TE || EPI == EPI_BIAS_SILU_TE ||
+                           EPI == EPI_BIAS_GELU_TE || EPI == EPI_GATE_RES;
+    const int xw = tx * BN + wx * 64 + 4 * fhalf;  // + j*32 + 8*g
+    float4 bv[2][4];
+    if (kBias && EPI != EPI_GATE_RES) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bv[j][g] = *reinterpret_cast<const float4*>(p.bias + xw + j * 32 + 8 * g);
+    }
+#pragma unroll
+    for (int i = 0; i < RY; ++i) {
+      const int y = ty * G::BM + wy * RY * 32 + i * 32 + frow;
+      float rb = 0.f;
+      if (EPI == EPI_ROWBIAS_TE) rb = p.bias[y];
+      float4 gv[2][4], rv[2][4];
+      if (EPI == EPI_GATE_RES) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) bv[j][g] = *reinterpret_cast<const float4*>(p.bias + xw + j * 32 + 8 * g);
+        int sample = y / p.rows_per_sample;
+        if (sample >= p.n_samples) sample = p.n_samples - 1;  // padding rows
+        const float* rsrc = p.res ? p.res : reinterpret_cast<const float*>(p.out);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            gv[j][g] = *reinterpret_cast<const float4*>(p.gate + (size_t)sample * p.ld_gate + xw + j * 32 + 8 * g);
+            rv[j][g] = *reinterpret_cast<const float4*>(rsrc + (size_t)y * p.ldo + xw + j * 32 + 8 * g);
+          }
+      }
+      if (EPI == EPI_ACCUM_F32) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            rv[j][g] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.out) + (size_t)y * p.ldo + xw +
+                                                        j * 32 + 8 * g);
+      }
+      if (EPI == EPI_GELUGRAD_TE) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const TE* a = reinterpret_cast<const TE*>(p.aux) + (size_t)y * p.ldo + xw + j * 32 + 8 * g;
+            rv[j][g] = make_float4(load_elem(a), load_elem(a + 1), load_elem(a + 2), load_elem(a + 3));
+          }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int x = tx * BN + wx * 64 + j * 32 + 8 * g + 4 * fhalf;
-          gv[j][g] = *reinterpret_cast<const float4*>(p.gate + (size_t)sample * p.ld_gate + x);
-          rv[j][g] = *reinterpret_cast<const float4*>(rsrc + (size_t)y * p.ldo + x);
-        }
-    }
-    if (EPI == EPI_ACCUM_F32) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          rv[j][g] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.out) + (size_t)y * p.ldo +
-                                                      tx * BN + wx * 64 + j * 32 + 8 * g + 4 * fhalf);
-    }
-    if (EPI == EPI_GELUGRAD_TE) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const TE* a = reinterpret_cast<const TE*>(p.aux) + (size_t)y * p.ldo + tx * BN + wx * 64 + j * 32 + 8 * g + 4 * fhalf;
-          rv[j][g] = make_float4(load_elem(a), load_elem(a + 1), load_elem(a + 2), load_elem(a + 3));
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int x = tx * BN + wx * 64 + j * 32 + 8 * g + 4 * fhalf;
-        float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2],
-              v3 = acc[i][j][4 * g + 3];
-        if (kBias) { v0 += bv[j][g].x; v1 += bv[j][g].y; v2 += bv[j][g].z; v3 += bv[j][g].w; }
-        if (EPI == EPI_ROWBIAS_TE) { v0 += rb; v1 += rb; v2 += rb; v3 += rb; }
-        const size_t o = (size_t)y * p.ldo + x;
-        if (EPI == EPI_BIAS_F32 || EPI == EPI_NONE_F32) {
-          store4(reinterpret_cast<float*>(p.out) + o, v0, v1, v2, v3);
-        } else if (EPI == EPI_ACCUM_F32) {
-          store4(reinterpret_cast<float*>(p.out) + o, rv[j][g].x + v0, rv[j][g].y + v1, rv[j][g].z + v2,
-                 rv[j][g].w + v3);
-        } else if (EPI == EPI_GATE_RES) {
-          if (p.out2) store4(reinterpret_cast<TE*>(p.out2) + o, v0, v1, v2, v3);  // branch output (training)
-          store4(reinterpret_cast<float*>(p.out) + o, rv[j][g].x + gv[j][g].x * v0, rv[j][g].y + gv[j][g].y * v1,
-                 rv[j][g].z + gv[j][g].z * v2, rv[j][g].w + gv[j][g].w * v3);
-        } else if (EPI == EPI_BIAS_SILU_TE) {
-          if (p.out2) store4(reinterpret_cast<TE*>(p.out2) + o, v0, v1, v2, v3);  // pre-activation (training)
-          store4(reinterpret_cast<TE*>(p.out) + o, silu_t<FAST>(v0), silu_t<FAST>(v1), silu_t<FAST>(v2),
-                 silu_t<FAST>(v3));
-        } else if (EPI == EPI_BIAS_GELU_TE) {
-          if (p.out2) store4(reinterpret_cast<TE*>(p.out2) + o, v0, v1, v2, v3);
-          store4(reinterpret_cast<TE*>(p.out) + o, gelu_tanh_t<FAST>(v0), gelu_tanh_t<FAST>(v1),
-                 gelu_tanh_t<FAST>(v2), gelu_tanh_t<FAST>(v3));
-        } else if (EPI == EPI_GELUGRAD_TE) {
-          store4(reinterpret_cast<TE*>(p.out) + o, v0 * gelu_tanh_grad_t<FAST>(rv[j][g].x),
-                 v1 * gelu_tanh_grad_t<FAST>(rv[j][g].y), v2 * gelu_tanh_grad_t<FAST>(rv[j][g].z),
-                 v3 * gelu_tanh_grad_t<FAST>(rv[j][g].w));
-        } else {  // EPI_BIAS_TE, EPI_ROWBIAS_TE, EPI_NONE_TE
-          store4(reinterpret_cast<TE*>(p.out) + o, v0, v1, v2, v3);
+          const int x = xw + j * 32 + 8 * g;
+          float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2],
+                v3 = acc[i][j][4 * g + 3];
+          if (kBias) { v0 += bv[j][g].x; v1 += bv[j][g].y; v2 += bv[j][g].z; v3 += bv[j][g].w; }
+          if (EPI == EPI_ROWBIAS_TE) { v0 += rb; v1 += rb; v2 += rb; v3 += rb; }
+          const size_t o = (size_t)y * p.ldo + x;
+          if (EPI == EPI_BIAS_F32 || EPI == EPI_NONE_F32) {
+            store4(reinterpret_cast<float*>(p.out) + o, v0, v1, v2, v3);
+          } else if (EPI == EPI_ACCUM_F32) {
+            store4(reinterpret_cast<float*>(p.out) + o, rv[j][g].x + v0, rv[j][g].y + v1, rv[j][g].z + v2,
+                   rv[j][g].w + v3);
+          } else if (EPI == EPI_GATE_RES) {
+            if (p.out2) store4(reinterpret_cast<TE*>(p.out2) + o, v0, v1, v2, v3);  // branch output (training)
+            store4(reinterpret_cast<float*>(p.out) + o, rv[j][g].x + gv[j][g].x * v0, rv[j][g].y + gv[j][g].y * v1,
+                   rv[j][g].z + gv[j][g].z * v2, rv[j][g].w + gv[j][g].w * v3);
+          } else if (EPI == EPI_BIAS_SILU_TE) {
+            if (p.out2) store4(reinterpret_cast<TE*>(p.out2) + o, v0, v1, v2, v3);  // pre-activation (training)
+            store4(reinterpret_cast<TE*>(p.out) + o, silu_t<FAST>(v0), silu_t<FAST>(v1), silu_t<FAST>(v2),
+                   silu_t<FAST>(v3));
+          } else if (EPI == EPI_BIAS_GELU_TE) {
+            if (p.out2) store4(reinterpret_cast<TE*>(p.out2) + o, v0, v1, v2, v3);
+            store4(reinterpret_cast<TE*>(p.out) + o, gelu_tanh_t<FAST>(v0), gelu_tanh_t<FAST>(v1),
+                   gelu_tanh_t<FAST>(v2), gelu_tanh_t<FAST>(v3));
+          } else if (EPI == EPI_GELUGRAD_TE) {
+            store4(reinterpret_cast<TE*>(p.out) + o, v0 * gelu_tanh_grad_t<FAST>(rv[j][g].x),
+                   v1 * gelu_tanh_grad_t<FAST>(rv[j][g].y), v2 * gelu_tanh_grad_t<FAST>(rv[j][g].z),
+                   v3 * gelu_tanh_grad_t<FAST>(rv[j][g].w));
+          } else {  // EPI_BIAS_TE, EPI_ROWBIAS_TE, EPI_NONE_TE
+            store4(reinterpret_cast<TE*>(p.out) + o, v0, v1, v2, v3);
+          }
         }
       }
     }
-  }
+  }  // tile loop
 }
 
-template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
-  const int nwg = (p.My / BM) * (p.Nx / BN);
-  hipLaunchKernelGGL((gemm_kernel<TE, EPI>), dim3(nwg), dim3(256), 0, st, p);
+int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <typename TE, int EPI, int WY, int WX, int RY> int launch_w(const GemmP& p, hipStream_t st) {
+  using G = Geo<WY, WX, RY>;
+  const size_t lds = (size_t)G::NSTAGE * G::STAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int ntiles = (p.My / G::BM) * (p.Nx / G::BN), splits = p.split_k > 1 ? p.split_k : 1;
+  int grid = num_cus() / splits;  // one persistent workgroup per CU (LDS-limited), shared by the K splits
+  if (grid < 1) grid = 1;
+  if (grid > ntiles) grid = ntiles;
+  hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY>), dim3(grid, splits), dim3(G::NT), lds, st, p);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
+}
+
+// Tile choice.  Geometries: 256x256 (8 waves of 128x64: least LDS traffic per MFMA), 256x128 (4 waves of
+// 128x64), 128x128 (4 waves of 64x64).  Pick the largest tile that still fills whole rounds of CUs.
+template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
+  const int cus = num_cus(), splits = p.split_k > 1 ? p.split_k : 1;
+  auto eff = [&](int bm, int bn) -> double {  // fraction of CU-rounds doing useful work
+    if (p.My % bm || p.Nx % bn) return 0.0;
+    const long tiles = (long)(p.My / bm) * (p.Nx / bn) * splits;
+    const long rounds = (tiles + cus - 1) / cus;
+    return (double)tiles / (double)(rounds * cus);
+  };
+  const double e256 = eff(256, 256), e256x128 = eff(256, 128), e128 = eff(128, 128);
+  int pick = 0;  // 0: 128x128, 1: 256x128, 2: 256x256
+  if (e256x128 + 0.03 >= e128 && e256x128 > 0) pick = 1;
+  if (e256 + 0.06 >= (pick == 1 ? e256x128 : e128) && e256 > 0) pick = 2;
+  if (const char* force = getenv("OSUD_GEMM_TILE")) {  // "128" | "256x128" | "256": tuning / A-B runs
+    const std::string f(force);
+    if (f == "128") pick = 0;
+    else if (f == "256x128" && e256x128 > 0) pick = 1;
+    else if (f == "256" && e256 > 0) pick = 2;
+  }
+  if (pick == 2) return launch_w<TE, EPI, 2, 4, 4>(p, st);
+  if (pick == 1) return launch_w<TE, EPI, 2, 2, 4>(p, st);
+  return launch_w<TE, EPI, 2, 2, 2>(p, st);
 }
 
 template <typename TE> int launch_e(int epi, const GemmP& p, hipStream_t st) {
@@ -268,7 +375,7 @@ template <typename TE> int launch_e(int epi, const GemmP& p, hipStream_t st) {
 
 int launch_gemm(int prec, int epi, const GemmP& p, hipStream_t st) {
   const int esz = (int)elem_size(prec);
-  OSUD_CHECK_ARG(p.My > 0 && p.Nx > 0 && p.K > 0 && p.My % BM == 0 && p.Nx % BN == 0 && (p.K * esz) % SLAB == 0,
+  OSUD_CHECK_ARG(p.My > 0 && p.Nx > 0 && p.K > 0 && p.My % 128 == 0 && p.Nx % 128 == 0 && (p.K * esz) % SLAB == 0,
                  "gemm: My=%d Nx=%d must be multiples of 128 and K=%d a multiple of %d", p.My, p.Nx, p.K, SLAB / esz);
   OSUD_CHECK_ARG((p.ldy * esz) % 16 == 0 && (p.ldx * esz) % 16 == 0 && p.ldo % 4 == 0,
                  "gemm: leading dimensions must keep 16-byte alignment (ldy=%d ldx=%d ldo=%d)", p.ldy, p.ldx, p.ldo);
@@ -279,7 +386,35 @@ int launch_gemm(int prec, int epi, const GemmP& p, hipStream_t st) {
       epi == EPI_BIAS_GELU_TE)
     OSUD_CHECK_ARG(p.bias != nullptr, "gemm: epilogue %d needs a bias", epi);
   if (epi == EPI_GELUGRAD_TE) OSUD_CHECK_ARG(p.aux != nullptr, "gemm: epilogue %d needs aux", epi);
+  if (p.split_k > 1) {
+    OSUD_CHECK_ARG(epi == EPI_NONE_F32 || epi == EPI_NONE_TE, "gemm: split-K needs a plain epilogue");
+    OSUD_CHECK_ARG(((size_t)p.K * esz / SLAB) % p.split_k == 0, "gemm: K=%d does not split %d ways", p.K, p.split_k);
+  }
   return prec == OSUD_PREC_BF16 ? launch_e<bf16_t>(epi, p, st) : launch_e<float>(epi, p, st);
+}
+
+namespace {
+__global__ void splitk_reduce_kernel(const float4* __restrict__ part, int splits, size_t stride4, float4* __restrict__ out,
+                                     size_t n4) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    float4 a = part[i];
+    for (int s = 1; s < splits; ++s) {
+      const float4 b = part[(size_t)s * stride4 + i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    out[i] = a;
+  }
+}
+}  // namespace
+
+int launch_splitk_reduce(const float* part, int splits, size_t stride, float* out, size_t n, hipStream_t st) {
+  OSUD_CHECK_ARG(n % 4 == 0 && stride % 4 == 0, "splitk_reduce: sizes must be multiples of 4");
+  const size_t n4 = n / 4;
+  const int grid = (int)((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, st, reinterpret_cast<const float4*>(part), splits,
+                     stride / 4, reinterpret_cast<float4*>(out), n4);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
 }
 
 }  // namespace osud

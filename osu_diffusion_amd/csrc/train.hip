@@ -56,6 +56,23 @@ int dbg_sync(hipStream_t st, const char* stage) {
   return e == hipSuccess ? OSUD_OK : hip_fail(e, stage, __FILE__, __LINE__);
 }
 
+// Weight-gradient product out[My][Nx] = Y[My][K] . X[Nx][K]^T with K = number of tokens: few output
+// tiles, very long contraction -> split K over workgroups (partial slabs + deterministic combine).
+int wgrad(osud_dit* m, const void* Y, const void* X, int My, int Nx, int K, float* out, int ldo, hipStream_t st) {
+  const int tiles = (My / 128) * (Nx / 128);
+  const int slabs = (int)((size_t)K * m->esz / 128);
+  int S = 1;
+  while (S < 16 && tiles * S * 2 <= 1024 && slabs % (S * 2) == 0 && slabs / (S * 2) >= 8 &&
+         (size_t)(S * 2) * My * Nx <= m->bw.splitk_elems)
+    S *= 2;
+  if (S == 1 || ldo != Nx) return gemm(m, EPI_NONE_F32, Y, K, X, K, My, Nx, K, out, ldo, nullptr, st);
+  GemmP p{};
+  p.Y = Y; p.X = X; p.ldy = K; p.ldx = K; p.My = My; p.Nx = Nx; p.K = K;
+  p.out = m->bw.splitk; p.ldo = Nx; p.split_k = S; p.split_stride = (size_t)My * Nx;
+  OSUD_TRY(launch_gemm(m->prec, EPI_NONE_F32, p, st));
+  return launch_splitk_reduce(m->bw.splitk, S, (size_t)My * Nx, out, (size_t)My * Nx, st);
+}
+
 float* grad_of(osud_dit* m, const std::string& key) {
   auto it = m->grad.find(key);
   return it == m->grad.end() ? nullptr : it->second;
@@ -117,13 +134,13 @@ int dit_backward_impl(osud_dit* m, const float* dout, hipStream_t st) {
     OSUD_TRY(dbg_sync(st, "dgrad fc2 (gelu grad)"));
     OSUD_TRY(launch_transpose(prec, w.dbr, D, w.tB, Mp, Mp, D, g_b2, st));
     OSUD_TRY(launch_transpose(prec, sv.g, 4 * D, w.tA, Mp, Mp, 4 * D, nullptr, st));
-    OSUD_TRY(gemm(m, EPI_NONE_F32, w.tB, Mp, w.tA, Mp, D, 4 * D, Mp, G(p + "mlp.fc2.weight"), 4 * D, nullptr, st));
+    OSUD_TRY(wgrad(m, w.tB, w.tA, D, 4 * D, Mp, G(p + "mlp.fc2.weight"), 4 * D, st));
     OSUD_TRY(dbg_sync(st, "wgrad fc2"));
     OSUD_TRY(gemm(m, EPI_NONE_F32, w.dz1, 4 * D, bw.w1_t, 4 * D, Mp, D, 4 * D, w.du, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "dgrad fc1"));
     OSUD_TRY(launch_transpose(prec, w.dz1, 4 * D, w.tB, Mp, Mp, 4 * D, g_b1, st));
     OSUD_TRY(launch_transpose(prec, sv.u2, D, w.tA, Mp, Mp, D, nullptr, st));
-    OSUD_TRY(gemm(m, EPI_NONE_F32, w.tB, Mp, w.tA, Mp, 4 * D, D, Mp, G(p + "mlp.fc1.weight"), D, nullptr, st));
+    OSUD_TRY(wgrad(m, w.tB, w.tA, 4 * D, D, Mp, G(p + "mlp.fc1.weight"), D, st));
     OSUD_TRY(dbg_sync(st, "wgrad fc1"));
     OSUD_TRY(launch_ln_mod_bwd(sv.h_mid, sv.stats2, w.du, m->ada, AC, base + 3 * D, base + 4 * D, dh, dh_other, w.dada, M,
                                Tp, D, st));
@@ -135,7 +152,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, hipStream_t st) {
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dbr, D, bw.w_o_t, D, Mp, D, D, w.dao, D, nullptr, st));
     OSUD_TRY(launch_transpose(prec, w.dbr, D, w.tB, Mp, Mp, D, g_bo, st));
     OSUD_TRY(launch_transpose(prec, sv.ao, D, w.tA, Mp, Mp, D, nullptr, st));
-    OSUD_TRY(gemm(m, EPI_NONE_F32, w.tB, Mp, w.tA, Mp, D, D, Mp, G(p + "attn.out_proj.weight"), D, nullptr, st));
+    OSUD_TRY(wgrad(m, w.tB, w.tA, D, D, Mp, G(p + "attn.out_proj.weight"), D, st));
     OSUD_TRY(dbg_sync(st, "wgrad out_proj"));
     OSUD_TRY(launch_attention_bwd(prec, sv.qk, w.dao, sv.ao, sv.lse, w.dqkv, N, T, m->H, m->hd, st));
     OSUD_TRY(dbg_sync(st, "attention bwd"));
@@ -143,7 +160,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, hipStream_t st) {
     OSUD_TRY(dbg_sync(st, "dgrad qkv"));
     OSUD_TRY(launch_transpose(prec, w.dqkv, 3 * D, w.tB, Mp, Mp, 3 * D, g_bqkv, st));
     OSUD_TRY(launch_transpose(prec, sv.u1, D, w.tA, Mp, Mp, D, nullptr, st));
-    OSUD_TRY(gemm(m, EPI_NONE_F32, w.tB, Mp, w.tA, Mp, 3 * D, D, Mp, G(p + "attn.in_proj_weight"), D, nullptr, st));
+    OSUD_TRY(wgrad(m, w.tB, w.tA, 3 * D, D, Mp, G(p + "attn.in_proj_weight"), D, st));
     OSUD_TRY(dbg_sync(st, "wgrad qkv"));
     OSUD_TRY(launch_ln_mod_bwd(sv.h_in, sv.stats1, w.du, m->ada, AC, base, base + D, dh, dh_other, w.dada, M, Tp, D, st));
     OSUD_TRY(dbg_sync(st, "ln1 bwd"));
@@ -156,7 +173,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, hipStream_t st) {
     OSUD_TRY(zero(g_be, (size_t)D * 4));
     OSUD_TRY(launch_transpose_f32(prec, dh, D, w.tB, Mp, Mp, D, g_be, st));
     OSUD_TRY(launch_transpose(prec, m->e0, m->Kp, w.tA, Mp, Mp, m->Kp, nullptr, st));
-    OSUD_TRY(gemm(m, EPI_NONE_F32, w.tB, Mp, w.tA, Mp, D, m->Kp, Mp, w.dWe, m->Kp, nullptr, st));
+    OSUD_TRY(wgrad(m, w.tB, w.tA, D, m->Kp, Mp, w.dWe, m->Kp, st));
     OSUD_TRY(launch_unpad_rows(w.dWe, m->Kp, G("xoc_embedder.mlp.0.weight"), 384 + m->E, D, st));
     OSUD_TRY(dbg_sync(st, "first layer"));
   }
