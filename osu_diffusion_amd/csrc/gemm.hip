@@ -34,55 +34,61 @@ template <> __device__ __forceinline__ void mma<float>(f32x16& acc, const u32x4&
   for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[j], acc, 0, 0, 0);
 }
 
-// Per-wave register block: (RY x 32) rows of Y by 64 rows of X -> RY x 2 MFMA 32x32 accumulators.
-template <int RY> struct FragSet {
-  u32x4 y[RY], x[2];
-};
-// ya/xa: this lane's LDS byte address of (first Y / X row of the wave, k-substep s) in the current stage
-template <int RY> __device__ __forceinline__ void read_set(FragSet<RY>& f, uint32_t ya, uint32_t xa) {
-  f.y[0] = ds_read16<0>(ya);
-  f.y[1] = ds_read16<32 * SLAB>(ya);
-  if constexpr (RY == 4) {
-    f.y[2] = ds_read16<64 * SLAB>(ya);
-    f.y[3] = ds_read16<96 * SLAB>(ya);
-  }
-  f.x[0] = ds_read16<0>(xa);
-  f.x[1] = ds_read16<32 * SLAB>(xa);
-}
-template <typename TE, int RY> __device__ __forceinline__ void mma_set(f32x16 (&acc)[RY][2], const FragSet<RY>& f) {
-#pragma unroll
-  for (int i = 0; i < RY; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) mma<TE>(acc[i][j], f.x[j], f.y[i]);
-}
 #define OSUD_LGKM_WAIT(n)                                  \
   asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
   __builtin_amdgcn_sched_barrier(0)
 
+// Per-wave register block: (RY x 32) rows of Y by (RX x 32) rows of X -> RY x RX MFMA 32x32 accumulators.
+template <int RY, int RX> struct FragSet {
+  u32x4 y[RY], x[RX];
+};
+// ya/xa: this lane's LDS byte address of (first Y / X row of the wave, k-substep s) in the current stage
+template <int RY, int RX> __device__ __forceinline__ void read_set(FragSet<RY, RX>& f, uint32_t ya, uint32_t xa) {
+  f.y[0] = ds_read16<0>(ya);
+  f.y[1] = ds_read16<32 * SLAB>(ya);
+  if constexpr (RY >= 3) f.y[2] = ds_read16<64 * SLAB>(ya);
+  if constexpr (RY == 4) f.y[3] = ds_read16<96 * SLAB>(ya);
+  f.x[0] = ds_read16<0>(xa);
+  f.x[1] = ds_read16<32 * SLAB>(xa);
+  if constexpr (RX == 3) f.x[2] = ds_read16<64 * SLAB>(xa);
+}
+template <typename TE, int RY, int RX>
+__device__ __forceinline__ void mma_set(f32x16 (&acc)[RY][RX], const FragSet<RY, RX>& f) {
+#pragma unroll
+  for (int i = 0; i < RY; ++i)
+#pragma unroll
+    for (int j = 0; j < RX; ++j) mma<TE>(acc[i][j], f.x[j], f.y[i]);
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() {
+  if constexpr (N == 4) { OSUD_LGKM_WAIT(4); }
+  else if constexpr (N == 5) { OSUD_LGKM_WAIT(5); }
+  else if constexpr (N == 6) { OSUD_LGKM_WAIT(6); }
+  else { OSUD_LGKM_WAIT(0); }
+}
 // One 128-byte K slab from the LDS stage at byte offset `so`: 4 sub-steps, reads of sub-step s+1 in
 // flight under the MFMAs of sub-step s (LDS returns in order, so lgkmcnt(R) == "all but the newest R").
-template <typename TE, int RY>
-__device__ __forceinline__ void compute_slab(f32x16 (&acc)[RY][2], const uint32_t (&ya)[4], const uint32_t (&xa)[4],
+template <typename TE, int RY, int RX>
+__device__ __forceinline__ void compute_slab(f32x16 (&acc)[RY][RX], const uint32_t (&ya)[4], const uint32_t (&xa)[4],
                                              uint32_t so) {
-  FragSet<RY> f0, f1;
-  read_set<RY>(f0, ya[0] + so, xa[0] + so);
-  read_set<RY>(f1, ya[1] + so, xa[1] + so);
-  if constexpr (RY == 4) { OSUD_LGKM_WAIT(6); } else { OSUD_LGKM_WAIT(4); }
-  mma_set<TE, RY>(acc, f0);
-  read_set<RY>(f0, ya[2] + so, xa[2] + so);
-  if constexpr (RY == 4) { OSUD_LGKM_WAIT(6); } else { OSUD_LGKM_WAIT(4); }
-  mma_set<TE, RY>(acc, f1);
-  read_set<RY>(f1, ya[3] + so, xa[3] + so);
-  if constexpr (RY == 4) { OSUD_LGKM_WAIT(6); } else { OSUD_LGKM_WAIT(4); }
-  mma_set<TE, RY>(acc, f0);
-  OSUD_LGKM_WAIT(0);
-  mma_set<TE, RY>(acc, f1);
+  FragSet<RY, RX> f0, f1;
+  read_set<RY, RX>(f0, ya[0] + so, xa[0] + so);
+  read_set<RY, RX>(f1, ya[1] + so, xa[1] + so);
+  wait_lgkm<RY + RX>();
+  mma_set<TE, RY, RX>(acc, f0);
+  read_set<RY, RX>(f0, ya[2] + so, xa[2] + so);
+  wait_lgkm<RY + RX>();
+  mma_set<TE, RY, RX>(acc, f1);
+  read_set<RY, RX>(f1, ya[3] + so, xa[3] + so);
+  wait_lgkm<RY + RX>();
+  mma_set<TE, RY, RX>(acc, f0);
+  wait_lgkm<0>();
+  mma_set<TE, RY, RX>(acc, f1);
 }
 
-// Tile geometry: WY x WX waves, each wave (RY*32) x 64 outputs: BM = WY*RY*32 rows of Y, BN = WX*64 rows of X.
+// Tile geometry: WY x WX waves, each wave (RY*32) x (RX*32) outputs: BM = WY*RY*32 rows of Y, BN = WX*RX*32 rows of X.
 // A stage holds one K slab of both operands as ONE (BM+BN)-row x 128-byte image.
-template <int WY, int WX, int RY> struct Geo {
-  static constexpr int BM = WY * RY * 32, BN = WX * 64, NW = WY * WX, NT = 64 * NW;
+template <int WY, int WX, int RY, int RX> struct Geo {
+  static constexpr int BM = WY * RY * 32, BN = WX * RX * 32, NW = WY * WX, NT = 64 * NW;
   static constexpr int STAGE = (BM + BN) * SLAB;
   static constexpr int NSTAGE = STAGE * 4 <= 144 * 1024 ? 4 : (STAGE * 3 <= 160 * 1024 ? 3 : 2);
   static constexpr int PIECES = (BM + BN) / 8, PPW = PIECES / NW;  // 1 KiB LDS-DMA pieces per slab, per wave
@@ -108,6 +114,8 @@ __device__ __forceinline__ void stage_slab(const char* gy, size_t ldy_b, const c
 template <int N> __device__ __forceinline__ void wait_vm() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
   else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
@@ -115,9 +123,9 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else static_assert(N < 0, "add the literal");
 }
 
-template <typename TE, int EPI, int WY, int WX, int RY>
-__global__ __launch_bounds__((Geo<WY, WX, RY>::NT)) void gemm_kernel(GemmP p) {
-  using G = Geo<WY, WX, RY>;
+template <typename TE, int EPI, int WY, int WX, int RY, int RX>
+__global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p) {
+  using G = Geo<WY, WX, RY, RX>;
   constexpr int BN = G::BN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool FAST = sizeof(TE) == 2;
@@ -158,7 +166,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY>::NT)) void gemm_kernel(GemmP p) {
   for (int s = 0; s < 4; ++s) {
     const uint32_t sw = (uint32_t)(((2 * s + fhalf) ^ ((frow >> 1) & 7)) << 4);
     ya[s] = lds0 + (wy * RY * 32 + frow) * SLAB + sw;
-    xa[s] = lds0 + (G::BM + wx * 64 + frow) * SLAB + sw;
+    xa[s] = lds0 + (G::BM + wx * RX * 32 + frow) * SLAB + sw;
   }
 
   // ---- prologue: fill NSTAGE-1 stages
@@ -182,11 +190,11 @@ __global__ __launch_bounds__((Geo<WY, WX, RY>::NT)) void gemm_kernel(GemmP p) {
 
   for (int tile = first; tile < ntiles; tile += G8) {
     const int ty = tile / ntx, tx = tile % ntx;
-    f32x16 acc[RY][2];
+    f32x16 acc[RY][RX];
 #pragma unroll
     for (int i = 0; i < RY; ++i)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < RX; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -200,7 +208,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY>::NT)) void gemm_kernel(GemmP p) {
       else wait_vm<(G::NSTAGE > 3 ? 2 * G::PPW : 0)>();
       __builtin_amdgcn_s_barrier();  // every wave's share landed; the stage consumed last round is free again
       issue_next();
-      compute_slab<TE, RY>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
+      compute_slab<TE, RY, RX>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
       ++consumed;
     }
     // The next tile's first slabs are already in flight: make sure they landed NOW, while no store is
@@ -213,11 +221,11 @@ __global__ __launch_bounds__((Geo<WY, WX, RY>::NT)) void gemm_kernel(GemmP p) {
     // vmcnt counts stores too, so a load waited for between stores would drain every earlier store.
     constexpr bool kBias = EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_TE || EPI == EPI_BIAS_SILU_TE ||
                            EPI == EPI_BIAS_GELU_TE || EPI == EPI_GATE_RES;
-    const int xw = tx * BN + wx * 64 + 4 * fhalf;  // + j*32 + 8*g
-    float4 bv[2][4];
-    if (kBias && EPI != EPI_GATE_RES) {
+    const int xw = tx * BN + wx * RX * 32 + 4 * fhalf;  // + j*32 + 8*g
+    float4 bv[RX][4];
+    if (kBias) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < RX; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) bv[j][g] = *reinterpret_cast<const float4*>(p.bias + xw + j * 32 + 8 * g);
     }
@@ -226,42 +234,36 @@ __global__ __launch_bounds__((Geo<WY, WX, RY>::NT)) void gemm_kernel(GemmP p) {
       const int y = ty * G::BM + wy * RY * 32 + i * 32 + frow;
       float rb = 0.f;
       if (EPI == EPI_ROWBIAS_TE) rb = p.bias[y];
-      float4 gv[2][4], rv[2][4];
+      int sample = 0;
       if (EPI == EPI_GATE_RES) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) bv[j][g] = *reinterpret_cast<const float4*>(p.bias + xw + j * 32 + 8 * g);
-        int sample = y / p.rows_per_sample;
+        sample = y / p.rows_per_sample;
         if (sample >= p.n_samples) sample = p.n_samples - 1;  // padding rows
-        const float* rsrc = p.res ? p.res : reinterpret_cast<const float*>(p.out);
+      }
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < RX; ++j) {
+        // operands of this 32x32 block first (one batch of loads), then its 4 stores
+        float4 gv[4], rv[4];
+        if (EPI == EPI_GATE_RES) {
+          const float* rsrc = p.res ? p.res : reinterpret_cast<const float*>(p.out);
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            gv[j][g] = *reinterpret_cast<const float4*>(p.gate + (size_t)sample * p.ld_gate + xw + j * 32 + 8 * g);
-            rv[j][g] = *reinterpret_cast<const float4*>(rsrc + (size_t)y * p.ldo + xw + j * 32 + 8 * g);
+            gv[g] = *reinterpret_cast<const float4*>(p.gate + (size_t)sample * p.ld_gate + xw + j * 32 + 8 * g);
+            rv[g] = *reinterpret_cast<const float4*>(rsrc + (size_t)y * p.ldo + xw + j * 32 + 8 * g);
           }
-      }
-      if (EPI == EPI_ACCUM_F32) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
+        }
+        if (EPI == EPI_ACCUM_F32) {
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            rv[j][g] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.out) + (size_t)y * p.ldo + xw +
-                                                        j * 32 + 8 * g);
-      }
-      if (EPI == EPI_GELUGRAD_TE) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
+            rv[g] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.out) + (size_t)y * p.ldo + xw +
+                                                     j * 32 + 8 * g);
+        }
+        if (EPI == EPI_GELUGRAD_TE) {
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const TE* a = reinterpret_cast<const TE*>(p.aux) + (size_t)y * p.ldo + xw + j * 32 + 8 * g;
-            rv[j][g] = make_float4(load_elem(a), load_elem(a + 1), load_elem(a + 2), load_elem(a + 3));
+            rv[g] = make_float4(load_elem(a), load_elem(a + 1), load_elem(a + 2), load_elem(a + 3));
           }
-      }
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int x = xw + j * 32 + 8 * g;
@@ -273,12 +275,12 @@ __global__ __launch_bounds__((Geo<WY, WX, RY>::NT)) void gemm_kernel(GemmP p) {
           if (EPI == EPI_BIAS_F32 || EPI == EPI_NONE_F32) {
             store4(reinterpret_cast<float*>(p.out) + o, v0, v1, v2, v3);
           } else if (EPI == EPI_ACCUM_F32) {
-            store4(reinterpret_cast<float*>(p.out) + o, rv[j][g].x + v0, rv[j][g].y + v1, rv[j][g].z + v2,
-                   rv[j][g].w + v3);
+            store4(reinterpret_cast<float*>(p.out) + o, rv[g].x + v0, rv[g].y + v1, rv[g].z + v2,
+                   rv[g].w + v3);
           } else if (EPI == EPI_GATE_RES) {
             if (p.out2) store4(reinterpret_cast<TE*>(p.out2) + o, v0, v1, v2, v3);  // branch output (training)
-            store4(reinterpret_cast<float*>(p.out) + o, rv[j][g].x + gv[j][g].x * v0, rv[j][g].y + gv[j][g].y * v1,
-                   rv[j][g].z + gv[j][g].z * v2, rv[j][g].w + gv[j][g].w * v3);
+            store4(reinterpret_cast<float*>(p.out) + o, rv[g].x + gv[g].x * v0, rv[g].y + gv[g].y * v1,
+                   rv[g].z + gv[g].z * v2, rv[g].w + gv[g].w * v3);
           } else if (EPI == EPI_BIAS_SILU_TE) {
             if (p.out2) store4(reinterpret_cast<TE*>(p.out2) + o, v0, v1, v2, v3);  // pre-activation (training)
             store4(reinterpret_cast<TE*>(p.out) + o, silu_t<FAST>(v0), silu_t<FAST>(v1), silu_t<FAST>(v2),
@@ -288,9 +290,9 @@ __global__ __launch_bounds__((Geo<WY, WX, RY>::NT)) void gemm_kernel(GemmP p) {
             store4(reinterpret_cast<TE*>(p.out) + o, gelu_tanh_t<FAST>(v0), gelu_tanh_t<FAST>(v1),
                    gelu_tanh_t<FAST>(v2), gelu_tanh_t<FAST>(v3));
           } else if (EPI == EPI_GELUGRAD_TE) {
-            store4(reinterpret_cast<TE*>(p.out) + o, v0 * gelu_tanh_grad_t<FAST>(rv[j][g].x),
-                   v1 * gelu_tanh_grad_t<FAST>(rv[j][g].y), v2 * gelu_tanh_grad_t<FAST>(rv[j][g].z),
-                   v3 * gelu_tanh_grad_t<FAST>(rv[j][g].w));
+            store4(reinterpret_cast<TE*>(p.out) + o, v0 * gelu_tanh_grad_t<FAST>(rv[g].x),
+                   v1 * gelu_tanh_grad_t<FAST>(rv[g].y), v2 * gelu_tanh_grad_t<FAST>(rv[g].z),
+                   v3 * gelu_tanh_grad_t<FAST>(rv[g].w));
           } else {  // EPI_BIAS_TE, EPI_ROWBIAS_TE, EPI_NONE_TE
             store4(reinterpret_cast<TE*>(p.out) + o, v0, v1, v2, v3);
           }
@@ -311,12 +313,12 @@ int num_cus() {
   return n;
 }
 
-template <typename TE, int EPI, int WY, int WX, int RY> int launch_w(const GemmP& p, hipStream_t st) {
-  using G = Geo<WY, WX, RY>;
+template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(const GemmP& p, hipStream_t st) {
+  using G = Geo<WY, WX, RY, RX>;
   const size_t lds = (size_t)G::NSTAGE * G::STAGE;
   static bool attr_set = false;
   if (!attr_set) {
-    OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY>),
+    OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -324,34 +326,41 @@ template <typename TE, int EPI, int WY, int WX, int RY> int launch_w(const GemmP
   int grid = num_cus() / splits;  // one persistent workgroup per CU (LDS-limited), shared by the K splits
   if (grid < 1) grid = 1;
   if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY>), dim3(grid, splits), dim3(G::NT), lds, st, p);
+  hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY, RX>), dim3(grid, splits), dim3(G::NT), lds, st, p);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }
 
-// Tile choice.  Geometries: 256x256 (8 waves of 128x64: least LDS traffic per MFMA), 256x128 (4 waves of
-// 128x64), 128x128 (4 waves of 64x64).  Pick the largest tile that still fills whole rounds of CUs.
+// Tile choice.  Geometries (all 8 waves = 2 per SIMD, except the 128x128 fallback):
+//   256x256: 2x4 waves of 128x64   least LDS traffic per MFMA; needs Nx % 256 == 0
+//   256x192: 4x2 waves of 64x96    for Nx = 768-like widths (3 x 256 would leave 1.5 rounds of tiles)
+//   192x256: 2x4 waves of 96x64    the same for My = 768-like heights (V^T projection, weight gradients)
+//   128x128: 2x2 waves of 64x64    small problems
+// Pick by the fraction of CU-rounds doing useful work, preferring the larger tile on ties.
 template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
   const int cus = num_cus(), splits = p.split_k > 1 ? p.split_k : 1;
-  auto eff = [&](int bm, int bn) -> double {  // fraction of CU-rounds doing useful work
+  auto eff = [&](int bm, int bn) -> double {
     if (p.My % bm || p.Nx % bn) return 0.0;
     const long tiles = (long)(p.My / bm) * (p.Nx / bn) * splits;
     const long rounds = (tiles + cus - 1) / cus;
     return (double)tiles / (double)(rounds * cus);
   };
-  const double e256 = eff(256, 256), e256x128 = eff(256, 128), e128 = eff(128, 128);
-  int pick = 0;  // 0: 128x128, 1: 256x128, 2: 256x256
-  if (e256x128 + 0.03 >= e128 && e256x128 > 0) pick = 1;
-  if (e256 + 0.06 >= (pick == 1 ? e256x128 : e128) && e256 > 0) pick = 2;
-  if (const char* force = getenv("OSUD_GEMM_TILE")) {  // "128" | "256x128" | "256": tuning / A-B runs
+  const double e[4] = {eff(128, 128), eff(256, 192), eff(256, 256), eff(192, 256)};
+  int pick = 0;
+  if (e[1] > 0 && e[1] + 0.05 >= e[0]) pick = 1;
+  if (e[3] > 0 && e[3] + 0.05 >= e[pick] && pick == 0) pick = 3;
+  if (e[2] > 0 && e[2] + 0.05 >= e[pick]) pick = 2;
+  if (const char* force = getenv("OSUD_GEMM_TILE")) {  // "128" | "192" | "256": tuning / A-B runs
     const std::string f(force);
     if (f == "128") pick = 0;
-    else if (f == "256x128" && e256x128 > 0) pick = 1;
-    else if (f == "256" && e256 > 0) pick = 2;
+    else if (f == "192" && e[1] > 0) pick = 1;
+    else if (f == "256" && e[2] > 0) pick = 2;
+    else if (f == "192y" && e[3] > 0) pick = 3;
   }
-  if (pick == 2) return launch_w<TE, EPI, 2, 4, 4>(p, st);
-  if (pick == 1) return launch_w<TE, EPI, 2, 2, 4>(p, st);
-  return launch_w<TE, EPI, 2, 2, 2>(p, st);
+  if (pick == 2) return launch_w<TE, EPI, 2, 4, 4, 2>(p, st);
+  if (pick == 1) return launch_w<TE, EPI, 4, 2, 2, 3>(p, st);
+  if (pick == 3) return launch_w<TE, EPI, 2, 4, 3, 2>(p, st);
+  return launch_w<TE, EPI, 2, 2, 2, 2>(p, st);
 }
 
 template <typename TE> int launch_e(int epi, const GemmP& p, hipStream_t st) {

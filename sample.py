@@ -1,0 +1,136 @@
+#!/usr/bin/env python3
+"""Sample beatmap object coordinates with a pre-trained DiT — flag-compatible with the reference's
+sample.py (sample.py:208-232), running the native MI355X path.
+
+The reference turns a `.osu` file into a (19, T) sequence with the third-party `slider` parser
+and exports the result back to `.osu`; both are outside the accelerated path.  Here
+`--beatmap` accepts a `.pt`/`.npy` file holding that (19, T) float tensor (x, y, time_ms, 16 one-hot
+type rows — data_loading.py:32-39), or `--synthetic T` draws a synthetic one.  The sampled
+sequences are written as `results/<name>/result.pt` ((n, 19, T): sampled x,y + original features).
+"""
+import argparse
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from osu_diffusion_amd.diffusion import create_diffusion
+from osu_diffusion_amd.models import DiT_models, find_model
+from osu_diffusion_amd.positional_embedding import timestep_embedding
+from osu_diffusion_amd.synthetic import banded_attn_mask
+
+feature_size = 19
+playfield_size = torch.tensor((512, 384))
+
+
+def split_and_process_sequence(seq):
+    """(19,T) -> ((x (2,T), o (T), c (144,T)), T)  — data_loading.py:146-169 without the random flip
+    (the flipped positions are discarded at sampling time anyway, sample.py:64)."""
+    offset = torch.roll(seq[:2, :], 1, 1)
+    offset[0, 0], offset[1, 0] = 256, 192
+    seq_d = torch.linalg.vector_norm(seq[:2, :] - offset, ord=2, dim=0)
+    seq_x = seq[:2, :] / playfield_size.unsqueeze(1)
+    seq_c = torch.concatenate([timestep_embedding(seq_d, 128).T, seq[3:, :]], 0)
+    return (seq_x, seq[2, :], seq_c), seq.shape[1]
+
+
+def load_sequence(args):
+    if args.synthetic:
+        g = torch.Generator().manual_seed(args.seed)
+        T = args.synthetic
+        seq = torch.zeros(feature_size, T)
+        seq[0] = torch.rand(T, generator=g) * 512
+        seq[1] = torch.rand(T, generator=g) * 384
+        seq[2] = torch.cumsum(torch.randint(50, 601, (T,), generator=g).float(), 0)
+        seq[3 + torch.randint(0, 16, (T,), generator=g), torch.arange(T)] = 1
+        return seq, f"synthetic-{T}"
+    path = args.beatmap
+    if path.endswith(".osu"):
+        raise SystemExit("parsing .osu files needs the third-party `slider` package (reference data_loading.py:127-135), "
+                         "which is outside this build; pass the (19, T) sequence as .pt/.npy or use --synthetic T")
+    seq = torch.from_numpy(np.load(path)) if path.endswith(".npy") else torch.load(path)
+    assert seq.shape[0] == feature_size, f"expected a ({feature_size}, T) sequence, got {tuple(seq.shape)}"
+    return seq.float(), os.path.splitext(os.path.basename(path))[0]
+
+
+def main(args):
+    torch.manual_seed(args.seed)
+    torch.set_grad_enabled(False)
+    assert torch.cuda.is_available(), "the native path needs an AMD GPU (there is no CPU fallback)"
+    device = "cuda"
+    seq_no_embed, name = load_sequence(args)
+    result_dir = os.path.join("results", name)
+    os.makedirs(result_dir, exist_ok=True)
+    (seq_x, seq_o, seq_c), seq_len = split_and_process_sequence(seq_no_embed)
+    seq_o = seq_o - seq_o[0]  # relative time (sample.py:65)
+    print(f"seq len {seq_len}")
+
+    model = DiT_models[args.model](num_classes=args.num_classes, context_size=feature_size - 3 + 128,
+                                   precision=args.precision).to(device)
+    if args.ckpt:
+        model.load_state_dict(find_model(args.ckpt))
+    else:
+        from osu_diffusion_amd.synthetic import randomize_zero_init
+        print("no --ckpt: using seeded random weights (bench / smoke use only)")
+        randomize_zero_init(model, seed=args.seed)
+    model.eval()
+    diffusion = create_diffusion(str(args.num_sampling_steps), noise_schedule="squaredcos_cap_v2")
+    attn_mask = banded_attn_mask(seq_len, args.seq_len).to(device)  # sample.py:81-84
+
+    if args.style_id is not None:
+        with open(args.beatmap_idx, "rb") as f:
+            idx = pickle.load(f)[args.style_id]
+        class_labels = [idx + i for i in range(args.num_variants)]
+    else:
+        class_labels = [args.num_classes]  # null class (sample.py:91-93)
+    n = len(class_labels)
+    z = torch.randn(n, 2, seq_len, device=device)
+    o = seq_o.repeat(n, 1).to(device)
+    c = seq_c.repeat(n, 1, 1).to(device)
+    y = torch.tensor(class_labels, device=device)
+    z, o, c = torch.cat([z, z], 0), torch.cat([o, o], 0), torch.cat([c, c], 0)  # classifier-free guidance
+    y = torch.cat([y, torch.tensor([args.num_classes] * n, device=device)], 0)
+    model_kwargs = dict(o=o, c=c, y=y, cfg_scale=args.cfg_scale, attn_mask=attn_mask)
+
+    def to_seq(samples):
+        samples, _ = samples.chunk(2, dim=0)
+        return torch.concatenate([samples.cpu() * playfield_size.view(1, 2, 1), seq_no_embed[2:].repeat(n, 1, 1)], 1)
+
+    samples = diffusion.p_sample_loop(model.forward_with_cfg, z.shape, z, clip_denoised=True, model_kwargs=model_kwargs,
+                                      progress=False, device=device)
+    if args.refine_ckpt is not None:  # sample.py:186-205: repeated t=0 steps with the refine model
+        model.load_state_dict(find_model(args.refine_ckpt))
+        for _ in range(args.refine_iters):
+            t = torch.tensor([0] * samples.shape[0], device=device)
+            samples = diffusion.p_sample(model.forward_with_cfg, samples, t, clip_denoised=True,
+                                         model_kwargs=model_kwargs)["sample"]
+    out = os.path.join(result_dir, "result.pt")
+    torch.save(to_seq(samples), out)
+    print(f"saved {n} sampled sequence(s) to {out}")
+
+
+if __name__ == "__main__":
+    p = argparse.ArgumentParser()
+    p.add_argument("--beatmap", type=str, default=None)
+    p.add_argument("--ckpt", type=str, default=None)
+    p.add_argument("--model", type=str, choices=list(DiT_models.keys()), default="DiT-B")
+    p.add_argument("--num-classes", type=int, default=52670)
+    p.add_argument("--beatmap-idx", type=str, default="beatmap_idx.pickle")
+    p.add_argument("--cfg-scale", type=float, default=1.0)
+    p.add_argument("--num-sampling-steps", type=int, default=250)
+    p.add_argument("--seed", type=int, default=0)
+    p.add_argument("--seq-len", type=int, default=128)
+    p.add_argument("--use-amp", type=bool, default=True)  # kept for compatibility (unused by the reference too)
+    p.add_argument("--style-id", type=int, default=None)
+    p.add_argument("--plot-time", type=float, default=None)   # plotting / animation: out of scope, accepted & ignored
+    p.add_argument("--plot-width", type=float, default=2000)
+    p.add_argument("--num-variants", type=int, default=1)
+    p.add_argument("--make-animation", type=bool, default=False)
+    p.add_argument("--refine-ckpt", type=str, default=None)
+    p.add_argument("--refine-iters", type=int, default=10)
+    p.add_argument("--synthetic", type=int, default=0, metavar="T", help="use a synthetic T-token sequence")
+    p.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    a = p.parse_args()
+    assert a.beatmap or a.synthetic, "--beatmap <seq.pt|seq.npy> or --synthetic T"
+    main(a)

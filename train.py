@@ -1,0 +1,144 @@
+#!/usr/bin/env python3
+"""DDP-style trainer — flag-compatible with the reference's train.py (train.py:306-337), one process
+per GPU (`torchrun --nproc-per-node=G train.py ...`), running the native MI355X step
+(osu_diffusion_amd.training.NativeTrainer) with ONE RCCL all-reduce per step on a flat fp32
+gradient arena instead of DDP's bucketed reducer.
+
+Real `.osu` datasets need the third-party `slider` parser (out of scope); `--synthetic`
+trains on synthetic windows with the reference's tensor contract, sharded per rank like train.py:165-170.
+"""
+import argparse
+import logging
+import os
+from glob import glob
+from time import time
+
+import torch
+import torch.distributed as dist
+
+from osu_diffusion_amd.diffusion import create_diffusion
+from osu_diffusion_amd.models import DiT_models
+from osu_diffusion_amd.synthetic import synthetic_windows
+from osu_diffusion_amd.training import NativeTrainer, shard_range
+
+feature_size = 19
+
+
+def create_logger(logging_dir, rank):
+    """train.py:73-91."""
+    if rank == 0:
+        logging.basicConfig(level=logging.INFO, format="[\033[34m%(asctime)s\033[0m] %(message)s", datefmt="%Y-%m-%d %H:%M:%S",
+                            handlers=[logging.StreamHandler(), logging.FileHandler(f"{logging_dir}/log.txt")])
+        return logging.getLogger(__name__)
+    logger = logging.getLogger(__name__)
+    logger.addHandler(logging.NullHandler())
+    return logger
+
+
+def main(args):
+    assert torch.cuda.is_available(), "Training currently requires at least one GPU."
+    distributed = "RANK" in os.environ
+    if distributed:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(args.dist)  # "nccl" == RCCL on ROCm
+    world_size = dist.get_world_size() if distributed else 1
+    rank = dist.get_rank() if distributed else 0
+    assert args.global_batch_size % world_size == 0, "Batch size must be divisible by world size."
+    device = rank % torch.cuda.device_count()
+    seed = args.global_seed * world_size + rank
+    torch.manual_seed(seed)
+    torch.cuda.set_device(device)
+    print(f"Starting rank={rank}, seed={seed}, world_size={world_size}.")
+
+    if rank == 0:
+        os.makedirs(args.results_dir, exist_ok=True)
+        experiment_index = len(glob(f"{args.results_dir}/*"))
+        experiment_dir = f"{args.results_dir}/{experiment_index:03d}-{args.model.replace('/', '-')}"
+        checkpoint_dir = f"{experiment_dir}/checkpoints"
+        os.makedirs(checkpoint_dir, exist_ok=True)
+        logger = create_logger(experiment_dir, rank)
+        logger.info(f"Experiment directory created at {experiment_dir}")
+    else:
+        checkpoint_dir = ""
+        logger = create_logger(None, rank)
+
+    model = DiT_models[args.model](num_classes=args.num_classes, context_size=feature_size - 3 + 128,
+                                   class_dropout_prob=0.2, precision=args.precision).to(device)
+    diffusion = create_diffusion(timestep_respacing="", noise_schedule=args.noise_schedule, use_l1=args.l1_loss)
+    logger.info(f"DiT Parameters: {sum(p.numel() for p in model.parameters()):,}")
+    trainer = NativeTrainer(model, diffusion, lr=args.lr)  # AdamW(lr, wd=0) + EMA 0.9999 + init broadcast
+    model.train()
+    if args.ckpt is not None:
+        trainer.load_checkpoint(torch.load(args.ckpt, map_location="cpu", weights_only=False), lr=args.lr,
+                                relearn_embeds=args.relearn_embeds)
+        logger.info(f"Restored from checkpoint at {args.ckpt}")
+
+    batch_size = args.global_batch_size // world_size
+    dataset_start, dataset_end = shard_range(args.data_start, args.data_end, rank, world_size)
+    assert args.synthetic, "real datasets need the `slider` parser (out of scope); pass --synthetic"
+    logger.info(f"Dataset contains {(dataset_end - dataset_start):,} (synthetic) beatmap sets")
+
+    train_steps, log_steps, start_time = 0, 0, time()
+    running_loss = torch.zeros((), device=device)  # accumulated on the device: no host sync per step
+    logger.info(f"Training for {args.epochs} epochs...")
+    for epoch in range(args.epochs):
+        logger.info(f"Beginning epoch {epoch}...")
+        for it in range(args.steps_per_epoch):
+            track = dataset_start + (epoch * args.steps_per_epoch + it) % max(1, dataset_end - dataset_start)
+            (x, o, c), y = synthetic_windows(batch_size, args.seq_len, args.num_classes, seed=track)
+            terms = trainer.step(x, o, c, y)
+            running_loss += terms[2].mean()
+            log_steps += 1
+            train_steps += 1
+            if train_steps % args.log_every == 0:
+                torch.cuda.synchronize()
+                steps_per_sec = log_steps / (time() - start_time)
+                avg_loss = running_loss / log_steps
+                if distributed:
+                    dist.all_reduce(avg_loss, op=dist.ReduceOp.SUM)
+                logger.info(f"(step={train_steps:07d}) Train Loss: {avg_loss.item() / world_size:.4f}, "
+                            f"Train Steps/Sec: {steps_per_sec:.2f}")
+                running_loss.zero_()
+                log_steps, start_time = 0, time()
+            if train_steps % args.ckpt_every == 0 and train_steps > 0:
+                if rank == 0:
+                    path = f"{checkpoint_dir}/{train_steps:07d}.pt"
+                    torch.save(trainer.checkpoint(args), path)
+                    logger.info(f"Saved checkpoint to {path}")
+                if distributed:
+                    dist.barrier()
+    model.eval()
+    logger.info("Done!")
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    p = argparse.ArgumentParser()
+    p.add_argument("--data-path", type=str, default=None)
+    p.add_argument("--num-classes", type=int, default=52670)
+    p.add_argument("--data-start", type=int, default=0)
+    p.add_argument("--data-end", type=int, default=13402)
+    p.add_argument("--results-dir", type=str, default="results")
+    p.add_argument("--model", type=str, choices=list(DiT_models.keys()), default="DiT-B")
+    p.add_argument("--epochs", type=int, default=1400)
+    p.add_argument("--global-batch-size", type=int, default=256)
+    p.add_argument("--global-seed", type=int, default=0)
+    p.add_argument("--num-workers", type=int, default=4)
+    p.add_argument("--log-every", type=int, default=100)
+    p.add_argument("--ckpt-every", type=int, default=50000)
+    p.add_argument("--seq-len", type=int, default=128)
+    p.add_argument("--stride", type=int, default=16)
+    p.add_argument("--use-amp", type=bool, default=True)  # bf16 MFMA tier; no GradScaler needed
+    p.add_argument("--ckpt", type=str, default=None)
+    p.add_argument("--dist", type=str, default="nccl")
+    p.add_argument("--fine-tune-ids", type=int, nargs="+")
+    p.add_argument("--noise-schedule", type=str, default="squaredcos_cap_v2")
+    p.add_argument("--l1-loss", type=bool, default=True)
+    p.add_argument("--lr", type=float, default=1e-4)
+    p.add_argument("--relearn-embeds", type=bool, default=False)
+    p.add_argument("--embed-only-epochs", type=int, default=0)
+    p.add_argument("--synthetic", action="store_true", help="train on synthetic windows (no `slider` needed)")
+    p.add_argument("--steps-per-epoch", type=int, default=1000)
+    p.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    main(p.parse_args())
