@@ -44,6 +44,11 @@ int launch_mask_rows(int prec, float* a, void* a_te, int N, int Np, int C, hipSt
 int launch_unpad_rows(const float* src, int ld_src, float* dst, int cols, int rows, hipStream_t st);
 int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_t st);
 
+// wgrad.hip (bf16 tier): transpose-free weight-gradient product and bias-gradient column sums
+int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int Nx, int M, float* out, float* ws,
+                    size_t ws_elems, hipStream_t st);
+int launch_colsum_bf16(const void* a, int ld, int M, int N, float* out, hipStream_t st);
+
 // sampler.hip
 struct StepCoefs;  // device table, 8 floats per step
 int launch_sampler_step(const float* coefs, int mode, float eta, const float* model_out, const float* x,

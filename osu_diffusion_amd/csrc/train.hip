@@ -73,6 +73,22 @@ int wgrad(osud_dit* m, const void* Y, const void* X, int My, int Nx, int K, floa
   return launch_splitk_reduce(m->bw.splitk, S, (size_t)My * Nx, out, (size_t)My * Nx, st);
 }
 
+// dW[Ny][Nx] = dC[:, :Ny]^T . A[:, :Nx] and db = column sums of dC.
+//   bf16 tier: transpose-free kernel (wgrad.hip) + a column-sum pass;
+//   f32 tier : transposes (the column sums ride along) + the generic GEMM.
+int weight_grad(osud_dit* m, const void* dC, int ld_dc, const void* A, int ld_a, int Ny, int Nx, int M, float* dW,
+                float* db, hipStream_t st) {
+  BwdWs& w = m->bw;
+  if (m->prec == OSUD_PREC_BF16) {
+    OSUD_TRY(launch_wgrad_tr(dC, ld_dc, A, ld_a, Ny, Nx, M, dW, w.splitk, w.splitk_elems, st));
+    if (db) OSUD_TRY(launch_colsum_bf16(dC, ld_dc, M, Ny, db, st));
+    return OSUD_OK;
+  }
+  OSUD_TRY(launch_transpose(m->prec, dC, ld_dc, w.tB, M, M, Ny, db, st));
+  OSUD_TRY(launch_transpose(m->prec, A, ld_a, w.tA, M, M, Nx, nullptr, st));
+  return wgrad(m, w.tB, w.tA, Ny, Nx, M, dW, Nx, st);
+}
+
 float* grad_of(osud_dit* m, const std::string& key) {
   auto it = m->grad.find(key);
   return it == m->grad.end() ? nullptr : it->second;
@@ -132,15 +148,11 @@ int dit_backward_impl(osud_dit* m, const float* dout, hipStream_t st) {
     OSUD_TRY(gemm(m, EPI_GELUGRAD_TE, w.dbr, D, bw.w2_t, D, Mp, 4 * D, D, w.dz1, 4 * D, nullptr, st, nullptr, 0, 0, 0,
                   nullptr, nullptr, sv.z1));
     OSUD_TRY(dbg_sync(st, "dgrad fc2 (gelu grad)"));
-    OSUD_TRY(launch_transpose(prec, w.dbr, D, w.tB, Mp, Mp, D, g_b2, st));
-    OSUD_TRY(launch_transpose(prec, sv.g, 4 * D, w.tA, Mp, Mp, 4 * D, nullptr, st));
-    OSUD_TRY(wgrad(m, w.tB, w.tA, D, 4 * D, Mp, G(p + "mlp.fc2.weight"), 4 * D, st));
+    OSUD_TRY(weight_grad(m, w.dbr, D, sv.g, 4 * D, D, 4 * D, Mp, G(p + "mlp.fc2.weight"), g_b2, st));
     OSUD_TRY(dbg_sync(st, "wgrad fc2"));
     OSUD_TRY(gemm(m, EPI_NONE_F32, w.dz1, 4 * D, bw.w1_t, 4 * D, Mp, D, 4 * D, w.du, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "dgrad fc1"));
-    OSUD_TRY(launch_transpose(prec, w.dz1, 4 * D, w.tB, Mp, Mp, 4 * D, g_b1, st));
-    OSUD_TRY(launch_transpose(prec, sv.u2, D, w.tA, Mp, Mp, D, nullptr, st));
-    OSUD_TRY(wgrad(m, w.tB, w.tA, 4 * D, D, Mp, G(p + "mlp.fc1.weight"), D, st));
+    OSUD_TRY(weight_grad(m, w.dz1, 4 * D, sv.u2, D, 4 * D, D, Mp, G(p + "mlp.fc1.weight"), g_b1, st));
     OSUD_TRY(dbg_sync(st, "wgrad fc1"));
     OSUD_TRY(launch_ln_mod_bwd(sv.h_mid, sv.stats2, w.du, m->ada, AC, base + 3 * D, base + 4 * D, dh, dh_other, w.dada, M,
                                Tp, D, st));
@@ -150,17 +162,13 @@ int dit_backward_impl(osud_dit* m, const float* dout, hipStream_t st) {
     OSUD_TRY(launch_gate_bwd(prec, dh, sv.br1, m->ada + base + 2 * D, AC, w.dbr, w.dada + base + 2 * D, M, Tp, D, st));
     OSUD_TRY(dbg_sync(st, "gate_bwd attn"));
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dbr, D, bw.w_o_t, D, Mp, D, D, w.dao, D, nullptr, st));
-    OSUD_TRY(launch_transpose(prec, w.dbr, D, w.tB, Mp, Mp, D, g_bo, st));
-    OSUD_TRY(launch_transpose(prec, sv.ao, D, w.tA, Mp, Mp, D, nullptr, st));
-    OSUD_TRY(wgrad(m, w.tB, w.tA, D, D, Mp, G(p + "attn.out_proj.weight"), D, st));
+    OSUD_TRY(weight_grad(m, w.dbr, D, sv.ao, D, D, D, Mp, G(p + "attn.out_proj.weight"), g_bo, st));
     OSUD_TRY(dbg_sync(st, "wgrad out_proj"));
     OSUD_TRY(launch_attention_bwd(prec, sv.qk, w.dao, sv.ao, sv.lse, w.dqkv, N, T, m->H, m->hd, st));
     OSUD_TRY(dbg_sync(st, "attention bwd"));
     OSUD_TRY(gemm(m, EPI_NONE_F32, w.dqkv, 3 * D, bw.w_qkv_t, 3 * D, Mp, D, 3 * D, w.du, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "dgrad qkv"));
-    OSUD_TRY(launch_transpose(prec, w.dqkv, 3 * D, w.tB, Mp, Mp, 3 * D, g_bqkv, st));
-    OSUD_TRY(launch_transpose(prec, sv.u1, D, w.tA, Mp, Mp, D, nullptr, st));
-    OSUD_TRY(wgrad(m, w.tB, w.tA, 3 * D, D, Mp, G(p + "attn.in_proj_weight"), D, st));
+    OSUD_TRY(weight_grad(m, w.dqkv, 3 * D, sv.u1, D, 3 * D, D, Mp, G(p + "attn.in_proj_weight"), g_bqkv, st));
     OSUD_TRY(dbg_sync(st, "wgrad qkv"));
     OSUD_TRY(launch_ln_mod_bwd(sv.h_in, sv.stats1, w.du, m->ada, AC, base, base + D, dh, dh_other, w.dada, M, Tp, D, st));
     OSUD_TRY(dbg_sync(st, "ln1 bwd"));

@@ -1,0 +1,288 @@
+// Weight-gradient product without operand transposes (bf16 tier):
+//     out[y][x] = sum_m P[m][y0 + y] * Q[m][x0 + x]          (m = token index)
+// P = gradient of a Linear's output [M][ldp], Q = its input activations [M][ldq], both row-major as
+// the forward/backward kernels left them, i.e. the contraction index m is the ROW index.  The MFMA
+// wants 8 consecutive m per lane for a fixed feature; gfx950's ds_read_b64_tr_b16 delivers exactly that
+// from a token-major LDS tile: each 16-lane group reads a 4-token x 16-feature block and every lane
+// receives one feature's 4 tokens (semantics pinned on hardware by tools/probes/tr_probe.hip).
+//
+// Structure = gemm.hip's: persistent workgroups, stages of 64 tokens HBM->LDS via global_load_lds
+// (1 KiB pieces), counted waits, one barrier per stage, 8 waves of (RY*32) x (RX*32) outputs, split over
+// the token axis (blockIdx.y) into fp32 partial slabs combined deterministically by splitk_reduce.
+// LDS image per stage: [64 tokens][BM features] | [64 tokens][BN features]; the 16-byte chunk index of a
+// token row is XOR-swizzled with (token&3)<<2 (source side) so the 4 token rows of one transposing read
+// fall into 4 different 64-byte bank segments.
+#include <stdlib.h>
+
+#include "gemm.h"
+
+namespace osud {
+
+namespace {
+
+constexpr int BKT = 64;  // tokens per stage
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+template <int OFF> __device__ __forceinline__ u32x2 ds_read_tr(uint32_t addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+
+template <int WY, int WX, int RY, int RX> struct WGeo {
+  static constexpr int BM = WY * RY * 32, BN = WX * RX * 32, NW = WY * WX, NT = 64 * NW;
+  static constexpr int ROWY = BM * 2, ROWX = BN * 2;               // bytes per token row
+  static constexpr int YB = BKT * ROWY, XB = BKT * ROWX, STAGE = YB + XB;
+  static constexpr int NSTAGE = STAGE * 3 <= 160 * 1024 ? 3 : 2;
+  static constexpr int PIECES = STAGE / 1024, PPW = PIECES / NW;   // 1 KiB LDS-DMA pieces per stage / per wave
+  static_assert(PIECES % NW == 0 && 1024 % ROWY == 0 && 1024 % ROWX == 0, "geometry");
+};
+
+// this wave's share of one 64-token stage
+template <typename G>
+__device__ __forceinline__ void stage_tokens(const char* gp, size_t ldp_b, const char* gq, size_t ldq_b, char* stage,
+                                             int wave, int lane) {
+#pragma unroll
+  for (int q = 0; q < G::PPW; ++q) {
+    const int piece = wave * G::PPW + q;  // wave-uniform
+    const bool isY = piece * 1024 < G::YB;
+    const int rowb = isY ? G::ROWY : G::ROWX;                // bytes per token row in this part
+    const int pb = isY ? piece * 1024 : piece * 1024 - G::YB;  // byte offset inside the part
+    const int lpr = rowb / 16;                                // lanes (16-byte chunks) per token row
+    const int tok = pb / rowb + lane / lpr, pos = lane % lpr;
+    const int c = pos ^ ((tok & 3) << 2);                     // source chunk for LDS position `pos`
+    const char* g = (isY ? gp + (size_t)tok * ldp_b : gq + (size_t)tok * ldq_b) + c * 16;
+    char* dst = stage + __builtin_amdgcn_readfirstlane(piece * 1024);
+    __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)dst, 16, 0, 0);
+  }
+}
+
+template <int RY, int RX> struct TFrag {
+  u32x2 y[RY][2], x[RX][2];
+};
+template <int RY, int RX, int S, int ROWY, int ROWX>
+__device__ __forceinline__ void read_frags(TFrag<RY, RX>& f, const uint32_t (&ya)[RY], const uint32_t (&xa)[RX], uint32_t so) {
+#pragma unroll
+  for (int i = 0; i < RY; ++i) {
+    f.y[i][0] = ds_read_tr<S * 16 * ROWY>(ya[i] + so);
+    f.y[i][1] = ds_read_tr<S * 16 * ROWY + 4 * ROWY>(ya[i] + so);
+  }
+#pragma unroll
+  for (int j = 0; j < RX; ++j) {
+    f.x[j][0] = ds_read_tr<S * 16 * ROWX>(xa[j] + so);
+    f.x[j][1] = ds_read_tr<S * 16 * ROWX + 4 * ROWX>(xa[j] + so);
+  }
+}
+template <int RY, int RX> __device__ __forceinline__ void mma_frags(f32x16 (&acc)[RY][RX], const TFrag<RY, RX>& f) {
+#pragma unroll
+  for (int i = 0; i < RY; ++i) {
+    u32x4 yv;
+    yv[0] = f.y[i][0][0]; yv[1] = f.y[i][0][1]; yv[2] = f.y[i][1][0]; yv[3] = f.y[i][1][1];
+#pragma unroll
+    for (int j = 0; j < RX; ++j) {
+      u32x4 xv;
+      xv[0] = f.x[j][0][0]; xv[1] = f.x[j][0][1]; xv[2] = f.x[j][1][0]; xv[3] = f.x[j][1][1];
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, xv), __builtin_bit_cast(bf16x8, yv),
+                                                          acc[i][j], 0, 0, 0);
+    }
+  }
+}
+#define OSUD_WG_WAIT(n)                                     \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory");  \
+  __builtin_amdgcn_sched_barrier(0)
+
+struct WgradP {
+  const bf16_t* P;
+  const bf16_t* Q;
+  int ldp, ldq;   // elements
+  int Ny, Nx, M;  // output rows (features of P), output cols (features of Q), tokens
+  float* out;     // [splits][Ny][Nx] fp32
+  int split_k;
+  size_t split_stride;
+};
+
+template <int WY, int WX, int RY, int RX>
+__global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(WgradP p) {
+  using G = WGeo<WY, WX, RY, RX>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wy = wave / WX, wx = wave % WX;
+  const int frow = lane & 31, fhalf = lane >> 5;
+
+  const int ntx = p.Nx / G::BN, ntiles = (p.Ny / G::BM) * ntx;
+  // this split's share of the token axis (any split count: ranges differ by at most one stage)
+  const int st_total = p.M / BKT;
+  const int st_begin = (int)((long)blockIdx.y * st_total / p.split_k);
+  const int nst = (int)((long)(blockIdx.y + 1) * st_total / p.split_k) - st_begin;
+  const size_t ldp_b = (size_t)p.ldp * 2, ldq_b = (size_t)p.ldq * 2;
+  const char* gp0 = reinterpret_cast<const char*>(p.P) + (size_t)st_begin * BKT * ldp_b;
+  const char* gq0 = reinterpret_cast<const char*>(p.Q) + (size_t)st_begin * BKT * ldq_b;
+  float* outp = p.out + (size_t)blockIdx.y * p.split_stride;
+
+  // per-lane LDS byte addresses (stage 0, k-substep 0, first of the two transposing reads):
+  //   token row = 8*fhalf + ((lane&15)>>2), feature = block + 32*i + 16*((lane>>4)&1) + 4*(lane&3)
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_void*)smem;
+  const int tok0 = 8 * fhalf + ((lane & 15) >> 2);
+  const int sw = tok0 & 3;                                     // (token&3); +4 rows keeps it
+  const int fbyte = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);   // byte offset inside a 64-byte (32-feature) group
+  uint32_t ya[RY], xa[RX];
+#pragma unroll
+  for (int i = 0; i < RY; ++i) {
+    const int hi = (wy * RY + i) ^ sw;  // 64-byte group index, swizzled (chunk bits 2..3 <-> group bits 0..1)
+    ya[i] = lds0 + tok0 * G::ROWY + hi * 64 + fbyte;
+  }
+#pragma unroll
+  for (int j = 0; j < RX; ++j) {
+    const int hi = (wx * RX + j) ^ sw;
+    xa[j] = lds0 + G::YB + tok0 * G::ROWX + hi * 64 + fbyte;
+  }
+
+  const int G8 = gridDim.x;
+  int first;
+  {
+    const int b = blockIdx.x, q = G8 >> 3, r = G8 & 7, xcd = b & 7, idx = b >> 3;
+    first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int ic_tile = first, ic_st = 0, issued = 0, consumed = 0;
+  auto issue_next = [&]() {
+    if (ic_tile < ntiles) {
+      const int ty = ic_tile / ntx, tx = ic_tile % ntx;
+      const char* gp = gp0 + (size_t)ic_st * BKT * ldp_b + (size_t)ty * G::BM * 2;
+      const char* gq = gq0 + (size_t)ic_st * BKT * ldq_b + (size_t)tx * G::BN * 2;
+      stage_tokens<G>(gp, ldp_b, gq, ldq_b, smem + (issued % G::NSTAGE) * G::STAGE, wave, lane);
+      ++issued;
+      if (++ic_st == nst) {
+        ic_st = 0;
+        ic_tile += G8;
+      }
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < G::NSTAGE - 1; ++i) issue_next();
+
+  for (int tile = first; tile < ntiles; tile += G8) {
+    const int ty = tile / ntx, tx = tile % ntx;
+    f32x16 acc[RY][RX];
+#pragma unroll
+    for (int i = 0; i < RY; ++i)
+#pragma unroll
+      for (int j = 0; j < RX; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int st = 0; st < nst; ++st) {
+      const int ahead = issued - consumed - 1;
+      if (ahead <= 0 || G::NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else if (G::PPW == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      issue_next();
+      const uint32_t so = (uint32_t)((consumed % G::NSTAGE) * G::STAGE);
+      TFrag<RY, RX> f0, f1;
+      read_frags<RY, RX, 0, G::ROWY, G::ROWX>(f0, ya, xa, so);
+      read_frags<RY, RX, 1, G::ROWY, G::ROWX>(f1, ya, xa, so);
+      if constexpr (RY + RX == 6) { OSUD_WG_WAIT(12); } else { OSUD_WG_WAIT(8); }
+      mma_frags<RY, RX>(acc, f0);
+      read_frags<RY, RX, 2, G::ROWY, G::ROWX>(f0, ya, xa, so);
+      if constexpr (RY + RX == 6) { OSUD_WG_WAIT(12); } else { OSUD_WG_WAIT(8); }
+      mma_frags<RY, RX>(acc, f1);
+      read_frags<RY, RX, 3, G::ROWY, G::ROWX>(f1, ya, xa, so);
+      if constexpr (RY + RX == 6) { OSUD_WG_WAIT(12); } else { OSUD_WG_WAIT(8); }
+      mma_frags<RY, RX>(acc, f0);
+      OSUD_WG_WAIT(0);
+      mma_frags<RY, RX>(acc, f1);
+      ++consumed;
+    }
+    // lane holds, for y = ..+frow, x = xb + 8g + 4*fhalf + {0..3}
+#pragma unroll
+    for (int i = 0; i < RY; ++i) {
+      const int y = ty * G::BM + wy * RY * 32 + i * 32 + frow;
+#pragma unroll
+      for (int j = 0; j < RX; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int x = tx * G::BN + wx * RX * 32 + j * 32 + 8 * g + 4 * fhalf;
+          store4(outp + (size_t)y * p.Nx + x, acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2],
+                 acc[i][j][4 * g + 3]);
+        }
+    }
+  }
+}
+
+// column sums of a bf16 [M][N] matrix: out[c] += sum_m a[m][c]   (bias gradients)
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ a, int ld, int M, float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx, r0 = blockIdx.y * 512;
+  float s = 0.f;
+  const int r1 = r0 + 512 < M ? r0 + 512 : M;
+  for (int r = r0 + ty; r < r1; r += 4) s += bf2f(a[(size_t)r * ld + c]);
+  part[ty][tx] = s;
+  __syncthreads();
+  if (ty == 0) atomicAdd(out + c, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+}
+
+int num_cus_w() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <int WY, int WX, int RY, int RX> int launch_wg(const WgradP& p, hipStream_t st) {
+  using G = WGeo<WY, WX, RY, RX>;
+  const size_t lds = (size_t)G::NSTAGE * G::STAGE;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<WY, WX, RY, RX>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  const int ntiles = (p.Ny / G::BM) * (p.Nx / G::BN);
+  int grid = num_cus_w() / p.split_k;
+  if (grid < 1) grid = 1;
+  if (grid > ntiles || p.split_k > 1) grid = ntiles;  // with splits: one tile per workgroup
+  hipLaunchKernelGGL((wgrad_kernel<WY, WX, RY, RX>), dim3(grid, p.split_k), dim3(G::NT), lds, st, p);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+}  // namespace
+
+// out[Ny][Nx] (fp32, ld = Nx) = P[:, 0:Ny]^T . Q[:, 0:Nx] over M tokens; `ws` holds the split-K partial slabs.
+int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int Nx, int M, float* out, float* ws,
+                    size_t ws_elems, hipStream_t st) {
+  OSUD_CHECK_ARG(Ny % 128 == 0 && Nx % 128 == 0 && M % BKT == 0 && ldp % 8 == 0 && ldq % 8 == 0,
+                 "wgrad: Ny=%d Nx=%d must be multiples of 128, M=%d of 64", Ny, Nx, M);
+  const bool big = Ny % 256 == 0 && Nx % 256 == 0;
+  const int tiles = big ? (Ny / 256) * (Nx / 256) : (Ny / 128) * (Nx / 128);
+  const int stages = M / BKT;
+  // fill the chip in ONE round: splits = CUs / tiles, each split at least 8 stages (512 tokens)
+  int S = num_cus_w() / tiles;
+  if (S > 32) S = 32;
+  while (S > 1 && (stages / S < 8 || (size_t)S * Ny * Nx > ws_elems)) --S;
+  if (S < 1) S = 1;
+  WgradP p{};
+  p.P = (const bf16_t*)P; p.Q = (const bf16_t*)Q; p.ldp = ldp; p.ldq = ldq; p.Ny = Ny; p.Nx = Nx; p.M = M;
+  p.split_k = S; p.split_stride = (size_t)Ny * Nx; p.out = S > 1 ? ws : out;
+  OSUD_TRY(big ? (launch_wg<2, 4, 4, 2>(p, st)) : (launch_wg<2, 2, 2, 2>(p, st)));
+  if (S > 1) OSUD_TRY(launch_splitk_reduce(ws, S, (size_t)Ny * Nx, out, (size_t)Ny * Nx, st));
+  return OSUD_OK;
+}
+
+int launch_colsum_bf16(const void* a, int ld, int M, int N, float* out, hipStream_t st) {
+  OSUD_CHECK_ARG(N % 64 == 0, "colsum: N=%d must be a multiple of 64", N);
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(N / 64, (M + 511) / 512), dim3(256), 0, st, (const bf16_t*)a, ld, M, out);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+}  // namespace osud
