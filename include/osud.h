@@ -142,6 +142,10 @@ int osud_dit_forward_train(osud_dit* m, const float* x, const int64_t* t, const 
                            const int64_t* y, int N, int T, float* out, osud_stream stream);
 /* backward of the last osud_dit_forward_train: dout (N,4,T) = dLoss/d(out) */
 int osud_dit_backward(osud_dit* m, const float* dout, osud_stream stream);
+/* The same backward in phases, so the host can start reducing finished gradient slices while the rest is
+ * still being computed: phase 0 = final layer, phase p (1..depth) = block depth-p, phase depth+1 = first
+ * linear + conditioning path (adaLN / embedder / class-table gradients).  Phases must run in order. */
+int osud_dit_backward_phases(osud_dit* m, const float* dout, int phase_lo, int phase_hi, osud_stream stream);
 /* x_t = sqrt(ac_t) x_0 + sqrt(1-ac_t) noise   (gaussian_diffusion.py:231-247); t = step indices */
 int osud_q_sample(const osud_sched* s, const float* x_start, const int64_t* t, const float* noise, int N, int T,
                   float* x_t, osud_stream stream);

@@ -55,6 +55,7 @@ _SIGNATURES = {
     "osud_dit_refresh": (_i, [_vp, _vp]),
     "osud_dit_forward_train": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "osud_dit_backward": (_i, [_vp, _vp, _vp]),
+    "osud_dit_backward_phases": (_i, [_vp, _vp, _i, _i, _vp]),
     "osud_q_sample": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "osud_train_loss": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "osud_adamw_ema_step": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _sz, _sz, _f, _vp]),

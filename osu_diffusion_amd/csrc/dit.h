@@ -82,6 +82,7 @@ struct osud_dit {
   void *w_ada_t = nullptr, *w_t2_t = nullptr;  // transposed copies (training)
   bool transposed_ready = false;
   BwdWs bw;
+  int bw_dh_cur = 0;  // which residual-gradient buffer currently holds d(loss)/d(h) (phased backward)
   void* z0 = nullptr;  // [Np][D] TE: TimestepEmbedder pre-activation
   // last training forward (inputs needed again by the backward pass)
   const int64_t* last_y = nullptr;

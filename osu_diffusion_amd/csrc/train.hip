@@ -96,12 +96,17 @@ float* grad_of(osud_dit* m, const std::string& key) {
 
 }  // namespace
 
-int dit_backward_impl(osud_dit* m, const float* dout, hipStream_t st) {
+// Phases: 0 = zero the atomic accumulators + final layer; p in 1..L = block L-p; L+1 = first linear +
+// conditioning path.  Running them in order [0, L+1] is the whole backward; the host may interleave
+// gradient all-reduces of finished parameter slices between phases.
+int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi, hipStream_t st) {
   OSUD_CHECK_ARG(m && dout, "backward: null argument");
   OSUD_CHECK_ARG(m->training && m->last_N > 0, "backward: no training forward to differentiate");
   const int N = m->last_N, T = m->last_T, D = m->D, L = m->L, prec = m->prec, AC = m->ada_cols;
   const int Tp = round_up(T, 64), M = N * Tp, Mp = round_up(M, 128), Np = round_up(N, 128);
   OSUD_CHECK_ARG(T == Tp && M == Mp, "training needs seq_len %% 64 == 0 and batch*seq_len %% 128 == 0 (got N=%d, T=%d)", N, T);
+  OSUD_CHECK_ARG(phase_lo >= 0 && phase_hi <= L + 1 && phase_lo <= phase_hi, "backward: phases %d..%d outside 0..%d", phase_lo,
+                 phase_hi, L + 1);
   for (auto& kv : m->have)
     if (kv.first != "xoc_embedder.playfield_size" && !grad_of(m, kv.first)) {
       set_error("backward: no gradient buffer bound for '%s'", kv.first.c_str());
@@ -116,6 +121,9 @@ int dit_backward_impl(osud_dit* m, const float* dout, hipStream_t st) {
   };
   auto G = [&](const std::string& k) { return grad_of(m, k); };
 
+  float* dh = m->bw_dh_cur ? w.dhB : w.dhA;
+  float* dh_other = m->bw_dh_cur ? w.dhA : w.dhB;
+  if (phase_lo == 0) {
   // ---- accumulators that are filled by atomics
   OSUD_TRY(zero(w.dada, (size_t)Np * AC * 4));
   OSUD_TRY(zero(G("final_layer.linear.weight"), (size_t)m->C2 * D * 4));
@@ -124,14 +132,18 @@ int dit_backward_impl(osud_dit* m, const float* dout, hipStream_t st) {
 
   // ---- final layer
   const LayerSaved& fin = m->saved[(size_t)L];
-  float* dh = w.dhA;
-  float* dh_other = w.dhB;
+  dh = w.dhA;
+  dh_other = w.dhB;
   OSUD_TRY(launch_final_bwd(fin.h_in, fin.stats1, dout, m->w_f, m->ada, AC, L * 6 * D, L * 6 * D + D, dh, w.dada,
                             G("final_layer.linear.weight"), G("final_layer.linear.bias"), N, T, Tp, D, m->C2, st));
     OSUD_TRY(dbg_sync(st, "final_bwd"));
 
+  }  // phase 0
+
   // ---- blocks, last to first
   for (int l = L - 1; l >= 0; --l) {
+    const int phase = L - l;
+    if (phase < phase_lo || phase > phase_hi) continue;
     const BlockWeights& bw = m->blk[(size_t)l];
     const LayerSaved& sv = m->saved[(size_t)l];
     const std::string p = "blocks." + std::to_string(l) + ".";
@@ -174,6 +186,9 @@ int dit_backward_impl(osud_dit* m, const float* dout, hipStream_t st) {
     OSUD_TRY(dbg_sync(st, "ln1 bwd"));
     std::swap(dh, dh_other);  // dh = grad wrt h_in
   }
+
+  m->bw_dh_cur = dh == w.dhB ? 1 : 0;
+  if (phase_hi < L + 1) return OSUD_OK;
 
   // ---- token embedding linear: h0 = e0 We^T + be   (inputs need no gradient)
   {
@@ -408,7 +423,13 @@ extern "C" int osud_dit_forward_train(osud_dit* m, const float* x, const int64_t
 }
 
 extern "C" int osud_dit_backward(osud_dit* m, const float* dout, osud_stream stream) {
-  return dit_backward_impl(m, dout, (hipStream_t)stream);
+  OSUD_CHECK_ARG(m, "backward: null handle");
+  return dit_backward_impl(m, dout, 0, m->L + 1, (hipStream_t)stream);
+}
+
+extern "C" int osud_dit_backward_phases(osud_dit* m, const float* dout, int phase_lo, int phase_hi, osud_stream stream) {
+  OSUD_CHECK_ARG(m, "backward: null handle");
+  return dit_backward_impl(m, dout, phase_lo, phase_hi, (hipStream_t)stream);
 }
 
 extern "C" int osud_q_sample(const osud_sched* s, const float* x_start, const int64_t* t, const float* noise, int N,

@@ -16,6 +16,7 @@ from __future__ import annotations
 import copy
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import torch
@@ -124,12 +125,65 @@ def native_forward_train(model, x, t, o, c, y):
     return out
 
 
-def native_backward(model, dout):
-    """Runs the native backward of the last training forward; gradients land in model._arena.grads."""
+def native_backward(model, dout, phases=None):
+    """Runs the native backward of the last training forward (all of it, or phases [lo, hi]); gradients
+    land in model._arena.grads."""
     h = model._handle
     dout = dout.contiguous().float()
     with torch.cuda.device(dout.device):
-        _lib.check(_lib.lib().osud_dit_backward(h, _lib.ptr(dout), _lib.stream_ptr(dout.device)))
+        if phases is None:
+            _lib.check(_lib.lib().osud_dit_backward(h, _lib.ptr(dout), _lib.stream_ptr(dout.device)))
+        else:
+            _lib.check(_lib.lib().osud_dit_backward_phases(h, _lib.ptr(dout), int(phases[0]), int(phases[1]),
+                                                           _lib.stream_ptr(dout.device)))
+    return dout
+
+
+def overlap_slices(arena, depth):
+    """Element ranges of the flat gradient arena in the order they become final during the phased backward:
+    ("block", l, lo, hi) right after block l's phase — its 8 attention/MLP tensors are contiguous — then the
+    ("tail", ...) ranges that need the last phase (embedders + class table, every adaLN pair, final layer)."""
+    off = {n: (int(o), int(o + s)) for n, o, s in zip(arena.names, arena.offsets[:-1], arena.sizes)}
+    blocks, tail = [], []
+    for l in range(depth):
+        lo = off[f"blocks.{l}.attn.in_proj_weight"][0]
+        hi = off[f"blocks.{l}.mlp.fc2.bias"][1]
+        blocks.append(("block", l, lo, hi))
+        tail.append(("tail", l, off[f"blocks.{l}.adaLN_modulation.1.weight"][0], off[f"blocks.{l}.adaLN_modulation.1.bias"][1]))
+    tail.insert(0, ("tail", -1, 0, off["blocks.0.attn.in_proj_weight"][0]))
+    tail.append(("tail", depth, off["final_layer.linear.weight"][0], arena.total))
+    covered = sorted((lo, hi) for _, _, lo, hi in blocks + tail)
+    assert covered[0][0] == 0 and covered[-1][1] == arena.total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    return blocks, tail
+
+
+def backward_with_overlapped_allreduce(model, dout, group=None, force=False):
+    """Backward in phases; each block's gradient slice is SUM-all-reduced (async, RCCL's own stream) as soon
+    as its phase is enqueued, overlapping the exchange with the remaining backward compute — the role of
+    DDP's bucketed reducer (train.py:152,257).  Returns the 1/world factor for the optimizer."""
+    import torch.distributed as dist
+
+    inited = dist.is_available() and dist.is_initialized()
+    active = inited and (dist.get_world_size(group) > 1 or force)  # force: exercise RCCL even on one rank
+    if not (active or force):
+        native_backward(model, dout)
+        return 1.0
+    arena, depth = model._arena, model.depth
+    blocks, tail = overlap_slices(arena, depth)
+    reduce = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)) if active else (lambda t: None)
+    handles = []
+    dout = native_backward(model, dout, phases=(0, 0))
+    for p in range(1, depth + 1):
+        native_backward(model, dout, phases=(p, p))
+        _, _, lo, hi = blocks[depth - p]
+        handles.append(reduce(arena.grads[lo:hi]))
+    native_backward(model, dout, phases=(depth + 1, depth + 1))
+    for _, _, lo, hi in tail:
+        handles.append(reduce(arena.grads[lo:hi]))
+    for h in handles:
+        if h is not None:
+            h.wait()
+    return 1.0 / dist.get_world_size(group) if active else 1.0
 
 
 class _DiTFunction(torch.autograd.Function):
@@ -181,6 +235,7 @@ class NativeTrainer:
         self.exp_avg = torch.zeros_like(self.arena.flat)
         self.exp_avg_sq = torch.zeros_like(self.arena.flat)
         self.step_count = 0
+        self.force_phased = os.environ.get("OSUD_FORCE_PHASED", "0") == "1"  # exercise the phased path on 1 GPU
         import torch.distributed as dist
 
         if broadcast_init and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -218,8 +273,7 @@ class NativeTrainer:
             dout = torch.empty_like(out)
             _lib.check(L.osud_train_loss(d._sched.handle, self.use_l1, _lib.ptr(out), _lib.ptr(x0), _lib.ptr(x_t), _lib.ptr(noise),
                                          _lib.ptr(t), B, T, _lib.ptr(terms), _lib.ptr(dout), st))
-            native_backward(model, dout)
-            scale = allreduce_mean_(self.arena.grads, self.group)
+            scale = backward_with_overlapped_allreduce(model, dout, self.group, force=self.force_phased)
             self.optimizer_step(scale)
         return terms
 

@@ -60,3 +60,22 @@ def test_allreduce_mean_two_ranks_gloo():
 def test_allreduce_mean_without_process_group_is_identity():
     t = torch.ones(4)
     assert allreduce_mean_(t) == 1.0 and torch.equal(t, torch.ones(4))
+
+
+def test_overlap_slices_cover_the_arena_exactly_once():
+    from osu_diffusion_amd.models import DiT
+    from osu_diffusion_amd.training import ParamArena, overlap_slices
+
+    m = DiT(depth=3, hidden_size=128, num_heads=2, context_size=144, num_classes=4)
+    arena = ParamArena(m)
+    blocks, tail = overlap_slices(arena, 3)
+    assert [b[1] for b in blocks] == [0, 1, 2] and len(tail) == 3 + 2
+    seen = torch.zeros(arena.total, dtype=torch.int32)
+    for _, _, lo, hi in blocks + tail:
+        seen[lo:hi] += 1
+    assert bool((seen == 1).all())
+    names = dict(zip(arena.names, zip(arena.offsets[:-1], arena.sizes)))
+    lo, n = names["blocks.1.mlp.fc1.weight"]
+    assert blocks[1][2] <= lo and lo + n <= blocks[1][3]
+    lo, n = names["y_embedder.embedding_table.weight"]
+    assert tail[0][2] <= lo and lo + n <= tail[0][3]
