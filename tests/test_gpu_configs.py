@@ -1,0 +1,150 @@
+"""GPU (-m gpu): the BASELINE.json configurations as parity / property cases.
+
+config 1  DiT-S, seq-len 64, batch 4 training step (also the train_nodist.py variant: t == 0 for every
+          sample, train_nodist.py:222) against the oracle's autograd;
+config 5  DiT-XL geometry (hidden 1152, 16 heads -> head_dim 72) on a 2-block stack, T = 256: forward and
+          backward in the fp32 tier; the bf16 tier must refuse head_dim 72 loudly;
+configs 2/4 at FULL bench size through size-independent properties (determinism, graph == eager,
+          cfg_scale = 1 equals the conditional forward, rows are independent, finite outputs)."""
+import pytest
+import torch
+
+from oracle import diffusion_oracle as do
+from oracle import dit_oracle as mo
+from osu_diffusion_amd import _lib
+from osu_diffusion_amd.diffusion import create_diffusion
+from osu_diffusion_amd.models import DiT, DiT_models
+from osu_diffusion_amd.synthetic import randomize_zero_init, synthetic_windows
+from osu_diffusion_amd.training import NativeTrainer
+from tests.helpers import maxdiff
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build(shape, sd, precision, train=False):
+    m = DiT(depth=shape.depth, hidden_size=shape.hidden, num_heads=shape.heads, context_size=shape.context,
+            num_classes=shape.num_classes, class_dropout_prob=0.2, precision=precision)
+    m.load_state_dict(sd)
+    m = m.to(DEV)
+    return m.train() if train else m.eval()
+
+
+def oracle_step(shape, sd, x, o, c, y, t, noise, loss="l1"):
+    osd = {k: v.clone().requires_grad_(k != "xoc_embedder.playfield_size") for k, v in sd.items()}
+    sch = do.create_schedule("", "squaredcos_cap_v2")
+    terms = do.training_losses(sch, lambda xx, tt: mo.forward(osd, shape, xx, tt, o, c, y), x, t, noise, loss=loss)
+    terms["loss"].mean().backward()
+    return terms, {k: v.grad for k, v in osd.items() if v.grad is not None}
+
+
+@pytest.mark.parametrize("t_mode", ["uniform", "refine_t0"])
+def test_config1_dit_s_training_step(t_mode):
+    shape = mo.shape_of("DiT-S", num_classes=16)
+    sd = mo.seeded_state_dict(shape, 31)
+    (x, o, c), y = synthetic_windows(4, 64, 16, seed=8)
+    g = torch.Generator().manual_seed(9)
+    t = torch.zeros(4, dtype=torch.long) if t_mode == "refine_t0" else torch.randint(0, 1000, (4,), generator=g)
+    noise = torch.randn(4, 2, 64, generator=g)
+    terms, grads = oracle_step(shape, sd, x, o, c, y, t, noise)
+    tr = NativeTrainer(build(shape, sd, "fp32"), create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True))
+    got = tr.step(x, o, c, y, t=t, noise=noise).cpu()
+    ref = terms["loss"].detach()
+    assert float(((got[2] - ref).abs() / ref.abs().clamp_min(1.0)).max()) < 2e-5
+    gv = tr.arena.grad_views()
+    for k, gref in grads.items():
+        assert maxdiff(gv[k].cpu(), gref) < 2e-5 + 2e-3 * float(gref.abs().max()), k
+
+
+def test_config5_xl_head_dim_72_fp32_forward_and_backward():
+    shape = mo.DitShape(depth=2, hidden=1152, heads=16, num_classes=8)  # DiT-XL geometry, 2 of its 28 blocks
+    sd = mo.seeded_state_dict(shape, 41)
+    (x, o, c), y = synthetic_windows(2, 256, 8, seed=3)
+    t = torch.tensor([10, 800])
+    m = build(shape, sd, "fp32")
+    with torch.no_grad():
+        got = m(x, t, o, c, y).cpu()
+        want = mo.forward(sd, shape, x, t, o, c, y)
+    assert maxdiff(got, want) < 3e-4 * max(1.0, float(want.abs().max()))
+    noise = torch.randn(2, 2, 256, generator=torch.Generator().manual_seed(1))
+    terms, grads = oracle_step(shape, sd, x, o, c, y, t, noise)
+    tr = NativeTrainer(m, create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True))
+    out = tr.step(x, o, c, y, t=t, noise=noise).cpu()
+    assert maxdiff(out[2], terms["loss"].detach()) < 1e-4
+    gv = tr.arena.grad_views()
+    for k in ("blocks.0.attn.in_proj_weight", "blocks.1.mlp.fc2.weight", "xoc_embedder.mlp.0.weight",
+              "blocks.0.adaLN_modulation.1.weight", "final_layer.linear.weight"):
+        assert maxdiff(gv[k].cpu(), grads[k]) < 2e-5 + 2e-3 * float(grads[k].abs().max()), k
+
+
+def test_bf16_tier_refuses_head_dim_72_loudly():
+    shape = mo.DitShape(depth=1, hidden=1152, heads=16, num_classes=4)
+    m = build(shape, mo.seeded_state_dict(shape, 1), "bf16")
+    (x, o, c), y = synthetic_windows(2, 64, 4, seed=0)
+    with torch.no_grad(), pytest.raises(_lib.NativeError, match="head_dim"):
+        m(x, torch.zeros(2, dtype=torch.long), o, c, y)
+
+
+@pytest.fixture(scope="module")
+def dit_b():
+    torch.manual_seed(0)
+    m = DiT_models["DiT-B"](num_classes=52670, context_size=144, precision="bf16").to(DEV)
+    return randomize_zero_init(m, seed=0).eval()
+
+
+def test_full_size_sampling_properties(dit_b):
+    """BASELINE config 4 shapes: 64 windows x2 (CFG 4.0), T = 128, DiT-B, bf16 tier."""
+    n, T_ = 64, 128
+    (x, o, c), y = synthetic_windows(n, T_, 52670, seed=5, train_offsets=False)
+    o, c = torch.cat([o, o]).to(DEV), torch.cat([c, c]).to(DEV)
+    y2 = torch.cat([y, torch.full_like(y, 52670)]).to(DEV)
+    z = torch.randn(2 * n, 2, T_, device=DEV)
+    t = torch.full((2 * n,), 777, device=DEV)
+    with torch.no_grad():
+        a = dit_b.forward_with_cfg(z, t, o, c, y2, 4.0)
+        b = dit_b.forward_with_cfg(z, t, o, c, y2, 4.0)
+        assert torch.equal(a, b) and torch.isfinite(a).all()  # deterministic
+        assert torch.equal(a[:n, :2], a[n:, :2])  # both halves carry the same guided eps
+        one = dit_b.forward_with_cfg(z, t, o, c, y2, 1.0)  # cfg_scale 1 -> the conditional prediction
+        zz = torch.cat([z[:n], z[:n]])
+        plain = dit_b(zz, t, o, c, y2)
+        assert maxdiff(one[:n, :2].cpu(), plain[:n, :2].cpu()) < 1e-5
+        assert torch.equal(one[:, 2:], plain[:, 2:])
+        # rows are independent: a sub-batch gives the same rows (same tile shapes are not guaranteed -> tolerance)
+        sub = dit_b(zz[:8], t[:8], o[:8], c[:8], y2[:8])
+        assert maxdiff(sub.cpu(), plain[:8].cpu()) < 2e-2 * float(plain.abs().max())
+    d = create_diffusion("1000", noise_schedule="squaredcos_cap_v2")
+    kw = dict(o=o, c=c, y=y2, cfg_scale=4.0, attn_mask=None)
+    noise = torch.randn(6, 2 * n, 2, T_, device=DEV)
+    import os
+    outs = []
+    for graph in ("0", "1"):
+        os.environ["OSUD_NO_GRAPH"] = graph
+        s = z.clone()
+        d.run_steps(dit_b.forward_with_cfg, s, kw, first_step=999, last_step=994, step_noise=noise)
+        outs.append(s)
+    os.environ["OSUD_NO_GRAPH"] = "0"
+    assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()  # graph replay == eager
+    assert float(outs[0].min()) >= -40 and float(outs[0].max()) <= 40
+
+
+def test_full_size_training_step_properties():
+    """BASELINE config 2 shapes: DiT-B, batch 256 x 128 tokens, bf16 tier: finite loss, loss decreases over a
+    few steps on a fixed batch, label-dropout statistics, EMA tracks."""
+    torch.manual_seed(0)
+    m = DiT_models["DiT-B"](num_classes=52670, context_size=144, class_dropout_prob=0.2, precision="bf16").to(DEV)
+    m = randomize_zero_init(m, seed=0).train()
+    tr = NativeTrainer(m, create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True), lr=1e-4)
+    (x, o, c), y = synthetic_windows(256, 128, 52670, seed=1)
+    t = torch.randint(1, 1000, (256,), generator=torch.Generator().manual_seed(2))
+    noise = torch.randn(256, 2, 128, generator=torch.Generator().manual_seed(3))
+    w0 = tr.arena.flat.clone()
+    losses = [float(tr.step(x, o, c, y, t=t, noise=noise)[0].mean()) for _ in range(6)]
+    assert all(l == l and l < 10 for l in losses)  # finite
+    assert losses[-1] < losses[0], losses  # same batch, same noise: L1 term goes down
+    moved = (tr.arena.flat - w0).abs()
+    assert float(moved.max()) <= 9e-4 and float(moved.mean()) > 1e-5  # 6 Adam steps of lr 1e-4 (|m/sqrt(v)| ~ 1)
+    assert float((tr.ema_arena.flat - w0).abs().max()) <= 9e-4 * 1e-3 * 6 + 1e-6  # EMA moves (1 - 0.9999) of the way per step
+    drops = torch.stack([m.y_embedder.token_drop(torch.zeros(4096, dtype=torch.long, device=DEV)) for _ in range(4)])
+    frac = float((drops == 52670).float().mean())
+    assert 0.17 < frac < 0.23
