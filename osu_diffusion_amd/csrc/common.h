@@ -76,6 +76,21 @@ __device__ __forceinline__ void store4(float* p, float a, float b, float c, floa
   *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
 }
 
+// 2 consecutive elements (4 B bf16 / 8 B f32)
+__device__ __forceinline__ void store2(bf16_t* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = pack_bf2(a, b); }
+__device__ __forceinline__ void store2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+
+__device__ __forceinline__ void load2(const bf16_t* p, float& a, float& b) {
+  const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+  a = __uint_as_float(u << 16);
+  b = __uint_as_float(u & 0xffff0000u);
+}
+__device__ __forceinline__ void load2(const float* p, float& a, float& b) {
+  const float2 v = *reinterpret_cast<const float2*>(p);
+  a = v.x;
+  b = v.y;
+}
+
 // FAST = bf16 tier (hardware v_exp_f32 based), !FAST = parity tier (accurate expf / division)
 template <bool FAST> __device__ __forceinline__ float exp_t(float v) { return FAST ? __expf(v) : expf(v); }
 template <bool FAST> __device__ __forceinline__ float sigmoid_t(float v) {

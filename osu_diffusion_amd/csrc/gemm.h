@@ -51,6 +51,7 @@ struct GemmP {
   const float* res;  // EPI_GATE_RES: residual input [My][ldo]; nullptr = update `out` in place
   int split_k;       // > 1: blockIdx.y walks K in split_k equal ranges, range s writes out + s * split_stride (elements)
   size_t split_stride;
+  int tile_order;  // 0/1 = plain x-fastest runs per XCD (default), 2 = banded per XCD (fewer weight re-reads, not faster)
 };
 
 int launch_gemm(int prec, int epi, const GemmP& p, hipStream_t st);

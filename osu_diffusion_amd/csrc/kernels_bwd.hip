@@ -97,11 +97,11 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
     for (int i = 0; i < VPL / 2; ++i) {
       const int d = 2 * lane + 128 * i;
       const float2 dv = *reinterpret_cast<const float2*>(dh + row + d);
-      const float b0 = load_elem(br + row + d), b1 = load_elem(br + row + d + 1);
+      float b0, b1;
+      load2(br + row + d, b0, b1);
       acc[2 * i] += dv.x * b0;
       acc[2 * i + 1] += dv.y * b1;
-      store_elem(dbr + row + d, gv[2 * i] * dv.x);
-      store_elem(dbr + row + d + 1, gv[2 * i + 1] * dv.y);
+      store2(dbr + row + d, gv[2 * i] * dv.x, gv[2 * i + 1] * dv.y);
     }
   }
 #pragma unroll

@@ -145,8 +145,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ h
     const float2 h2 = *reinterpret_cast<const float2*>(sh + d);
     const float a = (v[2 * i] - mu) * rstd * (1.0f + s2.x) + h2.x;
     const float b = (v[2 * i + 1] - mu) * rstd * (1.0f + s2.y) + h2.y;
-    store_elem(orow + d, a);
-    store_elem(orow + d + 1, b);
+    store2(orow + d, a, b);
   }
 }
 
