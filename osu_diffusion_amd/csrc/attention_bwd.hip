@@ -12,7 +12,8 @@
 // pass B — each wave owns 32 keys and walks the queries (dK, dV).  S and dO.V^T are recomputed
 // in the orientation each pass needs (lane = the owned index), which keeps P / dS in registers
 // as MFMA B operands exactly like the forward kernel; the A operands that need the contraction
-// index contiguous come from transposed LDS copies (K^T, Q^T, dO^T) built once per workgroup.
+// index contiguous (K^T, Q^T, dO^T) are read straight from the row-major LDS tiles with
+// ds_read_b64_tr_b16, so no transposed copies exist (LDS 66 KB for T = 128 -> two workgroups per CU).
 // f32 tier: plain VALU kernels (one thread per query / per key).
 #include "kernels.h"
 
@@ -26,9 +27,25 @@ typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ u32x4 rowfrag(const char* tile, int row, int chunk) {
   return *reinterpret_cast<const u32x4*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
 }
-__device__ __forceinline__ u32x4 tfrag(const char* tt, int ts, int d, int e0) {
-  const u32x2 lo = *reinterpret_cast<const u32x2*>(tt + d * ts + e0 * 2);
-  const u32x2 hi = *reinterpret_cast<const u32x2*>(tt + d * ts + (e0 + 8) * 2);
+// A operand whose contraction index is the ROW of a row-major [rows][64 d] tile (128-byte rows, chunk index
+// XOR-swizzled with (row>>1)&7): lane (d = d0 + (lane&31), half) gets, for column d, the 8 rows
+//   r0 + 4*half + {0..3}  and  r0 + 8 + 4*half + {0..3}
+// — the same permuted order in which P / dS leave the S-layout registers (see pack8) — via two transposing reads
+// (each 16-lane group: 4 rows x 16 columns; semantics pinned by tools/probes/tr_probe.hip).
+__device__ __forceinline__ u32x2 ds_tr(uint32_t addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+  return v;
+}
+__device__ __forceinline__ u32x4 trfrag(const char* tile, int r0, int d0, int lane) {
+  const int row = r0 + 4 * (lane >> 5) + ((lane & 15) >> 2);
+  const int colb = (d0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;  // byte offset of this lane's 4 columns
+  const int chunk = colb >> 4, within = colb & 15;
+  const uint32_t base = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)tile;
+  const uint32_t a0 = base + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) + within;
+  const uint32_t a1 = base + (row + 8) * 128 + ((chunk ^ (((row + 8) >> 1) & 7)) << 4) + within;
+  const u32x2 lo = ds_tr(a0), hi = ds_tr(a1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   u32x4 v;
   v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
   return v;
@@ -50,15 +67,11 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __rest
                                                             bf16_t* __restrict__ dqkv, int T, int D, float c1,
                                                             float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int TS = T * 2 + 8;  // padded row stride of the transposed tiles (bytes)
   char* Qs = smem;
   char* Ks = Qs + T * 128;
   char* Vs = Ks + T * 128;
-  char* Os = Vs + T * 128;            // dO rows
-  char* Kt = Os + T * 128;            // [64 d][T] (+pad)
-  char* Qt = Kt + 64 * TS;
-  char* Ot = Qt + 64 * TS;            // dO^T
-  float* lse_s = reinterpret_cast<float*>(Ot + 64 * TS);
+  char* Os = Vs + T * 128;  // dO rows
+  float* lse_s = reinterpret_cast<float*>(Os + T * 128);
   float* del_s = lse_s + T;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -91,21 +104,6 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __rest
   }
   for (int r = tid; r < T; r += 256) lse_s[r] = lse[((size_t)n * H + h) * T + r];
   __syncthreads();
-  // ---- transposed copies: lanes take consecutive rows so the 2-byte LDS writes spread over banks
-  for (int idx = tid; idx < T * 8; idx += 256) {
-    const int r = idx % T, cp = idx / T;
-    const u32x4 kq = rowfrag(Ks, r, cp), qq = rowfrag(Qs, r, cp), oq = rowfrag(Os, r, cp);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int d = cp * 8 + e;
-      const int sh = (e & 1) * 16;
-      *reinterpret_cast<bf16_t*>(Kt + d * TS + r * 2) = (bf16_t)(kq[e >> 1] >> sh);
-      *reinterpret_cast<bf16_t*>(Qt + d * TS + r * 2) = (bf16_t)(qq[e >> 1] >> sh);
-      *reinterpret_cast<bf16_t*>(Ot + d * TS + r * 2) = (bf16_t)(oq[e >> 1] >> sh);
-    }
-  }
-  __syncthreads();
-
   const int own = wave * 32;  // first query (pass A) / key (pass B) this wave owns
   if (own < T) {
     // =============================== pass A: dQ for queries own..own+31 ======================
@@ -141,7 +139,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __rest
           const u32x4 dsf = pack8(s, 8 * ss);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt)
-            dq[dt] = mfma_bf16(tfrag(Kt, TS, dt * 32 + frow, kt * 32 + 16 * ss + 4 * fhalf), dsf, dq[dt]);
+            dq[dt] = mfma_bf16(trfrag(Ks, kt * 32 + 16 * ss, dt * 32, lane), dsf, dq[dt]);
         }
       }
       bf16_t* orow = dqkv + (m0 + own + frow) * ld3 + h * 64;
@@ -190,8 +188,8 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __rest
           const u32x4 pf = pack8(p, 8 * ss), dsf = pack8(s, 8 * ss);
 #pragma unroll
           for (int dt = 0; dt < 2; ++dt) {
-            dv[dt] = mfma_bf16(tfrag(Ot, TS, dt * 32 + frow, qt * 32 + 16 * ss + 4 * fhalf), pf, dv[dt]);
-            dk[dt] = mfma_bf16(tfrag(Qt, TS, dt * 32 + frow, qt * 32 + 16 * ss + 4 * fhalf), dsf, dk[dt]);
+            dv[dt] = mfma_bf16(trfrag(Os, qt * 32 + 16 * ss, dt * 32, lane), pf, dv[dt]);
+            dk[dt] = mfma_bf16(trfrag(Qs, qt * 32 + 16 * ss, dt * 32, lane), dsf, dk[dt]);
           }
         }
       }
@@ -321,7 +319,7 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
       set_error("attention backward (bf16 tier) is built for head_dim 64 and T <= 128 (got hd=%d, T=%d)", head_dim, T);
       return OSUD_ERR_UNSUPPORTED;
     }
-    const size_t lds = (size_t)4 * T * 128 + (size_t)3 * 64 * (T * 2 + 8) + (size_t)2 * T * 4;
+    const size_t lds = (size_t)4 * T * 128 + (size_t)2 * T * 4;
     static bool attr_set = false;
     if (!attr_set) {
       OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bf16_kernel),
