@@ -32,11 +32,6 @@ __device__ __forceinline__ u32x4 rowfrag(const char* tile, int row, int chunk) {
 //   r0 + 4*half + {0..3}  and  r0 + 8 + 4*half + {0..3}
 // — the same permuted order in which P / dS leave the S-layout registers (see pack8) — via two transposing reads
 // (each 16-lane group: 4 rows x 16 columns; semantics pinned by tools/probes/tr_probe.hip).
-__device__ __forceinline__ u32x2 ds_tr(uint32_t addr) {
-  u32x2 v;
-  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
-  return v;
-}
 __device__ __forceinline__ u32x4 trfrag(const char* tile, int r0, int d0, int lane) {
   const int row = r0 + 4 * (lane >> 5) + ((lane & 15) >> 2);
   const int colb = (d0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;  // byte offset of this lane's 4 columns
@@ -44,8 +39,16 @@ __device__ __forceinline__ u32x4 trfrag(const char* tile, int r0, int d0, int la
   const uint32_t base = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)tile;
   const uint32_t a0 = base + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) + within;
   const uint32_t a1 = base + (row + 8) * 128 + ((chunk ^ (((row + 8) >> 1) & 7)) << 4) + within;
-  const u32x2 lo = ds_tr(a0), hi = ds_tr(a1);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  // reads and their wait are ONE asm statement: a separate s_waitcnt statement does not stop the scheduler from
+  // moving the consumers (register moves, MFMA) above it, because the asm outputs look ready to the compiler
+  u32x2 lo, hi;
+  asm volatile(
+      "ds_read_b64_tr_b16 %0, %2\n\t"
+      "ds_read_b64_tr_b16 %1, %3\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(lo), "=&v"(hi)
+      : "v"(a0), "v"(a1)
+      : "memory");
   u32x4 v;
   v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
   return v;

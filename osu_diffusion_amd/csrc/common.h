@@ -39,16 +39,17 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN kept quiet
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
-__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// fp32 -> bf16, round-to-nearest-even: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32)
+typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+typedef float f32x2_hw __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  f32x2_hw v;
+  v[0] = lo;
+  v[1] = hi;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_hw));
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
 template <typename TE> struct ElemTraits;
 template <> struct ElemTraits<bf16_t> {
@@ -93,24 +94,35 @@ __device__ __forceinline__ void load2(const float* p, float& a, float& b) {
 
 // FAST = bf16 tier (hardware v_exp_f32 based), !FAST = parity tier (accurate expf / division)
 template <bool FAST> __device__ __forceinline__ float exp_t(float v) { return FAST ? __expf(v) : expf(v); }
+// The fast tier spends exactly two transcendental issues per sigmoid (v_exp_f32 + v_rcp_f32): `1.0f / x` and
+// __frcp_rn expand to the ~10-instruction IEEE division sequence, which made the GELU epilogue VALU-bound.
 template <bool FAST> __device__ __forceinline__ float sigmoid_t(float v) {
-  if (FAST) return __frcp_rn(1.0f + __expf(-v));
+  if (FAST) return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
   return 1.0f / (1.0f + expf(-v));
 }
 template <bool FAST> __device__ __forceinline__ float silu_t(float v) { return v * sigmoid_t<FAST>(v); }
 // nn.GELU(approximate="tanh"): 0.5 z (1 + tanh(u)), u = sqrt(2/pi) (z + 0.044715 z^3)
 //   == z * sigmoid(2u)  (one exp instead of a tanh)
+//   == z / (1 + 2^(z (A z^2 + B))),  B = -log2(e) 2 sqrt(2/pi),  A = 0.044715 B      (fast tier: 5 VALU + 2 transcendental)
+constexpr float kGeluK2 = 2.0f * 0.7978845608028654f;
+constexpr float kGeluB = -1.4426950408889634f * kGeluK2;
+constexpr float kGeluA = kGeluB * 0.044715f;
 template <bool FAST> __device__ __forceinline__ float gelu_tanh_t(float z) {
-  const float k2 = 2.0f * 0.7978845608028654f;
-  float u2 = k2 * (z + 0.044715f * z * z * z);
+  if (FAST) return z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * fmaf(z * z, kGeluA, kGeluB)));
+  float u2 = kGeluK2 * (z + 0.044715f * z * z * z);
   return z * sigmoid_t<FAST>(u2);
 }
-// d/dz of the above
+// d/dz of the above: s + z s (1 - s) du2/dz
 template <bool FAST> __device__ __forceinline__ float gelu_tanh_grad_t(float z) {
-  const float k2 = 2.0f * 0.7978845608028654f;
-  float u2 = k2 * (z + 0.044715f * z * z * z);
+  if (FAST) {
+    const float z2 = z * z;
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * fmaf(z2, kGeluA, kGeluB)));
+    const float t = z * fmaf(z2, 3.0f * 0.044715f * kGeluK2, kGeluK2);
+    return fmaf(t, fmaf(-s, s, s), s);
+  }
+  float u2 = kGeluK2 * (z + 0.044715f * z * z * z);
   float s = sigmoid_t<FAST>(u2);
-  float du2 = k2 * (1.0f + 3.0f * 0.044715f * z * z);
+  float du2 = kGeluK2 * (1.0f + 3.0f * 0.044715f * z * z);
   return s + z * s * (1.0f - s) * du2;
 }
 

@@ -23,6 +23,15 @@ template <int OFF> __device__ __forceinline__ u32x4 ds_read16(uint32_t addr) {
   return v;
 }
 
+template <int OFF> __device__ __forceinline__ f32x4 ds_read16f(uint32_t addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+__device__ __forceinline__ void ds_write16(uint32_t addr, const f32x4& v) {
+  asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(v) : "memory");
+}
+
 template <typename TE> __device__ __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b);
 template <> __device__ __forceinline__ void mma<bf16_t>(f32x16& acc, const u32x4& a, const u32x4& b) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0,
@@ -93,6 +102,7 @@ template <int WY, int WX, int RY, int RX> struct Geo {
   static constexpr int NSTAGE = STAGE * 4 <= 144 * 1024 ? 4 : (STAGE * 3 <= 160 * 1024 ? 3 : 2);
   static constexpr int PIECES = (BM + BN) / 8, PPW = PIECES / NW;  // 1 KiB LDS-DMA pieces per slab, per wave
   static_assert(PIECES % NW == 0, "pieces must divide evenly over the waves");
+  static_assert(NSTAGE * STAGE + NW * 4096 <= 160 * 1024, "stage ring + epilogue patches must fit the LDS");
 };
 
 // HBM -> LDS: this wave's share of one K slab (PPW pieces of 8 rows x 128 bytes).  The 16-byte chunk index
@@ -200,6 +210,13 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
     xa[s] = lds0 + (G::BM + wx * RX * 32 + frow) * SLAB + sw;
   }
 
+  // epilogue patch (4 KiB per wave, behind the stage ring): write address per register group g, read address
+  const uint32_t patch = lds0 + G::NSTAGE * G::STAGE + wave * 4096;
+  uint32_t pw[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) pw[g] = patch + frow * 128 + (((2 * g + fhalf) ^ (frow & 7)) << 4);
+  const uint32_t pr = patch + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+
   // ---- prologue: fill NSTAGE-1 stages
   int ic_tile = first, ic_kt = 0;  // issue cursor
   int issued = 0, consumed = 0;
@@ -248,71 +265,91 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
     wait_vm<0>();
     landed = issued - consumed;
 
-    // ---- epilogue: lane holds, for y = ..+frow, x = xb + 8g + 4*fhalf + {0..3}, g = 0..3 -----
-    // All loads of a batch (bias / gate / residual / aux) are issued BEFORE its stores: on gfx950
-    // vmcnt counts stores too, so a load waited for between stores would drain every earlier store.
+    // ---- epilogue -------------------------------------------------------------------------------
+    // The MFMA leaves lane (frow, fhalf) with y = frow and x = 8g + 4*fhalf + {0..3}: stored as is, one store
+    // instruction touches 32 rows with 8..32 bytes each and the epilogue is bound by the L2 REQUEST rate
+    // (measured: ~9 us per 256x256 tile, a third of the kernel).  So every 32x32 block takes a round trip
+    // through a wave-private 4 KiB LDS patch (16-byte slot index XOR-swizzled with row&7, conflict free both
+    // ways) and comes back row-major: lane l holds rows 8p + (l>>3), p = 0..3, and x = 4*(l&7) + {0..3} --
+    // 8 lanes cover one full 128-byte (f32) / 64-byte (bf16) row segment, and the operand loads (residual,
+    // saved pre-activation) are coalesced the same way.
+    // All loads of a block are issued BEFORE its stores: vmcnt counts stores too, so a load waited for
+    // between stores would drain every earlier store.
     constexpr bool kBias = EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_TE || EPI == EPI_BIAS_SILU_TE ||
                            EPI == EPI_BIAS_GELU_TE || EPI == EPI_GATE_RES;
-    const int xw = tx * BN + wx * RX * 32 + 4 * fhalf;  // + j*32 + 8*g
-    float4 bv[RX][4];
+    const int lrow = lane >> 3, lcol = 4 * (lane & 7);
+    const int xw = tx * BN + wx * RX * 32 + lcol;  // + j*32
+    float4 bv[RX];
     if (kBias) {
 #pragma unroll
-      for (int j = 0; j < RX; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bv[j][g] = *reinterpret_cast<const float4*>(p.bias + xw + j * 32 + 8 * g);
+      for (int j = 0; j < RX; ++j) bv[j] = *reinterpret_cast<const float4*>(p.bias + xw + j * 32);
     }
 #pragma unroll
     for (int i = 0; i < RY; ++i) {
-      const int y = ty * G::BM + wy * RY * 32 + i * 32 + frow;
-      float rb = 0.f;
-      if (EPI == EPI_ROWBIAS_TE) rb = p.bias[y];
+      const int yb = ty * G::BM + wy * RY * 32 + i * 32;  // wave-uniform first row of the block
+      const int y0 = yb + lrow;                           // + 8p
       int sample = 0;
-      if (EPI == EPI_GATE_RES) {
-        sample = y / p.rows_per_sample;
+      if (EPI == EPI_GATE_RES) {  // rows_per_sample % 32 == 0: one sample per 32-row block
+        sample = __builtin_amdgcn_readfirstlane(yb) / p.rows_per_sample;
         if (sample >= p.n_samples) sample = p.n_samples - 1;  // padding rows
       }
 #pragma unroll
       for (int j = 0; j < RX; ++j) {
-        // operands of this 32x32 block first (one batch of loads), then its 4 stores
-        float4 gv[4], rv[4];
+        // round trip through the patch (LDS operations of one wave execute in order: no wait between blocks)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+          v[0] = acc[i][j][4 * g + 0]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
+          ds_write16(pw[g], v);
+        }
+        f32x4 t[4];
+        t[0] = ds_read16f<0>(pr);
+        t[1] = ds_read16f<1024>(pr);
+        t[2] = ds_read16f<2048>(pr);
+        t[3] = ds_read16f<3072>(pr);
+        const int x = xw + j * 32;
+        float4 gv, rv[4];
+        float rb[4];
         if (EPI == EPI_GATE_RES) {
           const float* rsrc = p.res ? p.res : reinterpret_cast<const float*>(p.out);
+          gv = *reinterpret_cast<const float4*>(p.gate + (size_t)sample * p.ld_gate + x);
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            gv[g] = *reinterpret_cast<const float4*>(p.gate + (size_t)sample * p.ld_gate + xw + j * 32 + 8 * g);
-            rv[g] = *reinterpret_cast<const float4*>(rsrc + (size_t)y * p.ldo + xw + j * 32 + 8 * g);
-          }
+          for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const float4*>(rsrc + (size_t)(y0 + 8 * q) * p.ldo + x);
         }
         if (EPI == EPI_ACCUM_F32) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            rv[g] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.out) + (size_t)y * p.ldo + xw +
-                                                     j * 32 + 8 * g);
+          for (int q = 0; q < 4; ++q)
+            rv[q] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.out) + (size_t)(y0 + 8 * q) * p.ldo + x);
         }
         if (EPI == EPI_GELUGRAD_TE) {
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const TE* a = reinterpret_cast<const TE*>(p.aux) + (size_t)y * p.ldo + xw + j * 32 + 8 * g;
-            rv[g] = make_float4(load_elem(a), load_elem(a + 1), load_elem(a + 2), load_elem(a + 3));
+          for (int q = 0; q < 4; ++q) {
+            const TE* a = reinterpret_cast<const TE*>(p.aux) + (size_t)(y0 + 8 * q) * p.ldo + x;
+            float a0, a1, a2, a3;
+            load2(a, a0, a1);
+            load2(a + 2, a2, a3);
+            rv[q] = make_float4(a0, a1, a2, a3);
           }
         }
+        if (EPI == EPI_ROWBIAS_TE) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int x = xw + j * 32 + 8 * g;
-          float v0 = acc[i][j][4 * g + 0], v1 = acc[i][j][4 * g + 1], v2 = acc[i][j][4 * g + 2],
-                v3 = acc[i][j][4 * g + 3];
-          if (kBias) { v0 += bv[j][g].x; v1 += bv[j][g].y; v2 += bv[j][g].z; v3 += bv[j][g].w; }
-          if (EPI == EPI_ROWBIAS_TE) { v0 += rb; v1 += rb; v2 += rb; v3 += rb; }
-          const size_t o = (size_t)y * p.ldo + x;
+          for (int q = 0; q < 4; ++q) rb[q] = p.bias[y0 + 8 * q];
+        }
+        OSUD_LGKM_WAIT(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v0 = t[q][0], v1 = t[q][1], v2 = t[q][2], v3 = t[q][3];
+          if (kBias) { v0 += bv[j].x; v1 += bv[j].y; v2 += bv[j].z; v3 += bv[j].w; }
+          if (EPI == EPI_ROWBIAS_TE) { v0 += rb[q]; v1 += rb[q]; v2 += rb[q]; v3 += rb[q]; }
+          const size_t o = (size_t)(y0 + 8 * q) * p.ldo + x;
           if (EPI == EPI_BIAS_F32 || EPI == EPI_NONE_F32) {
             store4(reinterpret_cast<float*>(p.out) + o, v0, v1, v2, v3);
           } else if (EPI == EPI_ACCUM_F32) {
-            store4(reinterpret_cast<float*>(p.out) + o, rv[g].x + v0, rv[g].y + v1, rv[g].z + v2,
-                   rv[g].w + v3);
+            store4(reinterpret_cast<float*>(p.out) + o, rv[q].x + v0, rv[q].y + v1, rv[q].z + v2, rv[q].w + v3);
           } else if (EPI == EPI_GATE_RES) {
             if (p.out2) store4(reinterpret_cast<TE*>(p.out2) + o, v0, v1, v2, v3);  // branch output (training)
-            store4(reinterpret_cast<float*>(p.out) + o, rv[g].x + gv[g].x * v0, rv[g].y + gv[g].y * v1,
-                   rv[g].z + gv[g].z * v2, rv[g].w + gv[g].w * v3);
+            store4(reinterpret_cast<float*>(p.out) + o, rv[q].x + gv.x * v0, rv[q].y + gv.y * v1, rv[q].z + gv.z * v2,
+                   rv[q].w + gv.w * v3);
           } else if (EPI == EPI_BIAS_SILU_TE) {
             if (p.out2) store4(reinterpret_cast<TE*>(p.out2) + o, v0, v1, v2, v3);  // pre-activation (training)
             store4(reinterpret_cast<TE*>(p.out) + o, silu_t<FAST>(v0), silu_t<FAST>(v1), silu_t<FAST>(v2),
@@ -322,9 +359,9 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
             store4(reinterpret_cast<TE*>(p.out) + o, gelu_tanh_t<FAST>(v0), gelu_tanh_t<FAST>(v1),
                    gelu_tanh_t<FAST>(v2), gelu_tanh_t<FAST>(v3));
           } else if (EPI == EPI_GELUGRAD_TE) {
-            store4(reinterpret_cast<TE*>(p.out) + o, v0 * gelu_tanh_grad_t<FAST>(rv[g].x),
-                   v1 * gelu_tanh_grad_t<FAST>(rv[g].y), v2 * gelu_tanh_grad_t<FAST>(rv[g].z),
-                   v3 * gelu_tanh_grad_t<FAST>(rv[g].w));
+            store4(reinterpret_cast<TE*>(p.out) + o, v0 * gelu_tanh_grad_t<FAST>(rv[q].x),
+                   v1 * gelu_tanh_grad_t<FAST>(rv[q].y), v2 * gelu_tanh_grad_t<FAST>(rv[q].z),
+                   v3 * gelu_tanh_grad_t<FAST>(rv[q].w));
           } else {  // EPI_BIAS_TE, EPI_ROWBIAS_TE, EPI_NONE_TE
             store4(reinterpret_cast<TE*>(p.out) + o, v0, v1, v2, v3);
           }
@@ -347,7 +384,7 @@ int num_cus() {
 
 template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(const GemmP& p, hipStream_t st) {
   using G = Geo<WY, WX, RY, RX>;
-  const size_t lds = (size_t)G::NSTAGE * G::STAGE;
+  const size_t lds = (size_t)G::NSTAGE * G::STAGE + (size_t)G::NW * 4096;  // stage ring + epilogue patches
   static bool attr_set = false;
   if (!attr_set) {
     OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX>),
@@ -427,7 +464,8 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
                  "gemm: leading dimensions must keep 16-byte alignment (ldy=%d ldx=%d ldo=%d)", p.ldy, p.ldx, p.ldo);
   OSUD_CHECK_ARG(p.Y && p.X && p.out, "gemm: null operand");
   if (epi == EPI_GATE_RES)
-    OSUD_CHECK_ARG(p.gate && p.bias && p.rows_per_sample > 0 && p.n_samples > 0, "gemm: gated epilogue needs gate/bias");
+    OSUD_CHECK_ARG(p.gate && p.bias && p.rows_per_sample > 0 && p.rows_per_sample % 32 == 0 && p.n_samples > 0,
+                   "gemm: gated epilogue needs gate/bias and rows_per_sample %% 32 == 0");
   if (epi == EPI_BIAS_F32 || epi == EPI_BIAS_TE || epi == EPI_BIAS_SILU_TE || epi == EPI_ROWBIAS_TE ||
       epi == EPI_BIAS_GELU_TE)
     OSUD_CHECK_ARG(p.bias != nullptr, "gemm: epilogue %d needs a bias", epi);

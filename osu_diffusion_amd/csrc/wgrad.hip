@@ -32,6 +32,15 @@ template <int OFF> __device__ __forceinline__ u32x2 ds_read_tr(uint32_t addr) {
   return v;
 }
 
+template <int OFF> __device__ __forceinline__ f32x4 ds_read16f(uint32_t addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+__device__ __forceinline__ void ds_write16(uint32_t addr, const f32x4& v) {
+  asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(v) : "memory");
+}
+
 template <int WY, int WX, int RY, int RX> struct WGeo {
   static constexpr int BM = WY * RY * 32, BN = WX * RX * 32, NW = WY * WX, NT = 64 * NW;
   static constexpr int ROWY = BM * 2, ROWX = BN * 2;               // bytes per token row
@@ -39,6 +48,7 @@ template <int WY, int WX, int RY, int RX> struct WGeo {
   static constexpr int NSTAGE = STAGE * 3 <= 160 * 1024 ? 3 : 2;
   static constexpr int PIECES = STAGE / 1024, PPW = PIECES / NW;   // 1 KiB LDS-DMA pieces per stage / per wave
   static_assert(PIECES % NW == 0 && 1024 % ROWY == 0 && 1024 % ROWX == 0, "geometry");
+  static_assert(NSTAGE * STAGE + NW * 4096 <= 160 * 1024, "stage ring + epilogue patches must fit the LDS");
 };
 
 // this wave's share of one 64-token stage
@@ -141,6 +151,13 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
     xa[j] = lds0 + G::YB + tok0 * G::ROWX + hi * 64 + fbyte;
   }
 
+  // epilogue patch (4 KiB per wave, behind the stage ring)
+  const uint32_t patch = lds0 + G::NSTAGE * G::STAGE + wave * 4096;
+  uint32_t pw[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) pw[g] = patch + frow * 128 + (((2 * g + fhalf) ^ (frow & 7)) << 4);
+  const uint32_t pr = patch + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+
   const int G8 = gridDim.x;
   int first;
   {
@@ -197,33 +214,72 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
       mma_frags<RY, RX>(acc, f1);
       ++consumed;
     }
-    // lane holds, for y = ..+frow, x = xb + 8g + 4*fhalf + {0..3}
+    // The MFMA leaves lane (frow, fhalf) with y = frow, x = 8g + 4*fhalf + {0..3}; every 32x32 block goes through the
+    // wave's 4 KiB LDS patch and comes back row-major (rows 8q + (lane>>3), x = 4*(lane&7)..+3) so that 8 lanes
+    // store one full 128-byte row segment (see gemm.hip's epilogue).
 #pragma unroll
     for (int i = 0; i < RY; ++i) {
-      const int y = ty * G::BM + wy * RY * 32 + i * 32 + frow;
+      const int y0 = ty * G::BM + wy * RY * 32 + i * 32 + (lane >> 3);
 #pragma unroll
-      for (int j = 0; j < RX; ++j)
+      for (int j = 0; j < RX; ++j) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int x = tx * G::BN + wx * RX * 32 + j * 32 + 8 * g + 4 * fhalf;
-          store4(outp + (size_t)y * p.Nx + x, acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2],
-                 acc[i][j][4 * g + 3]);
+          f32x4 v;
+          v[0] = acc[i][j][4 * g + 0]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
+          ds_write16(pw[g], v);
         }
+        f32x4 t[4];
+        t[0] = ds_read16f<0>(pr);
+        t[1] = ds_read16f<1024>(pr);
+        t[2] = ds_read16f<2048>(pr);
+        t[3] = ds_read16f<3072>(pr);
+        OSUD_WG_WAIT(0);
+        const int x = tx * G::BN + wx * RX * 32 + j * 32 + 4 * (lane & 7);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store4(outp + (size_t)(y0 + 8 * q) * p.Nx + x, t[q][0], t[q][1], t[q][2], t[q][3]);
+      }
     }
   }
 }
 
-// column sums of a bf16 [M][N] matrix: out[c] += sum_m a[m][c]   (bias gradients)
-__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ a, int ld, int M, float* __restrict__ out) {
-  __shared__ float part[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + tx, r0 = blockIdx.y * 512;
-  float s = 0.f;
-  const int r1 = r0 + 512 < M ? r0 + 512 : M;
-  for (int r = r0 + ty; r < r1; r += 4) s += bf2f(a[(size_t)r * ld + c]);
-  part[ty][tx] = s;
+// column sums of a bf16 [M][N] matrix: out[c] += sum_m a[m][c]   (bias gradients).  HBM-bound: a workgroup sweeps
+// 256 rows x 256 columns with 16-byte loads (32 lanes = one 512-byte row segment, 8 rows per pass, 4 passes in
+// flight), combines its 8 row groups through LDS and issues one atomic per column.
+constexpr int CS_ROWS = 256;
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ a, int ld, int M, int N,
+                                                          float* __restrict__ out) {
+  __shared__ float part[8][256 + 4];
+  const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 256 + cl * 8;
+  const int r0 = blockIdx.y * CS_ROWS, r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
+  float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < N) {
+    for (int r = r0 + rg; r < r1; r += 32) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rr = r + 8 * u;
+        v[u] = rr < r1 ? *reinterpret_cast<const uint4*>(a + (size_t)rr * ld + c) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s[0] += __uint_as_float(v[u].x << 16); s[1] += __uint_as_float(v[u].x & 0xffff0000u);
+        s[2] += __uint_as_float(v[u].y << 16); s[3] += __uint_as_float(v[u].y & 0xffff0000u);
+        s[4] += __uint_as_float(v[u].z << 16); s[5] += __uint_as_float(v[u].z & 0xffff0000u);
+        s[6] += __uint_as_float(v[u].w << 16); s[7] += __uint_as_float(v[u].w & 0xffff0000u);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[rg][cl * 8 + j] = s[j];
   __syncthreads();
-  if (ty == 0) atomicAdd(out + c, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+  const int t = threadIdx.x, col = blockIdx.x * 256 + t;
+  if (col < N) {
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) sum += part[g][t];
+    atomicAdd(out + col, sum);
+  }
 }
 
 int num_cus_w() {
@@ -239,7 +295,7 @@ int num_cus_w() {
 
 template <int WY, int WX, int RY, int RX> int launch_wg(const WgradP& p, hipStream_t st) {
   using G = WGeo<WY, WX, RY, RX>;
-  const size_t lds = (size_t)G::NSTAGE * G::STAGE;
+  const size_t lds = (size_t)G::NSTAGE * G::STAGE + (size_t)G::NW * 4096;
   static bool attr_set = false;
   if (!attr_set) {
     OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<WY, WX, RY, RX>),
@@ -279,8 +335,9 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
 }
 
 int launch_colsum_bf16(const void* a, int ld, int M, int N, float* out, hipStream_t st) {
-  OSUD_CHECK_ARG(N % 64 == 0, "colsum: N=%d must be a multiple of 64", N);
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3(N / 64, (M + 511) / 512), dim3(256), 0, st, (const bf16_t*)a, ld, M, out);
+  OSUD_CHECK_ARG(N % 8 == 0 && ld % 8 == 0, "colsum: N=%d and ld=%d must be multiples of 8", N, ld);
+  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N + 255) / 256, (M + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, st,
+                     (const bf16_t*)a, ld, M, N, out);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }
