@@ -80,6 +80,10 @@ struct osud_dit {
   std::map<std::string, const float*> master;  // caller's fp32 parameter (as last passed to set_param)
   std::map<std::string, float*> grad;          // caller's fp32 gradient buffer (osud_dit_bind_grad)
   void *w_ada_t = nullptr, *w_t2_t = nullptr;  // transposed copies (training)
+  // osud_dit_refresh re-packs every parameter: while `defer` is set, set_param records its copies / conversions
+  // here instead of launching them one by one, and refresh sends each list as one batched launch (batch.hip)
+  osud::SegBatch* defer_copy = nullptr;
+  osud::SegBatch* defer_convert = nullptr;
   bool transposed_ready = false;
   BwdWs bw;
   int bw_dh_cur = 0;  // which residual-gradient buffer currently holds d(loss)/d(h) (phased backward)

@@ -198,8 +198,14 @@ extern "C" const char* osud_build_arch(void) { return "gfx950"; }
 
 static int upload_f32(osud_dit* m, float** dst, const float* src, size_t n, hipStream_t st) {
   if (!*dst) OSUD_TRY(dev_alloc(m->owned, dst, n * 4, false));
+  if (m->defer_copy && n % 4 == 0) return m->defer_copy->add(src, *dst, n / 4);
   OSUD_HIP(hipMemcpyAsync(*dst, src, n * 4, hipMemcpyDeviceToDevice, st));
   return OSUD_OK;
+}
+// fp32 master -> TE copy of a weight (n % 4 == 0 for every DiT weight)
+static int convert_w(osud_dit* m, const float* src, void* dst, size_t n, hipStream_t st) {
+  if (m->defer_convert && n % 4 == 0) return m->defer_convert->add(src, dst, n / 4);
+  return launch_convert(m->prec, src, dst, n, st);
 }
 
 extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
@@ -325,9 +331,9 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
     SHAPE(D, 384 + m->E);
     rc = launch_pack_rows(prec, src, 384 + m->E, 384 + m->E, m->w_e, m->Kp, m->Kp, (int)D, st);
   } else if (k == "xoc_embedder.mlp.0.bias") { SHAPE(D); rc = upload_f32(m, &m->b_e, src, D, st);
-  } else if (k == "t_embedder.mlp.0.weight") { SHAPE(D, 256); rc = launch_convert(prec, src, m->w_t0, D * 256, st);
+  } else if (k == "t_embedder.mlp.0.weight") { SHAPE(D, 256); rc = convert_w(m, src, m->w_t0, D * 256, st);
   } else if (k == "t_embedder.mlp.0.bias") { SHAPE(D); rc = upload_f32(m, &m->b_t0, src, D, st);
-  } else if (k == "t_embedder.mlp.2.weight") { SHAPE(D, D); rc = launch_convert(prec, src, m->w_t2, D * D, st);
+  } else if (k == "t_embedder.mlp.2.weight") { SHAPE(D, D); rc = convert_w(m, src, m->w_t2, D * D, st);
   } else if (k == "t_embedder.mlp.2.bias") { SHAPE(D); rc = upload_f32(m, &m->b_t2, src, D, st);
   } else if (k == "y_embedder.embedding_table.weight") {
     SHAPE(m->cfg.table_rows, D);
@@ -336,7 +342,7 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
   } else if (k == "final_layer.linear.bias") { SHAPE(m->C2); rc = upload_f32(m, &m->b_f, src, m->C2, st);
   } else if (k == "final_layer.adaLN_modulation.1.weight") {
     SHAPE(2 * D, D);
-    rc = launch_convert(prec, src, (char*)m->w_ada + (size_t)m->L * 6 * D * D * m->esz, 2 * D * D, st);
+    rc = convert_w(m, src, (char*)m->w_ada + (size_t)m->L * 6 * D * D * m->esz, 2 * D * D, st);
   } else if (k == "final_layer.adaLN_modulation.1.bias") {
     SHAPE(2 * D);
     float* dst = m->b_ada + (size_t)m->L * 6 * D;
@@ -349,19 +355,19 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
     const size_t es = m->esz;
     if (name == "attn.in_proj_weight") {
       SHAPE(3 * D, D);  // rows [Wq; Wk; Wv]
-      rc = launch_convert(prec, src, b.w_qkv, 3 * D * D, st);
+      rc = convert_w(m, src, b.w_qkv, 3 * D * D, st);
     } else if (name == "attn.in_proj_bias") {
       SHAPE(3 * D);
       rc = upload_f32(m, &b.b_qkv, src, 3 * D, st);
-    } else if (name == "attn.out_proj.weight") { SHAPE(D, D); rc = launch_convert(prec, src, b.w_o, D * D, st);
+    } else if (name == "attn.out_proj.weight") { SHAPE(D, D); rc = convert_w(m, src, b.w_o, D * D, st);
     } else if (name == "attn.out_proj.bias") { SHAPE(D); rc = upload_f32(m, &b.b_o, src, D, st);
-    } else if (name == "mlp.fc1.weight") { SHAPE(4 * D, D); rc = launch_convert(prec, src, b.w1, 4 * D * D, st);
+    } else if (name == "mlp.fc1.weight") { SHAPE(4 * D, D); rc = convert_w(m, src, b.w1, 4 * D * D, st);
     } else if (name == "mlp.fc1.bias") { SHAPE(4 * D); rc = upload_f32(m, &b.b1, src, 4 * D, st);
-    } else if (name == "mlp.fc2.weight") { SHAPE(D, 4 * D); rc = launch_convert(prec, src, b.w2, 4 * D * D, st);
+    } else if (name == "mlp.fc2.weight") { SHAPE(D, 4 * D); rc = convert_w(m, src, b.w2, 4 * D * D, st);
     } else if (name == "mlp.fc2.bias") { SHAPE(D); rc = upload_f32(m, &b.b2, src, D, st);
     } else if (name == "adaLN_modulation.1.weight") {
       SHAPE(6 * D, D);
-      rc = launch_convert(prec, src, (char*)m->w_ada + (size_t)l * 6 * D * D * es, 6 * D * D, st);
+      rc = convert_w(m, src, (char*)m->w_ada + (size_t)l * 6 * D * D * es, 6 * D * D, st);
     } else if (name == "adaLN_modulation.1.bias") {
       SHAPE(6 * D);
       float* dst = m->b_ada + (size_t)l * 6 * D;

@@ -174,10 +174,11 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
   const size_t ldy_b = (size_t)p.ldy * sizeof(TE), ldx_b = (size_t)p.ldx * sizeof(TE);
   const char* gy0 = reinterpret_cast<const char*>(p.Y);
   const char* gx0 = reinterpret_cast<const char*>(p.X);
-  if (p.split_k > 1) {  // this workgroup's share of the contraction
-    nk /= p.split_k;
-    gy0 += (size_t)blockIdx.y * nk * SLAB;
-    gx0 += (size_t)blockIdx.y * nk * SLAB;
+  if (p.split_k > 1) {  // this workgroup's share of the contraction (ranges differ by at most one slab)
+    const int k0 = (int)((long)blockIdx.y * nk / p.split_k), k1 = (int)((long)(blockIdx.y + 1) * nk / p.split_k);
+    nk = k1 - k0;
+    gy0 += (size_t)k0 * SLAB;
+    gx0 += (size_t)k0 * SLAB;
     p.out = reinterpret_cast<char*>(p.out) + (size_t)blockIdx.y * p.split_stride * (EPI == EPI_NONE_F32 ? 4 : sizeof(TE));
   }
   // Persistent workgroups: gridDim.x <= #CUs.  Blocks are dispatched round-robin over the 8 XCDs (b % 8);
@@ -472,7 +473,7 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
   if (epi == EPI_GELUGRAD_TE) OSUD_CHECK_ARG(p.aux != nullptr, "gemm: epilogue %d needs aux", epi);
   if (p.split_k > 1) {
     OSUD_CHECK_ARG(epi == EPI_NONE_F32 || epi == EPI_NONE_TE, "gemm: split-K needs a plain epilogue");
-    OSUD_CHECK_ARG(((size_t)p.K * esz / SLAB) % p.split_k == 0, "gemm: K=%d does not split %d ways", p.K, p.split_k);
+    OSUD_CHECK_ARG((size_t)p.K * esz / SLAB >= (size_t)p.split_k, "gemm: K=%d does not split %d ways", p.K, p.split_k);
   }
   return prec == OSUD_PREC_BF16 ? launch_e<bf16_t>(epi, p, st) : launch_e<float>(epi, p, st);
 }

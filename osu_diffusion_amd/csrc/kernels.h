@@ -49,6 +49,43 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
                     size_t ws_elems, hipStream_t st);
 int launch_colsum_bf16(const void* a, int ld, int M, int N, float* out, hipStream_t st);
 
+// batch.hip: one launch for a list of small buffers (passed by value in the kernel arguments)
+enum SegOp { SEG_ZERO = 0, SEG_COPY = 1, SEG_CONVERT = 2 };
+struct SegList {
+  static constexpr int kMax = 64;
+  const void* src[kMax];
+  void* dst[kMax];
+  size_t n[kMax];  // SEG_ZERO / SEG_COPY: 16-byte chunks; SEG_CONVERT (fp32 -> TE): groups of 4 elements
+  int count;
+};
+struct TransposeList {  // dst[c][r] = src[r][c], TE, dense (ld = C / R), R and C multiples of 64
+  static constexpr int kMax = 64;
+  const void* src[kMax];
+  void* dst[kMax];
+  int R[kMax], C[kMax], tile_begin[kMax];
+  int count;
+};
+int launch_segments(int op, int prec, const SegList& L, hipStream_t st);
+int launch_transpose_many(int prec, TransposeList& L, hipStream_t st);
+// host-side accumulator: add() launches by itself whenever the list is full, flush() sends the rest
+struct SegBatch {
+  int op, prec;
+  hipStream_t st;
+  SegList L{};
+  SegBatch(int op_, int prec_, hipStream_t st_) : op(op_), prec(prec_), st(st_) {}
+  int flush() {
+    const int rc = launch_segments(op, prec, L, st);
+    L.count = 0;
+    return rc;
+  }
+  int add(const void* src, void* dst, size_t n) {
+    if (L.count == SegList::kMax) OSUD_TRY(flush());
+    L.src[L.count] = src; L.dst[L.count] = dst; L.n[L.count] = n;
+    ++L.count;
+    return OSUD_OK;
+  }
+};
+
 // sampler.hip
 struct StepCoefs;  // device table, 8 floats per step
 int launch_sampler_step(const float* coefs, int mode, float eta, const float* model_out, const float* x,

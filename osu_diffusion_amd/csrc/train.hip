@@ -28,9 +28,16 @@ int build_transposed(osud_dit* m, hipStream_t st) {
   if (m->transposed_ready) return OSUD_OK;
   const int D = m->D, prec = m->prec;
   const size_t es = m->esz;
+  TransposeList tl{};
   auto T_ = [&](void* src, int R, int C, void** dst) -> int {
     if (!*dst) OSUD_TRY(dev_alloc(m->owned, dst, (size_t)R * C * es, false));
-    return launch_transpose(prec, src, C, *dst, R, R, C, nullptr, st);
+    if (tl.count == TransposeList::kMax) {
+      OSUD_TRY(launch_transpose_many(prec, tl, st));
+      tl.count = 0;
+    }
+    tl.src[tl.count] = src; tl.dst[tl.count] = *dst; tl.R[tl.count] = R; tl.C[tl.count] = C;
+    ++tl.count;
+    return OSUD_OK;
   };
   for (auto& b : m->blk) {
     OSUD_TRY(T_(b.w_qkv, 3 * D, D, &b.w_qkv_t));
@@ -40,6 +47,7 @@ int build_transposed(osud_dit* m, hipStream_t st) {
   }
   OSUD_TRY(T_(m->w_ada, m->ada_cols, D, &m->w_ada_t));
   OSUD_TRY(T_(m->w_t2, D, D, &m->w_t2_t));
+  OSUD_TRY(launch_transpose_many(prec, tl, st));
   m->transposed_ready = true;
   return OSUD_OK;
 }
@@ -61,10 +69,11 @@ int dbg_sync(hipStream_t st, const char* stage) {
 int wgrad(osud_dit* m, const void* Y, const void* X, int My, int Nx, int K, float* out, int ldo, hipStream_t st) {
   const int tiles = (My / 128) * (Nx / 128);
   const int slabs = (int)((size_t)K * m->esz / 128);
-  int S = 1;
-  while (S < 16 && tiles * S * 2 <= 1024 && slabs % (S * 2) == 0 && slabs / (S * 2) >= 8 &&
-         (size_t)(S * 2) * My * Nx <= m->bw.splitk_elems)
-    S *= 2;
+  // fill the chip in one round: splits = CUs / tiles (uneven K ranges are fine), each at least 8 slabs
+  int S = 256 / (tiles > 0 ? tiles : 1);
+  if (S > 32) S = 32;
+  while (S > 1 && (slabs / S < 8 || (size_t)S * My * Nx > m->bw.splitk_elems)) --S;
+  if (S < 1) S = 1;
   if (S == 1 || ldo != Nx) return gemm(m, EPI_NONE_F32, Y, K, X, K, My, Nx, K, out, ldo, nullptr, st);
   GemmP p{};
   p.Y = Y; p.X = X; p.ldy = K; p.ldx = K; p.My = My; p.Nx = Nx; p.K = K;
@@ -125,10 +134,26 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
   float* dh_other = m->bw_dh_cur ? w.dhA : w.dhB;
   if (phase_lo == 0) {
   // ---- accumulators that are filled by atomics
+  // (every phase's small accumulators in ONE launch; the two big ones as plain memsets)
   OSUD_TRY(zero(w.dada, (size_t)Np * AC * 4));
-  OSUD_TRY(zero(G("final_layer.linear.weight"), (size_t)m->C2 * D * 4));
-  OSUD_TRY(zero(G("final_layer.linear.bias"), (size_t)m->C2 * 4));
   OSUD_TRY(zero(G("y_embedder.embedding_table.weight"), (size_t)m->cfg.table_rows * D * 4));
+  {
+    SegBatch zb(SEG_ZERO, prec, st);
+    OSUD_TRY(zb.add(nullptr, G("final_layer.linear.weight"), (size_t)m->C2 * D / 4));
+    OSUD_TRY(zb.add(nullptr, G("final_layer.linear.bias"), (size_t)m->C2 / 4));
+    for (int l = 0; l < L; ++l) {
+      const std::string p = "blocks." + std::to_string(l) + ".";
+      OSUD_TRY(zb.add(nullptr, G(p + "mlp.fc2.bias"), (size_t)D / 4));
+      OSUD_TRY(zb.add(nullptr, G(p + "mlp.fc1.bias"), (size_t)D));
+      OSUD_TRY(zb.add(nullptr, G(p + "attn.out_proj.bias"), (size_t)D / 4));
+      OSUD_TRY(zb.add(nullptr, G(p + "attn.in_proj_bias"), (size_t)3 * D / 4));
+    }
+    OSUD_TRY(zb.add(nullptr, G("xoc_embedder.mlp.0.bias"), (size_t)D / 4));
+    OSUD_TRY(zb.add(nullptr, G("t_embedder.mlp.2.bias"), (size_t)D / 4));
+    OSUD_TRY(zb.add(nullptr, G("t_embedder.mlp.0.bias"), (size_t)D / 4));
+    OSUD_TRY(zb.add(nullptr, w.dbada, (size_t)AC / 4));
+    OSUD_TRY(zb.flush());
+  }
 
   // ---- final layer
   const LayerSaved& fin = m->saved[(size_t)L];
@@ -150,10 +175,6 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     const int base = l * 6 * D;
     float *g_b2 = G(p + "mlp.fc2.bias"), *g_b1 = G(p + "mlp.fc1.bias"), *g_bo = G(p + "attn.out_proj.bias"),
           *g_bqkv = G(p + "attn.in_proj_bias");
-    OSUD_TRY(zero(g_b2, (size_t)D * 4));
-    OSUD_TRY(zero(g_b1, (size_t)4 * D * 4));
-    OSUD_TRY(zero(g_bo, (size_t)D * 4));
-    OSUD_TRY(zero(g_bqkv, (size_t)3 * D * 4));
     // MLP branch: h_out = h_mid + g2 * (gelu(u2 W1^T + b1) W2^T + b2)
     OSUD_TRY(launch_gate_bwd(prec, dh, sv.br2, m->ada + base + 5 * D, AC, w.dbr, w.dada + base + 5 * D, M, Tp, D, st));
     OSUD_TRY(dbg_sync(st, "gate_bwd mlp"));
@@ -193,7 +214,6 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
   // ---- token embedding linear: h0 = e0 We^T + be   (inputs need no gradient)
   {
     float* g_be = G("xoc_embedder.mlp.0.bias");
-    OSUD_TRY(zero(g_be, (size_t)D * 4));
     OSUD_TRY(launch_transpose_f32(prec, dh, D, w.tB, Mp, Mp, D, g_be, st));
     OSUD_TRY(launch_transpose(prec, m->e0, m->Kp, w.tA, Mp, Mp, m->Kp, nullptr, st));
     OSUD_TRY(wgrad(m, w.tB, w.tA, D, m->Kp, Mp, w.dWe, m->Kp, st));
@@ -206,25 +226,26 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     char* dada_te = (char*)w.dada_te;
     char* dada_t = dada_te + (size_t)Np * AC * es;  // [AC][Np]
     OSUD_TRY(launch_mask_rows(prec, w.dada, dada_te, N, Np, AC, st));
-    OSUD_TRY(zero(w.dbada, (size_t)AC * 4));
     OSUD_TRY(launch_transpose(prec, dada_te, AC, dada_t, Np, Np, AC, w.dbada, st));
     OSUD_TRY(launch_transpose(prec, m->sb, D, w.small_t1, Np, Np, D, nullptr, st));  // sb^T [D][Np]
     OSUD_TRY(gemm(m, EPI_NONE_F32, dada_t, Np, w.small_t1, Np, AC, D, Np, w.dWada, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "wgrad ada"));
-    for (int l = 0; l <= L; ++l) {
-      const std::string key = l < L ? "blocks." + std::to_string(l) + ".adaLN_modulation.1." : "final_layer.adaLN_modulation.1.";
-      const size_t rows = l < L ? 6 * (size_t)D : 2 * (size_t)D, off = (size_t)l * 6 * D;
-      OSUD_HIP(hipMemcpyAsync(G(key + "weight"), w.dWada + off * D, rows * D * 4, hipMemcpyDeviceToDevice, st));
-      OSUD_HIP(hipMemcpyAsync(G(key + "bias"), w.dbada + off, rows * 4, hipMemcpyDeviceToDevice, st));
+    {
+      SegBatch cb(SEG_COPY, prec, st);
+      for (int l = 0; l <= L; ++l) {
+        const std::string key = l < L ? "blocks." + std::to_string(l) + ".adaLN_modulation.1." : "final_layer.adaLN_modulation.1.";
+        const size_t rows = l < L ? 6 * (size_t)D : 2 * (size_t)D, off = (size_t)l * 6 * D;
+        OSUD_TRY(cb.add(w.dWada + off * D, G(key + "weight"), rows * D / 4));
+        OSUD_TRY(cb.add(w.dbada + off, G(key + "bias"), rows / 4));
+      }
+      OSUD_TRY(cb.flush());
     }
-    OSUD_TRY(gemm(m, EPI_NONE_F32, dada_te, AC, m->w_ada_t, AC, Np, D, AC, w.dsb, D, nullptr, st));
+    OSUD_TRY(wgrad(m, dada_te, m->w_ada_t, Np, D, AC, w.dsb, D, st));  // K = 6(L+1)D: split over workgroups
     OSUD_TRY(launch_cond_bwd(prec, w.dsb, m->bvec, m->last_y, m->cfg.table_rows, w.db, w.db_te,
                              G("y_embedder.embedding_table.weight"), N, Np, D, st));
     OSUD_TRY(dbg_sync(st, "cond bwd"));
     // TimestepEmbedder: tvec = silu(temb W0^T + b0) W2^T + b2
     float *g_bt2 = G("t_embedder.mlp.2.bias"), *g_bt0 = G("t_embedder.mlp.0.bias");
-    OSUD_TRY(zero(g_bt2, (size_t)D * 4));
-    OSUD_TRY(zero(g_bt0, (size_t)D * 4));
     OSUD_TRY(launch_transpose(prec, w.db_te, D, w.small_t1, Np, Np, D, g_bt2, st));  // db^T [D][Np]
     OSUD_TRY(launch_transpose(prec, m->th, D, w.small_t2, Np, Np, D, nullptr, st));  // th^T [D][Np]
     OSUD_TRY(gemm(m, EPI_NONE_F32, w.small_t1, Np, w.small_t2, Np, D, D, Np, G("t_embedder.mlp.2.weight"), D, nullptr, st));
@@ -383,6 +404,14 @@ extern "C" int osud_dit_refresh(osud_dit* m, osud_stream stream) {
   OSUD_CHECK_ARG(m, "refresh: null handle");
   // re-pack every parameter from the caller's fp32 master (after an optimizer step)
   std::vector<std::pair<std::string, const float*>> items(m->master.begin(), m->master.end());
+  // set_param only RECORDS its copies / conversions while these are set; each list then goes out as one launch
+  SegBatch copies(SEG_COPY, m->prec, (hipStream_t)stream), converts(SEG_CONVERT, m->prec, (hipStream_t)stream);
+  struct Guard {
+    osud_dit* m;
+    ~Guard() { m->defer_copy = m->defer_convert = nullptr; }
+  } guard{m};
+  m->defer_copy = &copies;
+  m->defer_convert = &converts;
   for (auto& kv : items) {
     int64_t shape[2];
     int nd = 0;
@@ -409,6 +438,9 @@ extern "C" int osud_dit_refresh(osud_dit* m, osud_stream stream) {
     else { shape[0] = D; nd = 1; }  // every remaining bias is (D,)
     OSUD_TRY(osud_dit_set_param(m, k.c_str(), kv.second, shape, nd, stream));
   }
+  OSUD_TRY(copies.flush());
+  OSUD_TRY(converts.flush());
+  m->defer_copy = m->defer_convert = nullptr;
   if (m->training) OSUD_TRY(build_transposed(m, (hipStream_t)stream));
   return OSUD_OK;
 }
