@@ -99,10 +99,14 @@ __device__ __forceinline__ void compute_slab(f32x16 (&acc)[RY][RX], const uint32
 template <int WY, int WX, int RY, int RX> struct Geo {
   static constexpr int BM = WY * RY * 32, BN = WX * RX * 32, NW = WY * WX, NT = 64 * NW;
   static constexpr int STAGE = (BM + BN) * SLAB;
-  static constexpr int NSTAGE = STAGE * 4 <= 144 * 1024 ? 4 : (STAGE * 3 <= 160 * 1024 ? 3 : 2);
+  // 8-wave geometries own the CU (all 160 KiB); 4-wave geometries take half so that TWO workgroups share a CU and one's
+  // epilogue (VALU + stores) runs under the other's MFMA main loop
+  static constexpr int WGS = (NW == 4 && BM * BN > 128 * 128) ? 2 : 1;
+  static constexpr int LDS_MAX = 160 * 1024 / WGS;
+  static constexpr int NSTAGE = STAGE * 5 <= LDS_MAX ? 5 : (STAGE * 4 <= LDS_MAX ? 4 : (STAGE * 3 <= LDS_MAX ? 3 : 2));
   static constexpr int PIECES = (BM + BN) / 8, PPW = PIECES / NW;  // 1 KiB LDS-DMA pieces per slab, per wave
   static_assert(PIECES % NW == 0, "pieces must divide evenly over the waves");
-  static_assert(NSTAGE * STAGE + NW * 4096 <= 160 * 1024, "stage ring + epilogue patches must fit the LDS");
+  static_assert(NSTAGE * STAGE <= LDS_MAX && NW * 4096 <= STAGE, "stage ring must fit the LDS; the epilogue patches live in one stage");
 };
 
 // HBM -> LDS: this wave's share of one K slab (PPW pieces of 8 rows x 128 bytes).  The 16-byte chunk index
@@ -152,6 +156,8 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
   else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
   else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
   else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
@@ -211,8 +217,9 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
     xa[s] = lds0 + (G::BM + wx * RX * 32 + frow) * SLAB + sw;
   }
 
-  // epilogue patch (4 KiB per wave, behind the stage ring): write address per register group g, read address
-  const uint32_t patch = lds0 + G::NSTAGE * G::STAGE + wave * 4096;
+  // epilogue patch (4 KiB per wave, inside whichever stage is free when the epilogue runs): write address per
+  // register group g and read address, relative to that stage
+  const uint32_t patch = lds0 + wave * 4096;
   uint32_t pw[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) pw[g] = patch + frow * 128 + (((2 * g + fhalf) ^ (frow & 7)) << 4);
@@ -265,6 +272,11 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
     // queued behind them, so the next tile can start right after the epilogue without draining its stores.
     wait_vm<0>();
     landed = issued - consumed;
+    // The stage consumed last holds nothing the next tile needs (its prefetch sits in the other stages): it becomes
+    // the epilogue patch area, once every wave has finished reading the last slab from it.  The barrier at the top
+    // of the next tile's first slab orders the patch reads before the LDS-DMA that refills the stage.
+    __builtin_amdgcn_s_barrier();
+    const uint32_t pso = (uint32_t)(((consumed + G::NSTAGE - 1) % G::NSTAGE) * G::STAGE);
 
     // ---- epilogue -------------------------------------------------------------------------------
     // The MFMA leaves lane (frow, fhalf) with y = frow and x = 8g + 4*fhalf + {0..3}: stored as is, one store
@@ -301,13 +313,13 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
         for (int g = 0; g < 4; ++g) {
           f32x4 v;
           v[0] = acc[i][j][4 * g + 0]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
-          ds_write16(pw[g], v);
+          ds_write16(pw[g] + pso, v);
         }
         f32x4 t[4];
-        t[0] = ds_read16f<0>(pr);
-        t[1] = ds_read16f<1024>(pr);
-        t[2] = ds_read16f<2048>(pr);
-        t[3] = ds_read16f<3072>(pr);
+        t[0] = ds_read16f<0>(pr + pso);
+        t[1] = ds_read16f<1024>(pr + pso);
+        t[2] = ds_read16f<2048>(pr + pso);
+        t[3] = ds_read16f<3072>(pr + pso);
         const int x = xw + j * 32;
         float4 gv, rv[4];
         float rb[4];
@@ -385,7 +397,7 @@ int num_cus() {
 
 template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(const GemmP& p, hipStream_t st) {
   using G = Geo<WY, WX, RY, RX>;
-  const size_t lds = (size_t)G::NSTAGE * G::STAGE + (size_t)G::NW * 4096;  // stage ring + epilogue patches
+  const size_t lds = (size_t)G::NSTAGE * G::STAGE;  // stage ring (the epilogue patches borrow the free stage)
   static bool attr_set = false;
   if (!attr_set) {
     OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX>),
@@ -393,7 +405,7 @@ template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(con
     attr_set = true;
   }
   const int ntiles = (p.My / G::BM) * (p.Nx / G::BN), splits = p.split_k > 1 ? p.split_k : 1;
-  int grid = num_cus() / splits;  // one persistent workgroup per CU (LDS-limited), shared by the K splits
+  int grid = num_cus() * G::WGS / splits;  // persistent workgroups: WGS per CU (LDS-limited), shared by the K splits
   if (grid < 1) grid = 1;
   if (grid > ntiles) grid = ntiles;
   hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY, RX>), dim3(grid, splits), dim3(G::NT), lds, st, p);
@@ -426,7 +438,9 @@ template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
     else if (f == "192" && e[1] > 0) pick = 1;
     else if (f == "256" && e[2] > 0) pick = 2;
     else if (f == "192y" && e[3] > 0) pick = 3;
+    else if (f == "2wg" && p.Nx % 192 == 0) pick = 4;
   }
+  if (pick == 4) return launch_w<TE, EPI, 2, 2, 2, 3>(p, st);
   if (pick == 2) return launch_w<TE, EPI, 2, 4, 4, 2>(p, st);
   if (pick == 1) return launch_w<TE, EPI, 4, 2, 2, 3>(p, st);
   if (pick == 3) return launch_w<TE, EPI, 2, 4, 3, 2>(p, st);

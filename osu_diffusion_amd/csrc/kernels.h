@@ -10,11 +10,14 @@ int launch_embed(int prec, const float* x, const float* o, const float* c, const
 int launch_temb(int prec, const int64_t* t, const float* freqs128, void* out, int N, int Np, hipStream_t st);
 int launch_cond(int prec, const float* tvec, const float* table, const int64_t* y, int table_rows, float* b_out,
                 void* sb_out, int N, int Np, int D, hipStream_t st);
+// br != nullptr: the row is first updated to h + ada[n][off_gate..] * br (written to h_out if given, may be h itself)
 int launch_ln_mod(int prec, const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, void* out,
-                  float* stats, int M, int Tp, int N, int D, hipStream_t st);
+                  float* stats, int M, int Tp, int N, int D, hipStream_t st, const void* br = nullptr, int off_gate = 0,
+                  float* h_out = nullptr);
 int launch_final(const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, const float* w,
                  const float* bias, float* out, float* u_save, float* stats, int N, int T, int Tp, int D, int C,
-                 hipStream_t st);
+                 hipStream_t st, int prec = OSUD_PREC_F32, const void* br = nullptr, int off_gate = 0,
+                 float* h_out = nullptr);
 int launch_cfg_combine(float* out, int N, int C, int C2, int T, float s, hipStream_t st);
 int launch_convert(int prec, const float* src, void* dst, size_t n, hipStream_t st);
 int launch_pack_rows(int prec, const float* src, int ld_src, int cols_src, void* dst, int ld_dst, int cols_dst, int rows,

@@ -104,10 +104,14 @@ __global__ void cond_kernel(const float* __restrict__ tvec, const float* __restr
 
 // LayerNorm (eps 1e-6, no affine, biased variance) + adaLN modulate (models.py:12-13,160,173):
 //   u = LN(h) * (1 + scale[n]) + shift[n]        one wave per token row, D/64 values per lane
+// The gated residual update of the PREVIOUS branch rides along (models.py:161-175): with br != nullptr the row is
+//   h' = h + gate[n] * br,  written to h_out (may be h itself), and u = LN(h') ...
+// so the branch GEMMs (attention out-projection, fc2) keep a plain bias epilogue and the residual stream is read
+// once instead of twice.  `out` may alias `br` (a wave reads its whole row before it writes).
 template <typename TE, int VPL>
-__global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ h, const float* __restrict__ ada,
-                                                     int ld_ada, int off_shift, int off_scale, TE* __restrict__ out,
-                                                     float* __restrict__ stats, int M, int Tp, int N) {
+__global__ __launch_bounds__(256) void ln_mod_kernel(const float* h, const float* __restrict__ ada, int ld_ada,
+                                                     int off_shift, int off_scale, TE* out, float* __restrict__ stats,
+                                                     int M, int Tp, int N, const TE* br, int off_gate, float* h_out) {
   constexpr int D = VPL * 64;
   const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
@@ -121,8 +125,27 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ h
     const float2 p = *reinterpret_cast<const float2*>(hr + 2 * lane + 128 * i);
     v[2 * i] = p.x;
     v[2 * i + 1] = p.y;
-    sum += p.x + p.y;
   }
+  if (br != nullptr) {
+    const TE* brow = br + (size_t)m * D;
+    const float* gt = ada + (size_t)n * ld_ada + off_gate;
+#pragma unroll
+    for (int i = 0; i < VPL / 2; ++i) {
+      const int d = 2 * lane + 128 * i;
+      float b0, b1;
+      load2(brow + d, b0, b1);
+      const float2 g2 = *reinterpret_cast<const float2*>(gt + d);
+      v[2 * i] += g2.x * b0;
+      v[2 * i + 1] += g2.y * b1;
+    }
+    if (h_out != nullptr) {
+#pragma unroll
+      for (int i = 0; i < VPL / 2; ++i)
+        *reinterpret_cast<float2*>(h_out + (size_t)m * D + 2 * lane + 128 * i) = make_float2(v[2 * i], v[2 * i + 1]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) sum += v[i];
   const float mu = wave_sum(sum) * (1.0f / D);
   float sq = 0.f;
 #pragma unroll
@@ -151,12 +174,13 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ h
 
 // Final layer (models.py:192-196,324): LN -> modulate -> Linear(D -> C) -> channel-major (N,C,T).
 // Memory bound (one read of h); one wave per token, C (<= 4) dot products reduced in-wave.
-template <int VPL>
-__global__ __launch_bounds__(256) void final_kernel(const float* __restrict__ h, const float* __restrict__ ada,
-                                                    int ld_ada, int off_shift, int off_scale,
-                                                    const float* __restrict__ w, const float* __restrict__ bias,
-                                                    float* __restrict__ out, float* __restrict__ u_save,
-                                                    float* __restrict__ stats, int N, int T, int Tp, int C) {
+// The last block's gated MLP branch is added here (br != nullptr), as in ln_mod_kernel.
+template <typename TE, int VPL>
+__global__ __launch_bounds__(256) void final_kernel(const float* h, const float* __restrict__ ada, int ld_ada,
+                                                    int off_shift, int off_scale, const float* __restrict__ w,
+                                                    const float* __restrict__ bias, float* __restrict__ out,
+                                                    float* __restrict__ u_save, float* __restrict__ stats, int N, int T,
+                                                    int Tp, int C, const TE* __restrict__ br, int off_gate, float* h_out) {
   constexpr int D = VPL * 64;
   const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int n = m / Tp, t = m % Tp;
@@ -169,8 +193,27 @@ __global__ __launch_bounds__(256) void final_kernel(const float* __restrict__ h,
     const float2 p = *reinterpret_cast<const float2*>(hr + 2 * lane + 128 * i);
     v[2 * i] = p.x;
     v[2 * i + 1] = p.y;
-    sum += p.x + p.y;
   }
+  if (br != nullptr) {
+    const TE* brow = br + (size_t)m * D;
+    const float* gt = ada + (size_t)n * ld_ada + off_gate;
+#pragma unroll
+    for (int i = 0; i < VPL / 2; ++i) {
+      const int d = 2 * lane + 128 * i;
+      float b0, b1;
+      load2(brow + d, b0, b1);
+      const float2 g2 = *reinterpret_cast<const float2*>(gt + d);
+      v[2 * i] += g2.x * b0;
+      v[2 * i + 1] += g2.y * b1;
+    }
+    if (h_out != nullptr) {
+#pragma unroll
+      for (int i = 0; i < VPL / 2; ++i)
+        *reinterpret_cast<float2*>(h_out + (size_t)m * D + 2 * lane + 128 * i) = make_float2(v[2 * i], v[2 * i + 1]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) sum += v[i];
   const float mu = wave_sum(sum) * (1.0f / D);
   float sq = 0.f;
 #pragma unroll
@@ -281,11 +324,11 @@ int launch_cond(int prec, const float* tvec, const float* table, const int64_t* 
 
 template <typename TE>
 static int ln_mod_t(const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, void* out, float* stats,
-                    int M, int Tp, int N, int D, hipStream_t st) {
+                    int M, int Tp, int N, int D, hipStream_t st, const void* br, int off_gate, float* h_out) {
   const dim3 grid((M + 3) / 4), block(256);
 #define OSUD_LN(V)                                                                                                  \
   hipLaunchKernelGGL((ln_mod_kernel<TE, V>), grid, block, 0, st, h, ada, ld_ada, off_shift, off_scale, (TE*)out, \
-                     stats, M, Tp, N)
+                     stats, M, Tp, N, (const TE*)br, off_gate, h_out)
   switch (D) {
     case 128: OSUD_LN(2); break;
     case 384: OSUD_LN(6); break;
@@ -299,19 +342,26 @@ static int ln_mod_t(const float* h, const float* ada, int ld_ada, int off_shift,
   return OSUD_OK;
 }
 int launch_ln_mod(int prec, const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, void* out,
-                  float* stats, int M, int Tp, int N, int D, hipStream_t st) {
-  return prec == OSUD_PREC_BF16 ? ln_mod_t<bf16_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st)
-                                : ln_mod_t<float>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st);
+                  float* stats, int M, int Tp, int N, int D, hipStream_t st, const void* br, int off_gate, float* h_out) {
+  return prec == OSUD_PREC_BF16
+             ? ln_mod_t<bf16_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, br, off_gate, h_out)
+             : ln_mod_t<float>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, br, off_gate, h_out);
 }
 
 int launch_final(const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, const float* w,
                  const float* bias, float* out, float* u_save, float* stats, int N, int T, int Tp, int D, int C,
-                 hipStream_t st) {
+                 hipStream_t st, int prec, const void* br, int off_gate, float* h_out) {
   OSUD_CHECK_ARG(C >= 1 && C <= 4, "final layer: out channels %d not in 1..4", C);
   const dim3 grid((N * Tp + 3) / 4), block(256);
-#define OSUD_FIN(V)                                                                                                   \
-  hipLaunchKernelGGL((final_kernel<V>), grid, block, 0, st, h, ada, ld_ada, off_shift, off_scale, w, bias, out, \
-                     u_save, stats, N, T, Tp, C)
+#define OSUD_FIN(V)                                                                                                     \
+  do {                                                                                                                  \
+    if (prec == OSUD_PREC_BF16)                                                                                         \
+      hipLaunchKernelGGL((final_kernel<bf16_t, V>), grid, block, 0, st, h, ada, ld_ada, off_shift, off_scale, w, bias,  \
+                         out, u_save, stats, N, T, Tp, C, (const bf16_t*)br, off_gate, h_out);                          \
+    else                                                                                                                \
+      hipLaunchKernelGGL((final_kernel<float, V>), grid, block, 0, st, h, ada, ld_ada, off_shift, off_scale, w, bias,   \
+                         out, u_save, stats, N, T, Tp, C, (const float*)br, off_gate, h_out);                           \
+  } while (0)
   switch (D) {
     case 128: OSUD_FIN(2); break;
     case 384: OSUD_FIN(6); break;
