@@ -32,11 +32,15 @@ int launch_transpose(int prec, const void* in, int ld_in, void* out, int ld_out,
                      hipStream_t st);
 int launch_transpose_f32(int prec, const float* in, int ld_in, void* out, int ld_out, int R, int C, float* colsum,
                          hipStream_t st);
+// db (optional) += column sums of dbr = the branch Linear's bias gradient
 int launch_gate_bwd(int prec, const float* dh, const void* br, const float* gate, int ld_ada, void* dbr, float* dgate,
-                    int M, int Tp, int D, hipStream_t st);
-int launch_ln_mod_bwd(const float* h, const float* stats, const float* du, const float* ada, int ld_ada, int off_shift,
-                      int off_scale, const float* dh_skip, float* dh_out, float* dada, int M, int Tp, int D,
-                      hipStream_t st);
+                    int M, int Tp, int D, hipStream_t st, float* db = nullptr);
+// du is TE.  br_next != nullptr: also run the gate_bwd of the branch added in front of this LayerNorm on the fresh dh_out
+// rows (dbr = gate * dh_out, dada[n][off_gate_next..] += sum_t dh_out * br_next, db_next += column sums of dbr)
+int launch_ln_mod_bwd(int prec, const float* h, const float* stats, const void* du, const float* ada, int ld_ada,
+                      int off_shift, int off_scale, const float* dh_skip, float* dh_out, float* dada, int M, int Tp, int D,
+                      hipStream_t st, const void* br_next = nullptr, int off_gate_next = 0, void* dbr = nullptr,
+                      float* db_next = nullptr);
 int launch_final_bwd(const float* h, const float* stats, const float* dout, const float* w, const float* ada, int ld_ada,
                      int off_shift, int off_scale, float* dh_out, float* dada, float* dw, float* dbias, int N, int T, int Tp,
                      int D, int C, hipStream_t st);

@@ -74,22 +74,24 @@ __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restr
 // Gated residual branch backward:  h_out = h_in + gate[n] * br   (models.py:161-175)
 //   dbr[m][d]  = gate[n][d] * dh[m][d]                       (TE, operand of the next GEMMs)
 //   dgate[n][d] += sum_t dh[m][d] * br[m][d]
+//   db[d]      += gate[n][d] * sum_t dh[m][d]                (= column sums of dbr: the branch Linear's bias gradient)
 // Block = 64 consecutive rows (one sample: Tp % 64 == 0), wave w takes rows w, w+4, ...
 template <typename TE, int VPL>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dh, const TE* __restrict__ br,
                                                        const float* __restrict__ gate, int ld_ada,
-                                                       TE* __restrict__ dbr, float* __restrict__ dgate, int Tp) {
+                                                       TE* __restrict__ dbr, float* __restrict__ dgate, int Tp,
+                                                       float* __restrict__ db) {
   constexpr int D = VPL * 64;
   __shared__ float red[4][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 64, n = m0 / Tp;
   const float* g = gate + (size_t)n * ld_ada;
-  float gv[VPL], acc[VPL];
+  float gv[VPL], acc[VPL], cs[VPL];
 #pragma unroll
   for (int i = 0; i < VPL / 2; ++i) {
     const float2 t = *reinterpret_cast<const float2*>(g + 2 * lane + 128 * i);
     gv[2 * i] = t.x; gv[2 * i + 1] = t.y;
-    acc[2 * i] = acc[2 * i + 1] = 0.f;
+    acc[2 * i] = acc[2 * i + 1] = cs[2 * i] = cs[2 * i + 1] = 0.f;
   }
   for (int r = wave; r < 64; r += 4) {
     const size_t row = (size_t)(m0 + r) * D;
@@ -101,6 +103,8 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
       load2(br + row + d, b0, b1);
       acc[2 * i] += dv.x * b0;
       acc[2 * i + 1] += dv.y * b1;
+      cs[2 * i] += dv.x;
+      cs[2 * i + 1] += dv.y;
       store2(dbr + row + d, gv[2 * i] * dv.x, gv[2 * i + 1] * dv.y);
     }
   }
@@ -112,59 +116,106 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
   __syncthreads();
   for (int d = threadIdx.x; d < D; d += 256)
     atomicAdd(dgate + (size_t)n * ld_ada + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
+  if (db != nullptr) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VPL / 2; ++i) {
+      red[wave][2 * lane + 128 * i] = gv[2 * i] * cs[2 * i];
+      red[wave][2 * lane + 128 * i + 1] = gv[2 * i + 1] * cs[2 * i + 1];
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256) atomicAdd(db + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
 // LayerNorm + modulate backward:  u = xhat * (1 + sc[n]) + sh[n],  xhat = (h - mu) * rstd
 //   dsh[n] += sum_t du ; dsc[n] += sum_t du * xhat ; dy = du * (1 + sc)
 //   dh_out = dh_skip + rstd * (dy - mean(dy) - xhat * mean(dy * xhat))
-template <int VPL>
+// dh_out is the gradient of the residual stream in front of this LayerNorm, i.e. exactly the input of the gate_bwd of the
+// branch that was added just before it; with br_next != nullptr that step is done here on the rows still in registers
+// (dbr, dgate, db as in gate_bwd_kernel), saving a second pass over dh.
+// Block = 64 consecutive rows of one sample, wave w takes rows w, w+4, ...  Every load of a row is issued before the
+// first reduction (one memory round trip per row: the grid is only 2 blocks per CU, so the kernel lives on per-row latency).
+// (Tried and dropped: column sums in LDS via ds_add_f32 with 16-wave blocks -- 2.4x slower, the LDS atomics serialise.)
+template <typename TE, int VPL>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict__ h, const float* __restrict__ stats,
-                                                         const float* __restrict__ du, const float* __restrict__ ada,
+                                                         const TE* __restrict__ du, const float* __restrict__ ada,
                                                          int ld_ada, int off_shift, int off_scale,
                                                          const float* __restrict__ dh_skip, float* __restrict__ dh_out,
-                                                         float* __restrict__ dada, int Tp) {
+                                                         float* __restrict__ dada, int Tp, const TE* __restrict__ br_next,
+                                                         int off_gate_next, TE* __restrict__ dbr, float* __restrict__ db_next) {
   constexpr int D = VPL * 64;
   __shared__ float red[2][4][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 64, n = m0 / Tp;
-  const float* sc = ada + (size_t)n * ld_ada + off_scale;
-  float scv[VPL], a_sh[VPL], a_sc[VPL];
+  const float* arow = ada + (size_t)n * ld_ada;
+  float scv[VPL], gv[VPL], a_sh[VPL], a_sc[VPL], a_g[VPL], a_cs[VPL];
 #pragma unroll
   for (int i = 0; i < VPL / 2; ++i) {
-    const float2 t = *reinterpret_cast<const float2*>(sc + 2 * lane + 128 * i);
+    const float2 t = *reinterpret_cast<const float2*>(arow + off_scale + 2 * lane + 128 * i);
     scv[2 * i] = 1.0f + t.x; scv[2 * i + 1] = 1.0f + t.y;
     a_sh[2 * i] = a_sh[2 * i + 1] = a_sc[2 * i] = a_sc[2 * i + 1] = 0.f;
+    a_g[2 * i] = a_g[2 * i + 1] = a_cs[2 * i] = a_cs[2 * i + 1] = 0.f;
+    gv[2 * i] = gv[2 * i + 1] = 0.f;
+    if (br_next != nullptr) {
+      const float2 g2 = *reinterpret_cast<const float2*>(arow + off_gate_next + 2 * lane + 128 * i);
+      gv[2 * i] = g2.x; gv[2 * i + 1] = g2.y;
+    }
   }
-  for (int r = wave; r < 64; r += 4) {
-    const int m = m0 + r;
+  struct Row {
+    float2 hv[VPL / 2], dv[VPL / 2], sk[VPL / 2], bn[VPL / 2];
+    float mu, rstd;
+  };
+  auto load_row = [&](Row& R, int m) {
     const size_t row = (size_t)m * D;
-    const float mu = stats[2 * (size_t)m], rstd = stats[2 * (size_t)m + 1];
-    float xh[VPL], dy[VPL];
-    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL / 2; ++i) {
       const int d = 2 * lane + 128 * i;
-      const float2 hv = *reinterpret_cast<const float2*>(h + row + d);
-      const float2 dv = *reinterpret_cast<const float2*>(du + row + d);
-      xh[2 * i] = (hv.x - mu) * rstd; xh[2 * i + 1] = (hv.y - mu) * rstd;
-      a_sh[2 * i] += dv.x; a_sh[2 * i + 1] += dv.y;
-      a_sc[2 * i] += dv.x * xh[2 * i]; a_sc[2 * i + 1] += dv.y * xh[2 * i + 1];
-      dy[2 * i] = dv.x * scv[2 * i]; dy[2 * i + 1] = dv.y * scv[2 * i + 1];
-      s1 += dy[2 * i] + dy[2 * i + 1];
-      s2 += dy[2 * i] * xh[2 * i] + dy[2 * i + 1] * xh[2 * i + 1];
+      R.hv[i] = *reinterpret_cast<const float2*>(h + row + d);
+      load2(du + row + d, R.dv[i].x, R.dv[i].y);
+      R.sk[i] = dh_skip != nullptr ? *reinterpret_cast<const float2*>(dh_skip + row + d) : make_float2(0.f, 0.f);
+      R.bn[i] = make_float2(0.f, 0.f);
+      if (br_next != nullptr) load2(br_next + row + d, R.bn[i].x, R.bn[i].y);
+    }
+    R.mu = stats[2 * (size_t)m];
+    R.rstd = stats[2 * (size_t)m + 1];
+  };
+  auto process_row = [&](Row& R, int m) {
+    const size_t row = (size_t)m * D;
+    const float mu = R.mu, rstd = R.rstd;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL / 2; ++i) {
+      R.hv[i].x = (R.hv[i].x - mu) * rstd; R.hv[i].y = (R.hv[i].y - mu) * rstd;  // xhat
+      a_sh[2 * i] += R.dv[i].x; a_sh[2 * i + 1] += R.dv[i].y;
+      a_sc[2 * i] += R.dv[i].x * R.hv[i].x; a_sc[2 * i + 1] += R.dv[i].y * R.hv[i].y;
+      R.dv[i].x *= scv[2 * i]; R.dv[i].y *= scv[2 * i + 1];  // dy
+      s1 += R.dv[i].x + R.dv[i].y;
+      s2 += R.dv[i].x * R.hv[i].x + R.dv[i].y * R.hv[i].y;
     }
     const float m1 = wave_sum(s1) * (1.0f / D), m2 = wave_sum(s2) * (1.0f / D);
 #pragma unroll
     for (int i = 0; i < VPL / 2; ++i) {
       const int d = 2 * lane + 128 * i;
-      float2 o = make_float2(rstd * (dy[2 * i] - m1 - xh[2 * i] * m2), rstd * (dy[2 * i + 1] - m1 - xh[2 * i + 1] * m2));
-      if (dh_skip != nullptr) {
-        const float2 sk = *reinterpret_cast<const float2*>(dh_skip + row + d);
-        o.x += sk.x; o.y += sk.y;
-      }
+      const float2 o = make_float2(R.sk[i].x + rstd * (R.dv[i].x - m1 - R.hv[i].x * m2),
+                                   R.sk[i].y + rstd * (R.dv[i].y - m1 - R.hv[i].y * m2));
       *reinterpret_cast<float2*>(dh_out + row + d) = o;
+      if (br_next != nullptr) {
+        a_g[2 * i] += o.x * R.bn[i].x; a_g[2 * i + 1] += o.y * R.bn[i].y;
+        a_cs[2 * i] += o.x; a_cs[2 * i + 1] += o.y;
+        store2(dbr + row + d, gv[2 * i] * o.x, gv[2 * i + 1] * o.y);
+      }
     }
+  };
+  // rows wave, wave+4, ..., two register sets: the next row's loads are in flight while this one is reduced
+  Row ra, rb;
+  load_row(ra, m0 + wave);
+  for (int r = wave; r < 64; r += 8) {
+    load_row(rb, m0 + r + 4);
+    process_row(ra, m0 + r);
+    if (r + 8 < 64) load_row(ra, m0 + r + 8);
+    process_row(rb, m0 + r + 4);
   }
 #pragma unroll
   for (int i = 0; i < VPL / 2; ++i) {
@@ -177,6 +228,20 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
   for (int d = threadIdx.x; d < D; d += 256) {
     atomicAdd(dn + off_shift + d, red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d]);
     atomicAdd(dn + off_scale + d, red[1][0][d] + red[1][1][d] + red[1][2][d] + red[1][3][d]);
+  }
+  if (br_next != nullptr) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < VPL / 2; ++i) {
+      const int d = 2 * lane + 128 * i;
+      red[0][wave][d] = a_g[2 * i]; red[0][wave][d + 1] = a_g[2 * i + 1];
+      red[1][wave][d] = gv[2 * i] * a_cs[2 * i]; red[1][wave][d + 1] = gv[2 * i + 1] * a_cs[2 * i + 1];
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += 256) {
+      atomicAdd(dn + off_gate_next + d, red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d]);
+      if (db_next != nullptr) atomicAdd(db_next + d, red[1][0][d] + red[1][1][d] + red[1][2][d] + red[1][3][d]);
+    }
   }
 }
 
@@ -383,15 +448,15 @@ int launch_transpose_f32(int prec, const float* in, int ld_in, void* out, int ld
   }
 
 int launch_gate_bwd(int prec, const float* dh, const void* br, const float* gate, int ld_ada, void* dbr, float* dgate,
-                    int M, int Tp, int D, hipStream_t st) {
+                    int M, int Tp, int D, hipStream_t st, float* db) {
   OSUD_CHECK_ARG(M % 64 == 0 && Tp % 64 == 0, "gate_bwd: rows must come in blocks of 64");
   const dim3 grid(M / 64), block(256);
   if (prec == OSUD_PREC_BF16) {
-#define CALL(V) hipLaunchKernelGGL((gate_bwd_kernel<bf16_t, V>), grid, block, 0, st, dh, (const bf16_t*)br, gate, ld_ada, (bf16_t*)dbr, dgate, Tp)
+#define CALL(V) hipLaunchKernelGGL((gate_bwd_kernel<bf16_t, V>), grid, block, 0, st, dh, (const bf16_t*)br, gate, ld_ada, (bf16_t*)dbr, dgate, Tp, db)
     OSUD_BY_D(D, CALL)
 #undef CALL
   } else {
-#define CALL(V) hipLaunchKernelGGL((gate_bwd_kernel<float, V>), grid, block, 0, st, dh, (const float*)br, gate, ld_ada, (float*)dbr, dgate, Tp)
+#define CALL(V) hipLaunchKernelGGL((gate_bwd_kernel<float, V>), grid, block, 0, st, dh, (const float*)br, gate, ld_ada, (float*)dbr, dgate, Tp, db)
     OSUD_BY_D(D, CALL)
 #undef CALL
   }
@@ -399,14 +464,20 @@ int launch_gate_bwd(int prec, const float* dh, const void* br, const float* gate
   return OSUD_OK;
 }
 
-int launch_ln_mod_bwd(const float* h, const float* stats, const float* du, const float* ada, int ld_ada, int off_shift,
-                      int off_scale, const float* dh_skip, float* dh_out, float* dada, int M, int Tp, int D,
-                      hipStream_t st) {
+int launch_ln_mod_bwd(int prec, const float* h, const float* stats, const void* du, const float* ada, int ld_ada,
+                      int off_shift, int off_scale, const float* dh_skip, float* dh_out, float* dada, int M, int Tp, int D,
+                      hipStream_t st, const void* br_next, int off_gate_next, void* dbr, float* db_next) {
   OSUD_CHECK_ARG(M % 64 == 0 && Tp % 64 == 0, "ln_mod_bwd: rows must come in blocks of 64");
   const dim3 grid(M / 64), block(256);
-#define CALL(V) hipLaunchKernelGGL((ln_mod_bwd_kernel<V>), grid, block, 0, st, h, stats, du, ada, ld_ada, off_shift, off_scale, dh_skip, dh_out, dada, Tp)
-  OSUD_BY_D(D, CALL)
+  if (prec == OSUD_PREC_BF16) {
+#define CALL(V) hipLaunchKernelGGL((ln_mod_bwd_kernel<bf16_t, V>), grid, block, 0, st, h, stats, (const bf16_t*)du, ada, ld_ada, off_shift, off_scale, dh_skip, dh_out, dada, Tp, (const bf16_t*)br_next, off_gate_next, (bf16_t*)dbr, db_next)
+    OSUD_BY_D(D, CALL)
 #undef CALL
+  } else {
+#define CALL(V) hipLaunchKernelGGL((ln_mod_bwd_kernel<float, V>), grid, block, 0, st, h, stats, (const float*)du, ada, ld_ada, off_shift, off_scale, dh_skip, dh_out, dada, Tp, (const float*)br_next, off_gate_next, (float*)dbr, db_next)
+    OSUD_BY_D(D, CALL)
+#undef CALL
+  }
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }

@@ -175,35 +175,46 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     const int base = l * 6 * D;
     float *g_b2 = G(p + "mlp.fc2.bias"), *g_b1 = G(p + "mlp.fc1.bias"), *g_bo = G(p + "attn.out_proj.bias"),
           *g_bqkv = G(p + "attn.in_proj_bias");
-    // MLP branch: h_out = h_mid + g2 * (gelu(u2 W1^T + b1) W2^T + b2)
-    OSUD_TRY(launch_gate_bwd(prec, dh, sv.br2, m->ada + base + 5 * D, AC, w.dbr, w.dada + base + 5 * D, M, Tp, D, st));
-    OSUD_TRY(dbg_sync(st, "gate_bwd mlp"));
+    // MLP branch: h_out = h_mid + g2 * (gelu(u2 W1^T + b1) W2^T + b2).  Its gate step (dbr = g2 * dh, dg2, db2) was done
+    // by the kernel that produced dh: final_bwd's successor below for the last block, the LN1 backward of block l+1 otherwise.
+    if (l == L - 1) {
+      OSUD_TRY(launch_gate_bwd(prec, dh, sv.br2, m->ada + base + 5 * D, AC, w.dbr, w.dada + base + 5 * D, M, Tp, D, st, g_b2));
+      OSUD_TRY(dbg_sync(st, "gate_bwd mlp"));
+    }
     OSUD_TRY(gemm(m, EPI_GELUGRAD_TE, w.dbr, D, bw.w2_t, D, Mp, 4 * D, D, w.dz1, 4 * D, nullptr, st, nullptr, 0, 0, 0,
                   nullptr, nullptr, sv.z1));
     OSUD_TRY(dbg_sync(st, "dgrad fc2 (gelu grad)"));
-    OSUD_TRY(weight_grad(m, w.dbr, D, sv.g, 4 * D, D, 4 * D, Mp, G(p + "mlp.fc2.weight"), g_b2, st));
+    OSUD_TRY(weight_grad(m, w.dbr, D, sv.g, 4 * D, D, 4 * D, Mp, G(p + "mlp.fc2.weight"), nullptr, st));
     OSUD_TRY(dbg_sync(st, "wgrad fc2"));
-    OSUD_TRY(gemm(m, EPI_NONE_F32, w.dz1, 4 * D, bw.w1_t, 4 * D, Mp, D, 4 * D, w.du, D, nullptr, st));
+    OSUD_TRY(gemm(m, EPI_NONE_TE, w.dz1, 4 * D, bw.w1_t, 4 * D, Mp, D, 4 * D, w.du, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "dgrad fc1"));
     OSUD_TRY(weight_grad(m, w.dz1, 4 * D, sv.u2, D, 4 * D, D, Mp, G(p + "mlp.fc1.weight"), g_b1, st));
     OSUD_TRY(dbg_sync(st, "wgrad fc1"));
-    OSUD_TRY(launch_ln_mod_bwd(sv.h_mid, sv.stats2, w.du, m->ada, AC, base + 3 * D, base + 4 * D, dh, dh_other, w.dada, M,
-                               Tp, D, st));
-    OSUD_TRY(dbg_sync(st, "ln2 bwd"));
-    std::swap(dh, dh_other);  // dh = grad wrt h_mid
-    // attention branch: h_mid = h_in + g1 * (attn(u1) Wo^T + bo)
-    OSUD_TRY(launch_gate_bwd(prec, dh, sv.br1, m->ada + base + 2 * D, AC, w.dbr, w.dada + base + 2 * D, M, Tp, D, st));
-    OSUD_TRY(dbg_sync(st, "gate_bwd attn"));
+    // LN2 backward -> dh = grad wrt h_mid, and on the same rows the gate step of the attention branch
+    // (h_mid = h_in + g1 * (attn(u1) Wo^T + bo)): dbr = g1 * dh, dg1, dbo
+    OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_mid, sv.stats2, w.du, m->ada, AC, base + 3 * D, base + 4 * D, dh, dh_other, w.dada,
+                               M, Tp, D, st, sv.br1, base + 2 * D, w.dbr, g_bo));
+    OSUD_TRY(dbg_sync(st, "ln2 bwd + gate_bwd attn"));
+    std::swap(dh, dh_other);
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dbr, D, bw.w_o_t, D, Mp, D, D, w.dao, D, nullptr, st));
-    OSUD_TRY(weight_grad(m, w.dbr, D, sv.ao, D, D, D, Mp, G(p + "attn.out_proj.weight"), g_bo, st));
+    OSUD_TRY(weight_grad(m, w.dbr, D, sv.ao, D, D, D, Mp, G(p + "attn.out_proj.weight"), nullptr, st));
     OSUD_TRY(dbg_sync(st, "wgrad out_proj"));
     OSUD_TRY(launch_attention_bwd(prec, sv.qk, w.dao, sv.ao, sv.lse, w.dqkv, N, T, m->H, m->hd, st));
     OSUD_TRY(dbg_sync(st, "attention bwd"));
-    OSUD_TRY(gemm(m, EPI_NONE_F32, w.dqkv, 3 * D, bw.w_qkv_t, 3 * D, Mp, D, 3 * D, w.du, D, nullptr, st));
+    OSUD_TRY(gemm(m, EPI_NONE_TE, w.dqkv, 3 * D, bw.w_qkv_t, 3 * D, Mp, D, 3 * D, w.du, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "dgrad qkv"));
     OSUD_TRY(weight_grad(m, w.dqkv, 3 * D, sv.u1, D, 3 * D, D, Mp, G(p + "attn.in_proj_weight"), g_bqkv, st));
     OSUD_TRY(dbg_sync(st, "wgrad qkv"));
-    OSUD_TRY(launch_ln_mod_bwd(sv.h_in, sv.stats1, w.du, m->ada, AC, base, base + D, dh, dh_other, w.dada, M, Tp, D, st));
+    // LN1 backward -> dh = grad wrt h_in = grad wrt the output of block l-1, whose MLP gate step rides along
+    if (l > 0) {
+      const LayerSaved& svp = m->saved[(size_t)l - 1];
+      const int basep = (l - 1) * 6 * D;
+      OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_in, sv.stats1, w.du, m->ada, AC, base, base + D, dh, dh_other, w.dada, M, Tp, D,
+                                 st, svp.br2, basep + 5 * D, w.dbr, G("blocks." + std::to_string(l - 1) + ".mlp.fc2.bias")));
+    } else {
+      OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_in, sv.stats1, w.du, m->ada, AC, base, base + D, dh, dh_other, w.dada, M, Tp, D,
+                                 st));
+    }
     OSUD_TRY(dbg_sync(st, "ln1 bwd"));
     std::swap(dh, dh_other);  // dh = grad wrt h_in
   }
