@@ -203,6 +203,10 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
   auto tile_ptrs = [&](int tile, int kt, const char*& gy, const char*& gx) {
     int ty, tx;
     tm.coords(tile, ty, tx);
+#ifdef OSUD_GEMM_TIMING
+    if (p.tile_order == 4) ty = tx = 0;           // experiment: every workgroup streams the SAME panels (all L2 hits)
+    if (p.tile_order == 5) { ty = ty % 8; tx = 0; }
+#endif
     gy = gy0 + (size_t)ty * G::BM * ldy_b + (size_t)kt * SLAB;
     gx = gx0 + (size_t)tx * BN * ldx_b + (size_t)kt * SLAB;
   };
@@ -244,6 +248,10 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
   for (int i = 0; i < G::NSTAGE - 1; ++i) issue_next();
   int landed = 0;  // slabs known to have landed already (waited for before the previous epilogue)
 
+#ifdef OSUD_GEMM_TIMING
+  uint64_t tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const uint64_t tk0 = __builtin_readcyclecounter();
+#endif
   for (int tile = first; tile < ntiles; tile += G8) {
     int ty, tx;
     tm.coords(tile, ty, tx);
@@ -256,6 +264,9 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     for (int kt = 0; kt < nk; ++kt) {
+#ifdef OSUD_GEMM_TIMING
+      const uint64_t tt0 = __builtin_readcyclecounter();
+#endif
       // slab `consumed` must have landed; up to NSTAGE-2 later slabs may stay in flight (loads return in order)
       // (stores of an epilogue may sit in the queue too; they only make the counted wait conservative)
       const int ahead = issued - consumed - 1;
@@ -263,13 +274,34 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
       else if (ahead <= 0 || G::NSTAGE == 2) wait_vm<0>();
       else if (ahead == 1) wait_vm<G::PPW>();
       else wait_vm<(G::NSTAGE > 3 ? 2 * G::PPW : 0)>();
+#ifdef OSUD_GEMM_TIMING
+      const uint64_t tt1 = __builtin_readcyclecounter();
+#endif
       __builtin_amdgcn_s_barrier();  // every wave's share landed; the stage consumed last round is free again
+#ifdef OSUD_GEMM_TIMING
+      const uint64_t tt2 = __builtin_readcyclecounter();
+#endif
+      // (Measured with -DOSUD_GEMM_TIMING: a slab costs ~3200 cycles = 64 LDS-DMA pieces x ~50 cycles, i.e. the CU's LDS-DMA
+      // issue rate (~20 B/clk), not L2/HBM -- all workgroups streaming the SAME panels run no faster -- and not the MFMA
+      // pipe (2 x 1024 cycles).  Issuing half the waves' pieces mid-slab instead of here changes nothing.)
       issue_next();
+#ifdef OSUD_GEMM_TIMING
+      const uint64_t tt3 = __builtin_readcyclecounter();
+#endif
       compute_slab<TE, RY, RX>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
+#ifdef OSUD_GEMM_TIMING
+      {
+        const uint64_t tt4 = __builtin_readcyclecounter();
+        tsum[0] += tt1 - tt0; tsum[1] += tt2 - tt1; tsum[2] += tt3 - tt2; tsum[3] += tt4 - tt3; tsum[4] += 1;
+      }
+#endif
       ++consumed;
     }
     // The next tile's first slabs are already in flight: make sure they landed NOW, while no store is
     // queued behind them, so the next tile can start right after the epilogue without draining its stores.
+#ifdef OSUD_GEMM_TIMING
+    const uint64_t te0 = __builtin_readcyclecounter();
+#endif
     wait_vm<0>();
     landed = issued - consumed;
     // The stage consumed last holds nothing the next tile needs (its prefetch sits in the other stages): it becomes
@@ -381,7 +413,17 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
         }
       }
     }
+#ifdef OSUD_GEMM_TIMING
+    tsum[5] += __builtin_readcyclecounter() - te0;  // epilogue (incl. the drain wait and barrier)
+#endif
   }  // tile loop
+#ifdef OSUD_GEMM_TIMING
+  if (p.gate != nullptr && lane == 0 && blockIdx.x < 16) {
+    float* dbg = const_cast<float*>(p.gate) + (blockIdx.x * G::NW + wave) * 8;
+    for (int i = 0; i < 6; ++i) dbg[i] = (float)tsum[i];
+    dbg[6] = (float)(__builtin_readcyclecounter() - tk0);
+  }
+#endif
 }
 
 int num_cus() {

@@ -1,0 +1,24 @@
+"""Per-phase cycle breakdown of the GEMM main loop (needs ab/libosud_timing.so built with -DOSUD_GEMM_TIMING)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from osu_diffusion_amd import _lib
+L = _lib.lib(); dev = torch.device("cuda:0")
+def run(name, epi, My, Nx, K, f32out=False, pad=0):
+    Y = torch.randn(My, K + pad, device=dev).to(torch.bfloat16); X = (torch.randn(Nx, K + pad, device=dev) / K ** 0.5).to(torch.bfloat16)
+    out = torch.zeros(My, Nx, dtype=torch.float32 if f32out else torch.bfloat16, device=dev)
+    bias = torch.randn(max(My, Nx), device=dev) * 0.02
+    dbg = torch.zeros(16 * 8 * 8, device=dev)
+    for _ in range(3):
+        _lib.check(L.osud_op_gemm(0, epi, _lib.ptr(Y), K + pad, _lib.ptr(X), K + pad, My, Nx, K, _lib.ptr(out), Nx, _lib.ptr(bias), _lib.ptr(dbg), Nx, 128, max(1, My // 128), None))
+    torch.cuda.synchronize()
+    d = dbg.view(16, 8, 8).cpu()
+    print(name, My, Nx, K)
+    for w in (0, 4):
+        v = d[0, w]
+        n = max(1.0, float(v[4]))
+        print(f"  wave {w}: per slab: wait_vm {v[0]/n:7.0f}  barrier {v[1]/n:7.0f}  dma_issue {v[2]/n:7.0f}  compute {v[3]/n:7.0f} | slabs {n:.0f}  epilogue/tile {v[5]/(n/ (K*2/128)):8.0f}  total {v[6]:9.0f}")
+D = 768
+pad = int(os.environ.get("PAD", "0"))
+run("fc1 plain bf16", _lib.EPI_BIAS_TE, 32768, 4 * D, D, pad=pad)
+run("fc2-shape bf16", _lib.EPI_BIAS_TE, 32768, D, 4 * D, pad=pad)
+run("square 8192", _lib.EPI_BIAS_TE, 8192, 8192, 8192, pad=pad)
