@@ -169,8 +169,9 @@ int osud_op_gemm(int precision, int epilogue, const void* Y, int ldy, const void
                  int n_samples, osud_stream stream);
 /* Convert n fp32 values to the tier's element type (bf16 round-to-nearest-even or f32 copy). */
 int osud_op_convert(int precision, const float* src, void* dst, size_t n, osud_stream stream);
-int osud_op_attention(int precision, const void* qk, const void* vt, const uint8_t* mask, void* out, int N, int T,
-                      int Tp, int Mp, int heads, int head_dim, osud_stream stream);
+/* Attention core on the packed in_proj output qkv [Mp][ld_qkv] (Q | K | V, head h = hd columns): out [Mp][hidden]. */
+int osud_op_attention(int precision, const void* qkv, int ld_qkv, const uint8_t* mask, void* out, int N, int T, int Tp,
+                      int Mp, int heads, int head_dim, osud_stream stream);
 
 #ifdef __cplusplus
 }

@@ -2,33 +2,29 @@
 // DiTBlock.forward, models.py:130-135,164-170): softmax(q k^T / sqrt(hd) + mask) v per
 // (sample, head), non-causal, optional (T,T) boolean mask shared by all samples/heads.
 //
-// Inputs come straight from the two projection GEMMs (no head-major reshuffle):
-//   qk  [Mp][2D]  row m = n*Tp + t : Q in columns [0,D), K in [D,2D); head h = 64 columns
-//   vt  [D][Mp]   V transposed (row = h*hd + d, column = m) — produced by running the V
-//                 projection with the operand roles swapped, so that the P.V product finds
-//                 its contraction index (the key) contiguous.
+// Input comes straight from the packed in_proj GEMM (no head-major reshuffle, no transposed V):
+//   qkv [Mp][3D]  row m = n*Tp + t : Q in columns [0,D), K in [D,2D), V in [2D,3D); head h = 64 columns
+// The P.V product needs its contraction index (the key) contiguous per lane; V stays row-major [key][d] in LDS
+// and the fragments come out of ds_read_b64_tr_b16 (attn_frag.h), as in the backward kernel.
 // Output ao [Mp][D].  Tp (tokens per sample incl. padding) is a multiple of 64; keys >= T
 // are masked out.
 //
-// bf16 tier: one workgroup = 128 queries of one (n,h); 4 waves x 32 queries; K / V^T blocks of
+// bf16 tier: one workgroup = 128 queries of one (n,h); 4 waves x 32 queries; K / V blocks of
 // 64 keys staged in LDS (XOR-swizzled 16-byte chunks); S^T = K.Q^T on MFMA 32x32x16 so every
 // lane owns ONE query (its 32 scores of the tile sit in its own registers + the partner lane
 // l^32) -> softmax needs one cross-lane exchange; P goes back into the MFMA as the B operand
 // without leaving registers (the key order inside a k-step is permuted identically on the
-// V^T side).  fp32 statistics, online softmax across key blocks.
+// V side).  fp32 statistics, online softmax across key blocks.
 // f32 (parity) tier: plain one-thread-per-query VALU kernel, fp32 everywhere.
-#include "common.h"
+#include "attn_frag.h"
 
 namespace osud {
 
 namespace {
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-
 __device__ __forceinline__ float fast_exp2(float v) { return __builtin_amdgcn_exp2f(v); }
 
-__global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ qk, const bf16_t* __restrict__ vt,
+__global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ qk,
                                                         const uint8_t* __restrict__ mask, bf16_t* __restrict__ out,
                                                         float* __restrict__ lse, int T, int Tp, int Mp, int D,
                                                         int ld_qk, float c1 /* scale*log2(e) */) {
@@ -39,7 +35,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
   const int n = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * 128 + wave * 32 + frow;
   const int qc = q < Tp ? q : Tp - 1;
-  const size_t ldq = (size_t)ld_qk;  // 2D (inference: Q|K) or 3D (training: Q|K|V)
+  const size_t ldq = (size_t)ld_qk;  // 3D (Q|K|V)
   const size_t mrow = (size_t)n * Tp + qc;
 
   // Q fragments (B operand of S^T = K.Q^T): 8 consecutive d per lane and k-step
@@ -66,7 +62,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
       const int pos = (cp ^ ((r >> 1) & 7)) << 4;
       const u32x4 kv = *reinterpret_cast<const u32x4*>(qk + ((size_t)n * Tp + kb * 64 + r) * ldq + D + h * 64 + cp * 8);
       *reinterpret_cast<u32x4*>(Ks + r * 128 + pos) = kv;
-      const u32x4 vv = *reinterpret_cast<const u32x4*>(vt + ((size_t)h * 64 + r) * Mp + (size_t)n * Tp + kb * 64 + cp * 8);
+      const u32x4 vv = *reinterpret_cast<const u32x4*>(qk + ((size_t)n * Tp + kb * 64 + r) * ldq + 2 * D + h * 64 + cp * 8);
       *reinterpret_cast<u32x4*>(Vs + r * 128 + pos) = vv;
     }
     __syncthreads();
@@ -124,6 +120,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
       for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
 
     // ---- O^T += V^T . P^T ; k-step (kt, ss) covers keys kt*32 + 16ss + {4*fhalf + 0..3, 8 + 4*fhalf + 0..3}
+    //      (V^T fragments = transposing reads of the row-major V tile)
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -134,16 +131,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
         pf[2] = pack_bf2(s[kt][8 * ss + 4], s[kt][8 * ss + 5]);
         pf[3] = pack_bf2(s[kt][8 * ss + 6], s[kt][8 * ss + 7]);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const int d = dt * 32 + frow;
-          const int sw = (d >> 1) & 7, c0 = kt * 4 + 2 * ss;
-          const u32x2 lo = *reinterpret_cast<const u32x2*>(Vs + d * 128 + ((c0 ^ sw) << 4) + 8 * fhalf);
-          const u32x2 hi = *reinterpret_cast<const u32x2*>(Vs + d * 128 + (((c0 + 1) ^ sw) << 4) + 8 * fhalf);
-          u32x4 vf;
-          vf[0] = lo[0]; vf[1] = lo[1]; vf[2] = hi[0]; vf[3] = hi[1];
-          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf),
-                                                          __builtin_bit_cast(bf16x8, pf), o[dt], 0, 0, 0);
-        }
+        for (int dt = 0; dt < 2; ++dt) o[dt] = mfma_bf16(trfrag(Vs, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
       }
   }
 
@@ -163,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
 
 // ---------------------------------------------------------------- parity tier (fp32, VALU)
 template <int HD>
-__global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ qk, const float* __restrict__ vt,
+__global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ qk,
                                                       const uint8_t* __restrict__ mask, float* __restrict__ out,
                                                       float* __restrict__ lse, int T, int Tp, int Mp, int D, int ld_qk,
                                                       float scale) {
@@ -188,8 +176,8 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
       Ks[r][d] = qk[((size_t)n * Tp + kb * 64 + r) * ldq + D + h * HD + d];
     }
     for (int idx = tid; idx < 64 * HD; idx += 64) {
-      const int d = idx / 64, j = idx % 64;
-      Vs[d][j] = vt[((size_t)h * HD + d) * Mp + (size_t)n * Tp + kb * 64 + j];
+      const int j = idx / HD, d = idx % HD;
+      Vs[d][j] = qk[((size_t)n * Tp + kb * 64 + j) * ldq + 2 * D + h * HD + d];
     }
     __syncthreads();
     for (int j = 0; j < 64; ++j) {
@@ -224,11 +212,12 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 
 }  // namespace
 
-int launch_attention(int prec, const void* qk, int ld_qk, const void* vt, const uint8_t* mask, void* out, float* lse,
-                     int N, int T, int Tp, int Mp, int heads, int head_dim, hipStream_t st) {
+int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, void* out, float* lse, int N, int T, int Tp,
+                     int Mp, int heads, int head_dim, hipStream_t st) {
   OSUD_CHECK_ARG(N > 0 && T > 0 && Tp >= T && Tp % 64 == 0 && Mp >= N * Tp, "attention: bad sizes N=%d T=%d Tp=%d Mp=%d", N,
                  T, Tp, Mp);
   const int D = heads * head_dim;
+  OSUD_CHECK_ARG(ld_qk >= 3 * D, "attention: packed q|k|v rows need ld >= 3*hidden (got %d)", ld_qk);
   const float scale = 1.0f / sqrtf((float)head_dim);
   if (prec == OSUD_PREC_BF16) {
     if (head_dim != 64) {
@@ -236,15 +225,15 @@ int launch_attention(int prec, const void* qk, int ld_qk, const void* vt, const 
       return OSUD_ERR_UNSUPPORTED;
     }
     dim3 grid((Tp + 127) / 128, heads, N);
-    hipLaunchKernelGGL(attn_bf16_kernel, grid, dim3(256), 0, st, (const bf16_t*)qk, (const bf16_t*)vt, mask,
+    hipLaunchKernelGGL(attn_bf16_kernel, grid, dim3(256), 0, st, (const bf16_t*)qk, mask,
                        (bf16_t*)out, lse, T, Tp, Mp, D, ld_qk, scale * 1.4426950408889634f);
   } else {
     dim3 grid(Tp / 64, heads, N);
     if (head_dim == 64)
-      hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(64), 0, st, (const float*)qk, (const float*)vt, mask,
+      hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(64), 0, st, (const float*)qk, mask,
                          (float*)out, lse, T, Tp, Mp, D, ld_qk, scale);
     else if (head_dim == 72)
-      hipLaunchKernelGGL(attn_f32_kernel<72>, grid, dim3(64), 0, st, (const float*)qk, (const float*)vt, mask,
+      hipLaunchKernelGGL(attn_f32_kernel<72>, grid, dim3(64), 0, st, (const float*)qk, mask,
                          (float*)out, lse, T, Tp, Mp, D, ld_qk, scale);
     else {
       set_error("attention: head_dim %d not built (64, 72)", head_dim);

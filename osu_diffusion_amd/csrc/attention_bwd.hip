@@ -15,55 +15,12 @@
 // index contiguous (K^T, Q^T, dO^T) are read straight from the row-major LDS tiles with
 // ds_read_b64_tr_b16, so no transposed copies exist (LDS 66 KB for T = 128 -> two workgroups per CU).
 // f32 tier: plain VALU kernels (one thread per query / per key).
+#include "attn_frag.h"
 #include "kernels.h"
 
 namespace osud {
 
 namespace {
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ u32x4 rowfrag(const char* tile, int row, int chunk) {
-  return *reinterpret_cast<const u32x4*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
-}
-// A operand whose contraction index is the ROW of a row-major [rows][64 d] tile (128-byte rows, chunk index
-// XOR-swizzled with (row>>1)&7): lane (d = d0 + (lane&31), half) gets, for column d, the 8 rows
-//   r0 + 4*half + {0..3}  and  r0 + 8 + 4*half + {0..3}
-// — the same permuted order in which P / dS leave the S-layout registers (see pack8) — via two transposing reads
-// (each 16-lane group: 4 rows x 16 columns; semantics pinned by tools/probes/tr_probe.hip).
-__device__ __forceinline__ u32x4 trfrag(const char* tile, int r0, int d0, int lane) {
-  const int row = r0 + 4 * (lane >> 5) + ((lane & 15) >> 2);
-  const int colb = (d0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;  // byte offset of this lane's 4 columns
-  const int chunk = colb >> 4, within = colb & 15;
-  const uint32_t base = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)tile;
-  const uint32_t a0 = base + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) + within;
-  const uint32_t a1 = base + (row + 8) * 128 + ((chunk ^ (((row + 8) >> 1) & 7)) << 4) + within;
-  // reads and their wait are ONE asm statement: a separate s_waitcnt statement does not stop the scheduler from
-  // moving the consumers (register moves, MFMA) above it, because the asm outputs look ready to the compiler
-  u32x2 lo, hi;
-  asm volatile(
-      "ds_read_b64_tr_b16 %0, %2\n\t"
-      "ds_read_b64_tr_b16 %1, %3\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(lo), "=&v"(hi)
-      : "v"(a0), "v"(a1)
-      : "memory");
-  u32x4 v;
-  v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
-  return v;
-}
-__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-__device__ __forceinline__ u32x4 pack8(const f32x16& v, int base) {
-  u32x4 r;
-  r[0] = pack_bf2(v[base + 0], v[base + 1]);
-  r[1] = pack_bf2(v[base + 2], v[base + 3]);
-  r[2] = pack_bf2(v[base + 4], v[base + 5]);
-  r[3] = pack_bf2(v[base + 6], v[base + 7]);
-  return r;
-}
 
 __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                             const bf16_t* __restrict__ O, const float* __restrict__ lse,

@@ -21,9 +21,9 @@ struct DevBuf {
 };
 
 struct BlockWeights {
-  // TE, [out][in].  w_qkv is the packed in_proj ([Wq;Wk;Wv], 3D x D); w_qk / w_v alias its first 2D / last D rows.
-  void *w_qkv = nullptr, *w_qk = nullptr, *w_v = nullptr, *w_o = nullptr, *w1 = nullptr, *w2 = nullptr;
-  float *b_qkv = nullptr, *b_qk = nullptr, *b_v = nullptr, *b_o = nullptr, *b1 = nullptr, *b2 = nullptr;
+  // TE, [out][in].  w_qkv is the packed in_proj ([Wq;Wk;Wv], 3D x D).
+  void *w_qkv = nullptr, *w_o = nullptr, *w1 = nullptr, *w2 = nullptr;
+  float *b_qkv = nullptr, *b_o = nullptr, *b1 = nullptr, *b2 = nullptr;
   // transposed copies ([in][out]) for the data-gradient products (training only)
   void *w_qkv_t = nullptr, *w_o_t = nullptr, *w1_t = nullptr, *w2_t = nullptr;
 };
@@ -34,7 +34,7 @@ struct LayerSaved {
   float* h_mid = nullptr;    // [Mp][D] after the attention branch
   float* stats1 = nullptr;   // [Mp][2] mean, rstd of LN1
   float* stats2 = nullptr;   // [Mp][2]
-  void *u1 = nullptr, *qk = nullptr /* [Mp][3D] q|k|v */, *vt = nullptr, *ao = nullptr, *u2 = nullptr, *z1 = nullptr,
+  void *u1 = nullptr, *qk = nullptr /* [Mp][3D] q|k|v */, *ao = nullptr, *u2 = nullptr, *z1 = nullptr,
        *g = nullptr, *br1 = nullptr /* attention branch output */, *br2 = nullptr /* MLP branch output */;
   float* lse = nullptr;  // [N][H][Tp]
 };
@@ -95,7 +95,7 @@ struct osud_dit {
 
   // workspaces (reserve)
   int cap_N = 0, cap_T = 0, cap_Mp = 0, cap_Np = 0, cap_Tp = 0;
-  void *e0 = nullptr, *u = nullptr, *qk = nullptr, *vt = nullptr, *ao = nullptr, *g = nullptr;
+  void *e0 = nullptr, *u = nullptr, *qk = nullptr /* [Mp][3D] q|k|v */, *ao = nullptr, *g = nullptr;
   float *h = nullptr, *tvec = nullptr, *bvec = nullptr, *ada = nullptr, *out_ws = nullptr;
   void *temb = nullptr, *th = nullptr, *sb = nullptr;
   int64_t *t_model = nullptr, *t_index = nullptr;

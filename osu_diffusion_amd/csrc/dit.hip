@@ -50,8 +50,7 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
   if (!tr) {
     OSUD_TRY(dev_alloc(W, &m->h, (size_t)Mp * D * 4));
     OSUD_TRY(dev_alloc(W, &m->u, (size_t)Mp * D * es));
-    OSUD_TRY(dev_alloc(W, &m->qk, (size_t)Mp * 2 * D * es));
-    OSUD_TRY(dev_alloc(W, &m->vt, (size_t)Mp * D * es));
+    OSUD_TRY(dev_alloc(W, &m->qk, (size_t)Mp * 3 * D * es));
     OSUD_TRY(dev_alloc(W, &m->ao, (size_t)Mp * D * es));
     OSUD_TRY(dev_alloc(W, &m->g, (size_t)Mp * 4 * D * es));
   } else {
@@ -68,7 +67,6 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
       OSUD_TRY(dev_alloc(W, &s.stats2, (size_t)Mp * 2 * 4));
       OSUD_TRY(dev_alloc(W, &s.u1, (size_t)Mp * D * es));
       OSUD_TRY(dev_alloc(W, &s.qk, (size_t)Mp * 3 * D * es));
-      OSUD_TRY(dev_alloc(W, &s.vt, (size_t)Mp * D * es));
       OSUD_TRY(dev_alloc(W, &s.ao, (size_t)Mp * D * es));
       OSUD_TRY(dev_alloc(W, &s.u2, (size_t)Mp * D * es));
       OSUD_TRY(dev_alloc(W, &s.z1, (size_t)Mp * 4 * D * es));
@@ -158,7 +156,6 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
     LayerSaved* sv = m->training ? &m->saved[(size_t)l] : nullptr;
     void* u1 = sv ? sv->u1 : m->u;
     void* qk = sv ? sv->qk : m->qk;
-    void* vt = sv ? sv->vt : m->vt;
     void* ao = sv ? sv->ao : m->ao;
     void* u2 = sv ? sv->u2 : m->u;
     void* g = sv ? sv->g : m->g;
@@ -169,11 +166,10 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
     const int base = l * 6 * D;
     OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base, base + D, u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st, pend,
                            pend_gate, pend ? h_in : nullptr));
-    // training keeps V row-major too (its backward contracts over d): one 3D-wide product instead of 2D
-    const int qcols = sv ? 3 * D : 2 * D;
+    // packed in_proj: one 3D-wide product, Q | K | V row-major (the attention kernels transpose V on the LDS read)
+    const int qcols = 3 * D;
     OSUD_TRY(gemm(m, EPI_BIAS_TE, u1, D, w.w_qkv, D, Mp, qcols, D, qk, qcols, w.b_qkv, st));
-    OSUD_TRY(gemm(m, EPI_ROWBIAS_TE, w.w_v, D, u1, D, D, Mp, D, vt, Mp, w.b_v, st));  // V^T = W_v . u^T
-    OSUD_TRY(launch_attention(prec, qk, qcols, vt, mask, ao, sv ? sv->lse : nullptr, N, T, Tp, Mp, m->H, m->hd, st));
+    OSUD_TRY(launch_attention(prec, qk, qcols, mask, ao, sv ? sv->lse : nullptr, N, T, Tp, Mp, m->H, m->hd, st));
     if (!sv) {
       OSUD_TRY(gemm(m, EPI_GATE_RES, ao, D, w.w_o, D, Mp, D, D, h, D, w.b_o, st, m->ada + base + 2 * D, AC, Tp, N));
       OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base + 3 * D, base + 4 * D, u2, nullptr, Mp, Tp, N, D, st));
@@ -267,10 +263,6 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   m->blk.resize((size_t)m->L);
   for (auto& b : m->blk) {
     A(&b.w_qkv, 3 * D * D * es); A(&b.b_qkv, 3 * D * 4);
-    if (rc == OSUD_OK) {
-      b.w_qk = b.w_qkv; b.w_v = (char*)b.w_qkv + 2 * D * D * es;
-      b.b_qk = b.b_qkv; b.b_v = b.b_qkv + 2 * D;
-    }
     A(&b.w_o, D * D * es);      A(&b.b_o, D * 4);
     A(&b.w1, 4 * D * D * es);   A(&b.b1, 4 * D * 4);
     A(&b.w2, 4 * D * D * es);   A(&b.b2, D * 4);
@@ -482,9 +474,9 @@ extern "C" int osud_op_convert(int precision, const float* src, void* dst, size_
   OSUD_CHECK_ARG(src && dst, "op_convert: null argument");
   return launch_convert(precision, src, dst, n, (hipStream_t)stream);
 }
-extern "C" int osud_op_attention(int precision, const void* qk, const void* vt, const uint8_t* mask, void* out, int N,
+extern "C" int osud_op_attention(int precision, const void* qkv, int ld_qkv, const uint8_t* mask, void* out, int N,
                                  int T, int Tp, int Mp, int heads, int head_dim, osud_stream stream) {
-  OSUD_CHECK_ARG(qk && vt && out, "op_attention: null argument");
-  return launch_attention(precision, qk, 2 * heads * head_dim, vt, mask, out, nullptr, N, T, Tp, Mp, heads, head_dim,
+  OSUD_CHECK_ARG(qkv && out, "op_attention: null argument");
+  return launch_attention(precision, qkv, ld_qkv, mask, out, nullptr, N, T, Tp, Mp, heads, head_dim,
                           (hipStream_t)stream);
 }

@@ -22,8 +22,9 @@ int launch_cfg_combine(float* out, int N, int C, int C2, int T, float s, hipStre
 int launch_convert(int prec, const float* src, void* dst, size_t n, hipStream_t st);
 int launch_pack_rows(int prec, const float* src, int ld_src, int cols_src, void* dst, int ld_dst, int cols_dst, int rows,
                      hipStream_t st);
-int launch_attention(int prec, const void* qk, int ld_qk, const void* vt, const uint8_t* mask, void* out, float* lse,
-                     int N, int T, int Tp, int Mp, int heads, int head_dim, hipStream_t st);
+// qkv: packed in_proj output [Mp][ld_qkv], Q | K | V in columns [0,D) [D,2D) [2D,3D)
+int launch_attention(int prec, const void* qkv, int ld_qkv, const uint8_t* mask, void* out, float* lse, int N, int T, int Tp,
+                     int Mp, int heads, int head_dim, hipStream_t st);
 int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* O, const float* lse, void* dqkv, int N,
                          int T, int heads, int head_dim, hipStream_t st);
 

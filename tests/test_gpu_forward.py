@@ -113,20 +113,20 @@ def test_attention_core(prec, tol, T_, masked):
     Tp = (T_ + 63) // 64 * 64
     Mp = (N * Tp + 127) // 128 * 128
     torch.manual_seed(T_)
-    qk = torch.randn(Mp, 2 * D, device=DEV)
-    v = torch.randn(Mp, D, device=DEV)
+    qkv = torch.randn(Mp, 3 * D, device=DEV)  # packed in_proj output: Q | K | V
     mask = banded_attn_mask(T_, 128).to(DEV) if masked else None
-    qkc, vtc = to_elem(prec, qk), to_elem(prec, v.T.contiguous())
-    qkr, vr = from_elem(prec, qkc, (Mp, 2 * D)), from_elem(prec, vtc, (D, Mp)).T
+    qkc = to_elem(prec, qkv)
+    qkr = from_elem(prec, qkc, (Mp, 3 * D))
+    vr = qkr[:, 2 * D:]
     out = torch.zeros(Mp * D * (2 if prec == 0 else 4), dtype=torch.uint8, device=DEV)
     m8 = None if mask is None else mask.to(torch.uint8).contiguous()
-    _lib.check(_lib.lib().osud_op_attention(prec, _lib.ptr(qkc), _lib.ptr(vtc), _lib.ptr(m8), _lib.ptr(out), N, T_, Tp, Mp, H,
+    _lib.check(_lib.lib().osud_op_attention(prec, _lib.ptr(qkc), 3 * D, _lib.ptr(m8), _lib.ptr(out), N, T_, Tp, Mp, H,
                                             hd, None))
     got = from_elem(prec, out, (Mp, D))
     for n in range(N):
         rows = slice(n * Tp, n * Tp + T_)
         q = qkr[rows, :D].reshape(T_, H, hd).transpose(0, 1).double()
-        k = qkr[rows, D:].reshape(T_, H, hd).transpose(0, 1).double()
+        k = qkr[rows, D:2 * D].reshape(T_, H, hd).transpose(0, 1).double()
         vv = vr[rows].reshape(T_, H, hd).transpose(0, 1).double()
         s = q @ k.transpose(-1, -2) / hd ** 0.5
         if mask is not None:
