@@ -279,6 +279,73 @@ def g9_init_and_keys():
          state_keys=np.array(list(sd.keys())), **{"probe:" + k: v for k, v in probe.items()})
 
 
+# ------------------------------------------------------------------ G9 windows (loader contract)
+def g9_windows():
+    """data_loading.py imports the third-party `slider` package at module scope (absent here): stub modules let the
+    reference's pure-tensor window code and its iterables run; `.osu` parsing itself is NOT exercised (out of scope)."""
+    import random
+    import types
+    print("G9 windows: window contract of the loader (slider stubbed)")
+    for name in ("slider", "slider.beatmap", "slider.curve"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    setattr(sys.modules["slider"], "Position", type("Position", (), {}))
+    for cls in ("Beatmap", "Circle", "Slider", "Spinner", "HitObject", "HoldNote"):
+        setattr(sys.modules["slider.beatmap"], cls, type(cls, (), {}))
+    for cls in ("Linear", "Catmull", "Perfect", "MultiBezier"):
+        setattr(sys.modules["slider.curve"], cls, type(cls, (), {}))
+    import data_loading as ref_dl  # noqa: E402  (reference)
+    from osu_diffusion_amd import windows as W
+
+    ref_dl.Beatmap.from_path = staticmethod(lambda path: path)  # the iterable only hands the result to seq_func
+    sources = W.synthetic_sequences(8, min_len=100, max_len=700, seed=5)
+    by_name = dict(sources)
+    # per-sequence maths
+    seq = sources[3][1]
+    close(W.calc_distances(seq.clone()), ref_dl.calc_distances(seq.clone()), 0.0, "calc_distances")
+    (rx, ro, rc), rl = ref_dl.split_and_process_sequence_no_augment(seq.clone())
+    (mx, mo_, mc), ml = W.split_and_process_sequence_no_augment(seq.clone())
+    assert rl == ml
+    close(mx, rx, 0.0, "no_augment x"); close(mo_, ro, 0.0, "no_augment o"); close(mc, rc, 0.0, "no_augment c")
+
+    def run(make_iter, n_max):
+        random.seed(2024)
+        out = []
+        for (x, o, c), y in make_iter():
+            out.append((x.clone(), o.clone(), c.clone(), int(y)))
+            if len(out) == n_max:
+                break
+        return out
+
+    def ref_iter(files, seq_len, stride):
+        return ref_dl.BeatmapDatasetIterable(files, seq_len, stride, lambda p: ref_dl.split_and_process_sequence(by_name[p].clone()),
+                                             ref_dl.window_and_relative_time)
+
+    cases = {}
+    names = [n for n, _ in sources]
+    for tag, seq_len, stride, cycle in (("plain", 128, 16, 1), ("inter", 64, 32, 3)):
+        if cycle == 1:
+            ref_out = run(lambda: ref_iter(names, seq_len, stride), 200)
+            my_out = run(lambda: W.WindowIterable(sources, seq_len, stride, lambda t: W.split_and_process_sequence(t.clone())), 200)
+        else:
+            ref_out = run(lambda: ref_dl.InterleavingBeatmapDatasetIterable(names, lambda f: ref_iter(f, seq_len, stride), cycle), 200)
+            my_out = run(lambda: W.InterleavingIterable(
+                sources, lambda srcs: W.WindowIterable(srcs, seq_len, stride, lambda t: W.split_and_process_sequence(t.clone())), cycle), 200)
+        assert len(ref_out) == len(my_out) and len(ref_out) > 10, (tag, len(ref_out), len(my_out))
+        for (a, b) in zip(ref_out, my_out):
+            assert a[3] == b[3]
+            for u, v in zip(a[:3], b[:3]):
+                assert torch.equal(u, v), tag
+        print(f"  windows [{tag}]: {len(ref_out)} windows identical to the reference")
+        cases[tag + ":count"] = len(ref_out)
+        cases[tag + ":labels"] = np.array([w[3] for w in ref_out])
+        cases[tag + ":offsets"] = np.array([float(w[1][0]) for w in ref_out])            # the random time offsets
+        cases[tag + ":xsum"] = np.array([float(w[0].double().sum()) for w in ref_out])
+        cases[tag + ":csum"] = np.array([float(w[2].double().sum()) for w in ref_out])
+        for k in (0, 1, len(ref_out) - 1):                                           # three windows in full
+            cases[f"{tag}:x{k}"], cases[f"{tag}:o{k}"], cases[f"{tag}:c{k}"] = ref_out[k][0], ref_out[k][1], ref_out[k][2]
+    save("g9_windows", seq3=seq, dist3=ref_dl.calc_distances(seq.clone()), x3=rx, o3=ro, c3=rc, **cases)
+
+
 if __name__ == "__main__":
     g1_schedules()
     g2_embeddings()
@@ -287,4 +354,5 @@ if __name__ == "__main__":
     g6_loop()
     g7_training()
     g9_init_and_keys()
+    g9_windows()
     print("all golden fixtures written; oracle pinned against the reference")

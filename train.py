@@ -19,6 +19,7 @@ import torch.distributed as dist
 from osu_diffusion_amd.diffusion import create_diffusion
 from osu_diffusion_amd.models import DiT_models
 from osu_diffusion_amd.synthetic import synthetic_windows
+from osu_diffusion_amd.windows import WindowIterableFactory, get_data_loader, synthetic_sequences
 from osu_diffusion_amd.training import NativeTrainer, shard_range
 
 feature_size = 19
@@ -74,8 +75,19 @@ def main(args):
         logger.info(f"Restored from checkpoint at {args.ckpt}")
 
     batch_size = args.global_batch_size // world_size
-    dataset_start, dataset_end = shard_range(args.data_start, args.data_end, rank, world_size)
     assert args.synthetic, "real datasets need the `slider` parser (out of scope); pass --synthetic"
+    loader = None
+    if args.synthetic_maps > 0:
+        # the reference's loader contract end to end (windows.py): sequences -> overlapping windows with random phase, flips
+        # and time offsets -> batches; tracks split per rank (train.py:165-170), then per DataLoader worker
+        catalogue = synthetic_sequences(args.synthetic_maps, min_len=args.seq_len, max_len=8 * args.seq_len,
+                                        seed=args.global_seed, first_id=0)
+        dataset_start, dataset_end = shard_range(0, len(catalogue), rank, world_size)
+        loader = get_data_loader(catalogue, dataset_start, dataset_end, WindowIterableFactory(args.seq_len, args.stride),
+                                 cycle_length=max(1, batch_size // 2), batch_size=batch_size, num_workers=args.num_workers, shuffle=True,
+                                 pin_memory=True, drop_last=True)
+    else:
+        dataset_start, dataset_end = shard_range(args.data_start, args.data_end, rank, world_size)
     logger.info(f"Dataset contains {(dataset_end - dataset_start):,} (synthetic) beatmap sets")
 
     train_steps, log_steps, start_time = 0, 0, time()
@@ -83,9 +95,15 @@ def main(args):
     logger.info(f"Training for {args.epochs} epochs...")
     for epoch in range(args.epochs):
         logger.info(f"Beginning epoch {epoch}...")
-        for it in range(args.steps_per_epoch):
-            track = dataset_start + (epoch * args.steps_per_epoch + it) % max(1, dataset_end - dataset_start)
-            (x, o, c), y = synthetic_windows(batch_size, args.seq_len, args.num_classes, seed=track)
+        def batches():
+            if loader is not None:
+                yield from loader
+                return
+            for it in range(args.steps_per_epoch):
+                track = dataset_start + (epoch * args.steps_per_epoch + it) % max(1, dataset_end - dataset_start)
+                yield synthetic_windows(batch_size, args.seq_len, args.num_classes, seed=track)
+
+        for (x, o, c), y in batches():
             terms = trainer.step(x, o, c, y)
             running_loss += terms[2].mean()
             log_steps += 1
@@ -139,6 +157,9 @@ if __name__ == "__main__":
     p.add_argument("--relearn-embeds", type=bool, default=False)
     p.add_argument("--embed-only-epochs", type=int, default=0)
     p.add_argument("--synthetic", action="store_true", help="train on synthetic windows (no `slider` needed)")
+    p.add_argument("--synthetic-maps", type=int, default=0,
+                   help="with --synthetic: stream windows from this many synthetic hit-object sequences through the "
+                        "reference's loader contract (windows.py) instead of drawing windows directly")
     p.add_argument("--steps-per-epoch", type=int, default=1000)
     p.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
     main(p.parse_args())
