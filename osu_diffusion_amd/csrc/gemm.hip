@@ -283,7 +283,8 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
 #endif
       // (Measured with -DOSUD_GEMM_TIMING: a slab costs ~3200 cycles = 64 LDS-DMA pieces x ~50 cycles, i.e. the CU's LDS-DMA
       // issue rate (~20 B/clk), not L2/HBM -- all workgroups streaming the SAME panels run no faster -- and not the MFMA
-      // pipe (2 x 1024 cycles).  Issuing half the waves' pieces mid-slab instead of here changes nothing.)
+      // pipe (2 x 1024 cycles).  Issuing half the waves' pieces mid-slab instead of here changes nothing; touching the
+      // lines of the slab 2-4 ahead with one plain load per wave (L2 warm-up) costs 4-7 % end to end.)
       issue_next();
 #ifdef OSUD_GEMM_TIMING
       const uint64_t tt3 = __builtin_readcyclecounter();
