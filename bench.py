@@ -64,8 +64,11 @@ def dist_setup(args):
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # OSUD_DIST_BACKEND=gloo + OSUD_SINGLE_DEVICE=1: functional check of the N>1 path on a one-GPU box (all ranks on GPU 0)
+        if os.environ.get("OSUD_SINGLE_DEVICE", "0") == "1":
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl")  # RCCL on ROCm
+        dist.init_process_group(os.environ.get("OSUD_DIST_BACKEND", "nccl"))  # nccl = RCCL on ROCm
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -238,7 +241,7 @@ def bench_train(args, world, rank, dev):
         "config": {"workload": f"train.py step: {args.model} seq-len {T}, per-GPU batch {B} synthetic windows (global {B * world}), "
                                f"L1+vb loss, AdamW lr 1e-4, EMA 0.9999, label dropout 0.2, squaredcos_cap_v2 1000 steps",
                    "per_gpu_batch": B, "global_batch": B * world, "seq_len": T,
-                   "parallelism": f"dp{world}: flat fp32 gradient arena, one RCCL all-reduce per step" if world > 1 else "single GPU",
+                   "parallelism": f"dp{world}: flat fp32 gradient arena, per-slice RCCL all-reduces overlapped with the phased backward" if world > 1 else "single GPU",
                    "last_loss": round(loss, 4)},
         "per_gpu_tokens_per_s": round(tokens_per_s / world, 1),
     }

@@ -1,0 +1,51 @@
+"""Worker of tests/test_gpu_multiproc.py: one data-parallel rank of a tiny fp32-tier training run.  All ranks share GPU 0
+(the GPU box has one device) and exchange gradients through gloo, so the whole multi-process path — rank-0 broadcast,
+phased backward with per-slice async all-reduce, 1/world folded into the optimizer — runs exactly as under RCCL."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from osu_diffusion_amd.diffusion import create_diffusion  # noqa: E402
+from osu_diffusion_amd.models import DiT  # noqa: E402
+from osu_diffusion_amd.synthetic import randomize_zero_init, synthetic_windows  # noqa: E402
+from osu_diffusion_amd.training import NativeTrainer  # noqa: E402
+
+
+def build(seed):
+    torch.manual_seed(seed)
+    m = DiT(depth=2, hidden_size=128, num_heads=2, context_size=144, num_classes=10, class_dropout_prob=0.0, precision="fp32")
+    return randomize_zero_init(m.to("cuda:0"), seed=seed).train()
+
+
+def batch():
+    (x, o, c), y = synthetic_windows(8, 64, 10, seed=11)
+    t = torch.tensor([0, 1, 17, 250, 500, 731, 998, 999])
+    noise = torch.randn(8, 2, 64, generator=torch.Generator().manual_seed(12))
+    return x, o, c, y, t, noise
+
+
+def run(rank, world, steps=2):
+    # every rank starts from DIFFERENT weights: the constructor's rank-0 broadcast must make them equal
+    model = build(100 + rank)
+    tr = NativeTrainer(model, create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True), lr=1e-3)
+    x, o, c, y, t, noise = batch()
+    per = 8 // world
+    sl = slice(rank * per, (rank + 1) * per)
+    for _ in range(steps):
+        tr.step(x[sl], o[sl], c[sl], y[sl], t=t[sl], noise=noise[sl])
+    torch.cuda.synchronize()
+    return tr.arena.flat.detach().cpu().clone(), tr.ema_arena.flat.detach().cpu().clone()
+
+
+if __name__ == "__main__":
+    out_dir = sys.argv[1]
+    torch.cuda.set_device(0)
+    dist.init_process_group(os.environ.get("OSUD_DIST_BACKEND", "gloo"))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    flat, ema = run(rank, world)
+    torch.save({"flat": flat, "ema": ema}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
