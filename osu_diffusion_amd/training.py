@@ -141,8 +141,9 @@ def native_backward(model, dout, phases=None):
 
 def overlap_slices(arena, depth):
     """Element ranges of the flat gradient arena in the order they become final during the phased backward:
-    ("block", l, lo, hi) right after block l's phase — its 8 attention/MLP tensors are contiguous — then the
-    ("tail", ...) ranges that need the last phase (embedders + class table, every adaLN pair, final layer)."""
+    ("block", l, lo, hi) right after block l's phase — its 8 attention/MLP tensors are contiguous — then the ranges that
+    need the last phase: ("tail", ...) = embedders, every adaLN pair, final layer, and ("table", ...) = the class table,
+    whose gradient is row-sparse and is exchanged as rows (exchange_table_rows) instead of densely."""
     off = {n: (int(o), int(o + s)) for n, o, s in zip(arena.names, arena.offsets[:-1], arena.sizes)}
     blocks, tail = [], []
     for l in range(depth):
@@ -150,17 +151,50 @@ def overlap_slices(arena, depth):
         hi = off[f"blocks.{l}.mlp.fc2.bias"][1]
         blocks.append(("block", l, lo, hi))
         tail.append(("tail", l, off[f"blocks.{l}.adaLN_modulation.1.weight"][0], off[f"blocks.{l}.adaLN_modulation.1.bias"][1]))
-    tail.insert(0, ("tail", -1, 0, off["blocks.0.attn.in_proj_weight"][0]))
+    t_lo, t_hi = off["y_embedder.embedding_table.weight"]
+    first_block = off["blocks.0.attn.in_proj_weight"][0]
+    head = [("tail", -1, 0, t_lo), ("table", -1, t_lo, t_hi)]
+    if t_hi < first_block:
+        head.append(("tail", -1, t_hi, first_block))
+    tail = head + tail
     tail.append(("tail", depth, off["final_layer.linear.weight"][0], arena.total))
     covered = sorted((lo, hi) for _, _, lo, hi in blocks + tail)
     assert covered[0][0] == 0 and covered[-1][1] == arena.total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
     return blocks, tail
 
 
-def backward_with_overlapped_allreduce(model, dout, group=None, force=False):
+def exchange_table_rows(table_grad, labels, group=None):
+    """SUM the class-table gradient over ranks by exchanging only the touched rows.
+
+    The table gradient (52 671 x D, 162 MB for DiT-B — a quarter of the whole gradient) is non-zero only in the rows of
+    the step's (post-dropout) labels, at most B per rank (models.py:56-74; the reference's DDP all-reduces it densely).
+    Each rank contributes its labels sorted, with one copy of every touched row (duplicates zeroed), via all_gather
+    (2 x W x B x D floats in total); every rank then rebuilds the touched rows by adding the contributions in RANK ORDER,
+    so replicas stay bit-identical (a scatter with atomics in arbitrary order would not guarantee that)."""
+    import torch.distributed as dist
+
+    W = dist.get_world_size(group)
+    ys, _ = torch.sort(labels.to(torch.int64).reshape(-1))
+    first = torch.ones_like(ys, dtype=torch.bool)
+    first[1:] = ys[1:] != ys[:-1]
+    rows = table_grad[ys] * first.unsqueeze(1).to(table_grad.dtype)
+    all_idx = [torch.empty_like(ys) for _ in range(W)]
+    all_rows = [torch.empty_like(rows) for _ in range(W)]
+    dist.all_gather(all_idx, ys, group=group)
+    dist.all_gather(all_rows, rows, group=group)
+    for idx in all_idx:
+        table_grad.index_fill_(0, idx, 0.0)
+    for idx, r in zip(all_idx, all_rows):  # within one rank's list a row index carries at most one non-zero row
+        table_grad.index_add_(0, idx, r)
+    return table_grad
+
+
+def backward_with_overlapped_allreduce(model, dout, group=None, force=False, on_blocks_reduced=None):
     """Backward in phases; each block's gradient slice is SUM-all-reduced (async, RCCL's own stream) as soon
     as its phase is enqueued, overlapping the exchange with the remaining backward compute — the role of
-    DDP's bucketed reducer (train.py:152,257).  Returns the 1/world factor for the optimizer."""
+    DDP's bucketed reducer (train.py:152,257).  `on_blocks_reduced()` (optional) is called once every block slice has
+    been reduced, while the tail exchange is still in flight (the optimizer uses that window).
+    Returns the 1/world factor for the optimizer."""
     import torch.distributed as dist
 
     inited = dist.is_available() and dist.is_initialized()
@@ -178,9 +212,20 @@ def backward_with_overlapped_allreduce(model, dout, group=None, force=False):
         _, _, lo, hi = blocks[depth - p]
         handles.append(reduce(arena.grads[lo:hi]))
     native_backward(model, dout, phases=(depth + 1, depth + 1))
-    for _, _, lo, hi in tail:
-        handles.append(reduce(arena.grads[lo:hi]))
+    tail_handles = []
+    for kind, _, lo, hi in tail:
+        if kind == "tail":
+            tail_handles.append(reduce(arena.grads[lo:hi]))
     for h in handles:
+        if h is not None:
+            h.wait()
+    if on_blocks_reduced is not None:
+        on_blocks_reduced([(lo, hi) for _, _, lo, hi in blocks])
+    if active:
+        _, _, t_lo, t_hi = next(s for s in tail if s[0] == "table")
+        rows = dict(model.named_parameters())["y_embedder.embedding_table.weight"].shape[0]
+        exchange_table_rows(arena.grads[t_lo:t_hi].view(rows, -1), model._train_keep[4], group)
+    for h in tail_handles:
         if h is not None:
             h.wait()
     return 1.0 / dist.get_world_size(group) if active else 1.0
@@ -212,6 +257,18 @@ def dit_forward_autograd(model, x, t, o, c, y, attn_mask):
 
 
 # ------------------------------------------------------------------------------ fused trainer
+def _complement(ranges, total):
+    """Element ranges of [0, total) not covered by `ranges`."""
+    out, pos = [], 0
+    for lo, hi in sorted(ranges):
+        if lo > pos:
+            out.append((pos, lo))
+        pos = max(pos, hi)
+    if pos < total:
+        out.append((pos, total))
+    return out
+
+
 class NativeTrainer:
     """The step body of train.py:243-261, natively.  `model` is trained in place; `ema` (a deepcopy
     made here unless given) tracks it with decay 0.9999."""
@@ -273,24 +330,51 @@ class NativeTrainer:
             dout = torch.empty_like(out)
             _lib.check(L.osud_train_loss(d._sched.handle, self.use_l1, _lib.ptr(out), _lib.ptr(x0), _lib.ptr(x_t), _lib.ptr(noise),
                                          _lib.ptr(t), B, T, _lib.ptr(terms), _lib.ptr(dout), st))
-            scale = backward_with_overlapped_allreduce(model, dout, self.group, force=self.force_phased)
-            self.optimizer_step(scale)
+            done = []
+
+            def early(ranges, _self=self):  # block slices are final: update them while the tail exchange is in flight
+                import torch.distributed as dist
+                _self.step_count += 1
+                _self._adamw(ranges, 1.0 / dist.get_world_size(_self.group) if dist.is_initialized() else 1.0)
+                done.extend(ranges)
+
+            scale = backward_with_overlapped_allreduce(model, dout, self.group, force=self.force_phased, on_blocks_reduced=early)
+            if done:
+                self._adamw(_complement(done, self.arena.total), scale)
+                self._refresh()
+            else:
+                self.optimizer_step(scale)
         return terms
+
+    def _adamw(self, ranges, grad_scale):
+        """AdamW + EMA on element ranges of the arenas (step_count already advanced)."""
+        a, dev = self.arena, self.arena.flat.device
+        f_lo, f_hi = a.frozen_range()
+        L = _lib.lib()
+        with torch.cuda.device(dev):
+            st = _lib.stream_ptr(dev)
+            for lo, hi in ranges:
+                if hi <= lo:
+                    continue
+                fl, fh = max(f_lo, lo) - lo, min(f_hi, hi) - lo  # frozen playfield_size, relative to this range
+                if fh <= fl:
+                    fl = fh = 0
+                _lib.check(L.osud_adamw_ema_step(_lib.ptr(a.flat[lo:hi]), _lib.ptr(a.grads[lo:hi]), _lib.ptr(self.exp_avg[lo:hi]),
+                                                 _lib.ptr(self.exp_avg_sq[lo:hi]), _lib.ptr(self.ema_arena.flat[lo:hi]), hi - lo,
+                                                 self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                                                 self.step_count, self.ema_decay, fl, fh, float(grad_scale), st))
+
+    def _refresh(self):
+        dev = self.arena.flat.device
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().osud_dit_refresh(self.model._handle, _lib.stream_ptr(dev)))
+        self.ema._uploaded = {}  # its masters changed behind torch's back
 
     def optimizer_step(self, grad_scale=1.0):
         """AdamW(lr, betas, eps, wd) + EMA (train.py:258-261) + re-pack of the low-precision copies."""
         self.step_count += 1
-        a, dev = self.arena, self.arena.flat.device
-        lo, hi = a.frozen_range()
-        L = _lib.lib()
-        with torch.cuda.device(dev):
-            st = _lib.stream_ptr(dev)
-            _lib.check(L.osud_adamw_ema_step(_lib.ptr(a.flat), _lib.ptr(a.grads), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
-                                             _lib.ptr(self.ema_arena.flat), a.total, self.lr, self.betas[0], self.betas[1],
-                                             self.eps, self.weight_decay, self.step_count, self.ema_decay, lo, hi,
-                                             float(grad_scale), st))
-            _lib.check(L.osud_dit_refresh(self.model._handle, st))
-        self.ema._uploaded = {}  # its masters changed behind torch's back
+        self._adamw([(0, self.arena.total)], grad_scale)
+        self._refresh()
 
     # ---- checkpoint layout of train.py:287-293 ------------------------------------------------
     def opt_state_dict(self):

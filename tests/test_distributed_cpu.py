@@ -69,7 +69,7 @@ def test_overlap_slices_cover_the_arena_exactly_once():
     m = DiT(depth=3, hidden_size=128, num_heads=2, context_size=144, num_classes=4)
     arena = ParamArena(m)
     blocks, tail = overlap_slices(arena, 3)
-    assert [b[1] for b in blocks] == [0, 1, 2] and len(tail) == 3 + 2
+    assert [b[1] for b in blocks] == [0, 1, 2] and [t[0] for t in tail] == ["tail", "table"] + ["tail"] * 4
     seen = torch.zeros(arena.total, dtype=torch.int32)
     for _, _, lo, hi in blocks + tail:
         seen[lo:hi] += 1
@@ -78,4 +78,33 @@ def test_overlap_slices_cover_the_arena_exactly_once():
     lo, n = names["blocks.1.mlp.fc1.weight"]
     assert blocks[1][2] <= lo and lo + n <= blocks[1][3]
     lo, n = names["y_embedder.embedding_table.weight"]
-    assert tail[0][2] <= lo and lo + n <= tail[0][3]
+    assert tail[1] == ("table", -1, int(lo), int(lo + n))  # exchanged as rows, not densely
+
+
+def _table_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from osu_diffusion_amd.training import exchange_table_rows
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(7 + rank)
+    labels = torch.randint(0, 12, (16,), generator=g)  # duplicates inside a rank and overlaps across ranks
+    dense = torch.zeros(12, 8)
+    dense.index_add_(0, labels, torch.randn(16, 8, generator=g))  # what the backward leaves: only label rows non-zero
+    ref = dense.clone()
+    dist.all_reduce(ref)  # the reference's dense DDP all-reduce
+    got = exchange_table_rows(dense.clone(), labels)
+    out[rank] = (ref, got)
+    dist.destroy_process_group()
+
+
+def test_row_exchange_of_the_class_table_equals_dense_allreduce():
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_table_worker, args=(2, port, out), nprocs=2, join=True)
+        (ref0, got0), (ref1, got1) = out[0], out[1]
+    assert torch.equal(got0, got1)  # replicas bit-identical
+    assert float((got0 - ref0).abs().max()) <= 1e-6 and float((ref0 - ref1).abs().max()) == 0.0
