@@ -51,22 +51,16 @@ template <int WY, int WX, int RY, int RX> struct WGeo {
   static_assert(NSTAGE * STAGE + NW * 4096 <= 160 * 1024, "stage ring + epilogue patches must fit the LDS");
 };
 
-// this wave's share of one 64-token stage
+// this wave's share of one 64-token stage: SGPR panel base + per-lane 32-bit offset computed once (see gemm.hip)
 template <typename G>
-__device__ __forceinline__ void stage_tokens(const char* gp, size_t ldp_b, const char* gq, size_t ldq_b, char* stage,
-                                             int wave, int lane) {
+__device__ __forceinline__ void stage_tokens(const char* gp, const char* gq, uint32_t stage_lds, const uint32_t (&voff)[G::PPW],
+                                             int wave) {
 #pragma unroll
   for (int q = 0; q < G::PPW; ++q) {
     const int piece = wave * G::PPW + q;  // wave-uniform
-    const bool isY = piece * 1024 < G::YB;
-    const int rowb = isY ? G::ROWY : G::ROWX;                // bytes per token row in this part
-    const int pb = isY ? piece * 1024 : piece * 1024 - G::YB;  // byte offset inside the part
-    const int lpr = rowb / 16;                                // lanes (16-byte chunks) per token row
-    const int tok = pb / rowb + lane / lpr, pos = lane % lpr;
-    const int c = pos ^ ((tok & 3) << 2);                     // source chunk for LDS position `pos`
-    const char* g = (isY ? gp + (size_t)tok * ldp_b : gq + (size_t)tok * ldq_b) + c * 16;
-    char* dst = stage + __builtin_amdgcn_readfirstlane(piece * 1024);
-    __builtin_amdgcn_global_load_lds((glb_void*)g, (lds_void*)dst, 16, 0, 0);
+    const char* sbase = (piece * 1024 < G::YB) ? gp : gq;
+    const uint32_t dst = stage_lds + (uint32_t)__builtin_amdgcn_readfirstlane(piece * 1024);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff[q]), "s"(sbase), "s"(dst) : "memory");
   }
 }
 
@@ -151,6 +145,19 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
     xa[j] = lds0 + G::YB + tok0 * G::ROWX + hi * 64 + fbyte;
   }
 
+  // per-lane byte offsets of this wave's LDS-DMA pieces inside a (P panel | Q panel) stage of 64 tokens
+  uint32_t dma_off[G::PPW];
+#pragma unroll
+  for (int q = 0; q < G::PPW; ++q) {
+    const int piece = wave * G::PPW + q;
+    const bool isY = piece * 1024 < G::YB;
+    const int rowb = isY ? G::ROWY : G::ROWX;                  // bytes per token row in this part
+    const int pb = isY ? piece * 1024 : piece * 1024 - G::YB;  // byte offset inside the part
+    const int lpr = rowb / 16;                                  // lanes (16-byte chunks) per token row
+    const int tok = pb / rowb + lane / lpr, pos = lane % lpr;
+    const int c = pos ^ ((tok & 3) << 2);                       // source chunk for LDS position `pos`
+    dma_off[q] = (uint32_t)((size_t)tok * (isY ? ldp_b : ldq_b) + c * 16);
+  }
   // epilogue patch (4 KiB per wave, behind the stage ring)
   const uint32_t patch = lds0 + G::NSTAGE * G::STAGE + wave * 4096;
   uint32_t pw[4];
@@ -170,7 +177,7 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
       const int ty = ic_tile / ntx, tx = ic_tile % ntx;
       const char* gp = gp0 + (size_t)ic_st * BKT * ldp_b + (size_t)ty * G::BM * 2;
       const char* gq = gq0 + (size_t)ic_st * BKT * ldq_b + (size_t)tx * G::BN * 2;
-      stage_tokens<G>(gp, ldp_b, gq, ldq_b, smem + (issued % G::NSTAGE) * G::STAGE, wave, lane);
+      stage_tokens<G>(gp, gq, lds0 + (uint32_t)((issued % G::NSTAGE) * G::STAGE), dma_off, wave);
       ++issued;
       if (++ic_st == nst) {
         ic_st = 0;
