@@ -228,7 +228,9 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
   uint32_t pw[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) pw[g] = patch + frow * 128 + (((2 * g + fhalf) ^ (frow & 7)) << 4);
-  const uint32_t pr = patch + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+  // read-back: lane l takes rows (l>>2) and 16 + (l>>2), 8 consecutive x = two 16-byte slots 2*(l&3), 2*(l&3)+1
+  const uint32_t pr0 = patch + (lane >> 2) * 128 + (((2 * (lane & 3)) ^ ((lane >> 2) & 7)) << 4);
+  const uint32_t pr1 = patch + (lane >> 2) * 128 + (((2 * (lane & 3) + 1) ^ ((lane >> 2) & 7)) << 4);
 
   // per-lane byte offsets of this wave's LDS-DMA pieces inside a (Y panel | X panel) slab; < 2^32 is checked by the launcher
   uint32_t dma_off[G::PPW];
@@ -326,101 +328,124 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
     // instruction touches 32 rows with 8..32 bytes each and the epilogue is bound by the L2 REQUEST rate
     // (measured: ~9 us per 256x256 tile, a third of the kernel).  So every 32x32 block takes a round trip
     // through a wave-private 4 KiB LDS patch (16-byte slot index XOR-swizzled with row&7, conflict free both
-    // ways) and comes back row-major: lane l holds rows 8p + (l>>3), p = 0..3, and x = 4*(l&7) + {0..3} --
-    // 8 lanes cover one full 128-byte (f32) / 64-byte (bf16) row segment, and the operand loads (residual,
-    // saved pre-activation) are coalesced the same way.
+    // ways) and comes back row-major: lane l holds rows (l>>2) and 16 + (l>>2) and x = 8*(l&3) + {0..7} -- 4 lanes
+    // cover one 128-byte (f32) / 64-byte (bf16) row segment with 16-byte (bf16) / 2 x 16-byte (f32) stores per lane, which
+    // halves the number of store instructions of a bf16 output (the TA spends ~16 cycles per vector-memory instruction
+    // whatever its width); the operand loads (residual, saved pre-activation) are coalesced the same way.
     // All loads of a block are issued BEFORE its stores: vmcnt counts stores too, so a load waited for
     // between stores would drain every earlier store.
     constexpr bool kBias = EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_TE || EPI == EPI_BIAS_SILU_TE ||
                            EPI == EPI_BIAS_GELU_TE || EPI == EPI_GATE_RES;
-    const int lrow = lane >> 3, lcol = 4 * (lane & 7);
+    const int lrow = lane >> 2, lcol = 8 * (lane & 3);
     const int xw = tx * BN + wx * RX * 32 + lcol;  // + j*32
-    float4 bv[RX];
+    float bv[RX][8];
     if (kBias) {
 #pragma unroll
-      for (int j = 0; j < RX; ++j) bv[j] = *reinterpret_cast<const float4*>(p.bias + xw + j * 32);
+      for (int j = 0; j < RX; ++j) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + xw + j * 32);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + xw + j * 32 + 4);
+        bv[j][0] = b0.x; bv[j][1] = b0.y; bv[j][2] = b0.z; bv[j][3] = b0.w;
+        bv[j][4] = b1.x; bv[j][5] = b1.y; bv[j][6] = b1.z; bv[j][7] = b1.w;
+      }
     }
+    // The blocks are software-pipelined: block b+1 enters the patch (4 writes + 4 reads) before block b is finished, so
+    // the LDS round trip hides under block b's arithmetic and stores.  One wave's LDS operations execute in order: the
+    // reads of b are done once at most the 8 newer operations are outstanding, and the writes of b+1 cannot overtake them.
+    constexpr int NB = RY * RX;
+    auto patch_trip = [&](int b, f32x4 (&t)[4]) {
+      const int i = b / RX, j = b % RX;
 #pragma unroll
-    for (int i = 0; i < RY; ++i) {
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+        v[0] = acc[i][j][4 * g + 0]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
+        ds_write16(pw[g] + pso, v);
+      }
+      t[0] = ds_read16f<0>(pr0 + pso);      // rows 0..15 : x 0..3 | 4..7 of this lane's 8
+      t[1] = ds_read16f<0>(pr1 + pso);
+      t[2] = ds_read16f<2048>(pr0 + pso);   // rows 16..31
+      t[3] = ds_read16f<2048>(pr1 + pso);
+    };
+    f32x4 tq[2][4];
+    patch_trip(0, tq[0]);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int i = b / RX, j = b % RX;
       const int yb = ty * G::BM + wy * RY * 32 + i * 32;  // wave-uniform first row of the block
-      const int y0 = yb + lrow;                           // + 8p
+      const int y0 = yb + lrow;                           // + 16q
       int sample = 0;
       if (EPI == EPI_GATE_RES) {  // rows_per_sample % 32 == 0: one sample per 32-row block
         sample = __builtin_amdgcn_readfirstlane(yb) / p.rows_per_sample;
         if (sample >= p.n_samples) sample = p.n_samples - 1;  // padding rows
       }
+      f32x4 (&t)[4] = tq[b & 1];
+      const int x = xw + j * 32;
+      float gv[8], rv[2][8];
+      float rb[2];
+      if (EPI == EPI_GATE_RES) {
+        const float* rsrc = p.res ? p.res : reinterpret_cast<const float*>(p.out);
+        load8(p.gate + (size_t)sample * p.ld_gate + x, gv);
 #pragma unroll
-      for (int j = 0; j < RX; ++j) {
-        // round trip through the patch (LDS operations of one wave execute in order: no wait between blocks)
+        for (int q = 0; q < 2; ++q) load8(rsrc + (size_t)(y0 + 16 * q) * p.ldo + x, rv[q]);
+      }
+      if (EPI == EPI_ACCUM_F32) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 v;
-          v[0] = acc[i][j][4 * g + 0]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
-          ds_write16(pw[g] + pso, v);
-        }
-        f32x4 t[4];
-        t[0] = ds_read16f<0>(pr + pso);
-        t[1] = ds_read16f<1024>(pr + pso);
-        t[2] = ds_read16f<2048>(pr + pso);
-        t[3] = ds_read16f<3072>(pr + pso);
-        const int x = xw + j * 32;
-        float4 gv, rv[4];
-        float rb[4];
-        if (EPI == EPI_GATE_RES) {
-          const float* rsrc = p.res ? p.res : reinterpret_cast<const float*>(p.out);
-          gv = *reinterpret_cast<const float4*>(p.gate + (size_t)sample * p.ld_gate + x);
+        for (int q = 0; q < 2; ++q) load8(reinterpret_cast<const float*>(p.out) + (size_t)(y0 + 16 * q) * p.ldo + x, rv[q]);
+      }
+      if (EPI == EPI_GELUGRAD_TE) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) rv[q] = *reinterpret_cast<const float4*>(rsrc + (size_t)(y0 + 8 * q) * p.ldo + x);
-        }
-        if (EPI == EPI_ACCUM_F32) {
+        for (int q = 0; q < 2; ++q) load8(reinterpret_cast<const TE*>(p.aux) + (size_t)(y0 + 16 * q) * p.ldo + x, rv[q]);
+      }
+      if (EPI == EPI_ROWBIAS_TE) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q)
-            rv[q] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.out) + (size_t)(y0 + 8 * q) * p.ldo + x);
-        }
-        if (EPI == EPI_GELUGRAD_TE) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const TE* a = reinterpret_cast<const TE*>(p.aux) + (size_t)(y0 + 8 * q) * p.ldo + x;
-            float a0, a1, a2, a3;
-            load2(a, a0, a1);
-            load2(a + 2, a2, a3);
-            rv[q] = make_float4(a0, a1, a2, a3);
-          }
-        }
-        if (EPI == EPI_ROWBIAS_TE) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) rb[q] = p.bias[y0 + 8 * q];
-        }
+        for (int q = 0; q < 2; ++q) rb[q] = p.bias[y0 + 16 * q];
+      }
+      if (b + 1 < NB) {
+        patch_trip(b + 1, tq[(b + 1) & 1]);
+        OSUD_LGKM_WAIT(8);
+      } else {
         OSUD_LGKM_WAIT(0);
+      }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v0 = t[q][0], v1 = t[q][1], v2 = t[q][2], v3 = t[q][3];
-          if (kBias) { v0 += bv[j].x; v1 += bv[j].y; v2 += bv[j].z; v3 += bv[j].w; }
-          if (EPI == EPI_ROWBIAS_TE) { v0 += rb[q]; v1 += rb[q]; v2 += rb[q]; v3 += rb[q]; }
-          const size_t o = (size_t)(y0 + 8 * q) * p.ldo + x;
-          if (EPI == EPI_BIAS_F32 || EPI == EPI_NONE_F32) {
-            store4(reinterpret_cast<float*>(p.out) + o, v0, v1, v2, v3);
-          } else if (EPI == EPI_ACCUM_F32) {
-            store4(reinterpret_cast<float*>(p.out) + o, rv[q].x + v0, rv[q].y + v1, rv[q].z + v2, rv[q].w + v3);
-          } else if (EPI == EPI_GATE_RES) {
-            if (p.out2) store4(reinterpret_cast<TE*>(p.out2) + o, v0, v1, v2, v3);  // branch output (training)
-            store4(reinterpret_cast<float*>(p.out) + o, rv[q].x + gv.x * v0, rv[q].y + gv.y * v1, rv[q].z + gv.z * v2,
-                   rv[q].w + gv.w * v3);
-          } else if (EPI == EPI_BIAS_SILU_TE) {
-            if (p.out2) store4(reinterpret_cast<TE*>(p.out2) + o, v0, v1, v2, v3);  // pre-activation (training)
-            store4(reinterpret_cast<TE*>(p.out) + o, silu_t<FAST>(v0), silu_t<FAST>(v1), silu_t<FAST>(v2),
-                   silu_t<FAST>(v3));
-          } else if (EPI == EPI_BIAS_GELU_TE) {
-            if (p.out2) store4(reinterpret_cast<TE*>(p.out2) + o, v0, v1, v2, v3);
-            store4(reinterpret_cast<TE*>(p.out) + o, gelu_tanh_t<FAST>(v0), gelu_tanh_t<FAST>(v1),
-                   gelu_tanh_t<FAST>(v2), gelu_tanh_t<FAST>(v3));
-          } else if (EPI == EPI_GELUGRAD_TE) {
-            store4(reinterpret_cast<TE*>(p.out) + o, v0 * gelu_tanh_grad_t<FAST>(rv[q].x),
-                   v1 * gelu_tanh_grad_t<FAST>(rv[q].y), v2 * gelu_tanh_grad_t<FAST>(rv[q].z),
-                   v3 * gelu_tanh_grad_t<FAST>(rv[q].w));
-          } else {  // EPI_BIAS_TE, EPI_ROWBIAS_TE, EPI_NONE_TE
-            store4(reinterpret_cast<TE*>(p.out) + o, v0, v1, v2, v3);
-          }
+      for (int q = 0; q < 2; ++q) {
+        float v[8], w[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = t[2 * q][e];
+          v[4 + e] = t[2 * q + 1][e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (kBias) v[e] += bv[j][e];
+          if (EPI == EPI_ROWBIAS_TE) v[e] += rb[q];
+        }
+        const size_t o = (size_t)(y0 + 16 * q) * p.ldo + x;
+        if (EPI == EPI_BIAS_F32 || EPI == EPI_NONE_F32) {
+          store8(reinterpret_cast<float*>(p.out) + o, v);
+        } else if (EPI == EPI_ACCUM_F32) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = rv[q][e] + v[e];
+          store8(reinterpret_cast<float*>(p.out) + o, w);
+        } else if (EPI == EPI_GATE_RES) {
+          if (p.out2) store8(reinterpret_cast<TE*>(p.out2) + o, v);  // branch output (training)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = rv[q][e] + gv[e] * v[e];
+          store8(reinterpret_cast<float*>(p.out) + o, w);
+        } else if (EPI == EPI_BIAS_SILU_TE) {
+          if (p.out2) store8(reinterpret_cast<TE*>(p.out2) + o, v);  // pre-activation (training)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = silu_t<FAST>(v[e]);
+          store8(reinterpret_cast<TE*>(p.out) + o, w);
+        } else if (EPI == EPI_BIAS_GELU_TE) {
+          if (p.out2) store8(reinterpret_cast<TE*>(p.out2) + o, v);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = gelu_tanh_t<FAST>(v[e]);
+          store8(reinterpret_cast<TE*>(p.out) + o, w);
+        } else if (EPI == EPI_GELUGRAD_TE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = v[e] * gelu_tanh_grad_t<FAST>(rv[q][e]);
+          store8(reinterpret_cast<TE*>(p.out) + o, w);
+        } else {  // EPI_BIAS_TE, EPI_ROWBIAS_TE, EPI_NONE_TE
+          store8(reinterpret_cast<TE*>(p.out) + o, v);
         }
       }
     }
@@ -528,7 +553,7 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
   const int esz = (int)elem_size(prec);
   OSUD_CHECK_ARG(p.My > 0 && p.Nx > 0 && p.K > 0 && p.My % 128 == 0 && p.Nx % 128 == 0 && (p.K * esz) % SLAB == 0,
                  "gemm: My=%d Nx=%d must be multiples of 128 and K=%d a multiple of %d", p.My, p.Nx, p.K, SLAB / esz);
-  OSUD_CHECK_ARG((p.ldy * esz) % 16 == 0 && (p.ldx * esz) % 16 == 0 && p.ldo % 4 == 0,
+  OSUD_CHECK_ARG((p.ldy * esz) % 16 == 0 && (p.ldx * esz) % 16 == 0 && p.ldo % 8 == 0,
                  "gemm: leading dimensions must keep 16-byte alignment (ldy=%d ldx=%d ldo=%d)", p.ldy, p.ldx, p.ldo);
   OSUD_CHECK_ARG(p.Y && p.X && p.out, "gemm: null operand");
   OSUD_CHECK_ARG((size_t)p.ldy * esz * 256 < (1ull << 31) && (size_t)p.ldx * esz * 256 < (1ull << 31),
