@@ -320,7 +320,15 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
     // The stage consumed last holds nothing the next tile needs (its prefetch sits in the other stages): it becomes
     // the epilogue patch area, once every wave has finished reading the last slab from it.  The barrier at the top
     // of the next tile's first slab orders the patch reads before the LDS-DMA that refills the stage.
+#ifdef OSUD_GEMM_TIMING
+    const uint64_t te1 = __builtin_readcyclecounter();
+#endif
     __builtin_amdgcn_s_barrier();
+#ifdef OSUD_GEMM_TIMING
+    const uint64_t te2 = __builtin_readcyclecounter();
+    tsum[6] += te1 - te0;  // drain wait before the epilogue
+    tsum[7] += te2 - te1;  // epilogue barrier
+#endif
     const uint32_t pso = (uint32_t)(((consumed + G::NSTAGE - 1) % G::NSTAGE) * G::STAGE);
 
     // ---- epilogue -------------------------------------------------------------------------------
@@ -457,7 +465,8 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
   if (p.gate != nullptr && lane == 0 && blockIdx.x < 16) {
     float* dbg = const_cast<float*>(p.gate) + (blockIdx.x * G::NW + wave) * 8;
     for (int i = 0; i < 6; ++i) dbg[i] = (float)tsum[i];
-    dbg[6] = (float)(__builtin_readcyclecounter() - tk0);
+    dbg[6] = (float)tsum[6];
+    dbg[7] = (float)tsum[7];
   }
 #endif
 }

@@ -16,9 +16,10 @@ def run(name, epi, My, Nx, K, f32out=False, pad=0):
     for w in (0, 4):
         v = d[0, w]
         n = max(1.0, float(v[4]))
-        print(f"  wave {w}: per slab: wait_vm {v[0]/n:7.0f}  barrier {v[1]/n:7.0f}  dma_issue {v[2]/n:7.0f}  compute {v[3]/n:7.0f} | slabs {n:.0f}  epilogue/tile {v[5]/(n/ (K*2/128)):8.0f}  total {v[6]:9.0f}")
+        print(f"  wave {w}: per slab: wait_vm {v[0]/n:7.0f}  barrier {v[1]/n:7.0f}  dma_issue {v[2]/n:7.0f}  compute {v[3]/n:7.0f} | slabs {n:.0f}  epilogue/tile {v[5]/(n/ (K*2/128)):8.0f} (drain wait {v[6]/(n/ (K*2/128)):6.0f}, barrier {v[7]/(n/ (K*2/128)):6.0f})")
 D = 768
 pad = int(os.environ.get("PAD", "0"))
 run("fc1 plain bf16", _lib.EPI_BIAS_TE, 32768, 4 * D, D, pad=pad)
+run("fc1 gelu bf16", _lib.EPI_BIAS_GELU_TE, 32768, 4 * D, D, pad=pad)
 run("fc2-shape bf16", _lib.EPI_BIAS_TE, 32768, D, 4 * D, pad=pad)
 run("square 8192", _lib.EPI_BIAS_TE, 8192, 8192, 8192, pad=pad)
