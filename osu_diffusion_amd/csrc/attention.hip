@@ -24,10 +24,34 @@ namespace {
 
 __device__ __forceinline__ float fast_exp2(float v) { return __builtin_amdgcn_exp2f(v); }
 
+// Tile map of an attention mask, one workgroup per 64-query x 64-key tile:
+//   kb_class[qb][kb] = 0 if every (query, key) pair of the tile is masked, 2 if none is (and all its keys < T), else 1.
+// The reference's long-sequence sampling uses a banded mask (sample.py:81-84): with this map the attention kernels skip
+// the fully masked tiles (O(T x band) work instead of O(T^2)) and read mask bytes only on the band's edge tiles.
+__global__ __launch_bounds__(256) void mask_tiles_kernel(const uint8_t* __restrict__ mask, int T, int nkb,
+                                                         uint8_t* __restrict__ kb_class) {
+  __shared__ int cnt;
+  const int q0 = blockIdx.y * 64, kb = blockIdx.x;
+  if (threadIdx.x == 0) cnt = 0;
+  __syncthreads();
+  int c = 0;
+  for (int e = threadIdx.x; e < 64 * 64; e += 256) {
+    const int r = q0 + (e >> 6), k = kb * 64 + (e & 63);
+    if (r < T && k < T && mask[(size_t)r * T + k] == 0) ++c;
+  }
+  if (c) atomicAdd(&cnt, c);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int rows = T - q0 < 64 ? (T - q0 > 0 ? T - q0 : 0) : 64;  // real queries of this block
+    kb_class[(size_t)blockIdx.y * nkb + kb] = cnt == 0 ? 0 : ((kb * 64 + 64 <= T && cnt == rows * 64) ? 2 : 1);
+  }
+}
+
 __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ qk,
                                                         const uint8_t* __restrict__ mask, bf16_t* __restrict__ out,
                                                         float* __restrict__ lse, int T, int Tp, int Mp, int D,
-                                                        int ld_qk, float c1 /* scale*log2(e) */) {
+                                                        int ld_qk, float c1 /* scale*log2(e) */,
+                                                        const uint8_t* __restrict__ kb_class) {
   __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
   __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -52,9 +76,16 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
   float m_run = -INFINITY, l_run = 0.f;
   const int qm = qc < T ? qc : T - 1;  // row of the mask this query reads
 
-  const int nkb = Tp / 64;
+  const int nkb = Tp / 64, nkb_all = nkb;
   for (int kb = 0; kb < nkb; ++kb) {
     if (kb * 64 >= T) break;  // whole block is padding
+    bool check_mask = mask != nullptr;
+    if (kb_class != nullptr) {  // workgroup-uniform: skip fully masked tiles, read no mask bytes on fully open ones
+      const int ca = kb_class[(size_t)(2 * blockIdx.x) * nkb_all + kb];
+      const int cb = 2 * blockIdx.x + 1 < nkb_all ? kb_class[(size_t)(2 * blockIdx.x + 1) * nkb_all + kb] : ca;
+      if (ca == 0 && cb == 0) continue;
+      check_mask = !(ca == 2 && cb == 2);
+    }
     __syncthreads();          // previous block fully consumed
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -92,7 +123,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
         for (int i = 0; i < 4; ++i) {
           const int key = key0 + i;
           bool dead = key >= T;
-          if (mask != nullptr && !dead) dead = mask[(size_t)qm * T + key] != 0;
+          if (check_mask && !dead) dead = mask[(size_t)qm * T + key] != 0;
           const float v = dead ? -INFINITY : s[kt][4 * g + i] * c1;
           s[kt][4 * g + i] = v;
           mx = fmaxf(mx, v);
@@ -154,7 +185,7 @@ template <int HD>
 __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ qk,
                                                       const uint8_t* __restrict__ mask, float* __restrict__ out,
                                                       float* __restrict__ lse, int T, int Tp, int Mp, int D, int ld_qk,
-                                                      float scale) {
+                                                      float scale, const uint8_t* __restrict__ kb_class) {
   __shared__ float Ks[64][HD];
   __shared__ float Vs[HD][64];
   const int tid = threadIdx.x, n = blockIdx.z, h = blockIdx.y;
@@ -170,6 +201,12 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
   float m_run = -INFINITY, l_run = 0.f;
   const int qm = q < T ? q : T - 1;
   for (int kb = 0; kb * 64 < T; ++kb) {
+    bool check_mask = mask != nullptr;
+    if (kb_class != nullptr) {
+      const int cls = kb_class[(size_t)blockIdx.x * (Tp / 64) + kb];
+      if (cls == 0) continue;
+      check_mask = cls != 2;
+    }
     __syncthreads();
     for (int idx = tid; idx < 64 * HD; idx += 64) {
       const int r = idx / HD, d = idx % HD;
@@ -183,7 +220,7 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
     for (int j = 0; j < 64; ++j) {
       const int key = kb * 64 + j;
       if (key >= T) break;
-      if (mask != nullptr && mask[(size_t)qm * T + key]) continue;
+      if (check_mask && mask[(size_t)qm * T + key]) continue;
       float s = 0.f;
 #pragma unroll
       for (int d = 0; d < HD; ++d) s = fmaf(qv[d], Ks[j][d], s);
@@ -212,8 +249,15 @@ __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ 
 
 }  // namespace
 
+int launch_mask_tiles(const uint8_t* mask, int T, int Tp, uint8_t* kb_class, hipStream_t st) {
+  OSUD_CHECK_ARG(mask && kb_class && T > 0 && Tp % 64 == 0, "mask_tiles: bad arguments");
+  hipLaunchKernelGGL(mask_tiles_kernel, dim3(Tp / 64, Tp / 64), dim3(256), 0, st, mask, T, Tp / 64, kb_class);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
 int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, void* out, float* lse, int N, int T, int Tp,
-                     int Mp, int heads, int head_dim, hipStream_t st) {
+                     int Mp, int heads, int head_dim, hipStream_t st, const uint8_t* kb_class) {
   OSUD_CHECK_ARG(N > 0 && T > 0 && Tp >= T && Tp % 64 == 0 && Mp >= N * Tp, "attention: bad sizes N=%d T=%d Tp=%d Mp=%d", N,
                  T, Tp, Mp);
   const int D = heads * head_dim;
@@ -226,15 +270,15 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
     }
     dim3 grid((Tp + 127) / 128, heads, N);
     hipLaunchKernelGGL(attn_bf16_kernel, grid, dim3(256), 0, st, (const bf16_t*)qk, mask,
-                       (bf16_t*)out, lse, T, Tp, Mp, D, ld_qk, scale * 1.4426950408889634f);
+                       (bf16_t*)out, lse, T, Tp, Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr);
   } else {
     dim3 grid(Tp / 64, heads, N);
     if (head_dim == 64)
       hipLaunchKernelGGL(attn_f32_kernel<64>, grid, dim3(64), 0, st, (const float*)qk, mask,
-                         (float*)out, lse, T, Tp, Mp, D, ld_qk, scale);
+                         (float*)out, lse, T, Tp, Mp, D, ld_qk, scale, mask ? kb_class : nullptr);
     else if (head_dim == 72)
       hipLaunchKernelGGL(attn_f32_kernel<72>, grid, dim3(64), 0, st, (const float*)qk, mask,
-                         (float*)out, lse, T, Tp, Mp, D, ld_qk, scale);
+                         (float*)out, lse, T, Tp, Mp, D, ld_qk, scale, mask ? kb_class : nullptr);
     else {
       set_error("attention: head_dim %d not built (64, 72)", head_dim);
       return OSUD_ERR_UNSUPPORTED;

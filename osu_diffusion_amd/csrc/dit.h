@@ -100,6 +100,7 @@ struct osud_dit {
   void *temb = nullptr, *th = nullptr, *sb = nullptr;
   int64_t *t_model = nullptr, *t_index = nullptr;
   int* step_state = nullptr;
+  uint8_t* kb_class = nullptr;  // [cap_Tp / 64][cap_Tp / 64] tile classes of the current attention mask (banded long-sequence sampling)
   std::vector<LayerSaved> saved;
   std::vector<void*> ws_owned;
 

@@ -23,8 +23,11 @@ int launch_convert(int prec, const float* src, void* dst, size_t n, hipStream_t 
 int launch_pack_rows(int prec, const float* src, int ld_src, int cols_src, void* dst, int ld_dst, int cols_dst, int rows,
                      hipStream_t st);
 // qkv: packed in_proj output [Mp][ld_qkv], Q | K | V in columns [0,D) [D,2D) [2D,3D)
+// kb_class (optional, from launch_mask_tiles): class of every 64-query x 64-key tile of the mask (0 fully masked, 1 mixed,
+// 2 fully open): masked tiles are skipped, open tiles read no mask bytes
 int launch_attention(int prec, const void* qkv, int ld_qkv, const uint8_t* mask, void* out, float* lse, int N, int T, int Tp,
-                     int Mp, int heads, int head_dim, hipStream_t st);
+                     int Mp, int heads, int head_dim, hipStream_t st, const uint8_t* kb_class = nullptr);
+int launch_mask_tiles(const uint8_t* mask, int T, int Tp, uint8_t* kb_class, hipStream_t st);
 int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* O, const float* lse, void* dqkv, int N,
                          int T, int heads, int head_dim, hipStream_t st);
 

@@ -148,3 +148,29 @@ def test_full_size_training_step_properties():
     drops = torch.stack([m.y_embedder.token_drop(torch.zeros(4096, dtype=torch.long, device=DEV)) for _ in range(4)])
     frac = float((drops == 52670).float().mean())
     assert 0.17 < frac < 0.23
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-4), ("bf16", 6e-2)])
+def test_long_sequence_banded_sampling_forward(prec, tol):
+    """sample.py's real workload (sample.py:81-84): ONE long beatmap, few variants, banded attention mask of half-width 128.
+    T = 1000 is not a multiple of 64 (padding keys), the band covers 5 of the 16 key blocks per query block, and the
+    key-block ranges derived from the mask must not change the result."""
+    from osu_diffusion_amd.synthetic import banded_attn_mask
+    shape = mo.DitShape(depth=2, hidden=128, heads=2, num_classes=10)
+    sd = mo.seeded_state_dict(shape, 77)
+    T_ = 1000
+    (x, o, c), y = synthetic_windows(2, T_, 10, seed=5)
+    y[1] = 10  # null class row, as the CFG batch has
+    t = torch.tensor([999, 3])
+    mask = banded_attn_mask(T_, 128)
+    ref = mo.forward(sd, shape, x, t, o, c, y, attn_mask=mask)
+    m = build(shape, sd, prec)
+    with torch.no_grad():
+        got = m(x.to(DEV), t.to(DEV), o.to(DEV), c.to(DEV), y.to(DEV), attn_mask=mask.to(DEV)).cpu()
+        assert got.shape == (2, 4, T_)
+        assert maxdiff(got, ref) < tol * max(1.0, float(ref.abs().max())), maxdiff(got, ref)
+        # a mask that hides nothing must equal no mask at all (ranges = every block)
+        full = m(x.to(DEV), t.to(DEV), o.to(DEV), c.to(DEV), y.to(DEV),
+                 attn_mask=torch.zeros(T_, T_, dtype=torch.bool, device=DEV)).cpu()
+        none = m(x.to(DEV), t.to(DEV), o.to(DEV), c.to(DEV), y.to(DEV)).cpu()
+    assert torch.equal(full, none)
