@@ -152,6 +152,20 @@ template <bool FAST> __device__ __forceinline__ float gelu_tanh_grad_t(float z) 
   return s + z * s * (1.0f - s) * du2;
 }
 
+// value and derivative together (one exp + one rcp for both)
+template <bool FAST> __device__ __forceinline__ void gelu_tanh_both_t(float z, float& g, float& dg) {
+  if (FAST) {
+    const float z2 = z * z;
+    const float s = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * fmaf(z2, kGeluA, kGeluB)));
+    const float t = z * fmaf(z2, 3.0f * 0.044715f * kGeluK2, kGeluK2);
+    g = z * s;
+    dg = fmaf(t, fmaf(-s, s, s), s);
+  } else {
+    g = gelu_tanh_t<false>(z);
+    dg = gelu_tanh_grad_t<false>(z);
+  }
+}
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 static inline size_t elem_size(int prec) { return prec == OSUD_PREC_BF16 ? 2 : 4; }
 

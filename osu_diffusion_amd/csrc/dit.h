@@ -34,7 +34,7 @@ struct LayerSaved {
   float* h_mid = nullptr;    // [Mp][D] after the attention branch
   float* stats1 = nullptr;   // [Mp][2] mean, rstd of LN1
   float* stats2 = nullptr;   // [Mp][2]
-  void *u1 = nullptr, *qk = nullptr /* [Mp][3D] q|k|v */, *ao = nullptr, *u2 = nullptr, *z1 = nullptr,
+  void *u1 = nullptr, *qk = nullptr /* [Mp][3D] q|k|v */, *ao = nullptr, *u2 = nullptr, *z1 = nullptr /* gelu'(fc1 pre-activation) */,
        *g = nullptr, *br1 = nullptr /* attention branch output */, *br2 = nullptr /* MLP branch output */;
   float* lse = nullptr;  // [N][H][Tp]
 };

@@ -25,12 +25,12 @@ enum GemmEpilogue {
   EPI_BIAS_TE = 1,        // out TE  = acc + bias[x]
   EPI_BIAS_SILU_TE = 2,   // out TE  = silu(acc + bias[x]); out2 TE (optional) = acc + bias[x]
   EPI_ROWBIAS_TE = 3,     // out TE  = acc + bias[y]            (transposed products)
-  EPI_BIAS_GELU_TE = 4,   // out TE  = gelu_tanh(acc + bias[x]); out2 TE (optional) = acc + bias[x]
+  EPI_BIAS_GELU_TE = 4,   // out TE  = gelu_tanh(acc + bias[x]); out2 TE (optional) = gelu_tanh'(acc + bias[x])
   EPI_GATE_RES = 5,       // out f32 = res + gate[sample(y)][x] * (acc + bias[x]); out2 TE (optional) = acc + bias[x]
   EPI_NONE_F32 = 6,       // out f32 = acc
   EPI_NONE_TE = 7,        // out TE  = acc
   EPI_ACCUM_F32 = 8,      // out f32 += acc                      (gradient accumulation)
-  EPI_GELUGRAD_TE = 9,    // out TE  = acc * gelu'(aux[y][x])    (dgrad through fc1's activation)
+  EPI_GELUGRAD_TE = 9,    // out TE  = acc * aux[y][x], aux = the saved gelu' of fc1's pre-activation (dgrad through it)
   EPI_COUNT
 };
 
@@ -47,7 +47,7 @@ struct GemmP {
   int ld_gate;
   int rows_per_sample;  // Tp
   int n_samples;
-  const void* aux;   // TE [My][ldo] (EPI_GELUGRAD_TE: saved pre-activation)
+  const void* aux;   // TE [My][ldo] (EPI_GELUGRAD_TE: saved GELU derivative)
   const float* res;  // EPI_GATE_RES: residual input [My][ldo]; nullptr = update `out` in place
   int split_k;       // > 1: blockIdx.y walks K in split_k equal ranges, range s writes out + s * split_stride (elements)
   size_t split_stride;

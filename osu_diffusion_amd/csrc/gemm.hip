@@ -444,13 +444,20 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
           for (int e = 0; e < 8; ++e) w[e] = silu_t<FAST>(v[e]);
           store8(reinterpret_cast<TE*>(p.out) + o, w);
         } else if (EPI == EPI_BIAS_GELU_TE) {
-          if (p.out2) store8(reinterpret_cast<TE*>(p.out2) + o, v);
+          if (p.out2) {  // training: the DERIVATIVE goes out (same exp/rcp as the value), so that the backward epilogue
+                         // is a plain multiply instead of two more quarter-rate transcendentals per element
+            float dg[8];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) w[e] = gelu_tanh_t<FAST>(v[e]);
+            for (int e = 0; e < 8; ++e) gelu_tanh_both_t<FAST>(v[e], w[e], dg[e]);
+            store8(reinterpret_cast<TE*>(p.out2) + o, dg);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = gelu_tanh_t<FAST>(v[e]);
+          }
           store8(reinterpret_cast<TE*>(p.out) + o, w);
         } else if (EPI == EPI_GELUGRAD_TE) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) w[e] = v[e] * gelu_tanh_grad_t<FAST>(rv[q][e]);
+          for (int e = 0; e < 8; ++e) w[e] = v[e] * rv[q][e];
           store8(reinterpret_cast<TE*>(p.out) + o, w);
         } else {  // EPI_BIAS_TE, EPI_ROWBIAS_TE, EPI_NONE_TE
           store8(reinterpret_cast<TE*>(p.out) + o, v);

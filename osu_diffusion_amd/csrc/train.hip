@@ -184,12 +184,13 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     OSUD_TRY(gemm(m, EPI_GELUGRAD_TE, w.dbr, D, bw.w2_t, D, Mp, 4 * D, D, w.dz1, 4 * D, nullptr, st, nullptr, 0, 0, 0,
                   nullptr, nullptr, sv.z1));
     OSUD_TRY(dbg_sync(st, "dgrad fc2 (gelu grad)"));
-    OSUD_TRY(weight_grad(m, w.dbr, D, sv.g, 4 * D, D, 4 * D, Mp, G(p + "mlp.fc2.weight"), nullptr, st));
-    OSUD_TRY(dbg_sync(st, "wgrad fc2"));
+    // consumers of dz1 (201 MB, fresh in the Infinity Cache) first, the fc2 weight gradient (dbr, g) after them
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dz1, 4 * D, bw.w1_t, 4 * D, Mp, D, 4 * D, w.du, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "dgrad fc1"));
     OSUD_TRY(weight_grad(m, w.dz1, 4 * D, sv.u2, D, 4 * D, D, Mp, G(p + "mlp.fc1.weight"), g_b1, st));
     OSUD_TRY(dbg_sync(st, "wgrad fc1"));
+    OSUD_TRY(weight_grad(m, w.dbr, D, sv.g, 4 * D, D, 4 * D, Mp, G(p + "mlp.fc2.weight"), nullptr, st));
+    OSUD_TRY(dbg_sync(st, "wgrad fc2"));
     // LN2 backward -> dh = grad wrt h_mid, and on the same rows the gate step of the attention branch
     // (h_mid = h_in + g1 * (attn(u1) Wo^T + bo)): dbr = g1 * dh, dg1, dbo
     OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_mid, sv.stats2, w.du, m->ada, AC, base + 3 * D, base + 4 * D, dh, dh_other, w.dada,

@@ -257,6 +257,15 @@ def dit_forward_autograd(model, x, t, o, c, y, attn_mask):
 
 
 # ------------------------------------------------------------------------------ fused trainer
+def _split_at(ranges, cut):
+    """`ranges` with every range split at the boundaries of `cut` (so that no piece straddles it)."""
+    out = []
+    for lo, hi in ranges:
+        pts = [lo] + [c for c in cut if lo < c < hi] + [hi]
+        out += list(zip(pts[:-1], pts[1:]))
+    return out
+
+
 def _complement(ranges, total):
     """Element ranges of [0, total) not covered by `ranges`."""
     out, pos = [], 0
@@ -292,6 +301,10 @@ class NativeTrainer:
         self.exp_avg = torch.zeros_like(self.arena.flat)
         self.exp_avg_sq = torch.zeros_like(self.arena.flat)
         self.step_count = 0
+        # --embed-only-epochs (train.py:223-241): only the class table trains while `embed_only` is set; torch's AdamW keeps a
+        # step counter per parameter, so the table's bias correction runs `table_extra_steps` ahead of the trunk's afterwards
+        self.embed_only = False
+        self.table_extra_steps = 0
         self.force_phased = os.environ.get("OSUD_FORCE_PHASED", "0") == "1"  # exercise the phased path on 1 GPU
         import torch.distributed as dist
 
@@ -330,6 +343,9 @@ class NativeTrainer:
             dout = torch.empty_like(out)
             _lib.check(L.osud_train_loss(d._sched.handle, self.use_l1, _lib.ptr(out), _lib.ptr(x0), _lib.ptr(x_t), _lib.ptr(noise),
                                          _lib.ptr(t), B, T, _lib.ptr(terms), _lib.ptr(dout), st))
+            if self.embed_only:
+                self._embed_only_update(dout, y)
+                return terms
             done = []
 
             def early(ranges, _self=self):  # block slices are final: update them while the tail exchange is in flight
@@ -346,23 +362,48 @@ class NativeTrainer:
                 self.optimizer_step(scale)
         return terms
 
-    def _adamw(self, ranges, grad_scale):
-        """AdamW + EMA on element ranges of the arenas (step_count already advanced)."""
+    def _table_range(self):
+        i = self.arena.names.index("y_embedder.embedding_table.weight")
+        return int(self.arena.offsets[i]), int(self.arena.offsets[i] + self.arena.sizes[i])
+
+    def _embed_only_update(self, dout, labels):
+        """Frozen trunk (train.py:223-225, requires_grad_non_embed): the backward runs, but only the class table is
+        exchanged (as rows) and updated; every other parameter gets just its EMA update."""
+        import torch.distributed as dist
+
+        native_backward(self.model, dout)
+        t_lo, t_hi = self._table_range()
+        scale = 1.0
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            rows = dict(self.model.named_parameters())["y_embedder.embedding_table.weight"].shape[0]
+            exchange_table_rows(self.arena.grads[t_lo:t_hi].view(rows, -1), self.model._train_keep[4], self.group)
+            scale = 1.0 / dist.get_world_size(self.group)
+        self.table_extra_steps += 1
+        self._adamw([(0, t_lo), (t_hi, self.arena.total)], 1.0, frozen=True)
+        self._adamw([(t_lo, t_hi)], scale)
+        self._refresh()
+
+    def _adamw(self, ranges, grad_scale, frozen=False):
+        """AdamW + EMA on element ranges of the arenas (step_count already advanced); frozen: EMA only."""
         a, dev = self.arena, self.arena.flat.device
         f_lo, f_hi = a.frozen_range()
+        t_lo, t_hi = self._table_range()
         L = _lib.lib()
         with torch.cuda.device(dev):
             st = _lib.stream_ptr(dev)
-            for lo, hi in ranges:
+            for lo, hi in _split_at(ranges, (t_lo, t_hi)):
                 if hi <= lo:
                     continue
                 fl, fh = max(f_lo, lo) - lo, min(f_hi, hi) - lo  # frozen playfield_size, relative to this range
                 if fh <= fl:
                     fl = fh = 0
+                if frozen:
+                    fl, fh = 0, hi - lo
+                step = self.step_count + (self.table_extra_steps if (lo >= t_lo and hi <= t_hi) else 0)
                 _lib.check(L.osud_adamw_ema_step(_lib.ptr(a.flat[lo:hi]), _lib.ptr(a.grads[lo:hi]), _lib.ptr(self.exp_avg[lo:hi]),
                                                  _lib.ptr(self.exp_avg_sq[lo:hi]), _lib.ptr(self.ema_arena.flat[lo:hi]), hi - lo,
                                                  self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
-                                                 self.step_count, self.ema_decay, fl, fh, float(grad_scale), st))
+                                                 max(step, 1), self.ema_decay, fl, fh, float(grad_scale), st))
 
     def _refresh(self):
         dev = self.arena.flat.device
@@ -384,7 +425,8 @@ class NativeTrainer:
         for i, name in enumerate(self.arena.names):
             if name.endswith("playfield_size"):
                 continue
-            state[i] = {"step": torch.tensor(float(self.step_count)),
+            extra = self.table_extra_steps if name == "y_embedder.embedding_table.weight" else 0
+            state[i] = {"step": torch.tensor(float(self.step_count + extra)),
                         "exp_avg": self.arena.view(self.exp_avg, name).clone(),
                         "exp_avg_sq": self.arena.view(self.exp_avg_sq, name).clone()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
@@ -394,11 +436,17 @@ class NativeTrainer:
 
     def load_opt_state_dict(self, sd):
         self.lr = sd["param_groups"][0]["lr"]
+        table_step = None
         for i, st in sd["state"].items():
             name = self.arena.names[int(i)]
             self.arena.view(self.exp_avg, name).copy_(st["exp_avg"])
             self.arena.view(self.exp_avg_sq, name).copy_(st["exp_avg_sq"])
-            self.step_count = int(float(st["step"]))
+            if name == "y_embedder.embedding_table.weight":
+                table_step = int(float(st["step"]))
+            else:
+                self.step_count = int(float(st["step"]))
+        if table_step is not None:
+            self.table_extra_steps = max(0, table_step - self.step_count)
 
     def checkpoint(self, args=None):
         scaler = {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000,

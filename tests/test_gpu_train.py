@@ -227,3 +227,37 @@ def test_phased_backward_equals_single_call(monkeypatch):
         grads.append(tr.arena.grads.clone().cpu())
     # atomically accumulated tensors (adaLN / final / table / bias sums) may differ in the last bits
     assert maxdiff(grads[0], grads[1]) < 1e-6 * max(1.0, float(grads[0].abs().max()))
+
+
+def test_embed_only_mode_trains_the_class_table_alone():
+    """--embed-only-epochs (train.py:223-241): with the trunk frozen one step must move exactly the class-table rows of the
+    batch labels — by the same amount as an ordinary step would — and leave every other parameter untouched, while the EMA
+    still tracks all of them; after unfreezing, the table's AdamW step counter runs ahead of the trunk's."""
+    fx = load("g7_train_l1")
+    shape, sd = weights_for(fx)
+
+    def trainer():
+        m = DiT(depth=shape.depth, hidden_size=shape.hidden, num_heads=shape.heads, context_size=144,
+                num_classes=shape.num_classes, class_dropout_prob=0.2, precision="fp32")
+        m.load_state_dict(sd)
+        return NativeTrainer(m.to(DEV).eval(), create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True), lr=1e-3)
+
+    args = (T(fx["x"]), T(fx["o"]), T(fx["c"]), T(fx["y"]))
+    kw = dict(t=T(fx["t"]), noise=T(fx["noise"]), drop_ids=T(fx["drop"]).long())
+    full, emb = trainer(), trainer()
+    w0 = full.arena.flat.clone()
+    full.step(*args, **kw)
+    emb.embed_only = True
+    emb.step(*args, **kw)
+    t_lo, t_hi = emb._table_range()
+    assert torch.equal(emb.arena.flat[:t_lo], w0[:t_lo]) and torch.equal(emb.arena.flat[t_hi:], w0[t_hi:])  # trunk frozen
+    assert torch.equal(emb.arena.flat[t_lo:t_hi], full.arena.flat[t_lo:t_hi])  # the table moved exactly as in a full step
+    moved = (emb.arena.flat[t_lo:t_hi] != w0[t_lo:t_hi]).view(-1, shape.hidden).any(1).nonzero().flatten().tolist()
+    labels = torch.where(T(fx["drop"]).bool(), torch.tensor(shape.num_classes), T(fx["y"]))
+    assert sorted(moved) == sorted(set(labels.tolist()))
+    assert torch.equal(emb.ema_arena.flat[t_lo:t_hi], full.ema_arena.flat[t_lo:t_hi])
+    assert emb.step_count == 0 and emb.table_extra_steps == 1
+    emb.embed_only = False
+    emb.step(*args, **kw)
+    sd_opt = emb.opt_state_dict()["state"]
+    assert float(sd_opt[7]["step"]) == 2.0 and float(sd_opt[8]["step"]) == 1.0  # index 7 = class table (train.py:212-215)

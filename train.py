@@ -93,8 +93,15 @@ def main(args):
     train_steps, log_steps, start_time = 0, 0, time()
     running_loss = torch.zeros((), device=device)  # accumulated on the device: no host sync per step
     logger.info(f"Training for {args.epochs} epochs...")
+    if args.embed_only_epochs > 0:  # train.py:223-225
+        logger.info(f"Freezing non-embedding layers for {args.embed_only_epochs} epochs")
+        trainer.embed_only = True
     for epoch in range(args.epochs):
         logger.info(f"Beginning epoch {epoch}...")
+        if 0 < args.embed_only_epochs == epoch:  # train.py:237-241
+            logger.info("Un-freezing non-embedding layers")
+            trainer.embed_only = False
+            trainer.lr = 1e-4
         def batches():
             if loader is not None:
                 yield from loader
