@@ -97,8 +97,12 @@ def main(args):
         samples, _ = samples.chunk(2, dim=0)
         return torch.concatenate([samples.cpu() * playfield_size.view(1, 2, 1), seq_no_embed[2:].repeat(n, 1, 1)], 1)
 
-    samples = diffusion.p_sample_loop(model.forward_with_cfg, z.shape, z, clip_denoised=True, model_kwargs=model_kwargs,
-                                      progress=False, device=device)
+    if args.sampler == "ddim":  # gaussian_diffusion.py:653-733 (the reference ships the sampler but no CLI switch for it)
+        samples = diffusion.ddim_sample_loop(model.forward_with_cfg, z.shape, z, clip_denoised=True, model_kwargs=model_kwargs,
+                                             progress=False, device=device, eta=args.ddim_eta)
+    else:
+        samples = diffusion.p_sample_loop(model.forward_with_cfg, z.shape, z, clip_denoised=True, model_kwargs=model_kwargs,
+                                          progress=False, device=device)
     if args.refine_ckpt is not None:  # sample.py:186-205: repeated t=0 steps with the refine model
         model.load_state_dict(find_model(args.refine_ckpt))
         for _ in range(args.refine_iters):
@@ -131,6 +135,8 @@ if __name__ == "__main__":
     p.add_argument("--refine-iters", type=int, default=10)
     p.add_argument("--synthetic", type=int, default=0, metavar="T", help="use a synthetic T-token sequence")
     p.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    p.add_argument("--sampler", choices=["p", "ddim"], default="p", help="ancestral p_sample loop (reference default) or DDIM")
+    p.add_argument("--ddim-eta", type=float, default=0.0)
     a = p.parse_args()
     assert a.beatmap or a.synthetic, "--beatmap <seq.pt|seq.npy> or --synthetic T"
     main(a)
