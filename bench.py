@@ -234,7 +234,7 @@ def bench_train(args, world, rank, dev):
     assert math.isfinite(loss), "non-finite training loss"
     tokens_per_s = world * B * T * K / dt
     res = {
-        "metric": "DiT-B seq128 train tokens/sec (whole job; per-GPU = value / n_gpus)", "value": round(tokens_per_s, 1),
+        "metric": f"{args.model} seq{args.seq_len} train tokens/sec (whole job; per-GPU = value / n_gpus)", "value": round(tokens_per_s, 1),
         "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
@@ -300,7 +300,7 @@ def bench_sample(args, world, rank, dev):
     M = 2 * n * T
     flop_step = M * FLOP_PER_TOKEN_FWD if args.model == "DiT-B" and T == 128 else None
     res = {
-        "metric": "1000-step CFG sample steps/sec (DiT-B seq128)", "value": round(world * steps_per_s, 3),
+        "metric": f"1000-step CFG sample steps/sec ({args.model} seq{args.seq_len})", "value": round(world * steps_per_s, 3),
         "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",

@@ -47,13 +47,18 @@ __global__ __launch_bounds__(256) void mask_tiles_kernel(const uint8_t* __restri
   }
 }
 
+// HD = head_dim (64, or 72 for DiT-XL), HDP = HD padded to a multiple of 32 (zero columns: they add nothing to q.k and give
+// zero output columns that are not stored)
+template <int HD, int HDP>
 __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ qk,
                                                         const uint8_t* __restrict__ mask, bf16_t* __restrict__ out,
                                                         float* __restrict__ lse, int T, int Tp, int Mp, int D,
                                                         int ld_qk, float c1 /* scale*log2(e) */,
                                                         const uint8_t* __restrict__ kb_class) {
-  __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
-  __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
+  using TL = AttnTile<HDP>;
+  constexpr int KS = HDP / 16, DT = HDP / 32, CPR = TL::CPR;
+  __shared__ __attribute__((aligned(16))) char Ks[64 * TL::RS];
+  __shared__ __attribute__((aligned(16))) char Vs[64 * TL::RS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 31, fhalf = lane >> 5;
   const int n = blockIdx.z, h = blockIdx.y;
@@ -61,16 +66,17 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
   const int qc = q < Tp ? q : Tp - 1;
   const size_t ldq = (size_t)ld_qk;  // 3D (Q|K|V)
   const size_t mrow = (size_t)n * Tp + qc;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   // Q fragments (B operand of S^T = K.Q^T): 8 consecutive d per lane and k-step
-  u32x4 qf[4];
+  u32x4 qf[KS];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
-    qf[ks] = *reinterpret_cast<const u32x4*>(qk + mrow * ldq + h * 64 + ks * 16 + fhalf * 8);
+  for (int ks = 0; ks < KS; ++ks)
+    qf[ks] = (ks * 16 + fhalf * 8) < HD ? *reinterpret_cast<const u32x4*>(qk + mrow * ldq + h * HD + ks * 16 + fhalf * 8) : zero4;
 
-  f32x16 o[2];
+  f32x16 o[DT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < DT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
@@ -87,14 +93,12 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
       check_mask = !(ca == 2 && cb == 2);
     }
     __syncthreads();          // previous block fully consumed
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int idx = tid + 256 * i, r = idx >> 3, cp = idx & 7;
-      const int pos = (cp ^ ((r >> 1) & 7)) << 4;
-      const u32x4 kv = *reinterpret_cast<const u32x4*>(qk + ((size_t)n * Tp + kb * 64 + r) * ldq + D + h * 64 + cp * 8);
-      *reinterpret_cast<u32x4*>(Ks + r * 128 + pos) = kv;
-      const u32x4 vv = *reinterpret_cast<const u32x4*>(qk + ((size_t)n * Tp + kb * 64 + r) * ldq + 2 * D + h * 64 + cp * 8);
-      *reinterpret_cast<u32x4*>(Vs + r * 128 + pos) = vv;
+    for (int idx = tid; idx < 64 * CPR; idx += 256) {
+      const int r = idx / CPR, cp = idx % CPR;
+      const bf16_t* src = qk + ((size_t)n * Tp + kb * 64 + r) * ldq + h * HD + cp * 8;
+      const bool real = cp * 8 < HD;
+      *reinterpret_cast<u32x4*>(Ks + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(src + D) : zero4;
+      *reinterpret_cast<u32x4*>(Vs + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(src + 2 * D) : zero4;
     }
     __syncthreads();
 
@@ -104,13 +108,8 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-      const int row = kt * 32 + frow;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const u32x4 kf = *reinterpret_cast<const u32x4*>(Ks + row * 128 + (((2 * ks + fhalf) ^ ((row >> 1) & 7)) << 4));
-        s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf),
-                                                        __builtin_bit_cast(bf16x8, qf[ks]), s[kt], 0, 0, 0);
-      }
+      for (int ks = 0; ks < KS; ++ks) s[kt] = mfma_bf16(rowfrag<HDP>(Ks, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s[kt]);
     }
     // ---- scale, mask, block max
     float mx = -INFINITY;
@@ -146,7 +145,7 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
     l_run = l_run * alpha + psum;
     m_run = m_new;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < DT; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
 
@@ -156,13 +155,9 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
-        u32x4 pf;
-        pf[0] = pack_bf2(s[kt][8 * ss + 0], s[kt][8 * ss + 1]);
-        pf[1] = pack_bf2(s[kt][8 * ss + 2], s[kt][8 * ss + 3]);
-        pf[2] = pack_bf2(s[kt][8 * ss + 4], s[kt][8 * ss + 5]);
-        pf[3] = pack_bf2(s[kt][8 * ss + 6], s[kt][8 * ss + 7]);
+        const u32x4 pf = pack8(s[kt], 8 * ss);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) o[dt] = mfma_bf16(trfrag(Vs, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
+        for (int dt = 0; dt < DT; ++dt) o[dt] = mfma_bf16(trfrag<HDP>(Vs, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
       }
   }
 
@@ -170,13 +165,14 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict
     if (lse != nullptr && fhalf == 0)  // log2-domain logsumexp of the scaled scores, for the backward pass
       lse[((size_t)n * gridDim.y + h) * Tp + q] = m_run + __builtin_amdgcn_logf(l_run);
     const float inv = 1.0f / l_run;
-    bf16_t* orow = out + ((size_t)n * Tp + q) * D + h * 64;
+    bf16_t* orow = out + ((size_t)n * Tp + q) * D + h * HD;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g)
-        store4(orow + dt * 32 + 8 * g + 4 * fhalf, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv,
-               o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+      for (int g = 0; g < 4; ++g) {
+        const int d = dt * 32 + 8 * g + 4 * fhalf;
+        if (d < HD) store4(orow + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+      }
   }
 }
 
@@ -264,13 +260,17 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
   OSUD_CHECK_ARG(ld_qk >= 3 * D, "attention: packed q|k|v rows need ld >= 3*hidden (got %d)", ld_qk);
   const float scale = 1.0f / sqrtf((float)head_dim);
   if (prec == OSUD_PREC_BF16) {
-    if (head_dim != 64) {
-      set_error("attention: the bf16 tier is built for head_dim 64 only (got %d); use the f32 tier", head_dim);
+    if (head_dim != 64 && head_dim != 72) {
+      set_error("attention: the bf16 tier is built for head_dim 64 and 72 (got %d); use the f32 tier", head_dim);
       return OSUD_ERR_UNSUPPORTED;
     }
     dim3 grid((Tp + 127) / 128, heads, N);
-    hipLaunchKernelGGL(attn_bf16_kernel, grid, dim3(256), 0, st, (const bf16_t*)qk, mask,
-                       (bf16_t*)out, lse, T, Tp, Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr);
+    if (head_dim == 64)
+      hipLaunchKernelGGL((attn_bf16_kernel<64, 64>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
+                         Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr);
+    else
+      hipLaunchKernelGGL((attn_bf16_kernel<72, 96>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
+                         Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr);
   } else {
     dim3 grid(Tp / 64, heads, N);
     if (head_dim == 64)

@@ -22,16 +22,19 @@ namespace osud {
 
 namespace {
 
+template <int HD, int HDP>
 __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                             const bf16_t* __restrict__ O, const float* __restrict__ lse,
                                                             bf16_t* __restrict__ dqkv, int T, int D, float c1,
                                                             float scale) {
+  using TL = AttnTile<HDP>;
+  constexpr int KS = HDP / 16, DT = HDP / 32, CPR = TL::CPR;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
-  char* Ks = Qs + T * 128;
-  char* Vs = Ks + T * 128;
-  char* Os = Vs + T * 128;  // dO rows
-  float* lse_s = reinterpret_cast<float*>(Os + T * 128);
+  char* Ks = Qs + T * TL::RS;
+  char* Vs = Ks + T * TL::RS;
+  char* Os = Vs + T * TL::RS;  // dO rows
+  float* lse_s = reinterpret_cast<float*>(Os + T * TL::RS);
   float* del_s = lse_s + T;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -40,26 +43,31 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __rest
   const size_t ld3 = 3 * (size_t)D;
   const size_t m0 = (size_t)n * T;
 
-  // ---- load row-major tiles (coalesced: 8 lanes per 128-byte row) + delta = rowsum(dO * O)
-  for (int idx = tid; idx < T * 8; idx += 256) {
-    const int r = idx >> 3, cp = idx & 7;
-    const int pos = (cp ^ ((r >> 1) & 7)) << 4;
-    const bf16_t* src = qkv + (m0 + r) * ld3 + h * 64 + cp * 8;
-    *reinterpret_cast<u32x4*>(Qs + r * 128 + pos) = *reinterpret_cast<const u32x4*>(src);
-    *reinterpret_cast<u32x4*>(Ks + r * 128 + pos) = *reinterpret_cast<const u32x4*>(src + D);
-    *reinterpret_cast<u32x4*>(Vs + r * 128 + pos) = *reinterpret_cast<const u32x4*>(src + 2 * D);
-    const u32x4 dov = *reinterpret_cast<const u32x4*>(dO + (m0 + r) * D + h * 64 + cp * 8);
-    const u32x4 ov = *reinterpret_cast<const u32x4*>(O + (m0 + r) * D + h * 64 + cp * 8);
-    *reinterpret_cast<u32x4*>(Os + r * 128 + pos) = dov;
+  // ---- load row-major tiles (coalesced, 16 bytes per lane; pad columns of a 72-wide head are zero) + delta = rowsum(dO * O):
+  //      16 lanes per row (chunks 0..15, only those < CPR exist), so that a row's partial sums meet in one 16-lane group
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  for (int idx = tid; idx < T * 16; idx += 256) {
+    const int r = idx >> 4, cp = idx & 15;
     float part = 0.f;
+    if (cp < CPR) {
+      const bool real = cp * 8 < HD;
+      const bf16_t* src = qkv + (m0 + r) * ld3 + h * HD + cp * 8;
+      *reinterpret_cast<u32x4*>(Qs + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(src) : zero4;
+      *reinterpret_cast<u32x4*>(Ks + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(src + D) : zero4;
+      *reinterpret_cast<u32x4*>(Vs + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(src + 2 * D) : zero4;
+      const u32x4 dov = real ? *reinterpret_cast<const u32x4*>(dO + (m0 + r) * D + h * HD + cp * 8) : zero4;
+      const u32x4 ov = real ? *reinterpret_cast<const u32x4*>(O + (m0 + r) * D + h * HD + cp * 8) : zero4;
+      *reinterpret_cast<u32x4*>(Os + TL::off(r, cp)) = dov;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      part += bf2f((bf16_t)(dov[e] & 0xffff)) * bf2f((bf16_t)(ov[e] & 0xffff));
-      part += bf2f((bf16_t)(dov[e] >> 16)) * bf2f((bf16_t)(ov[e] >> 16));
+      for (int e = 0; e < 4; ++e) {
+        part += bf2f((bf16_t)(dov[e] & 0xffff)) * bf2f((bf16_t)(ov[e] & 0xffff));
+        part += bf2f((bf16_t)(dov[e] >> 16)) * bf2f((bf16_t)(ov[e] >> 16));
+      }
     }
     part += __shfl_xor(part, 1, 64);
     part += __shfl_xor(part, 2, 64);
     part += __shfl_xor(part, 4, 64);
+    part += __shfl_xor(part, 8, 64);
     if (cp == 0) del_s[r] = part;
   }
   for (int r = tid; r < T; r += 256) lse_s[r] = lse[((size_t)n * H + h) * T + r];
@@ -68,16 +76,16 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __rest
   if (own < T) {
     // =============================== pass A: dQ for queries own..own+31 ======================
     {
-      u32x4 qf[4], of[4];
+      u32x4 qf[KS], of[KS];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        qf[ks] = rowfrag(Qs, own + frow, 2 * ks + fhalf);
-        of[ks] = rowfrag(Os, own + frow, 2 * ks + fhalf);
+      for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = rowfrag<HDP>(Qs, own + frow, 2 * ks + fhalf);
+        of[ks] = rowfrag<HDP>(Os, own + frow, 2 * ks + fhalf);
       }
       const float my_lse = lse_s[own + frow], my_del = del_s[own + frow];
-      f32x16 dq[2];
+      f32x16 dq[DT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < DT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
       for (int kt = 0; kt < T / 32; ++kt) {
@@ -85,9 +93,9 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s = mfma_bf16(rowfrag(Ks, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s);    // D[key][query]
-          dp = mfma_bf16(rowfrag(Vs, kt * 32 + frow, 2 * ks + fhalf), of[ks], dp);  // dO . V^T
+        for (int ks = 0; ks < KS; ++ks) {
+          s = mfma_bf16(rowfrag<HDP>(Ks, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s);    // D[key][query]
+          dp = mfma_bf16(rowfrag<HDP>(Vs, kt * 32 + frow, 2 * ks + fhalf), of[ks], dp);  // dO . V^T
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -98,28 +106,29 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __rest
         for (int ss = 0; ss < 2; ++ss) {
           const u32x4 dsf = pack8(s, 8 * ss);
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt)
-            dq[dt] = mfma_bf16(trfrag(Ks, kt * 32 + 16 * ss, dt * 32, lane), dsf, dq[dt]);
+          for (int dt = 0; dt < DT; ++dt)
+            dq[dt] = mfma_bf16(trfrag<HDP>(Ks, kt * 32 + 16 * ss, dt * 32, lane), dsf, dq[dt]);
         }
       }
-      bf16_t* orow = dqkv + (m0 + own + frow) * ld3 + h * 64;
+      bf16_t* orow = dqkv + (m0 + own + frow) * ld3 + h * HD;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          store4(orow + dt * 32 + 8 * g + 4 * fhalf, dq[dt][4 * g], dq[dt][4 * g + 1], dq[dt][4 * g + 2], dq[dt][4 * g + 3]);
+          if (dt * 32 + 8 * g + 4 * fhalf < HD)
+            store4(orow + dt * 32 + 8 * g + 4 * fhalf, dq[dt][4 * g], dq[dt][4 * g + 1], dq[dt][4 * g + 2], dq[dt][4 * g + 3]);
     }
     // =============================== pass B: dK, dV for keys own..own+31 =====================
     {
-      u32x4 kf[4], vf[4];
+      u32x4 kf[KS], vf[KS];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        kf[ks] = rowfrag(Ks, own + frow, 2 * ks + fhalf);
-        vf[ks] = rowfrag(Vs, own + frow, 2 * ks + fhalf);
+      for (int ks = 0; ks < KS; ++ks) {
+        kf[ks] = rowfrag<HDP>(Ks, own + frow, 2 * ks + fhalf);
+        vf[ks] = rowfrag<HDP>(Vs, own + frow, 2 * ks + fhalf);
       }
-      f32x16 dk[2], dv[2];
+      f32x16 dk[DT], dv[DT];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < DT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dk[i][r] = dv[i][r] = 0.f;
       for (int qt = 0; qt < T / 32; ++qt) {
@@ -127,9 +136,9 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s = mfma_bf16(rowfrag(Qs, qt * 32 + frow, 2 * ks + fhalf), kf[ks], s);    // D[query][key]
-          dp = mfma_bf16(rowfrag(Os, qt * 32 + frow, 2 * ks + fhalf), vf[ks], dp);
+        for (int ks = 0; ks < KS; ++ks) {
+          s = mfma_bf16(rowfrag<HDP>(Qs, qt * 32 + frow, 2 * ks + fhalf), kf[ks], s);    // D[query][key]
+          dp = mfma_bf16(rowfrag<HDP>(Os, qt * 32 + frow, 2 * ks + fhalf), vf[ks], dp);
         }
         f32x16 p;
 #pragma unroll
@@ -147,20 +156,22 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __rest
         for (int ss = 0; ss < 2; ++ss) {
           const u32x4 pf = pack8(p, 8 * ss), dsf = pack8(s, 8 * ss);
 #pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            dv[dt] = mfma_bf16(trfrag(Os, qt * 32 + 16 * ss, dt * 32, lane), pf, dv[dt]);
-            dk[dt] = mfma_bf16(trfrag(Qs, qt * 32 + 16 * ss, dt * 32, lane), dsf, dk[dt]);
+          for (int dt = 0; dt < DT; ++dt) {
+            dv[dt] = mfma_bf16(trfrag<HDP>(Os, qt * 32 + 16 * ss, dt * 32, lane), pf, dv[dt]);
+            dk[dt] = mfma_bf16(trfrag<HDP>(Qs, qt * 32 + 16 * ss, dt * 32, lane), dsf, dk[dt]);
           }
         }
       }
-      bf16_t* orow = dqkv + (m0 + own + frow) * ld3 + h * 64;
+      bf16_t* orow = dqkv + (m0 + own + frow) * ld3 + h * HD;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+      for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int d = dt * 32 + 8 * g + 4 * fhalf;
-          store4(orow + D + d, dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]);
-          store4(orow + 2 * D + d, dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
+          if (d < HD) {
+            store4(orow + D + d, dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]);
+            store4(orow + 2 * D + d, dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
+          }
         }
     }
   }
@@ -275,19 +286,25 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
   const int D = heads * head_dim;
   const float scale = 1.0f / sqrtf((float)head_dim);
   if (prec == OSUD_PREC_BF16) {
-    if (head_dim != 64 || T > 128) {
-      set_error("attention backward (bf16 tier) is built for head_dim 64 and T <= 128 (got hd=%d, T=%d)", head_dim, T);
+    if ((head_dim != 64 && head_dim != 72) || T > 128) {
+      set_error("attention backward (bf16 tier) is built for head_dim 64 / 72 and T <= 128 (got hd=%d, T=%d)", head_dim, T);
       return OSUD_ERR_UNSUPPORTED;
     }
-    const size_t lds = (size_t)4 * T * 128 + (size_t)2 * T * 4;
+    const size_t lds = (size_t)4 * T * (head_dim == 64 ? AttnTile<64>::RS : AttnTile<96>::RS) + (size_t)2 * T * 4;
     static bool attr_set = false;
     if (!attr_set) {
-      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bf16_kernel),
+      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bf16_kernel<64, 64>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bf16_kernel<72, 96>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set = true;
     }
-    hipLaunchKernelGGL(attn_bwd_bf16_kernel, dim3(heads, N), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)dO,
-                       (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, scale * 1.4426950408889634f, scale);
+    if (head_dim == 64)
+      hipLaunchKernelGGL((attn_bwd_bf16_kernel<64, 64>), dim3(heads, N), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)dO,
+                         (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, scale * 1.4426950408889634f, scale);
+    else
+      hipLaunchKernelGGL((attn_bwd_bf16_kernel<72, 96>), dim3(heads, N), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)dO,
+                         (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, scale * 1.4426950408889634f, scale);
   } else {
     const dim3 grid(T / 64, heads, N);
 #define OSUD_ABWD(HD)                                                                                                   \

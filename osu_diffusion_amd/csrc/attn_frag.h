@@ -1,5 +1,5 @@
 // MFMA operand fragments shared by the attention forward and backward kernels (bf16 tier, head_dim 64):
-// LDS tiles are row-major [rows][64 d] with 128-byte rows whose 16-byte chunk index is XOR-swizzled with (row>>1)&7.
+// LDS tiles are row-major [rows][padded head width]; see AttnTile for the two geometries.
 #pragma once
 #include "common.h"
 
@@ -8,21 +8,34 @@ namespace osud {
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ u32x4 rowfrag(const char* tile, int row, int chunk) {
-  return *reinterpret_cast<const u32x4*>(tile + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4));
+// Tile geometry by padded head width HDP (head_dim rounded up to a multiple of 32; the pad columns hold zeros):
+//   HDP = 64 : 128-byte rows, 16-byte chunk index XOR-swizzled with (row>>1)&7 (conflict-free ds_read_b128)
+//   HDP = 96 : 192-byte rows padded to 208 (52 dwords: 16 consecutive rows start in 16 different 4-bank groups), no swizzle
+//              -- DiT-XL's head_dim 72
+template <int HDP> struct AttnTile {
+  static_assert(HDP == 64 || HDP == 96, "attention tiles are built for padded head widths 64 and 96");
+  static constexpr int RS = HDP == 64 ? 128 : 208;  // row stride in bytes
+  static constexpr int CPR = HDP / 8;               // 16-byte chunks per row
+  static __device__ __forceinline__ int off(int row, int chunk) {
+    return row * RS + (HDP == 64 ? ((chunk ^ ((row >> 1) & 7)) << 4) : (chunk << 4));
+  }
+};
+
+template <int HDP> __device__ __forceinline__ u32x4 rowfrag(const char* tile, int row, int chunk) {
+  return *reinterpret_cast<const u32x4*>(tile + AttnTile<HDP>::off(row, chunk));
 }
-// A operand whose contraction index is the ROW of a row-major [rows][64 d] tile (128-byte rows, chunk index
-// XOR-swizzled with (row>>1)&7): lane (d = d0 + (lane&31), half) gets, for column d, the 8 rows
+// A operand whose contraction index is the ROW of a row-major [rows][HDP] tile: lane (d = d0 + (lane&31), half) gets, for
+// column d, the 8 rows
 //   r0 + 4*half + {0..3}  and  r0 + 8 + 4*half + {0..3}
 // — the same permuted order in which P / dS leave the S-layout registers (see pack8) — via two transposing reads
 // (each 16-lane group: 4 rows x 16 columns; semantics pinned by tools/probes/tr_probe.hip).
-__device__ __forceinline__ u32x4 trfrag(const char* tile, int r0, int d0, int lane) {
+template <int HDP> __device__ __forceinline__ u32x4 trfrag(const char* tile, int r0, int d0, int lane) {
   const int row = r0 + 4 * (lane >> 5) + ((lane & 15) >> 2);
   const int colb = (d0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;  // byte offset of this lane's 4 columns
   const int chunk = colb >> 4, within = colb & 15;
   const uint32_t base = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)tile;
-  const uint32_t a0 = base + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) + within;
-  const uint32_t a1 = base + (row + 8) * 128 + ((chunk ^ (((row + 8) >> 1) & 7)) << 4) + within;
+  const uint32_t a0 = base + AttnTile<HDP>::off(row, chunk) + within;
+  const uint32_t a1 = base + AttnTile<HDP>::off(row + 8, chunk) + within;
   // reads and their wait are ONE asm statement: a separate s_waitcnt statement does not stop the scheduler from
   // moving the consumers (register moves, MFMA) above it, because the asm outputs look ready to the compiler
   u32x2 lo, hi;

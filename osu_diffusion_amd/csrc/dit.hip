@@ -233,10 +233,6 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   OSUD_CHECK_ARG(cfg->precision == OSUD_PREC_BF16 || cfg->precision == OSUD_PREC_F32, "dit_create: unknown precision %d",
                  cfg->precision);
   const int hd = cfg->hidden / cfg->heads;
-  if (cfg->precision == OSUD_PREC_BF16 && hd != 64) {
-    set_error("dit_create: bf16 tier needs head_dim 64 (got %d); use OSUD_PREC_F32", hd);
-    return OSUD_ERR_UNSUPPORTED;
-  }
   if (hd != 64 && hd != 72) {
     set_error("dit_create: head_dim %d not built (64, 72)", hd);
     return OSUD_ERR_UNSUPPORTED;

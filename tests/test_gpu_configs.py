@@ -2,8 +2,8 @@
 
 config 1  DiT-S, seq-len 64, batch 4 training step (also the train_nodist.py variant: t == 0 for every
           sample, train_nodist.py:222) against the oracle's autograd;
-config 5  DiT-XL geometry (hidden 1152, 16 heads -> head_dim 72) on a 2-block stack, T = 256: forward and
-          backward in the fp32 tier; the bf16 tier must refuse head_dim 72 loudly;
+config 5  DiT-XL geometry (hidden 1152, 16 heads -> head_dim 72) on a 2-block stack: forward and backward at T = 256 in
+          the fp32 tier; bf16 tier forward at T = 256 / 200 and training at T = 128 (its attention backward refuses T > 128);
 configs 2/4 at FULL bench size through size-independent properties (determinism, graph == eager,
           cfg_scale = 1 equals the conditional forward, rows are independent, finite outputs)."""
 import pytest
@@ -77,12 +77,37 @@ def test_config5_xl_head_dim_72_fp32_forward_and_backward():
         assert maxdiff(gv[k].cpu(), grads[k]) < 2e-5 + 2e-3 * float(grads[k].abs().max()), k
 
 
-def test_bf16_tier_refuses_head_dim_72_loudly():
-    shape = mo.DitShape(depth=1, hidden=1152, heads=16, num_classes=4)
-    m = build(shape, mo.seeded_state_dict(shape, 1), "bf16")
-    (x, o, c), y = synthetic_windows(2, 64, 4, seed=0)
-    with torch.no_grad(), pytest.raises(_lib.NativeError, match="head_dim"):
-        m(x, torch.zeros(2, dtype=torch.long), o, c, y)
+def test_config5_xl_head_dim_72_bf16_tier():
+    """DiT-XL's head_dim 72 in the MFMA attention kernels (head padded to 96 zero columns inside the LDS tiles): forward at
+    T = 256 incl. a ragged T, training step at T = 128; the bf16 attention backward keeps a whole sequence in LDS and
+    must refuse T = 256 loudly instead of computing something else."""
+    shape = mo.DitShape(depth=2, hidden=1152, heads=16, num_classes=8)
+    sd = mo.seeded_state_dict(shape, 41)
+    m = build(shape, sd, "bf16")
+    for T_ in (256, 200):
+        (x, o, c), y = synthetic_windows(2, T_, 8, seed=3)
+        t = torch.tensor([10, 800])
+        with torch.no_grad():
+            got = m(x, t, o, c, y).cpu()
+            want = mo.forward(sd, shape, x, t, o, c, y)
+        assert maxdiff(got, want) < 3e-2 * max(1.0, float(want.abs().max())), (T_, maxdiff(got, want))
+    (x, o, c), y = synthetic_windows(2, 128, 8, seed=4)
+    t = torch.tensor([10, 800])
+    noise = torch.randn(2, 2, 128, generator=torch.Generator().manual_seed(1))
+    terms, grads = oracle_step(shape, sd, x, o, c, y, t, noise)
+    tr = NativeTrainer(build(shape, sd, "bf16"), create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True))
+    out = tr.step(x, o, c, y, t=t, noise=noise).cpu()
+    assert maxdiff(out[2], terms["loss"].detach()) < 3e-2 * max(1.0, float(terms["loss"].abs().max()))
+    gv = tr.arena.grad_views()
+    for k in ("blocks.0.attn.in_proj_weight", "blocks.1.attn.in_proj_weight", "blocks.1.mlp.fc2.weight",
+              "blocks.0.adaLN_modulation.1.weight", "final_layer.linear.weight"):
+        ref = grads[k]
+        rel = float((gv[k].cpu() - ref).norm() / ref.norm().clamp_min(1e-12))
+        assert rel < 5e-2, (k, rel)
+    (x, o, c), y = synthetic_windows(2, 256, 8, seed=5)
+    with pytest.raises(_lib.NativeError, match="T <= 128"):
+        tr.step(x, o, c, y, t=t, noise=torch.randn(2, 2, 256))
+        torch.cuda.synchronize()
 
 
 @pytest.fixture(scope="module")
