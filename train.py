@@ -111,7 +111,9 @@ def main(args):
                 yield synthetic_windows(batch_size, args.seq_len, args.num_classes, seed=track)
 
         for (x, o, c), y in batches():
-            terms = trainer.step(x, o, c, y)
+            # --refine: the refine-model recipe of train_nodist.py:222 (t = 0 for every sample; sample.py --refine-ckpt uses it)
+            t0 = torch.zeros(x.shape[0], dtype=torch.long) if args.refine else None
+            terms = trainer.step(x, o, c, y, t=t0)
             running_loss += terms[2].mean()
             log_steps += 1
             train_steps += 1
@@ -163,6 +165,7 @@ if __name__ == "__main__":
     p.add_argument("--lr", type=float, default=1e-4)
     p.add_argument("--relearn-embeds", type=bool, default=False)
     p.add_argument("--embed-only-epochs", type=int, default=0)
+    p.add_argument("--refine", action="store_true", help="train the t = 0 refine model (train_nodist.py's recipe)")
     p.add_argument("--synthetic", action="store_true", help="train on synthetic windows (no `slider` needed)")
     p.add_argument("--synthetic-maps", type=int, default=0,
                    help="with --synthetic: stream windows from this many synthetic hit-object sequences through the "
