@@ -44,10 +44,11 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __rest
   const size_t m0 = (size_t)n * T;
 
   // ---- load row-major tiles (coalesced, 16 bytes per lane; pad columns of a 72-wide head are zero) + delta = rowsum(dO * O):
-  //      16 lanes per row (chunks 0..15, only those < CPR exist), so that a row's partial sums meet in one 16-lane group
+  //      LPR lanes per row (8 for a 64-wide head, 16 for the padded 96), so that a row's partial sums meet in one lane group
+  constexpr int LPR = CPR <= 8 ? 8 : 16;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  for (int idx = tid; idx < T * 16; idx += 256) {
-    const int r = idx >> 4, cp = idx & 15;
+  for (int idx = tid; idx < T * LPR; idx += 256) {
+    const int r = idx / LPR, cp = idx % LPR;
     float part = 0.f;
     if (cp < CPR) {
       const bool real = cp * 8 < HD;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __rest
     part += __shfl_xor(part, 1, 64);
     part += __shfl_xor(part, 2, 64);
     part += __shfl_xor(part, 4, 64);
-    part += __shfl_xor(part, 8, 64);
+    if (LPR == 16) part += __shfl_xor(part, 8, 64);
     if (cp == 0) del_s[r] = part;
   }
   for (int r = tid; r < T; r += 256) lse_s[r] = lse[((size_t)n * H + h) * T + r];
