@@ -22,8 +22,8 @@ namespace osud {
 
 namespace {
 
-template <int HD, int HDP>
-__global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+template <int HD, int HDP, int NT>
+__global__ __launch_bounds__(NT) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                             const bf16_t* __restrict__ O, const float* __restrict__ lse,
                                                             bf16_t* __restrict__ dqkv, int T, int D, float c1,
                                                             float scale) {
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __rest
   //      LPR lanes per row (8 for a 64-wide head, 16 for the padded 96), so that a row's partial sums meet in one lane group
   constexpr int LPR = CPR <= 8 ? 8 : 16;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  for (int idx = tid; idx < T * LPR; idx += 256) {
+  for (int idx = tid; idx < T * LPR; idx += NT) {
     const int r = idx / LPR, cp = idx % LPR;
     float part = 0.f;
     if (cp < CPR) {
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void attn_bwd_bf16_kernel(const bf16_t* __rest
     if (LPR == 16) part += __shfl_xor(part, 8, 64);
     if (cp == 0) del_s[r] = part;
   }
-  for (int r = tid; r < T; r += 256) lse_s[r] = lse[((size_t)n * H + h) * T + r];
+  for (int r = tid; r < T; r += NT) lse_s[r] = lse[((size_t)n * H + h) * T + r];
   __syncthreads();
   const int own = wave * 32;  // first query (pass A) / key (pass B) this wave owns
   if (own < T) {
@@ -287,25 +287,33 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
   const int D = heads * head_dim;
   const float scale = 1.0f / sqrtf((float)head_dim);
   if (prec == OSUD_PREC_BF16) {
-    if ((head_dim != 64 && head_dim != 72) || T > 128) {
-      set_error("attention backward (bf16 tier) is built for head_dim 64 / 72 and T <= 128 (got hd=%d, T=%d)", head_dim, T);
+    // a workgroup keeps the whole sequence of one (sample, head) in LDS: 4 tiles of T rows (one wave per 32 rows)
+    const int rs = head_dim == 64 ? AttnTile<64>::RS : AttnTile<96>::RS;
+    const size_t lds = (size_t)4 * T * rs + (size_t)2 * T * 4;
+    if ((head_dim != 64 && head_dim != 72) || T > 256 || lds > 160 * 1024) {
+      set_error("attention backward (bf16 tier): head_dim 64 up to T <= 256, head_dim 72 up to T <= 128 (got hd=%d, T=%d)", head_dim, T);
       return OSUD_ERR_UNSUPPORTED;
     }
-    const size_t lds = (size_t)4 * T * (head_dim == 64 ? AttnTile<64>::RS : AttnTile<96>::RS) + (size_t)2 * T * 4;
     static bool attr_set = false;
     if (!attr_set) {
-      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bf16_kernel<64, 64>),
+      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bf16_kernel<64, 64, 256>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bf16_kernel<72, 96>),
+      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bf16_kernel<64, 64, 512>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bf16_kernel<72, 96, 256>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set = true;
     }
-    if (head_dim == 64)
-      hipLaunchKernelGGL((attn_bwd_bf16_kernel<64, 64>), dim3(heads, N), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)dO,
-                         (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, scale * 1.4426950408889634f, scale);
+    const float c1 = scale * 1.4426950408889634f;
+    if (head_dim == 64 && T <= 128)
+      hipLaunchKernelGGL((attn_bwd_bf16_kernel<64, 64, 256>), dim3(heads, N), dim3(256), lds, st, (const bf16_t*)qkv,
+                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale);
+    else if (head_dim == 64)
+      hipLaunchKernelGGL((attn_bwd_bf16_kernel<64, 64, 512>), dim3(heads, N), dim3(512), lds, st, (const bf16_t*)qkv,
+                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale);
     else
-      hipLaunchKernelGGL((attn_bwd_bf16_kernel<72, 96>), dim3(heads, N), dim3(256), lds, st, (const bf16_t*)qkv, (const bf16_t*)dO,
-                         (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, scale * 1.4426950408889634f, scale);
+      hipLaunchKernelGGL((attn_bwd_bf16_kernel<72, 96, 256>), dim3(heads, N), dim3(256), lds, st, (const bf16_t*)qkv,
+                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale);
   } else {
     const dim3 grid(T / 64, heads, N);
 #define OSUD_ABWD(HD)                                                                                                   \

@@ -223,3 +223,20 @@ def test_bf16_training_trajectory_tracks_the_fp32_tier():
     # (the backward's float atomics make runs differ in the last bits; vb spikes at small t amplify that in single steps)
     assert float(diff.median()) < 3e-3 and float(diff.quantile(0.9)) < 2e-2, (float(diff.median()), float(diff.quantile(0.9)), float(diff.max()))
     assert float(curves["bf16"][-8:].median()) < 0.7 * float(curves["bf16"][:4].median())  # median: vb spikes at small t
+
+
+def test_bf16_training_at_seq_len_256():
+    """64-wide heads train at T = 256 in the bf16 tier (8-wave attention backward, the whole 256-token sequence of a head in LDS)."""
+    shape = mo.DitShape(depth=2, hidden=128, heads=2, num_classes=8)
+    sd = mo.seeded_state_dict(shape, 23)
+    (x, o, c), y = synthetic_windows(2, 256, 8, seed=6)
+    t = torch.tensor([5, 700])
+    noise = torch.randn(2, 2, 256, generator=torch.Generator().manual_seed(2))
+    terms, grads = oracle_step(shape, sd, x, o, c, y, t, noise)
+    tr = NativeTrainer(build(shape, sd, "bf16"), create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True))
+    out = tr.step(x, o, c, y, t=t, noise=noise).cpu()
+    assert maxdiff(out[2], terms["loss"].detach()) < 3e-2 * max(1.0, float(terms["loss"].abs().max()))
+    gv = tr.arena.grad_views()
+    for k in ("blocks.0.attn.in_proj_weight", "blocks.1.attn.in_proj_weight", "blocks.0.attn.in_proj_bias", "blocks.1.mlp.fc1.weight"):
+        rel = float((gv[k].cpu() - grads[k]).norm() / grads[k].norm().clamp_min(1e-12))
+        assert rel < 5e-2, (k, rel)
