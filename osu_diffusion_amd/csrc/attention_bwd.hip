@@ -178,6 +178,187 @@ __global__ __launch_bounds__(NT) void attn_bwd_bf16_kernel(const bf16_t* __restr
   }
 }
 
+// ------------------------------------------------------------------------- any T (bf16 tier)
+// delta[n][h][t] = sum_d dO[m][h*HD + d] * O[m][h*HD + d]  (one thread per (row, head), 16-byte loads)
+template <int HD>
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ dO, const bf16_t* __restrict__ O,
+                                                         float* __restrict__ delta, int N, int T, int H) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * T * H) return;
+  const int h = i % H, m = i / H, n = m / T, t = m % T;
+  const bf16_t* a = dO + (size_t)m * H * HD + h * HD;
+  const bf16_t* b = O + (size_t)m * H * HD + h * HD;
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < HD / 8; ++c) {
+    float x[8], y[8];
+    load8(a + 8 * c, x);
+    load8(b + 8 * c, y);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s = fmaf(x[e], y[e], s);
+  }
+  delta[((size_t)n * H + h) * T + t] = s;
+}
+
+// The same two passes as attn_bwd_bf16_kernel, but a workgroup owns only 128 queries (pass A) / 128 keys (pass B) and
+// STREAMS the other side through two LDS tiles of 128 rows, so that T is unbounded (DiT-XL at T = 256, long sequences):
+// LDS = 2 x 128 x row stride + 1 KiB.  The owned rows' fragments come straight from global memory; delta is precomputed.
+template <int HD, int HDP>
+__global__ __launch_bounds__(256) void attn_bwd_tiled_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                             const float* __restrict__ lse, const float* __restrict__ delta,
+                                                             bf16_t* __restrict__ dqkv, int T, int D, float c1, float scale) {
+  using TL = AttnTile<HDP>;
+  constexpr int KS = HDP / 16, DT = HDP / 32, CPR = TL::CPR;
+  __shared__ __attribute__((aligned(16))) char Xs[128 * TL::RS];  // K (pass A) / Q (pass B) rows of the streamed block
+  __shared__ __attribute__((aligned(16))) char Ys[128 * TL::RS];  // V (pass A) / dO (pass B)
+  __shared__ float lse_s[128], del_s[128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int h = blockIdx.y, n = blockIdx.z, H = gridDim.y;
+  const size_t ld3 = 3 * (size_t)D;
+  const size_t m0 = (size_t)n * T;
+  const int own = blockIdx.x * 128 + wave * 32;  // first query (pass A) / key (pass B) this wave owns
+  const bool live = own < T;                     // T % 32 == 0: a wave is either fully inside or fully outside
+  const int orow_i = live ? own + frow : 0;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  const int nblk = (T + 127) / 128;
+  auto gfrag = [&](const bf16_t* base, size_t ld, int col0, int ks) -> u32x4 {  // chunk 2ks+fhalf of the owned row
+    const int c = 2 * ks + fhalf;
+    return (live && c * 8 < HD) ? *reinterpret_cast<const u32x4*>(base + (m0 + orow_i) * ld + col0 + h * HD + c * 8) : zero4;
+  };
+  auto load_block = [&](int blk, int colX, const bf16_t* ysrc, size_t yld, int colY, bool stats) {
+    const int rows = T - blk * 128 < 128 ? T - blk * 128 : 128;
+    __syncthreads();  // the previous block is fully consumed
+    for (int idx = tid; idx < 128 * CPR; idx += 256) {
+      const int r = idx / CPR, cp = idx % CPR;
+      const bool real = r < rows && cp * 8 < HD;
+      const size_t m = m0 + blk * 128 + r;
+      *reinterpret_cast<u32x4*>(Xs + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(qkv + m * ld3 + colX + h * HD + cp * 8) : zero4;
+      *reinterpret_cast<u32x4*>(Ys + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(ysrc + m * yld + colY + h * HD + cp * 8) : zero4;
+    }
+    if (stats && tid < 128) {
+      const bool real = tid < rows;
+      lse_s[tid] = real ? lse[((size_t)n * H + h) * T + blk * 128 + tid] : 0.f;
+      del_s[tid] = real ? delta[((size_t)n * H + h) * T + blk * 128 + tid] : 0.f;
+    }
+    __syncthreads();
+    return rows;
+  };
+
+  // =============================== pass A: dQ for the owned queries; K, V streamed ======================
+  {
+    u32x4 qf[KS], of[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[ks] = gfrag(qkv, ld3, 0, ks);
+      of[ks] = gfrag(dO, (size_t)D, 0, ks);
+    }
+    const float my_lse = live ? lse[((size_t)n * H + h) * T + orow_i] : 0.f;
+    const float my_del = live ? delta[((size_t)n * H + h) * T + orow_i] : 0.f;
+    f32x16 dq[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+    for (int kb = 0; kb < nblk; ++kb) {
+      const int rows = load_block(kb, D, qkv, ld3, 2 * D, false);
+      if (!live) continue;
+      for (int kt = 0; kt < rows / 32; ++kt) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          s = mfma_bf16(rowfrag<HDP>(Xs, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s);    // D[key][query]
+          dp = mfma_bf16(rowfrag<HDP>(Ys, kt * 32 + frow, 2 * ks + fhalf), of[ks], dp);  // dO . V^T
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(s[r] * c1 - my_lse);
+          s[r] = p * (dp[r] - my_del) * scale;  // dS
+        }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const u32x4 dsf = pack8(s, 8 * ss);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) dq[dt] = mfma_bf16(trfrag<HDP>(Xs, kt * 32 + 16 * ss, dt * 32, lane), dsf, dq[dt]);
+        }
+      }
+    }
+    if (live) {
+      bf16_t* orow = dqkv + (m0 + own + frow) * ld3 + h * HD;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (dt * 32 + 8 * g + 4 * fhalf < HD)
+            store4(orow + dt * 32 + 8 * g + 4 * fhalf, dq[dt][4 * g], dq[dt][4 * g + 1], dq[dt][4 * g + 2], dq[dt][4 * g + 3]);
+    }
+  }
+  // =============================== pass B: dK, dV for the owned keys; Q, dO streamed =====================
+  {
+    u32x4 kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      kf[ks] = gfrag(qkv, ld3, D, ks);
+      vf[ks] = gfrag(qkv, ld3, 2 * D, ks);
+    }
+    f32x16 dk[DT], dv[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dk[i][r] = dv[i][r] = 0.f;
+    for (int qb = 0; qb < nblk; ++qb) {
+      const int rows = load_block(qb, 0, dO, (size_t)D, 0, true);
+      if (!live) continue;
+      for (int qt = 0; qt < rows / 32; ++qt) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          s = mfma_bf16(rowfrag<HDP>(Xs, qt * 32 + frow, 2 * ks + fhalf), kf[ks], s);    // D[query][key]
+          dp = mfma_bf16(rowfrag<HDP>(Ys, qt * 32 + frow, 2 * ks + fhalf), vf[ks], dp);
+        }
+        f32x16 p;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 32 + 8 * g + 4 * fhalf);
+          const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qt * 32 + 8 * g + 4 * fhalf);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float pv = __builtin_amdgcn_exp2f(s[4 * g + i] * c1 - l4[i]);
+            p[4 * g + i] = pv;
+            s[4 * g + i] = pv * (dp[4 * g + i] - d4[i]) * scale;
+          }
+        }
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const u32x4 pf = pack8(p, 8 * ss), dsf = pack8(s, 8 * ss);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            dv[dt] = mfma_bf16(trfrag<HDP>(Ys, qt * 32 + 16 * ss, dt * 32, lane), pf, dv[dt]);
+            dk[dt] = mfma_bf16(trfrag<HDP>(Xs, qt * 32 + 16 * ss, dt * 32, lane), dsf, dk[dt]);
+          }
+        }
+      }
+    }
+    if (live) {
+      bf16_t* orow = dqkv + (m0 + own + frow) * ld3 + h * HD;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = dt * 32 + 8 * g + 4 * fhalf;
+          if (d < HD) {
+            store4(orow + D + d, dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]);
+            store4(orow + 2 * D + d, dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
+          }
+        }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------- f32 tier (VALU)
 template <int HD>
 __global__ __launch_bounds__(64) void attn_bwd_dq_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
@@ -282,7 +463,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_f32_kernel(const float* __res
 }  // namespace
 
 int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* O, const float* lse, void* dqkv, int N,
-                         int T, int heads, int head_dim, hipStream_t st) {
+                         int T, int heads, int head_dim, hipStream_t st, float* delta_ws) {
   OSUD_CHECK_ARG(N > 0 && T > 0 && T % 64 == 0, "attention backward: T=%d must be a multiple of 64", T);
   const int D = heads * head_dim;
   const float scale = 1.0f / sqrtf((float)head_dim);
@@ -290,9 +471,28 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
     // a workgroup keeps the whole sequence of one (sample, head) in LDS: 4 tiles of T rows (one wave per 32 rows)
     const int rs = head_dim == 64 ? AttnTile<64>::RS : AttnTile<96>::RS;
     const size_t lds = (size_t)4 * T * rs + (size_t)2 * T * 4;
-    if ((head_dim != 64 && head_dim != 72) || T > 256 || lds > 160 * 1024) {
-      set_error("attention backward (bf16 tier): head_dim 64 up to T <= 256, head_dim 72 up to T <= 128 (got hd=%d, T=%d)", head_dim, T);
+    if (head_dim != 64 && head_dim != 72) {
+      set_error("attention backward (bf16 tier) is built for head_dim 64 and 72 (got %d)", head_dim);
       return OSUD_ERR_UNSUPPORTED;
+    }
+    const float c1t = scale * 1.4426950408889634f;
+    if (T > 256 || lds > 160 * 1024) {  // the sequence of a head does not fit the LDS: streamed variant
+      OSUD_CHECK_ARG(delta_ws != nullptr, "attention backward: T=%d needs the delta workspace", T);
+      const int rows = N * T * heads;
+      const dim3 grid((T + 127) / 128, heads, N);
+      if (head_dim == 64) {
+        hipLaunchKernelGGL((attn_delta_kernel<64>), dim3((rows + 255) / 256), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O,
+                           delta_ws, N, T, heads);
+        hipLaunchKernelGGL((attn_bwd_tiled_kernel<64, 64>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dO, lse,
+                           delta_ws, (bf16_t*)dqkv, T, D, c1t, scale);
+      } else {
+        hipLaunchKernelGGL((attn_delta_kernel<72>), dim3((rows + 255) / 256), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O,
+                           delta_ws, N, T, heads);
+        hipLaunchKernelGGL((attn_bwd_tiled_kernel<72, 96>), grid, dim3(256), 0, st, (const bf16_t*)qkv, (const bf16_t*)dO, lse,
+                           delta_ws, (bf16_t*)dqkv, T, D, c1t, scale);
+      }
+      OSUD_HIP(hipGetLastError());
+      return OSUD_OK;
     }
     static bool attr_set = false;
     if (!attr_set) {

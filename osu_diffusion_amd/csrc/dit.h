@@ -42,7 +42,7 @@ struct LayerSaved {
 // workspaces of the backward pass
 struct BwdWs {
   float *dhA = nullptr, *dhB = nullptr, *du = nullptr, *dada = nullptr, *dWada = nullptr, *dbada = nullptr, *dsb = nullptr,
-        *db = nullptr, *dth = nullptr, *dWe = nullptr, *splitk = nullptr;
+        *db = nullptr, *dth = nullptr, *dWe = nullptr, *splitk = nullptr, *attn_delta = nullptr /* [N][H][Tp] */;
   size_t splitk_elems = 0;
   void *dbr = nullptr, *dz1 = nullptr, *dqkv = nullptr, *dao = nullptr, *tA = nullptr, *tB = nullptr, *dada_te = nullptr,
        *db_te = nullptr, *dz0 = nullptr, *small_t1 = nullptr, *small_t2 = nullptr;

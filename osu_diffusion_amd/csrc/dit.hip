@@ -105,6 +105,7 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
     OSUD_TRY(dev_alloc(W, &b.dWe, (size_t)D * m->Kp * 4));
     b.splitk_elems = (size_t)16 * 4 * D * D;  // up to 16 partial slabs of the largest weight gradient
     OSUD_TRY(dev_alloc(W, &b.splitk, b.splitk_elems * 4, false));
+    OSUD_TRY(dev_alloc(W, &b.attn_delta, (size_t)nN * m->H * Tp * 4));
   }
   m->cap_N = nN; m->cap_T = nT; m->cap_Tp = Tp; m->cap_Mp = Mp; m->cap_Np = Np;
   return OSUD_OK;

@@ -28,8 +28,9 @@ int launch_pack_rows(int prec, const float* src, int ld_src, int cols_src, void*
 int launch_attention(int prec, const void* qkv, int ld_qkv, const uint8_t* mask, void* out, float* lse, int N, int T, int Tp,
                      int Mp, int heads, int head_dim, hipStream_t st, const uint8_t* kb_class = nullptr);
 int launch_mask_tiles(const uint8_t* mask, int T, int Tp, uint8_t* kb_class, hipStream_t st);
+// delta_ws: [N][heads][T] fp32 scratch, needed when the sequence of one head does not fit the LDS (streamed variant)
 int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* O, const float* lse, void* dqkv, int N,
-                         int T, int heads, int head_dim, hipStream_t st);
+                         int T, int heads, int head_dim, hipStream_t st, float* delta_ws = nullptr);
 
 // kernels_bwd.hip
 int launch_transpose(int prec, const void* in, int ld_in, void* out, int ld_out, int R, int C, float* colsum,
