@@ -59,7 +59,8 @@ template <int RY, int RX> __device__ __forceinline__ void read_set(FragSet<RY, R
   if constexpr (RY == 4) f.y[3] = ds_read16<96 * SLAB>(ya);
   f.x[0] = ds_read16<0>(xa);
   f.x[1] = ds_read16<32 * SLAB>(xa);
-  if constexpr (RX == 3) f.x[2] = ds_read16<64 * SLAB>(xa);
+  if constexpr (RX >= 3) f.x[2] = ds_read16<64 * SLAB>(xa);
+  if constexpr (RX == 4) f.x[3] = ds_read16<96 * SLAB>(xa);
 }
 template <typename TE, int RY, int RX>
 __device__ __forceinline__ void mma_set(f32x16 (&acc)[RY][RX], const FragSet<RY, RX>& f) {
@@ -72,6 +73,7 @@ template <int N> __device__ __forceinline__ void wait_lgkm() {
   if constexpr (N == 4) { OSUD_LGKM_WAIT(4); }
   else if constexpr (N == 5) { OSUD_LGKM_WAIT(5); }
   else if constexpr (N == 6) { OSUD_LGKM_WAIT(6); }
+  else if constexpr (N == 8) { OSUD_LGKM_WAIT(8); }
   else { OSUD_LGKM_WAIT(0); }
 }
 // One 128-byte K slab from the LDS stage at byte offset `so`: 4 sub-steps, reads of sub-step s+1 in
@@ -99,9 +101,10 @@ __device__ __forceinline__ void compute_slab(f32x16 (&acc)[RY][RX], const uint32
 template <int WY, int WX, int RY, int RX> struct Geo {
   static constexpr int BM = WY * RY * 32, BN = WX * RX * 32, NW = WY * WX, NT = 64 * NW;
   static constexpr int STAGE = (BM + BN) * SLAB;
-  // 8-wave geometries own the CU (all 160 KiB); 4-wave geometries take half so that TWO workgroups share a CU and one's
-  // epilogue (VALU + stores) runs under the other's MFMA main loop
-  static constexpr int WGS = (NW == 4 && BM * BN > 128 * 128) ? 2 : 1;
+  // One persistent workgroup per CU owns all 160 KiB.  (Tried and dropped: two 4-wave workgroups per CU on 128x192 tiles so that
+  // one's epilogue runs under the other's main loop, 25-45 % slower; four waves of 128x128 with one wave per SIMD and 512
+  // registers, 20-60 % slower under hipcc's scheduling.)
+  static constexpr int WGS = 1;
   static constexpr int LDS_MAX = 160 * 1024 / WGS;
   static constexpr int NSTAGE = STAGE * 5 <= LDS_MAX ? 5 : (STAGE * 4 <= LDS_MAX ? 4 : (STAGE * 3 <= LDS_MAX ? 3 : 2));
   static constexpr int PIECES = (BM + BN) / 8, PPW = PIECES / NW;  // 1 KiB LDS-DMA pieces per slab, per wave
@@ -532,9 +535,7 @@ template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
     else if (f == "192" && e[1] > 0) pick = 1;
     else if (f == "256" && e[2] > 0) pick = 2;
     else if (f == "192y" && e[3] > 0) pick = 3;
-    else if (f == "2wg" && p.Nx % 192 == 0) pick = 4;
   }
-  if (pick == 4) return launch_w<TE, EPI, 2, 2, 2, 3>(p, st);
   if (pick == 2) return launch_w<TE, EPI, 2, 4, 4, 2>(p, st);
   if (pick == 1) return launch_w<TE, EPI, 4, 2, 2, 3>(p, st);
   if (pick == 3) return launch_w<TE, EPI, 2, 4, 3, 2>(p, st);
