@@ -49,8 +49,10 @@ __global__ __launch_bounds__(256) void mask_tiles_kernel(const uint8_t* __restri
 
 // HD = head_dim (64, or 72 for DiT-XL), HDP = HD padded to a multiple of 32 (zero columns: they add nothing to q.k and give
 // zero output columns that are not stored)
+// (4 waves per SIMD for the 64-wide head: the kernel has only two key blocks per workgroup at T = 128 and hides its load
+// latency through occupancy; prefetching the next block into registers instead was measured neutral-to-slower)
 template <int HD, int HDP>
-__global__ __launch_bounds__(256) void attn_bf16_kernel(const bf16_t* __restrict__ qk,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 4 : 2))) void attn_bf16_kernel(const bf16_t* __restrict__ qk,
                                                         const uint8_t* __restrict__ mask, bf16_t* __restrict__ out,
                                                         float* __restrict__ lse, int T, int Tp, int Mp, int D,
                                                         int ld_qk, float c1 /* scale*log2(e) */,
