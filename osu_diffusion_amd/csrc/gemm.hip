@@ -296,9 +296,11 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
 #ifdef OSUD_GEMM_TIMING
       const uint64_t tt2 = __builtin_readcyclecounter();
 #endif
-      // (Measured with -DOSUD_GEMM_TIMING: a slab costs ~3200 cycles = 64 LDS-DMA pieces x ~50 cycles, i.e. the CU's LDS-DMA
-      // issue rate (~20 B/clk), not L2/HBM -- all workgroups streaming the SAME panels run no faster -- and not the MFMA
-      // pipe (2 x 1024 cycles).  Issuing half the waves' pieces mid-slab instead of here changes nothing; touching the
+      // (Measured with -DOSUD_GEMM_TIMING, ticks calibrated at 1.67 per ns = the clock the chip holds under this load: a slab
+      // costs ~2900 cycles against 2 x 1024 cycles of MFMA issue per SIMD (71 % pipe utilisation); the rest is the barrier,
+      // the LDS-DMA issue (~90-160 cycles per 1 KiB piece) and the first fragment reads.  Not L2/HBM -- all workgroups
+      // streaming the SAME panels run no faster -- and not LDS bandwidth either: with the X operand neither staged nor read
+      // (half the DMA, 2/3 of the reads; timing experiment) the slab only drops to ~2700.  Issuing half the waves' pieces mid-slab instead of here changes nothing; touching the
       // lines of the slab 2-4 ahead with one plain load per wave (L2 warm-up) costs 4-7 % end to end.)
       issue_next();
 #ifdef OSUD_GEMM_TIMING
@@ -476,7 +478,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
     float* dbg = const_cast<float*>(p.gate) + (blockIdx.x * G::NW + wave) * 8;
     for (int i = 0; i < 6; ++i) dbg[i] = (float)tsum[i];
     dbg[6] = (float)tsum[6];
-    dbg[7] = (float)tsum[7];
+    dbg[7] = (float)(__builtin_readcyclecounter() - tk0);  // whole kernel, in the same ticks (calibrates ticks per ns)
   }
 #endif
 }
