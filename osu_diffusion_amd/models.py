@@ -190,10 +190,13 @@ class DiT(nn.Module):
                 _lib.lib().osud_dit_destroy(self._handle)
             except Exception:
                 pass
-            self._handle = None
+            self.__dict__["_handle"] = None  # not through nn.Module.__setattr__: it may be half torn down at interpreter exit
 
     def __del__(self):
-        self._free_handle()
+        try:
+            self._free_handle()
+        except Exception:  # interpreter shutdown: modules / torch internals may already be gone
+            pass
 
     def __getstate__(self):  # deepcopy (EMA copy, train.py:147) / pickling: never share a native handle
         state = self.__dict__.copy()
