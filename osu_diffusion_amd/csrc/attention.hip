@@ -120,11 +120,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int key0 = kb * 64 + kt * 32 + 8 * g + 4 * fhalf;
+        // the 4 mask bytes of this lane's 4 consecutive keys: one 32-bit load when rows are 4-byte aligned (T % 4 == 0)
+        // (-7...-10 % per long-sequence sampling step vs byte loads; bit-packing the mask first was slower again: the
+        // packing pass runs every forward)
+        uint32_t m4 = 0;
+        if (check_mask && key0 < T) {
+          const uint8_t* mp = mask + (size_t)qm * T + key0;
+          if ((T & 3) == 0) {
+            m4 = *reinterpret_cast<const uint32_t*>(mp);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (key0 + i < T) m4 |= (uint32_t)mp[i] << (8 * i);
+          }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int key = key0 + i;
           bool dead = key >= T;
-          if (check_mask && !dead) dead = mask[(size_t)qm * T + key] != 0;
+          if (check_mask && !dead) dead = ((m4 >> (8 * i)) & 0xffu) != 0;
           const float v = dead ? -INFINITY : s[kt][4 * g + i] * c1;
           s[kt][4 * g + i] = v;
           mx = fmaxf(mx, v);
