@@ -54,7 +54,7 @@ template <int RY, int RX> struct FragSet {
 // ya/xa: this lane's LDS byte address of (first Y / X row of the wave, k-substep s) in the current stage
 template <int RY, int RX> __device__ __forceinline__ void read_set(FragSet<RY, RX>& f, uint32_t ya, uint32_t xa) {
   f.y[0] = ds_read16<0>(ya);
-  f.y[1] = ds_read16<32 * SLAB>(ya);
+  if constexpr (RY >= 2) f.y[1] = ds_read16<32 * SLAB>(ya);
   if constexpr (RY >= 3) f.y[2] = ds_read16<64 * SLAB>(ya);
   if constexpr (RY == 4) f.y[3] = ds_read16<96 * SLAB>(ya);
   f.x[0] = ds_read16<0>(xa);
@@ -70,7 +70,8 @@ __device__ __forceinline__ void mma_set(f32x16 (&acc)[RY][RX], const FragSet<RY,
     for (int j = 0; j < RX; ++j) mma<TE>(acc[i][j], f.x[j], f.y[i]);
 }
 template <int N> __device__ __forceinline__ void wait_lgkm() {
-  if constexpr (N == 4) { OSUD_LGKM_WAIT(4); }
+  if constexpr (N == 3) { OSUD_LGKM_WAIT(3); }
+  else if constexpr (N == 4) { OSUD_LGKM_WAIT(4); }
   else if constexpr (N == 5) { OSUD_LGKM_WAIT(5); }
   else if constexpr (N == 6) { OSUD_LGKM_WAIT(6); }
   else if constexpr (N == 8) { OSUD_LGKM_WAIT(8); }
@@ -517,6 +518,7 @@ template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(con
 //   256x192: 4x2 waves of 64x96    for Nx = 768-like widths (3 x 256 would leave 1.5 rounds of tiles)
 //   192x256: 2x4 waves of 96x64    the same for My = 768-like heights (V^T projection, weight gradients)
 //   128x128: 2x2 waves of 64x64    small problems
+//    64x128: 2x2 waves of 32x64    problems with fewer 128x128 tiles than 3/4 of the CUs
 // Pick by the fraction of CU-rounds doing useful work, preferring the larger tile on ties.
 template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
   const int cus = num_cus(), splits = p.split_k > 1 ? p.split_k : 1;
@@ -531,9 +533,15 @@ template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
   if (e[1] > 0 && e[1] + 0.05 >= e[0]) pick = 1;
   if (e[3] > 0 && e[3] + 0.05 >= e[pick] && pick == 0) pick = 3;
   if (e[2] > 0 && e[2] + 0.05 >= e[pick]) pick = 2;
-  if (const char* force = getenv("OSUD_GEMM_TILE")) {  // "128" | "192" | "256": tuning / A-B runs
+  // few tiles (one beatmap, few variants: M ~ 2-4 K tokens): halve the tile height to double the workgroups in flight
+  {
+    static const int thr = [] { const char* e = getenv("OSUD_GEMM_SMALL_PCT"); return e ? atoi(e) : 75; }();
+    if (pick == 0 && (long)(p.My / 128) * (p.Nx / 128) * splits * 100 < (long)cus * thr) pick = 6;
+  }
+  if (const char* force = getenv("OSUD_GEMM_TILE")) {  // "64" | "128" | "192" | "256": tuning / A-B runs
     const std::string f(force);
     if (f == "128") pick = 0;
+    else if (f == "64") pick = 6;
     else if (f == "192" && e[1] > 0) pick = 1;
     else if (f == "256" && e[2] > 0) pick = 2;
     else if (f == "192y" && e[3] > 0) pick = 3;
@@ -541,6 +549,7 @@ template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
   if (pick == 2) return launch_w<TE, EPI, 2, 4, 4, 2>(p, st);
   if (pick == 1) return launch_w<TE, EPI, 4, 2, 2, 3>(p, st);
   if (pick == 3) return launch_w<TE, EPI, 2, 4, 3, 2>(p, st);
+  if (pick == 6) return launch_w<TE, EPI, 2, 2, 1, 2>(p, st);
   return launch_w<TE, EPI, 2, 2, 2, 2>(p, st);
 }
 
