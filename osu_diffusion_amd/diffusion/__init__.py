@@ -1,32 +1,32 @@
-"""`create_diffusion` — the reference's factory (diffusion/__init__.py:10-47), same keyword
-arguments and defaults."""
+"""`create_diffusion` — the reference's factory (diffusion/__init__.py:10-47): same keyword arguments, same defaults,
+same resulting object (a `SpacedDiffusion` over the respaced schedule)."""
 from . import gaussian_diffusion as gd
 from .respace import SpacedDiffusion, space_timesteps
+
+__all__ = ["create_diffusion", "SpacedDiffusion", "space_timesteps"]
+
+
+def _loss_type(use_kl: bool, rescale_learned_sigmas: bool, use_l1: bool):
+    """KL wins over everything; otherwise (rescaled?) x (L1 | MSE)."""
+    if use_kl:
+        return gd.LossType.RESCALED_KL
+    table = {(True, True): gd.LossType.RESCALED_L1, (True, False): gd.LossType.RESCALED_MSE,
+             (False, True): gd.LossType.L1, (False, False): gd.LossType.MSE}
+    return table[(bool(rescale_learned_sigmas), bool(use_l1))]
+
+
+def _var_type(learn_sigma: bool, sigma_small: bool):
+    if learn_sigma:
+        return gd.ModelVarType.LEARNED_RANGE
+    return gd.ModelVarType.FIXED_SMALL if sigma_small else gd.ModelVarType.FIXED_LARGE
 
 
 def create_diffusion(timestep_respacing, noise_schedule="linear", use_kl=False, sigma_small=False,
                      predict_xstart=False, learn_sigma=True, rescale_learned_sigmas=False, diffusion_steps=1000,
                      use_l1=False):
-    betas = gd.get_named_beta_schedule(noise_schedule, diffusion_steps)
-    if use_kl:
-        loss_type = gd.LossType.RESCALED_KL
-    elif rescale_learned_sigmas:
-        loss_type = gd.LossType.RESCALED_L1 if use_l1 else gd.LossType.RESCALED_MSE
-    else:
-        loss_type = gd.LossType.L1 if use_l1 else gd.LossType.MSE
-    if timestep_respacing is None or timestep_respacing == "":
-        timestep_respacing = [diffusion_steps]
-    if learn_sigma:
-        var_type = gd.ModelVarType.LEARNED_RANGE
-    else:
-        var_type = gd.ModelVarType.FIXED_SMALL if sigma_small else gd.ModelVarType.FIXED_LARGE
-    return SpacedDiffusion(
-        use_timesteps=space_timesteps(diffusion_steps, timestep_respacing),
-        betas=betas,
-        model_mean_type=gd.ModelMeanType.START_X if predict_xstart else gd.ModelMeanType.EPSILON,
-        model_var_type=var_type,
-        loss_type=loss_type,
-    )
-
-
-__all__ = ["create_diffusion", "SpacedDiffusion", "space_timesteps"]
+    respacing = timestep_respacing if timestep_respacing not in (None, "") else [diffusion_steps]
+    kept = space_timesteps(diffusion_steps, respacing)
+    mean_type = gd.ModelMeanType.START_X if predict_xstart else gd.ModelMeanType.EPSILON
+    return SpacedDiffusion(use_timesteps=kept, betas=gd.get_named_beta_schedule(noise_schedule, diffusion_steps),
+                           model_mean_type=mean_type, model_var_type=_var_type(learn_sigma, sigma_small),
+                           loss_type=_loss_type(use_kl, rescale_learned_sigmas, use_l1))
