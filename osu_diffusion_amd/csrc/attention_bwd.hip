@@ -15,6 +15,8 @@
 // index contiguous (K^T, Q^T, dO^T) are read straight from the row-major LDS tiles with
 // ds_read_b64_tr_b16, so no transposed copies exist (LDS 66 KB for T = 128 -> two workgroups per CU).
 // f32 tier: plain VALU kernels (one thread per query / per key).
+#include <stdlib.h>
+
 #include "attn_frag.h"
 #include "kernels.h"
 
@@ -476,7 +478,8 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
       return OSUD_ERR_UNSUPPORTED;
     }
     const float c1t = scale * 1.4426950408889634f;
-    if (T > 256 || lds > 160 * 1024) {  // the sequence of a head does not fit the LDS: streamed variant
+    static const bool force_tiled = [] { const char* e = getenv("OSUD_ATTN_BWD_TILED"); return e && e[0] == '1'; }();
+    if (T > 256 || lds > 160 * 1024 || force_tiled) {  // the sequence of a head does not fit the LDS: streamed variant
       OSUD_CHECK_ARG(delta_ws != nullptr, "attention backward: T=%d needs the delta workspace", T);
       const int rows = N * T * heads;
       const dim3 grid((T + 127) / 128, heads, N);
