@@ -17,22 +17,11 @@ import torch
 
 from osu_diffusion_amd.diffusion import create_diffusion
 from osu_diffusion_amd.models import DiT_models, find_model
-from osu_diffusion_amd.positional_embedding import timestep_embedding
 from osu_diffusion_amd.synthetic import banded_attn_mask
+from osu_diffusion_amd.windows import split_and_process_sequence_no_augment as split_and_process_sequence  # sample.py:64
 
 feature_size = 19
 playfield_size = torch.tensor((512, 384))
-
-
-def split_and_process_sequence(seq):
-    """(19,T) -> ((x (2,T), o (T), c (144,T)), T)  — data_loading.py:146-169 without the random flip
-    (the flipped positions are discarded at sampling time anyway, sample.py:64)."""
-    offset = torch.roll(seq[:2, :], 1, 1)
-    offset[0, 0], offset[1, 0] = 256, 192
-    seq_d = torch.linalg.vector_norm(seq[:2, :] - offset, ord=2, dim=0)
-    seq_x = seq[:2, :] / playfield_size.unsqueeze(1)
-    seq_c = torch.concatenate([timestep_embedding(seq_d, 128).T, seq[3:, :]], 0)
-    return (seq_x, seq[2, :], seq_c), seq.shape[1]
 
 
 def load_sequence(args):
