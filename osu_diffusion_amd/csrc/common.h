@@ -35,6 +35,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 
 // ---- element types of the two arithmetic tiers ---------------------------------------
 typedef uint16_t bf16_t;  // storage only
+struct fp8_t { uint8_t v; };  // OCP e4m3 storage (experimental GEMM operand type: osud_op_gemm precision 2)
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -96,6 +97,11 @@ __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
   v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
   v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
   v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ void store8(fp8_t*, const float (&)[8]) {}  // fp8 is an input-only type here
+__device__ __forceinline__ void load8(const fp8_t*, float (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 0.f;
 }
 __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
   const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
@@ -167,7 +173,7 @@ template <bool FAST> __device__ __forceinline__ void gelu_tanh_both_t(float z, f
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-static inline size_t elem_size(int prec) { return prec == OSUD_PREC_BF16 ? 2 : 4; }
+static inline size_t elem_size(int prec) { return prec == OSUD_PREC_BF16 ? 2 : (prec == 2 ? 1 : 4); }
 
 // wave-level reductions (wave = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {

@@ -463,7 +463,8 @@ extern "C" int osud_sample_loop(osud_dit* m, const osud_sched* s, int mode, floa
 extern "C" int osud_op_gemm(int precision, int epilogue, const void* Y, int ldy, const void* X, int ldx, int My, int Nx,
                             int K, void* out, int ldo, const float* bias, const float* gate, int ld_gate,
                             int rows_per_sample, int n_samples, osud_stream stream) {
-  OSUD_CHECK_ARG(precision == OSUD_PREC_BF16 || precision == OSUD_PREC_F32, "op_gemm: unknown precision");
+  OSUD_CHECK_ARG(precision == OSUD_PREC_BF16 || precision == OSUD_PREC_F32 || precision == 2 /* experimental fp8 e4m3 operands */,
+                 "op_gemm: unknown precision");
   GemmP p{};
   p.Y = Y; p.X = X; p.ldy = ldy; p.ldx = ldx; p.My = My; p.Nx = Nx; p.K = K; p.out = out; p.ldo = ldo; p.bias = bias;
   p.gate = gate; p.ld_gate = ld_gate; p.rows_per_sample = rows_per_sample; p.n_samples = n_samples;

@@ -43,6 +43,18 @@ template <> __device__ __forceinline__ void mma<float>(f32x16& acc, const u32x4&
   for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[j], acc, 0, 0, 0);
 }
 
+// fp8 (e4m3) operands: one v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (E8M0 127) consumes TWO 16-byte chunks per
+// lane and operand -- K = 64 per instruction at twice the bf16 rate.  Which 32 of the 64 k-slots a lane half feeds does not matter
+// as long as A and B agree, so the fragments of two consecutive sub-steps (chunks 2s+h and 2s+2+h) are simply concatenated.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void mma_f8(f32x16& acc, const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1) {
+  i32x8 a, b;
+  a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3]; a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
+  b[0] = b0[0]; b[1] = b0[1]; b[2] = b0[2]; b[3] = b0[3]; b[4] = b1[0]; b[5] = b1[1]; b[6] = b1[2]; b[7] = b1[3];
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+template <> __device__ __forceinline__ void mma<fp8_t>(f32x16&, const u32x4&, const u32x4&) {}  // fp8 goes through mma_f8
+
 #define OSUD_LGKM_WAIT(n)                                  \
   asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
   __builtin_amdgcn_sched_barrier(0)
@@ -83,6 +95,19 @@ template <typename TE, int RY, int RX>
 __device__ __forceinline__ void compute_slab(f32x16 (&acc)[RY][RX], const uint32_t (&ya)[4], const uint32_t (&xa)[4],
                                              uint32_t so) {
   FragSet<RY, RX> f0, f1;
+  if constexpr (sizeof(TE) == 1) {  // fp8: two K = 64 instructions per accumulator block and slab (128 bytes = 128 k)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      read_set<RY, RX>(f0, ya[2 * half] + so, xa[2 * half] + so);
+      read_set<RY, RX>(f1, ya[2 * half + 1] + so, xa[2 * half + 1] + so);
+      wait_lgkm<0>();
+#pragma unroll
+      for (int i = 0; i < RY; ++i)
+#pragma unroll
+        for (int j = 0; j < RX; ++j) mma_f8(acc[i][j], f0.x[j], f1.x[j], f0.y[i], f1.y[i]);
+    }
+    return;
+  }
   read_set<RY, RX>(f0, ya[0] + so, xa[0] + so);
   read_set<RY, RX>(f1, ya[1] + so, xa[1] + so);
   wait_lgkm<RY + RX>();
@@ -596,6 +621,10 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
   if (p.split_k > 1) {
     OSUD_CHECK_ARG(epi == EPI_NONE_F32 || epi == EPI_NONE_TE, "gemm: split-K needs a plain epilogue");
     OSUD_CHECK_ARG((size_t)p.K * esz / SLAB >= (size_t)p.split_k, "gemm: K=%d does not split %d ways", p.K, p.split_k);
+  }
+  if (prec == 2) {  // experimental: fp8 e4m3 operands, fp32 output (op-level only; unit scales)
+    OSUD_CHECK_ARG(epi == EPI_NONE_F32 || epi == EPI_BIAS_F32, "gemm: the fp8 operand type has fp32-output epilogues only");
+    return epi == EPI_NONE_F32 ? launch_t<fp8_t, EPI_NONE_F32>(p, st) : launch_t<fp8_t, EPI_BIAS_F32>(p, st);
   }
   return prec == OSUD_PREC_BF16 ? launch_e<bf16_t>(epi, p, st) : launch_e<float>(epi, p, st);
 }
