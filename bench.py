@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--mode", choices=["both", "sample", "train"], default=os.environ.get("OSUD_BENCH_MODE", "both"))
     ap.add_argument("--batch", type=int, default=256, help="training windows per GPU")
     ap.add_argument("--sample-steps", type=int, default=None, help="timed sampling steps in mode both (default 1000)")
-    ap.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--precision", choices=["bf16", "fp32", "fp8"], default="bf16")
     ap.add_argument("--maps", type=int, default=64, help="beatmap windows per GPU (CFG doubles the batch)")
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--model", default="DiT-B")
@@ -237,7 +237,7 @@ def bench_train(args, world, rank, dev):
         "metric": f"{args.model} seq{args.seq_len} train tokens/sec (whole job; per-GPU = value / n_gpus)", "value": round(tokens_per_s, 1),
         "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
+        "dtype": {"bf16": "bf16", "fp32": "f32", "fp8": "fp8(e4m3 GEMM operands)+bf16"}[args.precision], "data": "synthetic",
         "config": {"workload": f"train.py step: {args.model} seq-len {T}, per-GPU batch {B} synthetic windows (global {B * world}), "
                                f"L1+vb loss, AdamW lr 1e-4, EMA 0.9999, label dropout 0.2, squaredcos_cap_v2 1000 steps",
                    "per_gpu_batch": B, "global_batch": B * world, "seq_len": T,
@@ -303,7 +303,7 @@ def bench_sample(args, world, rank, dev):
         "metric": f"1000-step CFG sample steps/sec ({args.model} seq{args.seq_len})", "value": round(world * steps_per_s, 3),
         "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.precision if args.precision == "bf16" else "f32", "data": "synthetic",
+        "dtype": {"bf16": "bf16", "fp32": "f32", "fp8": "fp8(e4m3 GEMM operands)+bf16"}[args.precision], "data": "synthetic",
         "config": {"workload": f"sample.py path: {args.model} seq-len {T}, {n} synthetic beatmap windows x2 (CFG) per GPU, "
                                f"cfg-scale 4.0, 1000-step squaredcos schedule, steps t=999..{999 - K + 1}",
                    "rows_per_gpu": 2 * n, "seq_len": T, "sharding": "rows per rank, no collective"},

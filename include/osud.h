@@ -47,6 +47,8 @@ extern "C" {
 /* arithmetic tiers */
 #define OSUD_PREC_BF16 0 /* fast tier: bf16 MFMA operands, fp32 accumulate / residual / LN / softmax */
 #define OSUD_PREC_F32 1  /* parity tier: exact-f32 MFMA (v_mfma_f32_32x32x2_f32), fp32 everywhere */
+#define OSUD_PREC_FP8 2  /* inference only: the bf16 tier with the four big per-block GEMMs on OCP e4m3 operands
+                            (v_mfma_scale_f32_32x32x64_f8f6f4, per-output-channel weight scales, static activation scales) */
 
 typedef struct osud_dit osud_dit;
 typedef struct osud_sched osud_sched;

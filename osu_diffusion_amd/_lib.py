@@ -15,7 +15,8 @@ LIB_PATH = os.environ.get("OSUD_LIB", os.path.join(_HERE, "libosud.so"))
 OK, ERR_ARG, ERR_HIP, ERR_STATE, ERR_UNSUPPORTED = 0, 1, 2, 3, 4
 PREC_BF16, PREC_F32 = 0, 1
 SAMPLER_P, SAMPLER_DDIM = 0, 1
-PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32}
+PREC_FP8 = 2  # inference only: bf16 tier with e4m3 operands in the four big per-block GEMMs
+PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32, "fp8": PREC_FP8}
 
 # gemm epilogue codes (csrc/gemm.h)
 EPI_BIAS_F32, EPI_BIAS_TE, EPI_BIAS_SILU_TE, EPI_ROWBIAS_TE, EPI_BIAS_GELU_TE, EPI_GATE_RES = range(6)

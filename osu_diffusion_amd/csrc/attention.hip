@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
                                                         const uint8_t* __restrict__ mask, bf16_t* __restrict__ out,
                                                         float* __restrict__ lse, int T, int Tp, int Mp, int D,
                                                         int ld_qk, float c1 /* scale*log2(e) */,
-                                                        const uint8_t* __restrict__ kb_class) {
+                                                        const uint8_t* __restrict__ kb_class, float fp8_scale) {
   using TL = AttnTile<HDP>;
   constexpr int KS = HDP / 16, DT = HDP / 32, CPR = TL::CPR;
   __shared__ __attribute__((aligned(16))) char Ks[64 * TL::RS];
@@ -180,14 +180,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
   if (q < Tp) {
     if (lse != nullptr && fhalf == 0)  // log2-domain logsumexp of the scaled scores, for the backward pass
       lse[((size_t)n * gridDim.y + h) * Tp + q] = m_run + __builtin_amdgcn_logf(l_run);
-    const float inv = 1.0f / l_run;
+    const float inv = (fp8_scale > 0.f ? fp8_scale : 1.0f) / l_run;
     bf16_t* orow = out + ((size_t)n * Tp + q) * D + h * HD;
+    fp8_t* orow8 = reinterpret_cast<fp8_t*>(out) + ((size_t)n * Tp + q) * D + h * HD;  // fp8 tier: e4m3 operand of out_proj
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int d = dt * 32 + 8 * g + 4 * fhalf;
-        if (d < HD) store4(orow + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        if (d < HD) {
+          if (fp8_scale > 0.f) store4(orow8 + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+          else store4(orow + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        }
       }
   }
 }
@@ -269,7 +273,7 @@ int launch_mask_tiles(const uint8_t* mask, int T, int Tp, uint8_t* kb_class, hip
 }
 
 int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, void* out, float* lse, int N, int T, int Tp,
-                     int Mp, int heads, int head_dim, hipStream_t st, const uint8_t* kb_class) {
+                     int Mp, int heads, int head_dim, hipStream_t st, const uint8_t* kb_class, float fp8_scale) {
   OSUD_CHECK_ARG(N > 0 && T > 0 && Tp >= T && Tp % 64 == 0 && Mp >= N * Tp, "attention: bad sizes N=%d T=%d Tp=%d Mp=%d", N,
                  T, Tp, Mp);
   const int D = heads * head_dim;
@@ -283,10 +287,10 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
     dim3 grid((Tp + 127) / 128, heads, N);
     if (head_dim == 64)
       hipLaunchKernelGGL((attn_bf16_kernel<64, 64>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
-                         Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr);
+                         Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr, fp8_scale);
     else
       hipLaunchKernelGGL((attn_bf16_kernel<72, 96>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
-                         Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr);
+                         Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr, fp8_scale);
   } else {
     dim3 grid(Tp / 64, heads, N);
     if (head_dim == 64)

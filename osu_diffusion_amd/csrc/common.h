@@ -98,8 +98,29 @@ __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
   v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
   v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
 }
-__device__ __forceinline__ void store8(fp8_t*, const float (&)[8]) {}  // fp8 is an input-only type here
-__device__ __forceinline__ void load8(const fp8_t*, float (&v)[8]) {
+// fp32 -> OCP e4m3 (hardware v_cvt_pk_fp8_f32, round-to-nearest-even), saturating at the format's +-448
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+  a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
+  c = fminf(fmaxf(c, -448.f), 448.f); d = fminf(fmaxf(d, -448.f), 448.f);
+  int r = 0;
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, r, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (uint32_t)r;
+}
+__device__ __forceinline__ void store8(fp8_t* p, const float (&v)[8]) {
+  uint2 u;
+  u.x = pack_fp8x4(v[0], v[1], v[2], v[3]);
+  u.y = pack_fp8x4(v[4], v[5], v[6], v[7]);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+__device__ __forceinline__ void store4(fp8_t* p, float a, float b, float c, float d) {
+  *reinterpret_cast<uint32_t*>(p) = pack_fp8x4(a, b, c, d);
+}
+__device__ __forceinline__ void store2(fp8_t* p, float a, float b) {
+  *reinterpret_cast<uint16_t*>(p) = (uint16_t)(pack_fp8x4(a, b, 0.f, 0.f) & 0xffffu);
+}
+__device__ __forceinline__ void load2(const fp8_t*, float& a, float& b) { a = b = 0.f; }  // never read back
+__device__ __forceinline__ void load8(const fp8_t*, float (&v)[8]) {  // fp8 tensors are never epilogue operands
 #pragma unroll
   for (int i = 0; i < 8; ++i) v[i] = 0.f;
 }

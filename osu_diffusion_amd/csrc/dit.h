@@ -24,6 +24,9 @@ struct BlockWeights {
   // TE, [out][in].  w_qkv is the packed in_proj ([Wq;Wk;Wv], 3D x D).
   void *w_qkv = nullptr, *w_o = nullptr, *w1 = nullptr, *w2 = nullptr;
   float *b_qkv = nullptr, *b_o = nullptr, *b1 = nullptr, *b2 = nullptr;
+  // fp8 tier: e4m3 copies of the four big weights + per-output-channel de-quantisation factors (incl. the activation scale)
+  void *w8_qkv = nullptr, *w8_o = nullptr, *w8_1 = nullptr, *w8_2 = nullptr;
+  float *dq_qkv = nullptr, *dq_o = nullptr, *dq_1 = nullptr, *dq_2 = nullptr;
   // transposed copies ([in][out]) for the data-gradient products (training only)
   void *w_qkv_t = nullptr, *w_o_t = nullptr, *w1_t = nullptr, *w2_t = nullptr;
 };
@@ -65,6 +68,7 @@ struct osud_dit {
   int D = 0, L = 0, H = 0, hd = 0, E = 0, C = 0, C2 = 0, Kp = 0, prec = 0, esz = 0, ada_cols = 0;
   int device = -1;
   bool training = false;
+  bool fp8 = false;  // OSUD_PREC_FP8: prec == BF16 everywhere except the e4m3 operands of qkv / out_proj / fc1 / fc2
 
   // weights
   void* w_e = nullptr;  float* b_e = nullptr;
@@ -95,6 +99,7 @@ struct osud_dit {
 
   // workspaces (reserve)
   int cap_N = 0, cap_T = 0, cap_Mp = 0, cap_Np = 0, cap_Tp = 0;
+  void *u8 = nullptr, *ao8 = nullptr, *g8 = nullptr;  // fp8 tier: e4m3 activations [Mp][D], [Mp][D], [Mp][4D]
   void *e0 = nullptr, *u = nullptr, *qk = nullptr /* [Mp][3D] q|k|v */, *ao = nullptr, *g = nullptr;
   float *h = nullptr, *tvec = nullptr, *bvec = nullptr, *ada = nullptr, *out_ws = nullptr;
   void *temb = nullptr, *th = nullptr, *sb = nullptr;
@@ -130,6 +135,18 @@ inline int gemm(osud_dit* m, int epi, const void* Y, int ldy, const void* X, int
   p.out = out; p.out2 = out2; p.ldo = ldo; p.bias = bias; p.gate = gate; p.ld_gate = ld_gate;
   p.rows_per_sample = Tp; p.n_samples = N; p.res = res; p.aux = aux;
   return launch_gemm(m->prec, epi, p, st);
+}
+
+// GEMM on e4m3 operands (fp8 tier): Y [My][K] and X [Nx][K] are fp8, `dequant` the per-column factors, out per epilogue
+inline int gemm8(osud_dit* m, int epi, const void* Y, const void* X, int My, int Nx, int K, void* out, int ldo, const float* bias,
+                 const float* dequant, float out_scale, hipStream_t st, const float* gate = nullptr, int ld_gate = 0, int Tp = 0,
+                 int N = 0) {
+  GemmP p{};
+  p.Y = Y; p.X = X; p.ldy = K; p.ldx = K; p.My = My; p.Nx = Nx; p.K = K;
+  p.out = out; p.ldo = ldo; p.bias = bias; p.gate = gate; p.ld_gate = ld_gate;
+  p.rows_per_sample = Tp; p.n_samples = N; p.colscale = dequant; p.out_scale = out_scale;
+  (void)m;
+  return launch_gemm(OSUD_PREC_FP8, epi, p, st);
 }
 
 int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float* o, const float* c, const int64_t* y,

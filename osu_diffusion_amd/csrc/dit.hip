@@ -54,6 +54,11 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
     OSUD_TRY(dev_alloc(W, &m->qk, (size_t)Mp * 3 * D * es));
     OSUD_TRY(dev_alloc(W, &m->ao, (size_t)Mp * D * es));
     OSUD_TRY(dev_alloc(W, &m->g, (size_t)Mp * 4 * D * es));
+    if (m->fp8) {
+      OSUD_TRY(dev_alloc(W, &m->u8, (size_t)Mp * D));
+      OSUD_TRY(dev_alloc(W, &m->ao8, (size_t)Mp * D));
+      OSUD_TRY(dev_alloc(W, &m->g8, (size_t)Mp * 4 * D));
+    }
   } else {
     m->saved.resize((size_t)m->L + 1);
     for (int l = 0; l <= m->L; ++l) {
@@ -111,6 +116,10 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
   return OSUD_OK;
 }
 
+// fp8 tier: static activation scales (value * scale -> e4m3, saturating at +-448).  LayerNorm outputs are O(1) with a few
+// sigma of headroom after modulation, attention outputs are convex combinations of V rows, GELU outputs are >= -0.17.
+constexpr float kF8ScaleLN = 8.0f, kF8ScaleAttn = 16.0f, kF8ScaleGelu = 8.0f;
+
 int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float* o, const float* c, const int64_t* y,
                      const uint8_t* mask, int N, int T, float cfg_scale, bool combine_cfg, float* out, bool save,
                      hipStream_t st) {
@@ -129,6 +138,10 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
   const bool cfg = cfg_scale >= 0.f;
   OSUD_CHECK_ARG(!cfg || N % 2 == 0, "forward_with_cfg: batch must be [cond; uncond] halves, got N=%d", N);
   OSUD_CHECK_ARG(!save || m->training, "forward(save): workspaces were not reserved for training");
+  if (m->fp8 && (save || m->training)) {
+    set_error("the fp8 tier is inference only (train in bf16 or fp32)");
+    return OSUD_ERR_UNSUPPORTED;
+  }
   OSUD_TRY(dit_ensure_ws(m, N, T, m->training));
 
   const int D = m->D, L = m->L, Tp = round_up(T, 64), M = N * Tp, Mp = round_up(M, 128), Np = round_up(N, 128);
@@ -167,12 +180,27 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
     float* h_in = sv ? sv->h_in : h;    // residual stream entering the block (training keeps every version)
     float* h_mid = sv ? sv->h_mid : h;
     const int base = l * 6 * D;
-    OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base, base + D, u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st, pend,
-                           pend_gate, pend ? h_in : nullptr));
-    // packed in_proj: one 3D-wide product, Q | K | V row-major (the attention kernels transpose V on the LDS read)
     const int qcols = 3 * D;
-    OSUD_TRY(gemm(m, EPI_BIAS_TE, u1, D, w.w_qkv, D, Mp, qcols, D, qk, qcols, w.b_qkv, st));
-    OSUD_TRY(launch_attention(prec, qk, qcols, mask, ao, sv ? sv->lse : nullptr, N, T, Tp, Mp, m->H, m->hd, st, m->kb_class));
+    if (!sv && m->fp8) {
+      OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base, base + D, m->u8, nullptr, Mp, Tp, N, D, st, nullptr, 0, nullptr, kF8ScaleLN));
+      OSUD_TRY(gemm8(m, EPI_BIAS_TE, m->u8, w.w8_qkv, Mp, qcols, D, qk, qcols, w.b_qkv, w.dq_qkv, 0.f, st));
+      OSUD_TRY(launch_attention(prec, qk, qcols, mask, m->ao8, nullptr, N, T, Tp, Mp, m->H, m->hd, st, m->kb_class, kF8ScaleAttn));
+    } else {
+      OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base, base + D, u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st, pend,
+                             pend_gate, pend ? h_in : nullptr));
+      // packed in_proj: one 3D-wide product, Q | K | V row-major (the attention kernels transpose V on the LDS read)
+      OSUD_TRY(gemm(m, EPI_BIAS_TE, u1, D, w.w_qkv, D, Mp, qcols, D, qk, qcols, w.b_qkv, st));
+      OSUD_TRY(launch_attention(prec, qk, qcols, mask, ao, sv ? sv->lse : nullptr, N, T, Tp, Mp, m->H, m->hd, st, m->kb_class));
+    }
+    if (!sv && m->fp8) {
+      // the four big GEMMs of the block on e4m3 operands (this block's LN1 / qkv / attention were emitted above in fp8 form)
+      OSUD_TRY(gemm8(m, EPI_GATE_RES, m->ao8, w.w8_o, Mp, D, D, h, D, w.b_o, w.dq_o, 0.f, st, m->ada + base + 2 * D, AC, Tp, N));
+      OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base + 3 * D, base + 4 * D, m->u8, nullptr, Mp, Tp, N, D, st, nullptr, 0, nullptr,
+                             kF8ScaleLN));
+      OSUD_TRY(gemm8(m, EPI_BIAS_GELU_TE, m->u8, w.w8_1, Mp, 4 * D, D, m->g8, 4 * D, w.b1, w.dq_1, kF8ScaleGelu, st));
+      OSUD_TRY(gemm8(m, EPI_GATE_RES, m->g8, w.w8_2, Mp, D, 4 * D, h, D, w.b2, w.dq_2, 0.f, st, m->ada + base + 5 * D, AC, Tp, N));
+      continue;
+    }
     if (!sv) {
       OSUD_TRY(gemm(m, EPI_GATE_RES, ao, D, w.w_o, D, Mp, D, D, h, D, w.b_o, st, m->ada + base + 2 * D, AC, Tp, N));
       OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base + 3 * D, base + 4 * D, u2, nullptr, Mp, Tp, N, D, st));
@@ -231,8 +259,8 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
                  cfg->heads, cfg->hidden);
   OSUD_CHECK_ARG(cfg->depth > 0 && cfg->context > 0 && cfg->in_channels == 2 && cfg->table_rows > 0,
                  "dit_create: bad depth/context/in_channels/table_rows");
-  OSUD_CHECK_ARG(cfg->precision == OSUD_PREC_BF16 || cfg->precision == OSUD_PREC_F32, "dit_create: unknown precision %d",
-                 cfg->precision);
+  OSUD_CHECK_ARG(cfg->precision == OSUD_PREC_BF16 || cfg->precision == OSUD_PREC_F32 || cfg->precision == OSUD_PREC_FP8,
+                 "dit_create: unknown precision %d", cfg->precision);
   const int hd = cfg->hidden / cfg->heads;
   if (hd != 64 && hd != 72) {
     set_error("dit_create: head_dim %d not built (64, 72)", hd);
@@ -242,7 +270,9 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   m->cfg = *cfg;
   m->D = cfg->hidden; m->L = cfg->depth; m->H = cfg->heads; m->hd = hd; m->E = cfg->context;
   m->C = cfg->in_channels; m->C2 = cfg->learn_sigma ? 2 * cfg->in_channels : cfg->in_channels;
-  m->prec = cfg->precision; m->esz = (int)elem_size(cfg->precision);
+  m->fp8 = cfg->precision == OSUD_PREC_FP8;
+  m->prec = m->fp8 ? OSUD_PREC_BF16 : cfg->precision;
+  m->esz = (int)elem_size(m->prec);
   m->Kp = round_up(cfg->in_channels * 128 + 128 + cfg->context, 128);  // 528 -> 640
   m->ada_cols = 6 * m->D * m->L + 2 * m->D;
   if (hipGetDevice(&m->device) != hipSuccess) {
@@ -265,6 +295,12 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
     A(&b.w_o, D * D * es);      A(&b.b_o, D * 4);
     A(&b.w1, 4 * D * D * es);   A(&b.b1, 4 * D * 4);
     A(&b.w2, 4 * D * D * es);   A(&b.b2, D * 4);
+    if (m->fp8) {
+      A(&b.w8_qkv, 3 * D * D); A(&b.dq_qkv, 3 * D * 4);
+      A(&b.w8_o, D * D);       A(&b.dq_o, D * 4);
+      A(&b.w8_1, 4 * D * D);   A(&b.dq_1, 4 * D * 4);
+      A(&b.w8_2, 4 * D * D);   A(&b.dq_2, D * 4);
+    }
   }
   if (rc == OSUD_OK && hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking) != hipSuccess) rc = OSUD_ERR_HIP;
   if (rc != OSUD_OK) {
@@ -363,14 +399,24 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
     if (name == "attn.in_proj_weight") {
       SHAPE(3 * D, D);  // rows [Wq; Wk; Wv]
       rc = convert_w(m, src, b.w_qkv, 3 * D * D, st);
+      if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)(3 * D), (int)D, b.w8_qkv, b.dq_qkv, kF8ScaleLN, st);
     } else if (name == "attn.in_proj_bias") {
       SHAPE(3 * D);
       rc = upload_f32(m, &b.b_qkv, src, 3 * D, st);
-    } else if (name == "attn.out_proj.weight") { SHAPE(D, D); rc = convert_w(m, src, b.w_o, D * D, st);
+    } else if (name == "attn.out_proj.weight") {
+      SHAPE(D, D);
+      rc = convert_w(m, src, b.w_o, D * D, st);
+      if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)D, (int)D, b.w8_o, b.dq_o, kF8ScaleAttn, st);
     } else if (name == "attn.out_proj.bias") { SHAPE(D); rc = upload_f32(m, &b.b_o, src, D, st);
-    } else if (name == "mlp.fc1.weight") { SHAPE(4 * D, D); rc = convert_w(m, src, b.w1, 4 * D * D, st);
+    } else if (name == "mlp.fc1.weight") {
+      SHAPE(4 * D, D);
+      rc = convert_w(m, src, b.w1, 4 * D * D, st);
+      if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)(4 * D), (int)D, b.w8_1, b.dq_1, kF8ScaleLN, st);
     } else if (name == "mlp.fc1.bias") { SHAPE(4 * D); rc = upload_f32(m, &b.b1, src, 4 * D, st);
-    } else if (name == "mlp.fc2.weight") { SHAPE(D, 4 * D); rc = convert_w(m, src, b.w2, 4 * D * D, st);
+    } else if (name == "mlp.fc2.weight") {
+      SHAPE(D, 4 * D);
+      rc = convert_w(m, src, b.w2, 4 * D * D, st);
+      if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)D, (int)(4 * D), b.w8_2, b.dq_2, kF8ScaleGelu, st);
     } else if (name == "mlp.fc2.bias") { SHAPE(D); rc = upload_f32(m, &b.b2, src, D, st);
     } else if (name == "adaLN_modulation.1.weight") {
       SHAPE(6 * D, D);

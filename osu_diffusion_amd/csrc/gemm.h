@@ -49,6 +49,9 @@ struct GemmP {
   int n_samples;
   const void* aux;   // TE [My][ldo] (EPI_GELUGRAD_TE: saved GELU derivative)
   const float* res;  // EPI_GATE_RES: residual input [My][ldo]; nullptr = update `out` in place
+  const float* colscale;  // fp8 operands only: out = epilogue(acc * colscale[x]) -- the product of the activation and per-output-channel
+                          // weight de-quantisation factors
+  float out_scale;        // fp8 OUTPUT (EPI_BIAS_GELU_TE with fp8 operands): the value is multiplied by this before quantisation
   int split_k;       // > 1: blockIdx.y walks K in split_k equal ranges, range s writes out + s * split_stride (elements)
   size_t split_stride;
   int tile_order;  // 0/1 = plain x-fastest runs per XCD (default), 2 = banded per XCD (fewer weight re-reads, not faster)

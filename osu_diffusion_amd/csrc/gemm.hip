@@ -3,6 +3,8 @@
 
 #include <stdlib.h>
 
+#include <type_traits>
+
 namespace osud {
 
 namespace {
@@ -199,7 +201,9 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
   using G = Geo<WY, WX, RY, RX>;
   constexpr int BN = G::BN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool FAST = sizeof(TE) == 2;
+  constexpr bool FAST = sizeof(TE) <= 2;
+  constexpr bool kF8 = sizeof(TE) == 1;  // fp8 operands: outputs are bf16 (EPI_BIAS_TE), fp8 (EPI_BIAS_GELU_TE) or fp32
+  using TO = typename std::conditional<kF8, typename std::conditional<EPI == EPI_BIAS_GELU_TE, fp8_t, bf16_t>::type, TE>::type;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wy = wave / WX, wx = wave % WX;
@@ -377,6 +381,15 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
                            EPI == EPI_BIAS_GELU_TE || EPI == EPI_GATE_RES;
     const int lrow = lane >> 2, lcol = 8 * (lane & 3);
     const int xw = tx * BN + wx * RX * 32 + lcol;  // + j*32
+    float csv[RX][8];
+    if (kF8) {
+#pragma unroll
+      for (int j = 0; j < RX; ++j) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csv[j][e] = 1.0f;
+        if (p.colscale != nullptr) load8(p.colscale + xw + j * 32, csv[j]);
+      }
+    }
     float bv[RX][8];
     if (kBias) {
 #pragma unroll
@@ -454,6 +467,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
         }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
+          if (kF8) v[e] *= csv[j][e];
           if (kBias) v[e] += bv[j][e];
           if (EPI == EPI_ROWBIAS_TE) v[e] += rb[q];
         }
@@ -465,33 +479,33 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
           for (int e = 0; e < 8; ++e) w[e] = rv[q][e] + v[e];
           store8(reinterpret_cast<float*>(p.out) + o, w);
         } else if (EPI == EPI_GATE_RES) {
-          if (p.out2) store8(reinterpret_cast<TE*>(p.out2) + o, v);  // branch output (training)
+          if (p.out2) store8(reinterpret_cast<TO*>(p.out2) + o, v);  // branch output (training)
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = rv[q][e] + gv[e] * v[e];
           store8(reinterpret_cast<float*>(p.out) + o, w);
         } else if (EPI == EPI_BIAS_SILU_TE) {
-          if (p.out2) store8(reinterpret_cast<TE*>(p.out2) + o, v);  // pre-activation (training)
+          if (p.out2) store8(reinterpret_cast<TO*>(p.out2) + o, v);  // pre-activation (training)
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = silu_t<FAST>(v[e]);
-          store8(reinterpret_cast<TE*>(p.out) + o, w);
+          store8(reinterpret_cast<TO*>(p.out) + o, w);
         } else if (EPI == EPI_BIAS_GELU_TE) {
           if (p.out2) {  // training: the DERIVATIVE goes out (same exp/rcp as the value), so that the backward epilogue
                          // is a plain multiply instead of two more quarter-rate transcendentals per element
             float dg[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) gelu_tanh_both_t<FAST>(v[e], w[e], dg[e]);
-            store8(reinterpret_cast<TE*>(p.out2) + o, dg);
+            store8(reinterpret_cast<TO*>(p.out2) + o, dg);
           } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] = gelu_tanh_t<FAST>(v[e]);
+            for (int e = 0; e < 8; ++e) w[e] = gelu_tanh_t<FAST>(v[e]) * (kF8 ? p.out_scale : 1.0f);
           }
-          store8(reinterpret_cast<TE*>(p.out) + o, w);
+          store8(reinterpret_cast<TO*>(p.out) + o, w);
         } else if (EPI == EPI_GELUGRAD_TE) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = v[e] * rv[q][e];
-          store8(reinterpret_cast<TE*>(p.out) + o, w);
+          store8(reinterpret_cast<TO*>(p.out) + o, w);
         } else {  // EPI_BIAS_TE, EPI_ROWBIAS_TE, EPI_NONE_TE
-          store8(reinterpret_cast<TE*>(p.out) + o, v);
+          store8(reinterpret_cast<TO*>(p.out) + o, v);
         }
       }
     }
@@ -622,9 +636,16 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
     OSUD_CHECK_ARG(epi == EPI_NONE_F32 || epi == EPI_NONE_TE, "gemm: split-K needs a plain epilogue");
     OSUD_CHECK_ARG((size_t)p.K * esz / SLAB >= (size_t)p.split_k, "gemm: K=%d does not split %d ways", p.K, p.split_k);
   }
-  if (prec == 2) {  // experimental: fp8 e4m3 operands, fp32 output (op-level only; unit scales)
-    OSUD_CHECK_ARG(epi == EPI_NONE_F32 || epi == EPI_BIAS_F32, "gemm: the fp8 operand type has fp32-output epilogues only");
-    return epi == EPI_NONE_F32 ? launch_t<fp8_t, EPI_NONE_F32>(p, st) : launch_t<fp8_t, EPI_BIAS_F32>(p, st);
+  if (prec == 2) {  // fp8 e4m3 operands (inference): fp32, bf16 (EPI_BIAS_TE) or fp8 (EPI_BIAS_GELU_TE) outputs
+    switch (epi) {
+      case EPI_NONE_F32: return launch_t<fp8_t, EPI_NONE_F32>(p, st);
+      case EPI_BIAS_F32: return launch_t<fp8_t, EPI_BIAS_F32>(p, st);
+      case EPI_BIAS_TE: return launch_t<fp8_t, EPI_BIAS_TE>(p, st);
+      case EPI_BIAS_GELU_TE: return launch_t<fp8_t, EPI_BIAS_GELU_TE>(p, st);
+      case EPI_GATE_RES: return launch_t<fp8_t, EPI_GATE_RES>(p, st);
+    }
+    set_error("gemm: epilogue %d is not built for fp8 operands", epi);
+    return OSUD_ERR_UNSUPPORTED;
   }
   return prec == OSUD_PREC_BF16 ? launch_e<bf16_t>(epi, p, st) : launch_e<float>(epi, p, st);
 }

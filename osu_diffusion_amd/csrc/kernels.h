@@ -13,7 +13,9 @@ int launch_cond(int prec, const float* tvec, const float* table, const int64_t* 
 // br != nullptr: the row is first updated to h + ada[n][off_gate..] * br (written to h_out if given, may be h itself)
 int launch_ln_mod(int prec, const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, void* out,
                   float* stats, int M, int Tp, int N, int D, hipStream_t st, const void* br = nullptr, int off_gate = 0,
-                  float* h_out = nullptr);
+                  float* h_out = nullptr, float fp8_scale = 0.f /* > 0: out is e4m3, values multiplied by this */);
+// fp8 tier: per-output-channel e4m3 quantisation of a weight (rows x cols fp32) and its de-quantisation factors
+int launch_quantize_rows(const float* w, int rows, int cols, void* q, float* dequant, float act_scale, hipStream_t st);
 int launch_final(const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, const float* w,
                  const float* bias, float* out, float* u_save, float* stats, int N, int T, int Tp, int D, int C,
                  hipStream_t st, int prec = OSUD_PREC_F32, const void* br = nullptr, int off_gate = 0,
@@ -26,7 +28,8 @@ int launch_pack_rows(int prec, const float* src, int ld_src, int cols_src, void*
 // kb_class (optional, from launch_mask_tiles): class of every 64-query x 64-key tile of the mask (0 fully masked, 1 mixed,
 // 2 fully open): masked tiles are skipped, open tiles read no mask bytes
 int launch_attention(int prec, const void* qkv, int ld_qkv, const uint8_t* mask, void* out, float* lse, int N, int T, int Tp,
-                     int Mp, int heads, int head_dim, hipStream_t st, const uint8_t* kb_class = nullptr);
+                     int Mp, int heads, int head_dim, hipStream_t st, const uint8_t* kb_class = nullptr,
+                     float fp8_scale = 0.f /* > 0 (bf16 tier only): out is e4m3 [Mp][D], values multiplied by this */);
 int launch_mask_tiles(const uint8_t* mask, int T, int Tp, uint8_t* kb_class, hipStream_t st);
 // delta_ws: [N][heads][T] fp32 scratch, needed when the sequence of one head does not fit the LDS (streamed variant)
 int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* O, const float* lse, void* dqkv, int N,

@@ -111,7 +111,8 @@ __global__ void cond_kernel(const float* __restrict__ tvec, const float* __restr
 template <typename TE, int VPL>
 __global__ __launch_bounds__(256) void ln_mod_kernel(const float* h, const float* __restrict__ ada, int ld_ada,
                                                      int off_shift, int off_scale, TE* out, float* __restrict__ stats,
-                                                     int M, int Tp, int N, const TE* br, int off_gate, float* h_out) {
+                                                     int M, int Tp, int N, const TE* br, int off_gate, float* h_out,
+                                                     float out_scale) {
   constexpr int D = VPL * 64;
   const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
@@ -168,7 +169,8 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* h, const float
     const float2 h2 = *reinterpret_cast<const float2*>(sh + d);
     const float a = (v[2 * i] - mu) * rstd * (1.0f + s2.x) + h2.x;
     const float b = (v[2 * i + 1] - mu) * rstd * (1.0f + s2.y) + h2.y;
-    store2(orow + d, a, b);
+    if (sizeof(TE) == 1) store2(orow + d, a * out_scale, b * out_scale);  // fp8 operand of the next GEMM, statically scaled
+    else store2(orow + d, a, b);
   }
 }
 
@@ -282,7 +284,31 @@ __global__ void pack_rows_kernel(const float* __restrict__ src, int ld_src, int 
   }
 }
 
+// fp8 tier: one weight row (output channel) per block -> e4m3 with the row's own scale 448 / max|w|;
+// dequant[x] = max|w_x| / (448 * act_scale) is what the GEMM epilogue multiplies the accumulator with
+__global__ __launch_bounds__(256) void quantize_rows_kernel(const float* __restrict__ w, int cols, fp8_t* __restrict__ q,
+                                                            float* __restrict__ dequant, float act_scale) {
+  __shared__ float red[4];
+  const float* row = w + (size_t)blockIdx.x * cols;
+  float amax = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) amax = fmaxf(amax, fabsf(row[c]));
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float s = amax > 0.f ? 448.0f / amax : 1.0f;
+  for (int c = threadIdx.x * 4; c < cols; c += 1024) store4(q + (size_t)blockIdx.x * cols + c, row[c] * s, row[c + 1] * s, row[c + 2] * s, row[c + 3] * s);
+  if (threadIdx.x == 0) dequant[blockIdx.x] = 1.0f / (s * act_scale);
+}
+
 }  // namespace
+
+int launch_quantize_rows(const float* w, int rows, int cols, void* q, float* dequant, float act_scale, hipStream_t st) {
+  OSUD_CHECK_ARG(cols % 4 == 0, "quantize_rows: cols=%d must be a multiple of 4", cols);
+  hipLaunchKernelGGL(quantize_rows_kernel, dim3(rows), dim3(256), 0, st, w, cols, (fp8_t*)q, dequant, act_scale);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
 
 // ---------------------------------------------------------------------------------- launchers
 template <typename TE>
@@ -324,11 +350,11 @@ int launch_cond(int prec, const float* tvec, const float* table, const int64_t* 
 
 template <typename TE>
 static int ln_mod_t(const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, void* out, float* stats,
-                    int M, int Tp, int N, int D, hipStream_t st, const void* br, int off_gate, float* h_out) {
+                    int M, int Tp, int N, int D, hipStream_t st, const void* br, int off_gate, float* h_out, float out_scale = 1.0f) {
   const dim3 grid((M + 3) / 4), block(256);
 #define OSUD_LN(V)                                                                                                  \
   hipLaunchKernelGGL((ln_mod_kernel<TE, V>), grid, block, 0, st, h, ada, ld_ada, off_shift, off_scale, (TE*)out, \
-                     stats, M, Tp, N, (const TE*)br, off_gate, h_out)
+                     stats, M, Tp, N, (const TE*)br, off_gate, h_out, out_scale)
   switch (D) {
     case 128: OSUD_LN(2); break;
     case 384: OSUD_LN(6); break;
@@ -342,7 +368,10 @@ static int ln_mod_t(const float* h, const float* ada, int ld_ada, int off_shift,
   return OSUD_OK;
 }
 int launch_ln_mod(int prec, const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, void* out,
-                  float* stats, int M, int Tp, int N, int D, hipStream_t st, const void* br, int off_gate, float* h_out) {
+                  float* stats, int M, int Tp, int N, int D, hipStream_t st, const void* br, int off_gate, float* h_out,
+                  float fp8_scale) {
+  if (fp8_scale > 0.f)  // fp8 tier: the LayerNorm output is the e4m3 operand of the next GEMM
+    return ln_mod_t<fp8_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, br, off_gate, h_out, fp8_scale);
   return prec == OSUD_PREC_BF16
              ? ln_mod_t<bf16_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, br, off_gate, h_out)
              : ln_mod_t<float>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, br, off_gate, h_out);

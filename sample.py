@@ -123,7 +123,7 @@ if __name__ == "__main__":
     p.add_argument("--refine-ckpt", type=str, default=None)
     p.add_argument("--refine-iters", type=int, default=10)
     p.add_argument("--synthetic", type=int, default=0, metavar="T", help="use a synthetic T-token sequence")
-    p.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    p.add_argument("--precision", choices=["bf16", "fp32", "fp8"], default="bf16")
     p.add_argument("--sampler", choices=["p", "ddim"], default="p", help="ancestral p_sample loop (reference default) or DDIM")
     p.add_argument("--ddim-eta", type=float, default=0.0)
     a = p.parse_args()

@@ -1,0 +1,76 @@
+"""GPU (-m gpu): the fp8 tier (precision="fp8", inference only): the bf16 tier with the four big per-block GEMMs on OCP e4m3
+operands (unit-scale MX MFMA, per-output-channel weight scales, static activation scales).  It is a reduced-precision tier:
+the tests bound its deviation from the fp32 oracle (a few times the bf16 tier's), they do not claim parity."""
+import pytest
+import torch
+
+from oracle import dit_oracle as mo
+from osu_diffusion_amd import _lib
+from osu_diffusion_amd.diffusion import create_diffusion
+from osu_diffusion_amd.models import DiT
+from osu_diffusion_amd.synthetic import banded_attn_mask, synthetic_windows
+from osu_diffusion_amd.training import NativeTrainer
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build(shape, sd, precision):
+    m = DiT(depth=shape.depth, hidden_size=shape.hidden, num_heads=shape.heads, context_size=shape.context,
+            num_classes=shape.num_classes, class_dropout_prob=0.2, precision=precision)
+    m.load_state_dict(sd)
+    return m.to(DEV).eval()
+
+
+@pytest.mark.parametrize("hidden,heads,T_", [(384, 6, 128), (128, 2, 200), (1152, 16, 128)])
+def test_fp8_forward_stays_close_to_the_fp32_oracle(hidden, heads, T_):
+    shape = mo.DitShape(depth=3, hidden=hidden, heads=heads, num_classes=10)
+    sd = mo.seeded_state_dict(shape, 77)
+    (x, o, c), y = synthetic_windows(4, T_, 10, seed=5)
+    t = torch.tensor([999, 500, 30, 0])
+    mask = banded_attn_mask(T_, 128) if T_ > 128 else None
+    ref = mo.forward(sd, shape, x, t, o, c, y, attn_mask=mask)
+    errs = {}
+    for prec in ("bf16", "fp8"):
+        with torch.no_grad():
+            got = build(shape, sd, prec)(x.to(DEV), t.to(DEV), o.to(DEV), c.to(DEV), y.to(DEV),
+                                         attn_mask=None if mask is None else mask.to(DEV)).cpu()
+        assert torch.isfinite(got).all()
+        errs[prec] = float((got - ref).pow(2).mean().sqrt())
+    scale = float(ref.pow(2).mean().sqrt())
+    assert errs["fp8"] < 2e-2 * scale, (errs, scale)          # ~0.7 % rms measured
+    assert errs["fp8"] < 8 * errs["bf16"] + 1e-4, errs        # ~3x the bf16 tier's deviation
+
+
+def test_fp8_cfg_sampling_loop_tracks_the_bf16_tier():
+    """A short CFG-4 ancestral loop with identical start and per-step noise in the bf16 and fp8 tiers (well-posed weights,
+    see oracle.dit_oracle.seeded_state_dict): the final coordinates stay together."""
+    shape = mo.DitShape(depth=2, hidden=128, heads=2, num_classes=10)
+    sd = mo.seeded_state_dict(shape, 3)
+    (x0, o, c), y = synthetic_windows(2, 128, 10, seed=9)
+    o = torch.cat([o, o]).to(DEV); c = torch.cat([c, c]).to(DEV); y = torch.cat([y, torch.full((2,), 10)]).to(DEV)
+    d = create_diffusion("8", noise_schedule="squaredcos_cap_v2")
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(2, 2, 128, generator=g)
+    z = torch.cat([z, z]).to(DEV)
+    step_noise = torch.randn(8, 2, 2, 128, generator=g)
+    step_noise = torch.cat([step_noise, step_noise], 1).to(DEV)
+    outs = {}
+    for prec in ("bf16", "fp8"):
+        m = build(shape, sd, prec)
+        with torch.no_grad():
+            outs[prec] = d.p_sample_loop(m.forward_with_cfg, z.shape, z.clone(), clip_denoised=True,
+                                         model_kwargs=dict(o=o, c=c, y=y, cfg_scale=4.0), device=DEV, step_noise=step_noise).cpu()
+    assert torch.isfinite(outs["fp8"]).all()
+    diff = (outs["fp8"] - outs["bf16"]).abs()
+    stats = (float(diff.mean()), float(diff.max()))
+    assert stats[0] < 1e-2 and stats[1] < 0.25, stats  # e4m3 operands: a reduced-precision tier, not a parity tier
+
+
+def test_fp8_tier_is_inference_only():
+    shape = mo.DitShape(depth=2, hidden=128, heads=2, num_classes=10)
+    m = build(shape, mo.seeded_state_dict(shape, 3), "fp8").train()
+    tr = NativeTrainer(m, create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True))
+    (x, o, c), y = synthetic_windows(2, 128, 10, seed=1)
+    with pytest.raises(_lib.NativeError, match="inference only"):
+        tr.step(x, o, c, y)
