@@ -107,7 +107,7 @@ def test_configs():
         m = DiT_models[name](num_classes=4, context_size=144)
         assert (m.depth, m.hidden_size, m.num_heads) == (depth, hidden, heads)
     with pytest.raises(ValueError):
-        DiT(depth=1, hidden_size=128, num_heads=2, precision="fp8")
+        DiT(depth=1, hidden_size=128, num_heads=2, precision="int4")
 
 
 def test_no_cpu_fallback():
