@@ -2,26 +2,33 @@
 """Sample beatmap object coordinates with a pre-trained DiT — flag-compatible with the reference's
 sample.py (sample.py:208-232), running the native MI355X path.
 
-The reference turns a `.osu` file into a (19, T) sequence with the third-party `slider` parser
-and exports the result back to `.osu`; both are outside the accelerated path.  Here
-`--beatmap` accepts a `.pt`/`.npy` file holding that (19, T) float tensor (x, y, time_ms, 16 one-hot
-type rows — data_loading.py:32-39), or `--synthetic T` draws a synthetic one.  The sampled
-sequences are written as `results/<name>/result.pt` ((n, 19, T): sampled x,y + original features).
+`--beatmap` takes a `.osu` file like the reference (read by osu_diffusion_amd.beatmap — the reference's third-party
+`slider` parser is not needed) and writes `results/<id artist - title>/<id> result <style> <k>.osu` per variant
+(sample.py:114-130), or a `.pt`/`.npy` file holding the (19, T) sequence itself (x, y, time_ms, 16 one-hot type rows —
+data_loading.py:32-39); `--synthetic T` draws a synthetic one.  The sampled sequences are also saved as
+`results/<name>/result.pt` ((n, 19, T): sampled x, y in osu! pixels + the original features).  `--plot-time` trims the
+sequence as the reference does; the matplotlib plot / animation themselves are out of scope.
 """
 import argparse
+import logging
 import os
 import pickle
+import re
+from datetime import datetime
 
 import numpy as np
 import torch
 
+from osu_diffusion_amd.beatmap import Beatmap, beatmap_to_sequence
 from osu_diffusion_amd.diffusion import create_diffusion
+from osu_diffusion_amd.export import create_beatmap
 from osu_diffusion_amd.models import DiT_models, find_model
 from osu_diffusion_amd.synthetic import banded_attn_mask
 from osu_diffusion_amd.windows import split_and_process_sequence_no_augment as split_and_process_sequence  # sample.py:64
 
 feature_size = 19
 playfield_size = torch.tensor((512, 384))
+CLEAN_FILENAME_RX = re.compile(r"[/\\?%*:|\"<>\x7F\x00-\x1F]")
 
 
 def load_sequence(args):
@@ -33,14 +40,15 @@ def load_sequence(args):
         seq[1] = torch.rand(T, generator=g) * 384
         seq[2] = torch.cumsum(torch.randint(50, 601, (T,), generator=g).float(), 0)
         seq[3 + torch.randint(0, 16, (T,), generator=g), torch.arange(T)] = 1
-        return seq, f"synthetic-{T}"
+        return seq, f"synthetic-{T}", None
     path = args.beatmap
     if path.endswith(".osu"):
-        raise SystemExit("parsing .osu files needs the third-party `slider` package (reference data_loading.py:127-135), "
-                         "which is outside this build; pass the (19, T) sequence as .pt/.npy or use --synthetic T")
+        beatmap = Beatmap.from_path(path)
+        name = CLEAN_FILENAME_RX.sub("-", f"{beatmap.beatmap_id} {beatmap.artist} - {beatmap.title}")  # sample.py:48-49
+        return beatmap_to_sequence(beatmap), name, beatmap
     seq = torch.from_numpy(np.load(path)) if path.endswith(".npy") else torch.load(path)
     assert seq.shape[0] == feature_size, f"expected a ({feature_size}, T) sequence, got {tuple(seq.shape)}"
-    return seq.float(), os.path.splitext(os.path.basename(path))[0]
+    return seq.float(), os.path.splitext(os.path.basename(path))[0], None
 
 
 def main(args):
@@ -48,9 +56,13 @@ def main(args):
     torch.set_grad_enabled(False)
     assert torch.cuda.is_available(), "the native path needs an AMD GPU (there is no CPU fallback)"
     device = "cuda"
-    seq_no_embed, name = load_sequence(args)
+    seq_no_embed, name, beatmap = load_sequence(args)
     result_dir = os.path.join("results", name)
     os.makedirs(result_dir, exist_ok=True)
+    if args.plot_time is not None:  # sample.py:59-63: keep seq_len objects from that time on
+        start_index = int(torch.nonzero(seq_no_embed[2] >= args.plot_time)[0])
+        seq_no_embed = seq_no_embed[:, start_index:start_index + args.seq_len]
+        print(f"Sequence trimmed to length {seq_no_embed.shape[1]}")
     (seq_x, seq_o, seq_c), seq_len = split_and_process_sequence(seq_no_embed)
     seq_o = seq_o - seq_o[0]  # relative time (sample.py:65)
     print(f"seq len {seq_len}")
@@ -82,9 +94,27 @@ def main(args):
     y = torch.cat([y, torch.tensor([args.num_classes] * n, device=device)], 0)
     model_kwargs = dict(o=o, c=c, y=y, cfg_scale=args.cfg_scale, attn_mask=attn_mask)
 
-    def to_seq(samples):
+    def to_seq(samples):  # normalised positions + the source's time / type rows (sample.py:110-112)
         samples, _ = samples.chunk(2, dim=0)
-        return torch.concatenate([samples.cpu() * playfield_size.view(1, 2, 1), seq_no_embed[2:].repeat(n, 1, 1)], 1)
+        return torch.concatenate([samples.cpu(), seq_no_embed[2:].repeat(n, 1, 1)], 1)
+
+    def save_sequence(sampled_seq, iteration_number=None):  # sample.py:114-141
+        tail = "" if iteration_number is None else f" {iteration_number}"
+        pixels = sampled_seq.clone()
+        pixels[:, :2] *= playfield_size.view(1, 2, 1)
+        out = os.path.join(result_dir, f"result{tail.replace(' ', '_')}.pt")
+        torch.save(pixels, out)
+        print(f"saved {n} sampled sequence(s) to {out}")
+        if beatmap is None:
+            return
+        for idx, seq in enumerate(sampled_seq):
+            try:
+                new_beatmap = create_beatmap(seq, beatmap, f"Diffusion {args.style_id} {idx} {datetime.now()}{tail}")
+                path = os.path.join(result_dir, f"{beatmap.beatmap_id} result {args.style_id} {idx}{tail}.osu")
+                new_beatmap.write_path(path)
+                print(f"wrote {path}")
+            except Exception as e:  # the reference logs and carries on with the next variant
+                logging.error("Failed to create beatmap.", exc_info=e)
 
     if args.sampler == "ddim":  # gaussian_diffusion.py:653-733 (the reference ships the sampler but no CLI switch for it)
         samples = diffusion.ddim_sample_loop(model.forward_with_cfg, z.shape, z, clip_denoised=True, model_kwargs=model_kwargs,
@@ -92,15 +122,14 @@ def main(args):
     else:
         samples = diffusion.p_sample_loop(model.forward_with_cfg, z.shape, z, clip_denoised=True, model_kwargs=model_kwargs,
                                           progress=False, device=device)
+    save_sequence(to_seq(samples))
     if args.refine_ckpt is not None:  # sample.py:186-205: repeated t=0 steps with the refine model
         model.load_state_dict(find_model(args.refine_ckpt))
         for _ in range(args.refine_iters):
             t = torch.tensor([0] * samples.shape[0], device=device)
             samples = diffusion.p_sample(model.forward_with_cfg, samples, t, clip_denoised=True,
                                          model_kwargs=model_kwargs)["sample"]
-    out = os.path.join(result_dir, "result.pt")
-    torch.save(to_seq(samples), out)
-    print(f"saved {n} sampled sequence(s) to {out}")
+        save_sequence(to_seq(samples), args.refine_iters)
 
 
 if __name__ == "__main__":
@@ -116,7 +145,7 @@ if __name__ == "__main__":
     p.add_argument("--seq-len", type=int, default=128)
     p.add_argument("--use-amp", type=bool, default=True)  # kept for compatibility (unused by the reference too)
     p.add_argument("--style-id", type=int, default=None)
-    p.add_argument("--plot-time", type=float, default=None)   # plotting / animation: out of scope, accepted & ignored
+    p.add_argument("--plot-time", type=float, default=None)   # trims the sequence; the plot itself is out of scope
     p.add_argument("--plot-width", type=float, default=2000)
     p.add_argument("--num-variants", type=int, default=1)
     p.add_argument("--make-animation", type=bool, default=False)
@@ -127,5 +156,5 @@ if __name__ == "__main__":
     p.add_argument("--sampler", choices=["p", "ddim"], default="p", help="ancestral p_sample loop (reference default) or DDIM")
     p.add_argument("--ddim-eta", type=float, default=0.0)
     a = p.parse_args()
-    assert a.beatmap or a.synthetic, "--beatmap <seq.pt|seq.npy> or --synthetic T"
+    assert a.beatmap or a.synthetic, "--beatmap <map.osu|seq.pt|seq.npy> or --synthetic T"
     main(a)

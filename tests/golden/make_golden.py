@@ -346,13 +346,91 @@ def g9_windows():
     save("g9_windows", seq3=seq, dist3=ref_dl.calc_distances(seq.clone()), x3=rx, o3=ro, c3=rc, **cases)
 
 
+def g10_curves():
+    """Slider geometry of the reference's export step (export/path_approximator.py, export/slider_path.py: numpy only,
+    importable without `slider`) vs osu_diffusion_amd.curves on the same control points."""
+    import export.slider_path as ref_sp  # noqa: E402  (reference)
+    from export.path_approximator import approximate_bezier, approximate_catmull, approximate_circular_arc
+    from osu_diffusion_amd import curves as C
+    print("G10 curves: flattened slider paths, arc-length queries")
+    rng = np.random.default_rng(77)
+    cases = []
+    # hand-made: the reference's own demo path, red anchors, degenerate arcs, single / double points
+    cases.append(("Bezier", 100 * np.array([[0, 0], [1, 1], [1, -1], [2, 0], [2, 0], [3, -1], [2, -2]], dtype=float), None))
+    cases.append(("Bezier", np.array([[100, 100]], dtype=float), None))
+    cases.append(("Bezier", np.array([[100, 100], [200, 150]], dtype=float), 60.0))
+    cases.append(("Bezier", np.array([[100, 100], [200, 150]], dtype=float), 200.0))
+    cases.append(("Linear", np.array([[10, 10], [110, 10], [110, 210], [50, 300]], dtype=float), 250.0))
+    cases.append(("PerfectCurve", np.array([[100, 100], [150, 50], [200, 100]], dtype=float), None))
+    cases.append(("PerfectCurve", np.array([[100, 100], [150, 50], [200, 100]], dtype=float), 120.0))
+    cases.append(("PerfectCurve", np.array([[100, 100], [150, 160], [200, 100]], dtype=float), 400.0))
+    cases.append(("PerfectCurve", np.array([[100, 100], [150, 100], [200, 100]], dtype=float), None))      # collinear -> bezier
+    cases.append(("PerfectCurve", np.array([[100, 100], [150, 50], [200, 100], [250, 80]], dtype=float), None))  # 4 points -> bezier
+    cases.append(("Catmull", np.array([[50, 50], [120, 200], [260, 90], [400, 300]], dtype=float), None))
+    cases.append(("Catmull", np.array([[50, 50], [120, 200]], dtype=float), 100.0))
+    for k in range(24):  # random: integer (as in .osu files) and fractional control points
+        n = int(rng.integers(2, 9))
+        pts = rng.uniform(0, 512, (n, 2)) * np.array([1.0, 0.75])
+        if k % 2 == 0:
+            pts = np.round(pts)
+        kind = ("Bezier", "Catmull", "PerfectCurve", "Linear")[k % 4]
+        if kind == "PerfectCurve":
+            pts = pts[:3] if len(pts) >= 3 else np.vstack([pts, pts[-1:] + [[30.0, 40.0]]])
+        if kind == "Bezier" and n >= 5 and k % 3 == 0:
+            pts[2] = pts[3]  # a red anchor
+        want = None if k % 3 == 0 else float(rng.uniform(20, 600))
+        cases.append((kind, pts, want))
+    out = {"count": len(cases)}
+    progresses = np.array([0.0, 0.1, 0.3333, 0.5, 0.77, 1.0])
+    for i, (kind, pts, want) in enumerate(cases):
+        ref = ref_sp.SliderPath(kind, pts.copy(), want)
+        mine = C.SliderPath(kind, pts.copy(), want)
+        rcum = np.asarray(ref.cumulative_length, dtype=float)
+        rpath = np.vstack(ref.calculated_path)[:len(rcum)] if len(ref.calculated_path) else np.zeros((0, 2))
+        tol = 1e-9 if kind == "PerfectCurve" else 0.0
+        assert mine.calculated_path.shape == rpath.shape, (i, kind, mine.calculated_path.shape, rpath.shape)
+        assert np.abs(mine.calculated_path - rpath).max(initial=0) <= tol, (i, kind)
+        assert np.abs(mine.cumulative_length - rcum).max() <= tol * 100, (i, kind)
+        rpos = np.stack([ref.position_at(p) for p in progresses])
+        mpos = np.stack([mine.position_at(p) for p in progresses])
+        assert np.abs(rpos - mpos).max() <= tol * 100, (i, kind)
+        target = rpos[3] + np.array([3.0, -2.0])
+        # position_to_progress lives in export/create_beatmap.py, which imports `slider`: restated inline for the fixture
+        # from its text (create_beatmap.py:156-170) on the REFERENCE path object
+        t = 1
+        for _ in range(100):
+            g = np.linalg.norm(ref.position_at(t) - target) - np.linalg.norm(ref.position_at(t - 1e-4) - target)
+            t -= g
+            if g == 0 or t < 0 or t > 1:
+                break
+        rprog = float(np.clip(t, 0, 1))
+        assert abs(C.position_to_progress(mine, target) - rprog) <= 1e-9, (i, kind)
+        sub_r = []
+        ref.get_path_to_progress(sub_r, 0.2, 0.9)
+        sub_m = mine.path_to_progress(0.2, 0.9)
+        assert np.abs(np.vstack(sub_r) - sub_m).max() <= tol * 100, (i, kind)
+        out.update({f"{i}:kind": kind, f"{i}:points": pts, f"{i}:want": np.nan if want is None else want,
+                    f"{i}:path": rpath, f"{i}:cum": rcum, f"{i}:pos": rpos, f"{i}:target": target, f"{i}:progress": rprog,
+                    f"{i}:sub": np.vstack(sub_r)})
+    # the flatteners on their own
+    bez = rng.uniform(0, 400, (6, 2))
+    assert np.array_equal(C.flatten_bezier(bez), approximate_bezier(bez))
+    cat = np.round(rng.uniform(0, 400, (5, 2)))
+    ref_cat = np.vstack(approximate_catmull(cat))
+    keep = np.concatenate([[True], (ref_cat[1:] != ref_cat[:-1]).any(1)])
+    assert np.array_equal(C.flatten_catmull(cat)[np.concatenate([[True], (C.flatten_catmull(cat)[1:] != C.flatten_catmull(cat)[:-1]).any(1)])],
+                          ref_cat[keep])
+    arc = np.array([[0.0, 0.0], [30.0, 40.0], [90.0, 10.0]])
+    assert np.abs(C.flatten_arc(arc) - np.vstack(approximate_circular_arc(arc))).max() <= 1e-9
+    print(f"  {len(cases)} slider paths identical to the reference (arcs to 1e-9 px)")
+    out.update(bez_in=bez, bez_out=approximate_bezier(bez), progresses=progresses)
+    save("g10_curves", **out)
+
+
 if __name__ == "__main__":
-    g1_schedules()
-    g2_embeddings()
-    g3_forward()
-    g5_step()
-    g6_loop()
-    g7_training()
-    g9_init_and_keys()
-    g9_windows()
+    steps = [g1_schedules, g2_embeddings, g3_forward, g5_step, g6_loop, g7_training, g9_init_and_keys, g9_windows, g10_curves]
+    only = set(sys.argv[1:])  # e.g. `make_golden.py g10_curves` regenerates one family
+    for fn in steps:
+        if not only or fn.__name__ in only:
+            fn()
     print("all golden fixtures written; oracle pinned against the reference")

@@ -4,8 +4,9 @@ per GPU (`torchrun --nproc-per-node=G train.py ...`), running the native MI355X 
 (osu_diffusion_amd.training.NativeTrainer) with ONE RCCL all-reduce per step on a flat fp32
 gradient arena instead of DDP's bucketed reducer.
 
-Real `.osu` datasets need the third-party `slider` parser (out of scope); `--synthetic`
-trains on synthetic windows with the reference's tensor contract, sharded per rank like train.py:165-170.
+`--data-path <root>` streams windows from `<root>/TrackNNNNN/beatmaps/*.osu` exactly like the reference's loader
+(tracks split per rank, train.py:165-170, then per DataLoader worker; `.osu` files read by osu_diffusion_amd.beatmap — the
+third-party `slider` parser is not needed); `--synthetic` trains on synthetic windows with the same tensor contract.
 """
 import argparse
 import logging
@@ -16,6 +17,7 @@ from time import time
 import torch
 import torch.distributed as dist
 
+from osu_diffusion_amd.beatmap import open_beatmap_sequence, track_catalogue
 from osu_diffusion_amd.diffusion import create_diffusion
 from osu_diffusion_amd.models import DiT_models
 from osu_diffusion_amd.synthetic import synthetic_windows
@@ -75,9 +77,16 @@ def main(args):
         logger.info(f"Restored from checkpoint at {args.ckpt}")
 
     batch_size = args.global_batch_size // world_size
-    assert args.synthetic, "real datasets need the `slider` parser (out of scope); pass --synthetic"
+    assert args.synthetic or args.data_path, "pass --data-path <dataset root> or --synthetic"
     loader = None
-    if args.synthetic_maps > 0:
+    if not args.synthetic:
+        # train.py:165-190: this rank's track range -> interleaved, worker-sharded stream of augmented windows
+        dataset_start, dataset_end = shard_range(args.data_start, args.data_end, rank, world_size)
+        loader = get_data_loader(track_catalogue(args.data_path), dataset_start, dataset_end,
+                                 WindowIterableFactory(args.seq_len, args.stride, open_fn=open_beatmap_sequence),
+                                 cycle_length=max(1, batch_size // 2), batch_size=batch_size, num_workers=args.num_workers,
+                                 shuffle=True, pin_memory=True, drop_last=True)
+    elif args.synthetic_maps > 0:
         # the reference's loader contract end to end (windows.py): sequences -> overlapping windows with random phase, flips
         # and time offsets -> batches; tracks split per rank (train.py:165-170), then per DataLoader worker
         catalogue = synthetic_sequences(args.synthetic_maps, min_len=args.seq_len, max_len=8 * args.seq_len,
@@ -88,7 +97,7 @@ def main(args):
                                  pin_memory=True, drop_last=True)
     else:
         dataset_start, dataset_end = shard_range(args.data_start, args.data_end, rank, world_size)
-    logger.info(f"Dataset contains {(dataset_end - dataset_start):,} (synthetic) beatmap sets")
+    logger.info(f"Dataset contains {(dataset_end - dataset_start):,} beatmap sets ({'synthetic' if args.synthetic else args.data_path})")
 
     train_steps, log_steps, start_time = 0, 0, time()
     running_loss = torch.zeros((), device=device)  # accumulated on the device: no host sync per step
