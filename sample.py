@@ -132,29 +132,33 @@ def main(args):
         save_sequence(to_seq(samples), args.refine_iters)
 
 
-if __name__ == "__main__":
-    p = argparse.ArgumentParser()
-    p.add_argument("--beatmap", type=str, default=None)
-    p.add_argument("--ckpt", type=str, default=None)
+# flag -> (type, default) for the reference's flag set (sample.py:208-232); same names, same defaults
+REFERENCE_FLAGS = {
+    "beatmap": (str, None), "ckpt": (str, None), "num-classes": (int, 52670), "beatmap-idx": (str, "beatmap_idx.pickle"),
+    "cfg-scale": (float, 1.0), "num-sampling-steps": (int, 250), "seed": (int, 0), "seq-len": (int, 128),
+    "use-amp": (bool, True),            # accepted; the precision tier is chosen with --precision
+    "style-id": (int, None),
+    "plot-time": (float, None),         # trims the sequence; the plot itself is out of scope
+    "plot-width": (float, 2000), "num-variants": (int, 1), "make-animation": (bool, False),
+    "refine-ckpt": (str, None), "refine-iters": (int, 10),
+}
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    for flag, (kind, default) in REFERENCE_FLAGS.items():
+        p.add_argument("--" + flag, type=kind, default=default)
     p.add_argument("--model", type=str, choices=list(DiT_models.keys()), default="DiT-B")
-    p.add_argument("--num-classes", type=int, default=52670)
-    p.add_argument("--beatmap-idx", type=str, default="beatmap_idx.pickle")
-    p.add_argument("--cfg-scale", type=float, default=1.0)
-    p.add_argument("--num-sampling-steps", type=int, default=250)
-    p.add_argument("--seed", type=int, default=0)
-    p.add_argument("--seq-len", type=int, default=128)
-    p.add_argument("--use-amp", type=bool, default=True)  # kept for compatibility (unused by the reference too)
-    p.add_argument("--style-id", type=int, default=None)
-    p.add_argument("--plot-time", type=float, default=None)   # trims the sequence; the plot itself is out of scope
-    p.add_argument("--plot-width", type=float, default=2000)
-    p.add_argument("--num-variants", type=int, default=1)
-    p.add_argument("--make-animation", type=bool, default=False)
-    p.add_argument("--refine-ckpt", type=str, default=None)
-    p.add_argument("--refine-iters", type=int, default=10)
+    # additions of this build
     p.add_argument("--synthetic", type=int, default=0, metavar="T", help="use a synthetic T-token sequence")
     p.add_argument("--precision", choices=["bf16", "fp32", "fp8"], default="bf16")
     p.add_argument("--sampler", choices=["p", "ddim"], default="p", help="ancestral p_sample loop (reference default) or DDIM")
     p.add_argument("--ddim-eta", type=float, default=0.0)
-    a = p.parse_args()
-    assert a.beatmap or a.synthetic, "--beatmap <map.osu|seq.pt|seq.npy> or --synthetic T"
-    main(a)
+    a = p.parse_args(argv)
+    if not (a.beatmap or a.synthetic):
+        p.error("--beatmap <map.osu|seq.pt|seq.npy> or --synthetic T")
+    return a
+
+
+if __name__ == "__main__":
+    main(parse_args())

@@ -149,36 +149,34 @@ def main(args):
         dist.destroy_process_group()
 
 
-if __name__ == "__main__":
-    p = argparse.ArgumentParser()
-    p.add_argument("--data-path", type=str, default=None)
-    p.add_argument("--num-classes", type=int, default=52670)
-    p.add_argument("--data-start", type=int, default=0)
-    p.add_argument("--data-end", type=int, default=13402)
-    p.add_argument("--results-dir", type=str, default="results")
+# flag -> (type, default) for the reference's flag set (train.py:306-337); same names, same defaults
+REFERENCE_FLAGS = {
+    "data-path": (str, None), "num-classes": (int, 52670), "data-start": (int, 0), "data-end": (int, 13402),
+    "results-dir": (str, "results"), "epochs": (int, 1400), "global-batch-size": (int, 256), "global-seed": (int, 0),
+    "num-workers": (int, 4), "log-every": (int, 100), "ckpt-every": (int, 50000), "seq-len": (int, 128), "stride": (int, 16),
+    "use-amp": (bool, True),            # accepted; bf16 MFMA tier with fp32 masters, no GradScaler needed
+    "ckpt": (str, None), "dist": (str, "nccl"),
+    "fine-tune-ids": (str, None),       # declared but unused by the reference too
+    "noise-schedule": (str, "squaredcos_cap_v2"), "l1-loss": (bool, True), "lr": (float, 1e-4),
+    "relearn-embeds": (bool, False), "embed-only-epochs": (int, 0),
+}
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    for flag, (kind, default) in REFERENCE_FLAGS.items():
+        p.add_argument("--" + flag, type=kind, default=default)
     p.add_argument("--model", type=str, choices=list(DiT_models.keys()), default="DiT-B")
-    p.add_argument("--epochs", type=int, default=1400)
-    p.add_argument("--global-batch-size", type=int, default=256)
-    p.add_argument("--global-seed", type=int, default=0)
-    p.add_argument("--num-workers", type=int, default=4)
-    p.add_argument("--log-every", type=int, default=100)
-    p.add_argument("--ckpt-every", type=int, default=50000)
-    p.add_argument("--seq-len", type=int, default=128)
-    p.add_argument("--stride", type=int, default=16)
-    p.add_argument("--use-amp", type=bool, default=True)  # bf16 MFMA tier; no GradScaler needed
-    p.add_argument("--ckpt", type=str, default=None)
-    p.add_argument("--dist", type=str, default="nccl")
-    p.add_argument("--fine-tune-ids", type=int, nargs="+")
-    p.add_argument("--noise-schedule", type=str, default="squaredcos_cap_v2")
-    p.add_argument("--l1-loss", type=bool, default=True)
-    p.add_argument("--lr", type=float, default=1e-4)
-    p.add_argument("--relearn-embeds", type=bool, default=False)
-    p.add_argument("--embed-only-epochs", type=int, default=0)
+    # additions of this build
     p.add_argument("--refine", action="store_true", help="train the t = 0 refine model (train_nodist.py's recipe)")
-    p.add_argument("--synthetic", action="store_true", help="train on synthetic windows (no `slider` needed)")
+    p.add_argument("--synthetic", action="store_true", help="train on synthetic windows (no dataset needed)")
     p.add_argument("--synthetic-maps", type=int, default=0,
                    help="with --synthetic: stream windows from this many synthetic hit-object sequences through the "
                         "reference's loader contract (windows.py) instead of drawing windows directly")
     p.add_argument("--steps-per-epoch", type=int, default=1000)
     p.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
-    main(p.parse_args())
+    return p.parse_args(argv)
+
+
+if __name__ == "__main__":
+    main(parse_args())
