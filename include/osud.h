@@ -122,6 +122,17 @@ int osud_sampler_step(const osud_sched* s, int mode, float eta, const float* mod
                       const int64_t* t_index, const float* noise, int N, int T, float cfg_scale, int clip,
                       float* x_out, float* pred_xstart, osud_stream stream);
 
+/* In-painting: the reference passes `denoised_fn = lambda x0: torch.where(mask, x0, known)` to the sampling loops
+ * (testing/test_toy.py:56-74; applied to the predicted x0 before the clamp, gaussian_diffusion.py:341-346).  Both arrays are
+ * (N,2,T) device buffers; where keep == 0 the prediction is replaced by `known`.  A NULL `inpaint` = no in-painting. */
+typedef struct osud_inpaint {
+  const uint8_t* keep;
+  const float* known;
+} osud_inpaint;
+int osud_sampler_step_inpaint(const osud_sched* s, int mode, float eta, const float* model_out, const float* x,
+                              const int64_t* t_index, const float* noise, int N, int T, float cfg_scale, int clip,
+                              const osud_inpaint* inpaint, float* x_out, float* pred_xstart, osud_stream stream);
+
 /* Whole sampling loop for steps first_step, first_step-1, ..., last_step (inclusive; the full
  * loop is first = num_timesteps-1, last = 0), each step = forward (model sees
  * timestep_map[i]) + sampler update, replayed from one captured hipGraph.
@@ -130,6 +141,11 @@ int osud_sampler_step(const osud_sched* s, int mode, float eta, const float* mod
 int osud_sample_loop(osud_dit* m, const osud_sched* s, int mode, float eta, float* x, const float* o, const float* c,
                      const int64_t* y, const uint8_t* attn_mask, int N, int T, float cfg_scale, int clip,
                      int first_step, int last_step, const float* noise, uint64_t seed, osud_stream stream);
+/* the same loop with in-painting fused into every sampler update */
+int osud_sample_loop_inpaint(osud_dit* m, const osud_sched* s, int mode, float eta, float* x, const float* o,
+                             const float* c, const int64_t* y, const uint8_t* attn_mask, int N, int T, float cfg_scale,
+                             int clip, int first_step, int last_step, const float* noise, uint64_t seed,
+                             const osud_inpaint* inpaint, osud_stream stream);
 
 /* ------------------------------------------------------------------ training
  * Sizes must satisfy T % 64 == 0 and N*T % 128 == 0 (no padding rows in the gradient products). */

@@ -52,6 +52,8 @@ _SIGNATURES = {
     "osud_sched_timestep_map": (_i, [_vp, C.POINTER(C.c_int64), _i]),
     "osud_sampler_step": (_i, [_vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp]),
     "osud_sample_loop": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp, _u64, _vp]),
+    "osud_sampler_step_inpaint": (_i, [_vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
+    "osud_sample_loop_inpaint": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp, _u64, _vp, _vp]),
     "osud_dit_bind_grad": (_i, [_vp, C.c_char_p, _vp]),
     "osud_dit_refresh": (_i, [_vp, _vp]),
     "osud_dit_forward_train": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),

@@ -56,10 +56,11 @@ struct GraphKey {
   float cfg, eta;
   const void *o, *c, *y, *mask, *x, *noise;
   const void* sched;
+  const void *keep = nullptr, *known = nullptr;
   bool operator==(const GraphKey& r) const {
     return N == r.N && T == r.T && mode == r.mode && clip == r.clip && has_mask == r.has_mask &&
            has_noise == r.has_noise && cfg == r.cfg && eta == r.eta && o == r.o && c == r.c && y == r.y &&
-           mask == r.mask && x == r.x && noise == r.noise && sched == r.sched;
+           mask == r.mask && x == r.x && noise == r.noise && sched == r.sched && keep == r.keep && known == r.known;
   }
 };
 

@@ -453,11 +453,11 @@ extern "C" int osud_dit_forward(osud_dit* m, const float* x, const int64_t* t, c
 // one loop iteration: timestep bookkeeping -> forward -> sampler update (x updated in place)
 static int loop_body(osud_dit* m, const osud_sched* s, int mode, float eta, float* x, const float* o, const float* c,
                      const int64_t* y, const uint8_t* mask, int N, int T, float cfg_scale, int clip, const float* noise,
-                     uint64_t seed, hipStream_t st) {
+                     uint64_t seed, const osud_inpaint* inpaint, hipStream_t st) {
   OSUD_TRY(launch_step_begin(m->step_state, sched_tmap_dev(s), m->t_model, m->t_index, N, st));
   OSUD_TRY(dit_forward_impl(m, x, m->t_model, o, c, y, mask, N, T, cfg_scale, false, m->out_ws, false, st));
   OSUD_TRY(launch_sampler_step(sched_coefs(s), mode, eta, m->out_ws, x, nullptr, m->step_state, noise,
-                               (size_t)N * 2 * T, seed, N, T, cfg_scale, clip, x, nullptr, st));
+                               (size_t)N * 2 * T, seed, N, T, cfg_scale, clip, inpaint, x, nullptr, st));
   return OSUD_OK;
 }
 
@@ -465,7 +465,19 @@ extern "C" int osud_sample_loop(osud_dit* m, const osud_sched* s, int mode, floa
                                 const float* c, const int64_t* y, const uint8_t* attn_mask, int N, int T,
                                 float cfg_scale, int clip, int first_step, int last_step, const float* noise,
                                 uint64_t seed, osud_stream stream) {
+  return osud_sample_loop_inpaint(m, s, mode, eta, x, o, c, y, attn_mask, N, T, cfg_scale, clip, first_step, last_step,
+                                  noise, seed, nullptr, stream);
+}
+
+extern "C" int osud_sample_loop_inpaint(osud_dit* m, const osud_sched* s, int mode, float eta, float* x, const float* o,
+                                        const float* c, const int64_t* y, const uint8_t* attn_mask, int N, int T,
+                                        float cfg_scale, int clip, int first_step, int last_step, const float* noise,
+                                        uint64_t seed, const osud_inpaint* inpaint_in, osud_stream stream) {
   OSUD_CHECK_ARG(m && s && x && o && c && y, "sample_loop: null argument");
+  OSUD_CHECK_ARG(inpaint_in == nullptr || (inpaint_in->keep && inpaint_in->known),
+                 "sample_loop: in-painting needs both the keep mask and the known values");
+  const osud_inpaint held = inpaint_in ? *inpaint_in : osud_inpaint{nullptr, nullptr};  // the caller's struct may be a temporary
+  const osud_inpaint* inpaint = inpaint_in ? &held : nullptr;
   const int nt = osud_sched_num_timesteps(s);
   OSUD_CHECK_ARG(first_step < nt && last_step >= 0 && first_step >= last_step,
                  "sample_loop: steps %d..%d outside the schedule's %d steps", first_step, last_step, nt);
@@ -477,10 +489,11 @@ extern "C" int osud_sample_loop(osud_dit* m, const osud_sched* s, int mode, floa
   const char* ng = getenv("OSUD_NO_GRAPH");
   if (ng && ng[0] == '1') {
     for (int k = 0; k < n_steps; ++k)
-      OSUD_TRY(loop_body(m, s, mode, eta, x, o, c, y, attn_mask, N, T, cfg_scale, clip, noise, seed, st));
+      OSUD_TRY(loop_body(m, s, mode, eta, x, o, c, y, attn_mask, N, T, cfg_scale, clip, noise, seed, inpaint, st));
     return OSUD_OK;
   }
-  GraphKey key{N, T, mode, clip, attn_mask != nullptr, noise != nullptr, cfg_scale, eta, o, c, y, attn_mask, x, noise, s};
+  GraphKey key{N, T, mode, clip, attn_mask != nullptr, noise != nullptr, cfg_scale, eta, o, c, y, attn_mask, x, noise, s,
+               held.keep, held.known};
   if (!(m->graph_valid && m->graph_key == key)) {
     if (m->graph_exec) {
       (void)hipGraphExecDestroy(m->graph_exec);
@@ -489,7 +502,7 @@ extern "C" int osud_sample_loop(osud_dit* m, const osud_sched* s, int mode, floa
     m->graph_valid = false;
     hipGraph_t graph = nullptr;
     OSUD_HIP(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeThreadLocal));
-    const int rc = loop_body(m, s, mode, eta, x, o, c, y, attn_mask, N, T, cfg_scale, clip, noise, seed, m->cap_stream);
+    const int rc = loop_body(m, s, mode, eta, x, o, c, y, attn_mask, N, T, cfg_scale, clip, noise, seed, inpaint, m->cap_stream);
     const hipError_t e = hipStreamEndCapture(m->cap_stream, &graph);
     if (rc != OSUD_OK) {
       if (graph) (void)hipGraphDestroy(graph);

@@ -105,8 +105,8 @@ struct SegBatch {
 struct StepCoefs;  // device table, 8 floats per step
 int launch_sampler_step(const float* coefs, int mode, float eta, const float* model_out, const float* x,
                         const int64_t* t_index, const int* step_state, const float* noise, size_t noise_step_stride,
-                        uint64_t seed, int N, int T, float cfg_scale, int clip, float* x_out, float* pred_xstart,
-                        hipStream_t st);
+                        uint64_t seed, int N, int T, float cfg_scale, int clip, const osud_inpaint* inpaint, float* x_out,
+                        float* pred_xstart, hipStream_t st);
 int launch_step_init(int* step_state, int first, hipStream_t st);
 int launch_step_begin(int* step_state, const int64_t* tmap_dev, int64_t* t_model, int64_t* t_index, int N,
                       hipStream_t st);

@@ -104,7 +104,8 @@ __global__ void sampler_step_kernel(const float* __restrict__ coefs, int mode, f
                                     const float* __restrict__ model_out, const float* __restrict__ x,
                                     const int64_t* __restrict__ t_index, const int* __restrict__ step_state,
                                     const float* __restrict__ noise, size_t noise_step_stride, uint64_t seed, int N,
-                                    int T, float cfg_scale, int clip, float* __restrict__ x_out,
+                                    int T, float cfg_scale, int clip, const uint8_t* __restrict__ keep,
+                                    const float* __restrict__ known, float* __restrict__ x_out,
                                     float* __restrict__ pred_xstart) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * 2 * T) return;
@@ -132,6 +133,7 @@ __global__ void sampler_step_kernel(const float* __restrict__ coefs, int mode, f
   const float frac = (v + 1.0f) / 2.0f;                              // gaussian_diffusion.py:322
   const float log_var = frac * max_log + (1.0f - frac) * min_log;    // :323
   float x0 = A * xv - B * eps;                                       // :373-376
+  if (keep != nullptr && keep[i] == 0) x0 = known[i];                // denoised_fn (in-paint mask), before the clamp :341-344
   if (clip) x0 = fminf(fmaxf(x0, -1.0f), 2.0f);                      // :345
   float nz;
   if (noise != nullptr) nz = noise[(size_t)exec_k * noise_step_stride + i];
@@ -188,13 +190,16 @@ int launch_step_init(int* step_state, int first, hipStream_t st) {
 
 int launch_sampler_step(const float* coefs, int mode, float eta, const float* model_out, const float* x,
                         const int64_t* t_index, const int* step_state, const float* noise, size_t noise_step_stride,
-                        uint64_t seed, int N, int T, float cfg_scale, int clip, float* x_out, float* pred_xstart,
-                        hipStream_t st) {
+                        uint64_t seed, int N, int T, float cfg_scale, int clip, const osud_inpaint* inpaint, float* x_out,
+                        float* pred_xstart, hipStream_t st) {
+  OSUD_CHECK_ARG(inpaint == nullptr || (inpaint->keep != nullptr && inpaint->known != nullptr),
+                 "sampler: in-painting needs both the keep mask and the known values");
   OSUD_CHECK_ARG(mode == OSUD_SAMPLER_P || mode == OSUD_SAMPLER_DDIM, "sampler: unknown mode %d", mode);
   OSUD_CHECK_ARG(cfg_scale < 0.f || N % 2 == 0, "sampler: classifier-free guidance needs an even batch, got %d", N);
   const int total = N * 2 * T;
   hipLaunchKernelGGL(sampler_step_kernel, dim3((total + 255) / 256), dim3(256), 0, st, coefs, mode, eta, model_out, x,
-                     t_index, step_state, noise, noise_step_stride, seed, N, T, cfg_scale, clip, x_out, pred_xstart);
+                     t_index, step_state, noise, noise_step_stride, seed, N, T, cfg_scale, clip,
+                     inpaint ? inpaint->keep : nullptr, inpaint ? inpaint->known : nullptr, x_out, pred_xstart);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }
@@ -298,11 +303,21 @@ extern "C" int osud_sched_timestep_map(const osud_sched* s, int64_t* out, int n)
   return OSUD_OK;
 }
 
+extern "C" int osud_sampler_step_inpaint(const osud_sched* s, int mode, float eta, const float* model_out,
+                                         const float* x, const int64_t* t_index, const float* noise, int N, int T,
+                                         float cfg_scale, int clip, const osud_inpaint* inpaint, float* x_out,
+                                         float* pred_xstart, osud_stream stream) {
+  OSUD_CHECK_ARG(s && model_out && x && t_index && noise && x_out && N > 0 && T > 0, "sampler_step: null/empty argument");
+  OSUD_CHECK_ARG(inpaint == nullptr || (inpaint->keep != nullptr && inpaint->known != nullptr),
+                 "sampler_step: in-painting needs both the keep mask and the known values");
+  OSUD_TRY(sched_upload(const_cast<osud_sched*>(s)));
+  return launch_sampler_step(s->d_coefs, mode, eta, model_out, x, t_index, nullptr, noise, 0, 0, N, T, cfg_scale, clip,
+                             inpaint, x_out, pred_xstart, (hipStream_t)stream);
+}
+
 extern "C" int osud_sampler_step(const osud_sched* s, int mode, float eta, const float* model_out, const float* x,
                                  const int64_t* t_index, const float* noise, int N, int T, float cfg_scale, int clip,
                                  float* x_out, float* pred_xstart, osud_stream stream) {
-  OSUD_CHECK_ARG(s && model_out && x && t_index && noise && x_out && N > 0 && T > 0, "sampler_step: null/empty argument");
-  OSUD_TRY(sched_upload(const_cast<osud_sched*>(s)));
-  return launch_sampler_step(s->d_coefs, mode, eta, model_out, x, t_index, nullptr, noise, 0, 0, N, T, cfg_scale, clip,
-                             x_out, pred_xstart, (hipStream_t)stream);
+  return osud_sampler_step_inpaint(s, mode, eta, model_out, x, t_index, noise, N, T, cfg_scale, clip, nullptr, x_out,
+                                   pred_xstart, stream);
 }

@@ -1,9 +1,10 @@
 """`create_diffusion` — the reference's factory (diffusion/__init__.py:10-47): same keyword arguments, same defaults,
 same resulting object (a `SpacedDiffusion` over the respaced schedule)."""
 from . import gaussian_diffusion as gd
+from .gaussian_diffusion import InPaintMask
 from .respace import SpacedDiffusion, space_timesteps
 
-__all__ = ["create_diffusion", "SpacedDiffusion", "space_timesteps"]
+__all__ = ["create_diffusion", "SpacedDiffusion", "space_timesteps", "InPaintMask"]
 
 
 def _loss_type(use_kl: bool, rescale_learned_sigmas: bool, use_l1: bool):

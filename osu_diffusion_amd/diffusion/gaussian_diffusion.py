@@ -134,6 +134,32 @@ class _NativeSchedule:
             pass
 
 
+class InPaintMask:
+    """`denoised_fn` for in-painting: keep the prediction where `mask` is True, force `known` elsewhere — what the
+    reference builds as a closure (testing/test_toy.py:56-62: `torch.where(mask, x2, x)`).  Any callable still works
+    as `denoised_fn` (generic Python path); an instance of this class is also understood by the fused native loops,
+    which apply it inside the sampler-update kernel."""
+
+    def __init__(self, mask, known):
+        assert mask.shape == known.shape, "mask and known values must have the shape of the samples"
+        self.mask, self.known = mask.bool(), known
+
+    def __call__(self, x0):
+        return th.where(self.mask, x0, self.known)
+
+    def native(self, like):
+        """(ctypes struct, tensors to keep alive) for the C ABI's `osud_inpaint`."""
+        import ctypes as C
+
+        class _InPaint(C.Structure):
+            _fields_ = [("keep", C.c_void_p), ("known", C.c_void_p)]
+
+        keep = self.mask.to(device=like.device, dtype=th.uint8).expand(like.shape).contiguous()
+        known = self.known.to(device=like.device, dtype=th.float32).expand(like.shape).contiguous()
+        st = _InPaint(_lib.ptr(keep), _lib.ptr(known))
+        return C.cast(C.pointer(st), C.c_void_p), (st, keep, known)
+
+
 def _native_target(model):
     """(dit, uses_cfg) when `model` is the native DiT module or one of its two forward methods."""
     from ..models import DiT
@@ -196,7 +222,7 @@ class GaussianDiffusion:
 
     def _native_ok(self, model, x, denoised_fn, cond_fn):
         dit, use_cfg = _native_target(getattr(model, "model", model))
-        ok = (dit is not None and denoised_fn is None and cond_fn is None and x.is_cuda
+        ok = (dit is not None and (denoised_fn is None or isinstance(denoised_fn, InPaintMask)) and cond_fn is None and x.is_cuda
               and self.model_mean_type == ModelMeanType.EPSILON and self.model_var_type == ModelVarType.LEARNED_RANGE
               and dit.learn_sigma)
         return (dit, use_cfg) if ok else (None, False)
@@ -311,7 +337,7 @@ class GaussianDiffusion:
         return out
 
     # ------------------------------------------------------------------ native single step
-    def _native_step(self, dit, use_cfg, mode, eta, x, t, clip_denoised, model_kwargs, noise=None):
+    def _native_step(self, dit, use_cfg, mode, eta, x, t, clip_denoised, model_kwargs, noise=None, inpaint=None):
         kw = dict(model_kwargs or {})
         cfg_scale = kw.pop("cfg_scale", None)
         fwd = dit.forward_with_cfg if use_cfg else dit.forward
@@ -325,18 +351,20 @@ class GaussianDiffusion:
         sample = th.empty_like(x)
         x0 = th.empty_like(x)
         N, _, T = x.shape
+        ip, ip_keep = inpaint.native(x) if inpaint is not None else (None, None)
         with th.cuda.device(x.device):
-            _lib.check(_lib.lib().osud_sampler_step(self._sched.handle, mode, float(eta), _lib.ptr(model_out), _lib.ptr(x),
-                                                    _lib.ptr(t.to(th.int64).contiguous()), _lib.ptr(noise.contiguous()),
-                                                    N, T, -1.0, int(bool(clip_denoised)), _lib.ptr(sample), _lib.ptr(x0),
-                                                    _lib.stream_ptr(x.device)))
+            _lib.check(_lib.lib().osud_sampler_step_inpaint(
+                self._sched.handle, mode, float(eta), _lib.ptr(model_out), _lib.ptr(x), _lib.ptr(t.to(th.int64).contiguous()),
+                _lib.ptr(noise.contiguous()), N, T, -1.0, int(bool(clip_denoised)), ip, _lib.ptr(sample), _lib.ptr(x0),
+                _lib.stream_ptr(x.device)))
+        self._keepalive_step = ip_keep
         return {"sample": sample, "pred_xstart": x0}
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None):
         """One ancestral step x_t -> x_{t-1} (gaussian_diffusion.py:420-467)."""
         dit, use_cfg = self._native_ok(model, x, denoised_fn, cond_fn)
         if dit is not None and not th.is_grad_enabled():
-            return self._native_step(dit, use_cfg, _lib.SAMPLER_P, 0.0, x, t, clip_denoised, model_kwargs)
+            return self._native_step(dit, use_cfg, _lib.SAMPLER_P, 0.0, x, t, clip_denoised, model_kwargs, inpaint=denoised_fn)
         out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
                                    model_kwargs=model_kwargs)
         noise = th.randn_like(x)
@@ -350,7 +378,7 @@ class GaussianDiffusion:
         """One DDIM step (gaussian_diffusion.py:563-610)."""
         dit, use_cfg = self._native_ok(model, x, denoised_fn, cond_fn)
         if dit is not None and not th.is_grad_enabled():
-            return self._native_step(dit, use_cfg, _lib.SAMPLER_DDIM, eta, x, t, clip_denoised, model_kwargs)
+            return self._native_step(dit, use_cfg, _lib.SAMPLER_DDIM, eta, x, t, clip_denoised, model_kwargs, inpaint=denoised_fn)
         out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn,
                                    model_kwargs=model_kwargs)
         if cond_fn is not None:
@@ -379,7 +407,7 @@ class GaussianDiffusion:
 
     # ------------------------------------------------------------------ loops
     def _native_loop(self, dit, use_cfg, mode, eta, img, clip_denoised, model_kwargs, step_noise, seed,
-                     first_step=None, last_step=0, in_place=False):
+                     first_step=None, last_step=0, in_place=False, inpaint=None):
         """Steps first_step..last_step in the library: one captured hipGraph replayed per step."""
         kw = dict(model_kwargs or {})
         cfg_scale = float(kw.pop("cfg_scale")) if use_cfg else -1.0
@@ -396,26 +424,27 @@ class GaussianDiffusion:
         if step_noise is not None:
             assert step_noise.shape == (n_steps, *x.shape), "step_noise must be (number of steps, *shape)"
             step_noise = step_noise.to(device=x.device, dtype=th.float32).contiguous()
-        keep = (x, o, c, y, m, step_noise)  # alive until the stream has consumed them
+        ip, ip_keep = inpaint.native(x) if inpaint is not None else (None, None)
+        keep = (x, o, c, y, m, step_noise, ip_keep)  # alive until the stream has consumed them
         with th.cuda.device(x.device):
-            _lib.check(_lib.lib().osud_sample_loop(handle, self._sched.handle, mode, float(eta), _lib.ptr(x), _lib.ptr(o),
-                                                   _lib.ptr(c), _lib.ptr(y), _lib.ptr(m), N, T, cfg_scale,
-                                                   int(bool(clip_denoised)), first_step, int(last_step),
-                                                   _lib.ptr(step_noise), int(seed), _lib.stream_ptr(x.device)))
+            _lib.check(_lib.lib().osud_sample_loop_inpaint(
+                handle, self._sched.handle, mode, float(eta), _lib.ptr(x), _lib.ptr(o), _lib.ptr(c), _lib.ptr(y), _lib.ptr(m),
+                N, T, cfg_scale, int(bool(clip_denoised)), first_step, int(last_step), _lib.ptr(step_noise), int(seed), ip,
+                _lib.stream_ptr(x.device)))
         self._keepalive = keep
         return x
 
     def run_steps(self, model, x, model_kwargs, first_step, last_step=0, sampler="p", eta=0.0, clip_denoised=True,
-                  step_noise=None, seed=None):
+                  step_noise=None, seed=None, denoised_fn=None):
         """Extension: run sampler steps first_step, first_step-1, ..., last_step on `x` IN PLACE with the
         native DiT (the building block of the loops; also what bench.py times).  `step_noise` is
         (n_steps, *x.shape) or None (then `seed` keys the in-kernel Philox stream)."""
-        dit, use_cfg = self._native_ok(model, x, None, None)
+        dit, use_cfg = self._native_ok(model, x, denoised_fn, None)
         if dit is None:
             raise _lib.NativeError("run_steps needs the native DiT (model.forward / model.forward_with_cfg) on a GPU")
         mode = {"p": _lib.SAMPLER_P, "ddim": _lib.SAMPLER_DDIM}[sampler]
         return self._native_loop(dit, use_cfg, mode, eta, x, clip_denoised, model_kwargs, step_noise, seed or 0,
-                                 first_step=first_step, last_step=last_step, in_place=True)
+                                 first_step=first_step, last_step=last_step, in_place=True, inpaint=denoised_fn)
 
     def _loop(self, step_fn, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, progress,
               **extra):
@@ -449,7 +478,7 @@ class GaussianDiffusion:
             if step_noise is None and seed is None:
                 step_noise = th.randn(self.num_timesteps, *img.shape, device=img.device)
             return self._native_loop(dit, use_cfg, _lib.SAMPLER_P, 0.0, img, clip_denoised, model_kwargs, step_noise,
-                                     seed or 0)
+                                     seed or 0, inpaint=denoised_fn)
         final = None
         for sample in self.p_sample_loop_progressive(model, shape, noise=img, clip_denoised=clip_denoised,
                                                      denoised_fn=denoised_fn, cond_fn=cond_fn,
@@ -474,7 +503,7 @@ class GaussianDiffusion:
             if step_noise is None and seed is None:
                 step_noise = th.randn(self.num_timesteps, *img.shape, device=img.device)
             return self._native_loop(dit, use_cfg, _lib.SAMPLER_DDIM, eta, img, clip_denoised, model_kwargs,
-                                     step_noise, seed or 0)
+                                     step_noise, seed or 0, inpaint=denoised_fn)
         final = None
         for sample in self.ddim_sample_loop_progressive(model, shape, noise=img, clip_denoised=clip_denoised,
                                                         denoised_fn=denoised_fn, cond_fn=cond_fn,

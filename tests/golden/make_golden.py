@@ -427,8 +427,65 @@ def g10_curves():
     save("g10_curves", **out)
 
 
+def g11_inpaint():
+    """In-painting through `denoised_fn` (testing/test_toy.py:56-74: keep the prediction where mask is True, force the known
+    coordinates elsewhere): single p_sample / ddim_sample steps on fixed model outputs and a chained 20-step loop with
+    `model.forward` (no guidance), from the reference."""
+    print("G11 in-painting (denoised_fn masks)")
+    g = torch.Generator().manual_seed(11)
+    N, T = 6, 64
+    ref = ref_create_diffusion("250", noise_schedule="squaredcos_cap_v2")
+    ora = do.create_schedule("250", "squaredcos_cap_v2")
+    nt = ref.num_timesteps
+    t = torch.tensor([0, 1, nt // 2, nt - 1, 0, nt - 2], dtype=torch.long)
+    x = torch.randn(N, 2, T, generator=g) + 0.5
+    mout = torch.randn(N, 4, T, generator=g)
+    mout[:, 2:] = mout[:, 2:].clamp(-1.5, 1.5)
+    known = torch.rand(N, 2, T, generator=g) * 3.4 - 1.2          # some values outside [-1, 2]: the clamp comes after the mask
+    mask = torch.rand(N, 2, T, generator=g) < 0.3
+    mask[:, :, -1] = True
+    fn = lambda v: torch.where(mask, v, known)  # noqa: E731
+    model = lambda *_a, **_k: mout  # noqa: E731
+    outs = {}
+    for name, step, kw in [("p", ref.p_sample, {}), ("ddim", ref.ddim_sample, {"eta": 0.5})]:
+        torch.manual_seed(78)
+        r = step(model, x, t, clip_denoised=True, denoised_fn=fn, **kw)
+        torch.manual_seed(78)
+        nz = torch.randn_like(x)
+        o = (do.p_sample_step(ora, mout, x, t, nz, denoised_fn=fn) if name == "p"
+             else do.ddim_step(ora, mout, x, t, nz, eta=0.5, denoised_fn=fn))
+        close(o["sample"], r["sample"], 0.0, f"inpaint {name} sample")
+        close(o["pred_xstart"], r["pred_xstart"], 0.0, f"inpaint {name} x0")
+        outs[name + "_sample"], outs[name + "_x0"], outs[name + "_noise"] = r["sample"], r["pred_xstart"], nz
+    # chained loop, as test_toy.py runs it: only the last object of each window is sampled, the rest is given
+    shape, wseed = TINY, 11
+    sd = mo.seeded_state_dict(shape, wseed)
+    net = ref_model_for(shape, sd)
+    n, Tw = 4, 64
+    (x0, o, c), y = synthetic_windows(n, Tw, shape.num_classes, seed=9, train_offsets=False)
+    y = torch.full_like(y, shape.num_classes)                     # null class (test_toy.py:45)
+    lmask = torch.zeros(n, 2, Tw, dtype=torch.bool)
+    lmask[:, :, -1] = True
+    lfn = lambda v: torch.where(lmask, v, x0)  # noqa: E731
+    d20 = ref_create_diffusion("20", noise_schedule="squaredcos_cap_v2")
+    o20 = do.create_schedule("20", "squaredcos_cap_v2")
+    torch.manual_seed(5)
+    z = lfn(torch.randn(n, 2, Tw))
+    kw = dict(o=o, c=c, y=y, attn_mask=None)
+    torch.manual_seed(6)
+    final = d20.p_sample_loop(net.forward, z.shape, z, denoised_fn=lfn, clip_denoised=True, model_kwargs=kw, device="cpu")
+    torch.manual_seed(6)
+    noises = torch.stack([torch.randn_like(z) for _ in range(20)])
+    mine = do.sample_loop(o20, lambda xx, tt: mo.forward(sd, shape, xx, tt, o, c, y), z, noises, denoised_fn=lfn)
+    close(mine, final, 5e-4, "inpaint loop")
+    assert torch.equal(final[~lmask], x0[~lmask].clamp(-1, 2))    # the given coordinates come out untouched
+    save("g11_inpaint", x=x, t=t, model_out=mout, known=known, mask=mask, **outs,
+         shape=np.array([shape.depth, shape.hidden, shape.heads, shape.num_classes]), wseed=wseed, wsum=checksum(sd),
+         loop_x0=x0, loop_o=o, loop_c=c, loop_y=y, loop_mask=lmask, loop_z=z, loop_noises=noises, loop_final=final)
+
+
 if __name__ == "__main__":
-    steps = [g1_schedules, g2_embeddings, g3_forward, g5_step, g6_loop, g7_training, g9_init_and_keys, g9_windows, g10_curves]
+    steps = [g1_schedules, g2_embeddings, g3_forward, g5_step, g6_loop, g7_training, g9_init_and_keys, g9_windows, g10_curves, g11_inpaint]
     only = set(sys.argv[1:])  # e.g. `make_golden.py g10_curves` regenerates one family
     for fn in steps:
         if not only or fn.__name__ in only:
