@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--model", default="DiT-B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--h2d", action="store_true", help="also time the training steps with every batch copied from pinned host "
+                                                         "memory inside the step (reported as pcie_inclusive, never as value)")
     return ap.parse_args()
 
 
@@ -249,6 +251,17 @@ def bench_train(args, world, rank, dev):
         per_gpu = tokens_per_s / world
         res["end_to_end"] = {"flop_per_token": FLOP_PER_TOKEN_TRAIN, "achieved_tflops_per_gpu": round(per_gpu * FLOP_PER_TOKEN_TRAIN / 1e12, 1),
                              "mfma_frac": round(per_gpu * FLOP_PER_TOKEN_TRAIN / 1e12 / PEAK_BF16_TFLOPS, 4)}
+    if args.h2d:  # the loader's hand-over (train.py:244-248): pinned host batch -> device, every step
+        host = [tuple(v.cpu().pin_memory() for v in (x, o, c, y)) for (x, o, c), y in batches]
+        barrier(world)
+        t0 = time.perf_counter()
+        for i in range(K):
+            x, o, c, y = (v.to(dev, non_blocking=True) for v in host[i % 4])
+            trainer.step(x, o, c, y)
+        barrier(world)
+        dt_h = max_over_ranks(time.perf_counter() - t0, world, dev)
+        res["pcie_inclusive"] = {"value": round(world * B * T * K / dt_h, 1), "unit": "tokens/s", "ms_per_step": round(dt_h / K * 1e3, 3),
+                                 "bytes_per_step": sum(v.numel() * v.element_size() for v in host[0])}
     if rank == 0 and not args.no_roofline and args.precision == "bf16":
         D = model.hidden_size
         res["roofline"] = gemm_roofline(B * T, 4 * D, D, dev)
