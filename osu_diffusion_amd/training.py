@@ -306,6 +306,10 @@ class NativeTrainer:
         self.embed_only = False
         self.table_extra_steps = 0
         self.force_phased = os.environ.get("OSUD_FORCE_PHASED", "0") == "1"  # exercise the phased path on 1 GPU
+        # one GPU: the HBM-bound AdamW+EMA of a block's slice runs on a side stream under the MFMA-bound backward of the blocks
+        # in front of it (same arithmetic, same result); OSUD_ADAMW_OVERLAP=0 runs it after the backward instead
+        self.overlap_adamw = os.environ.get("OSUD_ADAMW_OVERLAP", "1") == "1"
+        self._side = None
         import torch.distributed as dist
 
         if broadcast_init and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -354,6 +358,11 @@ class NativeTrainer:
                 _self._adamw(ranges, 1.0 / dist.get_world_size(_self.group) if dist.is_initialized() else 1.0)
                 done.extend(ranges)
 
+            import torch.distributed as dist
+            single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1)
+            if single and self.overlap_adamw and not self.force_phased:
+                self._backward_with_overlapped_adamw(dout)
+                return terms
             scale = backward_with_overlapped_allreduce(model, dout, self.group, force=self.force_phased, on_blocks_reduced=early)
             if done:
                 self._adamw(_complement(done, self.arena.total), scale)
@@ -361,6 +370,31 @@ class NativeTrainer:
             else:
                 self.optimizer_step(scale)
         return terms
+
+    def _backward_with_overlapped_adamw(self, dout):
+        """Single GPU: phased backward on the current stream; as soon as a block's phase is enqueued its (final) gradient
+        slice is handed to AdamW+EMA on a side stream.  The masters / moments / EMA of a block are touched by nothing else
+        until the re-pack at the end, which waits for the side stream."""
+        model, dev = self.model, self.arena.flat.device
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        blocks, _ = overlap_slices(self.arena, model.depth)
+        self.step_count += 1
+        dout = native_backward(model, dout, phases=(0, 0))
+        done = []
+        for p in range(1, model.depth + 1):
+            native_backward(model, dout, phases=(p, p))
+            _, _, lo, hi = blocks[model.depth - p]
+            ev = main.record_event()
+            with torch.cuda.stream(self._side):
+                self._side.wait_event(ev)
+                self._adamw([(lo, hi)], 1.0)
+            done.append((lo, hi))
+        native_backward(model, dout, phases=(model.depth + 1, model.depth + 1))
+        self._adamw(_complement(done, self.arena.total), 1.0)
+        main.wait_stream(self._side)
+        self._refresh()
 
     def _table_range(self):
         i = self.arena.names.index("y_embedder.embedding_table.weight")

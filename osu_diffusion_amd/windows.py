@@ -11,7 +11,8 @@ from that tensor to the `((x, o, c), y)` batches the DiT path consumes is restat
   one source after the other, optionally `cycle_length` sources interleaved round-robin
   (BeatmapDatasetIterable / InterleavingBeatmapDatasetIterable);
 * `WindowDataset`, `worker_init_fn`, `get_data_loader` — the torch `IterableDataset` with the reference's
-  DataLoader-worker split; the per-rank split of train.py:165-170 is `training.shard_range`.
+  DataLoader-worker split; the per-rank split of train.py:165-170 is `training.shard_range`;
+* `cache_dataset`, `CachedDataset`, `get_cached_data_loader` — the reference's cached-epoch variant (:414-475).
 
 Reading `.osu` files needs the third-party `slider` package (absent here, unpinned upstream): a *source* is therefore
 anything `open_fn` turns into a (19, L) tensor — by default a `(name, tensor)` pair, with the class label taken from the
@@ -23,7 +24,7 @@ import random
 from typing import Callable, Iterable, Optional, Sequence
 
 import torch
-from torch.utils.data import DataLoader, IterableDataset
+from torch.utils.data import DataLoader, Dataset, IterableDataset
 
 from .positional_embedding import timestep_embedding
 
@@ -198,6 +199,34 @@ def get_data_loader(catalogue, start: int, end: int, iterable_factory: Callable,
     ds = WindowDataset(catalogue, start, end, iterable_factory, cycle_length, shuffle)
     return DataLoader(ds, batch_size=batch_size, worker_init_fn=worker_init_fn, num_workers=num_workers,
                       pin_memory=pin_memory, drop_last=drop_last, persistent_workers=num_workers > 0)
+
+
+class CachedDataset(Dataset):
+    """Map-style dataset over windows produced once and kept in memory (data_loading.py:414-424)."""
+
+    def __init__(self, cached_data):
+        self.cached_data = cached_data
+
+    def __getitem__(self, index):
+        return self.cached_data[index]
+
+    def __len__(self):
+        return len(self.cached_data)
+
+
+def cache_dataset(out_path: str, catalogue, start: int, end: int, iterable_factory: Callable, cycle_length: int = 1) -> int:
+    """Run the window stream once (no shuffling) and save every `((x, o, c), y)` item to `out_path` (:427-452); returns the
+    number of windows.  Parsing `.osu` files costs tens of ms per map, so a cached epoch keeps the GPU fed without workers."""
+    items = list(WindowDataset(catalogue, start, end, iterable_factory, cycle_length, shuffle=False))
+    torch.save(items, out_path)
+    return len(items)
+
+
+def get_cached_data_loader(data_path: str, batch_size: int = 1, num_workers: int = 0, shuffle: bool = False,
+                           pin_memory: bool = False, drop_last: bool = False) -> DataLoader:
+    """DataLoader over a file written by `cache_dataset` (:455-475)."""
+    return DataLoader(CachedDataset(torch.load(data_path, weights_only=False)), batch_size=batch_size, num_workers=num_workers,
+                      pin_memory=pin_memory, drop_last=drop_last, persistent_workers=num_workers > 0, shuffle=shuffle)
 
 
 def synthetic_sequences(n: int, min_len: int = 96, max_len: int = 600, seed: int = 0, first_id: int = 100000):
