@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from osu_diffusion_amd import _lib
 L = _lib.lib(); dev = torch.device("cuda:0")
-D, M = 768, 32768
+D, M = 768, int(os.environ.get('M', '32768'))
 SHAPES = [("qkv fwd", _lib.EPI_BIAS_TE, M, 3 * D, D, False), ("proj fwd", _lib.EPI_BIAS_TE, M, D, D, False),
           ("fc1 fwd", _lib.EPI_BIAS_GELU_TE, M, 4 * D, D, False), ("fc2 fwd", _lib.EPI_BIAS_TE, M, D, 4 * D, False),
           ("fc2 dgrad", _lib.EPI_NONE_TE, M, 4 * D, D, False), ("fc1 dgrad", _lib.EPI_NONE_TE, M, D, 4 * D, False),
