@@ -54,6 +54,9 @@ struct GemmP {
   float out_scale;        // fp8 OUTPUT (EPI_BIAS_GELU_TE with fp8 operands): the value is multiplied by this before quantisation
   int split_k;       // > 1: blockIdx.y walks K in split_k equal ranges, range s writes out + s * split_stride (elements)
   size_t split_stride;
+  float* colpart;     // EPI_GELUGRAD_TE, optional: f32 [R][Nx] partial column sums of the OUTPUT (before rounding), one row per wave-row
+                      // of the grid (R = My / rows per wave, reported through colpart_rows); summed over R they are the bias gradient
+  int* colpart_rows;  // host pointer, written at launch
   int tile_order;  // 0/1 = plain x-fastest runs per XCD (default), 2 = banded per XCD (fewer weight re-reads, not faster)
 };
 

@@ -417,6 +417,14 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
       t[2] = ds_read16f<2048>(pr0 + pso);   // rows 16..31
       t[3] = ds_read16f<2048>(pr1 + pso);
     };
+    constexpr bool kColsum = EPI == EPI_GELUGRAD_TE && !kF8;
+    float cs[kColsum ? RX : 1][8];
+    if (kColsum) {
+#pragma unroll
+      for (int j = 0; j < RX; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[j][e] = 0.f;
+    }
     f32x4 tq[2][4];
     patch_trip(0, tq[0]);
 #pragma unroll
@@ -503,10 +511,31 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
         } else if (EPI == EPI_GELUGRAD_TE) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = v[e] * rv[q][e];
+          if (kColsum) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[j][e] += w[e];
+          }
           store8(reinterpret_cast<TO*>(p.out) + o, w);
         } else {  // EPI_BIAS_TE, EPI_ROWBIAS_TE, EPI_NONE_TE
           store8(reinterpret_cast<TO*>(p.out) + o, v);
         }
+      }
+    }
+    if (kColsum && p.colpart != nullptr) {
+      // bias gradient riding along: this wave's RY*32 rows are summed per column -- over the lane's own rows above, over
+      // the 16 lane-rows here (fixed butterfly: deterministic) -- and stored as one row of partial sums
+#pragma unroll
+      for (int j = 0; j < RX; ++j) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = cs[j][e];
+          v += __shfl_xor(v, 4, 64);
+          v += __shfl_xor(v, 8, 64);
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          cs[j][e] = v;
+        }
+        if (lane < 4) store8(p.colpart + (size_t)(ty * WY + wy) * p.Nx + xw + j * 32, cs[j]);
       }
     }
 #ifdef OSUD_GEMM_TIMING
@@ -543,6 +572,7 @@ template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(con
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
+  if (p.colpart_rows != nullptr) *p.colpart_rows = p.My / (RY * 32);
   const int ntiles = (p.My / G::BM) * (p.Nx / G::BN), splits = p.split_k > 1 ? p.split_k : 1;
   int grid = num_cus() * G::WGS / splits;  // persistent workgroups: WGS per CU (LDS-limited), shared by the K splits
   if (grid < 1) grid = 1;

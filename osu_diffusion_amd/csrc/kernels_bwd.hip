@@ -535,7 +535,38 @@ int launch_unpad_rows(const float* src, int ld_src, float* dst, int cols, int ro
   return OSUD_OK;
 }
 
+// the same for tall partial-sum slabs (R in the hundreds): 16 row groups x 16 float4 columns per block, fixed-order combine
+__global__ __launch_bounds__(256) void colsum_f32_tall_kernel(const float* __restrict__ a, int R, int C, float* __restrict__ out) {
+  __shared__ float4 part[16][16];
+  const int tx = threadIdx.x & 15, tg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + tx * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = tg; r < R; r += 64) {  // four independent loads in flight per thread
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = r + 16 * u;
+      v[u] = rr < R ? *reinterpret_cast<const float4*>(a + (size_t)rr * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  part[tg][tx] = s;
+  __syncthreads();
+  if (tg == 0) {
+    float4 t = part[0][tx];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) { t.x += part[g][tx].x; t.y += part[g][tx].y; t.z += part[g][tx].z; t.w += part[g][tx].w; }
+    *reinterpret_cast<float4*>(out + c) = t;
+  }
+}
+
 int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_t st) {
+  if (R_valid >= 64 && C % 64 == 0) {
+    hipLaunchKernelGGL(colsum_f32_tall_kernel, dim3(C / 64), dim3(256), 0, st, a, R_valid, C, out);
+    OSUD_HIP(hipGetLastError());
+    return OSUD_OK;
+  }
   hipLaunchKernelGGL(colsum_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, st, a, R_valid, C, out);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;

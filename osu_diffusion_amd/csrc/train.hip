@@ -181,13 +181,26 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
       OSUD_TRY(launch_gate_bwd(prec, dh, sv.br2, m->ada + base + 5 * D, AC, w.dbr, w.dada + base + 5 * D, M, Tp, D, st, g_b2));
       OSUD_TRY(dbg_sync(st, "gate_bwd mlp"));
     }
-    OSUD_TRY(gemm(m, EPI_GELUGRAD_TE, w.dbr, D, bw.w2_t, D, Mp, 4 * D, D, w.dz1, 4 * D, nullptr, st, nullptr, 0, 0, 0,
-                  nullptr, nullptr, sv.z1));
+    // dz1 = (dbr . W2) * gelu'(z1); in the bf16 tier the fc1 bias gradient (column sums of dz1) rides in the same epilogue
+    // as per-wave-row partial sums (scratch: the split-K slab area, free until the weight gradients below)
+    const bool fused_b1 = prec == OSUD_PREC_BF16 && (size_t)(Mp / 32) * 4 * D <= w.splitk_elems;
+    {
+      GemmP gp{};
+      gp.Y = w.dbr; gp.X = bw.w2_t; gp.ldy = D; gp.ldx = D; gp.My = Mp; gp.Nx = 4 * D; gp.K = D;
+      gp.out = w.dz1; gp.ldo = 4 * D; gp.aux = sv.z1;
+      int part_rows = 0;
+      if (fused_b1) {
+        gp.colpart = w.splitk;
+        gp.colpart_rows = &part_rows;
+      }
+      OSUD_TRY(launch_gemm(prec, EPI_GELUGRAD_TE, gp, st));
+      if (fused_b1) OSUD_TRY(launch_colsum_f32(w.splitk, part_rows, 4 * D, g_b1, st));
+    }
     OSUD_TRY(dbg_sync(st, "dgrad fc2 (gelu grad)"));
     // consumers of dz1 (201 MB, fresh in the Infinity Cache) first, the fc2 weight gradient (dbr, g) after them
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dz1, 4 * D, bw.w1_t, 4 * D, Mp, D, 4 * D, w.du, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "dgrad fc1"));
-    OSUD_TRY(weight_grad(m, w.dz1, 4 * D, sv.u2, D, 4 * D, D, Mp, G(p + "mlp.fc1.weight"), g_b1, st));
+    OSUD_TRY(weight_grad(m, w.dz1, 4 * D, sv.u2, D, 4 * D, D, Mp, G(p + "mlp.fc1.weight"), fused_b1 ? nullptr : g_b1, st));
     OSUD_TRY(dbg_sync(st, "wgrad fc1"));
     OSUD_TRY(weight_grad(m, w.dbr, D, sv.g, 4 * D, D, 4 * D, Mp, G(p + "mlp.fc2.weight"), nullptr, st));
     OSUD_TRY(dbg_sync(st, "wgrad fc2"));
