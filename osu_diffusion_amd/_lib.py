@@ -108,6 +108,11 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+class InPaintStruct(C.Structure):
+    """`osud_inpaint` of include/osud.h: device pointers to the (N,2,T) keep mask (uint8) and known values (f32)."""
+    _fields_ = [("keep", C.c_void_p), ("known", C.c_void_p)]
+
+
 def stream_ptr(device=None):
     import torch
 

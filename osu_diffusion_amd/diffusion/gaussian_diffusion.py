@@ -151,12 +151,9 @@ class InPaintMask:
         """(ctypes struct, tensors to keep alive) for the C ABI's `osud_inpaint`."""
         import ctypes as C
 
-        class _InPaint(C.Structure):
-            _fields_ = [("keep", C.c_void_p), ("known", C.c_void_p)]
-
         keep = self.mask.to(device=like.device, dtype=th.uint8).expand(like.shape).contiguous()
         known = self.known.to(device=like.device, dtype=th.float32).expand(like.shape).contiguous()
-        st = _InPaint(_lib.ptr(keep), _lib.ptr(known))
+        st = _lib.InPaintStruct(_lib.ptr(keep), _lib.ptr(known))
         return C.cast(C.pointer(st), C.c_void_p), (st, keep, known)
 
 

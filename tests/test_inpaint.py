@@ -59,9 +59,7 @@ def test_oracle_loop_matches_reference():
 def test_library_rejects_half_an_inpaint_request():
     import ctypes as C
 
-    class Half(C.Structure):
-        _fields_ = [("keep", C.c_void_p), ("known", C.c_void_p)]
-
+    Half = _lib.InPaintStruct
     d = create_diffusion("250", noise_schedule="squaredcos_cap_v2")
     buf = torch.zeros(2 * 2 * 8)
     half = Half(_lib.ptr(buf), None)
