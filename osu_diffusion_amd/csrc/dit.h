@@ -48,7 +48,7 @@ struct BwdWs {
         *db = nullptr, *dth = nullptr, *dWe = nullptr, *splitk = nullptr, *attn_delta = nullptr /* [N][H][Tp] */;
   size_t splitk_elems = 0;
   void *dbr = nullptr, *dz1 = nullptr, *dqkv = nullptr, *dao = nullptr, *tA = nullptr, *tB = nullptr, *dada_te = nullptr,
-       *db_te = nullptr, *dz0 = nullptr, *small_t1 = nullptr, *small_t2 = nullptr;
+       *db_te = nullptr, *dz0 = nullptr, *small_t1 = nullptr, *small_t2 = nullptr, *sb_t = nullptr /* silu(b)^T [D][Np] */;
 };
 
 struct GraphKey {

@@ -107,6 +107,7 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
     OSUD_TRY(dev_alloc(W, &b.dz0, (size_t)Np * D * es));
     OSUD_TRY(dev_alloc(W, &b.small_t1, (size_t)Np * (D > 256 ? D : 256) * es));
     OSUD_TRY(dev_alloc(W, &b.small_t2, (size_t)Np * (D > 256 ? D : 256) * es));
+    OSUD_TRY(dev_alloc(W, &b.sb_t, (size_t)Np * D * es));
     OSUD_TRY(dev_alloc(W, &b.dWe, (size_t)D * m->Kp * 4));
     b.splitk_elems = (size_t)16 * 4 * D * D;  // up to 16 partial slabs of the largest weight gradient
     OSUD_TRY(dev_alloc(W, &b.splitk, b.splitk_elems * 4, false));

@@ -55,7 +55,7 @@ int launch_final_bwd(const float* h, const float* stats, const float* dout, cons
 int launch_cond_bwd(int prec, const float* dsb, const float* b, const int64_t* y, int table_rows, float* db_out,
                     void* db_te, float* dtable, int N, int Np, int D, hipStream_t st);
 int launch_silu_bwd(int prec, const float* dth, const void* z, void* dz, size_t n, hipStream_t st);
-int launch_mask_rows(int prec, float* a, void* a_te, int N, int Np, int C, hipStream_t st);
+int launch_mask_rows(int prec, float* a, void* a_te, int N, int Np, int C, hipStream_t st, int ld = 0);  // ld > C: a column slice
 int launch_unpad_rows(const float* src, int ld_src, float* dst, int cols, int rows, hipStream_t st);
 int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_t st);
 

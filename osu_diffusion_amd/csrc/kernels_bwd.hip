@@ -377,16 +377,17 @@ __global__ void silu_bwd_kernel(const float* __restrict__ dth, const TE* __restr
 
 // zero rows >= N of an f32 [Np][C] matrix and emit the TE copy (padding samples carry no gradient)
 template <typename TE>
-__global__ void mask_rows_kernel(float* __restrict__ a, TE* __restrict__ a_te, int N, int Np, int C) {
+__global__ void mask_rows_kernel(float* __restrict__ a, TE* __restrict__ a_te, int N, int Np, int C, int ld) {
   const size_t total = (size_t)Np * C;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int n = (int)(i / C);
-    float v = a[i];
+    const size_t j = (size_t)n * ld + (i % C);  // a column slice of a wider matrix when ld > C
+    float v = a[j];
     if (n >= N) {
       v = 0.f;
-      a[i] = 0.f;
+      a[j] = 0.f;
     }
-    store_elem(a_te + i, v);
+    store_elem(a_te + j, v);
   }
 }
 
@@ -516,13 +517,14 @@ int launch_silu_bwd(int prec, const float* dth, const void* z, void* dz, size_t 
   return OSUD_OK;
 }
 
-int launch_mask_rows(int prec, float* a, void* a_te, int N, int Np, int C, hipStream_t st) {
+int launch_mask_rows(int prec, float* a, void* a_te, int N, int Np, int C, hipStream_t st, int ld) {
+  if (ld <= 0) ld = C;
   const size_t total = (size_t)Np * C;
   const int grid = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   if (prec == OSUD_PREC_BF16)
-    hipLaunchKernelGGL((mask_rows_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a, (bf16_t*)a_te, N, Np, C);
+    hipLaunchKernelGGL((mask_rows_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a, (bf16_t*)a_te, N, Np, C, ld);
   else
-    hipLaunchKernelGGL((mask_rows_kernel<float>), dim3(grid), dim3(256), 0, st, a, (float*)a_te, N, Np, C);
+    hipLaunchKernelGGL((mask_rows_kernel<float>), dim3(grid), dim3(256), 0, st, a, (float*)a_te, N, Np, C, ld);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }

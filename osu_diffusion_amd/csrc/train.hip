@@ -129,6 +129,23 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     return OSUD_OK;
   };
   auto G = [&](const std::string& k) { return grad_of(m, k); };
+  // Phased invocation (the host reduces / updates finished slices between phases): the adaLN weight and bias gradients of a
+  // block are produced inside that block's phase -- its 6D modulation-gradient columns are final by then -- so that they can
+  // travel with the block's slice instead of waiting for the last phase.  A one-call backward keeps the single batched GEMM.
+  const bool per_block_ada = !(phase_lo == 0 && phase_hi == L + 1);
+  char* dada_te = (char*)w.dada_te;
+  char* dada_t = dada_te + (size_t)Np * AC * es;  // [AC][Np]
+  auto ada_slice = [&](int l) -> int {  // l == L: the final layer's two chunks
+    const std::string key = l < L ? "blocks." + std::to_string(l) + ".adaLN_modulation.1." : "final_layer.adaLN_modulation.1.";
+    const int rows = l < L ? 6 * D : 2 * D;
+    const size_t off = (size_t)l * 6 * D;
+    OSUD_TRY(launch_mask_rows(prec, w.dada + off, dada_te + off * es, N, Np, rows, st, AC));
+    OSUD_TRY(launch_transpose(prec, dada_te + off * es, AC, dada_t + off * Np * es, Np, Np, rows, w.dbada + off, st));
+    OSUD_TRY(gemm(m, EPI_NONE_F32, dada_t + off * Np * es, Np, w.sb_t, Np, rows, D, Np, G(key + "weight"), D, nullptr, st));
+    SegBatch cb(SEG_COPY, prec, st);
+    OSUD_TRY(cb.add(w.dbada + off, G(key + "bias"), (size_t)rows / 4));
+    return cb.flush();
+  };
 
   float* dh = m->bw_dh_cur ? w.dhB : w.dhA;
   float* dh_other = m->bw_dh_cur ? w.dhA : w.dhB;
@@ -162,6 +179,11 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
   OSUD_TRY(launch_final_bwd(fin.h_in, fin.stats1, dout, m->w_f, m->ada, AC, L * 6 * D, L * 6 * D + D, dh, w.dada,
                             G("final_layer.linear.weight"), G("final_layer.linear.bias"), N, T, Tp, D, m->C2, st));
     OSUD_TRY(dbg_sync(st, "final_bwd"));
+    if (per_block_ada) {
+      OSUD_TRY(launch_transpose(prec, m->sb, D, w.sb_t, Np, Np, D, nullptr, st));  // silu(b)^T [D][Np], shared by every slice
+      OSUD_TRY(ada_slice(L));
+      OSUD_TRY(dbg_sync(st, "wgrad ada (final layer)"));
+    }
 
   }  // phase 0
 
@@ -231,6 +253,10 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     }
     OSUD_TRY(dbg_sync(st, "ln1 bwd"));
     std::swap(dh, dh_other);  // dh = grad wrt h_in
+    if (per_block_ada) {
+      OSUD_TRY(ada_slice(l));
+      OSUD_TRY(dbg_sync(st, "wgrad ada (block)"));
+    }
   }
 
   m->bw_dh_cur = dh == w.dhB ? 1 : 0;
@@ -248,8 +274,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
 
   // ---- conditioning path: ada = silu(b) Wada^T + bada ; b = t_emb + table[y]
   {
-    char* dada_te = (char*)w.dada_te;
-    char* dada_t = dada_te + (size_t)Np * AC * es;  // [AC][Np]
+    if (!per_block_ada) {
     OSUD_TRY(launch_mask_rows(prec, w.dada, dada_te, N, Np, AC, st));
     OSUD_TRY(launch_transpose(prec, dada_te, AC, dada_t, Np, Np, AC, w.dbada, st));
     OSUD_TRY(launch_transpose(prec, m->sb, D, w.small_t1, Np, Np, D, nullptr, st));  // sb^T [D][Np]
@@ -265,6 +290,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
       }
       OSUD_TRY(cb.flush());
     }
+    }  // else: every slice was converted and differentiated in its own phase; dada_te is complete
     OSUD_TRY(wgrad(m, dada_te, m->w_ada_t, Np, D, AC, w.dsb, D, st));  // K = 6(L+1)D: split over workgroups
     OSUD_TRY(launch_cond_bwd(prec, w.dsb, m->bvec, m->last_y, m->cfg.table_rows, w.db, w.db_te,
                              G("y_embedder.embedding_table.weight"), N, Np, D, st));

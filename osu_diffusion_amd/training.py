@@ -141,23 +141,23 @@ def native_backward(model, dout, phases=None):
 
 def overlap_slices(arena, depth):
     """Element ranges of the flat gradient arena in the order they become final during the phased backward:
-    ("block", l, lo, hi) right after block l's phase — its 8 attention/MLP tensors are contiguous — then the ranges that
-    need the last phase: ("tail", ...) = embedders, every adaLN pair, final layer, and ("table", ...) = the class table,
-    whose gradient is row-sparse and is exchanged as rows (exchange_table_rows) instead of densely."""
+    ("final", depth, lo, hi) right after phase 0 (final linear + its adaLN pair), ("block", l, lo, hi) right after block l's
+    phase — its 8 attention/MLP tensors and its adaLN pair are contiguous (the library differentiates the adaLN slice of a
+    block inside that block's phase when it is driven phase by phase) — then what needs the last phase: ("tail", ...) =
+    the embedders, and ("table", ...) = the class table, whose gradient is row-sparse and is exchanged as rows
+    (exchange_table_rows) instead of densely."""
     off = {n: (int(o), int(o + s)) for n, o, s in zip(arena.names, arena.offsets[:-1], arena.sizes)}
-    blocks, tail = [], []
+    blocks = []
     for l in range(depth):
         lo = off[f"blocks.{l}.attn.in_proj_weight"][0]
-        hi = off[f"blocks.{l}.mlp.fc2.bias"][1]
+        hi = off[f"blocks.{l}.adaLN_modulation.1.bias"][1]
         blocks.append(("block", l, lo, hi))
-        tail.append(("tail", l, off[f"blocks.{l}.adaLN_modulation.1.weight"][0], off[f"blocks.{l}.adaLN_modulation.1.bias"][1]))
     t_lo, t_hi = off["y_embedder.embedding_table.weight"]
     first_block = off["blocks.0.attn.in_proj_weight"][0]
-    head = [("tail", -1, 0, t_lo), ("table", -1, t_lo, t_hi)]
+    tail = [("tail", -1, 0, t_lo), ("table", -1, t_lo, t_hi)]
     if t_hi < first_block:
-        head.append(("tail", -1, t_hi, first_block))
-    tail = head + tail
-    tail.append(("tail", depth, off["final_layer.linear.weight"][0], arena.total))
+        tail.append(("tail", -1, t_hi, first_block))
+    tail.append(("final", depth, off["final_layer.linear.weight"][0], arena.total))
     covered = sorted((lo, hi) for _, _, lo, hi in blocks + tail)
     assert covered[0][0] == 0 and covered[-1][1] == arena.total and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
     return blocks, tail
@@ -207,6 +207,8 @@ def backward_with_overlapped_allreduce(model, dout, group=None, force=False, on_
     reduce = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)) if active else (lambda t: None)
     handles = []
     dout = native_backward(model, dout, phases=(0, 0))
+    _, _, f_lo, f_hi = next(s for s in tail if s[0] == "final")
+    handles.append(reduce(arena.grads[f_lo:f_hi]))
     for p in range(1, depth + 1):
         native_backward(model, dout, phases=(p, p))
         _, _, lo, hi = blocks[depth - p]
@@ -220,7 +222,7 @@ def backward_with_overlapped_allreduce(model, dout, group=None, force=False, on_
         if h is not None:
             h.wait()
     if on_blocks_reduced is not None:
-        on_blocks_reduced([(lo, hi) for _, _, lo, hi in blocks])
+        on_blocks_reduced([(lo, hi) for _, _, lo, hi in blocks] + [(f_lo, f_hi)])
     if active:
         _, _, t_lo, t_hi = next(s for s in tail if s[0] == "table")
         rows = dict(model.named_parameters())["y_embedder.embedding_table.weight"].shape[0]
@@ -306,9 +308,10 @@ class NativeTrainer:
         self.embed_only = False
         self.table_extra_steps = 0
         self.force_phased = os.environ.get("OSUD_FORCE_PHASED", "0") == "1"  # exercise the phased path on 1 GPU
-        # one GPU: the HBM-bound AdamW+EMA of a block's slice runs on a side stream under the MFMA-bound backward of the blocks
-        # in front of it (same arithmetic, same result); OSUD_ADAMW_OVERLAP=0 runs it after the backward instead
-        self.overlap_adamw = os.environ.get("OSUD_ADAMW_OVERLAP", "1") == "1"
+        # one GPU, OSUD_ADAMW_OVERLAP=1: the HBM-bound AdamW+EMA of a block's slice runs on a side stream under the MFMA-bound
+        # backward of the blocks in front of it (same arithmetic, same result).  Measured worth 0.2 % — off by default, the
+        # one-call backward keeps the adaLN weight gradients in a single batched GEMM
+        self.overlap_adamw = os.environ.get("OSUD_ADAMW_OVERLAP", "0") == "1"
         self._side = None
         import torch.distributed as dist
 

@@ -69,14 +69,18 @@ def test_overlap_slices_cover_the_arena_exactly_once():
     m = DiT(depth=3, hidden_size=128, num_heads=2, context_size=144, num_classes=4)
     arena = ParamArena(m)
     blocks, tail = overlap_slices(arena, 3)
-    assert [b[1] for b in blocks] == [0, 1, 2] and [t[0] for t in tail] == ["tail", "table"] + ["tail"] * 4
+    kinds = [t[0] for t in tail]
+    assert [b[1] for b in blocks] == [0, 1, 2] and kinds[:2] == ["tail", "table"] and kinds[-1] == "final"
     seen = torch.zeros(arena.total, dtype=torch.int32)
     for _, _, lo, hi in blocks + tail:
         seen[lo:hi] += 1
     assert bool((seen == 1).all())
     names = dict(zip(arena.names, zip(arena.offsets[:-1], arena.sizes)))
-    lo, n = names["blocks.1.mlp.fc1.weight"]
-    assert blocks[1][2] <= lo and lo + n <= blocks[1][3]
+    for key in ("blocks.1.mlp.fc1.weight", "blocks.1.adaLN_modulation.1.weight", "blocks.1.adaLN_modulation.1.bias"):
+        lo, n = names[key]  # a block's adaLN pair travels with the block (differentiated inside the block's phase)
+        assert blocks[1][2] <= lo and lo + n <= blocks[1][3]
+    lo, n = names["final_layer.adaLN_modulation.1.weight"]
+    assert tail[-1][2] <= lo and lo + n <= tail[-1][3]
     lo, n = names["y_embedder.embedding_table.weight"]
     assert tail[1] == ("table", -1, int(lo), int(lo + n))  # exchanged as rows, not densely
 
