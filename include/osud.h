@@ -181,6 +181,13 @@ int osud_adamw_ema_step(float* params, const float* grads, float* exp_avg, float
 
 /* ------------------------------------------------------------------ op-level entry points
  * (the fused building blocks, exported so each can be parity-tested on its own) */
+/* Process-wide switch for multi-round GEMM launches (more output tiles than compute units): 1 = workgroups draw their tiles
+ * from per-XCD ticket queues instead of a fixed stride, so that a launch does not wait for workgroups whose compute unit is
+ * held by another kernel (RCCL collectives overlapped with the backward: 8 held CUs stretch a fixed-stride launch 1.5x, a
+ * queued one 1.1x); 0 = fixed stride (0.7 % faster when the GPU is not shared); -1 = follow the environment variable
+ * OSUD_GEMM_DYNAMIC (default 0).  Results are identical either way.  Data-parallel trainers switch it on. */
+int osud_set_gemm_dynamic_tiles(int on);
+
 /* out[y][x] = epilogue(sum_k Y[y][k] * X[x][k]); see csrc/gemm.h for the epilogue codes. */
 int osud_op_gemm(int precision, int epilogue, const void* Y, int ldy, const void* X, int ldx, int My, int Nx, int K,
                  void* out, int ldo, const float* bias, const float* gate, int ld_gate, int rows_per_sample,

@@ -64,6 +64,7 @@ _SIGNATURES = {
     "osud_adamw_ema_step": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _sz, _sz, _f, _vp]),
     "osud_op_gemm": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "osud_op_convert": (_i, [_i, _vp, _vp, _sz, _vp]),
+    "osud_set_gemm_dynamic_tiles": (_i, [_i]),
     "osud_op_attention": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
 }
 

@@ -25,6 +25,7 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 }
 
 int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
+  OSUD_TRY(gemm_sched_init());  // tile-queue counters: must exist before any launch is captured into a graph
   if (N <= m->cap_N && T <= m->cap_T && (!training || m->training)) return OSUD_OK;
   // grow: free the old set, allocate for the max of old/new
   for (void* p : m->ws_owned) (void)hipFree(p);
@@ -516,6 +517,11 @@ extern "C" int osud_sample_loop_inpaint(osud_dit* m, const osud_sched* s, int mo
     m->graph_valid = true;
   }
   for (int k = 0; k < n_steps; ++k) OSUD_HIP(hipGraphLaunch(m->graph_exec, st));
+  return OSUD_OK;
+}
+
+extern "C" int osud_set_gemm_dynamic_tiles(int on) {
+  gemm_set_dynamic_tiles(on);
   return OSUD_OK;
 }
 

@@ -57,10 +57,13 @@ struct GemmP {
   float* colpart;     // EPI_GELUGRAD_TE, optional: f32 [R][Nx] partial column sums of the OUTPUT (before rounding), one row per wave-row
                       // of the grid (R = My / rows per wave, reported through colpart_rows); summed over R they are the bias gradient
   int* colpart_rows;  // host pointer, written at launch
+  unsigned* sched;    // set by the launcher for multi-round launches: {ticket, done} counters of the dynamic tile queue
   int tile_order;  // 0/1 = plain x-fastest runs per XCD (default), 2 = banded per XCD (fewer weight re-reads, not faster)
 };
 
 int launch_gemm(int prec, int epi, const GemmP& p, hipStream_t st);
+void gemm_set_dynamic_tiles(int on);  // 1 / 0, -1 = follow the OSUD_GEMM_DYNAMIC environment variable (default off)
+int gemm_sched_init();  // allocates the tile-queue counters (call outside stream capture; launch_gemm does it lazily otherwise)
 // out[i] = sum_s part[s * stride + i], i < n (n % 4 == 0): deterministic split-K combine
 int launch_splitk_reduce(const float* part, int splits, size_t stride, float* out, size_t n, hipStream_t st);
 

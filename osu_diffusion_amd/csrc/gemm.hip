@@ -1,4 +1,6 @@
 // See gemm.h for the design.  gfx950 only.
+#include <atomic>
+
 #include "gemm.h"
 
 #include <stdlib.h>
@@ -274,18 +276,56 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
     const int c = (lane & 7) ^ ((R >> 1) & 7);
     dma_off[q] = (uint32_t)((piece * 8 < G::BM ? (size_t)R * ldy_b : (size_t)(R - G::BM) * ldx_b) + c * 16);
   }
-  // ---- prologue: fill NSTAGE-1 stages
-  int ic_tile = first, ic_kt = 0;  // issue cursor
+  // ---- tile sequence.  The first tile of a workgroup is static (`first`: XCD-contiguous runs).  Launches with more tiles
+  // than workgroups draw every later tile from a ticket counter (p.sched), two tiles ahead of the one being computed, so that a
+  // workgroup that starts late or runs slowly -- a collective's or an optimizer's kernel holding its compute unit -- takes fewer
+  // tiles instead of stretching the launch (measured: 8 held CUs cost a static launch 1.5x).  The ticket for tile j+2 is
+  // requested (wave 0, lane 0) at the top of tile j, has returned by the vmcnt(0) before tile j's epilogue, and is published
+  // through LDS across the epilogue barrier; the ticket for the second tile is requested before the prologue, is older than
+  // every LDS-DMA piece and so has returned after the first slab's wait.
+  constexpr bool kDynFits = G::NSTAGE * G::STAGE + 64 <= G::LDS_MAX;
+  const bool dyn = kDynFits && p.sched != nullptr;
+  volatile __attribute__((address_space(3))) uint32_t* sched_lds =
+      reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>((lds_void*)smem) + (G::NSTAGE * G::STAGE) / 4;
+  const bool ticket_lane = dyn && wave == 0 && lane == 0;
+  // One queue per XCD (16-bit fields of p.sched[0..3], two per word; [8] counts finished workgroups): ticket k of XCD x is the
+  // k-th tile of the runs a static schedule would give that XCD in rounds 1, 2, ... -- undisturbed, every XCD's L2 keeps seeing
+  // the same contiguous panels (one global queue scattered them: the K = 3072 launches got 25 % slower).  Queues are not
+  // stolen from: tickets run two tiles ahead of the arithmetic, so a workgroup that finds its queue empty cannot tell a
+  // neighbour in trouble from one about to finish (stealing on a snapshot of the counters made undisturbed launches 15-30 %
+  // slower); kernels that share the GPU spread over the XCDs round-robin like these workgroups do.
+  const int xcd = blockIdx.x & 7, per = G8 >> 3;
+  auto id_of = [&](uint32_t word) -> int {
+    const uint32_t k = (word >> (16 * (xcd & 1))) & 0xffffu;
+    return (int)((uint32_t)G8 * (1u + k / (uint32_t)per) + (uint32_t)(xcd * per) + k % (uint32_t)per);  // >= ntiles: queue empty
+  };
+  uint32_t tk_start = 0, tk = 0;
+  // (compiler-visible atomics, not inline asm: an asm result may be copied to another register before it has returned.  The
+  // compiler knows nothing of the asm-issued LDS-DMA pieces, so where it needs the ticket it waits for vmcnt(0) -- both
+  // places of use sit right behind a drain of this wave's queue anyway.  gemm.hip is built with LLVM's atomic optimizer off:
+  // it rewrites a uniform-address atomic into "one lane + readfirstlane" and reads the result at once)
+  auto take_ticket = [&](uint32_t& dst) {
+    if (ticket_lane)
+      dst = __hip_atomic_fetch_add(p.sched + (xcd >> 1), 1u << (16 * (xcd & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto resolve = [&](uint32_t word) -> int {
+    const int id = id_of(word);
+    return id < ntiles ? id : 0x7fffffff;
+  };
+  take_ticket(tk_start);
+  int t_cur = first, t_nxt = dyn ? 0x7fffffff : first + G8;
+  int ic_rel = 0, ic_kt = 0;  // issue cursor: which of (t_cur, t_nxt) it is in, and the slab
   int issued = 0, consumed = 0;
   auto issue_next = [&]() {
-    if (ic_tile < ntiles) {
+    const int ic_tile = ic_rel == 0 ? t_cur : t_nxt;
+    if (ic_rel < 2 && ic_tile < ntiles) {
       const char *gy, *gx;
       tile_ptrs(ic_tile, ic_kt, gy, gx);
       stage_slab<G>(gy, gx, lds0 + (uint32_t)((issued % G::NSTAGE) * G::STAGE), dma_off, wave);
       ++issued;
       if (++ic_kt == nk) {
         ic_kt = 0;
-        ic_tile += G8;
+        ++ic_rel;
       }
     }
   };
@@ -297,9 +337,11 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
   uint64_t tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const uint64_t tk0 = __builtin_readcyclecounter();
 #endif
-  for (int tile = first; tile < ntiles; tile += G8) {
+  bool first_tile = true;
+  while (t_cur < ntiles) {
     int ty, tx;
-    tm.coords(tile, ty, tx);
+    tm.coords(t_cur, ty, tx);
+    take_ticket(tk);  // for the tile after next
     f32x16 acc[RY][RX];
 #pragma unroll
     for (int i = 0; i < RY; ++i)
@@ -322,7 +364,12 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
 #ifdef OSUD_GEMM_TIMING
       const uint64_t tt1 = __builtin_readcyclecounter();
 #endif
+      if (dyn && first_tile && kt == 0) {  // the second tile's ticket (older than every piece waited for above)
+        if (ticket_lane) sched_lds[1] = (uint32_t)resolve(tk_start);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_s_barrier();  // every wave's share landed; the stage consumed last round is free again
+      if (dyn && first_tile && kt == 0) t_nxt = __builtin_amdgcn_readfirstlane((int)sched_lds[1]);
 #ifdef OSUD_GEMM_TIMING
       const uint64_t tt2 = __builtin_readcyclecounter();
 #endif
@@ -352,6 +399,11 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
 #endif
     wait_vm<0>();
     landed = issued - consumed;
+    int t_nxt2 = t_nxt + G8;
+    if (dyn) {  // the ticket requested at the top of this tile has returned: publish it across the epilogue barrier
+      if (ticket_lane) sched_lds[0] = (uint32_t)resolve(tk);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     // The stage consumed last holds nothing the next tile needs (its prefetch sits in the other stages): it becomes
     // the epilogue patch area, once every wave has finished reading the last slab from it.  The barrier at the top
     // of the next tile's first slab orders the patch reads before the LDS-DMA that refills the stage.
@@ -359,6 +411,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
     const uint64_t te1 = __builtin_readcyclecounter();
 #endif
     __builtin_amdgcn_s_barrier();
+    if (dyn) t_nxt2 = __builtin_amdgcn_readfirstlane((int)sched_lds[0]);
 #ifdef OSUD_GEMM_TIMING
     const uint64_t te2 = __builtin_readcyclecounter();
     tsum[6] += te1 - te0;  // drain wait before the epilogue
@@ -541,7 +594,18 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
 #ifdef OSUD_GEMM_TIMING
     tsum[5] += __builtin_readcyclecounter() - te0;  // epilogue (incl. the drain wait and barrier)
 #endif
+    t_cur = t_nxt;
+    t_nxt = t_nxt2;
+    if (ic_rel > 0) --ic_rel;
+    first_tile = false;
   }  // tile loop
+  if (ticket_lane) {  // the last workgroup out re-arms the counters for the next launch that borrows this slot
+    const unsigned done = __hip_atomic_fetch_add(p.sched + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x - 1) {
+#pragma unroll
+      for (int y = 0; y < 9; ++y) __hip_atomic_store(p.sched + y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 #ifdef OSUD_GEMM_TIMING
   if (p.gate != nullptr && lane == 0 && blockIdx.x < 16) {
     float* dbg = const_cast<float*>(p.gate) + (blockIdx.x * G::NW + wave) * 8;
@@ -563,9 +627,30 @@ int num_cus() {
   return n;
 }
 
-template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(const GemmP& p, hipStream_t st) {
+// Counter sets ({8 per-XCD tickets, done}, 64-byte slots) of the dynamic tile queue: zeroed once, re-armed by the last workgroup of every launch that used one.  Launches
+// take slots round-robin; kernels on one stream run in order, so a slot is idle again long before it comes round.
+constexpr int kSchedSlots = 256;
+// Off by default: alone on the GPU the queue costs 0.7 % of a training step (a one-off drain for the first ticket, less regular
+// tile order).  Data-parallel training switches it on (osud_set_gemm_dynamic_tiles), where collectives share the compute units.
+std::atomic<int> g_dynamic_tiles{-1};  // -1: follow OSUD_GEMM_DYNAMIC
+unsigned* g_sched_pool = nullptr;
+int gemm_sched_init_impl() {
+  if (g_sched_pool) return OSUD_OK;
+  OSUD_HIP(hipMalloc(&g_sched_pool, kSchedSlots * 16 * sizeof(unsigned)));
+  OSUD_HIP(hipMemset(g_sched_pool, 0, kSchedSlots * 16 * sizeof(unsigned)));
+  return OSUD_OK;
+}
+unsigned* sched_slot() {
+  static std::atomic<unsigned> seq{0};
+  return g_sched_pool ? g_sched_pool + 16 * (seq.fetch_add(1) % kSchedSlots) : nullptr;
+}
+
+template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(const GemmP& p_in, hipStream_t st) {
   using G = Geo<WY, WX, RY, RX>;
-  const size_t lds = (size_t)G::NSTAGE * G::STAGE;  // stage ring (the epilogue patches borrow the free stage)
+  GemmP p = p_in;
+  const size_t ring = (size_t)G::NSTAGE * G::STAGE;  // stage ring (the epilogue patches borrow the free stage)
+  constexpr bool kDynFits = G::NSTAGE * G::STAGE + 64 <= G::LDS_MAX;
+  const size_t lds = ring + (kDynFits ? 64 : 0);
   static bool attr_set = false;
   if (!attr_set) {
     OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX>),
@@ -577,6 +662,13 @@ template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(con
   int grid = num_cus() * G::WGS / splits;  // persistent workgroups: WGS per CU (LDS-limited), shared by the K splits
   if (grid < 1) grid = 1;
   if (grid > ntiles) grid = ntiles;
+  {
+    static const bool dyn_env = [] { const char* e = getenv("OSUD_GEMM_DYNAMIC"); return e && e[0] == '1'; }();
+    const int dyn_set = g_dynamic_tiles.load(std::memory_order_relaxed);
+    const bool dyn_on = dyn_set >= 0 ? dyn_set != 0 : dyn_env;
+    const int nk = (int)((size_t)p.K * sizeof(TE) / SLAB);
+    p.sched = (dyn_on && kDynFits && splits == 1 && ntiles > grid && grid % 8 == 0 && nk >= G::NSTAGE && ntiles / 8 + 2 * grid < 60000) ? sched_slot() : nullptr;
+  }
   hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY, RX>), dim3(grid, splits), dim3(G::NT), lds, st, p);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
@@ -641,7 +733,14 @@ template <typename TE> int launch_e(int epi, const GemmP& p, hipStream_t st) {
 
 }  // namespace
 
+int gemm_sched_init() { return gemm_sched_init_impl(); }
+void gemm_set_dynamic_tiles(int on) { g_dynamic_tiles.store(on < 0 ? -1 : (on != 0), std::memory_order_relaxed); }
+
 int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
+  if (!g_sched_pool) {  // normally done at handle creation; never reached while a stream is being captured
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) OSUD_TRY(gemm_sched_init_impl());
+  }
   GemmP p = p_in;
   {
     static const int order = [] { const char* e = getenv("OSUD_GEMM_ORDER"); return e ? atoi(e) : 0; }();

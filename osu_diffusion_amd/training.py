@@ -315,6 +315,9 @@ class NativeTrainer:
         self._side = None
         import torch.distributed as dist
 
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and "OSUD_GEMM_DYNAMIC" not in os.environ:
+            # collectives will share the compute units with the backward: let multi-round GEMM launches queue their tiles
+            _lib.check(_lib.lib().osud_set_gemm_dynamic_tiles(1))
         if broadcast_init and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.broadcast(self.arena.flat, 0, group=group)  # DDP ctor: rank 0's init wins (train.py:152)
         self.ema_arena.flat.copy_(self.arena.flat)  # update_ema(ema, model, decay=0), train.py:194-198

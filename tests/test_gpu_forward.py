@@ -325,3 +325,31 @@ def test_in_kernel_philox_noise_is_standard_normal_and_reproducible():
     b = d.p_sample_loop(m.forward, z.shape, z, model_kwargs=kw, seed=123)
     c2 = d.p_sample_loop(m.forward, z.shape, z, model_kwargs=kw, seed=124)
     assert torch.equal(a, b) and not torch.equal(a, c2) and torch.isfinite(a).all()
+
+
+def test_gemm_tile_queue_equals_fixed_stride():
+    """Multi-round launches (more tiles than compute units) with the per-XCD ticket queues switched on give the same bits as the
+    fixed-stride schedule, launch after launch (the last workgroup re-arms the counters), and match an fp32 reference."""
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(21)
+    try:
+        for (My, Nx, K) in [(32768, 768, 256), (16384, 2304, 768), (32768, 3072, 128)]:
+            y = torch.randn(My, K, generator=g).to(DEV)
+            x = (torch.randn(Nx, K, generator=g) / K ** 0.5).to(DEV)
+            bias = torch.randn(Nx, generator=g).to(DEV)
+            yb, xb = to_elem(_lib.PREC_BF16, y), to_elem(_lib.PREC_BF16, x)
+            outs = {}
+            for mode in (0, 1, 1, 1):
+                _lib.check(L.osud_set_gemm_dynamic_tiles(mode))
+                out = torch.empty(My * Nx * 2, dtype=torch.uint8, device=DEV)
+                _lib.check(L.osud_op_gemm(_lib.PREC_BF16, _lib.EPI_BIAS_TE, _lib.ptr(yb), K, _lib.ptr(xb), K, My, Nx, K, _lib.ptr(out), Nx,
+                                          _lib.ptr(bias), None, 0, 0, 0, None))
+                res = from_elem(_lib.PREC_BF16, out, (My, Nx))
+                if mode in outs:
+                    assert torch.equal(res, outs[mode])
+                outs[mode] = res
+            assert torch.equal(outs[0], outs[1])
+            ref = from_elem(_lib.PREC_BF16, yb, (My, K)) @ from_elem(_lib.PREC_BF16, xb, (Nx, K)).t() + bias
+            assert maxdiff(outs[1], ref) <= 1e-2 * float(ref.abs().max())
+    finally:
+        _lib.check(L.osud_set_gemm_dynamic_tiles(-1))
