@@ -269,6 +269,8 @@ def bench_train(args, world, rank, dev):
         res["cpu_baseline"] = cpu_baseline_train(model, args, batches[0])
     del trainer, model
     torch.cuda.empty_cache()
+    from osu_diffusion_amd import _lib
+    _lib.check(_lib.lib().osud_set_gemm_dynamic_tiles(-1))  # the data-parallel trainer queues GEMM tiles; sampling has no collectives
     return res
 
 
