@@ -62,6 +62,7 @@ struct GemmP {
 };
 
 int launch_gemm(int prec, int epi, const GemmP& p, hipStream_t st);
+bool gemm_dynamic_tiles_on();            // the effective setting
 void gemm_set_dynamic_tiles(int on);  // 1 / 0, -1 = follow the OSUD_GEMM_DYNAMIC environment variable (default off)
 int gemm_sched_init();  // allocates the tile-queue counters (call outside stream capture; launch_gemm does it lazily otherwise)
 // out[i] = sum_s part[s * stride + i], i < n (n % 4 == 0): deterministic split-K combine

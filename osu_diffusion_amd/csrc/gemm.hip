@@ -734,6 +734,11 @@ template <typename TE> int launch_e(int epi, const GemmP& p, hipStream_t st) {
 }  // namespace
 
 int gemm_sched_init() { return gemm_sched_init_impl(); }
+bool gemm_dynamic_tiles_on() {
+  static const bool dyn_env = [] { const char* e = getenv("OSUD_GEMM_DYNAMIC"); return e && e[0] == '1'; }();
+  const int v = g_dynamic_tiles.load(std::memory_order_relaxed);
+  return v >= 0 ? v != 0 : dyn_env;
+}
 void gemm_set_dynamic_tiles(int on) { g_dynamic_tiles.store(on < 0 ? -1 : (on != 0), std::memory_order_relaxed); }
 
 int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {

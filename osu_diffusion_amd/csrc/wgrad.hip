@@ -14,6 +14,8 @@
 // fall into 4 different 64-byte bank segments.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "gemm.h"
 
 namespace osud {
@@ -106,6 +108,8 @@ struct WgradP {
   float* out;     // [splits][Ny][Nx] fp32
   int split_k;
   size_t split_stride;
+  unsigned* queue;  // shared-GPU mode (256x256 geometry, splits > 1): [tile] chunk tickets, [63] finished workgroups; else null
+  int chunk;        // stages per chunk
 };
 
 template <int WY, int WX, int RY, int RX>
@@ -165,6 +169,120 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
   for (int g = 0; g < 4; ++g) pw[g] = patch + frow * 128 + (((2 * g + fhalf) ^ (frow & 7)) << 4);
   const uint32_t pr = patch + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
 
+  f32x16 acc[RY][RX];
+  auto clear_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < RY; ++i)
+#pragma unroll
+      for (int j = 0; j < RX; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+  auto compute_stage = [&](uint32_t so) {
+    TFrag<RY, RX> f0, f1;
+    read_frags<RY, RX, 0, G::ROWY, G::ROWX>(f0, ya, xa, so);
+    read_frags<RY, RX, 1, G::ROWY, G::ROWX>(f1, ya, xa, so);
+    if constexpr (RY + RX == 6) { OSUD_WG_WAIT(12); } else { OSUD_WG_WAIT(8); }
+    mma_frags<RY, RX>(acc, f0);
+    read_frags<RY, RX, 2, G::ROWY, G::ROWX>(f0, ya, xa, so);
+    if constexpr (RY + RX == 6) { OSUD_WG_WAIT(12); } else { OSUD_WG_WAIT(8); }
+    mma_frags<RY, RX>(acc, f1);
+    read_frags<RY, RX, 3, G::ROWY, G::ROWX>(f1, ya, xa, so);
+    if constexpr (RY + RX == 6) { OSUD_WG_WAIT(12); } else { OSUD_WG_WAIT(8); }
+    mma_frags<RY, RX>(acc, f0);
+    OSUD_WG_WAIT(0);
+    mma_frags<RY, RX>(acc, f1);
+  };
+  // The MFMA leaves lane (frow, fhalf) with y = frow, x = 8g + 4*fhalf + {0..3}; every 32x32 block goes through the
+  // wave's 4 KiB LDS patch and comes back row-major (rows 8q + (lane>>3), x = 4*(lane&7)..+3) so that 8 lanes
+  // store one full 128-byte row segment (see gemm.hip's epilogue).
+  auto store_tile = [&](int ty, int tx) {
+#pragma unroll
+    for (int i = 0; i < RY; ++i) {
+      const int y0 = ty * G::BM + wy * RY * 32 + i * 32 + (lane >> 3);
+#pragma unroll
+      for (int j = 0; j < RX; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+          v[0] = acc[i][j][4 * g + 0]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
+          ds_write16(pw[g], v);
+        }
+        f32x4 t[4];
+        t[0] = ds_read16f<0>(pr);
+        t[1] = ds_read16f<1024>(pr);
+        t[2] = ds_read16f<2048>(pr);
+        t[3] = ds_read16f<3072>(pr);
+        OSUD_WG_WAIT(0);
+        const int x = tx * G::BN + wx * RX * 32 + j * 32 + 4 * (lane & 7);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) store4(outp + (size_t)(y0 + 8 * q) * p.Nx + x, t[q][0], t[q][1], t[q][2], t[q][3]);
+      }
+    }
+  };
+
+  if constexpr (G::NSTAGE == 2) {
+    if (p.queue != nullptr) {
+      // ---- shared-GPU mode: the token axis of a tile is cut into chunks of p.chunk stages; the tile's split_k workgroups start
+      // on chunks 0..split_k-1 and draw every later chunk from the tile's ticket counter, accumulating in registers, so that a
+      // workgroup whose compute unit is held by another kernel leaves its share to the others instead of doubling the launch.
+      // With two stages the loop drains this wave's queue at every stage: the ticket requested behind the barrier of a chunk's
+      // first stage has returned by the wait of its second and is published through LDS (a word of the idle epilogue patch).
+      const int tile = blockIdx.x, ty = tile / ntx, tx = tile % ntx;
+      const int CH = p.chunk, nch = st_total / CH;  // the last chunk takes the remainder
+      auto chunk_len = [&](int c) { return c == nch - 1 ? st_total - c * CH : CH; };
+      volatile __attribute__((address_space(3))) uint32_t* word =
+          reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>((lds_void*)smem) + (G::NSTAGE * G::STAGE) / 4;
+      const bool ticket_lane = wave == 0 && lane == 0;
+      const char* gpt = reinterpret_cast<const char*>(p.P) + (size_t)ty * G::BM * 2;
+      const char* gqt = reinterpret_cast<const char*>(p.Q) + (size_t)tx * G::BN * 2;
+      int c_cur = blockIdx.y, c_nxt = 0x7fffffff;
+      int ic_rel = 0, ic_st = 0, issued = 0, consumed = 0;
+      auto issue_next = [&]() {
+        const int c = ic_rel == 0 ? c_cur : c_nxt;
+        if (ic_rel < 2 && c < nch) {
+          const size_t stage = (size_t)c * CH + ic_st;
+          stage_tokens<G>(gpt + stage * BKT * ldp_b, gqt + stage * BKT * ldq_b, lds0 + (uint32_t)((issued % G::NSTAGE) * G::STAGE),
+                          dma_off, wave);
+          ++issued;
+          if (++ic_st == chunk_len(c)) {
+            ic_st = 0;
+            ++ic_rel;
+          }
+        }
+      };
+      issue_next();
+      clear_acc();
+      uint32_t tk = 0;
+      while (c_cur < nch) {
+        const int len = chunk_len(c_cur);
+        for (int st = 0; st < len; ++st) {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          if (st == 1) {
+            if (ticket_lane) word[0] = (uint32_t)p.split_k + tk;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          }
+          __builtin_amdgcn_s_barrier();
+          if (st == 1) c_nxt = __builtin_amdgcn_readfirstlane((int)word[0]);
+          if (st == 0 && ticket_lane) tk = __hip_atomic_fetch_add(p.queue + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          issue_next();
+          compute_stage((uint32_t)((consumed % G::NSTAGE) * G::STAGE));
+          ++consumed;
+        }
+        c_cur = c_nxt;
+        c_nxt = 0x7fffffff;
+        if (ic_rel > 0) --ic_rel;
+      }
+      store_tile(ty, tx);
+      if (ticket_lane) {  // the last workgroup out re-arms the counters
+        const unsigned done = __hip_atomic_fetch_add(p.queue + 63, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x * gridDim.y - 1)
+          for (int i = 0; i < 64; ++i) __hip_atomic_store(p.queue + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      return;
+    }
+  }
+
   const int G8 = gridDim.x;
   int first;
   {
@@ -190,14 +308,7 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
 
   for (int tile = first; tile < ntiles; tile += G8) {
     const int ty = tile / ntx, tx = tile % ntx;
-    f32x16 acc[RY][RX];
-#pragma unroll
-    for (int i = 0; i < RY; ++i)
-#pragma unroll
-      for (int j = 0; j < RX; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
+    clear_acc();
     for (int st = 0; st < nst; ++st) {
       const int ahead = issued - consumed - 1;
       if (ahead <= 0 || G::NSTAGE == 2) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -205,47 +316,10 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       issue_next();
-      const uint32_t so = (uint32_t)((consumed % G::NSTAGE) * G::STAGE);
-      TFrag<RY, RX> f0, f1;
-      read_frags<RY, RX, 0, G::ROWY, G::ROWX>(f0, ya, xa, so);
-      read_frags<RY, RX, 1, G::ROWY, G::ROWX>(f1, ya, xa, so);
-      if constexpr (RY + RX == 6) { OSUD_WG_WAIT(12); } else { OSUD_WG_WAIT(8); }
-      mma_frags<RY, RX>(acc, f0);
-      read_frags<RY, RX, 2, G::ROWY, G::ROWX>(f0, ya, xa, so);
-      if constexpr (RY + RX == 6) { OSUD_WG_WAIT(12); } else { OSUD_WG_WAIT(8); }
-      mma_frags<RY, RX>(acc, f1);
-      read_frags<RY, RX, 3, G::ROWY, G::ROWX>(f1, ya, xa, so);
-      if constexpr (RY + RX == 6) { OSUD_WG_WAIT(12); } else { OSUD_WG_WAIT(8); }
-      mma_frags<RY, RX>(acc, f0);
-      OSUD_WG_WAIT(0);
-      mma_frags<RY, RX>(acc, f1);
+      compute_stage((uint32_t)((consumed % G::NSTAGE) * G::STAGE));
       ++consumed;
     }
-    // The MFMA leaves lane (frow, fhalf) with y = frow, x = 8g + 4*fhalf + {0..3}; every 32x32 block goes through the
-    // wave's 4 KiB LDS patch and comes back row-major (rows 8q + (lane>>3), x = 4*(lane&7)..+3) so that 8 lanes
-    // store one full 128-byte row segment (see gemm.hip's epilogue).
-#pragma unroll
-    for (int i = 0; i < RY; ++i) {
-      const int y0 = ty * G::BM + wy * RY * 32 + i * 32 + (lane >> 3);
-#pragma unroll
-      for (int j = 0; j < RX; ++j) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 v;
-          v[0] = acc[i][j][4 * g + 0]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
-          ds_write16(pw[g], v);
-        }
-        f32x4 t[4];
-        t[0] = ds_read16f<0>(pr);
-        t[1] = ds_read16f<1024>(pr);
-        t[2] = ds_read16f<2048>(pr);
-        t[3] = ds_read16f<3072>(pr);
-        OSUD_WG_WAIT(0);
-        const int x = tx * G::BN + wx * RX * 32 + j * 32 + 4 * (lane & 7);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) store4(outp + (size_t)(y0 + 8 * q) * p.Nx + x, t[q][0], t[q][1], t[q][2], t[q][3]);
-      }
-    }
+    store_tile(ty, tx);
   }
 }
 
@@ -300,6 +374,18 @@ int num_cus_w() {
   return n;
 }
 
+// counter sets of the chunk queues (64 words each: [tile] tickets, [63] finished workgroups), re-armed by the last workgroup out
+constexpr int kQueueSlots = 64;
+unsigned* g_queue_pool = nullptr;
+unsigned* queue_slot() {
+  static std::atomic<unsigned> seq{0};
+  if (!g_queue_pool) {
+    if (hipMalloc(&g_queue_pool, kQueueSlots * 64 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(g_queue_pool, 0, kQueueSlots * 64 * sizeof(unsigned)) != hipSuccess) return nullptr;
+  }
+  return g_queue_pool + 64 * (seq.fetch_add(1) % kQueueSlots);
+}
+
 template <int WY, int WX, int RY, int RX> int launch_wg(const WgradP& p, hipStream_t st) {
   using G = WGeo<WY, WX, RY, RX>;
   const size_t lds = (size_t)G::NSTAGE * G::STAGE + (size_t)G::NW * 4096;
@@ -336,6 +422,11 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
   WgradP p{};
   p.P = (const bf16_t*)P; p.Q = (const bf16_t*)Q; p.ldp = ldp; p.ldq = ldq; p.Ny = Ny; p.Nx = Nx; p.M = M;
   p.split_k = S; p.split_stride = (size_t)Ny * Nx; p.out = S > 1 ? ws : out;
+  if (big && S > 1 && tiles <= 62 && gemm_dynamic_tiles_on()) {  // the GPU is shared with collectives: queue the K-chunks per tile
+    const int share = stages / S;
+    p.chunk = share / 8 < 4 ? 4 : share / 8;
+    p.queue = queue_slot();
+  }
   OSUD_TRY(big ? (launch_wg<2, 4, 4, 2>(p, st)) : (launch_wg<2, 2, 2, 2>(p, st)));
   if (S > 1) OSUD_TRY(launch_splitk_reduce(ws, S, (size_t)Ny * Nx, out, (size_t)Ny * Nx, st));
   return OSUD_OK;

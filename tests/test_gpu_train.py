@@ -261,3 +261,30 @@ def test_embed_only_mode_trains_the_class_table_alone():
     emb.step(*args, **kw)
     sd_opt = emb.opt_state_dict()["state"]
     assert float(sd_opt[7]["step"]) == 2.0 and float(sd_opt[8]["step"]) == 1.0  # index 7 = class table (train.py:212-215)
+
+
+def test_queued_tiles_and_chunks_give_the_same_gradients():
+    """Shared-GPU mode (osud_set_gemm_dynamic_tiles(1): GEMM tiles and weight-gradient K-chunks drawn from ticket queues) against
+    the fixed schedule on a DiT-B-wide model, where the 256x256 split-K weight-gradient kernel and multi-round GEMMs are used:
+    GEMM outputs are bit-identical, weight gradients differ only by the order the K-chunks are summed in."""
+    shape = mo.DitShape(depth=2, hidden=768, heads=12, num_classes=16)
+    sd = mo.seeded_state_dict(shape, 5)
+    d = create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True)
+    (x, o, c), y = synthetic_windows(64, 128, 16, seed=2)
+    g = torch.Generator().manual_seed(3)
+    kw = dict(t=torch.randint(0, 1000, (64,), generator=g), noise=torch.randn(64, 2, 128, generator=g), drop_ids=torch.zeros(64).long())
+    grads, terms = [], []
+    L = _lib.lib()
+    try:
+        for mode in (0, 1, 1):
+            _lib.check(L.osud_set_gemm_dynamic_tiles(mode))
+            tr = NativeTrainer(native_model(shape, sd, "bf16", train=True), d)
+            tr.lr = 0.0
+            terms.append(tr.step(x, o, c, y, **kw).cpu())
+            grads.append(tr.arena.grads.clone().cpu())
+    finally:
+        _lib.check(L.osud_set_gemm_dynamic_tiles(-1))
+    assert torch.equal(terms[0], terms[1])                      # the forward (multi-round GEMMs) is bit-identical
+    scale = float(grads[0].abs().max())
+    assert maxdiff(grads[0], grads[1]) < 2e-5 * scale and maxdiff(grads[1], grads[2]) < 2e-5 * scale
+    assert float(grads[1].abs().sum()) > 0
