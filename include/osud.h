@@ -184,8 +184,8 @@ int osud_adamw_ema_step(float* params, const float* grads, float* exp_avg, float
 /* Process-wide switch for multi-round GEMM launches (more output tiles than compute units): 1 = workgroups draw their tiles
  * from per-XCD ticket queues instead of a fixed stride, so that a launch does not wait for workgroups whose compute unit is
  * held by another kernel (RCCL collectives overlapped with the backward: 8 held CUs stretch a fixed-stride launch 1.5x, a
- * queued one 1.1x), and the split-K weight-gradient kernel draws K-chunks from per-tile queues; 0 = fixed schedules (1.7 %
- * faster per training step when the GPU is not shared); -1 = follow the environment variable OSUD_GEMM_DYNAMIC (default 0).
+ * queued one 1.1x), and the split-K weight-gradient kernel draws K-chunks from per-tile queues; 0 = fixed schedules (0.3 %
+ * faster per training step, 2 % per sampling step, when the GPU is not shared); -1 = follow the environment variable OSUD_GEMM_DYNAMIC (default 0).
  * GEMM results are identical either way; weight gradients differ by the order the chunks are summed in.  Data-parallel
  * trainers switch it on. */
 int osud_set_gemm_dynamic_tiles(int on);

@@ -109,7 +109,7 @@ struct WgradP {
   int split_k;
   size_t split_stride;
   unsigned* queue;  // shared-GPU mode (256x256 geometry, splits > 1): [tile] chunk tickets, [63] finished workgroups; else null
-  int chunk;        // stages per chunk
+  int chunk;        // chunks per tile (a multiple of split_k)
 };
 
 template <int WY, int WX, int RY, int RX>
@@ -223,14 +223,15 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
 
   if constexpr (G::NSTAGE == 2) {
     if (p.queue != nullptr) {
-      // ---- shared-GPU mode: the token axis of a tile is cut into chunks of p.chunk stages; the tile's split_k workgroups start
+      // ---- shared-GPU mode: the token axis of a tile is cut into p.chunk equal chunks; the tile's split_k workgroups start
       // on chunks 0..split_k-1 and draw every later chunk from the tile's ticket counter, accumulating in registers, so that a
       // workgroup whose compute unit is held by another kernel leaves its share to the others instead of doubling the launch.
       // With two stages the loop drains this wave's queue at every stage: the ticket requested behind the barrier of a chunk's
       // first stage has returned by the wait of its second and is published through LDS (a word of the idle epilogue patch).
       const int tile = blockIdx.x, ty = tile / ntx, tx = tile % ntx;
-      const int CH = p.chunk, nch = st_total / CH;  // the last chunk takes the remainder
-      auto chunk_len = [&](int c) { return c == nch - 1 ? st_total - c * CH : CH; };
+      const int nch = p.chunk;  // chunks per tile: a multiple of split_k, so an undisturbed launch gives every workgroup the same number
+      auto chunk_begin = [&](int c) { return (int)((long)c * st_total / nch); };  // lengths differ by at most one stage
+      auto chunk_len = [&](int c) { return chunk_begin(c + 1) - chunk_begin(c); };
       volatile __attribute__((address_space(3))) uint32_t* word =
           reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>((lds_void*)smem) + (G::NSTAGE * G::STAGE) / 4;
       const bool ticket_lane = wave == 0 && lane == 0;
@@ -241,7 +242,7 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
       auto issue_next = [&]() {
         const int c = ic_rel == 0 ? c_cur : c_nxt;
         if (ic_rel < 2 && c < nch) {
-          const size_t stage = (size_t)c * CH + ic_st;
+          const size_t stage = (size_t)chunk_begin(c) + ic_st;
           stage_tokens<G>(gpt + stage * BKT * ldp_b, gqt + stage * BKT * ldq_b, lds0 + (uint32_t)((issued % G::NSTAGE) * G::STAGE),
                           dma_off, wave);
           ++issued;
@@ -423,8 +424,8 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
   p.P = (const bf16_t*)P; p.Q = (const bf16_t*)Q; p.ldp = ldp; p.ldq = ldq; p.Ny = Ny; p.Nx = Nx; p.M = M;
   p.split_k = S; p.split_stride = (size_t)Ny * Nx; p.out = S > 1 ? ws : out;
   if (big && S > 1 && tiles <= 62 && gemm_dynamic_tiles_on()) {  // the GPU is shared with collectives: queue the K-chunks per tile
-    const int share = stages / S;
-    p.chunk = share / 8 < 4 ? 4 : share / 8;
+    const int share = stages / S, per_wg = share / 4 < 8 ? (share / 4 < 1 ? 1 : share / 4) : 8;  // chunks of >= 4 stages
+    p.chunk = S * per_wg;
     p.queue = queue_slot();
   }
   OSUD_TRY(big ? (launch_wg<2, 4, 4, 2>(p, st)) : (launch_wg<2, 2, 2, 2>(p, st)));
