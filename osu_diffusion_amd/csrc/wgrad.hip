@@ -424,7 +424,7 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
   p.P = (const bf16_t*)P; p.Q = (const bf16_t*)Q; p.ldp = ldp; p.ldq = ldq; p.Ny = Ny; p.Nx = Nx; p.M = M;
   p.split_k = S; p.split_stride = (size_t)Ny * Nx; p.out = S > 1 ? ws : out;
   if (big && S > 1 && tiles <= 62 && gemm_dynamic_tiles_on()) {  // the GPU is shared with collectives: queue the K-chunks per tile
-    const int share = stages / S, per_wg = share / 4 < 8 ? (share / 4 < 1 ? 1 : share / 4) : 8;  // chunks of >= 4 stages
+    const int share = stages / S, per_wg = share / 4 < 16 ? (share / 4 < 1 ? 1 : share / 4) : 16;  // chunks of >= 4 stages
     p.chunk = S * per_wg;
     p.queue = queue_slot();
   }
