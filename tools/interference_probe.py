@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """How much does a GEMM slow down when another kernel (a collective, an optimizer update) holds a few compute units?
-Builds tools/probe/liboccupy.so on first use (hipcc), then times the library's GEMMs alone and beside the occupier.
+Builds tools/probes/liboccupy.so on first use (hipcc), then times the library's GEMMs alone and beside the occupier.
     python tools/interference_probe.py [wgs ...]"""
 import ctypes
 import os
@@ -13,10 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from osu_diffusion_amd import _lib  # noqa: E402
 
-so = os.path.join(ROOT, "tools", "probe", "liboccupy.so")
+so = os.path.join(ROOT, "tools", "probes", "liboccupy.so")
 if not os.path.exists(so):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so,
-                           os.path.join(ROOT, "tools", "probe", "occupy.hip")])
+                           os.path.join(ROOT, "tools", "probes", "occupy.hip")])
 occ = ctypes.CDLL(so)
 occ.occupy.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 L = _lib.lib()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A whole DiT-B training step while another kernel holds a few compute units for the entire time (the occupier of
-tools/probe/occupy.hip, standing in for collectives that overlap the backward): fixed-stride vs queued GEMM tiles.
+tools/probes/occupy.hip, standing in for collectives that overlap the backward): fixed-stride vs queued GEMM tiles.
     python tools/interference_step.py [held_cus]"""
 import ctypes
 import os
@@ -17,7 +17,7 @@ from osu_diffusion_amd.models import DiT_models  # noqa: E402
 from osu_diffusion_amd.synthetic import randomize_zero_init, synthetic_windows  # noqa: E402
 from osu_diffusion_amd.training import NativeTrainer  # noqa: E402
 
-occ = ctypes.CDLL(os.path.join(ROOT, "tools", "probe", "liboccupy.so"))
+occ = ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "liboccupy.so"))
 occ.occupy.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 held = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dev = torch.device("cuda:0")

@@ -1,7 +1,7 @@
 import ctypes, os, sys, time, torch
 ROOT="/root/repo"; sys.path.insert(0, ROOT)
 from osu_diffusion_amd import _lib
-occ = ctypes.CDLL(os.path.join(ROOT, "tools", "probe", "liboccupy.so"))
+occ = ctypes.CDLL(os.path.join(ROOT, "tools", "probes", "liboccupy.so"))
 occ.occupy.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 dev=torch.device("cuda:0"); side=torch.cuda.Stream(device=dev); L=_lib.lib()
 My,Nx,K=32768,3072,768
