@@ -509,33 +509,3 @@ class NativeTrainer:
         self.load_opt_state_dict(ckpt["opt"])
         self.model._uploaded = {}
         self.ema._uploaded = {}
-
-
-def smoke_train_step():
-    """One tiny native training step on cuda:0 against the oracle's autograd gradients."""
-    from oracle import diffusion_oracle as do
-    from oracle import dit_oracle as mo
-    from .diffusion import create_diffusion
-    from .models import DiT
-    from .synthetic import synthetic_windows
-
-    dev = "cuda:0"
-    shape = mo.DitShape(depth=2, hidden=128, heads=2, num_classes=10)
-    sd = mo.seeded_state_dict(shape, 11)
-    (x, o, c), y = synthetic_windows(4, 64, 10, seed=21)
-    t = torch.tensor([0, 3, 500, 999])
-    noise = torch.randn(4, 2, 64, generator=torch.Generator().manual_seed(1))
-    osd = {k: v.clone().requires_grad_(k != "xoc_embedder.playfield_size") for k, v in sd.items()}
-    sch = do.create_schedule("", "squaredcos_cap_v2")
-    terms = do.training_losses(sch, lambda xx, tt: mo.forward(osd, shape, xx, tt, o, c, y), x, t, noise, loss="l1")
-    terms["loss"].mean().backward()
-    m = DiT(depth=2, hidden_size=128, num_heads=2, context_size=144, num_classes=10, class_dropout_prob=0.2, precision="fp32")
-    m.load_state_dict(sd)
-    m = m.to(dev).eval()
-    tr = NativeTrainer(m, create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True))
-    got = tr.step(x, o, c, y, t=t, noise=noise).cpu()
-    e_loss = float((got[2] - terms["loss"].detach()).abs().max())
-    gv = tr.arena.grad_views()
-    e_grad = max(float((gv[k].cpu() - osd[k].grad).abs().max()) for k in osd if osd[k].grad is not None)
-    print(f"smoke[train fp32]: loss max|d|={e_loss:.3e}, grad max|d|={e_grad:.3e}")
-    assert e_loss < 1e-4 and e_grad < 1e-4

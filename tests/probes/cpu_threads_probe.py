@@ -1,6 +1,6 @@
 """How many host threads give the best CPU-oracle step time on this box (sizes bench.py's cpu_baseline)."""
 import os, sys, time, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import dit_oracle as mo
 from osu_diffusion_amd.synthetic import synthetic_windows
 shape = mo.shape_of("DiT-B", num_classes=100)

@@ -1,6 +1,6 @@
 """fp8 tier of the DiT forward: deviation from the fp32 oracle next to the bf16 tier's, and sampling speed."""
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import dit_oracle as mo
 from osu_diffusion_amd.models import DiT
 from osu_diffusion_amd.synthetic import synthetic_windows

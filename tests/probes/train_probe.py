@@ -1,5 +1,5 @@
 import os, sys, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import dit_oracle as mo
 from osu_diffusion_amd.diffusion import create_diffusion
 from osu_diffusion_amd.models import DiT
