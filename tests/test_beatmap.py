@@ -212,3 +212,32 @@ def test_loader_over_osu_files(tmp_path):
     assert set(y.tolist()) <= {123, 456}
     labels = [int(v) for (_, yy) in loader for v in yy]
     assert set(labels) == {123, 456}
+
+
+def test_file_dialects(tmp_path):
+    """CRLF line ends, a UTF-8 byte-order mark, comments, blank lines, hold notes (mania) and unknown keys survive."""
+    text = HAND.replace("[HitObjects]\n", "[HitObjects]\n// a comment\n\n64,192,300,128,0,900:0:0:0:0:\n")
+    text = text.replace("Mode: 0", "Mode: 3\nSpecialStyle: 1")
+    path = tmp_path / "crlf.osu"
+    path.write_bytes(b"\xef\xbb\xbf" + text.replace("\n", "\r\n").encode("utf-8"))
+    bm = B.Beatmap.from_path(str(path))
+    assert bm.mode == 3 and bm.sections["General"]["SpecialStyle"] == "1"
+    hos = bm.hit_objects()
+    assert isinstance(hos[0], B.HoldNote) and hos[0].end_time == 900 and len(hos) == 11
+    seq = B.beatmap_to_sequence(bm)
+    assert types_of(seq)[0] == 0 and seq[2, 0] == 300            # a hold note counts as a circle (data_loading.py:121-125)
+    again = B.Beatmap.parse(bm.pack())
+    assert again.sections == bm.sections and again.raw == bm.raw
+    assert [h.pack() for h in again.hit_objects()] == [h.pack() for h in hos]
+    assert [tp.pack() for tp in again.timing_points] == [tp.pack() for tp in bm.timing_points]
+
+
+def test_timing_point_lookup_and_velocity_clamp():
+    bm = B.Beatmap.parse(HAND)
+    assert bm.timing_point_at(-50) is bm.timing_points[0]         # before the first point: the first point
+    assert bm.timing_point_at(2999.9) is bm.timing_points[0] and bm.timing_point_at(3000) is bm.timing_points[1]
+    assert bm.timing_point_at(1e9) is bm.timing_points[2]
+    fast = B.Beatmap.parse(HAND.replace("3000,-50,", "3000,-1,"))  # SV 100 is clamped to 10 (osu!'s rule)
+    assert fast.slider_duration(3200, 160, 1) == pytest.approx(160 / (100 * 1.6 * 10.0) * 400)
+    slow = B.Beatmap.parse(HAND.replace("3000,-50,", "3000,-5000,"))
+    assert slow.slider_duration(3200, 160, 1) == pytest.approx(160 / (100 * 1.6 * 0.1) * 400)
