@@ -67,6 +67,8 @@ struct GraphKey {
 struct osud_dit {
   osud_dit_cfg cfg{};
   int D = 0, L = 0, H = 0, hd = 0, E = 0, C = 0, C2 = 0, Kp = 0, prec = 0, esz = 0, ada_cols = 0;
+  int Ke = 0;                // row length of e0 / w_e: Kp, or 3 * Kp in the split form of the bf16 tier's first linear
+  bool split_first = false;
   int device = -1;
   bool training = false;
   bool fp8 = false;  // OSUD_PREC_FP8: prec == BF16 everywhere except the e4m3 operands of qkv / out_proj / fc1 / fc2

@@ -36,7 +36,7 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
   const int Tp = round_up(nT, 64), Mp = round_up(nN * Tp, 128), Np = round_up(nN, 128);
   const size_t es = m->esz, D = m->D;
   auto& W = m->ws_owned;
-  OSUD_TRY(dev_alloc(W, &m->e0, (size_t)Mp * m->Kp * es));
+  OSUD_TRY(dev_alloc(W, &m->e0, (size_t)Mp * m->Ke * es));
   OSUD_TRY(dev_alloc(W, &m->temb, (size_t)Np * 256 * es));
   OSUD_TRY(dev_alloc(W, &m->th, (size_t)Np * D * es));
   OSUD_TRY(dev_alloc(W, &m->sb, (size_t)Np * D * es));
@@ -46,7 +46,7 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
   OSUD_TRY(dev_alloc(W, &m->out_ws, (size_t)nN * m->C2 * nT * 4));
   OSUD_TRY(dev_alloc(W, &m->t_model, (size_t)nN * 8));
   OSUD_TRY(dev_alloc(W, &m->t_index, (size_t)nN * 8));
-  OSUD_TRY(dev_alloc(W, &m->step_state, 16));
+  OSUD_TRY(dev_alloc(W, &m->step_state, 32));
   OSUD_TRY(dev_alloc(W, &m->kb_class, (size_t)(Tp / 64) * (Tp / 64)));
   const bool tr = training || m->training;
   if (!tr) {
@@ -150,9 +150,11 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
   const int prec = m->prec, AC = m->ada_cols;
 
   // token embedding + first linear (models.py:315-317)
-  OSUD_TRY(launch_embed(prec, x, o, c, m->freqs64, m->pf[0], m->pf[1], m->e0, N, T, Tp, Mp, m->E, m->Kp, cfg ? N / 2 : 0, st));
+  // (bf16 tier: rows and weights in the split [hi | lo | hi] x [w_hi | w_hi | w_lo] form, Ke = 3 Kp -- see embed_kernel)
+  OSUD_TRY(launch_embed(prec, x, o, c, m->freqs64, m->pf[0], m->pf[1], m->e0, N, T, Tp, Mp, m->E, m->Kp, cfg ? N / 2 : 0, st,
+                        m->split_first));
   float* h = m->training ? m->saved[0].h_in : m->h;
-  OSUD_TRY(gemm(m, EPI_BIAS_F32, m->e0, m->Kp, m->w_e, m->Kp, Mp, D, m->Kp, h, D, m->b_e, st));
+  OSUD_TRY(gemm(m, EPI_BIAS_F32, m->e0, m->Ke, m->w_e, m->Ke, Mp, D, m->Ke, h, D, m->b_e, st));
   // conditioning vector b = t_emb + y_emb (models.py:318-320) and ALL adaLN modulations in one GEMM:
   // b is the same for every block, so the 12 x (D -> 6D) + (D -> 2D) linears are one (Np x D) x (D x AC) product.
   OSUD_TRY(launch_temb(prec, t, m->freqs128, m->temb, N, Np, st));
@@ -276,6 +278,11 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   m->prec = m->fp8 ? OSUD_PREC_BF16 : cfg->precision;
   m->esz = (int)elem_size(m->prec);
   m->Kp = round_up(cfg->in_channels * 128 + 128 + cfg->context, 128);  // 528 -> 640
+  {  // OSUD_SPLIT_FIRST=0: plain bf16 first linear (A/B measurements of the fast tier's deviation)
+    const char* e = getenv("OSUD_SPLIT_FIRST");
+    m->split_first = m->prec == OSUD_PREC_BF16 && !(e && e[0] == '0');
+  }
+  m->Ke = m->split_first ? 3 * m->Kp : m->Kp;
   m->ada_cols = 6 * m->D * m->L + 2 * m->D;
   if (hipGetDevice(&m->device) != hipSuccess) {
     delete m;
@@ -284,7 +291,7 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   const size_t D = m->D, es = m->esz;
   int rc = OSUD_OK;
   auto A = [&](auto** p, size_t bytes) { if (rc == OSUD_OK) rc = dev_alloc(m->owned, p, bytes); };
-  A(&m->w_e, D * m->Kp * es); A(&m->b_e, D * 4);
+  A(&m->w_e, D * m->Ke * es); A(&m->b_e, D * 4);
   A(&m->w_t0, D * 256 * es);  A(&m->b_t0, D * 4);
   A(&m->w_t2, D * D * es);    A(&m->b_t2, D * 4);
   A(&m->table, (size_t)cfg->table_rows * D * 4);
@@ -374,7 +381,8 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
     OSUD_HIP(hipMemcpy(m->pf, src, 8, hipMemcpyDeviceToHost));
   } else if (k == "xoc_embedder.mlp.0.weight") {
     SHAPE(D, 384 + m->E);
-    rc = launch_pack_rows(prec, src, 384 + m->E, 384 + m->E, m->w_e, m->Kp, m->Kp, (int)D, st);
+    rc = m->split_first ? launch_pack_rows_split(src, 384 + m->E, 384 + m->E, m->w_e, m->Kp, (int)D, st)
+                        : launch_pack_rows(prec, src, 384 + m->E, 384 + m->E, m->w_e, m->Kp, m->Kp, (int)D, st);
   } else if (k == "xoc_embedder.mlp.0.bias") { SHAPE(D); rc = upload_f32(m, &m->b_e, src, D, st);
   } else if (k == "t_embedder.mlp.0.weight") { SHAPE(D, 256); rc = convert_w(m, src, m->w_t0, D * 256, st);
   } else if (k == "t_embedder.mlp.0.bias") { SHAPE(D); rc = upload_f32(m, &m->b_t0, src, D, st);
@@ -486,7 +494,7 @@ extern "C" int osud_sample_loop_inpaint(osud_dit* m, const osud_sched* s, int mo
   hipStream_t st = (hipStream_t)stream;
   OSUD_TRY(sched_upload(const_cast<osud_sched*>(s)));
   OSUD_TRY(dit_ensure_ws(m, N, T, m->training));
-  OSUD_TRY(launch_step_init(m->step_state, first_step, st));
+  OSUD_TRY(launch_step_init(m->step_state, first_step, seed, st));  // the seed travels in device memory, not in the graph
   const int n_steps = first_step - last_step + 1;
   const char* ng = getenv("OSUD_NO_GRAPH");
   if (ng && ng[0] == '1') {

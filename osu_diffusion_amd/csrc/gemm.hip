@@ -616,33 +616,47 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
 #endif
 }
 
+// Per-device state (one process normally drives one GPU, but nothing here may point a second device's kernels at the first
+// device's memory): CU count and the tile-queue counter pool, indexed by the current device.
+constexpr int kMaxDevices = 16;
+int cur_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  return dev;
+}
 int num_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
+  static int n[kMaxDevices] = {};
+  const int dev = cur_device();
+  if (n[dev] == 0) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n[dev] = prop.multiProcessorCount;
+    if (n[dev] <= 0) n[dev] = 256;
   }
-  return n;
+  return n[dev];
 }
 
 // Counter sets ({8 per-XCD tickets, done}, 64-byte slots) of the dynamic tile queue: zeroed once, re-armed by the last workgroup of every launch that used one.  Launches
-// take slots round-robin; kernels on one stream run in order, so a slot is idle again long before it comes round.
+// take slots round-robin; kernels on one stream run in order, so a slot is idle again long before it comes round (the library is
+// single-stream per device by contract -- include/osud.h: handles are not thread-safe, all work goes to the caller's stream; a
+// slot baked into a captured graph belongs to that graph's launch and is re-armed by it on every replay).
 constexpr int kSchedSlots = 256;
 // Off by default: alone on the GPU the queue costs 0.7 % of a training step (a one-off drain for the first ticket, less regular
 // tile order).  Data-parallel training switches it on (osud_set_gemm_dynamic_tiles), where collectives share the compute units.
 std::atomic<int> g_dynamic_tiles{-1};  // -1: follow OSUD_GEMM_DYNAMIC
-unsigned* g_sched_pool = nullptr;
+unsigned* g_sched_pool[kMaxDevices] = {};
 int gemm_sched_init_impl() {
-  if (g_sched_pool) return OSUD_OK;
-  OSUD_HIP(hipMalloc(&g_sched_pool, kSchedSlots * 16 * sizeof(unsigned)));
-  OSUD_HIP(hipMemset(g_sched_pool, 0, kSchedSlots * 16 * sizeof(unsigned)));
+  const int dev = cur_device();
+  if (g_sched_pool[dev]) return OSUD_OK;
+  unsigned* pool = nullptr;
+  OSUD_HIP(hipMalloc(&pool, kSchedSlots * 16 * sizeof(unsigned)));
+  OSUD_HIP(hipMemset(pool, 0, kSchedSlots * 16 * sizeof(unsigned)));
+  g_sched_pool[dev] = pool;
   return OSUD_OK;
 }
 unsigned* sched_slot() {
   static std::atomic<unsigned> seq{0};
-  return g_sched_pool ? g_sched_pool + 16 * (seq.fetch_add(1) % kSchedSlots) : nullptr;
+  unsigned* pool = g_sched_pool[cur_device()];
+  return pool ? pool + 16 * (seq.fetch_add(1) % kSchedSlots) : nullptr;
 }
 
 template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(const GemmP& p_in, hipStream_t st) {
@@ -742,7 +756,7 @@ bool gemm_dynamic_tiles_on() {
 void gemm_set_dynamic_tiles(int on) { g_dynamic_tiles.store(on < 0 ? -1 : (on != 0), std::memory_order_relaxed); }
 
 int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
-  if (!g_sched_pool) {  // normally done at handle creation; never reached while a stream is being captured
+  if (!g_sched_pool[cur_device()]) {  // normally done at handle creation; never reached while a stream is being captured
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) OSUD_TRY(gemm_sched_init_impl());
   }

@@ -6,7 +6,8 @@
 namespace osud {
 
 int launch_embed(int prec, const float* x, const float* o, const float* c, const float* freqs64, float pf0, float pf1,
-                 void* out, int N, int T, int Tp, int Mp, int E, int Kp, int x_dup_half, hipStream_t st);
+                 void* out, int N, int T, int Tp, int Mp, int E, int Kp, int x_dup_half, hipStream_t st,
+                 bool split = false /* bf16 only: rows are [hi | lo | hi], 3 * Kp columns (see embed_kernel) */);
 int launch_temb(int prec, const int64_t* t, const float* freqs128, void* out, int N, int Np, hipStream_t st);
 int launch_cond(int prec, const float* tvec, const float* table, const int64_t* y, int table_rows, float* b_out,
                 void* sb_out, int N, int Np, int D, hipStream_t st);
@@ -24,6 +25,8 @@ int launch_cfg_combine(float* out, int N, int C, int C2, int T, float s, hipStre
 int launch_convert(int prec, const float* src, void* dst, size_t n, hipStream_t st);
 int launch_pack_rows(int prec, const float* src, int ld_src, int cols_src, void* dst, int ld_dst, int cols_dst, int rows,
                      hipStream_t st);
+// first linear of the bf16 tier: dst [rows][3 * cols_dst] = [w_hi | w_hi | w_lo]
+int launch_pack_rows_split(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, hipStream_t st);
 // qkv: packed in_proj output [Mp][ld_qkv], Q | K | V in columns [0,D) [D,2D) [2D,3D)
 // kb_class (optional, from launch_mask_tiles): class of every 64-query x 64-key tile of the mask (0 fully masked, 1 mixed,
 // 2 fully open): masked tiles are skipped, open tiles read no mask bytes
@@ -107,7 +110,7 @@ int launch_sampler_step(const float* coefs, int mode, float eta, const float* mo
                         const int64_t* t_index, const int* step_state, const float* noise, size_t noise_step_stride,
                         uint64_t seed, int N, int T, float cfg_scale, int clip, const osud_inpaint* inpaint, float* x_out,
                         float* pred_xstart, hipStream_t st);
-int launch_step_init(int* step_state, int first, hipStream_t st);
+int launch_step_init(int* step_state, int first, uint64_t seed, hipStream_t st);  // step_state: 8 ints
 int launch_step_begin(int* step_state, const int64_t* tmap_dev, int64_t* t_model, int64_t* t_index, int N,
                       hipStream_t st);
 

@@ -17,21 +17,36 @@ namespace {
 // x, c are channel-major (N,2,T) / (N,E,T): T is the contiguous axis, so each block takes 32
 // consecutive tokens (TOK = 16), reads along T coalesced, transposes through LDS and writes whole rows.
 // Accurate sincosf on purpose: arguments reach ~1.4e4 rad.
-template <typename TE>
+// SPLIT (bf16 tier): the features are fine-grained functions of the sampled coordinates (512 rad per unit x), and rounding them
+// to bf16 was the largest single contribution to the fast tier's deviation from the fp32 path (tools/analysis/
+// bf16_error_budget.py: as much as all 48 trunk GEMMs of DiT-S together).  The row is therefore written as
+// [hi | lo | hi] (3 x Kp columns, hi = bf16(v), lo = bf16(v - hi)) against weights packed as [w_hi | w_hi | w_lo]: one bf16
+// GEMM with K = 3 Kp computes hi*w_hi + lo*w_hi + hi*w_lo, i.e. the fp32 product to ~2^-17 relative.
+template <typename TE, bool SPLIT>
 __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x, const float* __restrict__ o,
                                                     const float* __restrict__ c, const float* __restrict__ freqs64,
                                                     float pf0, float pf1, TE* __restrict__ out, int N, int T, int Tp,
                                                     int E, int Kp, int x_dup_half) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int TOK = 16;
-  TE* tile = reinterpret_cast<TE*>(smem_raw);  // [TOK][Kp]
+  const int ldr = SPLIT ? 3 * Kp : Kp;       // row length in elements
+  TE* tile = reinterpret_cast<TE*>(smem_raw);  // [TOK][ldr]
   const int tid = threadIdx.x;
   const int m0 = blockIdx.x * TOK;
   const int n = m0 / Tp, t0 = m0 % Tp;  // Tp % TOK == 0 -> one sample per block
   if (n >= N) {                          // rows past the last sample: zero
-    for (int i = tid; i < TOK * Kp; i += 256) store_elem(out + (size_t)m0 * Kp + i, 0.f);
+    for (int i = tid; i < TOK * ldr; i += 256) store_elem(out + (size_t)m0 * ldr + i, 0.f);
     return;
   }
+  auto put = [&](int tok, int col, float v) {
+    TE* r = tile + tok * ldr;
+    store_elem(r + col, v);
+    if (SPLIT) {
+      const float hi = load_elem(r + col);
+      store_elem(r + Kp + col, v - hi);
+      r[2 * Kp + col] = r[col];
+    }
+  };
   const int nx = (x_dup_half > 0 && n >= x_dup_half) ? n - x_dup_half : n;  // forward_with_cfg: cat([half, half])
   // (a) sin/cos features: TOK tokens x 3 scalars x 64 frequencies
   for (int idx = tid; idx < TOK * 192; idx += 256) {
@@ -46,25 +61,25 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x,
       const float arg = v * freqs64[k];
       sincosf(arg, &sn, &cs);
     }
-    store_elem(tile + tok * Kp + which * 128 + k, cs);       // cos first (positional_embedding.py:46)
-    store_elem(tile + tok * Kp + which * 128 + 64 + k, sn);
+    put(tok, which * 128 + k, cs);       // cos first (positional_embedding.py:46)
+    put(tok, which * 128 + 64 + k, sn);
   }
   // (b) context rows, read along T
   for (int idx = tid; idx < TOK * E; idx += 256) {
     const int e = idx / TOK, tok = idx % TOK;
     const int t = t0 + tok;
     const float v = t < T ? c[((size_t)n * E + e) * T + t] : 0.f;
-    store_elem(tile + tok * Kp + 384 + e, v);
+    put(tok, 384 + e, v);
   }
   for (int idx = tid; idx < TOK * (Kp - 384 - E); idx += 256) {
     const int tok = idx / (Kp - 384 - E), k = idx % (Kp - 384 - E);
-    store_elem(tile + tok * Kp + 384 + E + k, 0.f);
+    put(tok, 384 + E + k, 0.f);
   }
   __syncthreads();
   // (c) whole rows out, 16 bytes per lane
-  const int n16 = TOK * Kp * (int)sizeof(TE) / 16;
+  const int n16 = TOK * ldr * (int)sizeof(TE) / 16;
   const uint4* src = reinterpret_cast<const uint4*>(smem_raw);
-  uint4* dst = reinterpret_cast<uint4*>(out + (size_t)m0 * Kp);
+  uint4* dst = reinterpret_cast<uint4*>(out + (size_t)m0 * ldr);
   for (int i = tid; i < n16; i += 256) dst[i] = src[i];
 }
 
@@ -284,6 +299,22 @@ __global__ void pack_rows_kernel(const float* __restrict__ src, int ld_src, int 
   }
 }
 
+// bf16 tier, first linear: dst row = [w_hi | w_hi | w_lo], each part cols_dst wide (zero padded) -- the weight side of the
+// split product of embed_kernel<bf16, SPLIT>
+__global__ void pack_rows_split_kernel(const float* __restrict__ src, int ld_src, int cols_src, bf16_t* __restrict__ dst,
+                                       int cols_dst, int rows) {
+  const size_t total = (size_t)rows * cols_dst;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols_dst), cc = (int)(i % cols_dst);
+    const float v = cc < cols_src ? src[(size_t)r * ld_src + cc] : 0.f;
+    const bf16_t hi = f2bf(v);
+    bf16_t* d = dst + (size_t)r * 3 * cols_dst + cc;
+    d[0] = hi;
+    d[cols_dst] = hi;
+    d[2 * cols_dst] = f2bf(v - bf2f(hi));
+  }
+}
+
 // fp8 tier: one weight row (output channel) per block -> e4m3 with the row's own scale 448 / max|w|;
 // dequant[x] = max|w_x| / (448 * act_scale) is what the GEMM epilogue multiplies the accumulator with
 __global__ __launch_bounds__(256) void quantize_rows_kernel(const float* __restrict__ w, int cols, fp8_t* __restrict__ q,
@@ -311,20 +342,31 @@ int launch_quantize_rows(const float* w, int rows, int cols, void* q, float* deq
 }
 
 // ---------------------------------------------------------------------------------- launchers
-template <typename TE>
+template <typename TE, bool SPLIT>
 static int embed_t(const float* x, const float* o, const float* c, const float* freqs64, float pf0, float pf1, void* out,
                    int N, int T, int Tp, int Mp, int E, int Kp, int x_dup_half, hipStream_t st) {
-  const size_t lds = (size_t)16 * Kp * sizeof(TE);
-  hipLaunchKernelGGL((embed_kernel<TE>), dim3(Mp / 16), dim3(256), lds, st, x, o, c, freqs64, pf0, pf1, (TE*)out, N, T,
+  const size_t lds = (size_t)16 * Kp * sizeof(TE) * (SPLIT ? 3 : 1);
+  hipLaunchKernelGGL((embed_kernel<TE, SPLIT>), dim3(Mp / 16), dim3(256), lds, st, x, o, c, freqs64, pf0, pf1, (TE*)out, N, T,
                      Tp, E, Kp, x_dup_half);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }
 int launch_embed(int prec, const float* x, const float* o, const float* c, const float* freqs64, float pf0, float pf1,
-                 void* out, int N, int T, int Tp, int Mp, int E, int Kp, int x_dup_half, hipStream_t st) {
+                 void* out, int N, int T, int Tp, int Mp, int E, int Kp, int x_dup_half, hipStream_t st, bool split) {
   OSUD_CHECK_ARG(Tp % 16 == 0 && Mp % 16 == 0 && Kp >= 384 + E && (Kp * elem_size(prec)) % 16 == 0, "embed: bad sizes");
-  return prec == OSUD_PREC_BF16 ? embed_t<bf16_t>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st)
-                                : embed_t<float>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st);
+  OSUD_CHECK_ARG(!split || (prec == OSUD_PREC_BF16 && (size_t)16 * Kp * 6 <= 64 * 1024), "embed: the split row form is bf16 only");
+  if (split) return embed_t<bf16_t, true>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st);
+  return prec == OSUD_PREC_BF16 ? embed_t<bf16_t, false>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st)
+                                : embed_t<float, false>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st);
+}
+
+int launch_pack_rows_split(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, hipStream_t st) {
+  const size_t total = (size_t)rows * cols_dst;
+  if (total == 0) return OSUD_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_rows_split_kernel, dim3(grid), dim3(256), 0, st, src, ld_src, cols_src, (bf16_t*)dst, cols_dst, rows);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
 }
 
 int launch_temb(int prec, const int64_t* t, const float* freqs128, void* out, int N, int Np, hipStream_t st) {

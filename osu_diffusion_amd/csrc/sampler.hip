@@ -111,9 +111,10 @@ __global__ void sampler_step_kernel(const float* __restrict__ coefs, int mode, f
   if (i >= N * 2 * T) return;
   const int t = i % T, ch = (i / T) % 2, n = i / (2 * T);
   int step, exec_k = 0;
-  if (step_state != nullptr) {
-    step = step_state[1];
+  if (step_state != nullptr) {  // graph-replayed loop: step index, noise offset and the Philox seed live on the device, so ONE
+    step = step_state[1];       // captured graph serves every step of every run (the seed is not baked into the launch)
     exec_k = step_state[2];
+    seed = (uint64_t)(uint32_t)step_state[4] | ((uint64_t)(uint32_t)step_state[5] << 32);
   } else {
     step = (int)t_index[n];
   }
@@ -155,7 +156,7 @@ __global__ void sampler_step_kernel(const float* __restrict__ coefs, int mode, f
 }
 
 // Loop bookkeeping, one block: state[0] = next step index, state[1] = current, state[2] = number
-// of steps executed before this one.  Fills the model's timestep (timestep_map[i], respace.py:127-132).
+// of steps executed before this one, state[4..5] = Philox seed of the run.  Fills the model's timestep (timestep_map[i], respace.py:127-132).
 __global__ void step_begin_kernel(int* state, const int64_t* __restrict__ tmap, int64_t* __restrict__ t_model,
                                   int64_t* __restrict__ t_index, int N) {
   const int cur = state[0];
@@ -173,17 +174,19 @@ __global__ void step_begin_kernel(int* state, const int64_t* __restrict__ tmap, 
   }
 }
 
-__global__ void step_init_kernel(int* state, int first) {
+__global__ void step_init_kernel(int* state, int first, uint64_t seed) {
   state[0] = first;
   state[1] = first;
   state[2] = 0;
   state[3] = 0;
+  state[4] = (int)(uint32_t)seed;
+  state[5] = (int)(uint32_t)(seed >> 32);
 }
 
 }  // namespace
 
-int launch_step_init(int* step_state, int first, hipStream_t st) {
-  hipLaunchKernelGGL(step_init_kernel, dim3(1), dim3(1), 0, st, step_state, first);
+int launch_step_init(int* step_state, int first, uint64_t seed, hipStream_t st) {
+  hipLaunchKernelGGL(step_init_kernel, dim3(1), dim3(1), 0, st, step_state, first, seed);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }

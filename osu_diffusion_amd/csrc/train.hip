@@ -266,7 +266,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
   {
     float* g_be = G("xoc_embedder.mlp.0.bias");
     OSUD_TRY(launch_transpose_f32(prec, dh, D, w.tB, Mp, Mp, D, g_be, st));
-    OSUD_TRY(launch_transpose(prec, m->e0, m->Kp, w.tA, Mp, Mp, m->Kp, nullptr, st));
+    OSUD_TRY(launch_transpose(prec, m->e0, m->Ke, w.tA, Mp, Mp, m->Kp, nullptr, st));  // the hi part of a split row
     OSUD_TRY(wgrad(m, w.tB, w.tA, D, m->Kp, Mp, w.dWe, m->Kp, st));
     OSUD_TRY(launch_unpad_rows(w.dWe, m->Kp, G("xoc_embedder.mlp.0.weight"), 384 + m->E, D, st));
     OSUD_TRY(dbg_sync(st, "first layer"));
@@ -543,8 +543,9 @@ extern "C" int osud_adamw_ema_step(float* params, const float* grads, float* exp
                                    float ema_decay, size_t skip_begin, size_t skip_end, float grad_scale,
                                    osud_stream stream) {
   OSUD_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && n > 0 && step >= 1, "adamw_ema_step: bad argument");
-  const float bc1 = 1.0f - powf(beta1, (float)step);
-  const float bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+  // bias corrections in double, as torch evaluates them in Python floats (1 - 0.999f loses 4-5 digits in fp32 at small steps)
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   const int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
   hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
                      ema, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, ema_decay, skip_begin, skip_end, grad_scale);

@@ -364,27 +364,37 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
   }
 }
 
+// per-device state, as in gemm.hip
+constexpr int kMaxDevices = 16;
+int cur_device_w() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+  return dev;
+}
 int num_cus_w() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
+  static int n[kMaxDevices] = {};
+  const int dev = cur_device_w();
+  if (n[dev] == 0) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-    if (n <= 0) n = 256;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n[dev] = prop.multiProcessorCount;
+    if (n[dev] <= 0) n[dev] = 256;
   }
-  return n;
+  return n[dev];
 }
 
 // counter sets of the chunk queues (64 words each: [tile] tickets, [63] finished workgroups), re-armed by the last workgroup out
 constexpr int kQueueSlots = 64;
-unsigned* g_queue_pool = nullptr;
+unsigned* g_queue_pool[kMaxDevices] = {};
 unsigned* queue_slot() {
   static std::atomic<unsigned> seq{0};
-  if (!g_queue_pool) {
-    if (hipMalloc(&g_queue_pool, kQueueSlots * 64 * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemset(g_queue_pool, 0, kQueueSlots * 64 * sizeof(unsigned)) != hipSuccess) return nullptr;
+  const int dev = cur_device_w();
+  if (!g_queue_pool[dev]) {
+    unsigned* pool = nullptr;
+    if (hipMalloc(&pool, kQueueSlots * 64 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(pool, 0, kQueueSlots * 64 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    g_queue_pool[dev] = pool;
   }
-  return g_queue_pool + 64 * (seq.fetch_add(1) % kQueueSlots);
+  return g_queue_pool[dev] + 64 * (seq.fetch_add(1) % kQueueSlots);
 }
 
 template <int WY, int WX, int RY, int RX> int launch_wg(const WgradP& p, hipStream_t st) {

@@ -250,10 +250,12 @@ class DiT(nn.Module):
         y (N) class labels -> (N, out_channels, T).  Reference: models.py:306-325."""
         if self.training and self.y_embedder.dropout_prob > 0:
             y = self.y_embedder.token_drop(y)  # models.py:69-72
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        if attn_mask is None and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             from .training import dit_forward_autograd  # backward through the native kernels
 
             return dit_forward_autograd(self, x, t, o, c, y, attn_mask)
+        # Inference path.  A masked forward is always inference: the reference trains without a mask (train.py:255), the
+        # native backward has none, so with grad mode on the result simply carries no grad_fn (INTEGRATION.md).
         return self._run(x, t, o, c, y, attn_mask, -1.0)
 
     def forward_with_cfg(self, x, t, o, c, y, cfg_scale, attn_mask=None):

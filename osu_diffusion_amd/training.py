@@ -302,11 +302,13 @@ class NativeTrainer:
         self.ema.eval()
         self.exp_avg = torch.zeros_like(self.arena.flat)
         self.exp_avg_sq = torch.zeros_like(self.arena.flat)
+        # torch's AdamW keeps a step counter PER PARAMETER.  Two counters cover every reference recipe: the trunk's, and the
+        # class table's own absolute one -- ahead of the trunk after --embed-only-epochs (train.py:223-241: only the table
+        # trains while `embed_only` is set), behind it after --relearn-embeds (train.py:212-215 deletes optimizer state 7, so
+        # the table restarts at step 1 with fresh moments)
         self.step_count = 0
-        # --embed-only-epochs (train.py:223-241): only the class table trains while `embed_only` is set; torch's AdamW keeps a
-        # step counter per parameter, so the table's bias correction runs `table_extra_steps` ahead of the trunk's afterwards
+        self.table_step = 0
         self.embed_only = False
-        self.table_extra_steps = 0
         self.force_phased = os.environ.get("OSUD_FORCE_PHASED", "0") == "1"  # exercise the phased path on 1 GPU
         # one GPU, OSUD_ADAMW_OVERLAP=1: the HBM-bound AdamW+EMA of a block's slice runs on a side stream under the MFMA-bound
         # backward of the blocks in front of it (same arithmetic, same result).  Measured worth 0.2 % — off by default, the
@@ -360,7 +362,7 @@ class NativeTrainer:
 
             def early(ranges, _self=self):  # block slices are final: update them while the tail exchange is in flight
                 import torch.distributed as dist
-                _self.step_count += 1
+                _self._advance()
                 _self._adamw(ranges, 1.0 / dist.get_world_size(_self.group) if dist.is_initialized() else 1.0)
                 done.extend(ranges)
 
@@ -386,7 +388,7 @@ class NativeTrainer:
             self._side = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
         blocks, _ = overlap_slices(self.arena, model.depth)
-        self.step_count += 1
+        self._advance()
         dout = native_backward(model, dout, phases=(0, 0))
         done = []
         for p in range(1, model.depth + 1):
@@ -418,7 +420,7 @@ class NativeTrainer:
             rows = dict(self.model.named_parameters())["y_embedder.embedding_table.weight"].shape[0]
             exchange_table_rows(self.arena.grads[t_lo:t_hi].view(rows, -1), self.model._train_keep[4], self.group)
             scale = 1.0 / dist.get_world_size(self.group)
-        self.table_extra_steps += 1
+        self.table_step += 1
         self._adamw([(0, t_lo), (t_hi, self.arena.total)], 1.0, frozen=True)
         self._adamw([(t_lo, t_hi)], scale)
         self._refresh()
@@ -439,7 +441,7 @@ class NativeTrainer:
                     fl = fh = 0
                 if frozen:
                     fl, fh = 0, hi - lo
-                step = self.step_count + (self.table_extra_steps if (lo >= t_lo and hi <= t_hi) else 0)
+                step = self.table_step if (lo >= t_lo and hi <= t_hi) else self.step_count
                 _lib.check(L.osud_adamw_ema_step(_lib.ptr(a.flat[lo:hi]), _lib.ptr(a.grads[lo:hi]), _lib.ptr(self.exp_avg[lo:hi]),
                                                  _lib.ptr(self.exp_avg_sq[lo:hi]), _lib.ptr(self.ema_arena.flat[lo:hi]), hi - lo,
                                                  self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
@@ -451,9 +453,18 @@ class NativeTrainer:
             _lib.check(_lib.lib().osud_dit_refresh(self.model._handle, _lib.stream_ptr(dev)))
         self.ema._uploaded = {}  # its masters changed behind torch's back
 
+    def _advance(self):
+        """One optimizer step begins: every parameter's AdamW step counter moves on."""
+        self.step_count += 1
+        self.table_step += 1
+
+    @property
+    def table_extra_steps(self):  # how far the class table's counter runs ahead of (> 0) or behind (< 0) the trunk's
+        return self.table_step - self.step_count
+
     def optimizer_step(self, grad_scale=1.0):
         """AdamW(lr, betas, eps, wd) + EMA (train.py:258-261) + re-pack of the low-precision copies."""
-        self.step_count += 1
+        self._advance()
         self._adamw([(0, self.arena.total)], grad_scale)
         self._refresh()
 
@@ -465,8 +476,8 @@ class NativeTrainer:
         for i, name in enumerate(self.arena.names):
             if name.endswith("playfield_size"):
                 continue
-            extra = self.table_extra_steps if name == "y_embedder.embedding_table.weight" else 0
-            state[i] = {"step": torch.tensor(float(self.step_count + extra)),
+            step = self.table_step if name == "y_embedder.embedding_table.weight" else self.step_count
+            state[i] = {"step": torch.tensor(float(step)),
                         "exp_avg": self.arena.view(self.exp_avg, name).clone(),
                         "exp_avg_sq": self.arena.view(self.exp_avg_sq, name).clone()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
@@ -476,17 +487,19 @@ class NativeTrainer:
 
     def load_opt_state_dict(self, sd):
         self.lr = sd["param_groups"][0]["lr"]
-        table_step = None
+        # a parameter without an entry has no optimizer state: torch creates it lazily at step 0 with zero moments (this is
+        # what --relearn-embeds relies on for the class table, train.py:212-215)
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        self.step_count = self.table_step = 0
         for i, st in sd["state"].items():
             name = self.arena.names[int(i)]
             self.arena.view(self.exp_avg, name).copy_(st["exp_avg"])
             self.arena.view(self.exp_avg_sq, name).copy_(st["exp_avg_sq"])
             if name == "y_embedder.embedding_table.weight":
-                table_step = int(float(st["step"]))
+                self.table_step = int(float(st["step"]))
             else:
                 self.step_count = int(float(st["step"]))
-        if table_step is not None:
-            self.table_extra_steps = max(0, table_step - self.step_count)
 
     def checkpoint(self, args=None):
         scaler = {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000,

@@ -484,8 +484,144 @@ def g11_inpaint():
          loop_x0=x0, loop_o=o, loop_c=c, loop_y=y, loop_mask=lmask, loop_z=z, loop_noises=noises, loop_final=final)
 
 
+# ------------------------------------------------------------------ round 2: DiT-B geometry, long loops
+BASE = mo.shape_of("DiT-B", num_classes=10)                                  # D=768, 12 heads, 12 blocks: the benchmarked geometry
+BASE2 = mo.DitShape(depth=2, hidden=768, heads=12, num_classes=10)           # the same width, two blocks (gradient fixture)
+
+
+def g3_forward_dit_b():
+    """One forward at the geometry bench.py times (D=768, 12 heads of 64, depth 12, T=128): the GEMM instantiations with
+    K = 768 / 3072 and the 12-head attention are checked against REFERENCE outputs, not only against themselves."""
+    print("G3 forward, DiT-B geometry")
+    for tag, wseed, kw in [("dit_b_T128", 14, {}), ("dit_b_T128_rough", 15, dict(pos_gain=1.0, mod_std=0.2))]:
+        sd = mo.seeded_state_dict(BASE, wseed, **kw)
+        ref = ref_model_for(BASE, sd)
+        x, t, o, c, y = inputs(4, 128, BASE, seed=300, ts=[0, 1, 500, 999])
+        out_ref = ref(x, t, o, c, y)
+        close(mo.forward(sd, BASE, x, t, o, c, y), out_ref, 1e-4 if kw else 4e-5, tag)
+        cfg4 = ref.forward_with_cfg(x, t, o, c, y, 4.0)
+        cfg1 = ref.forward_with_cfg(x, t, o, c, y, 1.0)
+        close(mo.forward_with_cfg(sd, BASE, x, t, o, c, y, 4.0), cfg4, 4e-4, tag + " cfg4")
+        save(f"g3_forward_{tag}", shape=np.array([BASE.depth, BASE.hidden, BASE.heads, BASE.num_classes]), wseed=wseed,
+             wsum=checksum(sd), rough=bool(kw), x=x, t=t, o=o, c=c, y=y, out=out_ref, out_cfg4=cfg4, out_cfg1=cfg1)
+
+
+def grad_probe(name, g):
+    """What a fixture keeps of one gradient tensor: norm, a seeded random projection (catches transposes / permutations) and a
+    strided sample of the values (every tensor in full would be 90 MB at this width)."""
+    flat = g.detach().double().flatten()
+    gen = torch.Generator().manual_seed(sum(ord(ch) * (i + 1) for i, ch in enumerate(name)) % (2 ** 31))
+    proj = torch.randn(flat.numel(), generator=gen, dtype=torch.float64)
+    stride = max(1, flat.numel() // 4096)
+    return float(flat.norm()), float((flat * proj).sum() / proj.norm()), flat[::stride][:4096].float()
+
+
+def g7_training_dit_b():
+    """training_losses + backward at D=768 / 12 heads (two blocks, B=4, T=128): the 256x256 and 256x192 GEMM tiles, the
+    split-K weight-gradient kernel and the attention backward of the benchmarked geometry against REFERENCE gradients."""
+    print("G7 training, DiT-B width")
+    torch.set_grad_enabled(True)
+    shape, wseed = BASE2, 16
+    B, T = 4, 128
+    (x, o, c), y = synthetic_windows(B, T, shape.num_classes, seed=31, train_offsets=True)
+    t = torch.tensor([0, 7, 500, 999], dtype=torch.long)
+    noise = torch.randn(B, 2, T, generator=torch.Generator().manual_seed(32))
+    drop = torch.tensor([False, False, True, False])
+    y_eff = torch.where(drop, torch.full_like(y, shape.num_classes), y)
+    sd = mo.seeded_state_dict(shape, wseed)
+    ref = ref_model_for(shape, sd)
+    dref = ref_create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True)
+    terms = dref.training_losses(ref, x, t, dict(o=o, c=c, y=y_eff), noise=noise)
+    terms["loss"].mean().backward()
+    grads = {k: p.grad.clone() for k, p in ref.named_parameters() if p.grad is not None}
+    osd = {k: v.clone().requires_grad_(k != "xoc_embedder.playfield_size") for k, v in sd.items()}
+    ora = do.create_schedule("", "squaredcos_cap_v2")
+    ot = do.training_losses(ora, lambda xx, tt: mo.forward(osd, shape, xx, tt, o, c, y, drop_mask=drop), x, t, noise, loss="l1")
+    ot["loss"].mean().backward()
+    for k in ("loss", "vb", "l1"):
+        close(ot[k].detach(), terms[k].detach(), 2e-5, f"dit-b width term {k}")
+    worst = max((osd[k].grad - grads[k]).abs().max().item() for k in grads)
+    print(f"  oracle vs reference [dit-b width grads]: max|d| = {worst:.3e}")
+    assert worst < 1e-4
+    keys = sorted(grads)
+    probes = {k: grad_probe(k, grads[k]) for k in keys}
+    arrs = {"sample:" + k: probes[k][2] for k in keys}
+    save("g7_train_dit_b", shape=np.array([shape.depth, shape.hidden, shape.heads, shape.num_classes]), wseed=wseed,
+         wsum=checksum(sd), x=x, o=o, c=c, y=y, t=t, noise=noise, drop=drop, loss=terms["loss"].detach(),
+         vb=terms["vb"].detach(), main=terms["l1"].detach(), grad_keys=np.array(keys),
+         grad_norms=np.array([probes[k][0] for k in keys]), grad_projs=np.array([probes[k][1] for k in keys]), **arrs)
+    torch.set_grad_enabled(False)
+
+
+def g6_long_loops():
+    """a full 250-step respaced p_sample_loop, and the head (t = 999..995, where sqrt(1/ac - 1) ~ 2e4 and the
+    clamp decides x0) and tail (t = 4..0) of the 1000-step schedule, each on the damped seeded weights (pos_gain 0.1: fp32 and
+    fp64 evaluations of the reference agree to 1e-4, the 1e-3 bound is well-posed) and on UNDAMPED reference-like weights
+    (pos_gain 1), for which the reference's own fp32 result is stored next to an fp64 evaluation of the same loop: their
+    distance is the accuracy any fp32 implementation can claim on those weights."""
+    print("G6 long loops: p250, 1000-step head and tail")
+    shape, wseed = TINY, 11
+    n, T = 2, 64
+    (x0, o, c), y = synthetic_windows(n, T, shape.num_classes, seed=7, train_offsets=False)
+    o, c = torch.cat([o, o]), torch.cat([c, c])
+    y = torch.cat([y, torch.full_like(y, shape.num_classes)])
+    kw = dict(o=o, c=c, y=y, cfg_scale=4.0, attn_mask=None)
+    for damp_tag, pos_gain in (("", 0.1), ("_undamped", 1.0)):
+        sd = mo.seeded_state_dict(shape, wseed, pos_gain=pos_gain)
+        sd64 = mo.to_dtype(sd, torch.float64)
+        ref = ref_model_for(shape, sd)
+        fn = lambda xx, tt: mo.forward_with_cfg(sd, shape, xx, tt, o, c, y, 4.0)  # noqa: E731
+        fn64 = lambda xx, tt: mo.forward_with_cfg(sd64, shape, xx.double(), tt, o.double(), c.double(), y, 4.0).float()  # noqa: E731
+        # (a) 250-step loop
+        dref = ref_create_diffusion("250", noise_schedule="squaredcos_cap_v2")
+        ora = do.create_schedule("250", "squaredcos_cap_v2")
+        torch.manual_seed(13)
+        z = torch.randn(n, 2, T)
+        z = torch.cat([z, z])
+        torch.manual_seed(14)
+        final = dref.p_sample_loop(ref.forward_with_cfg, z.shape, z, clip_denoised=True, model_kwargs=kw, device="cpu")
+        torch.manual_seed(14)
+        noises = torch.stack([torch.randn_like(z) for _ in range(250)])
+        mine = do.sample_loop(ora, fn, z, noises)
+        d32 = (mine - final).abs().max().item()
+        f64 = do.sample_loop(ora, fn64, z, noises)
+        d64 = (f64 - final).abs().max().item()
+        print(f"  p250{damp_tag}: oracle fp32 vs reference {d32:.3e}; fp64 evaluation vs reference fp32 {d64:.3e}")
+        if pos_gain < 1:
+            assert d32 <= 5e-4 and d64 <= 5e-4
+        save(f"g6_loop_p250{damp_tag}", shape=np.array([shape.depth, shape.hidden, shape.heads, shape.num_classes]), wseed=wseed,
+             wsum=checksum(sd), pos_gain=pos_gain, z=z, o=o, c=c, y=y, noises=noises, final=final,
+             final_fp64=f64, respacing="250", eta=-1.0)
+        # (b) head and tail of the 1000-step schedule: reference p_sample, step by step
+        d1000 = ref_create_diffusion("1000", noise_schedule="squaredcos_cap_v2")
+        o1000 = do.create_schedule("1000", "squaredcos_cap_v2")
+        out = {}
+        for part, first, last, start in (("head", 999, 995, z),
+                                         ("tail", 4, 0, torch.cat([x0, x0]) + 0.02 * torch.randn(2 * n, 2, T, generator=torch.Generator().manual_seed(15)))):
+            xs = start.clone()
+            torch.manual_seed(16)
+            for i in range(first, last - 1, -1):
+                tt = torch.tensor([i] * len(xs))
+                xs = d1000.p_sample(ref.forward_with_cfg, xs, tt, clip_denoised=True, model_kwargs=kw)["sample"]
+            torch.manual_seed(16)
+            nz = torch.stack([torch.randn_like(start) for _ in range(first - last + 1)])
+            xo = start.clone()
+            tm = torch.from_numpy(o1000.timestep_map)
+            for k, i in enumerate(range(first, last - 1, -1)):
+                tt = torch.tensor([i] * len(xo))
+                xo = do.p_sample_step(o1000, fn(xo, tm[tt]), xo, tt, nz[k])["sample"]
+            dd = (xo - xs).abs().max().item()
+            print(f"  1000-step {part}{damp_tag}: oracle vs reference {dd:.3e}")
+            if pos_gain < 1:
+                assert dd <= 5e-4
+            out.update({part + "_start": start, part + "_noises": nz, part + "_final": xs, part + "_first": first, part + "_last": last})
+        save(f"g6_steps_1000{damp_tag}", shape=np.array([shape.depth, shape.hidden, shape.heads, shape.num_classes]), wseed=wseed,
+             wsum=checksum(sd), pos_gain=pos_gain, o=o, c=c, y=y, **out)
+
+
 if __name__ == "__main__":
-    steps = [g1_schedules, g2_embeddings, g3_forward, g5_step, g6_loop, g7_training, g9_init_and_keys, g9_windows, g10_curves, g11_inpaint]
+    steps = [g1_schedules, g2_embeddings, g3_forward, g5_step, g6_loop, g7_training, g9_init_and_keys, g9_windows, g10_curves, g11_inpaint,
+             g3_forward_dit_b, g7_training_dit_b, g6_long_loops]
     only = set(sys.argv[1:])  # e.g. `make_golden.py g10_curves` regenerates one family
     for fn in steps:
         if not only or fn.__name__ in only:

@@ -91,6 +91,48 @@ def test_training_step_gradients_match_reference(loss, precision):
     assert float(gv["xoc_embedder.playfield_size"].abs().sum()) == 0.0
 
 
+def _probe(name, g):
+    """tests/golden/make_golden.py::grad_probe on a native gradient tensor."""
+    flat = g.detach().double().flatten().cpu()
+    gen = torch.Generator().manual_seed(sum(ord(ch) * (i + 1) for i, ch in enumerate(name)) % (2 ** 31))
+    proj = torch.randn(flat.numel(), generator=gen, dtype=torch.float64)
+    stride = max(1, flat.numel() // 4096)
+    return float(flat.norm()), float((flat * proj).sum() / proj.norm()), flat[::stride][:4096].float()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_training_step_at_dit_b_width_matches_reference(precision):
+    """D = 768, 12 heads, K = 768 / 3072: the GEMM tiles (256x256, 256x192), the split-K weight-gradient kernel and the 12-head
+    attention backward that bench.py times, against gradients of the REFERENCE (fixture g7_train_dit_b: per-tensor norm, a
+    random projection and a strided sample of every gradient tensor).  fp32 tier: sample max|d| <= 2e-5 + 1e-3 max|g|, norms and
+    projections to 2e-3; bf16 tier: relative error of the sample <= 6e-2, norms to 8e-2."""
+    fx = load("g7_train_dit_b")
+    shape, sd = weights_for(fx)
+    tr = NativeTrainer(native_model(shape, sd, precision), create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True))
+    terms = tr.step(T(fx["x"]), T(fx["o"]), T(fx["c"]), T(fx["y"]), t=T(fx["t"]), noise=T(fx["noise"]),
+                    drop_ids=T(fx["drop"]).long()).cpu()
+    tol = 2e-5 if precision == "fp32" else 2e-2
+    for row, key in enumerate(("main", "vb", "loss")):
+        assert float(((terms[row] - T(fx[key])).abs() / T(fx[key]).abs().clamp_min(1.0)).max()) < tol, key
+    gv = tr.arena.grad_views()
+    keys = [str(k) for k in fx["grad_keys"]]
+    worst = 0.0
+    for k, n_ref, p_ref in zip(keys, fx["grad_norms"], fx["grad_projs"]):
+        n, pr, smp = _probe(k, gv[k])
+        ref = T(fx["sample:" + k])
+        if precision == "fp32":
+            assert maxdiff(smp, ref) < 2e-5 + 1e-3 * float(ref.abs().max()), k
+            assert abs(n - n_ref) <= 2e-3 * max(n_ref, 1e-4), (k, n, n_ref)
+            assert abs(pr - p_ref) <= 2e-3 * max(n_ref, 1e-4), (k, pr, p_ref)  # the projection of a unit-norm direction
+        else:
+            rel = float((smp - ref).norm() / ref.norm().clamp_min(1e-12))
+            worst = max(worst, rel)
+            assert rel < 6e-2, (k, rel)
+            assert abs(n - n_ref) <= 8e-2 * max(n_ref, 1e-4), (k, n, n_ref)
+    if precision == "bf16":
+        print(f"bf16 tier, D=768: worst per-tensor relative gradient error {worst:.3e}")
+
+
 def _check_first_adam_step(after, before, ref_after, ref_grad, key):
     """The first Adam step is lr * g / (|g| + eps): +-1e-4 wherever |g| >> eps = 1e-8, and ill-conditioned
     where |g| ~ eps (a 1e-9 gradient difference moves it by percents).  Compare the step tightly where the
@@ -200,6 +242,44 @@ def test_checkpoint_layout_and_resume(tmp_path):
     tr3 = NativeTrainer(native_model(shape, mo.seeded_state_dict(shape, 99), "fp32", train=True), d)
     tr3.load_checkpoint(torch.load(path, weights_only=False), relearn_embeds=True)
     assert float(tr3.arena.view(tr3.exp_avg, "y_embedder.embedding_table.weight").abs().sum()) == 0.0
+    assert tr3.table_step == 0 and tr3.step_count == tr.step_count - 1  # the table restarts, the trunk carries on
+
+
+def test_relearn_embeds_resume_matches_torch_adamw_with_state_7_deleted():
+    """--relearn-embeds (train.py:212-215) deletes optimizer state 7: torch's AdamW then restarts the class table at step 1
+    with fresh moments while every other parameter carries on at step N+1.  The fused optimizer must apply the same two bias
+    corrections (a table corrected as if at step N would move ~3x too far on its first step)."""
+    shape = mo.DitShape(depth=1, hidden=128, heads=2, num_classes=6)
+    sd = mo.seeded_state_dict(shape, 4)
+    d = create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True)
+    (x, o, c), y = synthetic_windows(4, 64, 6, seed=8)
+    g = torch.Generator().manual_seed(1)
+    tr = NativeTrainer(native_model(shape, sd, "fp32", train=True), d, lr=1e-3)
+    for _ in range(12):  # N = 12 trunk steps
+        tr.step(x, o, c, y, t=torch.randint(0, 1000, (4,), generator=g), noise=torch.randn(4, 2, 64, generator=g),
+                drop_ids=torch.zeros(4).long())
+    ck = tr.checkpoint()
+    tr2 = NativeTrainer(native_model(shape, mo.seeded_state_dict(shape, 77), "fp32", train=True), d, lr=1e-3)
+    tr2.load_checkpoint(ck, relearn_embeds=True)
+    assert tr2.step_count == 12 and tr2.table_step == 0 and tr2.table_extra_steps == -12
+    # torch reference: same parameters, the checkpoint's optimizer state minus entry 7, the native gradients of the next step
+    params = {k: v.detach().clone() for k, v in tr2.model.state_dict().items()}
+    kw = dict(t=torch.tensor([3, 400, 700, 999]), noise=torch.randn(4, 2, 64, generator=g), drop_ids=torch.zeros(4).long())
+    tr2.step(x, o, c, y, **kw)
+    grads = {k: v.detach().clone() for k, v in tr2.arena.grad_views().items()}
+    plist = [torch.nn.Parameter(params[k].clone(), requires_grad=not k.endswith("playfield_size")) for k in tr2.arena.names]
+    opt = torch.optim.AdamW(plist, lr=1e-3, weight_decay=0)
+    osd = {"state": {k: v for k, v in ck["opt"]["state"].items() if int(k) != 7}, "param_groups": ck["opt"]["param_groups"]}
+    opt.load_state_dict(osd)
+    for k, p in zip(tr2.arena.names, plist):
+        if p.requires_grad:
+            p.grad = grads[k].to(p.device)
+    opt.step()
+    got = dict(tr2.model.state_dict())
+    for k, p in zip(tr2.arena.names, plist):
+        assert maxdiff(got[k].cpu(), p.detach().cpu()) < 2e-7, k
+    st = tr2.opt_state_dict()["state"]
+    assert float(st[7]["step"]) == 1.0 and float(st[8]["step"]) == 13.0
 
 
 def test_training_rejects_padded_shapes():
