@@ -38,8 +38,9 @@ def test_fp8_forward_stays_close_to_the_fp32_oracle(hidden, heads, T_):
         assert torch.isfinite(got).all()
         errs[prec] = float((got - ref).pow(2).mean().sqrt())
     scale = float(ref.pow(2).mean().sqrt())
+    print(f"rms deviation from the fp32 oracle (rms of the output {scale:.3f}): bf16 tier {errs['bf16']:.3e}, fp8 tier {errs['fp8']:.3e}")
     assert errs["fp8"] < 2e-2 * scale, (errs, scale)          # ~0.7 % rms measured
-    assert errs["fp8"] < 8 * errs["bf16"] + 1e-4, errs        # ~3x the bf16 tier's deviation
+    assert errs["bf16"] < 3e-3 * scale, (errs, scale)         # the bf16 tier (split first linear) sits an order of magnitude below
 
 
 def test_fp8_cfg_sampling_loop_tracks_the_bf16_tier():
