@@ -8,6 +8,18 @@ sample.py (sample.py:208-232), running the native MI355X path.
 data_loading.py:32-39); `--synthetic T` draws a synthetic one.  The sampled sequences are also saved as
 `results/<name>/result.pt` ((n, 19, T): sampled x, y in osu! pixels + the original features).  `--plot-time` trims the
 sequence as the reference does; the matplotlib plot / animation themselves are out of scope.
+
+Reproducibility (`--noise cpu`): the noise is drawn from torch's CPU generator seeded by `--seed` in exactly the order the
+reference's CPU path consumes it -- `torch.randn(n, 2, T)` once (sample.py:97), then one `randn_like(x)` of shape (2n, 2, T)
+per sampling step (gaussian_diffusion.py:454 / :589) -- so `sample.py --noise cpu --precision fp32` is comparable with the
+reference run on the same (seed, beatmap, num-sampling-steps): final coordinates within 1e-3 (tests/test_gpu_scripts.py,
+fixture g12_cli_toy).  The default `--noise gpu` draws on the device (like the reference on CUDA, whose stream no CPU run
+reproduces either).
+
+Several GPUs (`torchrun --nproc-per-node G sample.py ...`): the variants are independent rows, so rank r samples variants
+[r*ceil(n/G), ...) with each conditional row next to its unconditional twin, and rank 0 gathers and writes the results
+(the reference is single-GPU, sample.py:43).  Every rank draws the noise of ALL variants and keeps its slice, so
+the result does not depend on G.
 """
 import argparse
 import logging
@@ -23,6 +35,7 @@ from osu_diffusion_amd.beatmap import Beatmap, beatmap_to_sequence
 from osu_diffusion_amd.diffusion import create_diffusion
 from osu_diffusion_amd.export import create_beatmap
 from osu_diffusion_amd.models import DiT_models, find_model
+from osu_diffusion_amd.sharding import gather_rows, shard_rows
 from osu_diffusion_amd.synthetic import banded_attn_mask
 from osu_diffusion_amd.windows import split_and_process_sequence_no_augment as split_and_process_sequence  # sample.py:64
 
@@ -51,14 +64,30 @@ def load_sequence(args):
     return seq.float(), os.path.splitext(os.path.basename(path))[0], None
 
 
+def dist_setup():
+    """(rank, world) — one process per GPU under torchrun, else (0, 1)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1, "cuda"
+    import torch.distributed as dist
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    local = 0 if os.environ.get("OSUD_SINGLE_DEVICE", "0") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist.init_process_group(os.environ.get("OSUD_DIST_BACKEND", "nccl"))  # nccl = RCCL on ROCm
+    return dist.get_rank(), world, f"cuda:{local}"
+
+
 def main(args):
     torch.manual_seed(args.seed)
     torch.set_grad_enabled(False)
     assert torch.cuda.is_available(), "the native path needs an AMD GPU (there is no CPU fallback)"
-    device = "cuda"
+    rank, world, device = dist_setup()
     seq_no_embed, name, beatmap = load_sequence(args)
     result_dir = os.path.join("results", name)
-    os.makedirs(result_dir, exist_ok=True)
+    if rank == 0:
+        os.makedirs(result_dir, exist_ok=True)
     if args.plot_time is not None:  # sample.py:59-63: keep seq_len objects from that time on
         start_index = int(torch.nonzero(seq_no_embed[2] >= args.plot_time)[0])
         seq_no_embed = seq_no_embed[:, start_index:start_index + args.seq_len]
@@ -85,8 +114,20 @@ def main(args):
         class_labels = [idx + i for i in range(args.num_variants)]
     else:
         class_labels = [args.num_classes]  # null class (sample.py:91-93)
-    n = len(class_labels)
-    z = torch.randn(n, 2, seq_len, device=device)
+    n_all = len(class_labels)
+    lo, hi = shard_rows(n_all, rank, world)  # this rank's variants (rows are independent: no exchange while sampling)
+    n = hi - lo
+    class_labels = class_labels[lo:hi]
+    noise_dev = "cpu" if args.noise == "cpu" else device
+    z_all = torch.randn(n_all, 2, seq_len, device=noise_dev)  # sample.py:97 — all variants on every rank, then this rank's rows
+    # one randn_like(x) of the doubled batch per step (gaussian_diffusion.py:454), for ALL variants, then this rank's rows: the
+    # result does not depend on the number of ranks.  cpu: torch's CPU generator, call by call in the reference's order.
+    rows = torch.cat([torch.arange(lo, hi), n_all + torch.arange(lo, hi)])
+    if args.noise == "cpu":
+        step_noise = torch.stack([torch.randn(2 * n_all, 2, seq_len)[rows] for _ in range(diffusion.num_timesteps)]).to(device)
+    else:
+        step_noise = torch.stack([torch.randn(2 * n_all, 2, seq_len, device=device)[rows.to(device)] for _ in range(diffusion.num_timesteps)])
+    z = z_all[lo:hi].to(device)
     o = seq_o.repeat(n, 1).to(device)
     c = seq_c.repeat(n, 1, 1).to(device)
     y = torch.tensor(class_labels, device=device)
@@ -96,15 +137,20 @@ def main(args):
 
     def to_seq(samples):  # normalised positions + the source's time / type rows (sample.py:110-112)
         samples, _ = samples.chunk(2, dim=0)
-        return torch.concatenate([samples.cpu(), seq_no_embed[2:].repeat(n, 1, 1)], 1)
+        samples = gather_rows(samples, n_all, rank, world)  # rank 0: all variants in order; other ranks: None
+        if samples is None:
+            return None
+        return torch.concatenate([samples.cpu(), seq_no_embed[2:].repeat(n_all, 1, 1)], 1)
 
     def save_sequence(sampled_seq, iteration_number=None):  # sample.py:114-141
+        if sampled_seq is None:  # not rank 0
+            return
         tail = "" if iteration_number is None else f" {iteration_number}"
         pixels = sampled_seq.clone()
         pixels[:, :2] *= playfield_size.view(1, 2, 1)
         out = os.path.join(result_dir, f"result{tail.replace(' ', '_')}.pt")
         torch.save(pixels, out)
-        print(f"saved {n} sampled sequence(s) to {out}")
+        print(f"saved {n_all} sampled sequence(s) to {out}")
         if beatmap is None:
             return
         for idx, seq in enumerate(sampled_seq):
@@ -116,20 +162,27 @@ def main(args):
             except Exception as e:  # the reference logs and carries on with the next variant
                 logging.error("Failed to create beatmap.", exc_info=e)
 
-    if args.sampler == "ddim":  # gaussian_diffusion.py:653-733 (the reference ships the sampler but no CLI switch for it)
+    if n == 0:  # more ranks than variants: nothing to sample here, but the gather is collective
+        samples = z
+    elif args.sampler == "ddim":  # gaussian_diffusion.py:653-733 (the reference ships the sampler but no CLI switch for it)
         samples = diffusion.ddim_sample_loop(model.forward_with_cfg, z.shape, z, clip_denoised=True, model_kwargs=model_kwargs,
-                                             progress=False, device=device, eta=args.ddim_eta)
+                                             progress=False, device=device, eta=args.ddim_eta, step_noise=step_noise)
     else:
         samples = diffusion.p_sample_loop(model.forward_with_cfg, z.shape, z, clip_denoised=True, model_kwargs=model_kwargs,
-                                          progress=False, device=device)
+                                          progress=False, device=device, step_noise=step_noise)
     save_sequence(to_seq(samples))
     if args.refine_ckpt is not None:  # sample.py:186-205: repeated t=0 steps with the refine model
         model.load_state_dict(find_model(args.refine_ckpt))
-        for _ in range(args.refine_iters):
+        for _ in range(args.refine_iters if n else 0):
             t = torch.tensor([0] * samples.shape[0], device=device)
             samples = diffusion.p_sample(model.forward_with_cfg, samples, t, clip_denoised=True,
                                          model_kwargs=model_kwargs)["sample"]
         save_sequence(to_seq(samples), args.refine_iters)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 # flag -> (type, default) for the reference's flag set (sample.py:208-232); same names, same defaults
@@ -154,6 +207,9 @@ def parse_args(argv=None):
     p.add_argument("--precision", choices=["bf16", "fp32", "fp8"], default="bf16")
     p.add_argument("--sampler", choices=["p", "ddim"], default="p", help="ancestral p_sample loop (reference default) or DDIM")
     p.add_argument("--ddim-eta", type=float, default=0.0)
+    p.add_argument("--noise", choices=["gpu", "cpu"], default="gpu",
+                   help="cpu: draw the initial and per-step noise from torch's CPU generator in the reference's order (reproducible "
+                        "against the reference's CPU path); gpu: draw on the device")
     a = p.parse_args(argv)
     if not (a.beatmap or a.synthetic):
         p.error("--beatmap <map.osu|seq.pt|seq.npy> or --synthetic T")

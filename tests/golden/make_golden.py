@@ -619,9 +619,61 @@ def g6_long_loops():
              wsum=checksum(sd), pos_gain=pos_gain, o=o, c=c, y=y, **out)
 
 
+def g12_cli_toy():
+    """What `sample.py --noise cpu` must reproduce: the reference's own sampling call sequence (sample.py:39-108,174-182 --
+    torch.manual_seed(seed); z = randn(n, 2, T); doubled [cond; null] batch; banded mask; p_sample_loop with randn_like per
+    step) on the toy beatmap's window tensors.  The reference's sample.py cannot be imported (`slider`), so its few lines of
+    setup are re-enacted here around the REFERENCE model and diffusion objects; the window tensors come from this repository's
+    `.osu` reader (parsing itself is unpinned) and are stored in the fixture."""
+    print("G12 CLI: reference sampling flow on the toy beatmap")
+    from osu_diffusion_amd.beatmap import Beatmap, beatmap_to_sequence
+    from osu_diffusion_amd.windows import split_and_process_sequence_no_augment
+    shape, wseed, num_classes, label = SMALL, 21, 10, 3
+    sd = mo.seeded_state_dict(shape, wseed)
+    ref = ref_model_for(shape, sd)
+    seq_full = beatmap_to_sequence(Beatmap.from_path(os.path.join(HERE, "toy_beatmap.osu")))
+    out = {}
+    for tag, steps, plot_time, seq_len_flag in (("full100", 100, None, 128), ("trim250", 250, 30000.0, 128)):
+        seq = seq_full
+        if plot_time is not None:  # sample.py:59-63
+            start = int(torch.nonzero(seq[2] >= plot_time)[0])
+            seq = seq[:, start:start + seq_len_flag]
+        (sx, so, sc), T = split_and_process_sequence_no_augment(seq)
+        so = so - so[0]                                                    # sample.py:65
+        mask = banded_attn_mask(T, seq_len_flag)                           # sample.py:81-84
+        r, i = torch.meshgrid(torch.arange(T), torch.arange(T), indexing="ij")
+        assert torch.equal(mask, ~((r >= i - seq_len_flag) & (r < i + seq_len_flag)))
+        dref = ref_create_diffusion(str(steps), noise_schedule="squaredcos_cap_v2")
+        torch.manual_seed(0)                                               # sample.py:41 (--seed 0)
+        n = 1
+        z = torch.randn(n, 2, T)                                           # sample.py:97
+        o, c = so.repeat(n, 1), sc.repeat(n, 1, 1)
+        y = torch.tensor([label])
+        z, o, c = torch.cat([z, z], 0), torch.cat([o, o], 0), torch.cat([c, c], 0)
+        y = torch.cat([y, torch.tensor([num_classes] * n)], 0)
+        kw = dict(o=o, c=c, y=y, cfg_scale=4.0, attn_mask=mask)
+        final = dref.p_sample_loop(ref.forward_with_cfg, z.shape, z, clip_denoised=True, model_kwargs=kw, progress=False, device="cpu")
+        samples, _ = final.chunk(2, dim=0)
+        # the oracle through the same flow (a 20-step run over the whole 757-object map is NOT well-posed to 1e-3: two fp32
+        # evaluations -- this oracle and the reference -- end 4.7e-3 apart; 50 steps: 7.6e-4; 100 steps: 2e-4)
+        torch.manual_seed(0)
+        zz = torch.randn(n, 2, T)
+        zz = torch.cat([zz, zz])
+        nz = torch.stack([torch.randn_like(zz) for _ in range(steps)])
+        mine = do.sample_loop(do.create_schedule(str(steps), "squaredcos_cap_v2"),
+                              lambda xx, tt: mo.forward_with_cfg(sd, shape, xx, tt, o, c, y, 4.0, attn_mask=mask), zz, nz)
+        close(mine[:n], samples, 5e-4, f"cli {tag}")
+        print(f"  {tag}: T={T}, {steps} steps, final range [{samples.min():.3f}, {samples.max():.3f}]")
+        out.update({tag + ":T": T, tag + ":steps": steps, tag + ":final": samples, tag + ":x": sx, tag + ":o": so, tag + ":c": sc})
+        if plot_time is not None:
+            out[tag + ":plot_time"] = plot_time
+    save("g12_cli_toy", shape=np.array([shape.depth, shape.hidden, shape.heads, shape.num_classes]), wseed=wseed, wsum=checksum(sd),
+         label=label, style_id=5, cfg_scale=4.0, seed=0, **out)
+
+
 if __name__ == "__main__":
     steps = [g1_schedules, g2_embeddings, g3_forward, g5_step, g6_loop, g7_training, g9_init_and_keys, g9_windows, g10_curves, g11_inpaint,
-             g3_forward_dit_b, g7_training_dit_b, g6_long_loops]
+             g3_forward_dit_b, g7_training_dit_b, g6_long_loops, g12_cli_toy]
     only = set(sys.argv[1:])  # e.g. `make_golden.py g10_curves` regenerates one family
     for fn in steps:
         if not only or fn.__name__ in only:

@@ -112,3 +112,37 @@ def test_row_exchange_of_the_class_table_equals_dense_allreduce():
         (ref0, got0), (ref1, got1) = out[0], out[1]
     assert torch.equal(got0, got1)  # replicas bit-identical
     assert float((got0 - ref0).abs().max()) <= 1e-6 and float((ref0 - ref1).abs().max()) == 0.0
+
+
+def test_sampling_row_shards():
+    from osu_diffusion_amd.sharding import shard_rows
+
+    assert [shard_rows(64, r, 8) for r in (0, 7)] == [(0, 8), (56, 64)]
+    assert [shard_rows(3, r, 2) for r in range(2)] == [(0, 2), (2, 3)]
+    assert [shard_rows(1, r, 4) for r in range(4)] == [(0, 1), (1, 1), (1, 1), (1, 1)]  # more ranks than variants: empty shards
+    for n, w in ((5, 3), (8, 8), (9, 4)):
+        got = [shard_rows(n, r, w) for r in range(w)]
+        assert got[0][0] == 0 and got[-1][1] == n and all(a[1] == b[0] for a, b in zip(got, got[1:]))
+
+
+def _gather_worker(rank, world, port, n_total, out):
+    import torch.distributed as dist
+    from osu_diffusion_amd.sharding import gather_rows, shard_rows
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = torch.arange(n_total * 6, dtype=torch.float32).view(n_total, 2, 3)
+    lo, hi = shard_rows(n_total, rank, world)
+    got = gather_rows(full[lo:hi].clone(), n_total, rank, world)
+    out[rank] = None if got is None else bool(torch.equal(got, full))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [3, 1, 4])
+def test_gather_rows_two_ranks_gloo(n_total):
+    """sample.py under torchrun: ragged shards (3 variants on 2 ranks), an empty shard (1 variant on 2 ranks), even shards."""
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_gather_worker, args=(2, port, n_total, out), nprocs=2, join=True)
+        assert dict(out) == {0: True, 1: None}

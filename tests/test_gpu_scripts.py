@@ -43,6 +43,75 @@ def test_sample_script_osu_in_osu_out(tmp_path):
     assert saved.shape == (1, 19, 757)
 
 
+def _cli_fixture(tmp_path):
+    """The synthetic checkpoint and style index the CLI golden (g12_cli_toy) was made with."""
+    import pickle
+
+    from oracle import dit_oracle as mo
+    from tests.helpers import load, weights_for
+
+    fx = load("g12_cli_toy")
+    shape, sd = weights_for(fx)
+    ckpt = tmp_path / "ckpt.pt"
+    torch.save({"ema": sd, "model": sd}, ckpt)             # find_model takes the "ema" weights (sample.py:31-36)
+    idx = tmp_path / "beatmap_idx.pickle"
+    with open(idx, "wb") as f:
+        pickle.dump({int(fx["style_id"]): int(fx["label"])}, f)
+    return fx, str(ckpt), str(idx)
+
+
+@pytest.mark.parametrize("tag", ["full100", "trim250"])
+def test_sample_cli_with_cpu_noise_reproduces_the_reference_run(tmp_path, tag):
+    """north_star: identical (seed, beatmap, num-sampling-steps) -> final (x, y) within 1e-3 of the reference's CPU path.
+    `sample.py --noise cpu --precision fp32` against fixture g12_cli_toy (the reference's sampling flow on the toy beatmap:
+    the whole 757-object map with 100 steps, and a 128-object window from t = 30 s with 250 steps; DiT-S, cfg-scale 4)."""
+    fx, ckpt, idx = _cli_fixture(tmp_path)
+    args = [os.path.join(ROOT, "sample.py"), "--beatmap", TOY, "--ckpt", ckpt, "--model", "DiT-S", "--num-classes", "10",
+            "--num-sampling-steps", str(int(fx[tag + ":steps"])), "--cfg-scale", "4.0", "--seed", "0", "--seq-len", "128",
+            "--style-id", str(int(fx["style_id"])), "--beatmap-idx", idx, "--noise", "cpu", "--precision", "fp32"]
+    if tag + ":plot_time" in fx:
+        args += ["--plot-time", str(float(fx[tag + ":plot_time"]))]
+    out = run(args, str(tmp_path))
+    assert f"seq len {int(fx[tag + ':T'])}" in out
+    saved = torch.load(glob.glob(os.path.join(str(tmp_path), "results", "*", "result.pt"))[0])  # (1, 19, T), positions in osu! pixels
+    got = saved[:, :2] / torch.tensor([512.0, 384.0]).view(1, 2, 1)
+    err = float((got - torch.from_numpy(fx[tag + ":final"])).abs().max())
+    print(f"sample.py --noise cpu --precision fp32 vs reference [{tag}]: max|d| = {err:.3e} (normalised coordinates)")
+    assert err < 1e-3
+
+
+def test_sample_cli_rows_sharded_over_two_ranks_equal_one_process(tmp_path):
+    """torchrun --nproc-per-node 2 sample.py (both ranks on GPU 0, gloo): 3 variants -> shards of 2 and 1 rows, gathered on
+    rank 0; equal to the single-process run because every rank draws the noise of all variants and keeps its rows."""
+    import socket
+
+    fx, ckpt, idx = _cli_fixture(tmp_path)
+    common = ["--beatmap", TOY, "--ckpt", ckpt, "--model", "DiT-S", "--num-classes", "10", "--num-sampling-steps", "8", "--cfg-scale",
+              "4.0", "--seed", "1", "--seq-len", "128", "--style-id", str(int(fx["style_id"])), "--beatmap-idx", idx, "--num-variants", "3",
+              "--plot-time", "30000", "--precision", "fp32"]
+    results = {}
+    for name, noise in (("one", "cpu"), ("two", "cpu"), ("one_gpu", "gpu"), ("two_gpu", "gpu")):
+        cwd = tmp_path / name
+        cwd.mkdir()
+        if name.startswith("one"):
+            run([os.path.join(ROOT, "sample.py")] + common + ["--noise", noise], str(cwd))
+        else:
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                port = s.getsockname()[1]
+            env = dict(os.environ, PYTHONPATH=ROOT, OSUD_DIST_BACKEND="gloo", OSUD_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+            r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                                "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "sample.py")] + common + ["--noise", noise],
+                               cwd=str(cwd), env=env, capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        results[name] = torch.load(glob.glob(os.path.join(str(cwd), "results", "*", "result.pt"))[0])
+        assert results[name].shape[0] == 3
+        assert len(glob.glob(os.path.join(str(cwd), "results", "*", "*.osu"))) == 3
+    assert float((results["one"] - results["two"]).abs().max()) <= 1e-3      # pixels
+    assert float((results["one_gpu"] - results["two_gpu"]).abs().max()) <= 1e-3
+    assert float((results["one"][0, :2] - results["one"][1, :2]).abs().max()) > 1.0   # the variants differ
+
+
 def test_train_script_on_osu_dataset(tmp_path):
     for track, ident in ((0, "000003"), (1, "000007")):
         folder = tmp_path / "data" / f"Track{track:05d}" / "beatmaps"

@@ -130,6 +130,28 @@ def test_training_at_dit_b_width():
         assert maxdiff(g[::stride][:4096].float(), fx["sample:" + k]) < 1e-5, k
 
 
+@pytest.mark.parametrize("tag", ["trim250"])  # "full100" (757 objects x 100 steps) is checked when the fixture is made: too slow here
+def test_cli_sampling_flow_on_the_toy_beatmap(tag):
+    """fixture g12_cli_toy (the reference's sample.py flow, --seed 0, cfg 4, banded mask): the oracle with noise drawn from the
+    CPU generator in the reference's order -- randn(n, 2, T) once, then randn_like(x) per step."""
+    from osu_diffusion_amd.synthetic import banded_attn_mask
+
+    fx = load("g12_cli_toy")
+    shape, sd = weights_for(fx)
+    Tn, steps = int(fx[tag + ":T"]), int(fx[tag + ":steps"])
+    o, c = T(fx[tag + ":o"]).repeat(2, 1), T(fx[tag + ":c"]).repeat(2, 1, 1)
+    y = torch.tensor([int(fx["label"]), shape.num_classes])
+    mask = banded_attn_mask(Tn, 128)
+    sch = do.create_schedule(str(steps), "squaredcos_cap_v2")
+    torch.manual_seed(int(fx["seed"]))
+    z = torch.randn(1, 2, Tn)
+    z = torch.cat([z, z])
+    noises = torch.stack([torch.randn_like(z) for _ in range(steps)])
+    fn = lambda xx, tt: mo.forward_with_cfg(sd, shape, xx, tt, o, c, y, float(fx["cfg_scale"]), attn_mask=mask)  # noqa: E731
+    final = do.sample_loop(sch, fn, z, noises)
+    assert maxdiff(final[:1], fx[tag + ":final"]) < 1e-3
+
+
 @pytest.mark.parametrize("loss", ["l1", "mse"])
 def test_training_losses_and_grads(loss):
     fx = load("g7_train_" + loss)
