@@ -58,6 +58,7 @@ struct GemmP {
                       // of the grid (R = My / rows per wave, reported through colpart_rows); summed over R they are the bias gradient
   int* colpart_rows;  // host pointer, written at launch
   unsigned* sched;    // set by the launcher for multi-round launches: {ticket, done} counters of the dynamic tile queue
+  int exp_delay;   // experiments only (-DOSUD_GEMM_EXP): odd workgroup groups start this many 100 MHz ticks late
   int tile_order;  // 0/1 = plain x-fastest runs per XCD (default), 2 = banded per XCD (fewer weight re-reads, not faster)
 };
 

@@ -337,6 +337,13 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
   uint64_t tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const uint64_t tk0 = __builtin_readcyclecounter();
 #endif
+#ifdef OSUD_GEMM_EXP
+  if (p.exp_delay > 0 && ((blockIdx.x >> 3) & 1)) {  // experiment: every other workgroup of each XCD starts late (de-phased epilogues)
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < (uint64_t)p.exp_delay) __builtin_amdgcn_s_sleep(8);
+  }
+  const bool exp_nostore = (p.tile_order & 16) != 0, exp_nomath = (p.tile_order & 32) != 0;
+#endif
   bool first_tile = true;
   while (t_cur < ntiles) {
     int ty, tx;
@@ -533,6 +540,21 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
           if (EPI == EPI_ROWBIAS_TE) v[e] += rb[q];
         }
         const size_t o = (size_t)(y0 + 16 * q) * p.ldo + x;
+#ifdef OSUD_GEMM_EXP
+        if (exp_nostore || exp_nomath) {  // timing experiments: (16) the epilogue's arithmetic without its stores, (32) its stores without the arithmetic
+          if (exp_nomath) {
+            store8(reinterpret_cast<TO*>(p.out) + o, v);
+            if (EPI == EPI_BIAS_GELU_TE && p.out2) store8(reinterpret_cast<TO*>(p.out2) + o, v);
+          } else {
+            float dg[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gelu_tanh_both_t<FAST>(v[e], w[e], dg[e]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(w[e]), "v"(dg[e]));
+          }
+          continue;
+        }
+#endif
         if (EPI == EPI_BIAS_F32 || EPI == EPI_NONE_F32) {
           store8(reinterpret_cast<float*>(p.out) + o, v);
         } else if (EPI == EPI_ACCUM_F32) {
@@ -764,6 +786,8 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
   {
     static const int order = [] { const char* e = getenv("OSUD_GEMM_ORDER"); return e ? atoi(e) : 0; }();
     if (order) p.tile_order = order;
+    static const int delay = [] { const char* e = getenv("OSUD_GEMM_DELAY"); return e ? atoi(e) : 0; }();
+    p.exp_delay = delay;
   }
   const int esz = (int)elem_size(prec);
   OSUD_CHECK_ARG(p.My > 0 && p.Nx > 0 && p.K > 0 && p.My % 128 == 0 && p.Nx % 128 == 0 && (p.K * esz) % SLAB == 0,

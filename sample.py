@@ -125,8 +125,8 @@ def main(args):
     rows = torch.cat([torch.arange(lo, hi), n_all + torch.arange(lo, hi)])
     if args.noise == "cpu":
         step_noise = torch.stack([torch.randn(2 * n_all, 2, seq_len)[rows] for _ in range(diffusion.num_timesteps)]).to(device)
-    else:
-        step_noise = torch.stack([torch.randn(2 * n_all, 2, seq_len, device=device)[rows.to(device)] for _ in range(diffusion.num_timesteps)])
+    else:  # the block draw p_sample_loop itself makes when no noise is handed in
+        step_noise = torch.randn(diffusion.num_timesteps, 2 * n_all, 2, seq_len, device=device)[:, rows.to(device)].contiguous()
     z = z_all[lo:hi].to(device)
     o = seq_o.repeat(n, 1).to(device)
     c = seq_c.repeat(n, 1, 1).to(device)

@@ -144,6 +144,8 @@ def test_cli_sampling_flow_on_the_toy_beatmap(tag):
     mask = banded_attn_mask(Tn, 128)
     sch = do.create_schedule(str(steps), "squaredcos_cap_v2")
     torch.manual_seed(int(fx["seed"]))
+    from osu_diffusion_amd.models import DiT_models  # sample.py:69-76 constructs the model after seeding: its init advances the generator
+    DiT_models["DiT-S"](num_classes=shape.num_classes, context_size=144)
     z = torch.randn(1, 2, Tn)
     z = torch.cat([z, z])
     noises = torch.stack([torch.randn_like(z) for _ in range(steps)])
