@@ -52,6 +52,8 @@ def parse():
     ap.add_argument("--model", default="DiT-B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--zero1", action="store_true", help="N > 1: sharded optimizer between reduce-scatter and all-gather instead of all-reduce")
+    ap.add_argument("--grad-wire", choices=["fp32", "bf16"], default="fp32", help="--zero1: dtype of the gradients on the wire")
     ap.add_argument("--no-family-table", action="store_true", help="skip the torch.profiler pass (use under rocprofv3)")
     ap.add_argument("--no-parity-tier", action="store_true", help="skip the fp32 parity-tier throughput and the bf16-vs-fp32 drift run")
     ap.add_argument("--drift-steps", type=int, default=1000, help="length of the CFG-4 loop the bf16 drift is measured on")
@@ -323,7 +325,8 @@ def bench_train(args, world, rank, dev):
     for i in range(4):  # a few distinct resident batches, cycled
         (x, o, c), y = synthetic_windows(B, T, num_classes, seed=10_000 * rank + i, train_offsets=True)
         batches.append(((x.to(dev), o.to(dev), c.to(dev)), y.to(dev)))
-    trainer = NativeTrainer(model, diffusion, lr=1e-4)
+    trainer = NativeTrainer(model, diffusion, lr=1e-4, shard_optimizer=True if args.zero1 else None,
+                            wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None)
     terms = None
     for i in range(W):
         (x, o, c), y = batches[i % 4]
@@ -346,7 +349,9 @@ def bench_train(args, world, rank, dev):
         "config": {"workload": f"train.py step: {args.model} seq-len {T}, per-GPU batch {B} synthetic windows (global {B * world}), "
                                f"L1+vb loss, AdamW lr 1e-4, EMA 0.9999, label dropout 0.2, squaredcos_cap_v2 1000 steps",
                    "per_gpu_batch": B, "global_batch": B * world, "seq_len": T,
-                   "parallelism": f"dp{world}: flat fp32 gradient arena, per-slice RCCL all-reduces overlapped with the phased backward" if world > 1 else "single GPU",
+                   "parallelism": (f"dp{world}: flat fp32 gradient arena, " + (f"per-slice RCCL reduce-scatter ({args.grad_wire} wire) -> AdamW/EMA on the own "
+                                                                                 f"1/{world} shard -> all-gather of the masters" if trainer.shard_optimizer else
+                                                                                 "per-slice RCCL all-reduces") + " overlapped with the phased backward") if world > 1 else "single GPU",
                    "last_loss": round(loss, 4)},
         "per_gpu_tokens_per_s": round(tokens_per_s / world, 1),
     }

@@ -233,6 +233,45 @@ def backward_with_overlapped_allreduce(model, dout, group=None, force=False, on_
     return 1.0 / dist.get_world_size(group) if active else 1.0
 
 
+# ------------------------------------------------------------------------------ ZeRO-1 exchange (reduce-scatter / all-gather)
+def shard_plan(lo, hi, world, align=4):
+    """How one contiguous gradient slice [lo, hi) of the flat arena is exchanged when the optimizer is sharded: a bulk of
+    world x per elements (per a multiple of `align`: 16-byte aligned shards) that is reduce-scattered -- rank r owns
+    [lo + r*per, lo + (r+1)*per) -- and a remainder of fewer than world x align elements that is all-reduced and updated by every
+    rank.  Returns (per, bulk_hi)."""
+    per = ((hi - lo) // world) // align * align
+    return per, lo + per * world
+
+
+def _reduce_scatter_sum(out, inp, group):
+    """SUM reduce-scatter of `inp` (world x out.numel()) into `out`; async handle.  RCCL: one reduce_scatter_tensor; backends
+    without it (gloo, used by the CPU / one-GPU tests): all-reduce, then keep the own shard."""
+    import torch.distributed as dist
+
+    if dist.get_backend(group) == "nccl":
+        return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group, async_op=True), None
+    h = dist.all_reduce(inp, op=dist.ReduceOp.SUM, group=group, async_op=True)
+    r, n = dist.get_rank(group), out.numel()
+    return h, (lambda: out.copy_(inp[r * n:(r + 1) * n]))
+
+
+def _all_gather_into(full, shard, group):
+    """all-gather equal shards into `full` (shard may be full's own slice: in place); async handle + finisher."""
+    import torch.distributed as dist
+
+    if dist.get_backend(group) == "nccl":
+        return dist.all_gather_into_tensor(full, shard, group=group, async_op=True), None
+    W = dist.get_world_size(group)
+    parts = [torch.empty_like(shard) for _ in range(W)]
+    h = dist.all_gather(parts, shard.clone(), group=group, async_op=True)
+    n = shard.numel()
+
+    def finish():
+        for r, part in enumerate(parts):
+            full[r * n:(r + 1) * n].copy_(part)
+    return h, finish
+
+
 class _DiTFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, t, o, c, y, *params):
@@ -285,7 +324,7 @@ class NativeTrainer:
     made here unless given) tracks it with decay 0.9999."""
 
     def __init__(self, model, diffusion, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ema_decay=0.9999,
-                 ema=None, group=None, broadcast_init=True):
+                 ema=None, group=None, broadcast_init=True, shard_optimizer=None, wire_dtype=None):
         from .diffusion import gaussian_diffusion as gd
 
         assert diffusion.model_mean_type == gd.ModelMeanType.EPSILON
@@ -315,6 +354,18 @@ class NativeTrainer:
         # one-call backward keeps the adaLN weight gradients in a single batched GEMM
         self.overlap_adamw = os.environ.get("OSUD_ADAMW_OVERLAP", "0") == "1"
         self._side = None
+        # ZeRO-1 between the two halves of the gradient exchange: every finished slice is reduce-SCATTERED
+        # (rank r receives the sum of its 1/world shard), AdamW + EMA run on that shard only (1/world of the 6.1 GB the optimizer
+        # streams per step), and the updated master weights are all-GATHERED.  Same bytes on the wire as the all-reduce, same
+        # results (the sum of a shard is formed once instead of world times).  OSUD_ZERO1=1 / shard_optimizer=True.
+        # wire_dtype=torch.bfloat16 (OSUD_GRAD_WIRE=bf16) halves the reduce-scatter bytes: gradients are rounded to bf16 for
+        # the exchange and summed by RCCL in bf16 (reduced precision of the AVERAGED gradient, 2^-9 relative: opt-in).
+        self.shard_optimizer = (os.environ.get("OSUD_ZERO1", "0") == "1") if shard_optimizer is None else bool(shard_optimizer)
+        if wire_dtype is None and os.environ.get("OSUD_GRAD_WIRE", "") == "bf16":
+            wire_dtype = torch.bfloat16
+        self.wire_dtype = wire_dtype
+        self._shard_buf = None
+        self._ema_stale = False
         import torch.distributed as dist
 
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and "OSUD_GEMM_DYNAMIC" not in os.environ:
@@ -371,6 +422,9 @@ class NativeTrainer:
             if single and self.overlap_adamw and not self.force_phased:
                 self._backward_with_overlapped_adamw(dout)
                 return terms
+            if self.shard_optimizer and (not single or self.force_phased) and dist.is_available() and dist.is_initialized():
+                self._backward_sharded(dout)
+                return terms
             scale = backward_with_overlapped_allreduce(model, dout, self.group, force=self.force_phased, on_blocks_reduced=early)
             if done:
                 self._adamw(_complement(done, self.arena.total), scale)
@@ -403,6 +457,98 @@ class NativeTrainer:
         self._adamw(_complement(done, self.arena.total), 1.0)
         main.wait_stream(self._side)
         self._refresh()
+
+    def _backward_sharded(self, dout):
+        """Phased backward with the sharded optimizer in the middle of the gradient exchange:
+            phase done -> async reduce-scatter of that slice (own shard lands in self._shard_buf)
+            all phases done -> small tail all-reduced, class-table rows exchanged (both updated by every rank)
+            AdamW + EMA on the own shards (gradient = the scattered sum x 1/world) and on the replicated parts
+            async all-gather of the updated master shards, slice by slice -> re-pack of the low-precision copies."""
+        import torch.distributed as dist
+
+        model, arena, group = self.model, self.arena, self.group
+        W, r = dist.get_world_size(group), dist.get_rank(group)
+        depth = model.depth
+        blocks, tail = overlap_slices(arena, depth)
+        _, _, f_lo, f_hi = next(s for s in tail if s[0] == "final")
+        order = [(f_lo, f_hi)] + [(blocks[depth - p][2], blocks[depth - p][3]) for p in range(1, depth + 1)]  # as the phases finish
+        plans = [(lo, hi) + shard_plan(lo, hi, W) for lo, hi in order]
+        need = sum(per for _, _, per, _ in plans)
+        wire = self.wire_dtype
+        if self._shard_buf is None or self._shard_buf.numel() < need or self._shard_buf.dtype != (wire or torch.float32):
+            self._shard_buf = torch.empty(need, dtype=wire or torch.float32, device=arena.flat.device)
+        pending, off = [], 0
+        dout = native_backward(model, dout, phases=(0, 0))
+        for p, (lo, hi, per, bulk_hi) in enumerate(plans):
+            if p > 0:
+                native_backward(model, dout, phases=(p, p))
+            out = self._shard_buf[off:off + per]
+            if per > 0:
+                src = arena.grads[lo:bulk_hi] if wire is None else arena.grads[lo:bulk_hi].to(wire)
+                pending.append(_reduce_scatter_sum(out, src, group) + (src,))  # (handle, finisher, keep-alive)
+            if bulk_hi < hi:
+                pending.append((dist.all_reduce(arena.grads[bulk_hi:hi], op=dist.ReduceOp.SUM, group=group, async_op=True), None, None))
+            off += per
+        native_backward(model, dout, phases=(depth + 1, depth + 1))
+        for kind, _, lo, hi in tail:
+            if kind == "tail":
+                pending.append((dist.all_reduce(arena.grads[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True), None, None))
+        for h, fin, _keep in pending:
+            h.wait()
+            if fin is not None:
+                fin()
+        _, _, t_lo, t_hi = next(s for s in tail if s[0] == "table")
+        rows = dict(model.named_parameters())["y_embedder.embedding_table.weight"].shape[0]
+        exchange_table_rows(arena.grads[t_lo:t_hi].view(rows, -1), model._train_keep[4], group)
+        # ---- optimizer: own shards from the scatter buffer, everything else replicated
+        self._advance()
+        scale, off, own, gathers = 1.0 / W, 0, [], []
+        for lo, hi, per, bulk_hi in plans:
+            if per > 0:
+                a, b = lo + r * per, lo + (r + 1) * per
+                g = self._shard_buf[off:off + per]
+                self._adamw_range(a, b, g if wire is None else g.float(), scale)
+                own.append((lo, bulk_hi))
+                gathers.append(_all_gather_into(arena.flat[lo:bulk_hi], arena.flat[a:b], group))
+            off += per
+        self._adamw(_complement(own, arena.total), scale)
+        for h, fin in gathers:
+            h.wait()
+            if fin is not None:
+                fin()
+        self._ema_stale = True  # every rank's EMA is current only on its own shards (and the replicated parts)
+        self._refresh()
+
+    def _adamw_range(self, lo, hi, grads, grad_scale):
+        """AdamW + EMA on arena elements [lo, hi) with the gradient taken from `grads` (hi - lo elements, e.g. a scattered shard)."""
+        a, dev = self.arena, self.arena.flat.device
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().osud_adamw_ema_step(
+                _lib.ptr(a.flat[lo:hi]), _lib.ptr(grads), _lib.ptr(self.exp_avg[lo:hi]), _lib.ptr(self.exp_avg_sq[lo:hi]),
+                _lib.ptr(self.ema_arena.flat[lo:hi]), hi - lo, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                max(self.step_count, 1), self.ema_decay, 0, 0, float(grad_scale), _lib.stream_ptr(dev)))
+
+    def sync_sharded_state(self):
+        """Sharded optimizer: bring the moments and the EMA of every shard to every rank (checkpoints and EMA evaluation need the
+        whole state; during training nobody reads the other ranks' shards)."""
+        import torch.distributed as dist
+
+        if not (self.shard_optimizer and self._ema_stale and dist.is_available() and dist.is_initialized()):
+            return
+        W, r = dist.get_world_size(self.group), dist.get_rank(self.group)
+        blocks, tail = overlap_slices(self.arena, self.model.depth)
+        _, _, f_lo, f_hi = next(s for s in tail if s[0] == "final")
+        for lo, hi in [(f_lo, f_hi)] + [(b[2], b[3]) for b in blocks]:
+            per, bulk_hi = shard_plan(lo, hi, W)
+            if per == 0:
+                continue
+            for buf in (self.exp_avg, self.exp_avg_sq, self.ema_arena.flat):
+                h, fin = _all_gather_into(buf[lo:bulk_hi], buf[lo + r * per:lo + (r + 1) * per], self.group)
+                h.wait()
+                if fin is not None:
+                    fin()
+        self._ema_stale = False
+        self.ema._uploaded = {}
 
     def _table_range(self):
         i = self.arena.names.index("y_embedder.embedding_table.weight")
@@ -502,6 +648,7 @@ class NativeTrainer:
                 self.step_count = int(float(st["step"]))
 
     def checkpoint(self, args=None):
+        self.sync_sharded_state()
         scaler = {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000,
                   "_growth_tracker": 0}  # bf16 needs no loss scaling; key kept for layout compatibility
         return {"model": {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},

@@ -27,16 +27,21 @@ def batch():
     return x, o, c, y, t, noise
 
 
-def run(rank, world, steps=2):
+def run(rank, world, steps=2, zero1=False, wire=None, full_state=False):
     # every rank starts from DIFFERENT weights: the constructor's rank-0 broadcast must make them equal
     model = build(100 + rank)
-    tr = NativeTrainer(model, create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True), lr=1e-3)
+    tr = NativeTrainer(model, create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True), lr=1e-3,
+                       shard_optimizer=zero1, wire_dtype=wire)
     x, o, c, y, t, noise = batch()
     per = 8 // world
     sl = slice(rank * per, (rank + 1) * per)
     for _ in range(steps):
         tr.step(x[sl], o[sl], c[sl], y[sl], t=t[sl], noise=noise[sl])
     torch.cuda.synchronize()
+    if full_state:  # checkpoint() gathers the sharded moments / EMA first
+        tr.sync_sharded_state()
+        return (tr.arena.flat.detach().cpu().clone(), tr.ema_arena.flat.detach().cpu().clone(), tr.exp_avg.detach().cpu().clone(),
+                tr.exp_avg_sq.detach().cpu().clone())
     return tr.arena.flat.detach().cpu().clone(), tr.ema_arena.flat.detach().cpu().clone()
 
 
@@ -45,7 +50,12 @@ if __name__ == "__main__":
     torch.cuda.set_device(0)
     dist.init_process_group(os.environ.get("OSUD_DIST_BACKEND", "gloo"))
     rank, world = dist.get_rank(), dist.get_world_size()
-    flat, ema = run(rank, world)
-    torch.save({"flat": flat, "ema": ema}, os.path.join(out_dir, f"rank{rank}.pt"))
+    mode = os.environ.get("OSUD_TEST_MODE", "allreduce")  # allreduce | zero1 | zero1_bf16
+    if mode == "allreduce":
+        flat, ema = run(rank, world)
+        torch.save({"flat": flat, "ema": ema}, os.path.join(out_dir, f"rank{rank}.pt"))
+    else:
+        flat, ema, m1, m2 = run(rank, world, zero1=True, wire=torch.bfloat16 if mode.endswith("bf16") else None, full_state=True)
+        torch.save({"flat": flat, "ema": ema, "exp_avg": m1, "exp_avg_sq": m2}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

@@ -146,3 +146,50 @@ def test_gather_rows_two_ranks_gloo(n_total):
         out = mgr.dict()
         mp.spawn(_gather_worker, args=(2, port, n_total, out), nprocs=2, join=True)
         assert dict(out) == {0: True, 1: None}
+
+
+def test_shard_plan_partitions_a_slice():
+    from osu_diffusion_amd.training import shard_plan
+
+    for lo, hi, W in ((0, 1000, 8), (17, 17 + 7_077_888, 8), (5, 5 + 30, 8), (100, 103, 2), (0, 4096, 1)):
+        per, bulk_hi = shard_plan(lo, hi, W)
+        assert per % 4 == 0 and bulk_hi == lo + per * W and bulk_hi <= hi and hi - bulk_hi < 4 * W + W
+
+
+def _zero1_worker(rank, world, port, out):
+    """The exchange of the sharded optimizer on CPU tensors over gloo (reduce-scatter falls back to all-reduce + own shard):
+    scatter -> local update of the own shard -> gather must equal all-reduce -> update everywhere."""
+    from osu_diffusion_amd.training import _all_gather_into, _reduce_scatter_sum, shard_plan
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(3 + rank)
+        lo, hi = 16, 16 + 1003                      # a slice that does not divide by world * 4
+        grads = torch.randn(1100, generator=g)
+        params = torch.arange(1100, dtype=torch.float32) / 100
+        ref_g = grads.clone()
+        dist.all_reduce(ref_g)
+        want = params.clone()
+        want[lo:hi] -= 0.1 * ref_g[lo:hi] / world
+        per, bulk_hi = shard_plan(lo, hi, world)
+        shard = torch.empty(per)
+        h, fin = _reduce_scatter_sum(shard, grads[lo:bulk_hi], None)
+        h2 = dist.all_reduce(grads[bulk_hi:hi], async_op=True)
+        h.wait(); fin and fin(); h2.wait()
+        a, b = lo + rank * per, lo + (rank + 1) * per
+        params[a:b] -= 0.1 * shard / world
+        params[bulk_hi:hi] -= 0.1 * grads[bulk_hi:hi] / world
+        h, fin = _all_gather_into(params[lo:bulk_hi], params[a:b], None)
+        h.wait(); fin and fin()
+        out[rank] = float((params - want).abs().max())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_exchange_two_ranks_gloo():
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_zero1_worker, args=(2, port, out), nprocs=2, join=True)
+        assert max(out.values()) <= 1e-6, dict(out)

@@ -39,3 +39,63 @@ def test_two_ranks_equal_one_process_on_the_full_batch():
     start = mp_worker.build(100)
     from osu_diffusion_amd.training import ParamArena
     assert float((ParamArena(start).flat.cpu() - flat).abs().max()) > 1e-4  # the two steps really moved the weights
+
+
+def _torchrun(nproc, script_args, env_extra, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT, **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port())] + script_args
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    return r.stdout
+
+
+def test_sharded_optimizer_two_ranks_equal_the_allreduce_path():
+    """ZeRO-1 between reduce-scatter and all-gather (training.NativeTrainer._backward_sharded), 2 ranks on GPU 0 over gloo:
+    replicas bit-identical, weights / EMA / both moments equal to the all-reduce path to 2e-6 (the shard sums are formed in a
+    different order), also after gathering the sharded optimizer state for a checkpoint."""
+    res = {}
+    for mode in ("allreduce", "zero1"):
+        with tempfile.TemporaryDirectory() as d:
+            _torchrun(2, [os.path.join(ROOT, "tests", "mp_worker.py"), d], dict(OSUD_DIST_BACKEND="gloo", OSUD_TEST_MODE=mode))
+            res[mode] = [torch.load(os.path.join(d, f"rank{r}.pt")) for r in (0, 1)]
+    z0, z1 = res["zero1"]
+    for k in ("flat", "ema", "exp_avg", "exp_avg_sq"):
+        assert torch.equal(z0[k], z1[k]), k                                  # replicas in lock step, full state on both
+    a0 = res["allreduce"][0]
+    scale = float(a0["flat"].abs().max())
+    assert float((z0["flat"] - a0["flat"]).abs().max()) <= 2e-6 * scale
+    assert float((z0["ema"] - a0["ema"]).abs().max()) <= 2e-6 * scale
+
+
+def test_rccl_is_executed_world_size_one():
+    """The process group the 8-GPU job uses -- backend "nccl" = RCCL -- initialised with one rank on this box: the phased backward
+    with its per-slice all-reduces, the row exchange of the class table, and the reduce-scatter / all-gather of the sharded
+    optimizer all run through RCCL (a 1-rank collective is a copy, but every call, stream hand-over and buffer aliasing rule is
+    the real one), in fp32 and with the bf16 wire.  Results equal the no-process-group run."""
+    from tests import mp_worker
+
+    want_flat, want_ema = mp_worker.run(0, 1)
+    for mode, tol in (("allreduce", 0.0), ("zero1", 0.0), ("zero1_bf16", 2e-3)):
+        with tempfile.TemporaryDirectory() as d:
+            _torchrun(1, [os.path.join(ROOT, "tests", "mp_worker.py"), d],
+                      dict(OSUD_DIST_BACKEND="nccl", OSUD_TEST_MODE=mode, OSUD_FORCE_PHASED="1"))
+            got = torch.load(os.path.join(d, "rank0.pt"))
+        err = float((got["flat"] - want_flat).abs().max())
+        scale = float(want_flat.abs().max())
+        assert err <= max(tol, 2e-6) * scale, (mode, err)
+
+
+def test_bench_two_ranks_over_gloo():
+    """bench.py's N > 1 code path (rank set-up, barriers, max-over-ranks timing, one JSON line from rank 0) with both ranks on
+    GPU 0; once with the all-reduce exchange, once with the sharded optimizer."""
+    import json
+
+    for extra in ([], ["--zero1"]):
+        out = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "train", "--steps", "2", "--warmup", "1", "--batch", "16",
+                            "--model", "DiT-S", "--no-cpu-baseline", "--no-roofline"] + extra,
+                        dict(OSUD_DIST_BACKEND="gloo", OSUD_SINGLE_DEVICE="1"))
+        line = [ln for ln in out.splitlines() if ln.startswith("{")][-1]
+        res = json.loads(line)
+        assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
+        assert res["config"]["global_batch"] == 32
