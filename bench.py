@@ -487,6 +487,7 @@ def parity_tier_and_drift(args, dev):
     states, sec = {}, {}
     pert = torch.randn(n, 2, T, device=dev, generator=g)
     for name, prec, eps in runs:
+        torch.manual_seed(4321)  # the trunk's Xavier / normal initialisation draws from the global generator: same weights every time
         model = DiT_models[args.model](num_classes=num_classes, context_size=19 - 3 + 128, precision=prec)
         model = randomize_zero_init(model.to(dev), seed=0).eval()
         model.reserve(2 * n, T)
