@@ -43,7 +43,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--mode", choices=["both", "sample", "train"], default=os.environ.get("OSUD_BENCH_MODE", "both"))
+    ap.add_argument("--mode", choices=["both", "sample", "train", "xl"], default=os.environ.get("OSUD_BENCH_MODE", "both"))
+    ap.add_argument("--no-xl", action="store_true", help="mode both: skip the DiT-XL seq-len 256 line (BASELINE configs[4] shape)")
+    ap.add_argument("--xl-precision", choices=["bf16", "fp8"], default=None, help="tier of the DiT-XL line (default: both, bf16 first)")
     ap.add_argument("--batch", type=int, default=256, help="training windows per GPU")
     ap.add_argument("--sample-steps", type=int, default=None, help="timed sampling steps in mode both (default 1000)")
     ap.add_argument("--precision", choices=["bf16", "fp32", "fp8"], default="bf16")
@@ -531,11 +533,34 @@ def parity_tier_and_drift(args, dev):
     return out, drift
 
 
+XL_TIERS = ["bf16"]  # + "fp8" once the fp8 training tier is built
+FLOP_PER_TOKEN_TRAIN_XL = 2783.5e6  # DiT-XL, T=256
+
+
+def bench_xl(args, world, rank, dev, precision="bf16", steps=None, warmup=None):
+    """BASELINE configs[4]'s shape on this job's GPUs: DiT-XL (D=1152, 28 blocks, 16 heads of 72), seq-len 256, 128 windows per
+    GPU, the whole train.py step.  A secondary line (the headline metric is DiT-B): few steps, no CPU leg."""
+    xa = argparse.Namespace(**vars(args))
+    xa.model, xa.seq_len, xa.batch, xa.precision = "DiT-XL", 256, 128, precision
+    xa.steps, xa.warmup = (steps if steps is not None else 6), (warmup if warmup is not None else 2)
+    xa.no_roofline, xa.no_cpu_baseline, xa.h2d, xa.no_family_table = True, True, False, True
+    r = bench_train(xa, world, rank, dev)
+    per_gpu = r["value"] / world
+    peak = PEAK_BF16_TFLOPS * (2.0 if precision == "fp8" else 1.0)
+    out = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "per_gpu_tokens_per_s")}
+    out["end_to_end"] = {"flop_per_token": FLOP_PER_TOKEN_TRAIN_XL, "achieved_tflops_per_gpu": round(per_gpu * FLOP_PER_TOKEN_TRAIN_XL / 1e12, 1),
+                         "peak_tflops": peak, "mfma_frac": round(per_gpu * FLOP_PER_TOKEN_TRAIN_XL / 1e12 / peak, 4)}
+    return out
+
+
 def main():
     args = parse()
     world, rank, local = dist_setup(args)
     dev = torch.device("cuda", local if world > 1 else 0)
-    if args.mode == "train":
+    if args.mode == "xl":
+        res = bench_xl(args, world, rank, dev, args.xl_precision or "bf16", args.steps, args.warmup)
+        res.update({"n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic"})
+    elif args.mode == "train":
         res = bench_train(args, world, rank, dev)
     elif args.mode == "sample":
         res = bench_sample(args, world, rank, dev)
@@ -548,6 +573,8 @@ def main():
                                                 "roofline", "cpu_baseline") if k in samp}
         if world == 1 and args.precision == "bf16" and not args.no_parity_tier:
             res["parity_tier"], res["bf16_drift"] = parity_tier_and_drift(args, dev)
+        if not args.no_xl and args.precision == "bf16":
+            res["xl"] = {p: bench_xl(args, world, rank, dev, p) for p in ([args.xl_precision] if args.xl_precision else XL_TIERS)}
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -28,9 +28,9 @@ template <int HD, int HDP, int NT>
 __global__ __launch_bounds__(NT) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                             const bf16_t* __restrict__ O, const float* __restrict__ lse,
                                                             bf16_t* __restrict__ dqkv, int T, int D, float c1,
-                                                            float scale) {
+                                                            float scale, float* __restrict__ dbias) {
   using TL = AttnTile<HDP>;
-  constexpr int KS = HDP / 16, DT = HDP / 32, CPR = TL::CPR;
+  constexpr int KS = HDP / 16, DT = HDP / 32, CPR = TL::CPR, NWV = NT / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
   char* Ks = Qs + T * TL::RS;
@@ -38,6 +38,25 @@ __global__ __launch_bounds__(NT) void attn_bwd_bf16_kernel(const bf16_t* __restr
   char* Os = Vs + T * TL::RS;  // dO rows
   float* lse_s = reinterpret_cast<float*>(Os + T * TL::RS);
   float* del_s = lse_s + T;
+  // in_proj bias gradient riding along (dbias != nullptr): column sums of this head's dQ | dK | dV over the workgroup's
+  // tokens, [3][waves][HDP] partial sums here, one atomic per column at the end (replaces a separate pass over dqkv)
+  float* cs_s = del_s + T;
+  // sum over the 32 rows a wave owns: lane (frow, fhalf) holds row frow; after the butterfly every lane of a half holds the sum
+  auto colsum_store = [&](const f32x16 (&acc)[DT], int part) {
+    if (dbias == nullptr) return;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = acc[dt][r];
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        if ((threadIdx.x & 31) == 0) cs_s[(part * NWV + (threadIdx.x >> 6)) * HDP + dt * 32 + 8 * (r >> 2) + 4 * ((threadIdx.x >> 5) & 1) + (r & 3)] = v;
+      }
+  };
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 31, fhalf = lane >> 5;
@@ -120,6 +139,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_bf16_kernel(const bf16_t* __restr
         for (int g = 0; g < 4; ++g)
           if (dt * 32 + 8 * g + 4 * fhalf < HD)
             store4(orow + dt * 32 + 8 * g + 4 * fhalf, dq[dt][4 * g], dq[dt][4 * g + 1], dq[dt][4 * g + 2], dq[dt][4 * g + 3]);
+      colsum_store(dq, 0);
     }
     // =============================== pass B: dK, dV for keys own..own+31 =====================
     {
@@ -176,6 +196,18 @@ __global__ __launch_bounds__(NT) void attn_bwd_bf16_kernel(const bf16_t* __restr
             store4(orow + 2 * D + d, dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
           }
         }
+      colsum_store(dk, 1);
+      colsum_store(dv, 2);
+    }
+  }
+  if (dbias != nullptr) {
+    __syncthreads();
+    const int nw = T / 32 < NWV ? T / 32 : NWV;  // waves that own rows
+    for (int i = tid; i < 3 * HD; i += NT) {
+      const int part = i / HD, d = i % HD;
+      float v = 0.f;
+      for (int w = 0; w < nw; ++w) v += cs_s[(part * NWV + w) * HDP + d];
+      atomicAdd(dbias + (size_t)part * D + h * HD + d, v);
     }
   }
 }
@@ -465,14 +497,14 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_f32_kernel(const float* __res
 }  // namespace
 
 int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* O, const float* lse, void* dqkv, int N,
-                         int T, int heads, int head_dim, hipStream_t st, float* delta_ws) {
+                         int T, int heads, int head_dim, hipStream_t st, float* delta_ws, float* dbias) {
   OSUD_CHECK_ARG(N > 0 && T > 0 && T % 64 == 0, "attention backward: T=%d must be a multiple of 64", T);
   const int D = heads * head_dim;
   const float scale = 1.0f / sqrtf((float)head_dim);
   if (prec == OSUD_PREC_BF16) {
     // a workgroup keeps the whole sequence of one (sample, head) in LDS: 4 tiles of T rows (one wave per 32 rows)
     const int rs = head_dim == 64 ? AttnTile<64>::RS : AttnTile<96>::RS;
-    const size_t lds = (size_t)4 * T * rs + (size_t)2 * T * 4;
+    const size_t lds = (size_t)4 * T * rs + (size_t)2 * T * 4 + (size_t)3 * 8 * 96 * 4;  // + column-sum partials [3][<= 8 waves][HDP]
     if (head_dim != 64 && head_dim != 72) {
       set_error("attention backward (bf16 tier) is built for head_dim 64 and 72 (got %d)", head_dim);
       return OSUD_ERR_UNSUPPORTED;
@@ -495,6 +527,7 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
                            delta_ws, (bf16_t*)dqkv, T, D, c1t, scale);
       }
       OSUD_HIP(hipGetLastError());
+      if (dbias != nullptr) OSUD_TRY(launch_colsum_bf16(dqkv, 3 * D, N * T, 3 * D, dbias, st));  // streamed variant: separate pass
       return OSUD_OK;
     }
     static bool attr_set = false;
@@ -510,13 +543,13 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
     const float c1 = scale * 1.4426950408889634f;
     if (head_dim == 64 && T <= 128)
       hipLaunchKernelGGL((attn_bwd_bf16_kernel<64, 64, 256>), dim3(heads, N), dim3(256), lds, st, (const bf16_t*)qkv,
-                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale);
+                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale, dbias);
     else if (head_dim == 64)
       hipLaunchKernelGGL((attn_bwd_bf16_kernel<64, 64, 512>), dim3(heads, N), dim3(512), lds, st, (const bf16_t*)qkv,
-                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale);
+                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale, dbias);
     else
       hipLaunchKernelGGL((attn_bwd_bf16_kernel<72, 96, 256>), dim3(heads, N), dim3(256), lds, st, (const bf16_t*)qkv,
-                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale);
+                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale, dbias);
   } else {
     const dim3 grid(T / 64, heads, N);
 #define OSUD_ABWD(HD)                                                                                                   \

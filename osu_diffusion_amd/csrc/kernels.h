@@ -35,8 +35,9 @@ int launch_attention(int prec, const void* qkv, int ld_qkv, const uint8_t* mask,
                      float fp8_scale = 0.f /* > 0 (bf16 tier only): out is e4m3 [Mp][D], values multiplied by this */);
 int launch_mask_tiles(const uint8_t* mask, int T, int Tp, uint8_t* kb_class, hipStream_t st);
 // delta_ws: [N][heads][T] fp32 scratch, needed when the sequence of one head does not fit the LDS (streamed variant)
+// dbias (optional, bf16 tier): [3 * hidden] fp32, += column sums of dqkv over all tokens (the in_proj bias gradient)
 int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* O, const float* lse, void* dqkv, int N,
-                         int T, int heads, int head_dim, hipStream_t st, float* delta_ws = nullptr);
+                         int T, int heads, int head_dim, hipStream_t st, float* delta_ws = nullptr, float* dbias = nullptr);
 
 // kernels_bwd.hip
 int launch_transpose(int prec, const void* in, int ld_in, void* out, int ld_out, int R, int C, float* colsum,

@@ -235,11 +235,14 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dbr, D, bw.w_o_t, D, Mp, D, D, w.dao, D, nullptr, st));
     OSUD_TRY(weight_grad(m, w.dbr, D, sv.ao, D, D, D, Mp, G(p + "attn.out_proj.weight"), nullptr, st));
     OSUD_TRY(dbg_sync(st, "wgrad out_proj"));
-    OSUD_TRY(launch_attention_bwd(prec, sv.qk, w.dao, sv.ao, sv.lse, w.dqkv, N, T, m->H, m->hd, st, w.attn_delta));
+    // (bf16 tier: the in_proj bias gradient = column sums of dqkv comes out of the attention backward kernel itself)
+    const bool fused_bqkv = prec == OSUD_PREC_BF16;
+    OSUD_TRY(launch_attention_bwd(prec, sv.qk, w.dao, sv.ao, sv.lse, w.dqkv, N, T, m->H, m->hd, st, w.attn_delta,
+                                  fused_bqkv ? g_bqkv : nullptr));
     OSUD_TRY(dbg_sync(st, "attention bwd"));
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dqkv, 3 * D, bw.w_qkv_t, 3 * D, Mp, D, 3 * D, w.du, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "dgrad qkv"));
-    OSUD_TRY(weight_grad(m, w.dqkv, 3 * D, sv.u1, D, 3 * D, D, Mp, G(p + "attn.in_proj_weight"), g_bqkv, st));
+    OSUD_TRY(weight_grad(m, w.dqkv, 3 * D, sv.u1, D, 3 * D, D, Mp, G(p + "attn.in_proj_weight"), fused_bqkv ? nullptr : g_bqkv, st));
     OSUD_TRY(dbg_sync(st, "wgrad qkv"));
     // LN1 backward -> dh = grad wrt h_in = grad wrt the output of block l-1, whose MLP gate step rides along
     if (l > 0) {
@@ -417,24 +420,53 @@ __global__ __launch_bounds__(256) void train_loss_kernel(const float* __restrict
 
 // AdamW (torch.optim.AdamW semantics, decoupled weight decay) + EMA in one pass over flat arenas.
 // Elements in [skip_begin, skip_end) (the frozen playfield_size parameter) get only the EMA update.
-__global__ void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1,
-                                 float* __restrict__ m2, float* __restrict__ ema, size_t n, float lr, float beta1,
-                                 float beta2, float eps, float wd, float bc1, float bc2_sqrt, float decay,
-                                 size_t skip_begin, size_t skip_end, float grad_scale) {
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    float pv = p[i];
-    if (i < skip_begin || i >= skip_end) {
-      const float gv = g[i] * grad_scale;
-      pv = pv * (1.0f - lr * wd);
-      const float a = m1[i] * beta1 + (1.0f - beta1) * gv;  // exp_avg.lerp_(grad, 1 - beta1)
-      const float b = m2[i] * beta2 + (1.0f - beta2) * gv * gv;
-      m1[i] = a;
-      m2[i] = b;
-      const float denom = sqrtf(b) / bc2_sqrt + eps;
-      pv = pv - (lr / bc1) * (a / denom);
-      p[i] = pv;
-    }
-    if (ema != nullptr) ema[i] = ema[i] * decay + pv * (1.0f - decay);  // update_ema, train.py:36-45
+struct AdamC {
+  float lr, beta1, beta2, eps, wd, bc1, bc2_sqrt, decay, grad_scale;
+};
+__device__ __forceinline__ void adamw_one(float& pv, float gv, float& a, float& b, float& e, const AdamC& c, bool frozen, bool has_ema) {
+  if (!frozen) {
+    gv *= c.grad_scale;
+    pv = pv * (1.0f - c.lr * c.wd);
+    a = a * c.beta1 + (1.0f - c.beta1) * gv;  // exp_avg.lerp_(grad, 1 - beta1)
+    b = b * c.beta2 + (1.0f - c.beta2) * gv * gv;
+    const float denom = sqrtf(b) / c.bc2_sqrt + c.eps;
+    pv = pv - (c.lr / c.bc1) * (a / denom);
+  }
+  if (has_ema) e = e * c.decay + pv * (1.0f - c.decay);  // update_ema, train.py:36-45
+}
+// Nine 4-byte streams per element (p, g, m1, m2, ema in; p, m1, m2, ema out): HBM-bound.  16 bytes per lane and stream in the
+// body; `head` scalar elements in front bring all five arrays (same element offset into equally aligned arenas) to a 16-byte
+// boundary, the remainder is scalar again.
+__global__ __launch_bounds__(256) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1,
+                                                        float* __restrict__ m2, float* __restrict__ ema, size_t n, AdamC c,
+                                                        size_t skip_begin, size_t skip_end, size_t head) {
+  const bool has_ema = ema != nullptr;
+  const size_t n4 = (n - head) / 4, tail0 = head + n4 * 4;
+  const size_t gid = blockIdx.x * (size_t)blockDim.x + threadIdx.x, gstride = (size_t)gridDim.x * blockDim.x;
+  for (size_t v = gid; v < n4; v += gstride) {
+    const size_t i = head + v * 4;
+    float4 pv = *reinterpret_cast<float4*>(p + i);
+    const float4 gv = *reinterpret_cast<const float4*>(g + i);
+    float4 a = *reinterpret_cast<float4*>(m1 + i), b = *reinterpret_cast<float4*>(m2 + i);
+    float4 e = has_ema ? *reinterpret_cast<float4*>(ema + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool any_frozen = i < skip_end && i + 4 > skip_begin;
+    adamw_one(pv.x, gv.x, a.x, b.x, e.x, c, any_frozen && i + 0 >= skip_begin && i + 0 < skip_end, has_ema);
+    adamw_one(pv.y, gv.y, a.y, b.y, e.y, c, any_frozen && i + 1 >= skip_begin && i + 1 < skip_end, has_ema);
+    adamw_one(pv.z, gv.z, a.z, b.z, e.z, c, any_frozen && i + 2 >= skip_begin && i + 2 < skip_end, has_ema);
+    adamw_one(pv.w, gv.w, a.w, b.w, e.w, c, any_frozen && i + 3 >= skip_begin && i + 3 < skip_end, has_ema);
+    *reinterpret_cast<float4*>(p + i) = pv;
+    *reinterpret_cast<float4*>(m1 + i) = a;
+    *reinterpret_cast<float4*>(m2 + i) = b;
+    if (has_ema) *reinterpret_cast<float4*>(ema + i) = e;
+  }
+  for (size_t k = gid; k < head + (n - tail0); k += gstride) {  // unaligned head and tail, one element per thread
+    const size_t i = k < head ? k : tail0 + (k - head);
+    float pv = p[i], a = m1[i], b = m2[i], e = has_ema ? ema[i] : 0.f;
+    adamw_one(pv, g[i], a, b, e, c, i >= skip_begin && i < skip_end, has_ema);
+    p[i] = pv;
+    m1[i] = a;
+    m2[i] = b;
+    if (has_ema) ema[i] = e;
   }
 }
 
@@ -546,9 +578,18 @@ extern "C" int osud_adamw_ema_step(float* params, const float* grads, float* exp
   // bias corrections in double, as torch evaluates them in Python floats (1 - 0.999f loses 4-5 digits in fp32 at small steps)
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-  const int grid = (int)((n + 255) / 256 > 8192 ? 8192 : (n + 255) / 256);
-  hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq,
-                     ema, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, ema_decay, skip_begin, skip_end, grad_scale);
+  // all five arenas are indexed by the same element offset and are equally aligned: `head` elements reach a 16-byte boundary
+  size_t head = (size_t)((16 - (reinterpret_cast<uintptr_t>(params) & 15)) & 15) / 4;
+  const bool same = ((reinterpret_cast<uintptr_t>(params) ^ reinterpret_cast<uintptr_t>(grads)) & 15) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(params) ^ reinterpret_cast<uintptr_t>(exp_avg)) & 15) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(params) ^ reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0 &&
+                    (ema == nullptr || ((reinterpret_cast<uintptr_t>(params) ^ reinterpret_cast<uintptr_t>(ema)) & 15) == 0);
+  if (!same || head > n) head = n;  // differently aligned buffers (never the trainer's arenas): everything on the scalar path
+  const size_t work = (n - head) / 4 + 8;
+  const int grid = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
+  const AdamC c{lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, ema_decay, grad_scale};
+  hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, ema, n, c,
+                     skip_begin, skip_end, head);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }

@@ -110,6 +110,10 @@ struct WgradP {
   size_t split_stride;
   unsigned* queue;  // shared-GPU mode (256x256 geometry, splits > 1): [tile] chunk tickets, [63] finished workgroups; else null
   int chunk;        // chunks per tile (a multiple of split_k)
+  // in-launch split-K combine (GPU not shared, splits > 1): `arrive` = [tile] arrival counters + [255] finished workgroups;
+  // the workgroups of a tile meet on its counter and each sums its share of the tile's rows over all partial slabs into `final`
+  unsigned* arrive;
+  float* final;
 };
 
 template <int WY, int WX, int RY, int RX>
@@ -322,6 +326,48 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
     }
     store_tile(ty, tx);
   }
+  if (p.arrive != nullptr) {
+    // ---- in-launch split-K combine (replaces the separate splitk_reduce launch and its kernel boundary).  One tile per
+    // workgroup here (gridDim.x == ntiles), all gridDim.x * split_k <= #CUs workgroups resident (one per CU by LDS).
+    // Publish: every wave drains its slab stores, one lane releases at agent scope and counts in; consume: ONE relaxed poll
+    // loop, ONE agent acquire, then plain loads (cdna_hip_programming.md Guideline 16: the per-XCD L2s are not coherent and
+    // a CU's L1 is never refreshed by other CUs' stores).  The sum runs over the splits in index order: deterministic.
+    const int tile = first /* the one tile this workgroup computed: the XCD-remapped index of blockIdx.x */, ty = tile / ntx, tx = tile % ntx, S = p.split_k,
+              sidx = blockIdx.y;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // restated behind the write-back where the compiler cannot drop it
+      __hip_atomic_fetch_add(p.arrive + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      unsigned spins = 0;
+      while (__hip_atomic_load(p.arrive + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > (1u << 26)) __builtin_trap();  // a workgroup of this tile never ran: fail loudly, never hang
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    const int r0 = (int)((long)sidx * G::BM / S), r1 = (int)((long)(sidx + 1) * G::BM / S);
+    constexpr int C4 = G::BN / 4;  // float4 columns per tile row
+    const float* slab0 = p.out + (size_t)(ty * G::BM) * p.Nx + (size_t)tx * G::BN;
+    float* fin = p.final + (size_t)(ty * G::BM) * p.Nx + (size_t)tx * G::BN;
+    for (int idx = tid; idx < (r1 - r0) * C4; idx += G::NT) {
+      const int row = r0 + idx / C4, c4 = idx % C4;
+      const size_t o = (size_t)row * p.Nx + (size_t)c4 * 4;
+      float4 a = *reinterpret_cast<const float4*>(slab0 + o);
+      for (int s2 = 1; s2 < S; ++s2) {
+        const float4 b = *reinterpret_cast<const float4*>(slab0 + (size_t)s2 * p.split_stride + o);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      *reinterpret_cast<float4*>(fin + o) = a;
+    }
+    if (tid == 0) {  // the last workgroup out re-arms the counters for the next launch that borrows this slot
+      const unsigned done = __hip_atomic_fetch_add(p.arrive + 255, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (done == gridDim.x * gridDim.y - 1)
+        for (int i = 0; i < 256; ++i) __hip_atomic_store(p.arrive + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // column sums of a bf16 [M][N] matrix: out[c] += sum_m a[m][c]   (bias gradients).  HBM-bound: a workgroup sweeps
@@ -397,6 +443,21 @@ unsigned* queue_slot() {
   return g_queue_pool[dev] + 64 * (seq.fetch_add(1) % kQueueSlots);
 }
 
+// counter sets of the in-launch combine (256 words: [tile] arrivals, [255] finished workgroups), re-armed by the last workgroup out
+constexpr int kArriveSlots = 64;
+unsigned* g_arrive_pool[kMaxDevices] = {};
+unsigned* arrive_slot() {
+  static std::atomic<unsigned> seq{0};
+  const int dev = cur_device_w();
+  if (!g_arrive_pool[dev]) {
+    unsigned* pool = nullptr;
+    if (hipMalloc(&pool, kArriveSlots * 256 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(pool, 0, kArriveSlots * 256 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    g_arrive_pool[dev] = pool;
+  }
+  return g_arrive_pool[dev] + 256 * (seq.fetch_add(1) % kArriveSlots);
+}
+
 template <int WY, int WX, int RY, int RX> int launch_wg(const WgradP& p, hipStream_t st) {
   using G = WGeo<WY, WX, RY, RX>;
   const size_t lds = (size_t)G::NSTAGE * G::STAGE + (size_t)G::NW * 4096;
@@ -438,8 +499,17 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
     p.chunk = S * per_wg;
     p.queue = queue_slot();
   }
+  // GPU not shared (no tile queues): the partial slabs are combined inside the launch, by the workgroups that wrote them
+  // (every one of the tiles * S <= #CUs workgroups is resident: one per CU).  OSUD_WGRAD_COMBINE=0: separate reduce launch.
+  static const bool combine_on = [] { const char* e = getenv("OSUD_WGRAD_COMBINE"); return !(e && e[0] == '0'); }();
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+  if (S > 1 && p.queue == nullptr && combine_on && !capturing && tiles < 255 && tiles * S <= num_cus_w()) {
+    p.arrive = arrive_slot();
+    p.final = out;
+  }
   OSUD_TRY(big ? (launch_wg<2, 4, 4, 2>(p, st)) : (launch_wg<2, 2, 2, 2>(p, st)));
-  if (S > 1) OSUD_TRY(launch_splitk_reduce(ws, S, (size_t)Ny * Nx, out, (size_t)Ny * Nx, st));
+  if (S > 1 && p.arrive == nullptr) OSUD_TRY(launch_splitk_reduce(ws, S, (size_t)Ny * Nx, out, (size_t)Ny * Nx, st));
   return OSUD_OK;
 }
 

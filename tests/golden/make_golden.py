@@ -676,9 +676,127 @@ def g12_cli_toy():
          label=label, style_id=5, cfg_scale=4.0, seed=0, **out)
 
 
+def g13_export():
+    """export/create_beatmap.py:22-147 (sampled sequence -> hit objects + slider-velocity timing points) run for real on a
+    jittered copy of the toy beatmap's sequence.  Its `slider` imports are satisfied by plain records (Position, Circle,
+    Slider, Spinner, TimingPoint, Curve, a Beatmap holding the toy map's timing points): the reference's own logic -- pixel
+    rounding, anchor bookkeeping, SliderPath geometry, nearest-progress search, span count, velocity formula -- is what runs.
+    What `slider` itself would do with the objects (packing the .osu text) stays unpinned."""
+    import collections
+    import types
+    from datetime import timedelta
+    print("G13 export: reference create_beatmap on the toy sequence")
+    from osu_diffusion_amd import beatmap as B
+
+    class Position(collections.namedtuple("Position", "x y")):
+        pass
+
+    class Rec:
+        def __init__(self, *a, **k):
+            self.args, self.__dict__ = a, dict(self.__dict__, **k)
+
+    class Circle(Rec):
+        def __init__(self, position, time, hitsound, new_combo=False):
+            super().__init__(position=position, time=time, hitsound=hitsound, new_combo=new_combo)
+
+    class Spinner(Rec):
+        def __init__(self, position, time, hitsound, end_time, new_combo=False):
+            super().__init__(position=position, time=time, hitsound=hitsound, end_time=end_time, new_combo=new_combo)
+
+    class Slider(Rec):
+        pass
+
+    class TimingPoint(Rec):
+        def __init__(self, offset, ms_per_beat, meter, sample_type, sample_set, volume, parent, kiai_mode):
+            super().__init__(offset=offset, ms_per_beat=ms_per_beat, meter=meter, sample_type=sample_type, sample_set=sample_set,
+                             volume=volume, parent=parent, kiai_mode=kiai_mode)
+
+    class Curve(Rec):
+        @staticmethod
+        def from_kind_and_points(kind, points, req_length):
+            return Curve(kind=kind, points=points, req_length=req_length)
+
+    class MultiBezier(Rec):
+        def __init__(self, points, req_length):
+            super().__init__(points=points, req_length=req_length)
+
+    class RefBeatmap(Rec):
+        def timing_point_at(self, time):  # slider.Beatmap.timing_point_at: the last point at or before `time`, else the first
+            cur = self.timing_points[0]
+            for tp in self.timing_points:
+                if tp.offset <= time:
+                    cur = tp
+                else:
+                    break
+            return cur
+
+    mods = {"slider": dict(Position=Position),
+            "slider.beatmap": dict(Beatmap=RefBeatmap, Circle=Circle, HitObject=Rec, Slider=Slider, Spinner=Spinner, TimingPoint=TimingPoint,
+                                   HoldNote=Rec),
+            "slider.curve": dict(Catmull=Rec, Curve=Curve, Linear=Rec, MultiBezier=MultiBezier, Perfect=Rec)}
+    saved = {k: sys.modules.get(k) for k in list(mods) + ["export.create_beatmap"]}
+    for name, attrs in mods.items():
+        m = types.ModuleType(name)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        sys.modules[name] = m
+    sys.modules.pop("export.create_beatmap", None)
+    try:
+        import export.create_beatmap as ref_cb  # noqa: E402  (reference)
+        src = B.Beatmap.from_path(os.path.join(HERE, "toy_beatmap.osu"))
+        seq = B.beatmap_to_sequence(src)                               # (19, L): px, px, ms, one-hot types
+        g = torch.Generator().manual_seed(13)
+        jit = seq.clone()
+        jit[:2] += torch.randn(2, seq.shape[1], generator=g) * 6.0     # "sampled" positions: a few pixels off the source's
+        norm = jit.clone()
+        norm[0] /= 512.0
+        norm[1] /= 384.0
+        # reference-side beatmap record: the toy map's timing points (red points have parent None, green ones point at theirs)
+        tps, by_id = [], {}
+        for tp in src.timing_points:
+            r = TimingPoint(timedelta(milliseconds=tp.offset), tp.ms_per_beat, tp.meter, tp.sample_type, tp.sample_set, tp.volume,
+                            by_id.get(id(tp.parent)), tp.kiai_mode)
+            by_id[id(tp)] = r
+            tps.append(r)
+        fields = ("format_version audio_filename audio_lead_in preview_time countdown sample_set stack_leniency mode letterbox_in_breaks "
+                  "widescreen_storyboard bookmarks distance_spacing beat_divisor grid_size timeline_zoom title title_unicode artist "
+                  "artist_unicode creator source tags beatmap_set_id hp_drain_rate circle_size overall_difficulty approach_rate "
+                  "slider_tick_rate").split()
+        ref_bm = RefBeatmap(timing_points=tps, slider_multiplier=src.slider_multiplier, **{f: None for f in fields})
+        out = ref_cb.create_beatmap(norm, ref_bm, "golden")
+        objs, n_tp = out.hit_objects, len(out.timing_points)
+        ms = lambda td: td.total_seconds() * 1000.0  # noqa: E731
+        kind, xy, t0, t1, rep, length, letter, npts, pts = [], [], [], [], [], [], [], [], []
+        for ho in objs:
+            k = 0 if isinstance(ho, Circle) else (1 if isinstance(ho, Spinner) else 2)
+            kind.append(k)
+            xy.append([ho.position.x, ho.position.y])
+            t0.append(ms(ho.time))
+            t1.append(ms(ho.end_time) if k else ms(ho.time))
+            rep.append(ho.repeat if k == 2 else 0)
+            length.append(float(ho.length) if k == 2 else 0.0)
+            letter.append(ho.curve.kind if k == 2 else "-")
+            cp = [[q.x, q.y] for q in ho.curve.points] if k == 2 else []
+            npts.append(len(cp))
+            pts += cp
+        new_tp = out.timing_points[len([tp for tp in tps if tp.parent is None]):]
+        print(f"  {len(objs)} hit objects ({kind.count(2)} sliders, {kind.count(1)} spinners), {len(new_tp)} slider-velocity points")
+        save("g13_export", seq=norm, kind=np.array(kind), xy=np.array(xy, dtype=np.float64), time=np.array(t0), end_time=np.array(t1),
+             repeat=np.array(rep), length=np.array(length), letter=np.array(letter), n_points=np.array(npts),
+             points=np.array(pts, dtype=np.float64).reshape(-1, 2), new_combo=np.array([bool(ho.new_combo) for ho in objs]),
+             tp_offset=np.array([ms(tp.offset) for tp in new_tp]), tp_ms_per_beat=np.array([tp.ms_per_beat for tp in new_tp]),
+             tp_parent_ms_per_beat=np.array([tp.parent.ms_per_beat for tp in new_tp]), n_timing_points=n_tp)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+
+
 if __name__ == "__main__":
     steps = [g1_schedules, g2_embeddings, g3_forward, g5_step, g6_loop, g7_training, g9_init_and_keys, g9_windows, g10_curves, g11_inpaint,
-             g3_forward_dit_b, g7_training_dit_b, g6_long_loops, g12_cli_toy]
+             g3_forward_dit_b, g7_training_dit_b, g6_long_loops, g12_cli_toy, g13_export]
     only = set(sys.argv[1:])  # e.g. `make_golden.py g10_curves` regenerates one family
     for fn in steps:
         if not only or fn.__name__ in only:

@@ -17,7 +17,7 @@ from osu_diffusion_amd import beatmap as B
 from osu_diffusion_amd import windows as W
 from osu_diffusion_amd.curves import BEZIER, CATMULL, LINEAR, PERFECT
 from osu_diffusion_amd.export import create_beatmap
-from tests.helpers import GOLDEN
+from tests.helpers import GOLDEN, T, load
 
 HAND = """osu file format v14
 
@@ -241,3 +241,38 @@ def test_timing_point_lookup_and_velocity_clamp():
     assert fast.slider_duration(3200, 160, 1) == pytest.approx(160 / (100 * 1.6 * 10.0) * 400)
     slow = B.Beatmap.parse(HAND.replace("3000,-50,", "3000,-5000,"))
     assert slow.slider_duration(3200, 160, 1) == pytest.approx(160 / (100 * 1.6 * 0.1) * 400)
+
+
+def test_create_beatmap_matches_the_reference_export():
+    """fixture g13_export: export/create_beatmap.py:22-147 of the reference run on a jittered copy of the toy beatmap's sequence
+    (tests/golden/make_golden.py::g13_export).  Same objects in the same order: kinds, rounded pixel positions, times, combo flags;
+    per slider the control points, path letter, span count and length (path length x nearest progress, 1e-9 px); and the
+    slider-velocity timing points (the reference keeps times in whole microseconds, after an fp32 division, so velocities agree to 2e-4 relative)."""
+    from osu_diffusion_amd.export import create_beatmap
+
+    fx = load("g13_export")
+    src = B.Beatmap.from_path(os.path.join(GOLDEN, "toy_beatmap.osu"))
+    out = create_beatmap(T(fx["seq"]), src, "golden")
+    objs = out._hit_objects
+    assert len(objs) == len(fx["kind"])
+    kinds = [0 if isinstance(o, B.Circle) else (1 if isinstance(o, B.Spinner) else 2) for o in objs]
+    assert kinds == list(fx["kind"])
+    p0 = 0
+    for i, o in enumerate(objs):
+        assert (o.x, o.y) == tuple(fx["xy"][i]) and bool(o.new_combo) == bool(fx["new_combo"][i]), i
+        assert abs(o.time - fx["time"][i]) < 5e-3, i   # the reference divides the fp32 time by 1000 in fp32 and rounds to microseconds
+        if kinds[i]:
+            assert abs(o.end_time - fx["end_time"][i]) < 5e-3, i
+        if kinds[i] == 2:
+            n = int(fx["n_points"][i])
+            assert [tuple(map(float, q)) for q in o.points] == [tuple(q) for q in fx["points"][p0:p0 + n]], i
+            p0 += n
+            assert o.repeat == int(fx["repeat"][i]) and o.letter == str(fx["letter"][i]), i
+            assert abs(o.length - fx["length"][i]) <= 1e-9 * max(1.0, fx["length"][i]), i
+    n_red = len([tp for tp in src.timing_points if tp.parent is None])
+    new_tp = out.timing_points[n_red:]
+    assert len(out.timing_points) == int(fx["n_timing_points"]) and len(new_tp) == len(fx["tp_offset"])
+    for tp, off, mpb, par in zip(new_tp, fx["tp_offset"], fx["tp_ms_per_beat"], fx["tp_parent_ms_per_beat"]):
+        assert abs(tp.offset - off) <= 0.5 + 1e-9                            # written on the whole ms of the slider head (export.py)
+        assert abs(tp.ms_per_beat - mpb) <= 2e-4 * abs(mpb), (tp.ms_per_beat, mpb)  # span times differ by up to 4e-3 ms (see above)
+        assert tp.parent.ms_per_beat == par
