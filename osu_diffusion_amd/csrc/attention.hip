@@ -51,7 +51,10 @@ __global__ __launch_bounds__(256) void mask_tiles_kernel(const uint8_t* __restri
 // zero output columns that are not stored)
 // (4 waves per SIMD for the 64-wide head: the kernel has only two key blocks per workgroup at T = 128 and hides its load
 // latency through occupancy; prefetching the next block into registers instead was measured neutral-to-slower)
-template <int HD, int HDP>
+// KB = key blocks (of 64 keys) staged per round: with KB = 2 a workgroup at T <= 128 -- the training / sampling window -- puts
+// ALL its loads (Q fragments, both K / V blocks) in flight at once and pays one memory round trip and one barrier instead of
+// three of each (measured: 30 -> see DESIGN.md us per launch at 128 windows x 2, 12 heads).
+template <int HD, int HDP, int KB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 4 : 2))) void attn_bf16_kernel(const bf16_t* __restrict__ qk,
                                                         const uint8_t* __restrict__ mask, bf16_t* __restrict__ out,
                                                         float* __restrict__ lse, int T, int Tp, int Mp, int D,
@@ -59,8 +62,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
                                                         const uint8_t* __restrict__ kb_class, float fp8_scale) {
   using TL = AttnTile<HDP>;
   constexpr int KS = HDP / 16, DT = HDP / 32, CPR = TL::CPR;
-  __shared__ __attribute__((aligned(16))) char Ks[64 * TL::RS];
-  __shared__ __attribute__((aligned(16))) char Vs[64 * TL::RS];
+  __shared__ __attribute__((aligned(16))) char Ks_all[KB * 64 * TL::RS];
+  __shared__ __attribute__((aligned(16))) char Vs_all[KB * 64 * TL::RS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 31, fhalf = lane >> 5;
   const int n = blockIdx.z, h = blockIdx.y;
@@ -85,24 +88,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
   const int qm = qc < T ? qc : T - 1;  // row of the mask this query reads
 
   const int nkb = Tp / 64, nkb_all = nkb;
-  for (int kb = 0; kb < nkb; ++kb) {
-    if (kb * 64 >= T) break;  // whole block is padding
-    bool check_mask = mask != nullptr;
-    if (kb_class != nullptr) {  // workgroup-uniform: skip fully masked tiles, read no mask bytes on fully open ones
-      const int ca = kb_class[(size_t)(2 * blockIdx.x) * nkb_all + kb];
-      const int cb = 2 * blockIdx.x + 1 < nkb_all ? kb_class[(size_t)(2 * blockIdx.x + 1) * nkb_all + kb] : ca;
-      if (ca == 0 && cb == 0) continue;
-      check_mask = !(ca == 2 && cb == 2);
+  for (int kb0 = 0; kb0 < nkb; kb0 += KB) {
+    if (kb0 * 64 >= T) break;  // whole round is padding
+    // which blocks of this round are live (workgroup-uniform): not padding, not fully masked
+    bool live[KB], chk[KB];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+      const int kb = kb0 + j;
+      live[j] = kb < nkb && kb * 64 < T;
+      chk[j] = mask != nullptr;
+      if (live[j] && kb_class != nullptr) {  // skip fully masked tiles, read no mask bytes on fully open ones
+        const int ca = kb_class[(size_t)(2 * blockIdx.x) * nkb_all + kb];
+        const int cb = 2 * blockIdx.x + 1 < nkb_all ? kb_class[(size_t)(2 * blockIdx.x + 1) * nkb_all + kb] : ca;
+        if (ca == 0 && cb == 0) live[j] = false;
+        chk[j] = !(ca == 2 && cb == 2);
+      }
+      any = any || live[j];
     }
-    __syncthreads();          // previous block fully consumed
-    for (int idx = tid; idx < 64 * CPR; idx += 256) {
-      const int r = idx / CPR, cp = idx % CPR;
-      const bf16_t* src = qk + ((size_t)n * Tp + kb * 64 + r) * ldq + h * HD + cp * 8;
-      const bool real = cp * 8 < HD;
-      *reinterpret_cast<u32x4*>(Ks + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(src + D) : zero4;
-      *reinterpret_cast<u32x4*>(Vs + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(src + 2 * D) : zero4;
+    if (!any) continue;
+    __syncthreads();          // previous round fully consumed
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+      if (!live[j]) continue;
+      for (int idx = tid; idx < 64 * CPR; idx += 256) {
+        const int r = idx / CPR, cp = idx % CPR;
+        const bf16_t* src = qk + ((size_t)n * Tp + (kb0 + j) * 64 + r) * ldq + h * HD + cp * 8;
+        const bool real = cp * 8 < HD;
+        *reinterpret_cast<u32x4*>(Ks_all + j * 64 * TL::RS + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(src + D) : zero4;
+        *reinterpret_cast<u32x4*>(Vs_all + j * 64 * TL::RS + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(src + 2 * D) : zero4;
+      }
     }
     __syncthreads();
+#pragma unroll
+    for (int j = 0; j < KB; ++j) {
+    if (!live[j]) continue;
+    const int kb = kb0 + j;
+    const bool check_mask = chk[j];
+    const char* Ks = Ks_all + j * 64 * TL::RS;
+    const char* Vs = Vs_all + j * 64 * TL::RS;
 
     // ---- S^T tiles: s[kt][4g+i] = score(key = kb*64 + kt*32 + 8g + 4*fhalf + i, query q)
     f32x16 s[2];
@@ -175,6 +199,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = mfma_bf16(trfrag<HDP>(Vs, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
       }
+    }  // blocks of the round
   }
 
   if (q < Tp) {
@@ -285,11 +310,15 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
       return OSUD_ERR_UNSUPPORTED;
     }
     dim3 grid((Tp + 127) / 128, heads, N);
-    if (head_dim == 64)
-      hipLaunchKernelGGL((attn_bf16_kernel<64, 64>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
+    static const bool one_block = [] { const char* e = getenv("OSUD_ATTN_KB"); return e && e[0] == '1'; }();  // A/B: the old staging
+    if (head_dim == 64 && one_block)
+      hipLaunchKernelGGL((attn_bf16_kernel<64, 64, 1>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
+                         Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr, fp8_scale);
+    else if (head_dim == 64)
+      hipLaunchKernelGGL((attn_bf16_kernel<64, 64, 2>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
                          Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr, fp8_scale);
     else
-      hipLaunchKernelGGL((attn_bf16_kernel<72, 96>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
+      hipLaunchKernelGGL((attn_bf16_kernel<72, 96, 1>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
                          Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr, fp8_scale);
   } else {
     dim3 grid(Tp / 64, heads, N);

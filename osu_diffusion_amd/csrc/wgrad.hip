@@ -499,9 +499,12 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
     p.chunk = S * per_wg;
     p.queue = queue_slot();
   }
-  // GPU not shared (no tile queues): the partial slabs are combined inside the launch, by the workgroups that wrote them
-  // (every one of the tiles * S <= #CUs workgroups is resident: one per CU).  OSUD_WGRAD_COMBINE=0: separate reduce launch.
-  static const bool combine_on = [] { const char* e = getenv("OSUD_WGRAD_COMBINE"); return !(e && e[0] == '0'); }();
+  // OSUD_WGRAD_COMBINE=1: combine the partial slabs inside the launch (the workgroups of a tile meet on an arrival counter and each
+  // sums its share of the rows) instead of the separate splitk_reduce launch.  Built, correct (same bits) and measured SLOWER:
+  // 29.99 vs 28.73 ms per DiT-B training step (+26 us per launch: the tile's workgroups finish their slabs at different times and
+  // the early ones sit in the poll, the release/acquire pair costs ~3.5 us, and the reduce has lost its own full-chip launch).
+  // The separate launch stays the default; this matches the guide's "cut at every split-K seam" verdict.
+  static const bool combine_on = [] { const char* e = getenv("OSUD_WGRAD_COMBINE"); return e && e[0] == '1'; }();
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
   if (S > 1 && p.queue == nullptr && combine_on && !capturing && tiles < 255 && tiles * S <= num_cus_w()) {
