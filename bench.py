@@ -347,7 +347,7 @@ def bench_train(args, world, rank, dev):
         "metric": f"{args.model} seq{args.seq_len} train tokens/sec (whole job; per-GPU = value / n_gpus)", "value": round(tokens_per_s, 1),
         "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"bf16": "bf16", "fp32": "f32", "fp8": "fp8(e4m3 GEMM operands)+bf16"}[args.precision], "data": "synthetic",
+        "dtype": {"bf16": "bf16", "fp32": "f32", "fp8": "fp8 (e4m3 operands, delayed per-tensor scaling: qkv/fc1/fc2 fwd + dgrad) + bf16 (wgrad, out_proj, attention)"}[args.precision], "data": "synthetic",
         "config": {"workload": f"train.py step: {args.model} seq-len {T}, per-GPU batch {B} synthetic windows (global {B * world}), "
                                f"L1+vb loss, AdamW lr 1e-4, EMA 0.9999, label dropout 0.2, squaredcos_cap_v2 1000 steps",
                    "per_gpu_batch": B, "global_batch": B * world, "seq_len": T,
@@ -533,7 +533,7 @@ def parity_tier_and_drift(args, dev):
     return out, drift
 
 
-XL_TIERS = ["bf16"]  # + "fp8" once the fp8 training tier is built
+XL_TIERS = ["bf16", "fp8"]
 FLOP_PER_TOKEN_TRAIN_XL = 2783.5e6  # DiT-XL, T=256
 
 
@@ -546,7 +546,8 @@ def bench_xl(args, world, rank, dev, precision="bf16", steps=None, warmup=None):
     xa.no_roofline, xa.no_cpu_baseline, xa.h2d, xa.no_family_table = True, True, False, True
     r = bench_train(xa, world, rank, dev)
     per_gpu = r["value"] / world
-    peak = PEAK_BF16_TFLOPS * (2.0 if precision == "fp8" else 1.0)
+    peak = PEAK_BF16_TFLOPS  # the fp8 tier runs 61 % of its GEMM FLOPs on e4m3 operands (qkv / fc1 / fc2 forward and data gradients); the
+    # rest -- out_proj, every weight gradient, attention -- is bf16: its fraction is quoted against the bf16 peak as well
     out = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "config", "per_gpu_tokens_per_s")}
     out["end_to_end"] = {"flop_per_token": FLOP_PER_TOKEN_TRAIN_XL, "achieved_tflops_per_gpu": round(per_gpu * FLOP_PER_TOKEN_TRAIN_XL / 1e12, 1),
                          "peak_tflops": peak, "mfma_frac": round(per_gpu * FLOP_PER_TOKEN_TRAIN_XL / 1e12 / peak, 4)}

@@ -51,9 +51,11 @@ __global__ __launch_bounds__(256) void mask_tiles_kernel(const uint8_t* __restri
 // zero output columns that are not stored)
 // (4 waves per SIMD for the 64-wide head: the kernel has only two key blocks per workgroup at T = 128 and hides its load
 // latency through occupancy; prefetching the next block into registers instead was measured neutral-to-slower)
-// KB = key blocks (of 64 keys) staged per round: with KB = 2 a workgroup at T <= 128 -- the training / sampling window -- puts
-// ALL its loads (Q fragments, both K / V blocks) in flight at once and pays one memory round trip and one barrier instead of
-// three of each (measured: 30 -> see DESIGN.md us per launch at 128 windows x 2, 12 heads).
+// KB = key blocks (of 64 keys) staged per round.  KB = 2 puts ALL loads of a T <= 128 workgroup (Q fragments, both K / V
+// blocks) in flight at once -- one memory round trip and one barrier instead of two.  Built and measured SLOWER (same box,
+// alternating runs: sampling step 4.41 vs 4.21 ms, training step 28.91 vs 28.59 ms): 32 KiB of LDS per workgroup and eight
+// staging loads per thread cost more occupancy-side latency hiding than the saved round trip buys.  KB = 1 stays the default
+// (OSUD_ATTN_KB=2 selects the other form for A/B runs).
 template <int HD, int HDP, int KB>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 4 : 2))) void attn_bf16_kernel(const bf16_t* __restrict__ qk,
                                                         const uint8_t* __restrict__ mask, bf16_t* __restrict__ out,
@@ -310,7 +312,7 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
       return OSUD_ERR_UNSUPPORTED;
     }
     dim3 grid((Tp + 127) / 128, heads, N);
-    static const bool one_block = [] { const char* e = getenv("OSUD_ATTN_KB"); return e && e[0] == '1'; }();  // A/B: the old staging
+    static const bool one_block = [] { const char* e = getenv("OSUD_ATTN_KB"); return !(e && e[0] == '2'); }();
     if (head_dim == 64 && one_block)
       hipLaunchKernelGGL((attn_bf16_kernel<64, 64, 1>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
                          Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr, fp8_scale);

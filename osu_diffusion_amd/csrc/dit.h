@@ -29,6 +29,9 @@ struct BlockWeights {
   float *dq_qkv = nullptr, *dq_o = nullptr, *dq_1 = nullptr, *dq_2 = nullptr;
   // transposed copies ([in][out]) for the data-gradient products (training only)
   void *w_qkv_t = nullptr, *w_o_t = nullptr, *w1_t = nullptr, *w2_t = nullptr;
+  // fp8 training: e4m3 copies of the transposed weights (quantised per row = per output column of the data-gradient product)
+  void *w_qkv_t8 = nullptr, *w1_t8 = nullptr, *w2_t8 = nullptr;
+  float *dq_qkv_t = nullptr, *dq_1_t = nullptr, *dq_2_t = nullptr;
 };
 
 // per-layer activations kept for the backward pass (training only)
@@ -103,6 +106,11 @@ struct osud_dit {
   // workspaces (reserve)
   int cap_N = 0, cap_T = 0, cap_Mp = 0, cap_Np = 0, cap_Tp = 0;
   void *u8 = nullptr, *ao8 = nullptr, *g8 = nullptr;  // fp8 tier: e4m3 activations [Mp][D], [Mp][D], [Mp][4D]
+  // fp8 TRAINING (delayed per-tensor scaling): per block 6 quantised tensors (u1, u2, gelu out, d(mlp branch), d(fc1 pre-act),
+  // dqkv), each with a slot {scale in use, 1/scale, amax seen this step, -}; e4m3 staging buffers [Mp][D] and [Mp][4D]
+  float* f8_slots = nullptr;
+  void *q8a = nullptr, *q8b = nullptr;
+  int f8_steps = 0;  // training forwards so far: the first one runs its GEMMs in bf16 and only records the amax history
   void *e0 = nullptr, *u = nullptr, *qk = nullptr /* [Mp][3D] q|k|v */, *ao = nullptr, *g = nullptr;
   float *h = nullptr, *tvec = nullptr, *bvec = nullptr, *ada = nullptr, *out_ws = nullptr;
   void *temb = nullptr, *th = nullptr, *sb = nullptr;
@@ -141,13 +149,17 @@ inline int gemm(osud_dit* m, int epi, const void* Y, int ldy, const void* X, int
 }
 
 // GEMM on e4m3 operands (fp8 tier): Y [My][K] and X [Nx][K] are fp8, `dequant` the per-column factors, out per epilogue
+// `dequant` = the weight's per-output-channel factors; the activation's factor is a host scalar (static scale, inference) or a
+// device scalar (dynamic scale, training)
 inline int gemm8(osud_dit* m, int epi, const void* Y, const void* X, int My, int Nx, int K, void* out, int ldo, const float* bias,
                  const float* dequant, float out_scale, hipStream_t st, const float* gate = nullptr, int ld_gate = 0, int Tp = 0,
-                 int N = 0) {
+                 int N = 0, float act_inv_host = 0.f, const float* act_inv_dev = nullptr, void* out2 = nullptr,
+                 const void* aux = nullptr, float* colpart = nullptr, int* colpart_rows = nullptr) {
   GemmP p{};
   p.Y = Y; p.X = X; p.ldy = K; p.ldx = K; p.My = My; p.Nx = Nx; p.K = K;
   p.out = out; p.ldo = ldo; p.bias = bias; p.gate = gate; p.ld_gate = ld_gate;
   p.rows_per_sample = Tp; p.n_samples = N; p.colscale = dequant; p.out_scale = out_scale;
+  p.act_inv_host = act_inv_host; p.act_inv = act_inv_dev; p.out2 = out2; p.aux = aux; p.colpart = colpart; p.colpart_rows = colpart_rows;
   (void)m;
   return launch_gemm(OSUD_PREC_FP8, epi, p, st);
 }

@@ -84,6 +84,15 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
     }
     m->h = m->saved[0].h_in;
     m->training = true;
+    if (m->fp8) {  // fp8 training: e4m3 staging of the GEMM operands + the scale slots (scale 1 until a history exists)
+      OSUD_TRY(dev_alloc(W, &m->q8a, (size_t)Mp * D));
+      OSUD_TRY(dev_alloc(W, &m->q8b, (size_t)Mp * 4 * D));
+      OSUD_TRY(dev_alloc(W, &m->f8_slots, (size_t)m->L * 6 * 4 * sizeof(float)));
+      std::vector<float> init((size_t)m->L * 6 * 4, 0.f);
+      for (size_t i = 0; i < init.size(); i += 4) init[i] = init[i + 1] = 1.0f;
+      OSUD_HIP(hipMemcpy(m->f8_slots, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice));
+      m->f8_steps = 0;
+    }
     OSUD_TRY(dev_alloc(W, &m->z0, (size_t)Np * D * es));
     BwdWs& b = m->bw;
     const size_t AC = m->ada_cols;
@@ -140,11 +149,15 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
   const bool cfg = cfg_scale >= 0.f;
   OSUD_CHECK_ARG(!cfg || N % 2 == 0, "forward_with_cfg: batch must be [cond; uncond] halves, got N=%d", N);
   OSUD_CHECK_ARG(!save || m->training, "forward(save): workspaces were not reserved for training");
-  if (m->fp8 && (save || m->training)) {
-    set_error("the fp8 tier is inference only (train in bf16 or fp32)");
-    return OSUD_ERR_UNSUPPORTED;
-  }
   OSUD_TRY(dit_ensure_ws(m, N, T, m->training));
+  // fp8 TRAINING (BASELINE config 5): qkv / fc1 / fc2 of every block on e4m3 operands with delayed per-tensor scaling -- a
+  // tensor is quantised with the scale derived from the amax it showed in the previous step (launch_f8_update, once per
+  // forward).  The very first training forward has no history: it runs its GEMMs in bf16 and only records.  Weights carry
+  // per-output-channel scales.  out_proj (1/12 of a block's FLOPs) and every weight gradient stay bf16.
+  const bool f8_train = m->fp8 && save;
+  const bool f8_live = f8_train && m->f8_steps > 0;
+  if (f8_train) OSUD_TRY(launch_f8_update(m->f8_slots, m->L * 6, st));
+  auto slot = [&](int l, int which) { return m->f8_slots + ((size_t)l * 6 + which) * 4; };
 
   const int D = m->D, L = m->L, Tp = round_up(T, 64), M = N * Tp, Mp = round_up(M, 128), Np = round_up(N, 128);
   const int prec = m->prec, AC = m->ada_cols;
@@ -187,22 +200,26 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
     const int qcols = 3 * D;
     if (!sv && m->fp8) {
       OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base, base + D, m->u8, nullptr, Mp, Tp, N, D, st, nullptr, 0, nullptr, kF8ScaleLN));
-      OSUD_TRY(gemm8(m, EPI_BIAS_TE, m->u8, w.w8_qkv, Mp, qcols, D, qk, qcols, w.b_qkv, w.dq_qkv, 0.f, st));
+      OSUD_TRY(gemm8(m, EPI_BIAS_TE, m->u8, w.w8_qkv, Mp, qcols, D, qk, qcols, w.b_qkv, w.dq_qkv, 0.f, st, nullptr, 0, 0, 0, 1.0f / kF8ScaleLN));
       OSUD_TRY(launch_attention(prec, qk, qcols, mask, m->ao8, nullptr, N, T, Tp, Mp, m->H, m->hd, st, m->kb_class, kF8ScaleAttn));
     } else {
       OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base, base + D, u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st, pend,
                              pend_gate, pend ? h_in : nullptr));
       // packed in_proj: one 3D-wide product, Q | K | V row-major (the attention kernels transpose V on the LDS read)
+      if (f8_train) OSUD_TRY(launch_f8_quantize(u1, f8_live ? m->q8a : nullptr, (size_t)Mp * D, slot(l, 0), st));
+      if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_TE, m->q8a, w.w8_qkv, Mp, qcols, D, qk, qcols, w.b_qkv, w.dq_qkv, 0.f, st, nullptr, 0, 0, 0, 0.f,
+                                  slot(l, 0) + 1));
+      else
       OSUD_TRY(gemm(m, EPI_BIAS_TE, u1, D, w.w_qkv, D, Mp, qcols, D, qk, qcols, w.b_qkv, st));
       OSUD_TRY(launch_attention(prec, qk, qcols, mask, ao, sv ? sv->lse : nullptr, N, T, Tp, Mp, m->H, m->hd, st, m->kb_class));
     }
     if (!sv && m->fp8) {
       // the four big GEMMs of the block on e4m3 operands (this block's LN1 / qkv / attention were emitted above in fp8 form)
-      OSUD_TRY(gemm8(m, EPI_GATE_RES, m->ao8, w.w8_o, Mp, D, D, h, D, w.b_o, w.dq_o, 0.f, st, m->ada + base + 2 * D, AC, Tp, N));
+      OSUD_TRY(gemm8(m, EPI_GATE_RES, m->ao8, w.w8_o, Mp, D, D, h, D, w.b_o, w.dq_o, 0.f, st, m->ada + base + 2 * D, AC, Tp, N, 1.0f / kF8ScaleAttn));
       OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base + 3 * D, base + 4 * D, m->u8, nullptr, Mp, Tp, N, D, st, nullptr, 0, nullptr,
                              kF8ScaleLN));
-      OSUD_TRY(gemm8(m, EPI_BIAS_GELU_TE, m->u8, w.w8_1, Mp, 4 * D, D, m->g8, 4 * D, w.b1, w.dq_1, kF8ScaleGelu, st));
-      OSUD_TRY(gemm8(m, EPI_GATE_RES, m->g8, w.w8_2, Mp, D, 4 * D, h, D, w.b2, w.dq_2, 0.f, st, m->ada + base + 5 * D, AC, Tp, N));
+      OSUD_TRY(gemm8(m, EPI_BIAS_GELU_TE, m->u8, w.w8_1, Mp, 4 * D, D, m->g8, 4 * D, w.b1, w.dq_1, kF8ScaleGelu, st, nullptr, 0, 0, 0, 1.0f / kF8ScaleLN));
+      OSUD_TRY(gemm8(m, EPI_GATE_RES, m->g8, w.w8_2, Mp, D, 4 * D, h, D, w.b2, w.dq_2, 0.f, st, m->ada + base + 5 * D, AC, Tp, N, 1.0f / kF8ScaleGelu));
       continue;
     }
     if (!sv) {
@@ -215,8 +232,19 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
     OSUD_TRY(gemm(m, EPI_BIAS_TE, ao, D, w.w_o, D, Mp, D, D, br1, D, w.b_o, st));
     OSUD_TRY(launch_ln_mod(prec, h_in, m->ada, AC, base + 3 * D, base + 4 * D, u2, sv->stats2, Mp, Tp, N, D, st, br1,
                            base + 2 * D, h_mid));
+    if (f8_train) {
+      OSUD_TRY(launch_f8_quantize(u2, f8_live ? m->q8a : nullptr, (size_t)Mp * D, slot(l, 1), st));
+      if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_GELU_BF, m->q8a, w.w8_1, Mp, 4 * D, D, g, 4 * D, w.b1, w.dq_1, 0.f, st, nullptr, 0, 0, 0, 0.f,
+                                  slot(l, 1) + 1, sv->z1));
+      else OSUD_TRY(gemm(m, EPI_BIAS_GELU_TE, u2, D, w.w1, D, Mp, 4 * D, D, g, 4 * D, w.b1, st, nullptr, 0, 0, 0, sv->z1));
+      OSUD_TRY(launch_f8_quantize(g, f8_live ? m->q8b : nullptr, (size_t)Mp * 4 * D, slot(l, 2), st));
+      if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_TE, m->q8b, w.w8_2, Mp, D, 4 * D, br2, D, w.b2, w.dq_2, 0.f, st, nullptr, 0, 0, 0, 0.f,
+                                  slot(l, 2) + 1));
+      else OSUD_TRY(gemm(m, EPI_BIAS_TE, g, 4 * D, w.w2, 4 * D, Mp, D, 4 * D, br2, D, w.b2, st));
+    } else {
     OSUD_TRY(gemm(m, EPI_BIAS_GELU_TE, u2, D, w.w1, D, Mp, 4 * D, D, g, 4 * D, w.b1, st, nullptr, 0, 0, 0, sv->z1));
     OSUD_TRY(gemm(m, EPI_BIAS_TE, g, 4 * D, w.w2, 4 * D, Mp, D, 4 * D, br2, D, w.b2, st));
+    }
     pend = br2;
     pend_gate = base + 5 * D;
     h = h_mid;
@@ -230,6 +258,7 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
     m->last_y = y;
     m->last_N = N;
     m->last_T = T;
+    if (f8_train) ++m->f8_steps;
   }
   return OSUD_OK;
 }
@@ -409,24 +438,24 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
     if (name == "attn.in_proj_weight") {
       SHAPE(3 * D, D);  // rows [Wq; Wk; Wv]
       rc = convert_w(m, src, b.w_qkv, 3 * D * D, st);
-      if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)(3 * D), (int)D, b.w8_qkv, b.dq_qkv, kF8ScaleLN, st);
+      if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)(3 * D), (int)D, b.w8_qkv, b.dq_qkv, 1.0f, st);
     } else if (name == "attn.in_proj_bias") {
       SHAPE(3 * D);
       rc = upload_f32(m, &b.b_qkv, src, 3 * D, st);
     } else if (name == "attn.out_proj.weight") {
       SHAPE(D, D);
       rc = convert_w(m, src, b.w_o, D * D, st);
-      if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)D, (int)D, b.w8_o, b.dq_o, kF8ScaleAttn, st);
+      if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)D, (int)D, b.w8_o, b.dq_o, 1.0f, st);
     } else if (name == "attn.out_proj.bias") { SHAPE(D); rc = upload_f32(m, &b.b_o, src, D, st);
     } else if (name == "mlp.fc1.weight") {
       SHAPE(4 * D, D);
       rc = convert_w(m, src, b.w1, 4 * D * D, st);
-      if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)(4 * D), (int)D, b.w8_1, b.dq_1, kF8ScaleLN, st);
+      if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)(4 * D), (int)D, b.w8_1, b.dq_1, 1.0f, st);
     } else if (name == "mlp.fc1.bias") { SHAPE(4 * D); rc = upload_f32(m, &b.b1, src, 4 * D, st);
     } else if (name == "mlp.fc2.weight") {
       SHAPE(D, 4 * D);
       rc = convert_w(m, src, b.w2, 4 * D * D, st);
-      if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)D, (int)(4 * D), b.w8_2, b.dq_2, kF8ScaleGelu, st);
+      if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)D, (int)(4 * D), b.w8_2, b.dq_2, 1.0f, st);
     } else if (name == "mlp.fc2.bias") { SHAPE(D); rc = upload_f32(m, &b.b2, src, D, st);
     } else if (name == "adaLN_modulation.1.weight") {
       SHAPE(6 * D, D);

@@ -31,6 +31,7 @@ enum GemmEpilogue {
   EPI_NONE_TE = 7,        // out TE  = acc
   EPI_ACCUM_F32 = 8,      // out f32 += acc                      (gradient accumulation)
   EPI_GELUGRAD_TE = 9,    // out TE  = acc * aux[y][x], aux = the saved gelu' of fc1's pre-activation (dgrad through it)
+  EPI_BIAS_GELU_BF = 10,  // fp8 operands only (fp8 training): EPI_BIAS_GELU_TE with bf16 outputs: out = gelu, out2 (optional) = gelu'
   EPI_COUNT
 };
 
@@ -51,6 +52,8 @@ struct GemmP {
   const float* res;  // EPI_GATE_RES: residual input [My][ldo]; nullptr = update `out` in place
   const float* colscale;  // fp8 operands only: out = epilogue(acc * colscale[x]) -- the product of the activation and per-output-channel
                           // weight de-quantisation factors
+  float act_inv_host;     // fp8 operands: host scalar multiplied into colscale (1 / a static activation scale); 0 = none
+  const float* act_inv;   // fp8 operands, optional: DEVICE scalar multiplied into colscale (1 / the activation's dynamic quantisation scale)
   float out_scale;        // fp8 OUTPUT (EPI_BIAS_GELU_TE with fp8 operands): the value is multiplied by this before quantisation
   int split_k;       // > 1: blockIdx.y walks K in split_k equal ranges, range s writes out + s * split_stride (elements)
   size_t split_stride;

@@ -206,6 +206,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
   constexpr bool FAST = sizeof(TE) <= 2;
   constexpr bool kF8 = sizeof(TE) == 1;  // fp8 operands: outputs are bf16 (EPI_BIAS_TE), fp8 (EPI_BIAS_GELU_TE) or fp32
   using TO = typename std::conditional<kF8, typename std::conditional<EPI == EPI_BIAS_GELU_TE, fp8_t, bf16_t>::type, TE>::type;
+  constexpr bool kGelu = EPI == EPI_BIAS_GELU_TE || EPI == EPI_BIAS_GELU_BF;  // _BF: fp8 operands with bf16 outputs (training)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wy = wave / WX, wx = wave % WX;
@@ -438,7 +439,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
     // All loads of a block are issued BEFORE its stores: vmcnt counts stores too, so a load waited for
     // between stores would drain every earlier store.
     constexpr bool kBias = EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_TE || EPI == EPI_BIAS_SILU_TE ||
-                           EPI == EPI_BIAS_GELU_TE || EPI == EPI_GATE_RES;
+                           kGelu || EPI == EPI_GATE_RES;
     const int lrow = lane >> 2, lcol = 8 * (lane & 3);
     const int xw = tx * BN + wx * RX * 32 + lcol;  // + j*32
     float csv[RX][8];
@@ -448,6 +449,11 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
 #pragma unroll
         for (int e = 0; e < 8; ++e) csv[j][e] = 1.0f;
         if (p.colscale != nullptr) load8(p.colscale + xw + j * 32, csv[j]);
+        if (p.act_inv != nullptr || p.act_inv_host != 0.f) {  // the activation's de-quantisation factor: static (host) or dynamic
+          const float ai = (p.act_inv != nullptr ? *p.act_inv : 1.0f) * (p.act_inv_host != 0.f ? p.act_inv_host : 1.0f);  // (device: fp8 training)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csv[j][e] *= ai;
+        }
       }
     }
     float bv[RX][8];
@@ -477,7 +483,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
       t[2] = ds_read16f<2048>(pr0 + pso);   // rows 16..31
       t[3] = ds_read16f<2048>(pr1 + pso);
     };
-    constexpr bool kColsum = EPI == EPI_GELUGRAD_TE && !kF8;
+    constexpr bool kColsum = EPI == EPI_GELUGRAD_TE;
     float cs[kColsum ? RX : 1][8];
     if (kColsum) {
 #pragma unroll
@@ -513,7 +519,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
       }
       if (EPI == EPI_GELUGRAD_TE) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) load8(reinterpret_cast<const TE*>(p.aux) + (size_t)(y0 + 16 * q) * p.ldo + x, rv[q]);
+        for (int q = 0; q < 2; ++q) load8(reinterpret_cast<const TO*>(p.aux) + (size_t)(y0 + 16 * q) * p.ldo + x, rv[q]);
       }
       if (EPI == EPI_ROWBIAS_TE) {
 #pragma unroll
@@ -544,7 +550,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
         if (exp_nostore || exp_nomath) {  // timing experiments: (16) the epilogue's arithmetic without its stores, (32) its stores without the arithmetic
           if (exp_nomath) {
             store8(reinterpret_cast<TO*>(p.out) + o, v);
-            if (EPI == EPI_BIAS_GELU_TE && p.out2) store8(reinterpret_cast<TO*>(p.out2) + o, v);
+            if (kGelu && p.out2) store8(reinterpret_cast<TO*>(p.out2) + o, v);
           } else {
             float dg[8];
 #pragma unroll
@@ -571,7 +577,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = silu_t<FAST>(v[e]);
           store8(reinterpret_cast<TO*>(p.out) + o, w);
-        } else if (EPI == EPI_BIAS_GELU_TE) {
+        } else if (kGelu) {
           if (p.out2) {  // training: the DERIVATIVE goes out (same exp/rcp as the value), so that the backward epilogue
                          // is a plain multiply instead of two more quarter-rate transcendentals per element
             float dg[8];
@@ -580,7 +586,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
             store8(reinterpret_cast<TO*>(p.out2) + o, dg);
           } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] = gelu_tanh_t<FAST>(v[e]) * (kF8 ? p.out_scale : 1.0f);
+            for (int e = 0; e < 8; ++e) w[e] = gelu_tanh_t<FAST>(v[e]) * ((kF8 && EPI == EPI_BIAS_GELU_TE) ? p.out_scale : 1.0f);
           }
           store8(reinterpret_cast<TO*>(p.out) + o, w);
         } else if (EPI == EPI_GELUGRAD_TE) {
@@ -801,7 +807,7 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
     OSUD_CHECK_ARG(p.gate && p.bias && p.rows_per_sample > 0 && p.rows_per_sample % 32 == 0 && p.n_samples > 0,
                    "gemm: gated epilogue needs gate/bias and rows_per_sample %% 32 == 0");
   if (epi == EPI_BIAS_F32 || epi == EPI_BIAS_TE || epi == EPI_BIAS_SILU_TE || epi == EPI_ROWBIAS_TE ||
-      epi == EPI_BIAS_GELU_TE)
+      epi == EPI_BIAS_GELU_TE || epi == EPI_BIAS_GELU_BF)
     OSUD_CHECK_ARG(p.bias != nullptr, "gemm: epilogue %d needs a bias", epi);
   if (epi == EPI_GELUGRAD_TE) OSUD_CHECK_ARG(p.aux != nullptr, "gemm: epilogue %d needs aux", epi);
   if (p.split_k > 1) {
@@ -815,6 +821,9 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
       case EPI_BIAS_TE: return launch_t<fp8_t, EPI_BIAS_TE>(p, st);
       case EPI_BIAS_GELU_TE: return launch_t<fp8_t, EPI_BIAS_GELU_TE>(p, st);
       case EPI_GATE_RES: return launch_t<fp8_t, EPI_GATE_RES>(p, st);
+      case EPI_BIAS_GELU_BF: return launch_t<fp8_t, EPI_BIAS_GELU_BF>(p, st);  // training: bf16 gelu + gelu' outputs
+      case EPI_NONE_TE: return launch_t<fp8_t, EPI_NONE_TE>(p, st);            // data gradients
+      case EPI_GELUGRAD_TE: return launch_t<fp8_t, EPI_GELUGRAD_TE>(p, st);
     }
     set_error("gemm: epilogue %d is not built for fp8 operands", epi);
     return OSUD_ERR_UNSUPPORTED;

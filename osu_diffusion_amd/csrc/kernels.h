@@ -17,6 +17,12 @@ int launch_ln_mod(int prec, const float* h, const float* ada, int ld_ada, int of
                   float* h_out = nullptr, float fp8_scale = 0.f /* > 0: out is e4m3, values multiplied by this */);
 // fp8 tier: per-output-channel e4m3 quantisation of a weight (rows x cols fp32) and its de-quantisation factors
 int launch_quantize_rows(const float* w, int rows, int cols, void* q, float* dequant, float act_scale, hipStream_t st);
+int launch_quantize_rows_bf16(const void* w_bf16, int rows, int cols, void* q, float* dequant, hipStream_t st);
+// fp8 training, delayed per-tensor scaling.  slot = {scale, 1/scale, amax of this step, -}:
+//   quantize: dst[i] = e4m3(src[i] * slot[0]) (dst may be null: record only), slot[2] = max(slot[2], max|src|)
+//   update  : for every slot with a recorded amax: scale = 448 / (2 * amax) (one binade of headroom), amax cleared
+int launch_f8_quantize(const void* src_bf16, void* dst_fp8, size_t n, float* slot, hipStream_t st);
+int launch_f8_update(float* slots, int n_slots, hipStream_t st);
 int launch_final(const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, const float* w,
                  const float* bias, float* out, float* u_save, float* stats, int N, int T, int Tp, int D, int C,
                  hipStream_t st, int prec = OSUD_PREC_F32, const void* br = nullptr, int off_gate = 0,

@@ -332,11 +332,81 @@ __global__ __launch_bounds__(256) void quantize_rows_kernel(const float* __restr
   if (threadIdx.x == 0) dequant[blockIdx.x] = 1.0f / (s * act_scale);
 }
 
+// bf16 source variant (the transposed weight copies of the data-gradient products exist only in bf16)
+__global__ __launch_bounds__(256) void quantize_rows_bf16_kernel(const bf16_t* __restrict__ w, int cols, fp8_t* __restrict__ q,
+                                                                 float* __restrict__ dequant) {
+  __shared__ float red[4];
+  const bf16_t* row = w + (size_t)blockIdx.x * cols;
+  float amax = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) amax = fmaxf(amax, fabsf(bf2f(row[c])));
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  const float s = amax > 0.f ? 448.0f / amax : 1.0f;
+  for (int c = threadIdx.x * 4; c < cols; c += 1024)
+    store4(q + (size_t)blockIdx.x * cols + c, bf2f(row[c]) * s, bf2f(row[c + 1]) * s, bf2f(row[c + 2]) * s, bf2f(row[c + 3]) * s);
+  if (threadIdx.x == 0) dequant[blockIdx.x] = 1.0f / s;
+}
+
+// fp8 training: bf16 tensor -> e4m3 with the slot's scale (delayed scaling: the scale comes from the previous step's amax),
+// recording this step's amax.  16 bytes in, 8 bytes out per lane; HBM-bound (3 bytes per element).
+__global__ __launch_bounds__(256) void f8_quantize_kernel(const bf16_t* __restrict__ src, fp8_t* __restrict__ dst, size_t n8,
+                                                          float* __restrict__ slot) {
+  const float scale = slot[0];
+  float amax = 0.f;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    float v[8];
+    load8(src + i * 8, v);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      amax = fmaxf(amax, fabsf(v[e]));
+      v[e] *= scale;
+    }
+    if (dst != nullptr) store8(dst + i * 8, v);
+  }
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot) + 2, __float_as_uint(amax));  // amax >= 0: bit order = value order
+}
+
+__global__ void f8_update_kernel(float* __restrict__ slots, int n_slots) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_slots) return;
+  float* s = slots + 4 * i;
+  const float amax = s[2];
+  if (amax > 0.f && amax < 3.0e38f) {
+    const float sc = 448.0f / (2.0f * amax);
+    s[0] = sc;
+    s[1] = 1.0f / sc;
+  }
+  s[2] = 0.f;
+}
+
 }  // namespace
 
 int launch_quantize_rows(const float* w, int rows, int cols, void* q, float* dequant, float act_scale, hipStream_t st) {
   OSUD_CHECK_ARG(cols % 4 == 0, "quantize_rows: cols=%d must be a multiple of 4", cols);
   hipLaunchKernelGGL(quantize_rows_kernel, dim3(rows), dim3(256), 0, st, w, cols, (fp8_t*)q, dequant, act_scale);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+int launch_quantize_rows_bf16(const void* w, int rows, int cols, void* q, float* dequant, hipStream_t st) {
+  OSUD_CHECK_ARG(cols % 4 == 0, "quantize_rows: cols=%d must be a multiple of 4", cols);
+  hipLaunchKernelGGL(quantize_rows_bf16_kernel, dim3(rows), dim3(256), 0, st, (const bf16_t*)w, cols, (fp8_t*)q, dequant);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+int launch_f8_quantize(const void* src, void* dst, size_t n, float* slot, hipStream_t st) {
+  OSUD_CHECK_ARG(n % 8 == 0 && slot != nullptr, "f8_quantize: n must be a multiple of 8");
+  const size_t n8 = n / 8;
+  const int grid = (int)((n8 + 255) / 256 > 4096 ? 4096 : (n8 + 255) / 256);
+  hipLaunchKernelGGL(f8_quantize_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (fp8_t*)dst, n8, slot);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+int launch_f8_update(float* slots, int n_slots, hipStream_t st) {
+  hipLaunchKernelGGL(f8_update_kernel, dim3((n_slots + 63) / 64), dim3(64), 0, st, slots, n_slots);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }

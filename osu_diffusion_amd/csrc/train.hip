@@ -48,6 +48,18 @@ int build_transposed(osud_dit* m, hipStream_t st) {
   OSUD_TRY(T_(m->w_ada, m->ada_cols, D, &m->w_ada_t));
   OSUD_TRY(T_(m->w_t2, D, D, &m->w_t2_t));
   OSUD_TRY(launch_transpose_many(prec, tl, st));
+  if (m->fp8) {  // fp8 training: e4m3 twins of the transposed weights, one scale per row (= per output column of the dgrad product)
+    for (auto& b : m->blk) {
+      auto Q8 = [&](void* src, int rows, int cols, void** q, float** dq) -> int {
+        if (!*q) OSUD_TRY(dev_alloc(m->owned, q, (size_t)rows * cols, false));
+        if (!*dq) OSUD_TRY(dev_alloc(m->owned, dq, (size_t)rows * 4, false));
+        return launch_quantize_rows_bf16(src, rows, cols, *q, *dq, st);
+      };
+      OSUD_TRY(Q8(b.w_qkv_t, D, 3 * D, &b.w_qkv_t8, &b.dq_qkv_t));
+      OSUD_TRY(Q8(b.w1_t, D, 4 * D, &b.w1_t8, &b.dq_1_t));
+      OSUD_TRY(Q8(b.w2_t, 4 * D, D, &b.w2_t8, &b.dq_2_t));
+    }
+  }
   m->transposed_ready = true;
   return OSUD_OK;
 }
@@ -206,20 +218,34 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     // dz1 = (dbr . W2) * gelu'(z1); in the bf16 tier the fc1 bias gradient (column sums of dz1) rides in the same epilogue
     // as per-wave-row partial sums (scratch: the split-K slab area, free until the weight gradients below)
     const bool fused_b1 = prec == OSUD_PREC_BF16 && (size_t)(Mp / 32) * 4 * D <= w.splitk_elems;
+    // fp8 training: the data-gradient products of fc2, fc1 and in_proj run on e4m3 operands (gradient tensors quantised with the
+    // scale from their previous step's amax, transposed weights per row); the very first step only records (see dit_forward_impl)
+    const bool f8_train = m->fp8, f8_live = m->fp8 && m->f8_steps > 1;
+    auto slot = [&](int which) { return m->f8_slots + ((size_t)l * 6 + which) * 4; };
     {
+      int part_rows = 0;
+      if (f8_train) OSUD_TRY(launch_f8_quantize(w.dbr, f8_live ? m->q8a : nullptr, (size_t)Mp * D, slot(3), st));
+      if (f8_live) {
+        OSUD_TRY(gemm8(m, EPI_GELUGRAD_TE, m->q8a, bw.w2_t8, Mp, 4 * D, D, w.dz1, 4 * D, nullptr, bw.dq_2_t, 0.f, st, nullptr, 0, 0, 0, 0.f,
+                       slot(3) + 1, nullptr, sv.z1, fused_b1 ? w.splitk : nullptr, fused_b1 ? &part_rows : nullptr));
+      } else {
       GemmP gp{};
       gp.Y = w.dbr; gp.X = bw.w2_t; gp.ldy = D; gp.ldx = D; gp.My = Mp; gp.Nx = 4 * D; gp.K = D;
       gp.out = w.dz1; gp.ldo = 4 * D; gp.aux = sv.z1;
-      int part_rows = 0;
       if (fused_b1) {
         gp.colpart = w.splitk;
         gp.colpart_rows = &part_rows;
       }
       OSUD_TRY(launch_gemm(prec, EPI_GELUGRAD_TE, gp, st));
+      }
       if (fused_b1) OSUD_TRY(launch_colsum_f32(w.splitk, part_rows, 4 * D, g_b1, st));
     }
     OSUD_TRY(dbg_sync(st, "dgrad fc2 (gelu grad)"));
     // consumers of dz1 (201 MB, fresh in the Infinity Cache) first, the fc2 weight gradient (dbr, g) after them
+    if (f8_train) OSUD_TRY(launch_f8_quantize(w.dz1, f8_live ? m->q8b : nullptr, (size_t)Mp * 4 * D, slot(4), st));
+    if (f8_live) OSUD_TRY(gemm8(m, EPI_NONE_TE, m->q8b, bw.w1_t8, Mp, D, 4 * D, w.du, D, nullptr, bw.dq_1_t, 0.f, st, nullptr, 0, 0, 0, 0.f,
+                                slot(4) + 1));
+    else
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dz1, 4 * D, bw.w1_t, 4 * D, Mp, D, 4 * D, w.du, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "dgrad fc1"));
     OSUD_TRY(weight_grad(m, w.dz1, 4 * D, sv.u2, D, 4 * D, D, Mp, G(p + "mlp.fc1.weight"), fused_b1 ? nullptr : g_b1, st));
@@ -240,6 +266,10 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     OSUD_TRY(launch_attention_bwd(prec, sv.qk, w.dao, sv.ao, sv.lse, w.dqkv, N, T, m->H, m->hd, st, w.attn_delta,
                                   fused_bqkv ? g_bqkv : nullptr));
     OSUD_TRY(dbg_sync(st, "attention bwd"));
+    if (f8_train) OSUD_TRY(launch_f8_quantize(w.dqkv, f8_live ? m->q8b : nullptr, (size_t)Mp * 3 * D, slot(5), st));
+    if (f8_live) OSUD_TRY(gemm8(m, EPI_NONE_TE, m->q8b, bw.w_qkv_t8, Mp, D, 3 * D, w.du, D, nullptr, bw.dq_qkv_t, 0.f, st, nullptr, 0, 0, 0, 0.f,
+                                slot(5) + 1));
+    else
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dqkv, 3 * D, bw.w_qkv_t, 3 * D, Mp, D, 3 * D, w.du, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "dgrad qkv"));
     OSUD_TRY(weight_grad(m, w.dqkv, 3 * D, sv.u1, D, 3 * D, D, Mp, G(p + "attn.in_proj_weight"), fused_bqkv ? nullptr : g_bqkv, st));
