@@ -131,8 +131,12 @@ namespace osud {
 
 template <typename P> inline int dev_alloc(std::vector<void*>& owner, P** out, size_t bytes, bool zero = true) {
   void* p = nullptr;
-  OSUD_HIP(hipMalloc(&p, bytes ? bytes : 16));
-  if (zero) OSUD_HIP(hipMemset(p, 0, bytes ? bytes : 16));
+  // 512 bytes of slack behind every buffer: the weight-gradient kernel's edge tiles (feature counts that are odd multiples of 128,
+  // e.g. DiT-XL's 1152 / 3456) stage up to 128 features past a row's end -- the next row's first bytes, and for the LAST token
+  // row up to 256 bytes past the buffer; the slack keeps that read inside the allocation (the values are never stored)
+  bytes = (bytes ? bytes : 16) + 512;
+  OSUD_HIP(hipMalloc(&p, bytes));
+  if (zero) OSUD_HIP(hipMemset(p, 0, bytes));
   owner.push_back(p);
   *out = reinterpret_cast<P*>(p);
   return OSUD_OK;

@@ -748,11 +748,15 @@ template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
     else if (f == "192" && e[1] > 0) pick = 1;
     else if (f == "256" && e[2] > 0) pick = 2;
     else if (f == "192y" && e[3] > 0) pick = 3;
+    else if (f == "256x128" && p.My % 256 == 0) pick = 7;  // experiment: three 48 KiB stages instead of two 64 KiB ones
+    else if (f == "128x256" && p.Nx % 256 == 0) pick = 8;
   }
   if (pick == 2) return launch_w<TE, EPI, 2, 4, 4, 2>(p, st);
   if (pick == 1) return launch_w<TE, EPI, 4, 2, 2, 3>(p, st);
   if (pick == 3) return launch_w<TE, EPI, 2, 4, 3, 2>(p, st);
   if (pick == 6) return launch_w<TE, EPI, 2, 2, 1, 2>(p, st);
+  if (pick == 7) return launch_w<TE, EPI, 4, 2, 2, 2>(p, st);
+  if (pick == 8) return launch_w<TE, EPI, 2, 4, 2, 2>(p, st);
   return launch_w<TE, EPI, 2, 2, 2, 2>(p, st);
 }
 

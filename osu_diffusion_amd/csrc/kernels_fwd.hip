@@ -353,6 +353,7 @@ __global__ __launch_bounds__(256) void quantize_rows_bf16_kernel(const bf16_t* _
 // recording this step's amax.  16 bytes in, 8 bytes out per lane; HBM-bound (3 bytes per element).
 __global__ __launch_bounds__(256) void f8_quantize_kernel(const bf16_t* __restrict__ src, fp8_t* __restrict__ dst, size_t n8,
                                                           float* __restrict__ slot) {
+  __shared__ float red[4];
   const float scale = slot[0];
   float amax = 0.f;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
@@ -365,8 +366,14 @@ __global__ __launch_bounds__(256) void f8_quantize_kernel(const bf16_t* __restri
     }
     if (dst != nullptr) store8(dst + i * 8, v);
   }
+  // ONE atomic per workgroup (a per-wave atomic on the single amax word cost 160 us per launch: 16 K serialised L2 atomics)
   amax = wave_max(amax);
-  if ((threadIdx.x & 63) == 0 && amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot) + 2, __float_as_uint(amax));  // amax >= 0: bit order = value order
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    if (amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot) + 2, __float_as_uint(amax));  // amax >= 0: bit order = value order
+  }
 }
 
 __global__ void f8_update_kernel(float* __restrict__ slots, int n_slots) {
@@ -400,7 +407,7 @@ int launch_quantize_rows_bf16(const void* w, int rows, int cols, void* q, float*
 int launch_f8_quantize(const void* src, void* dst, size_t n, float* slot, hipStream_t st) {
   OSUD_CHECK_ARG(n % 8 == 0 && slot != nullptr, "f8_quantize: n must be a multiple of 8");
   const size_t n8 = n / 8;
-  const int grid = (int)((n8 + 255) / 256 > 4096 ? 4096 : (n8 + 255) / 256);
+  const int grid = (int)((n8 + 255) / 256 > 1024 ? 1024 : (n8 + 255) / 256);
   hipLaunchKernelGGL(f8_quantize_kernel, dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (fp8_t*)dst, n8, slot);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;

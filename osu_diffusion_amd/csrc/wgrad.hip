@@ -125,7 +125,9 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
   const int wy = wave / WX, wx = wave % WX;
   const int frow = lane & 31, fhalf = lane >> 5;
 
-  const int ntx = p.Nx / G::BN, ntiles = (p.Ny / G::BM) * ntx;
+  // (edge tiles: Ny / Nx may be odd multiples of 128 under the 256-wide geometry; the out-of-range half is computed on
+  // whatever the staging reads -- see dev_alloc's slack -- and never stored)
+  const int ntx = (p.Nx + G::BN - 1) / G::BN, ntiles = ((p.Ny + G::BM - 1) / G::BM) * ntx;
   // this split's share of the token axis (any split count: ranges differ by at most one stage)
   const int st_total = p.M / BKT;
   const int st_begin = (int)((long)blockIdx.y * st_total / p.split_k);
@@ -219,8 +221,11 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
         t[3] = ds_read16f<3072>(pr);
         OSUD_WG_WAIT(0);
         const int x = tx * G::BN + wx * RX * 32 + j * 32 + 4 * (lane & 7);
+        if (x < p.Nx) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) store4(outp + (size_t)(y0 + 8 * q) * p.Nx + x, t[q][0], t[q][1], t[q][2], t[q][3]);
+          for (int q = 0; q < 4; ++q)
+            if (y0 + 8 * q < p.Ny) store4(outp + (size_t)(y0 + 8 * q) * p.Nx + x, t[q][0], t[q][1], t[q][2], t[q][3]);
+        }
       }
     }
   };
@@ -354,6 +359,7 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
     float* fin = p.final + (size_t)(ty * G::BM) * p.Nx + (size_t)tx * G::BN;
     for (int idx = tid; idx < (r1 - r0) * C4; idx += G::NT) {
       const int row = r0 + idx / C4, c4 = idx % C4;
+      if (ty * G::BM + row >= p.Ny || tx * G::BN + c4 * 4 >= p.Nx) continue;  // edge tile
       const size_t o = (size_t)row * p.Nx + (size_t)c4 * 4;
       float4 a = *reinterpret_cast<const float4*>(slab0 + o);
       for (int s2 = 1; s2 < S; ++s2) {
@@ -467,7 +473,7 @@ template <int WY, int WX, int RY, int RX> int launch_wg(const WgradP& p, hipStre
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  const int ntiles = (p.Ny / G::BM) * (p.Nx / G::BN);
+  const int ntiles = ((p.Ny + G::BM - 1) / G::BM) * ((p.Nx + G::BN - 1) / G::BN);
   int grid = num_cus_w() / p.split_k;
   if (grid < 1) grid = 1;
   if (grid > ntiles || p.split_k > 1) grid = ntiles;  // with splits: one tile per workgroup
@@ -483,8 +489,12 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
                     size_t ws_elems, hipStream_t st) {
   OSUD_CHECK_ARG(Ny % 128 == 0 && Nx % 128 == 0 && M % BKT == 0 && ldp % 8 == 0 && ldq % 8 == 0,
                  "wgrad: Ny=%d Nx=%d must be multiples of 128, M=%d of 64", Ny, Nx, M);
-  const bool big = Ny % 256 == 0 && Nx % 256 == 0;
-  const int tiles = big ? (Ny / 256) * (Nx / 256) : (Ny / 128) * (Nx / 128);
+  // 256x256 tiles (8 waves) also for odd multiples of 128 -- DiT-XL's 1152 and 3456 -- with half-empty edge tiles, as long as
+  // the padding stays below 25 % of the work: the 128x128 geometry (4 waves) runs at ~0.55x the 256-wide kernel's rate
+  // (profiles/r02_xl_*: 582 vs 1033 TFLOP/s), which made the weight gradients 30 % of a DiT-XL training step
+  const int t256 = ((Ny + 255) / 256) * ((Nx + 255) / 256);
+  const bool big = Ny >= 256 && Nx >= 256 && (double)t256 * 65536.0 <= 1.25 * (double)Ny * (double)Nx;
+  const int tiles = big ? t256 : (Ny / 128) * (Nx / 128);
   const int stages = M / BKT;
   // fill the chip in ONE round: splits = CUs / tiles, each split at least 8 stages (512 tokens)
   int S = num_cus_w() / tiles;
