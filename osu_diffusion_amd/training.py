@@ -376,9 +376,11 @@ class NativeTrainer:
         self.ema_arena.flat.copy_(self.arena.flat)  # update_ema(ema, model, decay=0), train.py:194-198
         self._tmap = torch.from_numpy(np.asarray(diffusion._model_timestep_map)).to(self.arena.flat.device)
 
-    def step(self, x, o, c, y, t=None, noise=None, drop_ids=None):
+    def step(self, x, o, c, y, t=None, noise=None, drop_ids=None, loss_weights=None):
         """One optimisation step on a batch of windows; returns the (3, B) tensor [l1|mse; vb; loss]
-        (device tensor, no host sync)."""
+        (device tensor, no host sync).  `loss_weights` (B,): per-sample factors of the objective, as a schedule sampler
+        returns them with its timesteps (diffusion/timestep_sampler.py: loss = mean(loss_b * w_b)); the returned terms stay
+        unweighted."""
         model, d = self.model, self.diffusion
         dev = self.arena.flat.device
         L = _lib.lib()
@@ -406,6 +408,8 @@ class NativeTrainer:
             dout = torch.empty_like(out)
             _lib.check(L.osud_train_loss(d._sched.handle, self.use_l1, _lib.ptr(out), _lib.ptr(x0), _lib.ptr(x_t), _lib.ptr(noise),
                                          _lib.ptr(t), B, T, _lib.ptr(terms), _lib.ptr(dout), st))
+            if loss_weights is not None:  # d(mean_b w_b loss_b)/d(out): the fused loss kernel's rows scale with their sample's weight
+                dout.mul_(loss_weights.to(dev, torch.float32).view(B, 1, 1))
             if self.embed_only:
                 self._embed_only_update(dout, y)
                 return terms

@@ -794,9 +794,38 @@ def g13_export():
                 sys.modules[k] = v
 
 
+def g14_timestep_sampler():
+    """diffusion/timestep_sampler.py of the reference (unused by its scripts; its loss-aware class cannot even be constructed
+    under numpy >= 1.24 -- `np.int` -- so the alias is restored for this run): sampled timesteps and weights of both samplers
+    under a seeded numpy generator, before and after a loss history."""
+    print("G14 timestep samplers")
+    import diffusion.timestep_sampler as ref_ts  # noqa: E402  (reference)
+    if not hasattr(np, "int"):
+        np.int = int
+    dref = ref_create_diffusion("", noise_schedule="squaredcos_cap_v2")
+    out = {}
+    uni = ref_ts.create_named_schedule_sampler("uniform", dref)
+    np.random.seed(11)
+    t, w = uni.sample(32, "cpu")
+    out["uniform_t"], out["uniform_w"] = t, w
+    lsm = ref_ts.create_named_schedule_sampler("loss-second-moment", dref)
+    np.random.seed(12)
+    t, w = lsm.sample(16, "cpu")          # not warmed up: uniform
+    out["cold_t"], out["cold_w"] = t, w
+    rng = np.random.default_rng(13)
+    ts_hist = np.concatenate([np.tile(np.arange(1000), 10), rng.integers(0, 1000, 3000)])   # full history, then overwrites
+    loss_hist = np.abs(rng.normal(size=ts_hist.shape)) * (1 + ts_hist / 250.0)
+    lsm.update_with_all_losses(list(ts_hist), list(loss_hist))
+    out["weights"] = lsm.weights()
+    np.random.seed(14)
+    t, w = lsm.sample(64, "cpu")
+    out["warm_t"], out["warm_w"] = t, w
+    save("g14_timestep_sampler", ts_hist=ts_hist, loss_hist=loss_hist, **out)
+
+
 if __name__ == "__main__":
     steps = [g1_schedules, g2_embeddings, g3_forward, g5_step, g6_loop, g7_training, g9_init_and_keys, g9_windows, g10_curves, g11_inpaint,
-             g3_forward_dit_b, g7_training_dit_b, g6_long_loops, g12_cli_toy, g13_export]
+             g3_forward_dit_b, g7_training_dit_b, g6_long_loops, g12_cli_toy, g13_export, g14_timestep_sampler]
     only = set(sys.argv[1:])  # e.g. `make_golden.py g10_curves` regenerates one family
     for fn in steps:
         if not only or fn.__name__ in only:

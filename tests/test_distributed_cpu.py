@@ -193,3 +193,41 @@ def test_sharded_exchange_two_ranks_gloo():
         out = mgr.dict()
         mp.spawn(_zero1_worker, args=(2, port, out), nprocs=2, join=True)
         assert max(out.values()) <= 1e-6, dict(out)
+
+
+def _sampler_worker(rank, world, port, out):
+    """LossAwareSampler.update_with_local_losses over gloo: ranks contribute batches of different sizes; afterwards every rank
+    holds the same history, equal to feeding rank 0's pairs then rank 1's."""
+    import numpy as np
+    from osu_diffusion_amd.diffusion import create_diffusion
+    from osu_diffusion_amd.diffusion.timestep_sampler import create_named_schedule_sampler
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = create_diffusion("20", noise_schedule="squaredcos_cap_v2")
+        s = create_named_schedule_sampler("loss-second-moment", d)
+        g = torch.Generator().manual_seed(50 + rank)
+        n = 5 + 3 * rank
+        ts = torch.randint(0, 20, (n,), generator=g)
+        losses = torch.rand(n, generator=g)
+        s.update_with_local_losses(ts, losses)
+        out[rank] = (s._loss_counts.copy(), np.sort(s._loss_history, axis=1), ts, losses)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_loss_aware_sampler_synchronises_over_gloo():
+    import numpy as np
+    from osu_diffusion_amd.diffusion import create_diffusion
+    from osu_diffusion_amd.diffusion.timestep_sampler import create_named_schedule_sampler
+
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_sampler_worker, args=(2, port, out), nprocs=2, join=True)
+        (c0, h0, t0, l0), (c1, h1, t1, l1) = out[0], out[1]
+    assert np.array_equal(c0, c1) and np.array_equal(h0, h1)
+    ref = create_named_schedule_sampler("loss-second-moment", create_diffusion("20", noise_schedule="squaredcos_cap_v2"))
+    ref.update_with_all_losses(t0.tolist() + t1.tolist(), l0.tolist() + l1.tolist())
+    assert np.array_equal(ref._loss_counts, c0) and np.allclose(np.sort(ref._loss_history, axis=1), h0)

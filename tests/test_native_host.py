@@ -144,3 +144,28 @@ def test_generic_diffusion_path_on_cpu_with_plain_callable():
     r = d.ddim_sample(model, x, t, clip_denoised=True, eta=1.0)
     assert float((r["sample"] - torch.from_numpy(fx["ddim1_sample"])).abs().max()) == 0.0
     assert float((r["pred_xstart"] - torch.from_numpy(fx["ddim1_x0"])).abs().max()) == 0.0
+
+
+def test_timestep_samplers_match_the_reference():
+    """fixture g14_timestep_sampler (the reference's diffusion/timestep_sampler.py under seeded numpy generators)."""
+    import numpy as np
+    from osu_diffusion_amd.diffusion.timestep_sampler import create_named_schedule_sampler
+    from tests.helpers import load
+
+    fx = load("g14_timestep_sampler")
+    d = create_diffusion("", noise_schedule="squaredcos_cap_v2")
+    uni = create_named_schedule_sampler("uniform", d)
+    np.random.seed(11)
+    t, w = uni.sample(32, "cpu")
+    assert np.array_equal(t.numpy(), fx["uniform_t"]) and np.array_equal(w.numpy(), fx["uniform_w"])
+    lsm = create_named_schedule_sampler("loss-second-moment", d)
+    np.random.seed(12)
+    t, w = lsm.sample(16, "cpu")
+    assert np.array_equal(t.numpy(), fx["cold_t"]) and np.array_equal(w.numpy(), fx["cold_w"])
+    lsm.update_with_all_losses(list(fx["ts_hist"]), list(fx["loss_hist"]))
+    assert np.allclose(lsm.weights(), fx["weights"], rtol=1e-12, atol=0)
+    np.random.seed(14)
+    t, w = lsm.sample(64, "cpu")
+    assert np.array_equal(t.numpy(), fx["warm_t"]) and np.allclose(w.numpy(), fx["warm_w"], rtol=1e-6)
+    with pytest.raises(NotImplementedError):
+        create_named_schedule_sampler("nope", d)
