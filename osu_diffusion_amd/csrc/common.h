@@ -145,6 +145,43 @@ __device__ __forceinline__ void load2(const float* p, float& a, float& b) {
   b = v.y;
 }
 
+// W consecutive elements (W = 2 or 4): the row-wise kernels give every lane W columns per group so that hidden sizes whose
+// per-lane count is a multiple of 4 (768, 1024) move 16 bytes per fp32 access, the others (1152 = 18 per lane) 8
+template <int W> __device__ __forceinline__ void loadw(const float* p, float* v) {
+  if constexpr (W == 4) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  } else {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    v[0] = t.x; v[1] = t.y;
+  }
+}
+template <int W> __device__ __forceinline__ void loadw(const bf16_t* p, float* v) {
+  if constexpr (W == 4) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+  } else {
+    load2(p, v[0], v[1]);
+  }
+}
+template <int W> __device__ __forceinline__ void loadw(const fp8_t*, float* v) {  // fp8 tensors are never read back by these kernels
+#pragma unroll
+  for (int e = 0; e < W; ++e) v[e] = 0.f;
+}
+template <int W> __device__ __forceinline__ void storew(float* p, const float* v) {
+  if constexpr (W == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  else *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
+}
+template <int W> __device__ __forceinline__ void storew(bf16_t* p, const float* v) {
+  if constexpr (W == 4) store4(p, v[0], v[1], v[2], v[3]);
+  else store2(p, v[0], v[1]);
+}
+template <int W> __device__ __forceinline__ void storew(fp8_t* p, const float* v) {
+  if constexpr (W == 4) store4(p, v[0], v[1], v[2], v[3]);
+  else store2(p, v[0], v[1]);
+}
+
 // FAST = bf16 tier (hardware v_exp_f32 based), !FAST = parity tier (accurate expf / division)
 template <bool FAST> __device__ __forceinline__ float exp_t(float v) { return FAST ? __expf(v) : expf(v); }
 // The fast tier spends exactly two transcendental issues per sigmoid (v_exp_f32 + v_rcp_f32): `1.0f / x` and

@@ -145,38 +145,45 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ dh_skip, float* __restrict__ dh_out,
                                                          float* __restrict__ dada, int Tp, const TE* __restrict__ br_next,
                                                          int off_gate_next, TE* __restrict__ dbr, float* __restrict__ db_next) {
-  constexpr int D = VPL * 64;
+  // lane l owns columns W*l + 64*W*g + {0..W-1}, g < NG: 16-byte fp32 / 8-byte bf16 accesses where VPL allows (W = 4)
+  constexpr int D = VPL * 64, W = (VPL % 4 == 0) ? 4 : 2, NG = VPL / W;
   __shared__ float red[2][4][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m0 = blockIdx.x * 64, n = m0 / Tp;
   const float* arow = ada + (size_t)n * ld_ada;
   float scv[VPL], gv[VPL], a_sh[VPL], a_sc[VPL], a_g[VPL], a_cs[VPL];
 #pragma unroll
-  for (int i = 0; i < VPL / 2; ++i) {
-    const float2 t = *reinterpret_cast<const float2*>(arow + off_scale + 2 * lane + 128 * i);
-    scv[2 * i] = 1.0f + t.x; scv[2 * i + 1] = 1.0f + t.y;
-    a_sh[2 * i] = a_sh[2 * i + 1] = a_sc[2 * i] = a_sc[2 * i + 1] = 0.f;
-    a_g[2 * i] = a_g[2 * i + 1] = a_cs[2 * i] = a_cs[2 * i + 1] = 0.f;
-    gv[2 * i] = gv[2 * i + 1] = 0.f;
-    if (br_next != nullptr) {
-      const float2 g2 = *reinterpret_cast<const float2*>(arow + off_gate_next + 2 * lane + 128 * i);
-      gv[2 * i] = g2.x; gv[2 * i + 1] = g2.y;
+  for (int g = 0; g < NG; ++g) {
+    const int d = W * lane + 64 * W * g;
+    loadw<W>(arow + off_scale + d, scv + g * W);
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+      scv[g * W + e] += 1.0f;
+      a_sh[g * W + e] = a_sc[g * W + e] = a_g[g * W + e] = a_cs[g * W + e] = gv[g * W + e] = 0.f;
     }
+    if (br_next != nullptr) loadw<W>(arow + off_gate_next + d, gv + g * W);
   }
   struct Row {
-    float2 hv[VPL / 2], dv[VPL / 2], sk[VPL / 2], bn[VPL / 2];
+    float hv[VPL], dv[VPL], sk[VPL], bn[VPL];
     float mu, rstd;
   };
   auto load_row = [&](Row& R, int m) {
     const size_t row = (size_t)m * D;
 #pragma unroll
-    for (int i = 0; i < VPL / 2; ++i) {
-      const int d = 2 * lane + 128 * i;
-      R.hv[i] = *reinterpret_cast<const float2*>(h + row + d);
-      load2(du + row + d, R.dv[i].x, R.dv[i].y);
-      R.sk[i] = dh_skip != nullptr ? *reinterpret_cast<const float2*>(dh_skip + row + d) : make_float2(0.f, 0.f);
-      R.bn[i] = make_float2(0.f, 0.f);
-      if (br_next != nullptr) load2(br_next + row + d, R.bn[i].x, R.bn[i].y);
+    for (int g = 0; g < NG; ++g) {
+      const int d = W * lane + 64 * W * g;
+      loadw<W>(h + row + d, R.hv + g * W);
+      loadw<W>(du + row + d, R.dv + g * W);
+      if (dh_skip != nullptr) loadw<W>(dh_skip + row + d, R.sk + g * W);
+      else {
+#pragma unroll
+        for (int e = 0; e < W; ++e) R.sk[g * W + e] = 0.f;
+      }
+      if (br_next != nullptr) loadw<W>(br_next + row + d, R.bn + g * W);
+      else {
+#pragma unroll
+        for (int e = 0; e < W; ++e) R.bn[g * W + e] = 0.f;
+      }
     }
     R.mu = stats[2 * (size_t)m];
     R.rstd = stats[2 * (size_t)m + 1];
@@ -186,26 +193,31 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
     const float mu = R.mu, rstd = R.rstd;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL / 2; ++i) {
-      R.hv[i].x = (R.hv[i].x - mu) * rstd; R.hv[i].y = (R.hv[i].y - mu) * rstd;  // xhat
-      a_sh[2 * i] += R.dv[i].x; a_sh[2 * i + 1] += R.dv[i].y;
-      a_sc[2 * i] += R.dv[i].x * R.hv[i].x; a_sc[2 * i + 1] += R.dv[i].y * R.hv[i].y;
-      R.dv[i].x *= scv[2 * i]; R.dv[i].y *= scv[2 * i + 1];  // dy
-      s1 += R.dv[i].x + R.dv[i].y;
-      s2 += R.dv[i].x * R.hv[i].x + R.dv[i].y * R.hv[i].y;
+    for (int i = 0; i < VPL; ++i) {
+      R.hv[i] = (R.hv[i] - mu) * rstd;  // xhat
+      a_sh[i] += R.dv[i];
+      a_sc[i] += R.dv[i] * R.hv[i];
+      R.dv[i] *= scv[i];  // dy
+      s1 += R.dv[i];
+      s2 += R.dv[i] * R.hv[i];
     }
     const float m1 = wave_sum(s1) * (1.0f / D), m2 = wave_sum(s2) * (1.0f / D);
 #pragma unroll
-    for (int i = 0; i < VPL / 2; ++i) {
-      const int d = 2 * lane + 128 * i;
-      const float2 o = make_float2(R.sk[i].x + rstd * (R.dv[i].x - m1 - R.hv[i].x * m2),
-                                   R.sk[i].y + rstd * (R.dv[i].y - m1 - R.hv[i].y * m2));
-      *reinterpret_cast<float2*>(dh_out + row + d) = o;
-      if (br_next != nullptr) {
-        a_g[2 * i] += o.x * R.bn[i].x; a_g[2 * i + 1] += o.y * R.bn[i].y;
-        a_cs[2 * i] += o.x; a_cs[2 * i + 1] += o.y;
-        store2(dbr + row + d, gv[2 * i] * o.x, gv[2 * i + 1] * o.y);
+    for (int g = 0; g < NG; ++g) {
+      const int d = W * lane + 64 * W * g;
+      float o[W], b[W];
+#pragma unroll
+      for (int e = 0; e < W; ++e) {
+        const int i = g * W + e;
+        o[e] = R.sk[i] + rstd * (R.dv[i] - m1 - R.hv[i] * m2);
+        if (br_next != nullptr) {
+          a_g[i] += o[e] * R.bn[i];
+          a_cs[i] += o[e];
+          b[e] = gv[i] * o[e];
+        }
       }
+      storew<W>(dh_out + row + d, o);
+      if (br_next != nullptr) storew<W>(dbr + row + d, b);
     }
   };
   // rows wave, wave+4, ..., two register sets: the next row's loads are in flight while this one is reduced
@@ -218,11 +230,13 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
     process_row(rb, m0 + r + 4);
   }
 #pragma unroll
-  for (int i = 0; i < VPL / 2; ++i) {
-    const int d = 2 * lane + 128 * i;
-    red[0][wave][d] = a_sh[2 * i]; red[0][wave][d + 1] = a_sh[2 * i + 1];
-    red[1][wave][d] = a_sc[2 * i]; red[1][wave][d + 1] = a_sc[2 * i + 1];
-  }
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+      const int d = W * lane + 64 * W * g + e;
+      red[0][wave][d] = a_sh[g * W + e];
+      red[1][wave][d] = a_sc[g * W + e];
+    }
   __syncthreads();
   float* dn = dada + (size_t)n * ld_ada;
   for (int d = threadIdx.x; d < D; d += 256) {
@@ -232,11 +246,13 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
   if (br_next != nullptr) {
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < VPL / 2; ++i) {
-      const int d = 2 * lane + 128 * i;
-      red[0][wave][d] = a_g[2 * i]; red[0][wave][d + 1] = a_g[2 * i + 1];
-      red[1][wave][d] = gv[2 * i] * a_cs[2 * i]; red[1][wave][d + 1] = gv[2 * i + 1] * a_cs[2 * i + 1];
-    }
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int e = 0; e < W; ++e) {
+        const int d = W * lane + 64 * W * g + e;
+        red[0][wave][d] = a_g[g * W + e];
+        red[1][wave][d] = gv[g * W + e] * a_cs[g * W + e];
+      }
     __syncthreads();
     for (int d = threadIdx.x; d < D; d += 256) {
       atomicAdd(dn + off_gate_next + d, red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d]);

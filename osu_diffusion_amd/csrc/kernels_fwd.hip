@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* h, const float
                                                      int off_shift, int off_scale, TE* out, float* __restrict__ stats,
                                                      int M, int Tp, int N, const TE* br, int off_gate, float* h_out,
                                                      float out_scale) {
-  constexpr int D = VPL * 64;
+  // lane l owns columns W*l + 64*W*g + {0..W-1}: 16-byte fp32 accesses where the per-lane count allows (W = 4)
+  constexpr int D = VPL * 64, W = (VPL % 4 == 0) ? 4 : 2, NG = VPL / W;
   const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (m >= M) return;
   int n = m / Tp;
@@ -137,27 +138,22 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* h, const float
   float v[VPL];
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < VPL / 2; ++i) {
-    const float2 p = *reinterpret_cast<const float2*>(hr + 2 * lane + 128 * i);
-    v[2 * i] = p.x;
-    v[2 * i + 1] = p.y;
-  }
+  for (int g = 0; g < NG; ++g) loadw<W>(hr + W * lane + 64 * W * g, v + g * W);
   if (br != nullptr) {
     const TE* brow = br + (size_t)m * D;
     const float* gt = ada + (size_t)n * ld_ada + off_gate;
 #pragma unroll
-    for (int i = 0; i < VPL / 2; ++i) {
-      const int d = 2 * lane + 128 * i;
-      float b0, b1;
-      load2(brow + d, b0, b1);
-      const float2 g2 = *reinterpret_cast<const float2*>(gt + d);
-      v[2 * i] += g2.x * b0;
-      v[2 * i + 1] += g2.y * b1;
+    for (int g = 0; g < NG; ++g) {
+      const int d = W * lane + 64 * W * g;
+      float b[W], gg[W];
+      loadw<W>(brow + d, b);
+      loadw<W>(gt + d, gg);
+#pragma unroll
+      for (int e = 0; e < W; ++e) v[g * W + e] += gg[e] * b[e];
     }
     if (h_out != nullptr) {
 #pragma unroll
-      for (int i = 0; i < VPL / 2; ++i)
-        *reinterpret_cast<float2*>(h_out + (size_t)m * D + 2 * lane + 128 * i) = make_float2(v[2 * i], v[2 * i + 1]);
+      for (int g = 0; g < NG; ++g) storew<W>(h_out + (size_t)m * D + W * lane + 64 * W * g, v + g * W);
     }
   }
 #pragma unroll
@@ -178,14 +174,17 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* h, const float
   const float* sc = ada + (size_t)n * ld_ada + off_scale;
   TE* orow = out + (size_t)m * D;
 #pragma unroll
-  for (int i = 0; i < VPL / 2; ++i) {
-    const int d = 2 * lane + 128 * i;
-    const float2 s2 = *reinterpret_cast<const float2*>(sc + d);
-    const float2 h2 = *reinterpret_cast<const float2*>(sh + d);
-    const float a = (v[2 * i] - mu) * rstd * (1.0f + s2.x) + h2.x;
-    const float b = (v[2 * i + 1] - mu) * rstd * (1.0f + s2.y) + h2.y;
-    if (sizeof(TE) == 1) store2(orow + d, a * out_scale, b * out_scale);  // fp8 operand of the next GEMM, statically scaled
-    else store2(orow + d, a, b);
+  for (int g = 0; g < NG; ++g) {
+    const int d = W * lane + 64 * W * g;
+    float s4[W], h4[W], r[W];
+    loadw<W>(sc + d, s4);
+    loadw<W>(sh + d, h4);
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+      r[e] = (v[g * W + e] - mu) * rstd * (1.0f + s4[e]) + h4[e];
+      if (sizeof(TE) == 1) r[e] *= out_scale;  // fp8 operand of the next GEMM, statically scaled
+    }
+    storew<W>(orow + d, r);
   }
 }
 
