@@ -198,7 +198,9 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else static_assert(N < 0, "add the literal");
 }
 
-template <typename TE, int EPI, int WY, int WX, int RY, int RX>
+// ROLES (8-wave geometries, static tile schedule): the two waves of every SIMD alternate between feeding the matrix pipe and
+// issuing the LDS-DMA of the next slab instead of doing both in lock step -- see the main loop.
+template <typename TE, int EPI, int WY, int WX, int RY, int RX, bool ROLES>
 __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p) {
   using G = Geo<WY, WX, RY, RX>;
   constexpr int BN = G::BN;
@@ -277,6 +279,40 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
     const int c = (lane & 7) ^ ((R >> 1) & 7);
     dma_off[q] = (uint32_t)((piece * 8 < G::BM ? (size_t)R * ldy_b : (size_t)(R - G::BM) * ldx_b) + c * 16);
   }
+  // ---- ROLES: who stages what.  Waves w and w + 4 share a SIMD; group 0 = waves 0-3 owns the top half of the Y rows, group 1
+  // the bottom half.  Per slab: group 1 issues the pieces group 0 needs first -- Y top + all of X (the EARLY set) -- while group 0
+  // computes; then group 0 issues Y bottom (the LATE set, only group 1 needs it, a whole period later) while group 1 computes.
+  constexpr int kNE = G::BM / 16 + G::BN / 8, kPE = ROLES ? kNE / 4 : 1, kPL = ROLES ? G::BM / 64 : 1, kPR = kPE > kPL ? kPE : kPL;
+  static_assert(!ROLES || (G::NW == 8 && kNE % 4 == 0 && (G::BM / 16) % 4 == 0), "role split needs 8 waves and evenly divisible piece sets");
+  const int grp = wave >> 2, wi = wave & 3;
+  uint32_t roff[kPR];
+  if constexpr (ROLES) {
+#pragma unroll
+    for (int q = 0; q < kPR; ++q) {
+      int piece = 0;
+      if (grp == 1) { const int e = wi * kPE + q; piece = e < G::BM / 16 ? e : G::BM / 8 + (e - G::BM / 16); }
+      else piece = G::BM / 16 + wi * kPL + (q < kPL ? q : 0);
+      const int R = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((R >> 1) & 7);
+      roff[q] = (uint32_t)((piece * 8 < G::BM ? (size_t)R * ldy_b : (size_t)(R - G::BM) * ldx_b) + c * 16);
+    }
+  }
+  auto role_issue = [&](const char* gy, const char* gx, uint32_t stage_lds) {  // this wave's share of its group's set
+    const int cnt = grp == 1 ? kPE : kPL;
+#pragma unroll
+    for (int q = 0; q < kPR; ++q) {
+      if (q < cnt) {
+        int piece;
+        if (grp == 1) { const int e = wi * kPE + q; piece = e < G::BM / 16 ? e : G::BM / 8 + (e - G::BM / 16); }
+        else piece = G::BM / 16 + wi * kPL + q;
+        piece = __builtin_amdgcn_readfirstlane(piece);
+        const char* sbase = (piece * 8 < G::BM) ? gy : gx;
+        const uint32_t dst = stage_lds + (uint32_t)(piece * 8 * SLAB);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(roff[q]), "s"(sbase), "s"(dst) : "memory");
+      }
+    }
+  };
+
   // ---- tile sequence.  The first tile of a workgroup is static (`first`: XCD-contiguous runs).  Launches with more tiles
   // than workgroups draw every later tile from a ticket counter (p.sched), two tiles ahead of the one being computed, so that a
   // workgroup that starts late or runs slowly -- a collective's or an optimizer's kernel holding its compute unit -- takes fewer
@@ -330,8 +366,19 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
       }
     }
   };
+  int cs = 0;  // ROLES: slabs consumed so far by this workgroup (stage = cs & 1)
+  if constexpr (ROLES) {
+    if (t_cur < ntiles) {  // the very first slab: both groups stage their sets, everybody waits
+      const char *gy, *gx;
+      tile_ptrs(t_cur, 0, gy, gx);
+      role_issue(gy, gx, lds0);
+    }
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+  } else {
 #pragma unroll
-  for (int i = 0; i < G::NSTAGE - 1; ++i) issue_next();
+    for (int i = 0; i < G::NSTAGE - 1; ++i) issue_next();
+  }
   int landed = 0;  // slabs known to have landed already (waited for before the previous epilogue)
 
 #ifdef OSUD_GEMM_TIMING
@@ -358,6 +405,42 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    uint32_t pso;
+    int t_nxt2 = t_nxt + G8;
+    if constexpr (ROLES) {
+      // ---- role-split main loop: two half-periods per slab, a barrier after each.
+      //   H1: group 0 runs the slab's MFMAs | group 1 issues the EARLY set of the NEXT slab (Y top + X) into the other stage
+      //   H2: group 1 runs the slab's MFMAs | group 0 issues the LATE set of the next slab (Y bottom)
+      // A SIMD's matrix pipe is fed by one of its two waves in each half while the other one pays the LDS-DMA issue cost
+      // (~100 cycles per 1 KiB piece, 64 pieces per slab: in lock step that was ~1000 cycles per slab with the pipe idle).
+      // Readiness: what a group computes on in its half was issued at least one half-period earlier by the OTHER group, which
+      // waits for its own pieces (vmcnt(0)) at the end of its computing half, just before the barrier -- no wave ever waits
+      // for a piece it has only just issued.  Two 64 KiB stages as before.
+      for (int kt = 0; kt < nk; ++kt) {
+        const bool last = kt + 1 == nk;
+        const int n_tile = last ? t_nxt : t_cur, n_kt = last ? 0 : kt + 1;
+        const bool has_next = n_tile < ntiles;
+        const char *gy = nullptr, *gx = nullptr;
+        if (has_next) tile_ptrs(n_tile, n_kt, gy, gx);
+        const uint32_t so = (uint32_t)((cs & 1) * G::STAGE), so_next = lds0 + (uint32_t)(((cs + 1) & 1) * G::STAGE);
+        if (grp == 0) {
+          compute_slab<TE, RY, RX>(acc, ya, xa, so);
+          wait_vm<0>();  // its LATE pieces of this slab's successor... issued in the previous H2: landed before group 1 reads them
+        } else if (has_next) {
+          role_issue(gy, gx, so_next);
+        }
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) {
+          compute_slab<TE, RY, RX>(acc, ya, xa, so);
+          wait_vm<0>();  // the EARLY pieces issued in H1: landed before group 0 reads them in the next H1
+        } else if (has_next) {
+          role_issue(gy, gx, so_next);
+        }
+        __builtin_amdgcn_s_barrier();
+        ++cs;
+      }
+      pso = (uint32_t)(((cs - 1) & 1) * G::STAGE);  // the stage consumed last: free, becomes the epilogue patch area
+    } else {
     for (int kt = 0; kt < nk; ++kt) {
 #ifdef OSUD_GEMM_TIMING
       const uint64_t tt0 = __builtin_readcyclecounter();
@@ -407,7 +490,6 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
 #endif
     wait_vm<0>();
     landed = issued - consumed;
-    int t_nxt2 = t_nxt + G8;
     if (dyn) {  // the ticket requested at the top of this tile has returned: publish it across the epilogue barrier
       if (ticket_lane) sched_lds[0] = (uint32_t)resolve(tk);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -425,7 +507,9 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
     tsum[6] += te1 - te0;  // drain wait before the epilogue
     tsum[7] += te2 - te1;  // epilogue barrier
 #endif
-    const uint32_t pso = (uint32_t)(((consumed + G::NSTAGE - 1) % G::NSTAGE) * G::STAGE);
+    pso = (uint32_t)(((consumed + G::NSTAGE - 1) % G::NSTAGE) * G::STAGE);
+    }
+
 
     // ---- epilogue -------------------------------------------------------------------------------
     // The MFMA leaves lane (frow, fhalf) with y = frow and x = 8g + 4*fhalf + {0..3}: stored as is, one store
@@ -622,6 +706,10 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
 #ifdef OSUD_GEMM_TIMING
     tsum[5] += __builtin_readcyclecounter() - te0;  // epilogue (incl. the drain wait and barrier)
 #endif
+    if constexpr (ROLES) {  // every wave's patch reads done before the next H1 refills that stage by LDS-DMA
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     t_cur = t_nxt;
     t_nxt = t_nxt2;
     if (ic_rel > 0) --ic_rel;
@@ -693,10 +781,15 @@ template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(con
   const size_t ring = (size_t)G::NSTAGE * G::STAGE;  // stage ring (the epilogue patches borrow the free stage)
   constexpr bool kDynFits = G::NSTAGE * G::STAGE + 64 <= G::LDS_MAX;
   const size_t lds = ring + (kDynFits ? 64 : 0);
+  // the role-split main loop: 8-wave geometries with two stages (the 64 KiB-per-stage tiles), piece sets divisible by 4 waves
+  constexpr bool kRolesOk = G::NW == 8 && G::NSTAGE == 2 && (G::BM / 16 + G::BN / 8) % 4 == 0 && (G::BM / 16) % 4 == 0;
   static bool attr_set = false;
   if (!attr_set) {
-    OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX>),
+    OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX, false>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if constexpr (kRolesOk)
+      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   if (p.colpart_rows != nullptr) *p.colpart_rows = p.My / (RY * 32);
@@ -711,7 +804,15 @@ template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(con
     const int nk = (int)((size_t)p.K * sizeof(TE) / SLAB);
     p.sched = (dyn_on && kDynFits && splits == 1 && ntiles > grid && grid % 8 == 0 && nk >= G::NSTAGE && ntiles / 8 + 2 * grid < 60000) ? sched_slot() : nullptr;
   }
-  hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY, RX>), dim3(grid, splits), dim3(G::NT), lds, st, p);
+  static const bool roles_env = [] { const char* e = getenv("OSUD_GEMM_ROLES"); return !(e && e[0] == '0'); }();
+  if constexpr (kRolesOk) {
+    if (roles_env && p.sched == nullptr) {  // (the tile queues of shared-GPU mode keep the lock-step loop)
+      hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY, RX, true>), dim3(grid, splits), dim3(G::NT), lds, st, p);
+      OSUD_HIP(hipGetLastError());
+      return OSUD_OK;
+    }
+  }
+  hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY, RX, false>), dim3(grid, splits), dim3(G::NT), lds, st, p);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }

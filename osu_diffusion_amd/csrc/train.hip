@@ -261,8 +261,10 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dbr, D, bw.w_o_t, D, Mp, D, D, w.dao, D, nullptr, st));
     OSUD_TRY(weight_grad(m, w.dbr, D, sv.ao, D, D, D, Mp, G(p + "attn.out_proj.weight"), nullptr, st));
     OSUD_TRY(dbg_sync(st, "wgrad out_proj"));
-    // (bf16 tier: the in_proj bias gradient = column sums of dqkv comes out of the attention backward kernel itself)
-    const bool fused_bqkv = prec == OSUD_PREC_BF16;
+    // (the in_proj bias gradient can ride in the attention backward kernel -- column sums of dQ | dK | dV by 96 five-step lane
+    // butterflies per wave -- but that made the kernel 0.74 ms per step slower to save a 0.29 ms column-sum pass: off)
+    static const bool fuse_env = [] { const char* e = getenv("OSUD_FUSE_BQKV"); return e && e[0] == '1'; }();
+    const bool fused_bqkv = prec == OSUD_PREC_BF16 && fuse_env;
     OSUD_TRY(launch_attention_bwd(prec, sv.qk, w.dao, sv.ao, sv.lse, w.dqkv, N, T, m->H, m->hd, st, w.attn_delta,
                                   fused_bqkv ? g_bqkv : nullptr));
     OSUD_TRY(dbg_sync(st, "attention bwd"));
