@@ -95,10 +95,37 @@ template <int N> __device__ __forceinline__ void wait_lgkm() {
 }
 // One 128-byte K slab from the LDS stage at byte offset `so`: 4 sub-steps, reads of sub-step s+1 in
 // flight under the MFMAs of sub-step s (LDS returns in order, so lgkmcnt(R) == "all but the newest R").
+#ifdef OSUD_GEMM_EXP
+__device__ int g_exp_flags;  // experiments: 64 = fragment reads without the MFMAs, 128 = no LDS-DMA (stale stages), 256 = MFMAs on stale fragments (no reads)
+#endif
 template <typename TE, int RY, int RX>
 __device__ __forceinline__ void compute_slab(f32x16 (&acc)[RY][RX], const uint32_t (&ya)[4], const uint32_t (&xa)[4],
                                              uint32_t so) {
   FragSet<RY, RX> f0, f1;
+#ifdef OSUD_GEMM_EXP
+  if (sizeof(TE) == 2 && (g_exp_flags & 512)) return;  // LDS-DMA only
+  if (sizeof(TE) == 2 && (g_exp_flags & (64 | 256))) {
+    if (g_exp_flags & 64) {  // reads only
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        read_set<RY, RX>(f0, ya[s2] + so, xa[s2] + so);
+        wait_lgkm<0>();
+#pragma unroll
+        for (int i = 0; i < RY; ++i) asm volatile("" ::"v"(f0.y[i]));
+#pragma unroll
+        for (int j = 0; j < RX; ++j) asm volatile("" ::"v"(f0.x[j]));
+      }
+    } else {  // MFMAs only, on whatever the registers hold
+#pragma unroll
+      for (int j = 0; j < RX; ++j) asm volatile("" : "=v"(f0.x[j]));
+#pragma unroll
+      for (int i = 0; i < RY; ++i) asm volatile("" : "=v"(f0.y[i]));
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) mma_set<TE, RY, RX>(acc, f0);
+    }
+    return;
+  }
+#endif
   if constexpr (sizeof(TE) == 1) {  // fp8: two K = 64 instructions per accumulator block and slab (128 bytes = 128 k)
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -150,6 +177,9 @@ template <int WY, int WX, int RY, int RX> struct Geo {
 template <typename G>
 __device__ __forceinline__ void stage_slab(const char* gy, const char* gx, uint32_t stage_lds, const uint32_t (&voff)[G::PPW],
                                            int wave) {
+#ifdef OSUD_GEMM_EXP
+  if (g_exp_flags & 128) return;
+#endif
 #pragma unroll
   for (int q = 0; q < G::PPW; ++q) {
     const int piece = wave * G::PPW + q;  // wave-uniform
@@ -804,7 +834,11 @@ template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(con
     const int nk = (int)((size_t)p.K * sizeof(TE) / SLAB);
     p.sched = (dyn_on && kDynFits && splits == 1 && ntiles > grid && grid % 8 == 0 && nk >= G::NSTAGE && ntiles / 8 + 2 * grid < 60000) ? sched_slot() : nullptr;
   }
-  static const bool roles_env = [] { const char* e = getenv("OSUD_GEMM_ROLES"); return !(e && e[0] == '0'); }();
+  // OSUD_GEMM_ROLES=1 selects the role-split main loop.  Built, bit-identical results, and measured EQUAL to the lock-step loop
+  // within run-to-run noise on every shape (fc1 168.7 vs 170.6 us, 4096^3 1179 vs 1169 TFLOP/s, training step 28.3 vs 28.2 ms):
+  // two schedules this different landing on the same throughput says the main loop is not issue-bound but clock-bound -- the chip
+  // trades any saved cycle against frequency under this MFMA + LDS load.  The lock-step loop stays the default.
+  static const bool roles_env = [] { const char* e = getenv("OSUD_GEMM_ROLES"); return e && e[0] == '1'; }();
   if constexpr (kRolesOk) {
     if (roles_env && p.sched == nullptr) {  // (the tile queues of shared-GPU mode keep the lock-step loop)
       hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY, RX, true>), dim3(grid, splits), dim3(G::NT), lds, st, p);
@@ -899,6 +933,13 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
     if (order) p.tile_order = order;
     static const int delay = [] { const char* e = getenv("OSUD_GEMM_DELAY"); return e ? atoi(e) : 0; }();
     p.exp_delay = delay;
+#ifdef OSUD_GEMM_EXP
+    static const bool flags_set = [] {
+      const int v = order;
+      return hipMemcpyToSymbol(HIP_SYMBOL(g_exp_flags), &v, sizeof(int)) == hipSuccess;
+    }();
+    (void)flags_set;
+#endif
   }
   const int esz = (int)elem_size(prec);
   OSUD_CHECK_ARG(p.My > 0 && p.Nx > 0 && p.K > 0 && p.My % 128 == 0 && p.Nx % 128 == 0 && (p.K * esz) % SLAB == 0,

@@ -13,8 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = [("baseline", {}), ("no stores", {"OSUD_GEMM_ORDER": "16"}), ("stores, no math", {"OSUD_GEMM_ORDER": "32"}),
-            ("dephase 8us", {"OSUD_GEMM_DELAY": "800"}), ("dephase 16us", {"OSUD_GEMM_DELAY": "1600"}),
-            ("dephase 24us", {"OSUD_GEMM_DELAY": "2400"})]
+            ("reads, no MFMA", {"OSUD_GEMM_ORDER": "64"}), ("no LDS-DMA", {"OSUD_GEMM_ORDER": "128"}),
+            ("MFMA only (no reads)", {"OSUD_GEMM_ORDER": "256"}), ("MFMA only, no DMA", {"OSUD_GEMM_ORDER": "384"}),
+            ("DMA only", {"OSUD_GEMM_ORDER": "512"}),
+            ("zero operands", {"OSUD_EXP_ZERO": "1"})]
 
 
 def child():
@@ -25,8 +27,10 @@ def child():
     res = []
     for name, epi, M, N, K, f32 in (("fc1 gelu", _lib.EPI_BIAS_GELU_TE, 32768, 3072, 768, False), ("fc1 gelu", _lib.EPI_BIAS_GELU_TE, 16384, 3072, 768, False),
                                     ("qkv bias", _lib.EPI_BIAS_TE, 32768, 2304, 768, False), ("fc2 bias", _lib.EPI_BIAS_TE, 32768, 768, 3072, False),
-                                    ("fc2 gate", _lib.EPI_GATE_RES, 16384, 768, 3072, True)):
+                                    ("fc2 gate", _lib.EPI_GATE_RES, 16384, 768, 3072, True), ("sq4096", _lib.EPI_NONE_TE, 4096, 4096, 4096, False)):
         Yf = torch.randn(M, K, device=dev); Xf = torch.randn(N, K, device=dev) / K ** 0.5
+        if os.environ.get("OSUD_EXP_ZERO"):
+            Yf.zero_(); Xf.zero_()
         Y = torch.empty(M, K, dtype=torch.bfloat16, device=dev); X = torch.empty(N, K, dtype=torch.bfloat16, device=dev)
         L.osud_op_convert(0, _lib.ptr(Yf), _lib.ptr(Y), Yf.numel(), None); L.osud_op_convert(0, _lib.ptr(Xf), _lib.ptr(X), Xf.numel(), None)
         out = torch.zeros(M, N, dtype=torch.float32 if f32 else torch.bfloat16, device=dev)
