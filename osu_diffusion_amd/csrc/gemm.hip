@@ -11,7 +11,7 @@ namespace osud {
 
 namespace {
 
-constexpr int SLAB = 128;  // bytes of K per pipeline stage row
+constexpr int SLAB = 128;  // bytes of K per pipeline stage row (SB = 64: half slabs, a deeper ring -- see Geo)
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
@@ -68,15 +68,15 @@ template <int RY, int RX> struct FragSet {
   u32x4 y[RY], x[RX];
 };
 // ya/xa: this lane's LDS byte address of (first Y / X row of the wave, k-substep s) in the current stage
-template <int RY, int RX> __device__ __forceinline__ void read_set(FragSet<RY, RX>& f, uint32_t ya, uint32_t xa) {
+template <int RY, int RX, int SB = SLAB> __device__ __forceinline__ void read_set(FragSet<RY, RX>& f, uint32_t ya, uint32_t xa) {
   f.y[0] = ds_read16<0>(ya);
-  if constexpr (RY >= 2) f.y[1] = ds_read16<32 * SLAB>(ya);
-  if constexpr (RY >= 3) f.y[2] = ds_read16<64 * SLAB>(ya);
-  if constexpr (RY == 4) f.y[3] = ds_read16<96 * SLAB>(ya);
+  if constexpr (RY >= 2) f.y[1] = ds_read16<32 * SB>(ya);
+  if constexpr (RY >= 3) f.y[2] = ds_read16<64 * SB>(ya);
+  if constexpr (RY == 4) f.y[3] = ds_read16<96 * SB>(ya);
   f.x[0] = ds_read16<0>(xa);
-  f.x[1] = ds_read16<32 * SLAB>(xa);
-  if constexpr (RX >= 3) f.x[2] = ds_read16<64 * SLAB>(xa);
-  if constexpr (RX == 4) f.x[3] = ds_read16<96 * SLAB>(xa);
+  f.x[1] = ds_read16<32 * SB>(xa);
+  if constexpr (RX >= 3) f.x[2] = ds_read16<64 * SB>(xa);
+  if constexpr (RX == 4) f.x[3] = ds_read16<96 * SB>(xa);
 }
 template <typename TE, int RY, int RX>
 __device__ __forceinline__ void mma_set(f32x16 (&acc)[RY][RX], const FragSet<RY, RX>& f) {
@@ -95,14 +95,31 @@ template <int N> __device__ __forceinline__ void wait_lgkm() {
 }
 // One 128-byte K slab from the LDS stage at byte offset `so`: 4 sub-steps, reads of sub-step s+1 in
 // flight under the MFMAs of sub-step s (LDS returns in order, so lgkmcnt(R) == "all but the newest R").
-#ifdef OSUD_GEMM_EXP
-__device__ int g_exp_flags;  // experiments: 64 = fragment reads without the MFMAs, 128 = no LDS-DMA (stale stages), 256 = MFMAs on stale fragments (no reads)
-#endif
-template <typename TE, int RY, int RX>
+// experiments (-DOSUD_EXP_MODE=<flags>, one build per variant: run-time flags here cost registers and spill): 64 = fragment reads without the MFMAs, 128 = no
+// LDS-DMA (stale stages), 256 = MFMAs on stale fragments (no reads), 512 = neither reads nor MFMAs (LDS-DMA only)
+template <typename TE, int RY, int RX, int SB = SLAB>
 __device__ __forceinline__ void compute_slab(f32x16 (&acc)[RY][RX], const uint32_t (&ya)[4], const uint32_t (&xa)[4],
                                              uint32_t so) {
   FragSet<RY, RX> f0, f1;
-#ifdef OSUD_GEMM_EXP
+  if constexpr (SB == 64) {  // half slab: two sub-steps (bf16 / f32) or one K = 64 instruction (fp8)
+    read_set<RY, RX, SB>(f0, ya[0] + so, xa[0] + so);
+    read_set<RY, RX, SB>(f1, ya[1] + so, xa[1] + so);
+    if constexpr (sizeof(TE) == 1) {
+      wait_lgkm<0>();
+#pragma unroll
+      for (int i = 0; i < RY; ++i)
+#pragma unroll
+        for (int j = 0; j < RX; ++j) mma_f8(acc[i][j], f0.x[j], f1.x[j], f0.y[i], f1.y[i]);
+    } else {
+      wait_lgkm<RY + RX>();
+      mma_set<TE, RY, RX>(acc, f0);
+      wait_lgkm<0>();
+      mma_set<TE, RY, RX>(acc, f1);
+    }
+    return;
+  }
+#ifdef OSUD_EXP_MODE
+  constexpr int g_exp_flags = OSUD_EXP_MODE;
   if (sizeof(TE) == 2 && (g_exp_flags & 512)) return;  // LDS-DMA only
   if (sizeof(TE) == 2 && (g_exp_flags & (64 | 256))) {
     if (g_exp_flags & 64) {  // reads only
@@ -155,18 +172,25 @@ __device__ __forceinline__ void compute_slab(f32x16 (&acc)[RY][RX], const uint32
 
 // Tile geometry: WY x WX waves, each wave (RY*32) x (RX*32) outputs: BM = WY*RY*32 rows of Y, BN = WX*RX*32 rows of X.
 // A stage holds one K slab of both operands as ONE (BM+BN)-row x 128-byte image.
-template <int WY, int WX, int RY, int RX> struct Geo {
+// SB = bytes of K per stage row.  128: the classic form (two 64 KiB stages for the 256-wide tiles: ONE slab in flight while one is
+// consumed).  64: half slabs in a ring of four with the epilogue patches in their own 32 KiB behind the ring -- three half slabs
+// in flight, because the component experiments (tools/gemm_exp.py) showed the LDS-DMA fill of a 64 KiB slab to take ~2800 cycles
+// issue-to-landed against 2048 cycles of MFMA work on it: with one slab of lead the fill IS the critical path.
+template <int WY, int WX, int RY, int RX, int SB = SLAB> struct Geo {
   static constexpr int BM = WY * RY * 32, BN = WX * RX * 32, NW = WY * WX, NT = 64 * NW;
-  static constexpr int STAGE = (BM + BN) * SLAB;
+  static constexpr int STAGE = (BM + BN) * SB;
+  static constexpr int RPP = 1024 / SB;        // rows per 1 KiB LDS-DMA piece
+  static constexpr bool PATCH_OUT = SB == 64;  // epilogue patches outside the ring
   // One persistent workgroup per CU owns all 160 KiB.  (Tried and dropped: two 4-wave workgroups per CU on 128x192 tiles so that
   // one's epilogue runs under the other's main loop, 25-45 % slower; four waves of 128x128 with one wave per SIMD and 512
   // registers, 20-60 % slower under hipcc's scheduling.)
   static constexpr int WGS = 1;
   static constexpr int LDS_MAX = 160 * 1024 / WGS;
-  static constexpr int NSTAGE = STAGE * 5 <= LDS_MAX ? 5 : (STAGE * 4 <= LDS_MAX ? 4 : (STAGE * 3 <= LDS_MAX ? 3 : 2));
-  static constexpr int PIECES = (BM + BN) / 8, PPW = PIECES / NW;  // 1 KiB LDS-DMA pieces per slab, per wave
-  static_assert(PIECES % NW == 0, "pieces must divide evenly over the waves");
-  static_assert(NSTAGE * STAGE <= LDS_MAX && NW * 4096 <= STAGE, "stage ring must fit the LDS; the epilogue patches live in one stage");
+  static constexpr int RING_MAX = PATCH_OUT ? LDS_MAX - NW * 4096 : LDS_MAX;
+  static constexpr int NSTAGE = STAGE * 5 <= RING_MAX ? 5 : (STAGE * 4 <= RING_MAX ? 4 : (STAGE * 3 <= RING_MAX ? 3 : 2));
+  static constexpr int PIECES = STAGE / 1024, PPW = PIECES / NW;  // 1 KiB LDS-DMA pieces per slab, per wave
+  static_assert(PIECES % NW == 0 && BM % RPP == 0, "pieces must divide evenly over the waves and not straddle the operands");
+  static_assert(NSTAGE * STAGE <= RING_MAX && (PATCH_OUT || NW * 4096 <= STAGE), "stage ring must fit the LDS; the epilogue patches live in one stage or behind the ring");
 };
 
 // HBM -> LDS: this wave's share of one K slab (PPW pieces of 8 rows x 128 bytes).  The 16-byte chunk index
@@ -177,14 +201,14 @@ template <int WY, int WX, int RY, int RX> struct Geo {
 template <typename G>
 __device__ __forceinline__ void stage_slab(const char* gy, const char* gx, uint32_t stage_lds, const uint32_t (&voff)[G::PPW],
                                            int wave) {
-#ifdef OSUD_GEMM_EXP
-  if (g_exp_flags & 128) return;
+#ifdef OSUD_EXP_MODE
+  if (OSUD_EXP_MODE & 128) return;
 #endif
 #pragma unroll
   for (int q = 0; q < G::PPW; ++q) {
     const int piece = wave * G::PPW + q;  // wave-uniform
-    const char* sbase = (piece * 8 < G::BM) ? gy : gx;
-    const uint32_t dst = stage_lds + (uint32_t)__builtin_amdgcn_readfirstlane(piece * 8 * SLAB);
+    const char* sbase = (piece * G::RPP < G::BM) ? gy : gx;
+    const uint32_t dst = stage_lds + (uint32_t)__builtin_amdgcn_readfirstlane(piece * 1024);
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff[q]), "s"(sbase), "s"(dst) : "memory");
   }
 }
@@ -216,6 +240,7 @@ struct TileMap {
 
 template <int N> __device__ __forceinline__ void wait_vm() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
   else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
   else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
@@ -230,9 +255,10 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 
 // ROLES (8-wave geometries, static tile schedule): the two waves of every SIMD alternate between feeding the matrix pipe and
 // issuing the LDS-DMA of the next slab instead of doing both in lock step -- see the main loop.
-template <typename TE, int EPI, int WY, int WX, int RY, int RX, bool ROLES>
-__global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p) {
-  using G = Geo<WY, WX, RY, RX>;
+template <typename TE, int EPI, int WY, int WX, int RY, int RX, bool ROLES, int SB = SLAB>
+__global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(GemmP p) {
+  using G = Geo<WY, WX, RY, RX, SB>;
+  static_assert(!ROLES || SB == SLAB, "the role split is built on the two-stage 128-byte form");
   constexpr int BN = G::BN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool FAST = sizeof(TE) <= 2;
@@ -245,15 +271,15 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
   const int frow = lane & 31, fhalf = lane >> 5;
 
   const int ntx = p.Nx / BN, ntiles = (p.My / G::BM) * ntx;
-  int nk = (int)((size_t)p.K * sizeof(TE) / SLAB);
+  int nk = (int)((size_t)p.K * sizeof(TE) / SB);
   const size_t ldy_b = (size_t)p.ldy * sizeof(TE), ldx_b = (size_t)p.ldx * sizeof(TE);
   const char* gy0 = reinterpret_cast<const char*>(p.Y);
   const char* gx0 = reinterpret_cast<const char*>(p.X);
   if (p.split_k > 1) {  // this workgroup's share of the contraction (ranges differ by at most one slab)
     const int k0 = (int)((long)blockIdx.y * nk / p.split_k), k1 = (int)((long)(blockIdx.y + 1) * nk / p.split_k);
     nk = k1 - k0;
-    gy0 += (size_t)k0 * SLAB;
-    gx0 += (size_t)k0 * SLAB;
+    gy0 += (size_t)k0 * SB;
+    gx0 += (size_t)k0 * SB;
     p.out = reinterpret_cast<char*>(p.out) + (size_t)blockIdx.y * p.split_stride * (EPI == EPI_NONE_F32 ? 4 : sizeof(TE));
   }
   // Persistent workgroups: gridDim.x <= #CUs.  Blocks are dispatched round-robin over the 8 XCDs (b % 8);
@@ -276,23 +302,24 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
     if (p.tile_order == 4) ty = tx = 0;           // experiment: every workgroup streams the SAME panels (all L2 hits)
     if (p.tile_order == 5) { ty = ty % 8; tx = 0; }
 #endif
-    gy = gy0 + (size_t)ty * G::BM * ldy_b + (size_t)kt * SLAB;
-    gx = gx0 + (size_t)tx * BN * ldx_b + (size_t)kt * SLAB;
+    gy = gy0 + (size_t)ty * G::BM * ldy_b + (size_t)kt * SB;
+    gx = gx0 + (size_t)tx * BN * ldx_b + (size_t)kt * SB;
   };
 
   // per-lane LDS byte addresses of the wave's first Y/X row for the 4 k-substeps (stage 0)
   const uint32_t lds0 = (uint32_t)(size_t)(lds_void*)smem;
   uint32_t ya[4], xa[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const uint32_t sw = (uint32_t)(((2 * s + fhalf) ^ ((frow >> 1) & 7)) << 4);
-    ya[s] = lds0 + (wy * RY * 32 + frow) * SLAB + sw;
-    xa[s] = lds0 + (G::BM + wx * RX * 32 + frow) * SLAB + sw;
+  for (int s = 0; s < 4; ++s) {  // (SB = 64: sub-steps 0 and 1 exist; the 4 chunks of a 64-byte row are swizzled with (row>>2)&3)
+    const uint32_t sw = SB == 128 ? (uint32_t)(((2 * s + fhalf) ^ ((frow >> 1) & 7)) << 4)
+                                  : (uint32_t)((((2 * s + fhalf) & 3) ^ ((frow >> 2) & 3)) << 4);
+    ya[s] = lds0 + (wy * RY * 32 + frow) * SB + sw;
+    xa[s] = lds0 + (G::BM + wx * RX * 32 + frow) * SB + sw;
   }
 
   // epilogue patch (4 KiB per wave, inside whichever stage is free when the epilogue runs): write address per
   // register group g and read address, relative to that stage
-  const uint32_t patch = lds0 + wave * 4096;
+  const uint32_t patch = lds0 + (G::PATCH_OUT ? G::NSTAGE * G::STAGE : 0) + wave * 4096;
   uint32_t pw[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) pw[g] = patch + frow * 128 + (((2 * g + fhalf) ^ (frow & 7)) << 4);
@@ -305,9 +332,9 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
 #pragma unroll
   for (int q = 0; q < G::PPW; ++q) {
     const int piece = wave * G::PPW + q;
-    const int R = piece * 8 + (lane >> 3);
-    const int c = (lane & 7) ^ ((R >> 1) & 7);
-    dma_off[q] = (uint32_t)((piece * 8 < G::BM ? (size_t)R * ldy_b : (size_t)(R - G::BM) * ldx_b) + c * 16);
+    const int R = piece * G::RPP + (SB == 128 ? (lane >> 3) : (lane >> 2));
+    const int c = SB == 128 ? ((lane & 7) ^ ((R >> 1) & 7)) : ((lane & 3) ^ ((R >> 2) & 3));
+    dma_off[q] = (uint32_t)((piece * G::RPP < G::BM ? (size_t)R * ldy_b : (size_t)(R - G::BM) * ldx_b) + c * 16);
   }
   // ---- ROLES: who stages what.  Waves w and w + 4 share a SIMD; group 0 = waves 0-3 owns the top half of the Y rows, group 1
   // the bottom half.  Per slab: group 1 issues the pieces group 0 needs first -- Y top + all of X (the EARLY set) -- while group 0
@@ -350,10 +377,10 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
   // requested (wave 0, lane 0) at the top of tile j, has returned by the vmcnt(0) before tile j's epilogue, and is published
   // through LDS across the epilogue barrier; the ticket for the second tile is requested before the prologue, is older than
   // every LDS-DMA piece and so has returned after the first slab's wait.
-  constexpr bool kDynFits = G::NSTAGE * G::STAGE + 64 <= G::LDS_MAX;
+  constexpr bool kDynFits = G::NSTAGE * G::STAGE + (G::PATCH_OUT ? G::NW * 4096 : 0) + 64 <= G::LDS_MAX;
   const bool dyn = kDynFits && p.sched != nullptr;
   volatile __attribute__((address_space(3))) uint32_t* sched_lds =
-      reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>((lds_void*)smem) + (G::NSTAGE * G::STAGE) / 4;
+      reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>((lds_void*)smem) + (G::NSTAGE * G::STAGE + (G::PATCH_OUT ? G::NW * 4096 : 0)) / 4;
   const bool ticket_lane = dyn && wave == 0 && lane == 0;
   // One queue per XCD (16-bit fields of p.sched[0..3], two per word; [8] counts finished workgroups): ticket k of XCD x is the
   // k-th tile of the runs a static schedule would give that XCD in rounds 1, 2, ... -- undisturbed, every XCD's L2 keeps seeing
@@ -481,7 +508,14 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
       if (landed > 0) --landed;
       else if (ahead <= 0 || G::NSTAGE == 2) wait_vm<0>();
       else if (ahead == 1) wait_vm<G::PPW>();
-      else wait_vm<(G::NSTAGE > 3 ? 2 * G::PPW : 0)>();
+      else {
+        if constexpr (SB == 64 && G::NSTAGE >= 5) {
+          if (ahead == 2) wait_vm<2 * G::PPW>();
+          else wait_vm<3 * G::PPW>();
+        } else {
+          wait_vm<(G::NSTAGE > 3 ? 2 * G::PPW : 0)>();
+        }
+      }
 #ifdef OSUD_GEMM_TIMING
       const uint64_t tt1 = __builtin_readcyclecounter();
 #endif
@@ -504,7 +538,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
 #ifdef OSUD_GEMM_TIMING
       const uint64_t tt3 = __builtin_readcyclecounter();
 #endif
-      compute_slab<TE, RY, RX>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
+      compute_slab<TE, RY, RX, SB>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
 #ifdef OSUD_GEMM_TIMING
       {
         const uint64_t tt4 = __builtin_readcyclecounter();
@@ -537,7 +571,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
     tsum[6] += te1 - te0;  // drain wait before the epilogue
     tsum[7] += te2 - te1;  // epilogue barrier
 #endif
-    pso = (uint32_t)(((consumed + G::NSTAGE - 1) % G::NSTAGE) * G::STAGE);
+    pso = G::PATCH_OUT ? 0u : (uint32_t)(((consumed + G::NSTAGE - 1) % G::NSTAGE) * G::STAGE);
     }
 
 
@@ -805,20 +839,20 @@ unsigned* sched_slot() {
   return pool ? pool + 16 * (seq.fetch_add(1) % kSchedSlots) : nullptr;
 }
 
-template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(const GemmP& p_in, hipStream_t st) {
-  using G = Geo<WY, WX, RY, RX>;
+template <typename TE, int EPI, int WY, int WX, int RY, int RX, int SB = SLAB> int launch_w(const GemmP& p_in, hipStream_t st) {
+  using G = Geo<WY, WX, RY, RX, SB>;
   GemmP p = p_in;
   const size_t ring = (size_t)G::NSTAGE * G::STAGE;  // stage ring (the epilogue patches borrow the free stage)
-  constexpr bool kDynFits = G::NSTAGE * G::STAGE + 64 <= G::LDS_MAX;
-  const size_t lds = ring + (kDynFits ? 64 : 0);
+  constexpr bool kDynFits = G::NSTAGE * G::STAGE + (G::PATCH_OUT ? G::NW * 4096 : 0) + 64 <= G::LDS_MAX;
+  const size_t lds = ring + (G::PATCH_OUT ? (size_t)G::NW * 4096 : 0) + (kDynFits ? 64 : 0);
   // the role-split main loop: 8-wave geometries with two stages (the 64 KiB-per-stage tiles), piece sets divisible by 4 waves
-  constexpr bool kRolesOk = G::NW == 8 && G::NSTAGE == 2 && (G::BM / 16 + G::BN / 8) % 4 == 0 && (G::BM / 16) % 4 == 0;
+  constexpr bool kRolesOk = SB == SLAB && G::NW == 8 && G::NSTAGE == 2 && (G::BM / 16 + G::BN / 8) % 4 == 0 && (G::BM / 16) % 4 == 0;
   static bool attr_set = false;
   if (!attr_set) {
-    OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX, false>),
+    OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX, false, SB>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if constexpr (kRolesOk)
-      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX, true>),
+      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX, true, SB>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
@@ -831,7 +865,7 @@ template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(con
     static const bool dyn_env = [] { const char* e = getenv("OSUD_GEMM_DYNAMIC"); return e && e[0] == '1'; }();
     const int dyn_set = g_dynamic_tiles.load(std::memory_order_relaxed);
     const bool dyn_on = dyn_set >= 0 ? dyn_set != 0 : dyn_env;
-    const int nk = (int)((size_t)p.K * sizeof(TE) / SLAB);
+    const int nk = (int)((size_t)p.K * sizeof(TE) / SB);
     p.sched = (dyn_on && kDynFits && splits == 1 && ntiles > grid && grid % 8 == 0 && nk >= G::NSTAGE && ntiles / 8 + 2 * grid < 60000) ? sched_slot() : nullptr;
   }
   // OSUD_GEMM_ROLES=1 selects the role-split main loop.  Built, bit-identical results, and measured EQUAL to the lock-step loop
@@ -841,12 +875,12 @@ template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(con
   static const bool roles_env = [] { const char* e = getenv("OSUD_GEMM_ROLES"); return e && e[0] == '1'; }();
   if constexpr (kRolesOk) {
     if (roles_env && p.sched == nullptr) {  // (the tile queues of shared-GPU mode keep the lock-step loop)
-      hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY, RX, true>), dim3(grid, splits), dim3(G::NT), lds, st, p);
+      hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY, RX, true, SB>), dim3(grid, splits), dim3(G::NT), lds, st, p);
       OSUD_HIP(hipGetLastError());
       return OSUD_OK;
     }
   }
-  hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY, RX, false>), dim3(grid, splits), dim3(G::NT), lds, st, p);
+  hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY, RX, false, SB>), dim3(grid, splits), dim3(G::NT), lds, st, p);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }
@@ -885,6 +919,10 @@ template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
     else if (f == "192y" && e[3] > 0) pick = 3;
     else if (f == "256x128" && p.My % 256 == 0) pick = 7;  // experiment: three 48 KiB stages instead of two 64 KiB ones
     else if (f == "128x256" && p.Nx % 256 == 0) pick = 8;
+  }
+  {  // half slabs + deeper ring for the 256x256 geometry (OSUD_GEMM_SLAB=128 selects the two-stage form for A/B runs)
+    static const bool half_slabs = [] { const char* e = getenv("OSUD_GEMM_SLAB"); return e && atoi(e) == 64; }();
+    if (pick == 2 && half_slabs) return launch_w<TE, EPI, 2, 4, 4, 2, 64>(p, st);
   }
   if (pick == 2) return launch_w<TE, EPI, 2, 4, 4, 2>(p, st);
   if (pick == 1) return launch_w<TE, EPI, 4, 2, 2, 3>(p, st);
@@ -933,13 +971,7 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
     if (order) p.tile_order = order;
     static const int delay = [] { const char* e = getenv("OSUD_GEMM_DELAY"); return e ? atoi(e) : 0; }();
     p.exp_delay = delay;
-#ifdef OSUD_GEMM_EXP
-    static const bool flags_set = [] {
-      const int v = order;
-      return hipMemcpyToSymbol(HIP_SYMBOL(g_exp_flags), &v, sizeof(int)) == hipSuccess;
-    }();
-    (void)flags_set;
-#endif
+
   }
   const int esz = (int)elem_size(prec);
   OSUD_CHECK_ARG(p.My > 0 && p.Nx > 0 && p.K > 0 && p.My % 128 == 0 && p.Nx % 128 == 0 && (p.K * esz) % SLAB == 0,

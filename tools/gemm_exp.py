@@ -13,9 +13,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 VARIANTS = [("baseline", {}), ("no stores", {"OSUD_GEMM_ORDER": "16"}), ("stores, no math", {"OSUD_GEMM_ORDER": "32"}),
-            ("reads, no MFMA", {"OSUD_GEMM_ORDER": "64"}), ("no LDS-DMA", {"OSUD_GEMM_ORDER": "128"}),
-            ("MFMA only (no reads)", {"OSUD_GEMM_ORDER": "256"}), ("MFMA only, no DMA", {"OSUD_GEMM_ORDER": "384"}),
-            ("DMA only", {"OSUD_GEMM_ORDER": "512"}),
+            ("reads, no MFMA", {"OSUD_LIB": "ab/libosud_exp64.so"}), ("no LDS-DMA", {"OSUD_LIB": "ab/libosud_exp128.so"}),
+            ("MFMA only (no reads)", {"OSUD_LIB": "ab/libosud_exp256.so"}), ("MFMA only, no DMA", {"OSUD_LIB": "ab/libosud_exp384.so"}),
+            ("DMA only", {"OSUD_LIB": "ab/libosud_exp512.so"}),
             ("zero operands", {"OSUD_EXP_ZERO": "1"})]
 
 
