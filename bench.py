@@ -134,9 +134,9 @@ def gemm_roofline(M, N, K, dev, iters=50):
     flops = 2.0 * M * N * K
     traffic, src = None, None
     try:  # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (not measurable in-process)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fc1.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_fc1.json")))
         traffic = pmc[f"M={M}"]["hbm_bytes_per_launch"]
-        src = "profiles/r01_pmc_fc1.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2 per the gfx950 note)"
+        src = "profiles/r02_pmc_fc1.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2 per the gfx950 note)"
     except Exception:
         pass
     return {"bound": "mfma", "kernel": "gemm_kernel<bf16, EPI_BIAS_GELU_TE> (fc1 %dx%dx%d)" % (M, N, K),
