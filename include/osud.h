@@ -98,6 +98,13 @@ int osud_dit_forward(osud_dit* m, const float* x, const int64_t* t, const float*
                      const int64_t* y, const uint8_t* attn_mask, int N, int T, float cfg_scale, float* out,
                      osud_stream stream);
 
+/* fp8 tier, inference: measure the activation scales of the e4m3 GEMM operands on a representative batch instead of using the
+ * built-in constants (no reference counterpart: the reference has no fp8 path).  Same arguments as osud_dit_forward; the forward
+ * runs in bf16 arithmetic and records, per block, the amax of the LayerNorm, attention and GELU outputs; scale = 448 / (2 amax).
+ * accumulate != 0: keep the maximum over this and earlier calls (e.g. a few timesteps of the schedule). */
+int osud_dit_calibrate_fp8(osud_dit* m, const float* x, const int64_t* t, const float* o, const float* c, const int64_t* y,
+                           const uint8_t* attn_mask, int N, int T, float cfg_scale, int accumulate, osud_stream stream);
+
 /* ------------------------------------------------------------------ diffusion schedule */
 /* `betas` are the BASE process's betas (fp64, n_base of them); `use_timesteps` the sorted kept
  * indices (n_use).  Re-derives the spaced betas and every fp64 table exactly as

@@ -45,6 +45,7 @@ _SIGNATURES = {
     "osud_dit_missing_params": (_i, [_vp]),
     "osud_dit_reserve": (_i, [_vp, _i, _i, _i]),
     "osud_dit_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _vp, _vp]),
+    "osud_dit_calibrate_fp8": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp]),
     "osud_sched_create": (_i, [C.POINTER(C.c_double), _i, C.POINTER(C.c_int64), _i, C.POINTER(_vp)]),
     "osud_sched_destroy": (None, [_vp]),
     "osud_sched_num_timesteps": (_i, [_vp]),

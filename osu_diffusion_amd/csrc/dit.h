@@ -110,6 +110,11 @@ struct osud_dit {
   // dqkv), each with a slot {scale in use, 1/scale, amax seen this step, -}; e4m3 staging buffers [Mp][D] and [Mp][4D]
   float* f8_slots = nullptr;
   void *q8a = nullptr, *q8b = nullptr;
+  // fp8 INFERENCE: per-block activation scales {LN1 out, attention out, LN2 out, GELU out}; defaults are the static constants, 
+  // osud_dit_calibrate_fp8 replaces them by 448 / (2 * amax) measured on the caller's batch
+  std::vector<float> f8_inf;
+  bool f8_calibrating = false;
+  float* f8_cal_slots = nullptr;  // [L][4] slots (device), used during calibration only
   int f8_steps = 0;  // training forwards so far: the first one runs its GEMMs in bf16 and only records the amax history
   void *e0 = nullptr, *u = nullptr, *qk = nullptr /* [Mp][3D] q|k|v */, *ao = nullptr, *g = nullptr;
   float *h = nullptr, *tvec = nullptr, *bvec = nullptr, *ada = nullptr, *out_ws = nullptr;

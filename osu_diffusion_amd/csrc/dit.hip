@@ -158,6 +158,16 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
   const bool f8_live = f8_train && m->f8_steps > 0;
   if (f8_train) OSUD_TRY(launch_f8_update(m->f8_slots, m->L * 6, st));
   auto slot = [&](int l, int which) { return m->f8_slots + ((size_t)l * 6 + which) * 4; };
+  // fp8 inference: per-block activation scales (static defaults, or calibrated: osud_dit_calibrate_fp8)
+  if (m->fp8 && m->f8_inf.empty()) {
+    m->f8_inf.resize((size_t)m->L * 4);
+    for (int l = 0; l < m->L; ++l) {
+      m->f8_inf[(size_t)l * 4 + 0] = kF8ScaleLN; m->f8_inf[(size_t)l * 4 + 1] = kF8ScaleAttn;
+      m->f8_inf[(size_t)l * 4 + 2] = kF8ScaleLN; m->f8_inf[(size_t)l * 4 + 3] = kF8ScaleGelu;
+    }
+  }
+  const bool cal = m->fp8 && m->f8_calibrating && !save;  // calibration forward: bf16 arithmetic, amax of the four tensors recorded
+  auto cslot = [&](int l, int which) { return m->f8_cal_slots + ((size_t)l * 4 + which) * 4; };
 
   const int D = m->D, L = m->L, Tp = round_up(T, 64), M = N * Tp, Mp = round_up(M, 128), Np = round_up(N, 128);
   const int prec = m->prec, AC = m->ada_cols;
@@ -198,10 +208,11 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
     float* h_mid = sv ? sv->h_mid : h;
     const int base = l * 6 * D;
     const int qcols = 3 * D;
-    if (!sv && m->fp8) {
-      OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base, base + D, m->u8, nullptr, Mp, Tp, N, D, st, nullptr, 0, nullptr, kF8ScaleLN));
-      OSUD_TRY(gemm8(m, EPI_BIAS_TE, m->u8, w.w8_qkv, Mp, qcols, D, qk, qcols, w.b_qkv, w.dq_qkv, 0.f, st, nullptr, 0, 0, 0, 1.0f / kF8ScaleLN));
-      OSUD_TRY(launch_attention(prec, qk, qcols, mask, m->ao8, nullptr, N, T, Tp, Mp, m->H, m->hd, st, m->kb_class, kF8ScaleAttn));
+    const float *fs = m->fp8 ? &m->f8_inf[(size_t)l * 4] : nullptr;  // this block's {LN1, attention, LN2, GELU} output scales
+    if (!sv && m->fp8 && !cal) {
+      OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base, base + D, m->u8, nullptr, Mp, Tp, N, D, st, nullptr, 0, nullptr, fs[0]));
+      OSUD_TRY(gemm8(m, EPI_BIAS_TE, m->u8, w.w8_qkv, Mp, qcols, D, qk, qcols, w.b_qkv, w.dq_qkv, 0.f, st, nullptr, 0, 0, 0, 1.0f / fs[0]));
+      OSUD_TRY(launch_attention(prec, qk, qcols, mask, m->ao8, nullptr, N, T, Tp, Mp, m->H, m->hd, st, m->kb_class, fs[1]));
     } else {
       OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base, base + D, u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st, pend,
                              pend_gate, pend ? h_in : nullptr));
@@ -212,20 +223,27 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
       else
       OSUD_TRY(gemm(m, EPI_BIAS_TE, u1, D, w.w_qkv, D, Mp, qcols, D, qk, qcols, w.b_qkv, st));
       OSUD_TRY(launch_attention(prec, qk, qcols, mask, ao, sv ? sv->lse : nullptr, N, T, Tp, Mp, m->H, m->hd, st, m->kb_class));
+      if (cal) {
+        OSUD_TRY(launch_f8_quantize(u1, nullptr, (size_t)Mp * D, cslot(l, 0), st));
+        OSUD_TRY(launch_f8_quantize(ao, nullptr, (size_t)Mp * D, cslot(l, 1), st));
+      }
     }
-    if (!sv && m->fp8) {
+    if (!sv && m->fp8 && !cal) {
       // the four big GEMMs of the block on e4m3 operands (this block's LN1 / qkv / attention were emitted above in fp8 form)
-      OSUD_TRY(gemm8(m, EPI_GATE_RES, m->ao8, w.w8_o, Mp, D, D, h, D, w.b_o, w.dq_o, 0.f, st, m->ada + base + 2 * D, AC, Tp, N, 1.0f / kF8ScaleAttn));
-      OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base + 3 * D, base + 4 * D, m->u8, nullptr, Mp, Tp, N, D, st, nullptr, 0, nullptr,
-                             kF8ScaleLN));
-      OSUD_TRY(gemm8(m, EPI_BIAS_GELU_TE, m->u8, w.w8_1, Mp, 4 * D, D, m->g8, 4 * D, w.b1, w.dq_1, kF8ScaleGelu, st, nullptr, 0, 0, 0, 1.0f / kF8ScaleLN));
-      OSUD_TRY(gemm8(m, EPI_GATE_RES, m->g8, w.w8_2, Mp, D, 4 * D, h, D, w.b2, w.dq_2, 0.f, st, m->ada + base + 5 * D, AC, Tp, N, 1.0f / kF8ScaleGelu));
+      OSUD_TRY(gemm8(m, EPI_GATE_RES, m->ao8, w.w8_o, Mp, D, D, h, D, w.b_o, w.dq_o, 0.f, st, m->ada + base + 2 * D, AC, Tp, N, 1.0f / fs[1]));
+      OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base + 3 * D, base + 4 * D, m->u8, nullptr, Mp, Tp, N, D, st, nullptr, 0, nullptr, fs[2]));
+      OSUD_TRY(gemm8(m, EPI_BIAS_GELU_TE, m->u8, w.w8_1, Mp, 4 * D, D, m->g8, 4 * D, w.b1, w.dq_1, fs[3], st, nullptr, 0, 0, 0, 1.0f / fs[2]));
+      OSUD_TRY(gemm8(m, EPI_GATE_RES, m->g8, w.w8_2, Mp, D, 4 * D, h, D, w.b2, w.dq_2, 0.f, st, m->ada + base + 5 * D, AC, Tp, N, 1.0f / fs[3]));
       continue;
     }
     if (!sv) {
       OSUD_TRY(gemm(m, EPI_GATE_RES, ao, D, w.w_o, D, Mp, D, D, h, D, w.b_o, st, m->ada + base + 2 * D, AC, Tp, N));
       OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base + 3 * D, base + 4 * D, u2, nullptr, Mp, Tp, N, D, st));
       OSUD_TRY(gemm(m, EPI_BIAS_GELU_TE, u2, D, w.w1, D, Mp, 4 * D, D, g, 4 * D, w.b1, st));
+      if (cal) {
+        OSUD_TRY(launch_f8_quantize(u2, nullptr, (size_t)Mp * D, cslot(l, 2), st));
+        OSUD_TRY(launch_f8_quantize(g, nullptr, (size_t)Mp * 4 * D, cslot(l, 3), st));
+      }
       OSUD_TRY(gemm(m, EPI_GATE_RES, g, 4 * D, w.w2, 4 * D, Mp, D, 4 * D, h, D, w.b2, st, m->ada + base + 5 * D, AC, Tp, N));
       continue;
     }
@@ -554,6 +572,42 @@ extern "C" int osud_sample_loop_inpaint(osud_dit* m, const osud_sched* s, int mo
     m->graph_valid = true;
   }
   for (int k = 0; k < n_steps; ++k) OSUD_HIP(hipGraphLaunch(m->graph_exec, st));
+  return OSUD_OK;
+}
+
+// fp8 inference tier: replace the static activation scales by ones measured on the caller's batch.  Runs one forward in bf16
+// arithmetic recording the amax of every block's LayerNorm / attention / GELU outputs; scale = 448 / (2 * amax).  `accumulate`
+// != 0 keeps the running maximum of earlier calls (several timesteps); the scales take effect at once (cached graphs are dropped).
+extern "C" int osud_dit_calibrate_fp8(osud_dit* m, const float* x, const int64_t* t, const float* o, const float* c, const int64_t* y,
+                                      const uint8_t* attn_mask, int N, int T, float cfg_scale, int accumulate, osud_stream stream) {
+  OSUD_CHECK_ARG(m && m->fp8, "calibrate_fp8: the handle is not an fp8-tier model");
+  OSUD_CHECK_ARG(!m->training, "calibrate_fp8: inference handles only (fp8 training scales follow their own amax history)");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nslots = (size_t)m->L * 4;
+  if (!m->f8_cal_slots) OSUD_TRY(dev_alloc(m->owned, &m->f8_cal_slots, nslots * 4 * sizeof(float)));
+  std::vector<float> host(nslots * 4, 0.f);
+  if (accumulate) OSUD_HIP(hipMemcpy(host.data(), m->f8_cal_slots, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < nslots; ++i) {
+    host[4 * i] = host[4 * i + 1] = 1.0f;
+    if (!accumulate) host[4 * i + 2] = 0.f;
+  }
+  OSUD_HIP(hipMemcpyAsync(m->f8_cal_slots, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, st));
+  OSUD_HIP(hipStreamSynchronize(st));  // `host` goes out of scope / is reused below
+  float* scratch = nullptr;  // the forward's (N, C2, T) output: not needed
+  OSUD_HIP(hipMalloc(&scratch, (size_t)N * m->C2 * T * sizeof(float)));
+  m->f8_calibrating = true;
+  const int rc = dit_forward_impl(m, x, t, o, c, y, attn_mask, N, T, cfg_scale, true, scratch, false, st);
+  m->f8_calibrating = false;
+  hipError_t e = hipStreamSynchronize(st);
+  (void)hipFree(scratch);
+  if (rc != OSUD_OK) return rc;
+  OSUD_HIP(e);
+  OSUD_HIP(hipMemcpy(host.data(), m->f8_cal_slots, host.size() * sizeof(float), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < nslots; ++i) {
+    const float amax = host[4 * i + 2];
+    if (amax > 0.f && amax < 3.0e38f) m->f8_inf[i] = 448.0f / (2.0f * amax);
+  }
+  m->graph_valid = false;  // the scales are launch arguments of the captured kernels
   return OSUD_OK;
 }
 

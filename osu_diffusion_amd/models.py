@@ -215,6 +215,20 @@ class DiT(nn.Module):
         with torch.cuda.device(self._device()):
             _lib.check(_lib.lib().osud_dit_reserve(h, int(max_batch), int(max_seq_len), int(training)))
 
+    def calibrate_fp8(self, x, t, o, c, y, cfg_scale=None, attn_mask=None, accumulate=False):
+        """fp8 tier, inference: measure the e4m3 activation scales on this batch (bf16 forward recording each block's LayerNorm /
+        attention / GELU output amax; scale = 448 / (2 amax)) instead of the built-in constants.  Call it on a few timesteps with
+        `accumulate=True` after the first to cover the schedule.  No effect on the other tiers' arithmetic."""
+        if self.precision != "fp8":
+            raise ValueError("calibrate_fp8 applies to precision='fp8' models")
+        N, T = self._check_inputs(x, t, o, c, y, attn_mask)
+        h = self.native_handle()
+        x, t, o, c, y, m = self._prep(x, t, o, c, y, attn_mask)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().osud_dit_calibrate_fp8(h, _lib.ptr(x), _lib.ptr(t), _lib.ptr(o), _lib.ptr(c), _lib.ptr(y), _lib.ptr(m), N, T,
+                                                         float(-1.0 if cfg_scale is None else cfg_scale), int(bool(accumulate)),
+                                                         _lib.stream_ptr(x.device)))
+
     # ------------------------------------------------------------------ forward
     def _check_inputs(self, x, t, o, c, y, attn_mask):
         assert x.dim() == 3 and x.shape[1] == self.in_channels, f"x must be (N, {self.in_channels}, T), got {tuple(x.shape)}"

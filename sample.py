@@ -135,6 +135,11 @@ def main(args):
     y = torch.cat([y, torch.tensor([args.num_classes] * n, device=device)], 0)
     model_kwargs = dict(o=o, c=c, y=y, cfg_scale=args.cfg_scale, attn_mask=attn_mask)
 
+    if args.precision == "fp8" and n:  # e4m3 activation scales measured on this beatmap (first, middle and last timestep of the run)
+        for k, step in enumerate((diffusion.num_timesteps - 1, diffusion.num_timesteps // 2, 0)):
+            t_cal = torch.full((2 * n,), int(diffusion._model_timestep_map[step]), device=device)
+            model.calibrate_fp8(z, t_cal, o, c, y, cfg_scale=args.cfg_scale, attn_mask=attn_mask, accumulate=k > 0)
+
     def to_seq(samples):  # normalised positions + the source's time / type rows (sample.py:110-112)
         samples, _ = samples.chunk(2, dim=0)
         samples = gather_rows(samples, n_all, rank, world)  # rank 0: all variants in order; other ranks: None

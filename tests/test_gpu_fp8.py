@@ -45,6 +45,28 @@ def test_fp8_forward_stays_close_to_the_fp32_oracle(hidden, heads, T_):
     assert errs["bf16"] < 3e-3 * scale, (errs, scale)         # the bf16 tier (split first linear) sits an order of magnitude below
 
 
+def test_fp8_inference_scales_can_be_calibrated_from_data():
+    """osud_dit_calibrate_fp8: activation scales measured on the batch (448 / (2 amax) per block and tensor) instead of the
+    static constants.  Weights with 8x larger modulation / MLP outputs than the defaults push GELU outputs towards the static
+    scale's saturation point (448 / 8 = 56); the calibrated model must be at least as close to the fp32 oracle as the static one
+    and stay finite; on ordinary weights calibration must not hurt."""
+    for gain, mod_std in ((1.0, 0.02), (3.0, 0.3)):
+        shape = mo.DitShape(depth=3, hidden=384, heads=6, num_classes=10)
+        sd = mo.seeded_state_dict(shape, 78, gain=gain, mod_std=mod_std)
+        (x, o, c), y = synthetic_windows(4, 128, 10, seed=6)
+        t = torch.tensor([999, 500, 30, 0])
+        ref = mo.forward(sd, shape, x, t, o, c, y)
+        args = [v.to(DEV) for v in (x, t, o, c, y)]
+        m = build(shape, sd, "fp8")
+        with torch.no_grad():
+            static = m(*args).cpu()
+            m.calibrate_fp8(*args)
+            calibrated = m(*args).cpu()
+        e_s, e_c = float((static - ref).pow(2).mean().sqrt()), float((calibrated - ref).pow(2).mean().sqrt())
+        print(f"gain {gain}: rms deviation from the fp32 oracle (rms {float(ref.pow(2).mean().sqrt()):.3f}): static scales {e_s:.3e}, calibrated {e_c:.3e}")
+        assert torch.isfinite(calibrated).all() and e_c <= 1.25 * e_s + 1e-6
+
+
 def test_fp8_cfg_sampling_loop_tracks_the_bf16_tier():
     """A short CFG-4 ancestral loop with identical start and per-step noise in the bf16 and fp8 tiers (well-posed weights,
     see oracle.dit_oracle.seeded_state_dict): the final coordinates stay together."""
