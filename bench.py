@@ -574,6 +574,11 @@ def main():
                                                 "roofline", "cpu_baseline") if k in samp}
         if world == 1 and args.precision == "bf16" and not args.no_parity_tier:
             res["parity_tier"], res["bf16_drift"] = parity_tier_and_drift(args, dev)
+            # the fp8 inference tier on the same sampling workload (reduced precision: 0.7 % rms from the fp32 oracle, tests/test_gpu_fp8.py)
+            fargs = argparse.Namespace(**vars(args))
+            fargs.precision, fargs.steps, fargs.warmup, fargs.no_roofline, fargs.no_cpu_baseline = "fp8", 300, 30, True, True
+            f8 = bench_sample(fargs, world, rank, dev)
+            res["sampling"]["fp8_tier"] = {"value": f8["value"], "unit": "steps/s", "ms_per_step": f8["ms_per_step"], "steps": f8["steps"], "dtype": f8["dtype"]}
         if not args.no_xl and args.precision == "bf16":
             res["xl"] = {p: bench_xl(args, world, rank, dev, p) for p in ([args.xl_precision] if args.xl_precision else XL_TIERS)}
     if rank == 0:
