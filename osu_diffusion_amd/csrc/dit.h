@@ -163,12 +163,14 @@ inline int gemm(osud_dit* m, int epi, const void* Y, int ldy, const void* X, int
 inline int gemm8(osud_dit* m, int epi, const void* Y, const void* X, int My, int Nx, int K, void* out, int ldo, const float* bias,
                  const float* dequant, float out_scale, hipStream_t st, const float* gate = nullptr, int ld_gate = 0, int Tp = 0,
                  int N = 0, float act_inv_host = 0.f, const float* act_inv_dev = nullptr, void* out2 = nullptr,
-                 const void* aux = nullptr, float* colpart = nullptr, int* colpart_rows = nullptr) {
+                 const void* aux = nullptr, float* colpart = nullptr, int* colpart_rows = nullptr, void* out8 = nullptr,
+                 float* out8_slot = nullptr) {
   GemmP p{};
   p.Y = Y; p.X = X; p.ldy = K; p.ldx = K; p.My = My; p.Nx = Nx; p.K = K;
   p.out = out; p.ldo = ldo; p.bias = bias; p.gate = gate; p.ld_gate = ld_gate;
   p.rows_per_sample = Tp; p.n_samples = N; p.colscale = dequant; p.out_scale = out_scale;
   p.act_inv_host = act_inv_host; p.act_inv = act_inv_dev; p.out2 = out2; p.aux = aux; p.colpart = colpart; p.colpart_rows = colpart_rows;
+  p.out8 = out8; p.out8_slot = out8_slot;
   (void)m;
   return launch_gemm(OSUD_PREC_FP8, epi, p, st);
 }

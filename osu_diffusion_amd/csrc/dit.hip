@@ -252,10 +252,13 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
                            base + 2 * D, h_mid));
     if (f8_train) {
       OSUD_TRY(launch_f8_quantize(u2, f8_live ? m->q8a : nullptr, (size_t)Mp * D, slot(l, 1), st));
+      // (live steps: the fc1 epilogue writes the e4m3 twin of its GELU output and records its amax itself)
       if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_GELU_BF, m->q8a, w.w8_1, Mp, 4 * D, D, g, 4 * D, w.b1, w.dq_1, 0.f, st, nullptr, 0, 0, 0, 0.f,
-                                  slot(l, 1) + 1, sv->z1));
-      else OSUD_TRY(gemm(m, EPI_BIAS_GELU_TE, u2, D, w.w1, D, Mp, 4 * D, D, g, 4 * D, w.b1, st, nullptr, 0, 0, 0, sv->z1));
-      OSUD_TRY(launch_f8_quantize(g, f8_live ? m->q8b : nullptr, (size_t)Mp * 4 * D, slot(l, 2), st));
+                                  slot(l, 1) + 1, sv->z1, nullptr, nullptr, nullptr, m->q8b, slot(l, 2)));
+      else {
+        OSUD_TRY(gemm(m, EPI_BIAS_GELU_TE, u2, D, w.w1, D, Mp, 4 * D, D, g, 4 * D, w.b1, st, nullptr, 0, 0, 0, sv->z1));
+        OSUD_TRY(launch_f8_quantize(g, nullptr, (size_t)Mp * 4 * D, slot(l, 2), st));
+      }
       if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_TE, m->q8b, w.w8_2, Mp, D, 4 * D, br2, D, w.b2, w.dq_2, 0.f, st, nullptr, 0, 0, 0, 0.f,
                                   slot(l, 2) + 1));
       else OSUD_TRY(gemm(m, EPI_BIAS_TE, g, 4 * D, w.w2, 4 * D, Mp, D, 4 * D, br2, D, w.b2, st));

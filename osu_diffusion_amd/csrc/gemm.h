@@ -54,6 +54,8 @@ struct GemmP {
                           // weight de-quantisation factors
   float act_inv_host;     // fp8 operands: host scalar multiplied into colscale (1 / a static activation scale); 0 = none
   const float* act_inv;   // fp8 operands, optional: DEVICE scalar multiplied into colscale (1 / the activation's dynamic quantisation scale)
+  void* out8;             // fp8 operands, EPI_BIAS_GELU_BF / EPI_GELUGRAD_TE, optional: e4m3 twin of `out` [My][ldo], quantised with the
+  float* out8_slot;       //   device slot {scale, 1/scale, amax}: value * slot[0], and slot[2] = max(slot[2], max|value|) (fp8 training)
   float out_scale;        // fp8 OUTPUT (EPI_BIAS_GELU_TE with fp8 operands): the value is multiplied by this before quantisation
   int split_k;       // > 1: blockIdx.y walks K in split_k equal ranges, range s writes out + s * split_stride (elements)
   size_t split_stride;

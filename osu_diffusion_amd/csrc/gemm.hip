@@ -449,6 +449,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
   }
   const bool exp_nostore = (p.tile_order & 16) != 0, exp_nomath = (p.tile_order & 32) != 0;
 #endif
+  float q_amax = 0.f;  // fp8 training: running max |value| of this lane's share of the e4m3 output
   bool first_tile = true;
   while (t_cur < ntiles) {
     int ty, tx;
@@ -631,6 +632,10 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
       t[2] = ds_read16f<2048>(pr0 + pso);   // rows 16..31
       t[3] = ds_read16f<2048>(pr1 + pso);
     };
+    // fp8 training: the e4m3 twin of a bf16 output (the operand of the NEXT fp8 GEMM) written here instead of by a separate pass
+    constexpr bool kOut8 = kF8 && (EPI == EPI_BIAS_GELU_BF || EPI == EPI_GELUGRAD_TE);
+    const bool out8_on = kOut8 && p.out8 != nullptr;
+    const float q_scale = out8_on ? p.out8_slot[0] : 1.0f;
     constexpr bool kColsum = EPI == EPI_GELUGRAD_TE;
     float cs[kColsum ? RX : 1][8];
     if (kColsum) {
@@ -732,6 +737,17 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
 #pragma unroll
             for (int e = 0; e < 8; ++e) gelu_tanh_both_t<FAST>(v[e], w[e], dg[e]);
             store8(reinterpret_cast<TO*>(p.out2) + o, dg);
+            if constexpr (kOut8) {
+              if (out8_on) {
+                float q8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  q_amax = fmaxf(q_amax, fabsf(w[e]));
+                  q8[e] = w[e] * q_scale;
+                }
+                store8(reinterpret_cast<fp8_t*>(p.out8) + o, q8);
+              }
+            }
           } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) w[e] = gelu_tanh_t<FAST>(v[e]) * ((kF8 && EPI == EPI_BIAS_GELU_TE) ? p.out_scale : 1.0f);
@@ -740,6 +756,17 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
         } else if (EPI == EPI_GELUGRAD_TE) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = v[e] * rv[q][e];
+          if constexpr (kOut8) {
+            if (out8_on) {
+              float q8[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                q_amax = fmaxf(q_amax, fabsf(w[e]));
+                q8[e] = w[e] * q_scale;
+              }
+              store8(reinterpret_cast<fp8_t*>(p.out8) + o, q8);
+            }
+          }
           if (kColsum) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) cs[j][e] += w[e];
@@ -779,6 +806,18 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
     if (ic_rel > 0) --ic_rel;
     first_tile = false;
   }  // tile loop
+  if (p.out8 != nullptr && p.out8_slot != nullptr) {  // one amax atomic per workgroup (through LDS: the ring is idle by now)
+    q_amax = wave_max(q_amax);
+    __syncthreads();
+    volatile float* red = reinterpret_cast<volatile float*>(smem);
+    if (lane == 0) red[wave] = q_amax;
+    __syncthreads();
+    if (tid == 0) {
+      float mx = 0.f;
+      for (int w2 = 0; w2 < G::NW; ++w2) mx = fmaxf(mx, red[w2]);
+      if (mx > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.out8_slot) + 2, __float_as_uint(mx));
+    }
+  }
   if (ticket_lane) {  // the last workgroup out re-arms the counters for the next launch that borrows this slot
     const unsigned done = __hip_atomic_fetch_add(p.sched + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (done == gridDim.x - 1) {

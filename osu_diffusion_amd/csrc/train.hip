@@ -227,7 +227,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
       if (f8_train) OSUD_TRY(launch_f8_quantize(w.dbr, f8_live ? m->q8a : nullptr, (size_t)Mp * D, slot(3), st));
       if (f8_live) {
         OSUD_TRY(gemm8(m, EPI_GELUGRAD_TE, m->q8a, bw.w2_t8, Mp, 4 * D, D, w.dz1, 4 * D, nullptr, bw.dq_2_t, 0.f, st, nullptr, 0, 0, 0, 0.f,
-                       slot(3) + 1, nullptr, sv.z1, fused_b1 ? w.splitk : nullptr, fused_b1 ? &part_rows : nullptr));
+                       slot(3) + 1, nullptr, sv.z1, fused_b1 ? w.splitk : nullptr, fused_b1 ? &part_rows : nullptr, m->q8b, slot(4)));
       } else {
       GemmP gp{};
       gp.Y = w.dbr; gp.X = bw.w2_t; gp.ldy = D; gp.ldx = D; gp.My = Mp; gp.Nx = 4 * D; gp.K = D;
@@ -242,7 +242,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     }
     OSUD_TRY(dbg_sync(st, "dgrad fc2 (gelu grad)"));
     // consumers of dz1 (201 MB, fresh in the Infinity Cache) first, the fc2 weight gradient (dbr, g) after them
-    if (f8_train) OSUD_TRY(launch_f8_quantize(w.dz1, f8_live ? m->q8b : nullptr, (size_t)Mp * 4 * D, slot(4), st));
+    if (f8_train && !f8_live) OSUD_TRY(launch_f8_quantize(w.dz1, nullptr, (size_t)Mp * 4 * D, slot(4), st));  // live: written by the epilogue above
     if (f8_live) OSUD_TRY(gemm8(m, EPI_NONE_TE, m->q8b, bw.w1_t8, Mp, D, 4 * D, w.du, D, nullptr, bw.dq_1_t, 0.f, st, nullptr, 0, 0, 0, 0.f,
                                 slot(4) + 1));
     else
