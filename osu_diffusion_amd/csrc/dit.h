@@ -50,6 +50,8 @@ struct BwdWs {
   float *dhA = nullptr, *dhB = nullptr, *du = nullptr, *dada = nullptr, *dWada = nullptr, *dbada = nullptr, *dsb = nullptr,
         *db = nullptr, *dth = nullptr, *dWe = nullptr, *splitk = nullptr, *attn_delta = nullptr /* [N][H][Tp] */;
   size_t splitk_elems = 0;
+  float** seg_tbl = nullptr;       // device: the per-block adaLN weight-gradient tensors (GemmP::seg_out), 32 entries
+  float* seg_tbl_host[32] = {};    // what the device table holds (uploaded again when a gradient tensor is re-bound)
   void *dbr = nullptr, *dz1 = nullptr, *dqkv = nullptr, *dao = nullptr, *tA = nullptr, *tB = nullptr, *dada_te = nullptr,
        *db_te = nullptr, *dz0 = nullptr, *small_t1 = nullptr, *small_t2 = nullptr, *sb_t = nullptr /* silu(b)^T [D][Np] */;
 };
@@ -81,6 +83,8 @@ struct osud_dit {
   void* w_t0 = nullptr; float* b_t0 = nullptr;
   void* w_t2 = nullptr; float* b_t2 = nullptr;
   float* table = nullptr;
+  const float* table_ref = nullptr;  // what the forward reads: `table`, or -- after osud_dit_refresh -- the caller's fp32 master itself
+                                     // (the class table is 162 MB at 52 670 classes: no second copy per optimizer step)
   std::vector<BlockWeights> blk;
   void* w_ada = nullptr; float* b_ada = nullptr;
   float* w_f = nullptr;  float* b_f = nullptr;

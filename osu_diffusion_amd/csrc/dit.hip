@@ -122,6 +122,8 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
     b.splitk_elems = (size_t)16 * 4 * D * D;  // up to 16 partial slabs of the largest weight gradient
     OSUD_TRY(dev_alloc(W, &b.splitk, b.splitk_elems * 4, false));
     OSUD_TRY(dev_alloc(W, &b.attn_delta, (size_t)nN * m->H * Tp * 4));
+    OSUD_TRY(dev_alloc(W, &b.seg_tbl, 32 * sizeof(float*)));
+    for (float*& q : b.seg_tbl_host) q = nullptr;
   }
   m->cap_N = nN; m->cap_T = nT; m->cap_Tp = Tp; m->cap_Mp = Mp; m->cap_Np = Np;
   return OSUD_OK;
@@ -184,7 +186,7 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
   OSUD_TRY(gemm(m, EPI_BIAS_SILU_TE, m->temb, 256, m->w_t0, 256, Np, D, 256, m->th, D, m->b_t0, st, nullptr, 0, 0, 0,
                 m->training ? m->z0 : nullptr));
   OSUD_TRY(gemm(m, EPI_BIAS_F32, m->th, D, m->w_t2, D, Np, D, D, m->tvec, D, m->b_t2, st));
-  OSUD_TRY(launch_cond(prec, m->tvec, m->table, y, m->cfg.table_rows, m->bvec, m->sb, N, Np, D, st));
+  OSUD_TRY(launch_cond(prec, m->tvec, m->table_ref ? m->table_ref : m->table, y, m->cfg.table_rows, m->bvec, m->sb, N, Np, D, st));
   OSUD_TRY(gemm(m, EPI_BIAS_F32, m->sb, D, m->w_ada, D, Np, AC, D, m->ada, AC, m->b_ada, st));
 
   if (mask != nullptr) OSUD_TRY(launch_mask_tiles(mask, T, Tp, m->kb_class, st));  // once per forward, shared by all blocks
@@ -440,7 +442,12 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
   } else if (k == "t_embedder.mlp.2.bias") { SHAPE(D); rc = upload_f32(m, &m->b_t2, src, D, st);
   } else if (k == "y_embedder.embedding_table.weight") {
     SHAPE(m->cfg.table_rows, D);
-    rc = upload_f32(m, &m->table, src, (size_t)m->cfg.table_rows * D, st);
+    if (m->defer_copy) {  // osud_dit_refresh: the master stays where it is (the caller keeps it alive between refreshes)
+      m->table_ref = src;
+    } else {
+      rc = upload_f32(m, &m->table, src, (size_t)m->cfg.table_rows * D, st);
+      m->table_ref = m->table;
+    }
   } else if (k == "final_layer.linear.weight") { SHAPE(m->C2, D); rc = upload_f32(m, &m->w_f, src, (size_t)m->C2 * D, st);
   } else if (k == "final_layer.linear.bias") { SHAPE(m->C2); rc = upload_f32(m, &m->b_f, src, m->C2, st);
   } else if (k == "final_layer.adaLN_modulation.1.weight") {

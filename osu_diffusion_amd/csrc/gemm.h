@@ -62,6 +62,8 @@ struct GemmP {
   float* colpart;     // EPI_GELUGRAD_TE, optional: f32 [R][Nx] partial column sums of the OUTPUT (before rounding), one row per wave-row
                       // of the grid (R = My / rows per wave, reported through colpart_rows); summed over R they are the bias gradient
   int* colpart_rows;  // host pointer, written at launch
+  int seg_rows;           // EPI_NONE_F32, optional (> 0): output row y goes to seg_out[y / seg_rows] + (y % seg_rows) * ldo instead of `out`
+  float* const* seg_out;  //   (DEVICE table) -- one product whose row panels land in different tensors: the adaLN weight gradients of all blocks
   unsigned* sched;    // set by the launcher for multi-round launches: {ticket, done} counters of the dynamic tile queue
   int exp_delay;   // experiments only (-DOSUD_GEMM_EXP): odd workgroup groups start this many 100 MHz ticks late
   int tile_order;  // 0/1 = plain x-fastest runs per XCD (default), 2 = banded per XCD (fewer weight re-reads, not faster)

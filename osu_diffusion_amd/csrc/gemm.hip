@@ -714,7 +714,10 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
           continue;
         }
 #endif
-        if (EPI == EPI_BIAS_F32 || EPI == EPI_NONE_F32) {
+        if (EPI == EPI_NONE_F32 && p.seg_rows > 0) {  // (a 32-row block never straddles two segments: seg_rows % 32 == 0)
+          const int sg = __builtin_amdgcn_readfirstlane(yb / p.seg_rows);
+          store8(p.seg_out[sg] + (size_t)(y0 + 16 * q - sg * p.seg_rows) * p.ldo + x, v);
+        } else if (EPI == EPI_BIAS_F32 || EPI == EPI_NONE_F32) {
           store8(reinterpret_cast<float*>(p.out) + o, v);
         } else if (EPI == EPI_ACCUM_F32) {
 #pragma unroll
@@ -1018,6 +1021,8 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
   OSUD_CHECK_ARG((p.ldy * esz) % 16 == 0 && (p.ldx * esz) % 16 == 0 && p.ldo % 8 == 0,
                  "gemm: leading dimensions must keep 16-byte alignment (ldy=%d ldx=%d ldo=%d)", p.ldy, p.ldx, p.ldo);
   OSUD_CHECK_ARG(p.Y && p.X && p.out, "gemm: null operand");
+  OSUD_CHECK_ARG(p.seg_rows == 0 || (epi == EPI_NONE_F32 && p.split_k <= 1 && p.seg_rows % 32 == 0 && p.seg_out != nullptr),
+                 "gemm: segmented output needs the plain f32 epilogue, no split-K and a device table of segment pointers");
   OSUD_CHECK_ARG((size_t)p.ldy * esz * 256 < (1ull << 31) && (size_t)p.ldx * esz * 256 < (1ull << 31),
                  "gemm: leading dimension too large for 32-bit panel offsets");
   if (epi == EPI_GATE_RES)

@@ -61,13 +61,13 @@ int launch_ln_mod_bwd(int prec, const float* h, const float* stats, const void* 
                       float* db_next = nullptr);
 int launch_final_bwd(const float* h, const float* stats, const float* dout, const float* w, const float* ada, int ld_ada,
                      int off_shift, int off_scale, float* dh_out, float* dada, float* dw, float* dbias, int N, int T, int Tp,
-                     int D, int C, hipStream_t st);
+                     int D, int C, hipStream_t st, float* scratch = nullptr, size_t scratch_elems = 0);
 int launch_cond_bwd(int prec, const float* dsb, const float* b, const int64_t* y, int table_rows, float* db_out,
                     void* db_te, float* dtable, int N, int Np, int D, hipStream_t st);
 int launch_silu_bwd(int prec, const float* dth, const void* z, void* dz, size_t n, hipStream_t st);
 int launch_mask_rows(int prec, float* a, void* a_te, int N, int Np, int C, hipStream_t st, int ld = 0);  // ld > C: a column slice
 int launch_unpad_rows(const float* src, int ld_src, float* dst, int cols, int rows, hipStream_t st);
-int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_t st);
+int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_t st, int split = 0, float* out2 = nullptr, int n2 = 0);
 
 // wgrad.hip (bf16 tier): transpose-free weight-gradient product and bias-gradient column sums
 int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int Nx, int M, float* out, float* ws,

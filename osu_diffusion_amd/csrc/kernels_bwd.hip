@@ -135,11 +135,64 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
 // dh_out is the gradient of the residual stream in front of this LayerNorm, i.e. exactly the input of the gate_bwd of the
 // branch that was added just before it; with br_next != nullptr that step is done here on the rows still in registers
 // (dbr, dgate, db as in gate_bwd_kernel), saving a second pass over dh.
-// Block = 64 consecutive rows of one sample, wave w takes rows w, w+4, ...  Every load of a row is issued before the
-// first reduction (one memory round trip per row: the grid is only 2 blocks per CU, so the kernel lives on per-row latency).
+#ifndef OSUD_LNB_ROWS
+#define OSUD_LNB_ROWS 64
+#endif
+#ifdef OSUD_LNB_OCCN
+#define OSUD_LNB_OCC(VPL) OSUD_LNB_OCCN
+#else
+#define OSUD_LNB_OCC(VPL) ((VPL) <= 12 ? 3 : 2)  // waves per SIMD the register allocation is held to (wider rows: 2, or it spills)
+#endif
+// W consecutive TE elements as they come from memory: bf16 stays packed (half the registers) until it is used
+template <typename TE, int W> struct RawW;
+template <int W> struct RawW<float, W> {
+  float v[W];
+  __device__ __forceinline__ void load(const float* p) { loadw<W>(p, v); }
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int e = 0; e < W; ++e) v[e] = 0.f;
+  }
+  __device__ __forceinline__ void get(float* o) const {
+#pragma unroll
+    for (int e = 0; e < W; ++e) o[e] = v[e];
+  }
+};
+template <int W> struct RawW<bf16_t, W> {
+  uint32_t u[W / 2];
+  __device__ __forceinline__ void load(const bf16_t* p) {
+    if constexpr (W == 4) {
+      const uint2 t = *reinterpret_cast<const uint2*>(p);
+      u[0] = t.x; u[1] = t.y;
+    } else {
+      u[0] = *reinterpret_cast<const uint32_t*>(p);
+    }
+  }
+  __device__ __forceinline__ void zero() {
+#pragma unroll
+    for (int e = 0; e < W / 2; ++e) u[e] = 0u;
+  }
+  __device__ __forceinline__ void get(float* o) const {
+#pragma unroll
+    for (int e = 0; e < W / 2; ++e) {
+      o[2 * e] = __uint_as_float(u[e] << 16);
+      o[2 * e + 1] = __uint_as_float(u[e] & 0xffff0000u);
+    }
+  }
+};
+
+// Block = ROWS consecutive rows of one sample, wave w takes rows w, w+4, ...; every load of a row is issued before the first
+// reduction (one memory round trip per row).  The kernel is a six-stream copy with a little arithmetic, so what matters is
+// how many rows the chip has in flight, i.e. registers per wave: the per-column constants live in LDS, bf16 rows stay
+// packed until they are used, the gate step is a template switch (no branches in the row loop) -> 168 registers and all 512
+// blocks resident at D = 768.  (The first version held two fp32 row sets and the constants in 274 registers: one wave per
+// SIMD, i.e. half of the blocks waiting for a slot -- 107 us per launch inside a training step at D = 768 and 248 us at
+// D = 1152; now 86 and 141 us, a plain device copy of the same bytes takes 84 / 127 us.  Measured and not kept: 16- or 32-row
+// blocks for more waves (the column-sum atomics grow with the block count: 103 us at 16 rows; at 32 rows 83 us but four
+// blocks per sample add in arrival order, and gradients must not depend on that), a second register set per wave
+// (equal at D = 768, spills at D = 1152), four waves per SIMD by a register cap (22 spills in the row loop, 128 us).)
 // (Tried and dropped: column sums in LDS via ds_add_f32 with 16-wave blocks -- 2.4x slower, the LDS atomics serialise.)
-template <typename TE, int VPL>
-__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict__ h, const float* __restrict__ stats,
+template <typename TE, int VPL, bool GATE>
+__global__ __launch_bounds__(256, OSUD_LNB_OCC(VPL)) void ln_mod_bwd_kernel(const float* __restrict__ h, const float* __restrict__ stats,
                                                          const TE* __restrict__ du, const float* __restrict__ ada,
                                                          int ld_ada, int off_shift, int off_scale,
                                                          const float* __restrict__ dh_skip, float* __restrict__ dh_out,
@@ -147,24 +200,24 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
                                                          int off_gate_next, TE* __restrict__ dbr, float* __restrict__ db_next) {
   // lane l owns columns W*l + 64*W*g + {0..W-1}, g < NG: 16-byte fp32 / 8-byte bf16 accesses where VPL allows (W = 4)
   constexpr int D = VPL * 64, W = (VPL % 4 == 0) ? 4 : 2, NG = VPL / W;
+  constexpr int ROWS = OSUD_LNB_ROWS;
   __shared__ float red[2][4][D];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m0 = blockIdx.x * 64, n = m0 / Tp;
+  __shared__ float cst[2][D];  // 1 + scale | gate of the next branch
+  // (the wave index as a scalar: row bases then live in SGPRs and every access is base + one per-lane offset + immediate)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int m0 = blockIdx.x * ROWS, n = m0 / Tp;
   const float* arow = ada + (size_t)n * ld_ada;
-  float scv[VPL], gv[VPL], a_sh[VPL], a_sc[VPL], a_g[VPL], a_cs[VPL];
-#pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    const int d = W * lane + 64 * W * g;
-    loadw<W>(arow + off_scale + d, scv + g * W);
-#pragma unroll
-    for (int e = 0; e < W; ++e) {
-      scv[g * W + e] += 1.0f;
-      a_sh[g * W + e] = a_sc[g * W + e] = a_g[g * W + e] = a_cs[g * W + e] = gv[g * W + e] = 0.f;
-    }
-    if (br_next != nullptr) loadw<W>(arow + off_gate_next + d, gv + g * W);
+  for (int d = threadIdx.x; d < D; d += 256) {
+    cst[0][d] = 1.0f + arow[off_scale + d];
+    cst[1][d] = GATE ? arow[off_gate_next + d] : 0.f;
   }
+  float a_sh[VPL], a_sc[VPL], a_g[VPL], a_cs[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) a_sh[i] = a_sc[i] = a_g[i] = a_cs[i] = 0.f;
+  __syncthreads();
   struct Row {
-    float hv[VPL], dv[VPL], sk[VPL], bn[VPL];
+    float hv[VPL], sk[VPL];
+    RawW<TE, W> dv[NG], bn[GATE ? NG : 1];
     float mu, rstd;
   };
   auto load_row = [&](Row& R, int m) {
@@ -173,17 +226,9 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
     for (int g = 0; g < NG; ++g) {
       const int d = W * lane + 64 * W * g;
       loadw<W>(h + row + d, R.hv + g * W);
-      loadw<W>(du + row + d, R.dv + g * W);
-      if (dh_skip != nullptr) loadw<W>(dh_skip + row + d, R.sk + g * W);
-      else {
-#pragma unroll
-        for (int e = 0; e < W; ++e) R.sk[g * W + e] = 0.f;
-      }
-      if (br_next != nullptr) loadw<W>(br_next + row + d, R.bn + g * W);
-      else {
-#pragma unroll
-        for (int e = 0; e < W; ++e) R.bn[g * W + e] = 0.f;
-      }
+      R.dv[g].load(du + row + d);
+      loadw<W>(dh_skip + row + d, R.sk + g * W);
+      if constexpr (GATE) R.bn[g].load(br_next + row + d);
     }
     R.mu = stats[2 * (size_t)m];
     R.rstd = stats[2 * (size_t)m + 1];
@@ -193,41 +238,54 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
     const float mu = R.mu, rstd = R.rstd;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < VPL; ++i) {
-      R.hv[i] = (R.hv[i] - mu) * rstd;  // xhat
-      a_sh[i] += R.dv[i];
-      a_sc[i] += R.dv[i] * R.hv[i];
-      R.dv[i] *= scv[i];  // dy
-      s1 += R.dv[i];
-      s2 += R.dv[i] * R.hv[i];
+    for (int g = 0; g < NG; ++g) {
+      const int d = W * lane + 64 * W * g;
+      float dvf[W], c[W];
+      R.dv[g].get(dvf);
+      loadw<W>(&cst[0][d], c);
+#pragma unroll
+      for (int e = 0; e < W; ++e) {
+        const int i = g * W + e;
+        const float xh = (R.hv[i] - mu) * rstd;
+        R.hv[i] = xh;
+        a_sh[i] += dvf[e];
+        a_sc[i] += dvf[e] * xh;
+        const float dy = dvf[e] * c[e];
+        s1 += dy;
+        s2 += dy * xh;
+      }
     }
     const float m1 = wave_sum(s1) * (1.0f / D), m2 = wave_sum(s2) * (1.0f / D);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int d = W * lane + 64 * W * g;
-      float o[W], b[W];
+      float o[W], b[W], dvf[W], c[W], bnf[W], gt[W];
+      R.dv[g].get(dvf);  // dy again from the packed row: cheaper than VPL live registers across the reductions
+      loadw<W>(&cst[0][d], c);
+      if constexpr (GATE) {
+        R.bn[g].get(bnf);
+        loadw<W>(&cst[1][d], gt);
+      }
 #pragma unroll
       for (int e = 0; e < W; ++e) {
         const int i = g * W + e;
-        o[e] = R.sk[i] + rstd * (R.dv[i] - m1 - R.hv[i] * m2);
-        if (br_next != nullptr) {
-          a_g[i] += o[e] * R.bn[i];
+        o[e] = R.sk[i] + rstd * (dvf[e] * c[e] - m1 - R.hv[i] * m2);
+        if constexpr (GATE) {
+          a_g[i] += o[e] * bnf[e];
           a_cs[i] += o[e];
-          b[e] = gv[i] * o[e];
+          b[e] = gt[e] * o[e];
         }
       }
       storew<W>(dh_out + row + d, o);
-      if (br_next != nullptr) storew<W>(dbr + row + d, b);
+      if constexpr (GATE) storew<W>(dbr + row + d, b);
     }
   };
-  // rows wave, wave+4, ..., two register sets: the next row's loads are in flight while this one is reduced
-  Row ra, rb;
-  load_row(ra, m0 + wave);
-  for (int r = wave; r < 64; r += 8) {
-    load_row(rb, m0 + r + 4);
-    process_row(ra, m0 + r);
-    if (r + 8 < 64) load_row(ra, m0 + r + 8);
-    process_row(rb, m0 + r + 4);
+  // rows wave, wave+4, ...: one row per wave in flight, three waves per SIMD (a second register set per wave costs a wave)
+  Row R;
+#pragma unroll 1
+  for (int i = 0; i < ROWS / 4; ++i) {
+    load_row(R, m0 + wave + 4 * i);
+    process_row(R, m0 + wave + 4 * i);
   }
 #pragma unroll
   for (int g = 0; g < NG; ++g)
@@ -243,7 +301,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
     atomicAdd(dn + off_shift + d, red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d]);
     atomicAdd(dn + off_scale + d, red[1][0][d] + red[1][1][d] + red[1][2][d] + red[1][3][d]);
   }
-  if (br_next != nullptr) {
+  if constexpr (GATE) {
     __syncthreads();
 #pragma unroll
     for (int g = 0; g < NG; ++g)
@@ -251,7 +309,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
       for (int e = 0; e < W; ++e) {
         const int d = W * lane + 64 * W * g + e;
         red[0][wave][d] = a_g[g * W + e];
-        red[1][wave][d] = gv[g * W + e] * a_cs[g * W + e];
+        red[1][wave][d] = cst[1][d] * a_cs[g * W + e];
       }
     __syncthreads();
     for (int d = threadIdx.x; d < D; d += 256) {
@@ -265,71 +323,87 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
 // Final layer backward (models.py:192-196): out[n][ch][t] = sum_d uF[m][d] Wf[ch][d] + bf[ch]
 //   duF = sum_ch dout * Wf ; dWf[ch][d] += sum_m dout * uF ; dbf[ch] += sum_m dout
 // then the same LN+modulate backward as above (dh_skip = 0), all in one pass over h.
+// Per-column constants (1 + scale, shift, the C weight rows) live in LDS, the next row's h is in flight while this one is
+// reduced, and the weight- and bias-gradient partial sums of a block go to `dw_part` [blocks][4 D + 64] (summed by a fixed-order
+// column pass: 512 blocks adding atomically into the same addresses made the result depend on arrival order, and slow).
 template <int VPL>
-__global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict__ h, const float* __restrict__ stats,
-                                                        const float* __restrict__ dout, const float* __restrict__ w,
-                                                        const float* __restrict__ ada, int ld_ada, int off_shift,
-                                                        int off_scale, float* __restrict__ dh_out,
-                                                        float* __restrict__ dada, float* __restrict__ dw,
-                                                        float* __restrict__ dbias, int T, int Tp, int C) {
+__global__ __launch_bounds__(256, 2) void final_bwd_kernel(const float* __restrict__ h, const float* __restrict__ stats,
+                                                           const float* __restrict__ dout, const float* __restrict__ w,
+                                                           const float* __restrict__ ada, int ld_ada, int off_shift,
+                                                           int off_scale, float* __restrict__ dh_out,
+                                                           float* __restrict__ dada, float* __restrict__ dw,
+                                                           float* __restrict__ dbias, int T, int Tp, int C,
+                                                           float* __restrict__ dw_part) {
   constexpr int D = VPL * 64;
-  __shared__ float red[4][D];  // one quantity at a time (6 of them) to stay inside 64 KiB
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  __shared__ float red[4][D];  // one quantity at a time (6 of them)
+  __shared__ float cst[6][D];  // 1 + scale | shift | weight rows (zero beyond C)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m0 = blockIdx.x * 64, n = m0 / Tp;
   const float* sc = ada + (size_t)n * ld_ada + off_scale;
   const float* sh = ada + (size_t)n * ld_ada + off_shift;
-  float scv[VPL], shv[VPL], a_sh[VPL], a_sc[VPL], wv[4][VPL], a_w[4][VPL];
+  for (int d = threadIdx.x; d < D; d += 256) {
+    cst[0][d] = 1.0f + sc[d];
+    cst[1][d] = sh[d];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) cst[2 + ch][d] = ch < C ? w[(size_t)ch * D + d] : 0.f;
+  }
+  float a_sh[VPL], a_sc[VPL], a_w[4][VPL];
   float a_b[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < VPL / 2; ++i) {
-    const int d = 2 * lane + 128 * i;
-    const float2 t = *reinterpret_cast<const float2*>(sc + d);
-    const float2 u = *reinterpret_cast<const float2*>(sh + d);
-    scv[2 * i] = 1.0f + t.x; scv[2 * i + 1] = 1.0f + t.y;
-    shv[2 * i] = u.x; shv[2 * i + 1] = u.y;
-    a_sh[2 * i] = a_sh[2 * i + 1] = a_sc[2 * i] = a_sc[2 * i + 1] = 0.f;
+  for (int i = 0; i < VPL; ++i) {
+    a_sh[i] = a_sc[i] = 0.f;
 #pragma unroll
-    for (int ch = 0; ch < 4; ++ch) {
-      float2 w2 = make_float2(0.f, 0.f);
-      if (ch < C) w2 = *reinterpret_cast<const float2*>(w + (size_t)ch * D + d);
-      wv[ch][2 * i] = w2.x; wv[ch][2 * i + 1] = w2.y;
-      a_w[ch][2 * i] = a_w[ch][2 * i + 1] = 0.f;
-    }
+    for (int ch = 0; ch < 4; ++ch) a_w[ch][i] = 0.f;
   }
-  for (int r = wave; r < 64; r += 4) {
-    const int m = m0 + r, t = m % Tp;
+  __syncthreads();
+  struct Row {
+    float hv[VPL], go[4], mu, rstd;
+  };
+  auto load_row = [&](Row& R, int m) {
+    const int t = m % Tp;
     const size_t row = (size_t)m * D;
-    float go[4] = {0.f, 0.f, 0.f, 0.f};
-    if (t < T) {
 #pragma unroll
-      for (int ch = 0; ch < 4; ++ch)
-        if (ch < C) go[ch] = dout[((size_t)n * C + ch) * T + t];
+    for (int i = 0; i < VPL / 2; ++i) {
+      const float2 v = *reinterpret_cast<const float2*>(h + row + 2 * lane + 128 * i);
+      R.hv[2 * i] = v.x; R.hv[2 * i + 1] = v.y;
     }
-    const float mu = stats[2 * (size_t)m], rstd = stats[2 * (size_t)m + 1];
-    float xh[VPL], dy[VPL];
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) R.go[ch] = (t < T && ch < C) ? dout[((size_t)n * C + ch) * T + t] : 0.f;
+    R.mu = stats[2 * (size_t)m];
+    R.rstd = stats[2 * (size_t)m + 1];
+  };
+  auto process_row = [&](Row& R, int m) {
+    const size_t row = (size_t)m * D;
+    const float mu = R.mu, rstd = R.rstd;
+    float dy[VPL];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int ch = 0; ch < 4; ++ch) a_b[ch] += go[ch];
+    for (int ch = 0; ch < 4; ++ch) a_b[ch] += R.go[ch];
 #pragma unroll
     for (int i = 0; i < VPL / 2; ++i) {
       const int d = 2 * lane + 128 * i;
-      const float2 hv = *reinterpret_cast<const float2*>(h + row + d);
+      float c0[2], c1[2], wr[4][2];
+      loadw<2>(&cst[0][d], c0);
+      loadw<2>(&cst[1][d], c1);
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) loadw<2>(&cst[2 + ch][d], wr[ch]);
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
         const int k = 2 * i + e;
-        xh[k] = ((e ? hv.y : hv.x) - mu) * rstd;
-        const float uF = xh[k] * scv[k] + shv[k];
+        const float xh = (R.hv[k] - mu) * rstd;
+        R.hv[k] = xh;
+        const float uF = xh * c0[e] + c1[e];
         float du = 0.f;
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
-          du += go[ch] * wv[ch][k];
-          a_w[ch][k] += go[ch] * uF;
+          du += R.go[ch] * wr[ch][e];
+          a_w[ch][k] += R.go[ch] * uF;
         }
         a_sh[k] += du;
-        a_sc[k] += du * xh[k];
-        dy[k] = du * scv[k];
+        a_sc[k] += du * xh;
+        dy[k] = du * c0[e];
         s1 += dy[k];
-        s2 += dy[k] * xh[k];
+        s2 += dy[k] * xh;
       }
     }
     const float m1 = wave_sum(s1) * (1.0f / D), m2 = wave_sum(s2) * (1.0f / D);
@@ -337,8 +411,17 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
     for (int i = 0; i < VPL / 2; ++i) {
       const int d = 2 * lane + 128 * i;
       *reinterpret_cast<float2*>(dh_out + row + d) =
-          make_float2(rstd * (dy[2 * i] - m1 - xh[2 * i] * m2), rstd * (dy[2 * i + 1] - m1 - xh[2 * i + 1] * m2));
+          make_float2(rstd * (dy[2 * i] - m1 - R.hv[2 * i] * m2), rstd * (dy[2 * i + 1] - m1 - R.hv[2 * i + 1] * m2));
     }
+  };
+  Row ra, rb;
+  load_row(ra, m0 + wave);
+#pragma unroll 1
+  for (int r = wave; r < 64; r += 8) {
+    load_row(rb, m0 + r + 4);
+    process_row(ra, m0 + r);
+    if (r + 8 < 64) load_row(ra, m0 + r + 8);
+    process_row(rb, m0 + r + 4);
   }
   float* dn = dada + (size_t)n * ld_ada;
 #pragma unroll
@@ -350,12 +433,27 @@ __global__ __launch_bounds__(256) void final_bwd_kernel(const float* __restrict_
       red[wave][d] = q == 0 ? a_sh[i] : (q == 1 ? a_sc[i] : a_w[q >= 2 ? q - 2 : 0][i]);
     }
     __syncthreads();
-    float* dst = q == 0 ? dn + off_shift : (q == 1 ? dn + off_scale : dw + (size_t)(q - 2) * D);
-    for (int d = threadIdx.x; d < D; d += 256) atomicAdd(dst + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
+    if (q >= 2 && dw_part != nullptr) {
+      float* dst = dw_part + (size_t)blockIdx.x * (4 * D + 64) + (size_t)(q - 2) * D;
+      for (int d = threadIdx.x; d < D; d += 256) dst[d] = red[0][d] + red[1][d] + red[2][d] + red[3][d];
+    } else {
+      float* dst = q == 0 ? dn + off_shift : (q == 1 ? dn + off_scale : dw + (size_t)(q - 2) * D);
+      for (int d = threadIdx.x; d < D; d += 256) atomicAdd(dst + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
+    }
     __syncthreads();
   }
-  if (lane == 0)  // every lane of a wave carries the same a_b
+  if (dw_part != nullptr) {  // bias partial sums behind the weight rows of the slab: [4 D + 0..3], the pad columns are never read back
+    if (lane == 0) {
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) red[wave][ch] = a_b[ch];  // every lane of a wave carries the same a_b
+    }
+    __syncthreads();
+    if (threadIdx.x < 4)
+      dw_part[(size_t)blockIdx.x * (4 * D + 64) + 4 * D + threadIdx.x] =
+          red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  } else if (lane == 0) {
     for (int ch = 0; ch < C; ++ch) atomicAdd(dbias + ch, a_b[ch]);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -485,29 +583,40 @@ int launch_ln_mod_bwd(int prec, const float* h, const float* stats, const void* 
                       int off_shift, int off_scale, const float* dh_skip, float* dh_out, float* dada, int M, int Tp, int D,
                       hipStream_t st, const void* br_next, int off_gate_next, void* dbr, float* db_next) {
   OSUD_CHECK_ARG(M % 64 == 0 && Tp % 64 == 0, "ln_mod_bwd: rows must come in blocks of 64");
-  const dim3 grid(M / 64), block(256);
+  OSUD_CHECK_ARG(dh_skip != nullptr, "ln_mod_bwd: the gradient of the residual stream behind the LayerNorm is required");
+  const dim3 grid(M / OSUD_LNB_ROWS), block(256);
+#define ARGS(T) h, stats, (const T*)du, ada, ld_ada, off_shift, off_scale, dh_skip, dh_out, dada, Tp, (const T*)br_next, off_gate_next, (T*)dbr, db_next
   if (prec == OSUD_PREC_BF16) {
-#define CALL(V) hipLaunchKernelGGL((ln_mod_bwd_kernel<bf16_t, V>), grid, block, 0, st, h, stats, (const bf16_t*)du, ada, ld_ada, off_shift, off_scale, dh_skip, dh_out, dada, Tp, (const bf16_t*)br_next, off_gate_next, (bf16_t*)dbr, db_next)
+#define CALL(V)                                                                                                      \
+  if (br_next != nullptr) hipLaunchKernelGGL((ln_mod_bwd_kernel<bf16_t, V, true>), grid, block, 0, st, ARGS(bf16_t)); \
+  else hipLaunchKernelGGL((ln_mod_bwd_kernel<bf16_t, V, false>), grid, block, 0, st, ARGS(bf16_t));
     OSUD_BY_D(D, CALL)
 #undef CALL
   } else {
-#define CALL(V) hipLaunchKernelGGL((ln_mod_bwd_kernel<float, V>), grid, block, 0, st, h, stats, (const float*)du, ada, ld_ada, off_shift, off_scale, dh_skip, dh_out, dada, Tp, (const float*)br_next, off_gate_next, (float*)dbr, db_next)
+#define CALL(V)                                                                                                    \
+  if (br_next != nullptr) hipLaunchKernelGGL((ln_mod_bwd_kernel<float, V, true>), grid, block, 0, st, ARGS(float)); \
+  else hipLaunchKernelGGL((ln_mod_bwd_kernel<float, V, false>), grid, block, 0, st, ARGS(float));
     OSUD_BY_D(D, CALL)
 #undef CALL
   }
+#undef ARGS
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }
 
 int launch_final_bwd(const float* h, const float* stats, const float* dout, const float* w, const float* ada, int ld_ada,
                      int off_shift, int off_scale, float* dh_out, float* dada, float* dw, float* dbias, int N, int T, int Tp,
-                     int D, int C, hipStream_t st) {
+                     int D, int C, hipStream_t st, float* scratch, size_t scratch_elems) {
   OSUD_CHECK_ARG(Tp % 64 == 0 && C <= 4, "final_bwd: bad sizes");
   const dim3 grid(N * Tp / 64), block(256);
-#define CALL(V) hipLaunchKernelGGL((final_bwd_kernel<V>), grid, block, 0, st, h, stats, dout, w, ada, ld_ada, off_shift, off_scale, dh_out, dada, dw, dbias, T, Tp, C)
+  // weight- and bias-gradient partial sums per block -> fixed-order column sums (scratch: [blocks][4 D + 64] floats: 512 blocks
+  // adding atomically into the same addresses serialised, 8192 of them on the bias's one cache line); without scratch: atomics
+  float* part = (scratch != nullptr && (size_t)grid.x * (4 * D + 64) <= scratch_elems && grid.x >= 64 && C == 4) ? scratch : nullptr;
+#define CALL(V) hipLaunchKernelGGL((final_bwd_kernel<V>), grid, block, 0, st, h, stats, dout, w, ada, ld_ada, off_shift, off_scale, dh_out, dada, dw, dbias, T, Tp, C, part)
   OSUD_BY_D(D, CALL)
 #undef CALL
   OSUD_HIP(hipGetLastError());
+  if (part != nullptr) return launch_colsum_f32(part, (int)grid.x, 4 * D + 64, dw, st, 4 * D, dbias, 4);
   return OSUD_OK;
 }
 
@@ -554,7 +663,9 @@ int launch_unpad_rows(const float* src, int ld_src, float* dst, int cols, int ro
 }
 
 // the same for tall partial-sum slabs (R in the hundreds): 16 row groups x 16 float4 columns per block, fixed-order combine
-__global__ __launch_bounds__(256) void colsum_f32_tall_kernel(const float* __restrict__ a, int R, int C, float* __restrict__ out) {
+// (columns >= split go to out2[c - split], of which only n2 exist: the final layer's bias gradient rides behind its weight gradient)
+__global__ __launch_bounds__(256) void colsum_f32_tall_kernel(const float* __restrict__ a, int R, int C, float* __restrict__ out,
+                                                              int split, float* __restrict__ out2, int n2) {
   __shared__ float4 part[16][16];
   const int tx = threadIdx.x & 15, tg = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + tx * 4;
@@ -575,13 +686,16 @@ __global__ __launch_bounds__(256) void colsum_f32_tall_kernel(const float* __res
     float4 t = part[0][tx];
 #pragma unroll
     for (int g = 1; g < 16; ++g) { t.x += part[g][tx].x; t.y += part[g][tx].y; t.z += part[g][tx].z; t.w += part[g][tx].w; }
-    *reinterpret_cast<float4*>(out + c) = t;
+    if (c < split) *reinterpret_cast<float4*>(out + c) = t;
+    else if (c - split < n2) *reinterpret_cast<float4*>(out2 + (c - split)) = t;
   }
 }
 
-int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_t st) {
+int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_t st, int split, float* out2, int n2) {
+  if (out2 == nullptr) split = C;
+  OSUD_CHECK_ARG(out2 == nullptr || (R_valid >= 64 && C % 64 == 0 && split % 4 == 0 && n2 % 4 == 0), "colsum: bad split");
   if (R_valid >= 64 && C % 64 == 0) {
-    hipLaunchKernelGGL(colsum_f32_tall_kernel, dim3(C / 64), dim3(256), 0, st, a, R_valid, C, out);
+    hipLaunchKernelGGL(colsum_f32_tall_kernel, dim3(C / 64), dim3(256), 0, st, a, R_valid, C, out, split, out2, n2);
     OSUD_HIP(hipGetLastError());
     return OSUD_OK;
   }
