@@ -207,6 +207,12 @@ int osud_op_convert(int precision, const float* src, void* dst, size_t n, osud_s
 int osud_op_attention(int precision, const void* qkv, int ld_qkv, const uint8_t* mask, void* out, int N, int T, int Tp,
                       int Mp, int heads, int head_dim, osud_stream stream);
 
+/* Backward of the attention core in the training layout (T == Tp, T % 64 == 0, no mask): qkv [N*T][3*hidden], d_out / out [N*T][hidden],
+ * lse [N][heads][T] as saved by the training forward (log2 domain in the bf16 tier, natural log in the f32 tier) -> dqkv [N*T][3*hidden].
+ * delta_ws: [N][heads][T] floats of scratch, needed when a head's sequence does not fit the LDS (T > 256); may be NULL otherwise. */
+int osud_op_attention_bwd(int precision, const void* qkv, const void* d_out, const void* out, const float* lse, void* dqkv,
+                          int N, int T, int heads, int head_dim, float* delta_ws, osud_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

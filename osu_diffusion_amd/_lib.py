@@ -67,6 +67,7 @@ _SIGNATURES = {
     "osud_op_convert": (_i, [_i, _vp, _vp, _sz, _vp]),
     "osud_set_gemm_dynamic_tiles": (_i, [_i]),
     "osud_op_attention": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "osud_op_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }
 
 

@@ -24,13 +24,148 @@ namespace osud {
 
 namespace {
 
+// The two register-resident passes on row-major LDS tiles of one (sample, head) (see the file comment), shared by the
+// one-workgroup-per-head kernel and the persistent streaming kernel below.
+// pass A: dQ for queries own..own+31, walking the keys
+template <int HDP>
+__device__ __forceinline__ void attn_bwd_pass_a(const char* Qs, const char* Ks, const char* Vs, const char* Os,
+                                                const float* lse_s, const float* del_s, int T, int own, int lane, float c1,
+                                                float scale, f32x16 (&dq)[HDP / 32]) {
+  constexpr int KS = HDP / 16, DT = HDP / 32;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  u32x4 qf[KS], of[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    qf[ks] = rowfrag<HDP>(Qs, own + frow, 2 * ks + fhalf);
+    of[ks] = rowfrag<HDP>(Os, own + frow, 2 * ks + fhalf);
+  }
+  const float my_lse = lse_s[own + frow], my_del = del_s[own + frow];
+#pragma unroll
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+  for (int kt = 0; kt < T / 32; ++kt) {
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      s = mfma_bf16(rowfrag<HDP>(Ks, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s);    // D[key][query]
+      dp = mfma_bf16(rowfrag<HDP>(Vs, kt * 32 + frow, 2 * ks + fhalf), of[ks], dp);  // dO . V^T
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p = __builtin_amdgcn_exp2f(s[r] * c1 - my_lse);
+      s[r] = p * (dp[r] - my_del) * scale;  // dS
+    }
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      const u32x4 dsf = pack8(s, 8 * ss);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        dq[dt] = mfma_bf16(trfrag<HDP>(Ks, kt * 32 + 16 * ss, dt * 32, lane), dsf, dq[dt]);
+    }
+  }
+}
+// pass B: dK, dV for keys own..own+31, walking the queries
+template <int HDP>
+__device__ __forceinline__ void attn_bwd_pass_b(const char* Qs, const char* Ks, const char* Vs, const char* Os,
+                                                const float* lse_s, const float* del_s, int T, int own, int lane, float c1,
+                                                float scale, f32x16 (&dk)[HDP / 32], f32x16 (&dv)[HDP / 32]) {
+  constexpr int KS = HDP / 16, DT = HDP / 32;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  u32x4 kf[KS], vf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kf[ks] = rowfrag<HDP>(Ks, own + frow, 2 * ks + fhalf);
+    vf[ks] = rowfrag<HDP>(Vs, own + frow, 2 * ks + fhalf);
+  }
+#pragma unroll
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dk[i][r] = dv[i][r] = 0.f;
+  for (int qt = 0; qt < T / 32; ++qt) {
+    f32x16 s, dp;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      s = mfma_bf16(rowfrag<HDP>(Qs, qt * 32 + frow, 2 * ks + fhalf), kf[ks], s);    // D[query][key]
+      dp = mfma_bf16(rowfrag<HDP>(Os, qt * 32 + frow, 2 * ks + fhalf), vf[ks], dp);
+    }
+    f32x16 p;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 32 + 8 * g + 4 * fhalf);
+      const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qt * 32 + 8 * g + 4 * fhalf);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float pv = __builtin_amdgcn_exp2f(s[4 * g + i] * c1 - l4[i]);
+        p[4 * g + i] = pv;
+        s[4 * g + i] = pv * (dp[4 * g + i] - d4[i]) * scale;
+      }
+    }
+#pragma unroll
+    for (int ss = 0; ss < 2; ++ss) {
+      const u32x4 pf = pack8(p, 8 * ss), dsf = pack8(s, 8 * ss);
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        dv[dt] = mfma_bf16(trfrag<HDP>(Os, qt * 32 + 16 * ss, dt * 32, lane), pf, dv[dt]);
+        dk[dt] = mfma_bf16(trfrag<HDP>(Qs, qt * 32 + 16 * ss, dt * 32, lane), dsf, dk[dt]);
+      }
+    }
+  }
+}
+// accumulator rows (lane = the owned row, 4 consecutive columns per register quad) -> bf16 row `orow`
+template <int HD, int HDP>
+__device__ __forceinline__ void attn_bwd_store(bf16_t* orow, const f32x16 (&acc)[HDP / 32], int fhalf) {
+#pragma unroll
+  for (int dt = 0; dt < HDP / 32; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int d = dt * 32 + 8 * g + 4 * fhalf;
+      if (d < HD) store4(orow + d, acc[dt][4 * g], acc[dt][4 * g + 1], acc[dt][4 * g + 2], acc[dt][4 * g + 3]);
+    }
+}
+
+// The same rows through a 2 KiB LDS patch of the wave (head_dim 64): a lane owns a ROW of the accumulators, so a direct store
+// instruction touches 32 rows with 16 bytes each -- 24 such instructions per head and wave were 56 of the streamed kernel's 132 us
+// (tools/attn_bench.py with the stores compiled out).  Sixteen rows at a time go to the patch (16-byte chunks XOR-swizzled with
+// the row) and come back as 16 bytes per lane, eight lanes per 128-byte row: every store instruction writes eight full lines.
+__device__ __forceinline__ void attn_bwd_store_patch(char* patch, bf16_t* rows, size_t ld, const f32x16 (&acc)[2], int lane) {
+  const int frow = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if ((frow >> 4) == half) {
+      const int r = frow & 15;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2 v;
+          v[0] = pack_bf2(acc[dt][4 * g], acc[dt][4 * g + 1]);
+          v[1] = pack_bf2(acc[dt][4 * g + 2], acc[dt][4 * g + 3]);
+          *reinterpret_cast<u32x2*>(patch + r * 128 + (((dt * 4 + g) ^ (r & 7)) << 4) + fhalf * 8) = v;
+        }
+    }
+    asm volatile("" ::: "memory");  // (LDS operations of a wave execute in order; this only pins the compiler's order)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rr = (lane >> 3) + 8 * j, c = lane & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(patch + rr * 128 + ((c ^ (rr & 7)) << 4));
+      *reinterpret_cast<u32x4*>(rows + (size_t)(16 * half + rr) * ld + c * 8) = v;
+    }
+    asm volatile("" ::: "memory");
+  }
+}
+
 template <int HD, int HDP, int NT>
 __global__ __launch_bounds__(NT) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                             const bf16_t* __restrict__ O, const float* __restrict__ lse,
                                                             bf16_t* __restrict__ dqkv, int T, int D, float c1,
                                                             float scale, float* __restrict__ dbias) {
   using TL = AttnTile<HDP>;
-  constexpr int KS = HDP / 16, DT = HDP / 32, CPR = TL::CPR, NWV = NT / 64;
+  constexpr int DT = HDP / 32, CPR = TL::CPR, NWV = NT / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Qs = smem;
   char* Ks = Qs + T * TL::RS;
@@ -96,106 +231,18 @@ __global__ __launch_bounds__(NT) void attn_bwd_bf16_kernel(const bf16_t* __restr
   __syncthreads();
   const int own = wave * 32;  // first query (pass A) / key (pass B) this wave owns
   if (own < T) {
-    // =============================== pass A: dQ for queries own..own+31 ======================
+    bf16_t* orow = dqkv + (m0 + own + frow) * ld3 + h * HD;
     {
-      u32x4 qf[KS], of[KS];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        qf[ks] = rowfrag<HDP>(Qs, own + frow, 2 * ks + fhalf);
-        of[ks] = rowfrag<HDP>(Os, own + frow, 2 * ks + fhalf);
-      }
-      const float my_lse = lse_s[own + frow], my_del = del_s[own + frow];
       f32x16 dq[DT];
-#pragma unroll
-      for (int i = 0; i < DT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
-      for (int kt = 0; kt < T / 32; ++kt) {
-        f32x16 s, dp;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          s = mfma_bf16(rowfrag<HDP>(Ks, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s);    // D[key][query]
-          dp = mfma_bf16(rowfrag<HDP>(Vs, kt * 32 + frow, 2 * ks + fhalf), of[ks], dp);  // dO . V^T
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(s[r] * c1 - my_lse);
-          s[r] = p * (dp[r] - my_del) * scale;  // dS
-        }
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-          const u32x4 dsf = pack8(s, 8 * ss);
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt)
-            dq[dt] = mfma_bf16(trfrag<HDP>(Ks, kt * 32 + 16 * ss, dt * 32, lane), dsf, dq[dt]);
-        }
-      }
-      bf16_t* orow = dqkv + (m0 + own + frow) * ld3 + h * HD;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-          if (dt * 32 + 8 * g + 4 * fhalf < HD)
-            store4(orow + dt * 32 + 8 * g + 4 * fhalf, dq[dt][4 * g], dq[dt][4 * g + 1], dq[dt][4 * g + 2], dq[dt][4 * g + 3]);
+      attn_bwd_pass_a<HDP>(Qs, Ks, Vs, Os, lse_s, del_s, T, own, lane, c1, scale, dq);
+      attn_bwd_store<HD, HDP>(orow, dq, fhalf);
       colsum_store(dq, 0);
     }
-    // =============================== pass B: dK, dV for keys own..own+31 =====================
     {
-      u32x4 kf[KS], vf[KS];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        kf[ks] = rowfrag<HDP>(Ks, own + frow, 2 * ks + fhalf);
-        vf[ks] = rowfrag<HDP>(Vs, own + frow, 2 * ks + fhalf);
-      }
       f32x16 dk[DT], dv[DT];
-#pragma unroll
-      for (int i = 0; i < DT; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dk[i][r] = dv[i][r] = 0.f;
-      for (int qt = 0; qt < T / 32; ++qt) {
-        f32x16 s, dp;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          s = mfma_bf16(rowfrag<HDP>(Qs, qt * 32 + frow, 2 * ks + fhalf), kf[ks], s);    // D[query][key]
-          dp = mfma_bf16(rowfrag<HDP>(Os, qt * 32 + frow, 2 * ks + fhalf), vf[ks], dp);
-        }
-        f32x16 p;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + qt * 32 + 8 * g + 4 * fhalf);
-          const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + qt * 32 + 8 * g + 4 * fhalf);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const float pv = __builtin_amdgcn_exp2f(s[4 * g + i] * c1 - l4[i]);
-            p[4 * g + i] = pv;
-            s[4 * g + i] = pv * (dp[4 * g + i] - d4[i]) * scale;
-          }
-        }
-#pragma unroll
-        for (int ss = 0; ss < 2; ++ss) {
-          const u32x4 pf = pack8(p, 8 * ss), dsf = pack8(s, 8 * ss);
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) {
-            dv[dt] = mfma_bf16(trfrag<HDP>(Os, qt * 32 + 16 * ss, dt * 32, lane), pf, dv[dt]);
-            dk[dt] = mfma_bf16(trfrag<HDP>(Qs, qt * 32 + 16 * ss, dt * 32, lane), dsf, dk[dt]);
-          }
-        }
-      }
-      bf16_t* orow = dqkv + (m0 + own + frow) * ld3 + h * HD;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d = dt * 32 + 8 * g + 4 * fhalf;
-          if (d < HD) {
-            store4(orow + D + d, dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]);
-            store4(orow + 2 * D + d, dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
-          }
-        }
+      attn_bwd_pass_b<HDP>(Qs, Ks, Vs, Os, lse_s, del_s, T, own, lane, c1, scale, dk, dv);
+      attn_bwd_store<HD, HDP>(orow + D, dk, fhalf);
+      attn_bwd_store<HD, HDP>(orow + 2 * D, dv, fhalf);
       colsum_store(dk, 1);
       colsum_store(dv, 2);
     }
@@ -208,6 +255,149 @@ __global__ __launch_bounds__(NT) void attn_bwd_bf16_kernel(const bf16_t* __restr
       float v = 0.f;
       for (int w = 0; w < nw; ++w) v += cs_s[(part * NWV + w) * HDP + d];
       atomicAdd(dbias + (size_t)part * D + h * HD + d, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------- T == 128, head_dim 64: persistent, streamed
+// The kernel above keeps the memory system idle while a workgroup computes and the matrix pipe idle while it loads: with two
+// workgroups per CU (66 KiB of LDS, 228 registers each) a head took 11.4 us of CU time against 6.2 us of HBM time (131 KB per head
+// at the 5.4 TB/s a device copy reaches).  Here ONE workgroup per CU walks heads b, b + G, ...: the four tiles of the next head
+// (Q | K | V | dO, 64 KiB) travel global -> LDS by LDS-DMA (no registers; wave w fetches tile w, the XOR swizzle of AttnTile is
+// applied on the source side) into the other half of a 128 KiB double buffer while the two passes run on this head's tiles.
+// delta = rowsum(dO . O) needs O, which is not a tile: its rows are fetched into registers one head ahead.
+#ifndef OSUD_ATTN_EXP
+#define OSUD_ATTN_EXP 0
+#endif
+template <int T>
+__global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                              const bf16_t* __restrict__ O, const float* __restrict__ lse,
+                                                              bf16_t* __restrict__ dqkv, int D, int H, int items, float c1,
+                                                              float scale) {
+  constexpr int HD = 64, HDP = 64, DT = 2;
+  using TL = AttnTile<HDP>;
+  constexpr int TILE = T * TL::RS;  // bytes
+  static_assert(T == 128, "eight waves: four walk the keys (dQ), four the queries (dK, dV), 32 rows each");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][4][TILE] | lse_s[2][T] | del_s[2][T] | store patches [8][2 KiB]
+  float* lse_s = reinterpret_cast<float*>(smem + 8 * TILE);
+  float* del_s = lse_s + 2 * T;
+  char* patch = reinterpret_cast<char*>(del_s + 2 * T) + (threadIdx.x >> 6) * 2048;
+  const uint32_t lds0 = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const size_t ld3 = 3 * (size_t)D;
+  // LDS-DMA: one instruction = 64 lanes x 16 bytes = 8 tile rows, written linearly; lane (lr = lane / 8, pc = lane % 8) therefore
+  // fetches the chunk that AttnTile::off places at physical position pc of row 8 p + lr: pc ^ ((row >> 1) & 7).
+  // Wave w fetches half w % 2 of tile w / 2 (Q, K, V, dO).
+  const int tile = wave >> 1;
+  const uint32_t ldb = (uint32_t)((tile == 3 ? (size_t)D : ld3) * 2);  // source row stride of this wave's tile, bytes
+  const int lr = lane >> 3, pc = lane & 7;
+  const uint32_t voff_even = (uint32_t)lr * ldb + (uint32_t)((pc ^ (lr >> 1)) << 4);
+  const uint32_t voff_odd = (uint32_t)lr * ldb + (uint32_t)((pc ^ (4 + (lr >> 1))) << 4);
+  auto issue = [&](int item, int buf) {
+    const int n = item / H, h = item - n * H;
+    const char* base = tile == 3 ? reinterpret_cast<const char*>(dO + (size_t)n * T * D + h * HD)
+                                 : reinterpret_cast<const char*>(qkv + (size_t)n * T * ld3 + (size_t)tile * D + h * HD);
+    const int p0 = (wave & 1) * (T / 16);  // first 8-row piece of this wave's half
+    base += (size_t)p0 * 8 * ldb;
+    const uint32_t dst0 = lds0 + (uint32_t)((buf * 4 + tile) * TILE + p0 * 1024);
+#pragma unroll
+    for (int pp = 0; pp < T / 16; ++pp) {  // (T / 16 is even: piece parity = pp parity)
+      const char* sb = base + (size_t)pp * 8 * ldb;
+      const uint32_t dst = dst0 + pp * 1024;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"((pp & 1) ? voff_odd : voff_even), "s"(sb), "s"(dst) : "memory");
+    }
+  };
+  // delta = rowsum(dO . O) and lse of the NEXT head are made while this head's stores drain: thread (row r = tid / 4, quarter =
+  // tid % 4) fetches 16 columns of O's and dO's row r into registers right after the next head's DMA is issued, and reduces them
+  // after the two passes -- by then everything older (that DMA included) has landed, and the compiler's wait for these
+  // registers, which counts only what it can see, has nothing left to wait for.  The statistics are double-buffered like the tiles.
+  const int dr = tid >> 2, dqt = tid & 3;
+  u32x4 oreg[2], doreg[2];
+  float lreg = 0.f;
+  auto fetch_stats = [&](int item) {
+    const int n = item / H, h = item - n * H;
+    const size_t off = ((size_t)n * T + dr) * D + h * HD + dqt * 16;
+    oreg[0] = *reinterpret_cast<const u32x4*>(O + off);
+    oreg[1] = *reinterpret_cast<const u32x4*>(O + off + 8);
+    doreg[0] = *reinterpret_cast<const u32x4*>(dO + off);
+    doreg[1] = *reinterpret_cast<const u32x4*>(dO + off + 8);
+    if (tid < T) lreg = lse[((size_t)n * H + h) * T + tid];
+  };
+  auto put_stats = [&](int sb) {
+    float part = 0.f;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        part += bf2f((bf16_t)(doreg[j][e] & 0xffff)) * bf2f((bf16_t)(oreg[j][e] & 0xffff));
+        part += bf2f((bf16_t)(doreg[j][e] >> 16)) * bf2f((bf16_t)(oreg[j][e] >> 16));
+      }
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    if (dqt == 0) del_s[sb * T + dr] = part;
+    if (tid < T) lse_s[sb * T + tid] = lreg;
+  };
+  int it = blockIdx.x, buf = 0;
+  if (it < items) {
+    issue(it, 0);
+    fetch_stats(it);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first head's tiles
+    put_stats(0);
+  }
+  for (; it < items; it += gridDim.x, buf ^= 1) {
+    const char* Qs = smem + (size_t)buf * 4 * TILE;
+    const char* Ks = Qs + TILE;
+    const char* Vs = Ks + TILE;
+    const char* Os = Vs + TILE;
+    const float* lse_b = lse_s + buf * T;
+    const float* del_b = del_s + buf * T;
+    // every wave has waited for its own pieces of this head and written its statistics; the other buffers are free from here on
+    __syncthreads();
+    const int nx = it + gridDim.x;
+    if (nx < items && !(OSUD_ATTN_EXP & 8)) {
+      issue(nx, buf ^ 1);
+      fetch_stats(nx);
+    }
+    const int n = it / H, h = it - n * H;
+    const int own = (wave & 3) * 32;
+    bf16_t* orow = dqkv + ((size_t)n * T + own + frow) * ld3 + h * HD;
+    bf16_t* orows = dqkv + ((size_t)n * T + own) * ld3 + h * HD;
+#ifndef OSUD_ATTN_EXP
+#define OSUD_ATTN_EXP 0
+#endif
+    if (wave < 4) {  // the two passes are independent once the tiles are in LDS: they run side by side, two waves per SIMD
+      f32x16 dq[DT];
+      if (OSUD_ATTN_EXP & 2) {
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dq[i][r] = lse_b[own + frow];
+      } else
+      attn_bwd_pass_a<HDP>(Qs, Ks, Vs, Os, lse_b, del_b, T, own, lane, c1, scale, dq);
+      if (nx < items) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next head (issued a whole pass ago)
+        put_stats(buf ^ 1);
+      }
+      if (!(OSUD_ATTN_EXP & 1)) attn_bwd_store_patch(patch, orows, ld3, dq, lane);
+      else if (dq[0][0] == 12345.f) orow[0] = 1;
+    } else {
+      f32x16 dk[DT], dv[DT];
+      if (OSUD_ATTN_EXP & 4) {
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dk[i][r] = dv[i][r] = lse_b[own + frow];
+      } else
+      attn_bwd_pass_b<HDP>(Qs, Ks, Vs, Os, lse_b, del_b, T, own, lane, c1, scale, dk, dv);
+      if (nx < items) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        put_stats(buf ^ 1);
+      }
+      if (!(OSUD_ATTN_EXP & 1)) {
+      attn_bwd_store_patch(patch, orows + D, ld3, dk, lane);
+      attn_bwd_store_patch(patch, orows + 2 * D, ld3, dv, lane);
+      } else if (dk[0][0] + dv[0][0] == 12345.f) orow[D] = 1;
     }
   }
 }
@@ -541,6 +731,24 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
       attr_set = true;
     }
     const float c1 = scale * 1.4426950408889634f;
+    const char* stream_env = getenv("OSUD_ATTN_BWD_STREAM");  // "0": the one-workgroup-per-head kernel (A/B runs, tests)
+    const bool stream_on = !(stream_env && stream_env[0] == '0');
+    if (head_dim == 64 && T == 128 && dbias == nullptr && stream_on) {
+      static bool stream_attr = false;
+      constexpr size_t slds = (size_t)8 * 128 * AttnTile<64>::RS + 4 * 128 * 4 + 8 * 2048;
+      if (!stream_attr) {
+        OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_stream_kernel<128>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        stream_attr = true;
+      }
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+      const int items = N * heads;
+      hipLaunchKernelGGL((attn_bwd_stream_kernel<128>), dim3(items < cus ? items : cus), dim3(512), slds, st, (const bf16_t*)qkv,
+                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, D, heads, items, c1, scale);
+      OSUD_HIP(hipGetLastError());
+      return OSUD_OK;
+    }
     if (head_dim == 64 && T <= 128)
       hipLaunchKernelGGL((attn_bwd_bf16_kernel<64, 64, 256>), dim3(heads, N), dim3(256), lds, st, (const bf16_t*)qkv,
                          (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale, dbias);

@@ -33,21 +33,19 @@ template <int HDP> __device__ __forceinline__ u32x4 trfrag(const char* tile, int
   const int row = r0 + 4 * (lane >> 5) + ((lane & 15) >> 2);
   const int colb = (d0 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;  // byte offset of this lane's 4 columns
   const int chunk = colb >> 4, within = colb & 15;
-  const uint32_t base = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)tile;
-  const uint32_t a0 = base + AttnTile<HDP>::off(row, chunk) + within;
-  const uint32_t a1 = base + AttnTile<HDP>::off(row + 8, chunk) + within;
-  // reads and their wait are ONE asm statement: a separate s_waitcnt statement does not stop the scheduler from
-  // moving the consumers (register moves, MFMA) above it, because the asm outputs look ready to the compiler
-  u32x2 lo, hi;
-  asm volatile(
-      "ds_read_b64_tr_b16 %0, %2\n\t"
-      "ds_read_b64_tr_b16 %1, %3\n\t"
-      "s_waitcnt lgkmcnt(0)"
-      : "=&v"(lo), "=&v"(hi)
-      : "v"(a0), "v"(a1)
-      : "memory");
+  // (the compiler's own builtin: it tracks the LDS counter itself, so these reads are hoisted above the MFMAs of the previous
+  // k-step and waited for only where they are used; the first version issued them from inline asm with the wait in the same
+  // statement -- every fragment cost a full LDS round trip with the matrix pipe idle)
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const lds_s16x4* base = (const lds_s16x4*)(const __attribute__((address_space(3))) char*)tile;
+  const lds_s16x4* p0 = (const lds_s16x4*)((const __attribute__((address_space(3))) char*)base + AttnTile<HDP>::off(row, chunk) + within);
+  const lds_s16x4* p1 = (const lds_s16x4*)((const __attribute__((address_space(3))) char*)base + AttnTile<HDP>::off(row + 8, chunk) + within);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_s16x4*>(p0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(const_cast<lds_s16x4*>(p1));
+  const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
   u32x4 v;
-  v[0] = lo[0]; v[1] = lo[1]; v[2] = hi[0]; v[3] = hi[1];
+  v[0] = l2[0]; v[1] = l2[1]; v[2] = h2[0]; v[3] = h2[1];
   return v;
 }
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, f32x16 c) {

@@ -641,6 +641,11 @@ extern "C" int osud_op_convert(int precision, const float* src, void* dst, size_
   OSUD_CHECK_ARG(src && dst, "op_convert: null argument");
   return launch_convert(precision, src, dst, n, (hipStream_t)stream);
 }
+extern "C" int osud_op_attention_bwd(int precision, const void* qkv, const void* d_out, const void* out, const float* lse,
+                                     void* dqkv, int N, int T, int heads, int head_dim, float* delta_ws, osud_stream stream) {
+  OSUD_CHECK_ARG(qkv && d_out && out && lse && dqkv, "op_attention_bwd: null argument");
+  return launch_attention_bwd(precision, qkv, d_out, out, lse, dqkv, N, T, heads, head_dim, (hipStream_t)stream, delta_ws, nullptr);
+}
 extern "C" int osud_op_attention(int precision, const void* qkv, int ld_qkv, const uint8_t* mask, void* out, int N,
                                  int T, int Tp, int Mp, int heads, int head_dim, osud_stream stream) {
   OSUD_CHECK_ARG(qkv && out, "op_attention: null argument");

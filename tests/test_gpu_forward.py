@@ -135,6 +135,40 @@ def test_attention_core(prec, tol, T_, masked):
         assert maxdiff(got[rows].cpu(), ref.cpu()) < tol, (n, T_)
 
 
+@pytest.mark.parametrize("prec,tol", [(_lib.PREC_BF16, 3e-2), (_lib.PREC_F32, 5e-5)])
+@pytest.mark.parametrize("N,H,T_,stream", [(3, 2, 64, "1"), (24, 12, 128, "1"), (24, 12, 128, "0"), (2, 2, 256, "1"), (2, 2, 320, "1")])
+def test_attention_core_backward(prec, tol, N, H, T_, stream, monkeypatch):
+    """osud_op_attention_bwd against torch autograd of softmax(q k^T / sqrt(hd)) v on the same (rounded) operands.  N*H = 288 heads
+    at T = 128 is more than one per compute unit: the persistent streamed kernel runs its double-buffered loop (a second head on
+    32 of the workgroups); OSUD_ATTN_BWD_STREAM=0 selects the one-workgroup-per-head kernel; T = 320 the tiled one."""
+    monkeypatch.setenv("OSUD_ATTN_BWD_STREAM", stream)
+    hd = 64
+    D = H * hd
+    M = N * T_
+    torch.manual_seed(N * 1000 + T_)
+    qkv = torch.randn(M, 3 * D, device=DEV)
+    dout = torch.randn(M, D, device=DEV)
+    qkc, doc = to_elem(prec, qkv), to_elem(prec, dout)
+    qkr = from_elem(prec, qkc, (M, 3 * D)).double().requires_grad_(True)
+    dor = from_elem(prec, doc, (M, D)).double()
+    q, k, v = (qkr[:, i * D:(i + 1) * D].reshape(N, T_, H, hd).transpose(1, 2) for i in range(3))
+    s = q @ k.transpose(-1, -2) / hd ** 0.5
+    o = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(M, D)
+    o.backward(dor)
+    lse = torch.logsumexp(s, -1)  # (N, H, T)
+    if prec == _lib.PREC_BF16:
+        lse = lse * 1.4426950408889634  # the bf16 tier keeps it in the log2 domain
+    lse = lse.float().contiguous()
+    oc = to_elem(prec, o.detach().float())
+    got = torch.zeros(M * 3 * D * (2 if prec == 0 else 4), dtype=torch.uint8, device=DEV)
+    ws = torch.zeros(N * H * T_, device=DEV)
+    _lib.check(_lib.lib().osud_op_attention_bwd(prec, _lib.ptr(qkc), _lib.ptr(doc), _lib.ptr(oc), _lib.ptr(lse), _lib.ptr(got), N, T_,
+                                                H, hd, _lib.ptr(ws), None))
+    g = from_elem(prec, got, (M, 3 * D))
+    ref = qkr.grad.float()
+    assert maxdiff(g.cpu(), ref.cpu()) < tol * max(1.0, float(ref.abs().max())), (N, H, T_)
+
+
 # ------------------------------------------------------------------------------------ forward
 FWD_TAGS = ["tiny_T64", "tiny_T128", "tiny_T200_band", "tiny_T128_allfalse", "small_T128", "tiny_T128_rough",
             "dit_b_T128", "dit_b_T128_rough"]  # dit_b: D=768, 12 heads, 12 blocks -- the geometry bench.py times
