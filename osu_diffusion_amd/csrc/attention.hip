@@ -16,6 +16,8 @@
 // without leaving registers (the key order inside a k-step is permuted identically on the
 // V side).  fp32 statistics, online softmax across key blocks.
 // f32 (parity) tier: plain one-thread-per-query VALU kernel, fp32 everywhere.
+#include <stdlib.h>
+
 #include "attn_frag.h"
 
 namespace osud {
@@ -223,6 +225,149 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
   }
 }
 
+// ---------------------------------------------------------------- T == Tp == 128, head_dim 64, no mask: persistent, streamed
+// The shape of training and of window sampling.  The kernel above is a 48 KB-in / 16 KB-out copy per head with a little MFMA
+// work: at four workgroups per CU it reached 4.3 TB/s in training and 3.1 TB/s at the sampling batch (a device copy: 5.4).  Here one
+// eight-wave workgroup per CU walks PAIRS of heads (waves 0-3 the first, 4-7 the second; a wave owns 32 queries): the K and V
+// tiles of the next pair travel global -> LDS by LDS-DMA (XOR swizzle applied on the source side, see attention_bwd.hip) into the
+// other half of a 128 KiB double buffer while this pair is computed; Q fragments are fetched into registers one pair ahead; the
+// output rows leave through per-wave LDS patches as full 128-byte lines.  All 128 keys are scored before the softmax (four
+// 32 x 32 score tiles in registers), so there is no running maximum to rescale by.
+template <int T>
+__global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                              float* __restrict__ lse, int D, int H, int items, float c1) {
+  constexpr int HD = 64, HDP = 64, KS = 4, DT = 2;
+  using TL = AttnTile<HDP>;
+  constexpr int TILE = T * TL::RS;  // bytes
+  static_assert(T == 128, "four waves x 32 queries per head, four 32-key score tiles");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][2 heads][K | V][TILE] | store patches [8][2 KiB]
+  char* patch = smem + 8 * TILE + (threadIdx.x >> 6) * 2048;
+  const uint32_t lds0 = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const size_t ld3 = 3 * (size_t)D;
+  const int npairs = (items + 1) / 2;
+  // LDS-DMA: wave w fetches half w % 2 of tile w / 2 (head (w / 2) / 2 of the pair, K or V = (w / 2) % 2)
+  const int tile = wave >> 1, thead = tile >> 1, tkv = tile & 1;
+  const uint32_t ldb = (uint32_t)(ld3 * 2);
+  const int lr = lane >> 3, pc = lane & 7;
+  const uint32_t voff_even = (uint32_t)lr * ldb + (uint32_t)((pc ^ (lr >> 1)) << 4);
+  const uint32_t voff_odd = (uint32_t)lr * ldb + (uint32_t)((pc ^ (4 + (lr >> 1))) << 4);
+  auto issue = [&](int pair, int buf) {
+    const int item = 2 * pair + thead;
+    if (item >= items) return;  // odd head count: the last pair is half empty
+    const int n = item / H, h = item - n * H;
+    const int p0 = (wave & 1) * (T / 16);
+    const char* base = reinterpret_cast<const char*>(qkv + (size_t)n * T * ld3 + (size_t)(1 + tkv) * D + h * HD) + (size_t)p0 * 8 * ldb;
+    const uint32_t dst0 = lds0 + (uint32_t)((buf * 4 + tile) * TILE + p0 * 1024);
+#pragma unroll
+    for (int pp = 0; pp < T / 16; ++pp) {
+      const char* sb = base + (size_t)pp * 8 * ldb;
+      const uint32_t dst = dst0 + pp * 1024;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"((pp & 1) ? voff_odd : voff_even), "s"(sb), "s"(dst) : "memory");
+    }
+  };
+  const int hw = wave >> 2, own = (wave & 3) * 32;  // which head of the pair, first query of this wave
+  auto fetch_q = [&](int pair, u32x4 (&qf)[KS]) {
+    int item = 2 * pair + hw;
+    if (item >= items) item = items - 1;  // (the empty half of an odd last pair reads a valid head and stores nothing: no select
+                                          //  on the loaded value, which would pull the wait for it right behind the load)
+    const int n = item / H, h = item - n * H;
+    const bf16_t* src = qkv + ((size_t)n * T + own + frow) * ld3 + h * HD + fhalf * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(src + ks * 16);
+  };
+  int it = blockIdx.x, buf = 0;
+  u32x4 qf[KS], qn[KS];
+  if (it < npairs) {
+    issue(it, 0);
+    fetch_q(it, qf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));  // (the compiler's wait for these registers: here, see below)
+  }
+  for (; it < npairs; it += gridDim.x, buf ^= 1) {
+    const char* Ks = smem + (size_t)((buf * 2 + hw) * 2) * TILE;
+    const char* Vs = Ks + TILE;
+    __syncthreads();  // every wave has waited for its pieces of this pair; the other buffer is free from here on
+    const int nx = it + gridDim.x;
+    if (nx < npairs) {
+      issue(nx, buf ^ 1);
+      fetch_q(nx, qn);
+    }
+    const int item = 2 * it + hw;
+    f32x16 o[DT];
+    float m_row = 0.f, l_row = 1.f;
+    if (item < items) {
+      // ---- S^T tiles: s[kt][4g+i] = score(key = kt*32 + 8g + 4*fhalf + i, query own + frow)
+      f32x16 s[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s[kt] = mfma_bf16(rowfrag<HDP>(Ks, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s[kt]);
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[kt][r] *= c1;
+          mx = fmaxf(mx, s[kt][r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      float psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = fast_exp2(s[kt][r] - mx);
+          s[kt][r] = p;
+          psum += p;
+        }
+      psum += __shfl_xor(psum, 32, 64);
+      m_row = mx;
+      l_row = psum;
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+      // ---- O^T += V^T . P^T (V^T fragments = transposing reads of the row-major V tile)
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const u32x4 pf = pack8(s[kt], 8 * ss);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) o[dt] = mfma_bf16(trfrag<HDP>(Vs, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
+        }
+      const float inv = 1.0f / l_row;
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= inv;
+    }
+    // Everything issued so far -- the next pair's DMA pieces and Q fragments -- has had the whole pair to land: wait for it HERE,
+    // before this pair's stores are issued, and let the compiler see the fragments used (its own wait for them then sits here as
+    // well and not behind the stores and the DMA it cannot see), so that the stores drain while the next pair is computed.
+    if (nx < npairs) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        asm volatile("" : "+v"(qn[ks]));
+        qf[ks] = qn[ks];
+      }
+    }
+    if (item < items) {
+      const int n = item / H, h = item - n * H;
+      if (lse != nullptr && fhalf == 0)  // log2-domain logsumexp of the scaled scores, for the backward pass
+        lse[((size_t)n * H + h) * T + own + frow] = m_row + __builtin_amdgcn_logf(l_row);
+      store_rows_patch(patch, out + ((size_t)n * T + own) * D + h * HD, (size_t)D, o, lane);
+    }
+  }
+}
+
 // ---------------------------------------------------------------- parity tier (fp32, VALU)
 template <int HD>
 __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ qk,
@@ -310,6 +455,23 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
     if (head_dim != 64 && head_dim != 72) {
       set_error("attention: the bf16 tier is built for head_dim 64 and 72 (got %d); use the f32 tier", head_dim);
       return OSUD_ERR_UNSUPPORTED;
+    }
+    const char* stream_env = getenv("OSUD_ATTN_FWD_STREAM");  // "0": the general kernel (A/B runs, tests)
+    if (head_dim == 64 && T == 128 && Tp == 128 && mask == nullptr && fp8_scale <= 0.f && ld_qk == 3 * D && !(stream_env && stream_env[0] == '0')) {
+      static bool stream_attr = false;
+      constexpr size_t slds = (size_t)8 * 128 * AttnTile<64>::RS + 8 * 2048;
+      if (!stream_attr) {
+        OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_stream_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+        stream_attr = true;
+      }
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+      const int items = N * heads, npairs = (items + 1) / 2;
+      hipLaunchKernelGGL((attn_fwd_stream_kernel<128>), dim3(npairs < cus ? npairs : cus), dim3(512), slds, st, (const bf16_t*)qk,
+                         (bf16_t*)out, lse, D, heads, items, scale * 1.4426950408889634f);
+      OSUD_HIP(hipGetLastError());
+      return OSUD_OK;
     }
     dim3 grid((Tp + 127) / 128, heads, N);
     static const bool one_block = [] { const char* e = getenv("OSUD_ATTN_KB"); return !(e && e[0] == '2'); }();

@@ -128,37 +128,6 @@ __device__ __forceinline__ void attn_bwd_store(bf16_t* orow, const f32x16 (&acc)
     }
 }
 
-// The same rows through a 2 KiB LDS patch of the wave (head_dim 64): a lane owns a ROW of the accumulators, so a direct store
-// instruction touches 32 rows with 16 bytes each -- 24 such instructions per head and wave were 56 of the streamed kernel's 132 us
-// (tools/attn_bench.py with the stores compiled out).  Sixteen rows at a time go to the patch (16-byte chunks XOR-swizzled with
-// the row) and come back as 16 bytes per lane, eight lanes per 128-byte row: every store instruction writes eight full lines.
-__device__ __forceinline__ void attn_bwd_store_patch(char* patch, bf16_t* rows, size_t ld, const f32x16 (&acc)[2], int lane) {
-  const int frow = lane & 31, fhalf = lane >> 5;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if ((frow >> 4) == half) {
-      const int r = frow & 15;
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          u32x2 v;
-          v[0] = pack_bf2(acc[dt][4 * g], acc[dt][4 * g + 1]);
-          v[1] = pack_bf2(acc[dt][4 * g + 2], acc[dt][4 * g + 3]);
-          *reinterpret_cast<u32x2*>(patch + r * 128 + (((dt * 4 + g) ^ (r & 7)) << 4) + fhalf * 8) = v;
-        }
-    }
-    asm volatile("" ::: "memory");  // (LDS operations of a wave execute in order; this only pins the compiler's order)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int rr = (lane >> 3) + 8 * j, c = lane & 7;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(patch + rr * 128 + ((c ^ (rr & 7)) << 4));
-      *reinterpret_cast<u32x4*>(rows + (size_t)(16 * half + rr) * ld + c * 8) = v;
-    }
-    asm volatile("" ::: "memory");
-  }
-}
-
 template <int HD, int HDP, int NT>
 __global__ __launch_bounds__(NT) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                             const bf16_t* __restrict__ O, const float* __restrict__ lse,
@@ -379,7 +348,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __re
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next head (issued a whole pass ago)
         put_stats(buf ^ 1);
       }
-      if (!(OSUD_ATTN_EXP & 1)) attn_bwd_store_patch(patch, orows, ld3, dq, lane);
+      if (!(OSUD_ATTN_EXP & 1)) store_rows_patch(patch, orows, ld3, dq, lane);
       else if (dq[0][0] == 12345.f) orow[0] = 1;
     } else {
       f32x16 dk[DT], dv[DT];
@@ -395,8 +364,8 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __re
         put_stats(buf ^ 1);
       }
       if (!(OSUD_ATTN_EXP & 1)) {
-      attn_bwd_store_patch(patch, orows + D, ld3, dk, lane);
-      attn_bwd_store_patch(patch, orows + 2 * D, ld3, dv, lane);
+      store_rows_patch(patch, orows + D, ld3, dk, lane);
+      store_rows_patch(patch, orows + 2 * D, ld3, dv, lane);
       } else if (dk[0][0] + dv[0][0] == 12345.f) orow[D] = 1;
     }
   }

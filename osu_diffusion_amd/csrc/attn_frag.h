@@ -60,4 +60,35 @@ __device__ __forceinline__ u32x4 pack8(const f32x16& v, int base) {
   return r;
 }
 
+// 32 accumulator rows of a wave (lane = row, 64 columns) -> bf16 rows in global memory through a 2 KiB LDS patch of the wave:
+// a lane owns a ROW of the accumulators, so a direct store instruction touches 32 rows with 16 bytes each -- 24 such
+// instructions per head and wave were 56 of the streamed backward kernel's 132 us (tools/attn_bench.py, stores compiled out).  Sixteen rows at a time go to the patch (16-byte chunks XOR-swizzled with
+// the row) and come back as 16 bytes per lane, eight lanes per 128-byte row: every store instruction writes eight full lines.
+__device__ __forceinline__ void store_rows_patch(char* patch, bf16_t* rows, size_t ld, const f32x16 (&acc)[2], int lane) {
+  const int frow = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if ((frow >> 4) == half) {
+      const int r = frow & 15;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          u32x2 v;
+          v[0] = pack_bf2(acc[dt][4 * g], acc[dt][4 * g + 1]);
+          v[1] = pack_bf2(acc[dt][4 * g + 2], acc[dt][4 * g + 3]);
+          *reinterpret_cast<u32x2*>(patch + r * 128 + (((dt * 4 + g) ^ (r & 7)) << 4) + fhalf * 8) = v;
+        }
+    }
+    asm volatile("" ::: "memory");  // (LDS operations of a wave execute in order; this only pins the compiler's order)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int rr = (lane >> 3) + 8 * j, c = lane & 7;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(patch + rr * 128 + ((c ^ (rr & 7)) << 4));
+      *reinterpret_cast<u32x4*>(rows + (size_t)(16 * half + rr) * ld + c * 8) = v;
+    }
+    asm volatile("" ::: "memory");
+  }
+}
+
 }  // namespace osud

@@ -106,9 +106,12 @@ def test_gemm_rejects_bad_shapes():
 
 # ------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("prec,tol", [(_lib.PREC_BF16, 2e-2), (_lib.PREC_F32, 2e-5)])
-@pytest.mark.parametrize("T_,masked", [(64, False), (128, False), (200, True), (77, False)])
-def test_attention_core(prec, tol, T_, masked):
-    N, H, hd = 2, 2, 64
+@pytest.mark.parametrize("T_,masked,N,H", [(64, False, 2, 2), (128, False, 2, 2), (200, True, 2, 2), (77, False, 2, 2),
+                                            (128, False, 41, 13), (128, True, 3, 2)])
+def test_attention_core(prec, tol, T_, masked, N, H):
+    """(N, H) = (41, 13): 533 heads at T = 128 without a mask -- the persistent streamed kernel of the bf16 tier with more head pairs
+    than compute units (a second loop iteration on some workgroups) and an odd head count (a half-empty last pair)."""
+    hd = 64
     D = H * hd
     Tp = (T_ + 63) // 64 * 64
     Mp = (N * Tp + 127) // 128 * 128
