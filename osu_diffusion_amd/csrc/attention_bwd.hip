@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // STREAMS the other side through two LDS tiles of 128 rows, so that T is unbounded (DiT-XL at T = 256, long sequences):
 // LDS = 2 x 128 x row stride + 1 KiB.  The owned rows' fragments come straight from global memory; delta is precomputed.
 template <int HD, int HDP>
-__global__ __launch_bounds__(256) void attn_bwd_tiled_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+__global__ __launch_bounds__(256, 2) void attn_bwd_tiled_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                              const float* __restrict__ lse, const float* __restrict__ delta,
                                                              bf16_t* __restrict__ dqkv, int T, int D, float c1, float scale) {
   using TL = AttnTile<HDP>;
