@@ -552,6 +552,278 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_tiled_kernel(const bf16_t* __
   }
 }
 
+// ------------------------------------------------------------------------- T == 256, head_dim 72 (DiT-XL): persistent, streamed
+// Four tiles of 256 x 96 (padded) columns do not fit the LDS, so the tiled kernel above gives a workgroup 128 queries / 128 keys
+// and lets it stream the other side: every tile is read twice, through registers, by workgroups that alternate between loading
+// and computing -- 426 us for 600 MB of algorithmic traffic (a device copy of those bytes: 110 us).  Here one eight-wave workgroup
+// per CU walks heads; a head is four block steps -- K|V rows 0..127, K|V 128..255 (all eight waves in the dQ pass, 32 queries
+// each), then Q|dO 0..127, Q|dO 128..255 (the dK/dV pass, 32 keys each) -- whose 128-row tile pairs (52 KiB) arrive by LDS-DMA in
+// a two-stage ring, one step ahead, across head boundaries.  The rows a wave owns (B operands of the score products) and the next
+// head's lse / delta come straight from global memory one pass ahead.  EVERY vector-memory instruction in the loop except the
+// stores is inline asm, so that the compiler inserts no wait of its own (it cannot see the DMA pieces and would wait for them,
+// or for the previous pass's stores); the waits below are counted by hand -- vector memory retires in issue order:
+//   per wave and head:  step 0: P DMA pieces, 10 fragment loads (K, V rows) | step 1: P pieces ... 6 stores (dQ)
+//                       step 2: P pieces | step 3: P pieces ... 10 fragment loads (next head's Q, dO rows), 2 statistics loads,
+//                       12 stores (dK, dV)
+__device__ uint4 g_attn_zero16 = {0u, 0u, 0u, 0u};  // source of the zero pad columns 72..95 of a tile row
+
+__device__ __forceinline__ void gload16(u32x4& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void gload4(float& dst, const void* p) {
+  asm volatile("global_load_dword %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+}
+#define OSUD_VM_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+
+// 32 accumulator rows (lane = row, 72 real of 96 columns) -> bf16 rows of 144 bytes through a 16-row LDS patch of the wave:
+// 6 store instructions per tile (2 x 16 rows x 9 chunks = 288 chunks of 16 bytes), each writing whole 144-byte rows
+__device__ __forceinline__ void store_rows_patch72(char* patch, bf16_t* rows, size_t ld, const f32x16 (&acc)[3], int lane) {
+  asm volatile("" : "+v"(lane));  // (opaque: per-lane offsets are recomputed per call instead of living in registers across the passes)
+  const int frow = lane & 31, fhalf = lane >> 5;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    if ((frow >> 4) == half) {
+      const int r = frow & 15;
+#pragma unroll
+      for (int dt = 0; dt < 3; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = dt * 32 + 8 * g + 4 * fhalf;
+          if (d < 72) {
+            u32x2 v;
+            v[0] = pack_bf2(acc[dt][4 * g], acc[dt][4 * g + 1]);
+            v[1] = pack_bf2(acc[dt][4 * g + 2], acc[dt][4 * g + 3]);
+            *reinterpret_cast<u32x2*>(patch + r * 208 + d * 2) = v;
+          }
+        }
+    }
+    asm volatile("" ::: "memory");  // (LDS operations of a wave execute in order; this only pins the compiler's order)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int idx = j * 64 + lane;
+      if (idx < 144) {
+        const int rr = idx / 9, c = idx - 9 * rr;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(patch + rr * 208 + c * 16);
+        *reinterpret_cast<u32x4*>(rows + (size_t)(16 * half + rr) * ld + c * 8) = v;
+      }
+    }
+    asm volatile("" ::: "memory");
+  }
+}
+
+template <int T>
+__global__ __launch_bounds__(512, 2) void attn_bwd_stream72_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
+                                                                   const float* __restrict__ lse, const float* __restrict__ delta,
+                                                                   bf16_t* __restrict__ dqkv, int D, int H, int items, float c1,
+                                                                   float scale) {
+  constexpr int HD = 72, HDP = 96, KS = 5, DT = 3, BLK = 128;  // KS: 16-column k-steps that hold real columns (72 -> 5; the sixth is all pad)
+  using TL = AttnTile<HDP>;
+  constexpr int TILE = BLK * TL::RS, STAGE = 2 * TILE;  // 26 624 / 53 248 bytes
+  static_assert(T == 256 && TL::RS == 208, "eight waves x 32 rows, two 128-row blocks per side");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][X | Y][TILE] | lse_s[2][T] | del_s[2][T] | patches [8][16 x 208]
+  float* lse_s = reinterpret_cast<float*>(smem + 2 * STAGE);
+  float* del_s = lse_s + 2 * T;
+  char* patch = reinterpret_cast<char*>(del_s + 2 * T) + (threadIdx.x >> 6) * (16 * 208);
+  const uint32_t lds0 = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const size_t ld3 = 3 * (size_t)D;
+  const int own = wave * 32;
+  // ---- LDS-DMA of one stage: 52 pieces of 1 KiB (64 lanes x 16 bytes, written linearly = 13 chunks per 208-byte row);
+  //      waves 0..3 issue 7 pieces, waves 4..7 six.  Lane -> (row, chunk); chunks 9..12 (pad columns, stride pad) read zeros.
+  const int p_first = wave < 4 ? 7 * wave : 28 + 6 * (wave - 4), p_count = wave < 4 ? 7 : 6;
+  const char* zsrc = reinterpret_cast<const char*>(&g_attn_zero16);
+  auto issue = [&](int head, int step, int stage) {  // step 0,1: K|V block step; 2,3: Q|dO block step - 2
+    const int n = head / H, h = head - n * H;
+    const int blk = step & 1;
+    const char* xb = reinterpret_cast<const char*>(qkv + ((size_t)n * T + blk * BLK) * ld3 + (step < 2 ? D : 0) + h * HD);
+    const char* yb = step < 2 ? reinterpret_cast<const char*>(qkv + ((size_t)n * T + blk * BLK) * ld3 + 2 * D + h * HD)
+                              : reinterpret_cast<const char*>(dO + ((size_t)n * T + blk * BLK) * D + h * HD);
+    const size_t xld = ld3 * 2, yld = (step < 2 ? ld3 : (size_t)D) * 2;
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));  // (opaque: the per-piece addresses are recomputed here, not kept in 30 registers across the passes)
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      if (q < p_count) {
+        const int p = p_first + q, t = p >= 26 ? 1 : 0, pp = p - 26 * t;  // wave-uniform
+        const int gi = pp * 64 + lane_o, row = (gi * 5042) >> 16, c = gi - 13 * row;
+        const char* src = c < 9 ? (t ? yb + (size_t)row * yld : xb + (size_t)row * xld) + c * 16 : zsrc;
+        const uint32_t dst = lds0 + (uint32_t)(stage * STAGE + t * TILE + pp * 1024);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory");
+      }
+    }
+  };
+  // ---- the rows this wave owns, as B-operand fragments straight from global memory: chunk 2 ks + fhalf of row own + frow
+  //      (five loads per tensor: k-steps 0..4; chunk 9 of k-step 4 is a pad column = zero; k-step 5 would be all pad: skipped)
+  auto fetch_frags = [&](int head, const bf16_t* a, size_t lda, int cola, const bf16_t* b, size_t ldb, int colb, u32x4 (&fa)[KS],
+                         u32x4 (&fb)[KS]) {
+    const int n = head / H, h = head - n * H;
+    const bf16_t* pa = a + ((size_t)n * T + own + frow) * lda + cola + h * HD;
+    const bf16_t* pb = b + ((size_t)n * T + own + frow) * ldb + colb + h * HD;
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      const int c = (ks == 4 && fhalf) ? 8 : 2 * ks + fhalf;  // (the pad chunk's lanes read a valid chunk and drop it)
+      gload16(fa[ks], pa + c * 8);
+      gload16(fb[ks], pb + c * 8);
+    }
+  };
+  auto settle_frags = [&](u32x4 (&fa)[KS], u32x4 (&fb)[KS]) {  // after the counted wait: the registers are defined from here
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int ks = 0; ks < 5; ++ks) {
+      asm volatile("" : "+v"(fa[ks]), "+v"(fb[ks]));
+    }
+    if (fhalf) fa[4] = fb[4] = zero4;
+  };
+  u32x4 qf[KS], of[KS], kf[KS], vf[KS];
+  float lreg = 0.f, dreg = 0.f;
+  auto fetch_stats = [&](int head) {  // thread t < T: lse / delta of query t (the other threads read entry 0 and drop it)
+    const int n = head / H, h = head - n * H;
+    const size_t o = ((size_t)n * H + h) * T + (tid < T ? tid : 0);
+    gload4(lreg, lse + o);
+    gload4(dreg, delta + o);
+  };
+  auto put_stats = [&](int sb) {
+    asm volatile("" : "+v"(lreg), "+v"(dreg));
+    if (tid < T) {
+      lse_s[sb * T + tid] = lreg;
+      del_s[sb * T + tid] = dreg;
+    }
+  };
+
+  int it = blockIdx.x, hb = 0;  // hb: statistics buffer of this head
+  if (it < items) {
+    issue(it, 0, 0);
+    fetch_frags(it, qkv, ld3, 0, dO, (size_t)D, 0, qf, of);
+    fetch_stats(it);
+    OSUD_VM_WAIT(0);
+    settle_frags(qf, of);
+    put_stats(0);
+  }
+  for (; it < items; it += gridDim.x, hb ^= 1) {
+    const int nx = it + gridDim.x;
+    const int n = it / H, h = it - n * H;
+    const float* lse_b = lse_s + hb * T;
+    const float* del_b = del_s + hb * T;
+    bf16_t* orows = dqkv + ((size_t)n * T + own) * ld3 + h * HD;
+    // =============================== pass A: dQ for queries own..own+31; K | V blocks streamed ======================
+    {
+      f32x16 dq[DT];
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq[i][r] = 0.f;
+      float my_lse = 0.f, my_del = 0.f;
+#pragma unroll
+      for (int step = 0; step < 2; ++step) {
+        // this step's tiles have landed (step 0: issued in step 3 of the previous head, with this head's fragments and statistics
+        // and the 12 dK / dV stores behind them; step 1: issued in step 0, 10 fragment loads behind them)
+        if (step == 0) {
+          OSUD_VM_WAIT(12);
+          if (it != (int)blockIdx.x) {  // (the first head's were settled in the prologue)
+            settle_frags(qf, of);
+            put_stats(hb);
+          }
+        } else {
+          OSUD_VM_WAIT(10);
+        }
+        __syncthreads();
+        if (step == 0) {
+          my_lse = lse_b[own + frow];
+          my_del = del_b[own + frow];
+        }
+        issue(it, step + 1, (step + 1) & 1);
+        if (step == 0) fetch_frags(it, qkv, ld3, D, qkv, ld3, 2 * D, kf, vf);
+        const char* Xs = smem + (step & 1) * STAGE;
+        const char* Ys = Xs + TILE;
+        for (int kt = 0; kt < BLK / 32; ++kt) {
+          f32x16 s, dp;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            s = mfma_bf16(rowfrag<HDP>(Xs, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s);    // D[key][query]
+            dp = mfma_bf16(rowfrag<HDP>(Ys, kt * 32 + frow, 2 * ks + fhalf), of[ks], dp);  // dO . V^T
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(s[r] * c1 - my_lse);
+            s[r] = p * (dp[r] - my_del) * scale;  // dS
+          }
+#pragma unroll
+          for (int ss = 0; ss < 2; ++ss) {
+            const u32x4 dsf = pack8(s, 8 * ss);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) dq[dt] = mfma_bf16(trfrag<HDP>(Xs, kt * 32 + 16 * ss, dt * 32, lane), dsf, dq[dt]);
+          }
+        }
+      }
+      store_rows_patch72(patch, orows, ld3, dq, lane);  // 6 stores
+    }
+    // =============================== pass B: dK, dV for keys own..own+31; Q | dO blocks streamed =====================
+    {
+      f32x16 dk[DT], dv[DT];
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dk[i][r] = dv[i][r] = 0.f;
+#pragma unroll
+      for (int step = 2; step < 4; ++step) {
+        // step 2: tiles issued in step 1, the 6 dQ stores behind them (this pass's fragments are older: landed as well);
+        // step 3: tiles issued in step 2, nothing behind them
+        if (step == 2) { OSUD_VM_WAIT(6); } else { OSUD_VM_WAIT(0); }
+        __syncthreads();
+        if (step == 2) {
+          settle_frags(kf, vf);
+          issue(it, 3, 1);
+        } else {
+          issue(nx < items ? nx : it, 0, 0);  // (past the last head: a harmless re-read into the free stage)
+        }
+        const char* Xs = smem + (step & 1) * STAGE;
+        const char* Ys = Xs + TILE;
+        const int q0 = (step - 2) * BLK;
+        for (int qt = 0; qt < BLK / 32; ++qt) {
+          f32x16 s, dp;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[r] = dp[r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            s = mfma_bf16(rowfrag<HDP>(Xs, qt * 32 + frow, 2 * ks + fhalf), kf[ks], s);    // D[query][key]
+            dp = mfma_bf16(rowfrag<HDP>(Ys, qt * 32 + frow, 2 * ks + fhalf), vf[ks], dp);
+          }
+          f32x16 p;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_b + q0 + qt * 32 + 8 * g + 4 * fhalf);
+            const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_b + q0 + qt * 32 + 8 * g + 4 * fhalf);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              const float pv = __builtin_amdgcn_exp2f(s[4 * g + i] * c1 - l4[i]);
+              p[4 * g + i] = pv;
+              s[4 * g + i] = pv * (dp[4 * g + i] - d4[i]) * scale;
+            }
+          }
+#pragma unroll
+          for (int ss = 0; ss < 2; ++ss) {
+            const u32x4 pf = pack8(p, 8 * ss), dsf = pack8(s, 8 * ss);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              dv[dt] = mfma_bf16(trfrag<HDP>(Ys, qt * 32 + 16 * ss, dt * 32, lane), pf, dv[dt]);
+              dk[dt] = mfma_bf16(trfrag<HDP>(Xs, qt * 32 + 16 * ss, dt * 32, lane), dsf, dk[dt]);
+            }
+          }
+        }
+      }
+      // the next head's own rows and statistics: issued here, where the score registers are dead, in front of this head's stores;
+      // they are waited for together with the next head's first tiles (the last head re-reads its own: same instruction counts)
+      fetch_frags(nx < items ? nx : it, qkv, ld3, 0, dO, (size_t)D, 0, qf, of);
+      fetch_stats(nx < items ? nx : it);
+      store_rows_patch72(patch, orows + D, ld3, dk, lane);      // 6 stores
+      store_rows_patch72(patch, orows + 2 * D, ld3, dv, lane);  // 6 stores
+    }
+  }
+}
+
 // ------------------------------------------------------------------------- f32 tier (VALU)
 template <int HD>
 __global__ __launch_bounds__(64) void attn_bwd_dq_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ dO,
@@ -674,6 +946,26 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
       OSUD_CHECK_ARG(delta_ws != nullptr, "attention backward: T=%d needs the delta workspace", T);
       const int rows = N * T * heads;
       const dim3 grid((T + 127) / 128, heads, N);
+      const char* s72_env = getenv("OSUD_ATTN_BWD_STREAM");
+      if (head_dim == 72 && T == 256 && !force_tiled && !(s72_env && s72_env[0] == '0')) {  // DiT-XL: persistent streamed kernel
+        hipLaunchKernelGGL((attn_delta_kernel<72>), dim3((rows + 255) / 256), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O,
+                           delta_ws, N, T, heads);
+        static bool attr72 = false;
+        constexpr size_t lds72 = (size_t)4 * 128 * AttnTile<96>::RS + 4 * 256 * 4 + 8 * 16 * 208;
+        if (!attr72) {
+          OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_stream72_kernel<256>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          attr72 = true;
+        }
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        const int items = N * heads;
+        hipLaunchKernelGGL((attn_bwd_stream72_kernel<256>), dim3(items < cus ? items : cus), dim3(512), lds72, st, (const bf16_t*)qkv,
+                           (const bf16_t*)dO, lse, delta_ws, (bf16_t*)dqkv, D, heads, items, c1t, scale);
+        OSUD_HIP(hipGetLastError());
+        if (dbias != nullptr) OSUD_TRY(launch_colsum_bf16(dqkv, 3 * D, N * T, 3 * D, dbias, st));
+        return OSUD_OK;
+      }
       if (head_dim == 64) {
         hipLaunchKernelGGL((attn_delta_kernel<64>), dim3((rows + 255) / 256), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O,
                            delta_ws, N, T, heads);

@@ -139,13 +139,15 @@ def test_attention_core(prec, tol, T_, masked, N, H):
 
 
 @pytest.mark.parametrize("prec,tol", [(_lib.PREC_BF16, 3e-2), (_lib.PREC_F32, 5e-5)])
-@pytest.mark.parametrize("N,H,T_,stream", [(3, 2, 64, "1"), (24, 12, 128, "1"), (24, 12, 128, "0"), (2, 2, 256, "1"), (2, 2, 320, "1")])
-def test_attention_core_backward(prec, tol, N, H, T_, stream, monkeypatch):
+@pytest.mark.parametrize("N,H,T_,stream,hd", [(3, 2, 64, "1", 64), (24, 12, 128, "1", 64), (24, 12, 128, "0", 64), (2, 2, 256, "1", 64),
+                                              (2, 2, 320, "1", 64), (2, 3, 256, "1", 72), (2, 3, 256, "0", 72), (34, 16, 256, "1", 72),
+                                              (2, 2, 128, "1", 72)])
+def test_attention_core_backward(prec, tol, N, H, T_, stream, hd, monkeypatch):
     """osud_op_attention_bwd against torch autograd of softmax(q k^T / sqrt(hd)) v on the same (rounded) operands.  N*H = 288 heads
     at T = 128 is more than one per compute unit: the persistent streamed kernel runs its double-buffered loop (a second head on
-    32 of the workgroups); OSUD_ATTN_BWD_STREAM=0 selects the one-workgroup-per-head kernel; T = 320 the tiled one."""
+    32 of the workgroups); OSUD_ATTN_BWD_STREAM=0 selects the one-workgroup-per-head kernel; T = 320 the tiled one.  head_dim 72 at
+    T = 256 is DiT-XL's shape: its own streamed kernel (34 x 16 = 544 heads: up to three per workgroup), or the tiled one with "0"."""
     monkeypatch.setenv("OSUD_ATTN_BWD_STREAM", stream)
-    hd = 64
     D = H * hd
     M = N * T_
     torch.manual_seed(N * 1000 + T_)

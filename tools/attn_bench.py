@@ -3,6 +3,7 @@
 (osud_op_attention_bwd) at N = 256 windows x 12 heads x T = 128, next to the bytes each has to move.
 
   python tools/attn_bench.py [N] [T]        # OSUD_ATTN_BWD_STREAM=0 selects the one-workgroup-per-head backward kernel
+  H=16 HD=72 python tools/attn_bench.py 128 256     # DiT-XL's shape
 """
 import os, sys
 import torch
@@ -13,7 +14,7 @@ L = _lib.lib()
 dev = torch.device("cuda:0")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-H, hd = 12, 64
+H, hd = int(os.environ.get("H", "12")), int(os.environ.get("HD", "64"))
 D, M = H * hd, N * T
 bf = torch.bfloat16
 qkv = torch.randn(M, 3 * D, device=dev).to(bf)
