@@ -368,6 +368,141 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const bf16_t* __re
   }
 }
 
+// ---------------------------------------------------------------- T == Tp == 256, head_dim 72 (DiT-XL), no mask: persistent, streamed
+// One eight-wave workgroup per CU walks heads (a wave owns 32 of the 256 queries); the K | V tile pairs of 128 keys (52 KiB, rows of
+// 208 bytes, pad columns read from a zero chunk) arrive by LDS-DMA in a two-stage ring, one step ahead, across head boundaries;
+// the next head's Q rows are fetched behind the second step; every load in the loop is inline asm and the waits are counted by
+// hand (see attn_bwd_stream72_kernel); online softmax across the two key blocks; the sixth k-step (columns 80..95: all pad) is
+// skipped; output rows leave as whole 144-byte rows through LDS patches.
+//   per wave and head:  step 0: P DMA pieces | step 1: P pieces ... 5 fragment loads (next head's Q rows), 6 stores (+1: lse)
+template <int T>
+__global__ __launch_bounds__(512, 2) void attn_fwd_stream72_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                   float* __restrict__ lse, int D, int H, int items, float c1) {
+  constexpr int HD = 72, HDP = 96, KS = 5, DT = 3, BLK = 128;
+  using TL = AttnTile<HDP>;
+  constexpr int TILE = BLK * TL::RS, STAGE = 2 * TILE;
+  static_assert(T == 256 && TL::RS == 208, "eight waves x 32 queries, two 128-key blocks");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K | V][TILE] | patches [8][16 x 208]
+  char* patch = smem + 2 * STAGE + (threadIdx.x >> 6) * (16 * 208);
+  const uint32_t lds0 = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const size_t ld3 = 3 * (size_t)D;
+  const int own = wave * 32;
+  const int p_first = wave < 4 ? 7 * wave : 28 + 6 * (wave - 4), p_count = wave < 4 ? 7 : 6;
+  const char* zsrc = reinterpret_cast<const char*>(&g_attn_zero16);
+  auto issue = [&](int head, int blk, int stage) {
+    const int n = head / H, h = head - n * H;
+    const char* xb = reinterpret_cast<const char*>(qkv + ((size_t)n * T + blk * BLK) * ld3 + D + h * HD);
+    const char* yb = xb + (size_t)D * 2;
+    const size_t ldb = ld3 * 2;
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));  // (opaque: the per-piece addresses are recomputed here, not kept in registers)
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+      if (q < p_count) {
+        const int p = p_first + q, t = p >= 26 ? 1 : 0, pp = p - 26 * t;  // wave-uniform
+        const int gi = pp * 64 + lane_o, row = (gi * 5042) >> 16, c = gi - 13 * row;
+        const char* src = c < 9 ? (t ? yb : xb) + (size_t)row * ldb + c * 16 : zsrc;
+        const uint32_t dst = lds0 + (uint32_t)(stage * STAGE + t * TILE + pp * 1024);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory");
+      }
+    }
+  };
+  u32x4 qf[KS];
+  auto fetch_q = [&](int head) {
+    const int n = head / H, h = head - n * H;
+    const bf16_t* pq = qkv + ((size_t)n * T + own + frow) * ld3 + h * HD;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) gload16(qf[ks], pq + ((ks == 4 && fhalf) ? 8 : 2 * ks + fhalf) * 8);
+  };
+  auto settle_q = [&]() {
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
+    if (fhalf) qf[4] = zero4;  // chunk 9: pad columns 72..79
+  };
+  int it = blockIdx.x;
+  if (it < items) {
+    issue(it, 0, 0);
+    fetch_q(it);
+    OSUD_VM_WAIT(0);
+  }
+  for (; it < items; it += gridDim.x) {
+    const int nx = it + gridDim.x;
+    const int n = it / H, h = it - n * H;
+    f32x16 o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
+      // step 0: this head's first tiles (issued in step 1 of the previous head) and Q rows, the 6 output stores behind them;
+      // step 1: tiles issued in step 0, nothing behind them
+      if (step == 0) { OSUD_VM_WAIT(6); } else { OSUD_VM_WAIT(0); }
+      if (step == 0) settle_q();
+      __syncthreads();
+      if (step == 0) issue(it, 1, 1);
+      else issue(nx < items ? nx : it, 0, 0);  // (past the last head: a harmless re-read into the free stage)
+      const char* Ks = smem + step * STAGE;
+      const char* Vs = Ks + TILE;
+      f32x16 s[4];
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) s[kt] = mfma_bf16(rowfrag<HDP>(Ks, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s[kt]);
+      }
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          s[kt][r] *= c1;
+          mx = fmaxf(mx, s[kt][r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = fast_exp2(m_run - m_new);  // first block: exp2(-inf) = 0
+      float psum = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = fast_exp2(s[kt][r] - m_new);
+          s[kt][r] = p;
+          psum += p;
+        }
+      psum += __shfl_xor(psum, 32, 64);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int ss = 0; ss < 2; ++ss) {
+          const u32x4 pf = pack8(s[kt], 8 * ss);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) o[dt] = mfma_bf16(trfrag<HDP>(Vs, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
+        }
+    }
+    fetch_q(nx < items ? nx : it);  // in front of the stores; waited for with the next head's first tiles
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= inv;
+    store_rows_patch72(patch, out + ((size_t)n * T + own) * D + h * HD, (size_t)D, o, lane);
+    if (lse != nullptr && fhalf == 0) lse[((size_t)n * H + h) * T + own + frow] = m_run + __builtin_amdgcn_logf(l_run);
+  }
+}
+
 // ---------------------------------------------------------------- parity tier (fp32, VALU)
 template <int HD>
 __global__ __launch_bounds__(64) void attn_f32_kernel(const float* __restrict__ qk,
@@ -469,6 +604,22 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
       const int items = N * heads, npairs = (items + 1) / 2;
       hipLaunchKernelGGL((attn_fwd_stream_kernel<128>), dim3(npairs < cus ? npairs : cus), dim3(512), slds, st, (const bf16_t*)qk,
+                         (bf16_t*)out, lse, D, heads, items, scale * 1.4426950408889634f);
+      OSUD_HIP(hipGetLastError());
+      return OSUD_OK;
+    }
+    if (head_dim == 72 && T == 256 && Tp == 256 && mask == nullptr && fp8_scale <= 0.f && ld_qk == 3 * D && !(stream_env && stream_env[0] == '0')) {
+      static bool attr72 = false;
+      constexpr size_t lds72 = (size_t)4 * 128 * AttnTile<96>::RS + 8 * 16 * 208;
+      if (!attr72) {
+        OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_stream72_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+        attr72 = true;
+      }
+      int dev = 0, cus = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+      const int items = N * heads;
+      hipLaunchKernelGGL((attn_fwd_stream72_kernel<256>), dim3(items < cus ? items : cus), dim3(512), lds72, st, (const bf16_t*)qk,
                          (bf16_t*)out, lse, D, heads, items, scale * 1.4426950408889634f);
       OSUD_HIP(hipGetLastError());
       return OSUD_OK;

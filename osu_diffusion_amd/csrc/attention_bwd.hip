@@ -565,52 +565,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_tiled_kernel(const bf16_t* __
 //   per wave and head:  step 0: P DMA pieces, 10 fragment loads (K, V rows) | step 1: P pieces ... 6 stores (dQ)
 //                       step 2: P pieces | step 3: P pieces ... 10 fragment loads (next head's Q, dO rows), 2 statistics loads,
 //                       12 stores (dK, dV)
-__device__ uint4 g_attn_zero16 = {0u, 0u, 0u, 0u};  // source of the zero pad columns 72..95 of a tile row
-
-__device__ __forceinline__ void gload16(u32x4& dst, const void* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void gload4(float& dst, const void* p) {
-  asm volatile("global_load_dword %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
-}
-#define OSUD_VM_WAIT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-
-// 32 accumulator rows (lane = row, 72 real of 96 columns) -> bf16 rows of 144 bytes through a 16-row LDS patch of the wave:
-// 6 store instructions per tile (2 x 16 rows x 9 chunks = 288 chunks of 16 bytes), each writing whole 144-byte rows
-__device__ __forceinline__ void store_rows_patch72(char* patch, bf16_t* rows, size_t ld, const f32x16 (&acc)[3], int lane) {
-  asm volatile("" : "+v"(lane));  // (opaque: per-lane offsets are recomputed per call instead of living in registers across the passes)
-  const int frow = lane & 31, fhalf = lane >> 5;
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    if ((frow >> 4) == half) {
-      const int r = frow & 15;
-#pragma unroll
-      for (int dt = 0; dt < 3; ++dt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d = dt * 32 + 8 * g + 4 * fhalf;
-          if (d < 72) {
-            u32x2 v;
-            v[0] = pack_bf2(acc[dt][4 * g], acc[dt][4 * g + 1]);
-            v[1] = pack_bf2(acc[dt][4 * g + 2], acc[dt][4 * g + 3]);
-            *reinterpret_cast<u32x2*>(patch + r * 208 + d * 2) = v;
-          }
-        }
-    }
-    asm volatile("" ::: "memory");  // (LDS operations of a wave execute in order; this only pins the compiler's order)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int idx = j * 64 + lane;
-      if (idx < 144) {
-        const int rr = idx / 9, c = idx - 9 * rr;
-        const u32x4 v = *reinterpret_cast<const u32x4*>(patch + rr * 208 + c * 16);
-        *reinterpret_cast<u32x4*>(rows + (size_t)(16 * half + rr) * ld + c * 8) = v;
-      }
-    }
-    asm volatile("" ::: "memory");
-  }
-}
-
 template <int T>
 __global__ __launch_bounds__(512, 2) void attn_bwd_stream72_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                                    const float* __restrict__ lse, const float* __restrict__ delta,

@@ -106,12 +106,13 @@ def test_gemm_rejects_bad_shapes():
 
 # ------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("prec,tol", [(_lib.PREC_BF16, 2e-2), (_lib.PREC_F32, 2e-5)])
-@pytest.mark.parametrize("T_,masked,N,H", [(64, False, 2, 2), (128, False, 2, 2), (200, True, 2, 2), (77, False, 2, 2),
-                                            (128, False, 41, 13), (128, True, 3, 2)])
-def test_attention_core(prec, tol, T_, masked, N, H):
+@pytest.mark.parametrize("T_,masked,N,H,hd", [(64, False, 2, 2, 64), (128, False, 2, 2, 64), (200, True, 2, 2, 64), (77, False, 2, 2, 64),
+                                               (128, False, 41, 13, 64), (128, True, 3, 2, 64), (256, False, 2, 3, 72),
+                                               (256, False, 34, 16, 72), (200, True, 2, 2, 72)])
+def test_attention_core(prec, tol, T_, masked, N, H, hd):
     """(N, H) = (41, 13): 533 heads at T = 128 without a mask -- the persistent streamed kernel of the bf16 tier with more head pairs
-    than compute units (a second loop iteration on some workgroups) and an odd head count (a half-empty last pair)."""
-    hd = 64
+    than compute units (a second loop iteration on some workgroups) and an odd head count (a half-empty last pair).  head_dim 72 at
+    T = 256 is DiT-XL's shape and has its own streamed kernel (544 heads: up to three per workgroup)."""
     D = H * hd
     Tp = (T_ + 63) // 64 * 64
     Mp = (N * Tp + 127) // 128 * 128
