@@ -593,15 +593,9 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
     }
     const char* stream_env = getenv("OSUD_ATTN_FWD_STREAM");  // "0": the general kernel (A/B runs, tests)
     if (head_dim == 64 && T == 128 && Tp == 128 && mask == nullptr && fp8_scale <= 0.f && ld_qk == 3 * D && !(stream_env && stream_env[0] == '0')) {
-      static bool stream_attr = false;
       constexpr size_t slds = (size_t)8 * 128 * AttnTile<64>::RS + 8 * 2048;
-      if (!stream_attr) {
-        OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_stream_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024));
-        stream_attr = true;
-      }
-      int dev = 0, cus = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+      OSUD_BIG_LDS_ONCE(attn_fwd_stream_kernel<128>);
+      const int cus = device_cus();
       const int items = N * heads, npairs = (items + 1) / 2;
       hipLaunchKernelGGL((attn_fwd_stream_kernel<128>), dim3(npairs < cus ? npairs : cus), dim3(512), slds, st, (const bf16_t*)qk,
                          (bf16_t*)out, lse, D, heads, items, scale * 1.4426950408889634f);
@@ -609,15 +603,9 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
       return OSUD_OK;
     }
     if (head_dim == 72 && T == 256 && Tp == 256 && mask == nullptr && fp8_scale <= 0.f && ld_qk == 3 * D && !(stream_env && stream_env[0] == '0')) {
-      static bool attr72 = false;
       constexpr size_t lds72 = (size_t)4 * 128 * AttnTile<96>::RS + 8 * 16 * 208;
-      if (!attr72) {
-        OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_stream72_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024));
-        attr72 = true;
-      }
-      int dev = 0, cus = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+      OSUD_BIG_LDS_ONCE(attn_fwd_stream72_kernel<256>);
+      const int cus = device_cus();
       const int items = N * heads;
       hipLaunchKernelGGL((attn_fwd_stream72_kernel<256>), dim3(items < cus ? items : cus), dim3(512), lds72, st, (const bf16_t*)qk,
                          (bf16_t*)out, lse, D, heads, items, scale * 1.4426950408889634f);

@@ -904,15 +904,9 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
       if (head_dim == 72 && T == 256 && !force_tiled && !(s72_env && s72_env[0] == '0')) {  // DiT-XL: persistent streamed kernel
         hipLaunchKernelGGL((attn_delta_kernel<72>), dim3((rows + 255) / 256), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O,
                            delta_ws, N, T, heads);
-        static bool attr72 = false;
         constexpr size_t lds72 = (size_t)4 * 128 * AttnTile<96>::RS + 4 * 256 * 4 + 8 * 16 * 208;
-        if (!attr72) {
-          OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_stream72_kernel<256>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-          attr72 = true;
-        }
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        OSUD_BIG_LDS_ONCE(attn_bwd_stream72_kernel<256>);
+        const int cus = device_cus();
         const int items = N * heads;
         hipLaunchKernelGGL((attn_bwd_stream72_kernel<256>), dim3(items < cus ? items : cus), dim3(512), lds72, st, (const bf16_t*)qkv,
                            (const bf16_t*)dO, lse, delta_ws, (bf16_t*)dqkv, D, heads, items, c1t, scale);
@@ -935,29 +929,16 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
       if (dbias != nullptr) OSUD_TRY(launch_colsum_bf16(dqkv, 3 * D, N * T, 3 * D, dbias, st));  // streamed variant: separate pass
       return OSUD_OK;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bf16_kernel<64, 64, 256>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bf16_kernel<64, 64, 512>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_bf16_kernel<72, 96, 256>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
-    }
+    OSUD_BIG_LDS_ONCE((attn_bwd_bf16_kernel<64, 64, 256>));
+    OSUD_BIG_LDS_ONCE((attn_bwd_bf16_kernel<64, 64, 512>));
+    OSUD_BIG_LDS_ONCE((attn_bwd_bf16_kernel<72, 96, 256>));
     const float c1 = scale * 1.4426950408889634f;
     const char* stream_env = getenv("OSUD_ATTN_BWD_STREAM");  // "0": the one-workgroup-per-head kernel (A/B runs, tests)
     const bool stream_on = !(stream_env && stream_env[0] == '0');
     if (head_dim == 64 && T == 128 && dbias == nullptr && stream_on) {
-      static bool stream_attr = false;
       constexpr size_t slds = (size_t)8 * 128 * AttnTile<64>::RS + 4 * 128 * 4 + 8 * 2048;
-      if (!stream_attr) {
-        OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_stream_kernel<128>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        stream_attr = true;
-      }
-      int dev = 0, cus = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+      OSUD_BIG_LDS_ONCE(attn_bwd_stream_kernel<128>);
+      const int cus = device_cus();
       const int items = N * heads;
       hipLaunchKernelGGL((attn_bwd_stream_kernel<128>), dim3(items < cus ? items : cus), dim3(512), slds, st, (const bf16_t*)qkv,
                          (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, D, heads, items, c1, scale);

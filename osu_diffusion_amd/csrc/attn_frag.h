@@ -138,4 +138,26 @@ __device__ __forceinline__ void store_rows_patch72(char* patch, bf16_t* rows, si
   }
 }
 
+// ---- host side of the kernels that want more than 64 KiB of dynamic LDS: the attribute is per device, so remember it per device
+//      (one process normally drives one GPU; tests and tools may touch several)
+inline int device_index() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev;
+}
+inline int device_cus() {
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_index()) != hipSuccess || cus <= 0) cus = 256;
+  return cus;
+}
+#define OSUD_BIG_LDS_ONCE(kernel)                                                                                                  \
+  do {                                                                                                                             \
+    static bool done_[64] = {};                                                                                                    \
+    const int d_ = device_index() & 63;                                                                                            \
+    if (!done_[d_]) {                                                                                                              \
+      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+      done_[d_] = true;                                                                                                            \
+    }                                                                                                                              \
+  } while (0)
+
 }  // namespace osud

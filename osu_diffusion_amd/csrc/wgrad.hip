@@ -49,7 +49,15 @@ template <int WY, int WX, int RY, int RX> struct WGeo {
   static constexpr int YB = BKT * ROWY, XB = BKT * ROWX, STAGE = YB + XB;
   static constexpr int NSTAGE = STAGE * 3 <= 160 * 1024 ? 3 : 2;
   static constexpr int PIECES = STAGE / 1024, PPW = PIECES / NW;   // 1 KiB LDS-DMA pieces per stage / per wave
-  static_assert(PIECES % NW == 0 && 1024 % ROWY == 0 && 1024 % ROWX == 0, "geometry");
+  // token rows of 256 / 512 bytes (128 / 256 features) divide a 1 KiB piece; rows of 384 bytes (192 features: DiT-XL's 1152 =
+  // 6 x 192) do not -- the per-lane source offsets below are computed per 16-byte chunk, so a piece may straddle token rows
+  static_assert(PIECES % NW == 0 && YB % 1024 == 0 && XB % 1024 == 0 && (ROWY == 256 || ROWY == 384 || ROWY == 512) &&
+                    (ROWX == 256 || ROWX == 384 || ROWX == 512),
+                "geometry");
+  // swizzle of the 16-byte chunk index of a token row (applied on the source side of the LDS-DMA): power-of-two rows XOR the
+  // chunk bits 2..3 with token & 3 (the 4 token rows of one transposing read fall into 4 different 64-byte bank segments);
+  // 384-byte rows start 32 banks apart, so rows t and t + 2 collide: XOR chunk bit 2 with (token >> 1) & 1
+  static constexpr int swz(int rowb, int tok) { return rowb == 384 ? ((tok >> 1) & 1) : (tok & 3); }
   static_assert(NSTAGE * STAGE + NW * 4096 <= 160 * 1024, "stage ring + epilogue patches must fit the LDS");
 };
 
@@ -141,17 +149,17 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
   //   token row = 8*fhalf + ((lane&15)>>2), feature = block + 32*i + 16*((lane>>4)&1) + 4*(lane&3)
   const uint32_t lds0 = (uint32_t)(size_t)(lds_void*)smem;
   const int tok0 = 8 * fhalf + ((lane & 15) >> 2);
-  const int sw = tok0 & 3;                                     // (token&3); +4 rows keeps it
+  const int swy = G::swz(G::ROWY, tok0), swx = G::swz(G::ROWX, tok0);  // (+4 and +16 token rows keep them)
   const int fbyte = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);   // byte offset inside a 64-byte (32-feature) group
   uint32_t ya[RY], xa[RX];
 #pragma unroll
   for (int i = 0; i < RY; ++i) {
-    const int hi = (wy * RY + i) ^ sw;  // 64-byte group index, swizzled (chunk bits 2..3 <-> group bits 0..1)
+    const int hi = (wy * RY + i) ^ swy;  // 64-byte group index, swizzled (chunk bits 2..3 <-> group bits 0..1)
     ya[i] = lds0 + tok0 * G::ROWY + hi * 64 + fbyte;
   }
 #pragma unroll
   for (int j = 0; j < RX; ++j) {
-    const int hi = (wx * RX + j) ^ sw;
+    const int hi = (wx * RX + j) ^ swx;
     xa[j] = lds0 + G::YB + tok0 * G::ROWX + hi * 64 + fbyte;
   }
 
@@ -163,9 +171,10 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
     const bool isY = piece * 1024 < G::YB;
     const int rowb = isY ? G::ROWY : G::ROWX;                  // bytes per token row in this part
     const int pb = isY ? piece * 1024 : piece * 1024 - G::YB;  // byte offset inside the part
-    const int lpr = rowb / 16;                                  // lanes (16-byte chunks) per token row
-    const int tok = pb / rowb + lane / lpr, pos = lane % lpr;
-    const int c = pos ^ ((tok & 3) << 2);                       // source chunk for LDS position `pos`
+    const int lpr = rowb / 16;                                  // 16-byte chunks per token row
+    const int cidx = pb / 16 + lane;                            // this lane's chunk inside the part
+    const int tok = cidx / lpr, pos = cidx - tok * lpr;
+    const int c = pos ^ (G::swz(rowb, tok) << 2);               // source chunk for LDS position `pos`
     dma_off[q] = (uint32_t)((size_t)tok * (isY ? ldp_b : ldq_b) + c * 16);
   }
   // epilogue patch (4 KiB per wave, behind the stage ring)
@@ -188,13 +197,13 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
     TFrag<RY, RX> f0, f1;
     read_frags<RY, RX, 0, G::ROWY, G::ROWX>(f0, ya, xa, so);
     read_frags<RY, RX, 1, G::ROWY, G::ROWX>(f1, ya, xa, so);
-    if constexpr (RY + RX == 6) { OSUD_WG_WAIT(12); } else { OSUD_WG_WAIT(8); }
+    if constexpr (RY + RX == 6) { OSUD_WG_WAIT(12); } else if constexpr (RY + RX == 5) { OSUD_WG_WAIT(10); } else { OSUD_WG_WAIT(8); }
     mma_frags<RY, RX>(acc, f0);
     read_frags<RY, RX, 2, G::ROWY, G::ROWX>(f0, ya, xa, so);
-    if constexpr (RY + RX == 6) { OSUD_WG_WAIT(12); } else { OSUD_WG_WAIT(8); }
+    if constexpr (RY + RX == 6) { OSUD_WG_WAIT(12); } else if constexpr (RY + RX == 5) { OSUD_WG_WAIT(10); } else { OSUD_WG_WAIT(8); }
     mma_frags<RY, RX>(acc, f1);
     read_frags<RY, RX, 3, G::ROWY, G::ROWX>(f1, ya, xa, so);
-    if constexpr (RY + RX == 6) { OSUD_WG_WAIT(12); } else { OSUD_WG_WAIT(8); }
+    if constexpr (RY + RX == 6) { OSUD_WG_WAIT(12); } else if constexpr (RY + RX == 5) { OSUD_WG_WAIT(10); } else { OSUD_WG_WAIT(8); }
     mma_frags<RY, RX>(acc, f0);
     OSUD_WG_WAIT(0);
     mma_frags<RY, RX>(acc, f1);
@@ -492,19 +501,42 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
   // 256x256 tiles (8 waves) also for odd multiples of 128 -- DiT-XL's 1152 and 3456 -- with half-empty edge tiles, as long as
   // the padding stays below 25 % of the work: the 128x128 geometry (4 waves) runs at ~0.55x the 256-wide kernel's rate
   // (profiles/r02_xl_*: 582 vs 1033 TFLOP/s), which made the weight gradients 30 % of a DiT-XL training step
+  const int cus = num_cus_w();
   const int t256 = ((Ny + 255) / 256) * ((Nx + 255) / 256);
   const bool big = Ny >= 256 && Nx >= 256 && (double)t256 * 65536.0 <= 1.25 * (double)Ny * (double)Nx;
-  const int tiles = big ? t256 : (Ny / 128) * (Nx / 128);
+  // ... and 256x192 / 192x256 tiles where a side is a multiple of 192 (1152 = 6 x 192, 3456 = 18 x 192, 4608 = 24 x 192) and
+  // that fills the chip better: useful fraction of the tiles x fraction of the CUs that one round of tiles x splits occupies
+  // (fc1 of DiT-XL, 4608 x 1152: 90 padded 256-wide tiles x 2 splits = 180 of 256 CUs at 90 % useful; 108 exact 256x192 tiles
+  // x 2 = 216 CUs).  The narrower tile reads 11 % more LDS bytes per MFMA, so it has to win by more than that.
+  auto score = [&](int bm, int bn, int* tiles_out) {
+    const int t = ((Ny + bm - 1) / bm) * ((Nx + bn - 1) / bn);
+    int s = cus / t;
+    if (s > 32) s = 32;
+    while (s > 1 && (M / BKT) / s < 8) --s;
+    if (s < 1) s = 1;
+    const int rounds = (t * s + cus - 1) / cus;
+    *tiles_out = t;
+    return (double)Ny * Nx / ((double)t * bm * bn) * ((double)t * s / ((double)rounds * cus));
+  };
+  int geo = big ? 0 : 3, tiles = big ? t256 : (Ny / 128) * (Nx / 128);  // 0: 256x256, 1: 256x192, 2: 192x256, 3: 128x128
+  static const bool narrow_on = [] { const char* e = getenv("OSUD_WGRAD_192"); return !(e && e[0] == '0'); }();
+  if (big && narrow_on && !gemm_dynamic_tiles_on()) {
+    int t0 = 0, t1 = 0, t2 = 0;
+    const double s0 = score(256, 256, &t0);
+    const double s1 = Nx % 192 == 0 ? score(256, 192, &t1) : 0.0, s2 = Ny % 192 == 0 ? score(192, 256, &t2) : 0.0;
+    if (s1 >= s2 && s1 > 1.12 * s0) { geo = 1; tiles = t1; }
+    else if (s2 > s1 && s2 > 1.12 * s0) { geo = 2; tiles = t2; }
+  }
   const int stages = M / BKT;
   // fill the chip in ONE round: splits = CUs / tiles, each split at least 8 stages (512 tokens)
-  int S = num_cus_w() / tiles;
+  int S = cus / tiles;
   if (S > 32) S = 32;
   while (S > 1 && (stages / S < 8 || (size_t)S * Ny * Nx > ws_elems)) --S;
   if (S < 1) S = 1;
   WgradP p{};
   p.P = (const bf16_t*)P; p.Q = (const bf16_t*)Q; p.ldp = ldp; p.ldq = ldq; p.Ny = Ny; p.Nx = Nx; p.M = M;
   p.split_k = S; p.split_stride = (size_t)Ny * Nx; p.out = S > 1 ? ws : out;
-  if (big && S > 1 && tiles <= 62 && gemm_dynamic_tiles_on()) {  // the GPU is shared with collectives: queue the K-chunks per tile
+  if (geo == 0 && S > 1 && tiles <= 62 && gemm_dynamic_tiles_on()) {  // the GPU is shared with collectives: queue the K-chunks per tile
     const int share = stages / S, per_wg = share / 4 < 16 ? (share / 4 < 1 ? 1 : share / 4) : 16;  // chunks of >= 4 stages
     p.chunk = S * per_wg;
     p.queue = queue_slot();
@@ -521,7 +553,10 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
     p.arrive = arrive_slot();
     p.final = out;
   }
-  OSUD_TRY(big ? (launch_wg<2, 4, 4, 2>(p, st)) : (launch_wg<2, 2, 2, 2>(p, st)));
+  if (geo == 0) OSUD_TRY((launch_wg<2, 4, 4, 2>(p, st)));
+  else if (geo == 1) OSUD_TRY((launch_wg<4, 2, 2, 3>(p, st)));
+  else if (geo == 2) OSUD_TRY((launch_wg<2, 4, 3, 2>(p, st)));
+  else OSUD_TRY((launch_wg<2, 2, 2, 2>(p, st)));
   if (S > 1 && p.arrive == nullptr) OSUD_TRY(launch_splitk_reduce(ws, S, (size_t)Ny * Nx, out, (size_t)Ny * Nx, st));
   return OSUD_OK;
 }
