@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "attn_frag.h"
+#include "gemm.h"
 
 namespace osud {
 
@@ -235,13 +236,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
 // 32 x 32 score tiles in registers), so there is no running maximum to rescale by.
 template <int T>
 __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                              float* __restrict__ lse, int D, int H, int items, float c1) {
+                                                              float* __restrict__ lse, int D, int H, int items, float c1,
+                                                              unsigned* __restrict__ queue) {
   constexpr int HD = 64, HDP = 64, KS = 4, DT = 2;
   using TL = AttnTile<HDP>;
   constexpr int TILE = T * TL::RS;  // bytes
   static_assert(T == 128, "four waves x 32 queries per head, four 32-key score tiles");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][2 heads][K | V][TILE] | store patches [8][2 KiB]
   char* patch = smem + 8 * TILE + (threadIdx.x >> 6) * 2048;
+  // shared-GPU mode (queue != nullptr): pairs b, b + G, then 2 G + ticket, drawn one pair ahead -- see attn_bwd_stream_kernel
+  volatile uint32_t* tword = reinterpret_cast<volatile uint32_t*>(smem + 8 * TILE + 8 * 2048);
   const uint32_t lds0 = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 31, fhalf = lane >> 5;
@@ -277,7 +281,9 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const bf16_t* __re
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(src + ks * 16);
   };
-  int it = blockIdx.x, buf = 0;
+  const int G = gridDim.x;
+  const bool ticket_lane = queue != nullptr && tid == 0;
+  int it = blockIdx.x, nx = blockIdx.x + G, buf = 0, iter = 0;
   u32x4 qf[KS], qn[KS];
   if (it < npairs) {
     issue(it, 0);
@@ -286,11 +292,13 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const bf16_t* __re
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));  // (the compiler's wait for these registers: here, see below)
   }
-  for (; it < npairs; it += gridDim.x, buf ^= 1) {
+  for (; it < npairs; it = nx, buf ^= 1, ++iter) {
     const char* Ks = smem + (size_t)((buf * 2 + hw) * 2) * TILE;
     const char* Vs = Ks + TILE;
     __syncthreads();  // every wave has waited for its pieces of this pair; the other buffer is free from here on
-    const int nx = it + gridDim.x;
+    if (iter > 0) nx = queue != nullptr ? 2 * G + __builtin_amdgcn_readfirstlane((int)tword[iter & 1]) : it + G;  // (iteration 0: b + G)
+    uint32_t tk = 0;
+    if (ticket_lane) tk = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (nx < npairs) {
       issue(nx, buf ^ 1);
       fetch_q(nx, qn);
@@ -359,11 +367,19 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const bf16_t* __re
         qf[ks] = qn[ks];
       }
     }
+    if (ticket_lane) tword[(iter + 1) & 1] = tk;  // (the ticket has had the whole pair to return)
     if (item < items) {
       const int n = item / H, h = item - n * H;
       if (lse != nullptr && fhalf == 0)  // log2-domain logsumexp of the scaled scores, for the backward pass
         lse[((size_t)n * H + h) * T + own + frow] = m_row + __builtin_amdgcn_logf(l_row);
       store_rows_patch(patch, out + ((size_t)n * T + own) * D + h * HD, (size_t)D, o, lane);
+    }
+  }
+  if (ticket_lane) {  // the last workgroup out re-arms the counters
+    const unsigned done = __hip_atomic_fetch_add(queue + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (unsigned)G - 1) {
+      __hip_atomic_store(queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(queue + 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -593,16 +609,18 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
     }
     const char* stream_env = getenv("OSUD_ATTN_FWD_STREAM");  // "0": the general kernel (A/B runs, tests)
     if (head_dim == 64 && T == 128 && Tp == 128 && mask == nullptr && fp8_scale <= 0.f && ld_qk == 3 * D && !(stream_env && stream_env[0] == '0')) {
-      constexpr size_t slds = (size_t)8 * 128 * AttnTile<64>::RS + 8 * 2048;
+      constexpr size_t slds = (size_t)8 * 128 * AttnTile<64>::RS + 8 * 2048 + 16;
       OSUD_BIG_LDS_ONCE(attn_fwd_stream_kernel<128>);
       const int cus = device_cus();
       const int items = N * heads, npairs = (items + 1) / 2;
       hipLaunchKernelGGL((attn_fwd_stream_kernel<128>), dim3(npairs < cus ? npairs : cus), dim3(512), slds, st, (const bf16_t*)qk,
-                         (bf16_t*)out, lse, D, heads, items, scale * 1.4426950408889634f);
+                         (bf16_t*)out, lse, D, heads, items, scale * 1.4426950408889634f,
+                         (gemm_dynamic_tiles_on() && npairs > 2 * cus) ? gemm_ticket_slot() : nullptr);
       OSUD_HIP(hipGetLastError());
       return OSUD_OK;
     }
-    if (head_dim == 72 && T == 256 && Tp == 256 && mask == nullptr && fp8_scale <= 0.f && ld_qk == 3 * D && !(stream_env && stream_env[0] == '0')) {
+    if (head_dim == 72 && T == 256 && Tp == 256 && mask == nullptr && fp8_scale <= 0.f && ld_qk == 3 * D && !(stream_env && stream_env[0] == '0') &&
+        !gemm_dynamic_tiles_on()) {  // (fixed head stride: not while collectives hold compute units)
       constexpr size_t lds72 = (size_t)4 * 128 * AttnTile<96>::RS + 8 * 16 * 208;
       OSUD_BIG_LDS_ONCE(attn_fwd_stream72_kernel<256>);
       const int cus = device_cus();

@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "attn_frag.h"
+#include "gemm.h"
 #include "kernels.h"
 
 namespace osud {
@@ -242,7 +243,7 @@ template <int T>
 __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                               const bf16_t* __restrict__ O, const float* __restrict__ lse,
                                                               bf16_t* __restrict__ dqkv, int D, int H, int items, float c1,
-                                                              float scale) {
+                                                              float scale, unsigned* __restrict__ queue) {
   constexpr int HD = 64, HDP = 64, DT = 2;
   using TL = AttnTile<HDP>;
   constexpr int TILE = T * TL::RS;  // bytes
@@ -251,6 +252,11 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __re
   float* lse_s = reinterpret_cast<float*>(smem + 8 * TILE);
   float* del_s = lse_s + 2 * T;
   char* patch = reinterpret_cast<char*>(del_s + 2 * T) + (threadIdx.x >> 6) * 2048;
+  // Shared-GPU mode (queue != nullptr: collectives hold compute units, so some of the G workgroups start late): a workgroup's first
+  // two heads are b and b + G, every later one is 2 G + a ticket drawn one head ahead (requested behind the barrier of head i,
+  // published through LDS for the barrier of head i + 1, where the DMA of head i + 2 is issued) -- a late workgroup finds the queue
+  // drained instead of doubling the launch.  Which workgroup computes a head does not change its result.
+  volatile uint32_t* tword = reinterpret_cast<volatile uint32_t*>(smem + 8 * TILE + 4 * T * 4 + 8 * 2048);
   const uint32_t lds0 = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 31, fhalf = lane >> 5;
@@ -307,14 +313,16 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __re
     if (dqt == 0) del_s[sb * T + dr] = part;
     if (tid < T) lse_s[sb * T + tid] = lreg;
   };
-  int it = blockIdx.x, buf = 0;
+  const int G = gridDim.x;
+  const bool ticket_lane = queue != nullptr && tid == 0;
+  int it = blockIdx.x, nx = blockIdx.x + G, buf = 0, iter = 0;
   if (it < items) {
     issue(it, 0);
     fetch_stats(it);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first head's tiles
     put_stats(0);
   }
-  for (; it < items; it += gridDim.x, buf ^= 1) {
+  for (; it < items; it = nx, buf ^= 1, ++iter) {
     const char* Qs = smem + (size_t)buf * 4 * TILE;
     const char* Ks = Qs + TILE;
     const char* Vs = Ks + TILE;
@@ -323,7 +331,9 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __re
     const float* del_b = del_s + buf * T;
     // every wave has waited for its own pieces of this head and written its statistics; the other buffers are free from here on
     __syncthreads();
-    const int nx = it + gridDim.x;
+    if (iter > 0) nx = queue != nullptr ? 2 * G + __builtin_amdgcn_readfirstlane((int)tword[iter & 1]) : it + G;  // (iteration 0: b + G)
+    uint32_t tk = 0;
+    if (ticket_lane) tk = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (nx < items && !(OSUD_ATTN_EXP & 8)) {
       issue(nx, buf ^ 1);
       fetch_stats(nx);
@@ -348,6 +358,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __re
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of the next head (issued a whole pass ago)
         put_stats(buf ^ 1);
       }
+      if (ticket_lane) tword[(iter + 1) & 1] = tk;  // (the ticket has had the whole pass to return)
       if (!(OSUD_ATTN_EXP & 1)) store_rows_patch(patch, orows, ld3, dq, lane);
       else if (dq[0][0] == 12345.f) orow[0] = 1;
     } else {
@@ -367,6 +378,13 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __re
       store_rows_patch(patch, orows + D, ld3, dk, lane);
       store_rows_patch(patch, orows + 2 * D, ld3, dv, lane);
       } else if (dk[0][0] + dv[0][0] == 12345.f) orow[D] = 1;
+    }
+  }
+  if (ticket_lane) {  // the last workgroup out re-arms the counters
+    const unsigned done = __hip_atomic_fetch_add(queue + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (unsigned)G - 1) {
+      __hip_atomic_store(queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(queue + 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -901,7 +919,8 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
       const int rows = N * T * heads;
       const dim3 grid((T + 127) / 128, heads, N);
       const char* s72_env = getenv("OSUD_ATTN_BWD_STREAM");
-      if (head_dim == 72 && T == 256 && !force_tiled && !(s72_env && s72_env[0] == '0')) {  // DiT-XL: persistent streamed kernel
+      if (head_dim == 72 && T == 256 && !force_tiled && !(s72_env && s72_env[0] == '0') &&
+          !gemm_dynamic_tiles_on()) {  // DiT-XL: persistent streamed kernel (fixed head stride: not while collectives hold compute units)
         hipLaunchKernelGGL((attn_delta_kernel<72>), dim3((rows + 255) / 256), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O,
                            delta_ws, N, T, heads);
         constexpr size_t lds72 = (size_t)4 * 128 * AttnTile<96>::RS + 4 * 256 * 4 + 8 * 16 * 208;
@@ -936,12 +955,13 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
     const char* stream_env = getenv("OSUD_ATTN_BWD_STREAM");  // "0": the one-workgroup-per-head kernel (A/B runs, tests)
     const bool stream_on = !(stream_env && stream_env[0] == '0');
     if (head_dim == 64 && T == 128 && dbias == nullptr && stream_on) {
-      constexpr size_t slds = (size_t)8 * 128 * AttnTile<64>::RS + 4 * 128 * 4 + 8 * 2048;
+      constexpr size_t slds = (size_t)8 * 128 * AttnTile<64>::RS + 4 * 128 * 4 + 8 * 2048 + 16;
       OSUD_BIG_LDS_ONCE(attn_bwd_stream_kernel<128>);
       const int cus = device_cus();
       const int items = N * heads;
       hipLaunchKernelGGL((attn_bwd_stream_kernel<128>), dim3(items < cus ? items : cus), dim3(512), slds, st, (const bf16_t*)qkv,
-                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, D, heads, items, c1, scale);
+                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, D, heads, items, c1, scale,
+                         (gemm_dynamic_tiles_on() && items > 2 * cus) ? gemm_ticket_slot() : nullptr);
       OSUD_HIP(hipGetLastError());
       return OSUD_OK;
     }

@@ -72,6 +72,9 @@ struct GemmP {
 int launch_gemm(int prec, int epi, const GemmP& p, hipStream_t st);
 bool gemm_dynamic_tiles_on();            // the effective setting
 void gemm_set_dynamic_tiles(int on);  // 1 / 0, -1 = follow the OSUD_GEMM_DYNAMIC environment variable (default off)
+// one 16-word counter set {[0] tickets, [8] finished workgroups} of the same pool, for other persistent kernels that draw their
+// work items from a queue while the GPU is shared (the attention kernels); zero on entry, re-armed by the kernel's last workgroup
+unsigned* gemm_ticket_slot();
 int gemm_sched_init();  // allocates the tile-queue counters (call outside stream capture; launch_gemm does it lazily otherwise)
 // out[i] = sum_s part[s * stride + i], i < n (n % 4 == 0): deterministic split-K combine
 int launch_splitk_reduce(const float* part, int splits, size_t stride, float* out, size_t n, hipStream_t st);

@@ -995,6 +995,10 @@ template <typename TE> int launch_e(int epi, const GemmP& p, hipStream_t st) {
 }  // namespace
 
 int gemm_sched_init() { return gemm_sched_init_impl(); }
+unsigned* gemm_ticket_slot() {
+  if (!g_sched_pool[cur_device()] && gemm_sched_init_impl() != OSUD_OK) return nullptr;
+  return sched_slot();
+}
 bool gemm_dynamic_tiles_on() {
   static const bool dyn_env = [] { const char* e = getenv("OSUD_GEMM_DYNAMIC"); return e && e[0] == '1'; }();
   const int v = g_dynamic_tiles.load(std::memory_order_relaxed);

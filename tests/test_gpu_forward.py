@@ -175,6 +175,34 @@ def test_attention_core_backward(prec, tol, N, H, T_, stream, hd, monkeypatch):
     assert maxdiff(g.cpu(), ref.cpu()) < tol * max(1.0, float(ref.abs().max())), (N, H, T_)
 
 
+def test_attention_head_queue_equals_fixed_stride():
+    """Shared-GPU mode (osud_set_gemm_dynamic_tiles(1), what data-parallel trainers switch on): the persistent attention kernels draw
+    their heads from a ticket queue instead of a fixed stride.  1152 heads (576 pairs) are more than two per compute unit, so the
+    queue is live; which workgroup computes a head must not change a bit of the result."""
+    N, H, T_, hd = 96, 12, 128, 64
+    D, M = H * hd, N * T_
+    torch.manual_seed(5)
+    qkc = to_elem(0, torch.randn(M, 3 * D, device=DEV))
+    doc = to_elem(0, torch.randn(M, D, device=DEV))
+    lse = torch.randn(N, H, T_, device=DEV) + 6.0
+    L = _lib.lib()
+    res = []
+    try:
+        for mode in (0, 1, 1):  # the second queued launch runs on counters the first one re-armed
+            L.osud_set_gemm_dynamic_tiles(mode)
+            out = torch.zeros(M * D * 2, dtype=torch.uint8, device=DEV)
+            dq = torch.zeros(M * 3 * D * 2, dtype=torch.uint8, device=DEV)
+            _lib.check(L.osud_op_attention(0, _lib.ptr(qkc), 3 * D, None, _lib.ptr(out), N, T_, T_, M, H, hd, None))
+            _lib.check(L.osud_op_attention_bwd(0, _lib.ptr(qkc), _lib.ptr(doc), _lib.ptr(out), _lib.ptr(lse), _lib.ptr(dq), N, T_, H, hd,
+                                               None, None))
+            torch.cuda.synchronize()
+            res.append((out.clone(), dq.clone()))
+    finally:
+        L.osud_set_gemm_dynamic_tiles(-1)
+    for o, g in res[1:]:
+        assert torch.equal(o, res[0][0]) and torch.equal(g, res[0][1])
+
+
 # ------------------------------------------------------------------------------------ forward
 FWD_TAGS = ["tiny_T64", "tiny_T128", "tiny_T200_band", "tiny_T128_allfalse", "small_T128", "tiny_T128_rough",
             "dit_b_T128", "dit_b_T128_rough"]  # dit_b: D=768, 12 heads, 12 blocks -- the geometry bench.py times
