@@ -113,6 +113,7 @@ struct osud_dit {
   // fp8 TRAINING (delayed per-tensor scaling): per block 6 quantised tensors (u1, u2, gelu out, d(mlp branch), d(fc1 pre-act),
   // dqkv), each with a slot {scale in use, 1/scale, amax seen this step, -}; e4m3 staging buffers [Mp][D] and [Mp][4D]
   float* f8_slots = nullptr;
+  float* f8_parts = nullptr;  // [slots][f8_amax_parts()] per-workgroup partial maxima of producers that do not use the slot's atomic word
   void *q8a = nullptr, *q8b = nullptr;
   // fp8 INFERENCE: per-block activation scales {LN1 out, attention out, LN2 out, GELU out}; defaults are the static constants, 
   // osud_dit_calibrate_fp8 replaces them by 448 / (2 * amax) measured on the caller's batch

@@ -88,6 +88,7 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
       OSUD_TRY(dev_alloc(W, &m->q8a, (size_t)Mp * D));
       OSUD_TRY(dev_alloc(W, &m->q8b, (size_t)Mp * 4 * D));
       OSUD_TRY(dev_alloc(W, &m->f8_slots, (size_t)m->L * 6 * 4 * sizeof(float)));
+      OSUD_TRY(dev_alloc(W, &m->f8_parts, (size_t)m->L * 6 * f8_amax_parts() * sizeof(float)));  // (zeroed)
       std::vector<float> init((size_t)m->L * 6 * 4, 0.f);
       for (size_t i = 0; i < init.size(); i += 4) init[i] = init[i + 1] = 1.0f;
       OSUD_HIP(hipMemcpy(m->f8_slots, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -158,8 +159,9 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
   // per-output-channel scales.  out_proj (1/12 of a block's FLOPs) and every weight gradient stay bf16.
   const bool f8_train = m->fp8 && save;
   const bool f8_live = f8_train && m->f8_steps > 0;
-  if (f8_train) OSUD_TRY(launch_f8_update(m->f8_slots, m->L * 6, st));
+  if (f8_train) OSUD_TRY(launch_f8_update(m->f8_slots, m->L * 6, st, m->f8_parts));
   auto slot = [&](int l, int which) { return m->f8_slots + ((size_t)l * 6 + which) * 4; };
+  auto parts = [&](int l, int which) { return m->f8_parts + ((size_t)l * 6 + which) * f8_amax_parts(); };
   // fp8 inference: per-block activation scales (static defaults, or calibrated: osud_dit_calibrate_fp8)
   if (m->fp8 && m->f8_inf.empty()) {
     m->f8_inf.resize((size_t)m->L * 4);
@@ -216,10 +218,14 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
       OSUD_TRY(gemm8(m, EPI_BIAS_TE, m->u8, w.w8_qkv, Mp, qcols, D, qk, qcols, w.b_qkv, w.dq_qkv, 0.f, st, nullptr, 0, 0, 0, 1.0f / fs[0]));
       OSUD_TRY(launch_attention(prec, qk, qcols, mask, m->ao8, nullptr, N, T, Tp, Mp, m->H, m->hd, st, m->kb_class, fs[1]));
     } else {
+      // (fp8 training: LayerNorm writes the e4m3 twin of its output and this step's amax itself)
+      if (f8_train)
+        OSUD_TRY(launch_ln_mod_twin(h, m->ada, AC, base, base + D, u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st, pend, pend_gate,
+                                    pend ? h_in : nullptr, f8_live ? m->q8a : nullptr, slot(l, 0), parts(l, 0)));
+      else
       OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base, base + D, u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st, pend,
                              pend_gate, pend ? h_in : nullptr));
       // packed in_proj: one 3D-wide product, Q | K | V row-major (the attention kernels transpose V on the LDS read)
-      if (f8_train) OSUD_TRY(launch_f8_quantize(u1, f8_live ? m->q8a : nullptr, (size_t)Mp * D, slot(l, 0), st));
       if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_TE, m->q8a, w.w8_qkv, Mp, qcols, D, qk, qcols, w.b_qkv, w.dq_qkv, 0.f, st, nullptr, 0, 0, 0, 0.f,
                                   slot(l, 0) + 1));
       else
@@ -250,10 +256,13 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
       continue;
     }
     OSUD_TRY(gemm(m, EPI_BIAS_TE, ao, D, w.w_o, D, Mp, D, D, br1, D, w.b_o, st));
+    if (f8_train)
+      OSUD_TRY(launch_ln_mod_twin(h_in, m->ada, AC, base + 3 * D, base + 4 * D, u2, sv->stats2, Mp, Tp, N, D, st, br1, base + 2 * D,
+                                  h_mid, f8_live ? m->q8a : nullptr, slot(l, 1), parts(l, 1)));
+    else
     OSUD_TRY(launch_ln_mod(prec, h_in, m->ada, AC, base + 3 * D, base + 4 * D, u2, sv->stats2, Mp, Tp, N, D, st, br1,
                            base + 2 * D, h_mid));
     if (f8_train) {
-      OSUD_TRY(launch_f8_quantize(u2, f8_live ? m->q8a : nullptr, (size_t)Mp * D, slot(l, 1), st));
       // (live steps: the fc1 epilogue writes the e4m3 twin of its GELU output and records its amax itself)
       if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_GELU_BF, m->q8a, w.w8_1, Mp, 4 * D, D, g, 4 * D, w.b1, w.dq_1, 0.f, st, nullptr, 0, 0, 0, 0.f,
                                   slot(l, 1) + 1, sv->z1, nullptr, nullptr, nullptr, m->q8b, slot(l, 2)));

@@ -22,7 +22,11 @@ int launch_quantize_rows_bf16(const void* w_bf16, int rows, int cols, void* q, f
 //   quantize: dst[i] = e4m3(src[i] * slot[0]) (dst may be null: record only), slot[2] = max(slot[2], max|src|)
 //   update  : for every slot with a recorded amax: scale = 448 / (2 * amax) (one binade of headroom), amax cleared
 int launch_f8_quantize(const void* src_bf16, void* dst_fp8, size_t n, float* slot, hipStream_t st);
-int launch_f8_update(float* slots, int n_slots, hipStream_t st);
+int launch_f8_update(float* slots, int n_slots, hipStream_t st, float* amax_parts = nullptr /* [n_slots][f8_amax_parts()] */);
+int f8_amax_parts();
+int launch_ln_mod_twin(const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, void* out, float* stats, int M,
+                       int Tp, int N, int D, hipStream_t st, const void* br, int off_gate, float* h_out, void* out8, const float* slot,
+                       float* amax_part);
 int launch_final(const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, const float* w,
                  const float* bias, float* out, float* u_save, float* stats, int N, int T, int Tp, int D, int C,
                  hipStream_t st, int prec = OSUD_PREC_F32, const void* br = nullptr, int off_gate = 0,
@@ -58,7 +62,8 @@ int launch_gate_bwd(int prec, const float* dh, const void* br, const float* gate
 int launch_ln_mod_bwd(int prec, const float* h, const float* stats, const void* du, const float* ada, int ld_ada,
                       int off_shift, int off_scale, const float* dh_skip, float* dh_out, float* dada, int M, int Tp, int D,
                       hipStream_t st, const void* br_next = nullptr, int off_gate_next = 0, void* dbr = nullptr,
-                      float* db_next = nullptr);
+                      float* db_next = nullptr, void* dbr8 = nullptr,
+                      const float* slot8 = nullptr, float* amax_part = nullptr);
 int launch_final_bwd(const float* h, const float* stats, const float* dout, const float* w, const float* ada, int ld_ada,
                      int off_shift, int off_scale, float* dh_out, float* dada, float* dw, float* dbias, int N, int T, int Tp,
                      int D, int C, hipStream_t st, float* scratch = nullptr, size_t scratch_elems = 0);

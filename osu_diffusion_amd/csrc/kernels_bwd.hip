@@ -197,10 +197,17 @@ __global__ __launch_bounds__(256, OSUD_LNB_OCC(VPL)) void ln_mod_bwd_kernel(cons
                                                          int ld_ada, int off_shift, int off_scale,
                                                          const float* __restrict__ dh_skip, float* __restrict__ dh_out,
                                                          float* __restrict__ dada, int Tp, const TE* __restrict__ br_next,
-                                                         int off_gate_next, TE* __restrict__ dbr, float* __restrict__ db_next) {
+                                                         int off_gate_next, TE* __restrict__ dbr, float* __restrict__ db_next,
+                                                         fp8_t* __restrict__ dbr8, const float* __restrict__ slot8,
+                                                         float* __restrict__ amax_part) {
   // lane l owns columns W*l + 64*W*g + {0..W-1}, g < NG: 16-byte fp32 / 8-byte bf16 accesses where VPL allows (W = 4)
   constexpr int D = VPL * 64, W = (VPL % 4 == 0) ? 4 : 2, NG = VPL / W;
   constexpr int ROWS = OSUD_LNB_ROWS;
+  // fp8 training (slot8 != nullptr, bf16 tier): dbr's e4m3 twin -- the operand of the next block's fc2 data-gradient GEMM -- and
+  // this step's amax as one partial maximum per workgroup, as in ln_mod_kernel's TWIN form
+  const bool twin = GATE && sizeof(TE) == 2 && slot8 != nullptr;
+  const float q_scale = twin ? slot8[0] : 1.0f;
+  float amax8 = 0.f;
   __shared__ float red[2][4][D];
   __shared__ float cst[2][D];  // 1 + scale | gate of the next branch
   // (the wave index as a scalar: row bases then live in SGPRs and every access is base + one per-lane offset + immediate)
@@ -277,7 +284,19 @@ __global__ __launch_bounds__(256, OSUD_LNB_OCC(VPL)) void ln_mod_bwd_kernel(cons
         }
       }
       storew<W>(dh_out + row + d, o);
-      if constexpr (GATE) storew<W>(dbr + row + d, b);
+      if constexpr (GATE) {
+        storew<W>(dbr + row + d, b);
+        if (twin) {
+          float q[W];
+#pragma unroll
+          for (int e = 0; e < W; ++e) {
+            const float rb = bf2f(f2bf(b[e]));  // the stored bf16 value
+            amax8 = fmaxf(amax8, fabsf(rb));
+            q[e] = rb * q_scale;
+          }
+          if (dbr8 != nullptr) storew<W>(dbr8 + row + d, q);
+        }
+      }
     }
   };
   // rows wave, wave+4, ...: one row per wave in flight, three waves per SIMD (a second register set per wave costs a wave)
@@ -315,6 +334,13 @@ __global__ __launch_bounds__(256, OSUD_LNB_OCC(VPL)) void ln_mod_bwd_kernel(cons
     for (int d = threadIdx.x; d < D; d += 256) {
       atomicAdd(dn + off_gate_next + d, red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d]);
       if (db_next != nullptr) atomicAdd(db_next + d, red[1][0][d] + red[1][1][d] + red[1][2][d] + red[1][3][d]);
+    }
+    if (twin) {
+      __syncthreads();
+      amax8 = wave_max(amax8);
+      if (lane == 0) red[0][wave][0] = amax8;
+      __syncthreads();
+      if (threadIdx.x == 0) amax_part[blockIdx.x] = fmaxf(fmaxf(red[0][0][0], red[0][1][0]), fmaxf(red[0][2][0], red[0][3][0]));
     }
   }
 }
@@ -581,11 +607,14 @@ int launch_gate_bwd(int prec, const float* dh, const void* br, const float* gate
 
 int launch_ln_mod_bwd(int prec, const float* h, const float* stats, const void* du, const float* ada, int ld_ada,
                       int off_shift, int off_scale, const float* dh_skip, float* dh_out, float* dada, int M, int Tp, int D,
-                      hipStream_t st, const void* br_next, int off_gate_next, void* dbr, float* db_next) {
+                      hipStream_t st, const void* br_next, int off_gate_next, void* dbr, float* db_next, void* dbr8, const float* slot8,
+                      float* amax_part) {
   OSUD_CHECK_ARG(M % 64 == 0 && Tp % 64 == 0, "ln_mod_bwd: rows must come in blocks of 64");
   OSUD_CHECK_ARG(dh_skip != nullptr, "ln_mod_bwd: the gradient of the residual stream behind the LayerNorm is required");
+  OSUD_CHECK_ARG(slot8 == nullptr || (amax_part != nullptr && br_next != nullptr && prec == OSUD_PREC_BF16 && M / OSUD_LNB_ROWS <= f8_amax_parts()),
+                 "ln_mod_bwd: the e4m3 twin rides with the gate step of the bf16 tier");
   const dim3 grid(M / OSUD_LNB_ROWS), block(256);
-#define ARGS(T) h, stats, (const T*)du, ada, ld_ada, off_shift, off_scale, dh_skip, dh_out, dada, Tp, (const T*)br_next, off_gate_next, (T*)dbr, db_next
+#define ARGS(T) h, stats, (const T*)du, ada, ld_ada, off_shift, off_scale, dh_skip, dh_out, dada, Tp, (const T*)br_next, off_gate_next, (T*)dbr, db_next, (fp8_t*)dbr8, slot8, amax_part
   if (prec == OSUD_PREC_BF16) {
 #define CALL(V)                                                                                                      \
   if (br_next != nullptr) hipLaunchKernelGGL((ln_mod_bwd_kernel<bf16_t, V, true>), grid, block, 0, st, ARGS(bf16_t)); \

@@ -123,15 +123,23 @@ __global__ void cond_kernel(const float* __restrict__ tvec, const float* __restr
 //   h' = h + gate[n] * br,  written to h_out (may be h itself), and u = LN(h') ...
 // so the branch GEMMs (attention out-projection, fc2) keep a plain bias epilogue and the residual stream is read
 // once instead of twice.  `out` may alias `br` (a wave reads its whole row before it writes).
-template <typename TE, int VPL>
+// TWIN (fp8 training, TE = bf16): the e4m3 operand of the next GEMM is written here as well -- the bf16 value times the slot's
+// delayed scale, exactly what the stand-alone f8_quantize pass produced -- and this step's amax goes out as one partial maximum per
+// workgroup (amax_part[blockIdx.x], reduced by f8_update_kernel: no atomics on the slot's single word).  The grid is capped at
+// kF8AmaxParts workgroups there, each wave walking rows blockIdx.x * 4 + wave, + 4 * gridDim.x, ...
+constexpr int kF8AmaxParts = 8192;  // (= rows / 4 of a 32 768-token step: one row per wave, as in the plain kernel)
+template <typename TE, int VPL, bool TWIN = false>
 __global__ __launch_bounds__(256) void ln_mod_kernel(const float* h, const float* __restrict__ ada, int ld_ada,
                                                      int off_shift, int off_scale, TE* out, float* __restrict__ stats,
                                                      int M, int Tp, int N, const TE* br, int off_gate, float* h_out,
-                                                     float out_scale) {
+                                                     float out_scale, fp8_t* __restrict__ out8 = nullptr,
+                                                     const float* __restrict__ slot = nullptr, float* __restrict__ amax_part = nullptr) {
   // lane l owns columns W*l + 64*W*g + {0..W-1}: 16-byte fp32 accesses where the per-lane count allows (W = 4)
   constexpr int D = VPL * 64, W = (VPL % 4 == 0) ? 4 : 2, NG = VPL / W;
-  const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (m >= M) return;
+  const int lane = threadIdx.x & 63;
+  float amax = 0.f;
+  const float q_scale = TWIN ? slot[0] : 1.0f;
+  for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += TWIN ? 4 * (int)gridDim.x : M) {
   int n = m / Tp;
   if (n >= N) n = N - 1;
   const float* hr = h + (size_t)m * D;
@@ -185,6 +193,24 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* h, const float
       if (sizeof(TE) == 1) r[e] *= out_scale;  // fp8 operand of the next GEMM, statically scaled
     }
     storew<W>(orow + d, r);
+    if constexpr (TWIN) {
+      float q[W];
+#pragma unroll
+      for (int e = 0; e < W; ++e) {
+        const float rb = bf2f(f2bf(r[e]));  // the stored bf16 value: what a separate pass over `out` would have read
+        amax = fmaxf(amax, fabsf(rb));
+        q[e] = rb * q_scale;
+      }
+      if (out8 != nullptr) storew<W>(out8 + (size_t)m * D + d, q);
+    }
+  }
+  }  // rows of this wave
+  if constexpr (TWIN) {
+    __shared__ float red[4];
+    amax = wave_max(amax);
+    if (lane == 0) red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) amax_part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   }
 }
 
@@ -375,11 +401,25 @@ __global__ __launch_bounds__(256) void f8_quantize_kernel(const bf16_t* __restri
   }
 }
 
-__global__ void f8_update_kernel(float* __restrict__ slots, int n_slots) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_slots) return;
+// one workgroup per slot: this step's amax = max(the slot's atomic word, the per-workgroup partial maxima of the producers that
+// write them), scale for the next step, both cleared
+__global__ __launch_bounds__(256) void f8_update_kernel(float* __restrict__ slots, int n_slots, float* __restrict__ parts) {
+  __shared__ float red[4];
+  const int i = blockIdx.x;
   float* s = slots + 4 * i;
-  const float amax = s[2];
+  float amax = 0.f;
+  if (parts != nullptr) {
+    float* p = parts + (size_t)i * kF8AmaxParts;
+    for (int j = threadIdx.x; j < kF8AmaxParts; j += 256) {
+      amax = fmaxf(amax, p[j]);
+      p[j] = 0.f;
+    }
+  }
+  amax = wave_max(amax);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  amax = fmaxf(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])), s[2]);
   if (amax > 0.f && amax < 3.0e38f) {
     const float sc = 448.0f / (2.0f * amax);
     s[0] = sc;
@@ -411,8 +451,9 @@ int launch_f8_quantize(const void* src, void* dst, size_t n, float* slot, hipStr
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }
-int launch_f8_update(float* slots, int n_slots, hipStream_t st) {
-  hipLaunchKernelGGL(f8_update_kernel, dim3((n_slots + 63) / 64), dim3(64), 0, st, slots, n_slots);
+int f8_amax_parts() { return kF8AmaxParts; }
+int launch_f8_update(float* slots, int n_slots, hipStream_t st, float* parts) {
+  hipLaunchKernelGGL(f8_update_kernel, dim3(n_slots), dim3(256), 0, st, slots, n_slots, parts);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }
@@ -473,6 +514,28 @@ static int ln_mod_t(const float* h, const float* ada, int ld_ada, int off_shift,
 #define OSUD_LN(V)                                                                                                  \
   hipLaunchKernelGGL((ln_mod_kernel<TE, V>), grid, block, 0, st, h, ada, ld_ada, off_shift, off_scale, (TE*)out, \
                      stats, M, Tp, N, (const TE*)br, off_gate, h_out, out_scale)
+  switch (D) {
+    case 128: OSUD_LN(2); break;
+    case 384: OSUD_LN(6); break;
+    case 768: OSUD_LN(12); break;
+    case 1024: OSUD_LN(16); break;
+    case 1152: OSUD_LN(18); break;
+    default: set_error("ln_mod: hidden size %d not built (128, 384, 768, 1024, 1152)", D); return OSUD_ERR_UNSUPPORTED;
+  }
+#undef OSUD_LN
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+// bf16 output + its e4m3 twin and amax partials (fp8 training)
+int launch_ln_mod_twin(const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, void* out, float* stats, int M,
+                       int Tp, int N, int D, hipStream_t st, const void* br, int off_gate, float* h_out, void* out8, const float* slot,
+                       float* amax_part) {
+  OSUD_CHECK_ARG(slot != nullptr && amax_part != nullptr, "ln_mod twin: slot and amax partials are required");
+  const int wgs = (M + 3) / 4;
+  const dim3 grid(wgs < kF8AmaxParts ? wgs : kF8AmaxParts), block(256);
+#define OSUD_LN(V)                                                                                                                \
+  hipLaunchKernelGGL((ln_mod_kernel<bf16_t, V, true>), grid, block, 0, st, h, ada, ld_ada, off_shift, off_scale, (bf16_t*)out, stats, \
+                     M, Tp, N, (const bf16_t*)br, off_gate, h_out, 1.0f, (fp8_t*)out8, slot, amax_part)
   switch (D) {
     case 128: OSUD_LN(2); break;
     case 384: OSUD_LN(6); break;

@@ -226,7 +226,9 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     auto slot = [&](int which) { return m->f8_slots + ((size_t)l * 6 + which) * 4; };
     {
       int part_rows = 0;
-      if (f8_train) OSUD_TRY(launch_f8_quantize(w.dbr, f8_live ? m->q8a : nullptr, (size_t)Mp * D, slot(3), st));
+      // (the e4m3 twin of dbr and its amax come from the kernel that produced dbr -- the LN1 backward of block l + 1 -- except
+      //  for the last block, whose gate step is its own kernel)
+      if (f8_train && l == L - 1) OSUD_TRY(launch_f8_quantize(w.dbr, f8_live ? m->q8a : nullptr, (size_t)Mp * D, slot(3), st));
       if (f8_live) {
         OSUD_TRY(gemm8(m, EPI_GELUGRAD_TE, m->q8a, bw.w2_t8, Mp, 4 * D, D, w.dz1, 4 * D, nullptr, bw.dq_2_t, 0.f, st, nullptr, 0, 0, 0, 0.f,
                        slot(3) + 1, nullptr, sv.z1, fused_b1 ? w.splitk : nullptr, fused_b1 ? &part_rows : nullptr, m->q8b, slot(4)));
@@ -282,8 +284,11 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     if (l > 0) {
       const LayerSaved& svp = m->saved[(size_t)l - 1];
       const int basep = (l - 1) * 6 * D;
+      float* slot_prev = m->f8_slots + ((size_t)(l - 1) * 6 + 3) * 4;  // fp8 training: block l - 1's dbr slot
       OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_in, sv.stats1, w.du, m->ada, AC, base, base + D, dh, dh_other, w.dada, M, Tp, D,
-                                 st, svp.br2, basep + 5 * D, w.dbr, G("blocks." + std::to_string(l - 1) + ".mlp.fc2.bias")));
+                                 st, svp.br2, basep + 5 * D, w.dbr, G("blocks." + std::to_string(l - 1) + ".mlp.fc2.bias"),
+                                 f8_live ? m->q8a : nullptr, f8_train ? slot_prev : nullptr,
+                                 f8_train ? m->f8_parts + ((size_t)(l - 1) * 6 + 3) * f8_amax_parts() : nullptr));
     } else {
       OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_in, sv.stats1, w.du, m->ada, AC, base, base + D, dh, dh_other, w.dada, M, Tp, D,
                                  st));
