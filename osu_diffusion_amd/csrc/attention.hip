@@ -226,6 +226,181 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
   }
 }
 
+// ---------------------------------------------------------------- any T, masks, head_dim 64: key blocks double-buffered by LDS-DMA
+// The kernel above pays a full memory round trip per 64-key block (barrier, global -> registers -> LDS, barrier, compute): one long
+// beatmap of T = 2048 spends 7.6 us per block and workgroup, of which the MFMAs need 0.25.  Same work split here (128 queries per
+// workgroup, a wave owns 32; online softmax over 64-key blocks; tile classes of the mask), but the K | V rows of the NEXT live block
+// travel by LDS-DMA into the other half of a 32 KiB double buffer while this block is computed: one barrier per block, no staging
+// registers.  The mask bytes of an edge tile (eight 32-bit loads per lane) are inline asm, issued in front of the DMA and waited
+// for with a count that leaves the DMA in flight -- a compiler-visible load there would wait for the pieces it cannot see.
+// Mask rows must be 4-byte aligned (T % 4 == 0; other T take the kernel above).  Output rows leave as full lines through the
+// (by then idle) stage memory.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_bf16_dma_kernel(
+    const bf16_t* __restrict__ qk, const uint8_t* __restrict__ mask, bf16_t* __restrict__ out, float* __restrict__ lse, int T, int Tp,
+    int D, int ld_qk, float c1 /* scale*log2(e) */, const uint8_t* __restrict__ kb_class) {
+  constexpr int HD = 64, HDP = 64, KS = 4, DT = 2;
+  using TL = AttnTile<HDP>;
+  constexpr int TILE = 64 * TL::RS, STAGE = 2 * TILE;  // 8 KiB K + 8 KiB V
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  const uint32_t lds0 = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int n = blockIdx.z, h = blockIdx.y;
+  const int q = blockIdx.x * 128 + wave * 32 + frow;
+  const int qc = q < Tp ? q : Tp - 1;
+  const size_t ldq = (size_t)ld_qk;
+  const size_t mrow = (size_t)n * Tp + qc;
+  const int nkb = Tp / 64;
+  // tile classes of this workgroup's two 64-query rows of the mask map: live = not padding, not fully masked; check = read mask bytes
+  auto classify = [&](int kb, bool& check) -> bool {
+    if (kb >= nkb || kb * 64 >= T) return false;
+    check = mask != nullptr;
+    if (kb_class != nullptr) {
+      const int ca = kb_class[(size_t)(2 * blockIdx.x) * nkb + kb];
+      const int cb = 2 * (int)blockIdx.x + 1 < nkb ? kb_class[(size_t)(2 * blockIdx.x + 1) * nkb + kb] : ca;
+      if (ca == 0 && cb == 0) return false;
+      check = !(ca == 2 && cb == 2);
+    }
+    return true;
+  };
+  auto next_live = [&](int from, bool& check) -> int {  // first live block >= from, nkb if none (workgroup-uniform)
+    int kb = from;
+    while (kb < nkb && !classify(kb, check)) ++kb;
+    return kb < nkb && kb * 64 < T ? kb : nkb;
+  };
+  // LDS-DMA of one key block: wave w fetches 8-row pieces 4 w .. 4 w + 3 of K | V (16 pieces); source-side XOR swizzle of AttnTile<64>
+  const uint32_t ldb = (uint32_t)(ldq * 2);
+  const int lr = lane >> 3, pc = lane & 7;
+  const uint32_t voff_even = (uint32_t)lr * ldb + (uint32_t)((pc ^ (lr >> 1)) << 4);
+  const uint32_t voff_odd = (uint32_t)lr * ldb + (uint32_t)((pc ^ (4 + (lr >> 1))) << 4);
+  auto issue = [&](int kb, int stage) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = 4 * wave + i, t = p >> 3, pp = p & 7;  // tile (K, V), piece inside the tile
+      const char* sb = reinterpret_cast<const char*>(qk + ((size_t)n * Tp + kb * 64 + pp * 8) * ldq + (size_t)(1 + t) * D + h * HD);
+      const uint32_t dst = lds0 + (uint32_t)(stage * STAGE + t * TILE + pp * 1024);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"((pp & 1) ? voff_odd : voff_even), "s"(sb), "s"(dst) : "memory");
+    }
+  };
+  bool chk_cur = false, chk_nxt = false;
+  int cur = next_live(0, chk_cur);
+  if (cur < nkb) issue(cur, 0);
+  // Q fragments (B operand of S^T = K.Q^T): 8 consecutive d per lane and k-step (compiler loads: their wait also covers the
+  // first block's pieces, which the first iteration needs anyway)
+  u32x4 qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const u32x4*>(qk + mrow * ldq + h * HD + ks * 16 + fhalf * 8);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));  // (the compiler's wait for them sits HERE, not at their first use
+                                                                    //  inside the loop, where it would drain the DMA every block)
+  f32x16 o[DT];
+#pragma unroll
+  for (int i = 0; i < DT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const int qm = qc < T ? qc : T - 1;  // row of the mask this query reads
+  int stage = 0;
+  while (cur < nkb) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this block's pieces (nothing else is in flight here)
+    __syncthreads();
+    const int nxt = next_live(cur + 1, chk_nxt);
+    const char* Ks = smem + stage * STAGE;
+    const char* Vs = Ks + TILE;
+    // the 4 mask bytes of this lane's 4 consecutive keys per (kt, g): eight 32-bit loads, in front of the next block's DMA
+    uint32_t m4[2][4];
+    if (chk_cur) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          int key0 = cur * 64 + kt * 32 + 8 * g + 4 * fhalf;
+          if (key0 > T - 4) key0 = T - 4;  // (keys past T are dead below whatever is read here; T % 4 == 0)
+          const uint8_t* mp = mask + (size_t)qm * T + key0;
+          asm volatile("global_load_dword %0, %1, off" : "=&v"(m4[kt][g]) : "v"(mp) : "memory");
+        }
+    }
+    if (nxt < nkb) issue(nxt, stage ^ 1);
+    // ---- S^T tiles: s[kt][4g+i] = score(key = cur*64 + kt*32 + 8g + 4*fhalf + i, query q)
+    f32x16 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) s[kt] = mfma_bf16(rowfrag<HDP>(Ks, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s[kt]);
+    }
+    if (chk_cur) {
+      if (nxt < nkb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // the mask words; the 4 DMA pieces behind them stay in flight
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(m4[kt][g]));
+    }
+    // ---- scale, mask, block max
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int key0 = cur * 64 + kt * 32 + 8 * g + 4 * fhalf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          bool dead = key0 + i >= T;
+          if (chk_cur && !dead) dead = ((m4[kt][g] >> (8 * i)) & 0xffu) != 0;
+          const float v = dead ? -INFINITY : s[kt][4 * g + i] * c1;
+          s[kt][4 * g + i] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_run, mx);
+    const float m_use = m_new == -INFINITY ? 0.f : m_new;
+    const float alpha = fast_exp2(m_run - m_use);  // m_run = -inf -> 0
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(s[kt][r] - m_use);
+        s[kt][r] = p;
+        psum += p;
+      }
+    psum += __shfl_xor(psum, 32, 64);
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+    // ---- O^T += V^T . P^T (V^T fragments = transposing reads of the row-major V tile)
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ss = 0; ss < 2; ++ss) {
+        const u32x4 pf = pack8(s[kt], 8 * ss);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[dt] = mfma_bf16(trfrag<HDP>(Vs, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
+      }
+    cur = nxt;
+    chk_cur = chk_nxt;
+    stage ^= 1;
+  }
+  __syncthreads();  // the stages are idle: they become the waves' output patches
+  if (blockIdx.x * 128 + wave * 32 < Tp) {  // (Tp % 64 == 0: a wave's 32 rows are all inside or all outside)
+    if (lse != nullptr && fhalf == 0)  // log2-domain logsumexp of the scaled scores, for the backward pass
+      lse[((size_t)n * gridDim.y + h) * Tp + q] = m_run + __builtin_amdgcn_logf(l_run);
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] *= inv;
+    store_rows_patch(smem + wave * 2048, out + ((size_t)n * Tp + blockIdx.x * 128 + wave * 32) * D + h * HD, (size_t)D, o, lane);
+  }
+}
+
 // ---------------------------------------------------------------- T == Tp == 128, head_dim 64, no mask: persistent, streamed
 // The shape of training and of window sampling.  The kernel above is a 48 KB-in / 16 KB-out copy per head with a little MFMA
 // work: at four workgroups per CU it reached 4.3 TB/s in training and 3.1 TB/s at the sampling batch (a device copy: 5.4).  Here one
@@ -631,6 +806,13 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
       return OSUD_OK;
     }
     dim3 grid((Tp + 127) / 128, heads, N);
+    const char* dma_env = getenv("OSUD_ATTN_DMA");  // "0": the register-staged kernel (A/B runs, tests)
+    if (head_dim == 64 && fp8_scale <= 0.f && (mask == nullptr || T % 4 == 0) && T >= 4 && !(dma_env && dma_env[0] == '0')) {
+      hipLaunchKernelGGL(attn_bf16_dma_kernel, grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp, D, ld_qk,
+                         scale * 1.4426950408889634f, mask ? kb_class : nullptr);
+      OSUD_HIP(hipGetLastError());
+      return OSUD_OK;
+    }
     static const bool one_block = [] { const char* e = getenv("OSUD_ATTN_KB"); return !(e && e[0] == '2'); }();
     if (head_dim == 64 && one_block)
       hipLaunchKernelGGL((attn_bf16_kernel<64, 64, 1>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
