@@ -62,8 +62,9 @@ struct GraphKey {
   const void *o, *c, *y, *mask, *x, *noise;
   const void* sched;
   const void *keep = nullptr, *known = nullptr;
+  int embed_const = 0;  // the captured step used the split-off constant part of the first linear
   bool operator==(const GraphKey& r) const {
-    return N == r.N && T == r.T && mode == r.mode && clip == r.clip && has_mask == r.has_mask &&
+    return embed_const == r.embed_const && N == r.N && T == r.T && mode == r.mode && clip == r.clip && has_mask == r.has_mask &&
            has_noise == r.has_noise && cfg == r.cfg && eta == r.eta && o == r.o && c == r.c && y == r.y &&
            mask == r.mask && x == r.x && noise == r.noise && sched == r.sched && keep == r.keep && known == r.known;
   }
@@ -80,6 +81,13 @@ struct osud_dit {
 
   // weights
   void* w_e = nullptr;  float* b_e = nullptr;
+  // sampler loops (o, c fixed over the steps; split first linear only): the offset / context part of the first linear is made once
+  // per loop (h0c, without the bias) and every step multiplies only the 256 coordinate features (w_ex = columns 0..255 of the weight
+  // in the split form) and adds it: out = h0c + 1 * (acc + bias) through the gated-residual epilogue with a gate of ones
+  void* w_ex = nullptr;
+  float* h0c = nullptr;
+  float* ones_d = nullptr;
+  bool embed_const_on = false;
   void* w_t0 = nullptr; float* b_t0 = nullptr;
   void* w_t2 = nullptr; float* b_t2 = nullptr;
   float* table = nullptr;

@@ -37,6 +37,7 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
   const size_t es = m->esz, D = m->D;
   auto& W = m->ws_owned;
   OSUD_TRY(dev_alloc(W, &m->e0, (size_t)Mp * m->Ke * es));
+  if (m->split_first) OSUD_TRY(dev_alloc(W, &m->h0c, (size_t)Mp * D * 4));
   OSUD_TRY(dev_alloc(W, &m->temb, (size_t)Np * 256 * es));
   OSUD_TRY(dev_alloc(W, &m->th, (size_t)Np * D * es));
   OSUD_TRY(dev_alloc(W, &m->sb, (size_t)Np * D * es));
@@ -178,10 +179,15 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
 
   // token embedding + first linear (models.py:315-317)
   // (bf16 tier: rows and weights in the split [hi | lo | hi] x [w_hi | w_hi | w_lo] form, Ke = 3 Kp -- see embed_kernel)
+  float* h = m->training ? m->saved[0].h_in : m->h;
+  if (m->embed_const_on) {  // inside a sampler loop: h = h0c (made by embed_const_prepare) + coordinate features x their 256 columns
+    OSUD_TRY(launch_embed(prec, x, o, c, m->freqs64, m->pf[0], m->pf[1], m->e0, N, T, Tp, Mp, m->E, m->Kp, cfg ? N / 2 : 0, st, true, 1));
+    OSUD_TRY(gemm(m, EPI_GATE_RES, m->e0, 768, m->w_ex, 768, Mp, D, 768, h, D, m->b_e, st, m->ones_d, 0, Tp, N, nullptr, m->h0c));
+  } else {
   OSUD_TRY(launch_embed(prec, x, o, c, m->freqs64, m->pf[0], m->pf[1], m->e0, N, T, Tp, Mp, m->E, m->Kp, cfg ? N / 2 : 0, st,
                         m->split_first));
-  float* h = m->training ? m->saved[0].h_in : m->h;
   OSUD_TRY(gemm(m, EPI_BIAS_F32, m->e0, m->Ke, m->w_e, m->Ke, Mp, D, m->Ke, h, D, m->b_e, st));
+  }
   // conditioning vector b = t_emb + y_emb (models.py:318-320) and ALL adaLN modulations in one GEMM:
   // b is the same for every block, so the 12 x (D -> 6D) + (D -> 2D) linears are one (Np x D) x (D x AC) product.
   OSUD_TRY(launch_temb(prec, t, m->freqs128, m->temb, N, Np, st));
@@ -353,6 +359,7 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   int rc = OSUD_OK;
   auto A = [&](auto** p, size_t bytes) { if (rc == OSUD_OK) rc = dev_alloc(m->owned, p, bytes); };
   A(&m->w_e, D * m->Ke * es); A(&m->b_e, D * 4);
+  if (m->split_first) { A(&m->w_ex, D * 768 * es); A(&m->ones_d, D * 4); }
   A(&m->w_t0, D * 256 * es);  A(&m->b_t0, D * 4);
   A(&m->w_t2, D * D * es);    A(&m->b_t2, D * 4);
   A(&m->table, (size_t)cfg->table_rows * D * 4);
@@ -376,6 +383,10 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   if (rc != OSUD_OK) {
     osud_dit_destroy(m);
     return rc;
+  }
+  if (m->ones_d) {
+    std::vector<float> ones((size_t)m->D, 1.0f);
+    (void)hipMemcpy(m->ones_d, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice);
   }
   // default frequency tables: exp(-ln(1e4) * k / half) in fp32 (positional_embedding.py:39-44).
   // The host may overwrite them with torch's own values through the "const.freqs64/128" keys.
@@ -444,6 +455,7 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
     SHAPE(D, 384 + m->E);
     rc = m->split_first ? launch_pack_rows_split(src, 384 + m->E, 384 + m->E, m->w_e, m->Kp, (int)D, st)
                         : launch_pack_rows(prec, src, 384 + m->E, 384 + m->E, m->w_e, m->Kp, m->Kp, (int)D, st);
+    if (rc == OSUD_OK && m->split_first) rc = launch_pack_rows_split(src, 384 + m->E, 256, m->w_ex, 256, (int)D, st);  // coordinate columns
   } else if (k == "xoc_embedder.mlp.0.bias") { SHAPE(D); rc = upload_f32(m, &m->b_e, src, D, st);
   } else if (k == "t_embedder.mlp.0.weight") { SHAPE(D, 256); rc = convert_w(m, src, m->w_t0, D * 256, st);
   } else if (k == "t_embedder.mlp.0.bias") { SHAPE(D); rc = upload_f32(m, &m->b_t0, src, D, st);
@@ -527,6 +539,14 @@ extern "C" int osud_dit_forward(osud_dit* m, const float* x, const int64_t* t, c
 }
 
 // one loop iteration: timestep bookkeeping -> forward -> sampler update (x updated in place)
+// The step-invariant part of the first linear, once per sampler loop: offsets and context (coordinate features zeroed) times the
+// whole weight, no bias.  (x is only read for its shape here.)
+static int embed_const_prepare(osud_dit* m, const float* x, const float* o, const float* c, int N, int T, bool cfg, hipStream_t st) {
+  const int Tp = round_up(T, 64), Mp = round_up(N * Tp, 128);
+  OSUD_TRY(launch_embed(m->prec, x, o, c, m->freqs64, m->pf[0], m->pf[1], m->e0, N, T, Tp, Mp, m->E, m->Kp, cfg ? N / 2 : 0, st, true, 2));
+  return gemm(m, EPI_NONE_F32, m->e0, m->Ke, m->w_e, m->Ke, Mp, m->D, m->Ke, m->h0c, m->D, nullptr, st);
+}
+
 static int loop_body(osud_dit* m, const osud_sched* s, int mode, float eta, float* x, const float* o, const float* c,
                      const int64_t* y, const uint8_t* mask, int N, int T, float cfg_scale, int clip, const float* noise,
                      uint64_t seed, const osud_inpaint* inpaint, hipStream_t st) {
@@ -562,6 +582,18 @@ extern "C" int osud_sample_loop_inpaint(osud_dit* m, const osud_sched* s, int mo
   OSUD_TRY(dit_ensure_ws(m, N, T, m->training));
   OSUD_TRY(launch_step_init(m->step_state, first_step, seed, st));  // the seed travels in device memory, not in the graph
   const int n_steps = first_step - last_step + 1;
+  // o and c do not change over the steps of a loop: their share of the first linear is computed here, once (OSUD_EMBED_CONST=0: off)
+  struct ConstGuard {
+    osud_dit* m;
+    ~ConstGuard() { m->embed_const_on = false; }
+  } const_guard{m};
+  {
+    const char* ec = getenv("OSUD_EMBED_CONST");
+    if (m->split_first && m->h0c != nullptr && !(ec && ec[0] == '0')) {
+      OSUD_TRY(embed_const_prepare(m, x, o, c, N, T, cfg_scale >= 0.f, st));
+      m->embed_const_on = true;  // (consulted while the step is captured / run eagerly; replays of the graph read h0c)
+    }
+  }
   const char* ng = getenv("OSUD_NO_GRAPH");
   if (ng && ng[0] == '1') {
     for (int k = 0; k < n_steps; ++k)
@@ -569,7 +601,7 @@ extern "C" int osud_sample_loop_inpaint(osud_dit* m, const osud_sched* s, int mo
     return OSUD_OK;
   }
   GraphKey key{N, T, mode, clip, attn_mask != nullptr, noise != nullptr, cfg_scale, eta, o, c, y, attn_mask, x, noise, s,
-               held.keep, held.known};
+               held.keep, held.known, m->embed_const_on ? 1 : 0};
   if (!(m->graph_valid && m->graph_key == key)) {
     if (m->graph_exec) {
       (void)hipGraphExecDestroy(m->graph_exec);

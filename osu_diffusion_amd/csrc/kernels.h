@@ -7,7 +7,8 @@ namespace osud {
 
 int launch_embed(int prec, const float* x, const float* o, const float* c, const float* freqs64, float pf0, float pf1,
                  void* out, int N, int T, int Tp, int Mp, int E, int Kp, int x_dup_half, hipStream_t st,
-                 bool split = false /* bf16 only: rows are [hi | lo | hi], 3 * Kp columns (see embed_kernel) */);
+                 bool split = false /* bf16 only: rows are [hi | lo | hi], 3 * Kp columns (see embed_kernel) */,
+                 int mode = 0 /* 1: coordinate features only (compact 256-column row), 2: whole row, coordinate features zeroed */);
 int launch_temb(int prec, const int64_t* t, const float* freqs128, void* out, int N, int Np, hipStream_t st);
 int launch_cond(int prec, const float* tvec, const float* table, const int64_t* y, int table_rows, float* b_out,
                 void* sb_out, int N, int Np, int D, hipStream_t st);

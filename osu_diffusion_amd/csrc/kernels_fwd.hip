@@ -26,7 +26,10 @@ template <typename TE, bool SPLIT>
 __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x, const float* __restrict__ o,
                                                     const float* __restrict__ c, const float* __restrict__ freqs64,
                                                     float pf0, float pf1, TE* __restrict__ out, int N, int T, int Tp,
-                                                    int E, int Kp, int x_dup_half) {
+                                                    int E, int Kp, int x_dup_half, int mode) {
+  // mode 0: the whole row.  The sampler loop splits the first linear into its step-invariant part (offsets and context: mode 2 =
+  // the whole row with the coordinate features zeroed, multiplied ONCE per loop) and the part that follows x (mode 1 = a compact row
+  // of the 256 coordinate features only, Kp = 256, E = 0: 40 % of the columns and of the sincos work per step)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int TOK = 16;
   const int ldr = SPLIT ? 3 * Kp : Kp;       // row length in elements
@@ -49,11 +52,12 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x,
   };
   const int nx = (x_dup_half > 0 && n >= x_dup_half) ? n - x_dup_half : n;  // forward_with_cfg: cat([half, half])
   // (a) sin/cos features: TOK tokens x 3 scalars x 64 frequencies
-  for (int idx = tid; idx < TOK * 192; idx += 256) {
-    const int tok = idx / 192, rem = idx % 192, which = rem >> 6, k = rem & 63;
+  const int nfeat = mode == 1 ? 128 : 192;  // scalar features x 64 frequencies per token
+  for (int idx = tid; idx < TOK * nfeat; idx += 256) {
+    const int tok = idx / nfeat, rem = idx % nfeat, which = rem >> 6, k = rem & 63;
     const int t = t0 + tok;
     float cs = 0.f, sn = 0.f;
-    if (t < T) {
+    if (t < T && !(mode == 2 && which < 2)) {
       float v;
       if (which == 0) v = x[((size_t)nx * 2 + 0) * T + t] * pf0;        // models.py:229
       else if (which == 1) v = x[((size_t)nx * 2 + 1) * T + t] * pf1;
@@ -65,16 +69,17 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x,
     put(tok, which * 128 + 64 + k, sn);
   }
   // (b) context rows, read along T
-  for (int idx = tid; idx < TOK * E; idx += 256) {
+  for (int idx = tid; idx < (mode == 1 ? 0 : TOK * E); idx += 256) {
     const int e = idx / TOK, tok = idx % TOK;
     const int t = t0 + tok;
     const float v = t < T ? c[((size_t)n * E + e) * T + t] : 0.f;
     put(tok, 384 + e, v);
   }
-  for (int idx = tid; idx < TOK * (Kp - 384 - E); idx += 256) {
-    const int tok = idx / (Kp - 384 - E), k = idx % (Kp - 384 - E);
-    put(tok, 384 + E + k, 0.f);
-  }
+  if (mode != 1)
+    for (int idx = tid; idx < TOK * (Kp - 384 - E); idx += 256) {
+      const int tok = idx / (Kp - 384 - E), k = idx % (Kp - 384 - E);
+      put(tok, 384 + E + k, 0.f);
+    }
   __syncthreads();
   // (c) whole rows out, 16 bytes per lane
   const int n16 = TOK * ldr * (int)sizeof(TE) / 16;
@@ -461,20 +466,25 @@ int launch_f8_update(float* slots, int n_slots, hipStream_t st, float* parts) {
 // ---------------------------------------------------------------------------------- launchers
 template <typename TE, bool SPLIT>
 static int embed_t(const float* x, const float* o, const float* c, const float* freqs64, float pf0, float pf1, void* out,
-                   int N, int T, int Tp, int Mp, int E, int Kp, int x_dup_half, hipStream_t st) {
+                   int N, int T, int Tp, int Mp, int E, int Kp, int x_dup_half, hipStream_t st, int mode) {
   const size_t lds = (size_t)16 * Kp * sizeof(TE) * (SPLIT ? 3 : 1);
   hipLaunchKernelGGL((embed_kernel<TE, SPLIT>), dim3(Mp / 16), dim3(256), lds, st, x, o, c, freqs64, pf0, pf1, (TE*)out, N, T,
-                     Tp, E, Kp, x_dup_half);
+                     Tp, E, Kp, x_dup_half, mode);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }
 int launch_embed(int prec, const float* x, const float* o, const float* c, const float* freqs64, float pf0, float pf1,
-                 void* out, int N, int T, int Tp, int Mp, int E, int Kp, int x_dup_half, hipStream_t st, bool split) {
-  OSUD_CHECK_ARG(Tp % 16 == 0 && Mp % 16 == 0 && Kp >= 384 + E && (Kp * elem_size(prec)) % 16 == 0, "embed: bad sizes");
+                 void* out, int N, int T, int Tp, int Mp, int E, int Kp, int x_dup_half, hipStream_t st, bool split, int mode) {
+  if (mode == 1) {  // coordinate features only: a compact row of 256 (x 3 in the split form) columns
+    OSUD_CHECK_ARG(split && prec == OSUD_PREC_BF16, "embed: the coordinate-only row exists in the split bf16 form");
+    E = 0;
+    Kp = 256;
+  }
+  OSUD_CHECK_ARG(Tp % 16 == 0 && Mp % 16 == 0 && Kp >= (mode == 1 ? 256 : 384 + E) && (Kp * elem_size(prec)) % 16 == 0, "embed: bad sizes");
   OSUD_CHECK_ARG(!split || (prec == OSUD_PREC_BF16 && (size_t)16 * Kp * 6 <= 64 * 1024), "embed: the split row form is bf16 only");
-  if (split) return embed_t<bf16_t, true>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st);
-  return prec == OSUD_PREC_BF16 ? embed_t<bf16_t, false>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st)
-                                : embed_t<float, false>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st);
+  if (split) return embed_t<bf16_t, true>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode);
+  return prec == OSUD_PREC_BF16 ? embed_t<bf16_t, false>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode)
+                                : embed_t<float, false>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode);
 }
 
 int launch_pack_rows_split(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, hipStream_t st) {

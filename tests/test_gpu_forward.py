@@ -395,6 +395,33 @@ def test_chained_loop_bf16_drift_is_bounded():
     assert drift < 5e-2
 
 
+def test_loop_with_split_off_constant_first_linear_part(monkeypatch):
+    """Inside a sampler loop the offsets / context share of the first linear is multiplied once and only the 256 coordinate features
+    every step (bf16 tier).  Same sums in a different order: one step must agree with the one-product form to fp32 rounding carried
+    through the bf16 trunk, the 20-step CFG-4 loop stays inside the tier's drift bound against the reference, and a second loop with
+    OTHER offsets / context through the same buffers must not see stale values."""
+    fx = load("g6_loop_p20")
+    shape, sd = weights_for(fx)
+    d = create_diffusion("20", noise_schedule="squaredcos_cap_v2")
+    z = T(fx["z"]).to(DEV)
+    o, c, y = T(fx["o"]).to(DEV), T(fx["c"]).to(DEV), T(fx["y"]).to(DEV)
+    one, fins = {}, {}
+    for flag in ("0", "1"):
+        monkeypatch.setenv("OSUD_EMBED_CONST", flag)
+        m = native_model(shape, sd, "bf16")
+        kw = dict(o=o.clone(), c=c.clone(), y=y, cfg_scale=4.0, attn_mask=None)
+        one[flag] = d.run_steps(m.forward_with_cfg, z.clone(), kw, 19, 19, seed=3).cpu()
+        a = d.p_sample_loop(m.forward_with_cfg, z.shape, z, model_kwargs=kw, step_noise=T(fx["noises"])).cpu()
+        kw["o"].add_(37.0)          # same buffers, new contents
+        kw["c"].mul_(0.5)
+        b = d.p_sample_loop(m.forward_with_cfg, z.shape, z, model_kwargs=kw, step_noise=T(fx["noises"])).cpu()
+        fins[flag] = (a, b)
+    assert maxdiff(one["0"], one["1"]) < 2e-3
+    assert maxdiff(fins["1"][0], fx["final"]) < 5e-2 and maxdiff(fins["0"][0], fx["final"]) < 5e-2
+    assert maxdiff(fins["0"][1], fins["1"][1]) < 5e-2
+    assert maxdiff(fins["1"][0], fins["1"][1]) > 1e-1  # the second loop did see the new offsets / context
+
+
 def test_generic_path_with_denoised_fn_uses_native_forward():
     """in-paint style hook (testing/test_toy.py:56-74): generic Python step around the native forward."""
     shape = mo.DitShape(depth=2, hidden=128, heads=2, num_classes=10)
