@@ -88,6 +88,12 @@ struct osud_dit {
   float* h0c = nullptr;
   float* ones_d = nullptr;
   bool embed_const_on = false;
+  // ... and the timestep-embedding MLP (models.py:29-36) once per loop for every schedule index (tv_all [steps][D]); a step's
+  // conditioning kernel reads its row through the per-row schedule index the step-begin kernel writes
+  float* tv_all = nullptr;
+  void *temb_all = nullptr, *th_all = nullptr;
+  int tv_cap = 0;  // rows the three buffers hold
+  bool tvec_table_on = false;
   void* w_t0 = nullptr; float* b_t0 = nullptr;
   void* w_t2 = nullptr; float* b_t2 = nullptr;
   float* table = nullptr;

@@ -190,11 +190,16 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
   }
   // conditioning vector b = t_emb + y_emb (models.py:318-320) and ALL adaLN modulations in one GEMM:
   // b is the same for every block, so the 12 x (D -> 6D) + (D -> 2D) linears are one (Np x D) x (D x AC) product.
+  if (m->tvec_table_on) {  // inside a sampler loop: the MLP's output for every schedule index was made by tvec_table_prepare
+    OSUD_TRY(launch_cond(prec, m->tv_all, m->table_ref ? m->table_ref : m->table, y, m->cfg.table_rows, m->bvec, m->sb, N, Np, D, st,
+                         m->t_index));
+  } else {
   OSUD_TRY(launch_temb(prec, t, m->freqs128, m->temb, N, Np, st));
   OSUD_TRY(gemm(m, EPI_BIAS_SILU_TE, m->temb, 256, m->w_t0, 256, Np, D, 256, m->th, D, m->b_t0, st, nullptr, 0, 0, 0,
                 m->training ? m->z0 : nullptr));
   OSUD_TRY(gemm(m, EPI_BIAS_F32, m->th, D, m->w_t2, D, Np, D, D, m->tvec, D, m->b_t2, st));
   OSUD_TRY(launch_cond(prec, m->tvec, m->table_ref ? m->table_ref : m->table, y, m->cfg.table_rows, m->bvec, m->sb, N, Np, D, st));
+  }
   OSUD_TRY(gemm(m, EPI_BIAS_F32, m->sb, D, m->w_ada, D, Np, AC, D, m->ada, AC, m->b_ada, st));
 
   if (mask != nullptr) OSUD_TRY(launch_mask_tiles(mask, T, Tp, m->kb_class, st));  // once per forward, shared by all blocks
@@ -547,6 +552,21 @@ static int embed_const_prepare(osud_dit* m, const float* x, const float* o, cons
   return gemm(m, EPI_NONE_F32, m->e0, m->Ke, m->w_e, m->Ke, Mp, m->D, m->Ke, m->h0c, m->D, nullptr, st);
 }
 
+// The timestep-embedding MLP for every schedule index of the loop's schedule, once per loop (the steps of a loop share their t over
+// the rows, and there are at most a thousand different ones): temb -> Linear + SiLU -> Linear, as in the forward.
+static int tvec_table_prepare(osud_dit* m, const osud_sched* s, hipStream_t st) {
+  const int nt = osud_sched_num_timesteps(s), rows = round_up(nt, 128), D = m->D;
+  if (rows > m->tv_cap) {  // (first loop on this handle, or a longer schedule: the old buffers stay owned until the handle goes)
+    OSUD_TRY(dev_alloc(m->owned, &m->tv_all, (size_t)rows * D * 4));
+    OSUD_TRY(dev_alloc(m->owned, &m->temb_all, (size_t)rows * 256 * m->esz));
+    OSUD_TRY(dev_alloc(m->owned, &m->th_all, (size_t)rows * D * m->esz));
+    m->tv_cap = rows;
+  }
+  OSUD_TRY(launch_temb(m->prec, sched_tmap_dev(s), m->freqs128, m->temb_all, nt, rows, st));
+  OSUD_TRY(gemm(m, EPI_BIAS_SILU_TE, m->temb_all, 256, m->w_t0, 256, rows, D, 256, m->th_all, D, m->b_t0, st));
+  return gemm(m, EPI_BIAS_F32, m->th_all, D, m->w_t2, D, rows, D, D, m->tv_all, D, m->b_t2, st);
+}
+
 static int loop_body(osud_dit* m, const osud_sched* s, int mode, float eta, float* x, const float* o, const float* c,
                      const int64_t* y, const uint8_t* mask, int N, int T, float cfg_scale, int clip, const float* noise,
                      uint64_t seed, const osud_inpaint* inpaint, hipStream_t st) {
@@ -585,8 +605,15 @@ extern "C" int osud_sample_loop_inpaint(osud_dit* m, const osud_sched* s, int mo
   // o and c do not change over the steps of a loop: their share of the first linear is computed here, once (OSUD_EMBED_CONST=0: off)
   struct ConstGuard {
     osud_dit* m;
-    ~ConstGuard() { m->embed_const_on = false; }
+    ~ConstGuard() { m->embed_const_on = m->tvec_table_on = false; }
   } const_guard{m};
+  {
+    const char* tt = getenv("OSUD_TVEC_TABLE");
+    if (!(tt && tt[0] == '0')) {
+      OSUD_TRY(tvec_table_prepare(m, s, st));
+      m->tvec_table_on = true;
+    }
+  }
   {
     const char* ec = getenv("OSUD_EMBED_CONST");
     if (m->split_first && m->h0c != nullptr && !(ec && ec[0] == '0')) {
@@ -601,7 +628,7 @@ extern "C" int osud_sample_loop_inpaint(osud_dit* m, const osud_sched* s, int mo
     return OSUD_OK;
   }
   GraphKey key{N, T, mode, clip, attn_mask != nullptr, noise != nullptr, cfg_scale, eta, o, c, y, attn_mask, x, noise, s,
-               held.keep, held.known, m->embed_const_on ? 1 : 0};
+               held.keep, held.known, (m->embed_const_on ? 1 : 0) | (m->tvec_table_on ? 2 : 0)};
   if (!(m->graph_valid && m->graph_key == key)) {
     if (m->graph_exec) {
       (void)hipGraphExecDestroy(m->graph_exec);

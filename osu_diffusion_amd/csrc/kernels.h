@@ -11,7 +11,7 @@ int launch_embed(int prec, const float* x, const float* o, const float* c, const
                  int mode = 0 /* 1: coordinate features only (compact 256-column row), 2: whole row, coordinate features zeroed */);
 int launch_temb(int prec, const int64_t* t, const float* freqs128, void* out, int N, int Np, hipStream_t st);
 int launch_cond(int prec, const float* tvec, const float* table, const int64_t* y, int table_rows, float* b_out,
-                void* sb_out, int N, int Np, int D, hipStream_t st);
+                void* sb_out, int N, int Np, int D, hipStream_t st, const int64_t* t_index = nullptr);
 // br != nullptr: the row is first updated to h + ada[n][off_gate..] * br (written to h_out if given, may be h itself)
 int launch_ln_mod(int prec, const float* h, const float* ada, int ld_ada, int off_shift, int off_scale, void* out,
                   float* stats, int M, int Tp, int N, int D, hipStream_t st, const void* br = nullptr, int off_gate = 0,

@@ -103,7 +103,8 @@ __global__ void temb_kernel(const int64_t* __restrict__ t, const float* __restri
 template <typename TE>
 __global__ void cond_kernel(const float* __restrict__ tvec, const float* __restrict__ table,
                             const int64_t* __restrict__ y, int table_rows, float* __restrict__ b_out,
-                            TE* __restrict__ sb_out, int N, int D) {
+                            TE* __restrict__ sb_out, int N, int D, const int64_t* __restrict__ t_index) {
+  // t_index != nullptr (sampler loops): tvec is a table with one row per schedule index, made once per loop; row n reads its step's
   constexpr bool FAST = sizeof(TE) == 2;
   const int n = blockIdx.x;
   if (n >= N) {
@@ -115,8 +116,9 @@ __global__ void cond_kernel(const float* __restrict__ tvec, const float* __restr
   }
   int64_t cls = y[n];
   cls = cls < 0 ? 0 : (cls >= table_rows ? table_rows - 1 : cls);
+  const float* trow = tvec + (size_t)(t_index != nullptr ? t_index[n] : (int64_t)n) * D;
   for (int d = threadIdx.x; d < D; d += blockDim.x) {
-    const float b = tvec[(size_t)n * D + d] + table[(size_t)cls * D + d];  // models.py:320
+    const float b = trow[d] + table[(size_t)cls * D + d];  // models.py:320
     b_out[(size_t)n * D + d] = b;
     store_elem(sb_out + (size_t)n * D + d, silu_t<FAST>(b));
   }
@@ -506,13 +508,13 @@ int launch_temb(int prec, const int64_t* t, const float* freqs128, void* out, in
 }
 
 int launch_cond(int prec, const float* tvec, const float* table, const int64_t* y, int table_rows, float* b_out,
-                void* sb_out, int N, int Np, int D, hipStream_t st) {
+                void* sb_out, int N, int Np, int D, hipStream_t st, const int64_t* t_index) {
   if (prec == OSUD_PREC_BF16)
     hipLaunchKernelGGL((cond_kernel<bf16_t>), dim3(Np), dim3(256), 0, st, tvec, table, y, table_rows, b_out,
-                       (bf16_t*)sb_out, N, D);
+                       (bf16_t*)sb_out, N, D, t_index);
   else
     hipLaunchKernelGGL((cond_kernel<float>), dim3(Np), dim3(256), 0, st, tvec, table, y, table_rows, b_out,
-                       (float*)sb_out, N, D);
+                       (float*)sb_out, N, D, t_index);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }
