@@ -952,6 +952,9 @@ template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
     static const int thr = [] { const char* e = getenv("OSUD_GEMM_SMALL_PCT"); return e ? atoi(e) : 75; }();
     if (pick == 0 && (long)(p.My / 128) * (p.Nx / 128) * splits * 100 < (long)cus * thr) pick = 6;
   }
+  // one row of 128-row tiles and a wide output (the adaLN product of a sampling step: 128 x 56 832 x 768 streams 87 MB of weights):
+  // 128x256 tiles make it one round instead of 1.7 (28.1 -> 23.9 us)
+  if (pick == 0 && p.My == 128 && p.Nx % 256 == 0 && splits == 1 && (long)(p.Nx / 128) > cus) pick = 8;
   if (const char* force = getenv("OSUD_GEMM_TILE")) {  // "64" | "128" | "192" | "256": tuning / A-B runs
     const std::string f(force);
     if (f == "128") pick = 0;
