@@ -239,11 +239,11 @@ __global__ __launch_bounds__(NT) void attn_bwd_bf16_kernel(const bf16_t* __restr
 #ifndef OSUD_ATTN_EXP
 #define OSUD_ATTN_EXP 0
 #endif
-template <int T>
+template <int T, bool DBIAS>
 __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                               const bf16_t* __restrict__ O, const float* __restrict__ lse,
                                                               bf16_t* __restrict__ dqkv, int D, int H, int items, float c1,
-                                                              float scale, unsigned* __restrict__ queue) {
+                                                              float scale, unsigned* __restrict__ queue, float* __restrict__ bias_part) {
   constexpr int HD = 64, HDP = 64, DT = 2;
   using TL = AttnTile<HDP>;
   constexpr int TILE = T * TL::RS;  // bytes
@@ -260,6 +260,31 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __re
   const uint32_t lds0 = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 31, fhalf = lane >> 5;
+  // DBIAS: the in_proj bias gradient (column sums of dQ | dK | dV over all tokens) rides along.  A wave's 32-row column sums come
+  // out of store_rows_patch<true> (an MFMA against ones on the rows already sitting in the LDS patch); they meet their three
+  // sibling waves in cs_s at the next head's barrier, where one wave per part adds the four in a fixed order and writes the head's
+  // 64 sums to bias_part[n][part * D + h * 64 ..] -- every element exactly once; a fixed-order column pass over the N rows follows
+  // the kernel.  (Before: a pass over the whole dqkv tensor, 24 us per launch, summed with atomics.)
+  float* cs_s = reinterpret_cast<float*>(smem + 8 * TILE + 4 * T * 4 + 8 * 2048 + 16);  // [2][3 parts][4 waves][64]
+  auto put_colsums = [&](const f32x16 (&cacc)[2], int slot, int part) {
+    int lo = lane;
+    asm volatile("" : "+v"(lo));  // (opaque, as above)
+    if ((lo & 31) == 0) {
+      float* dst = cs_s + ((slot * 3 + part) * 4 + (wave & 3)) * 64 + 4 * (lo >> 5);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(dst + dt * 32 + 8 * g) = f32x4{cacc[dt][4 * g], cacc[dt][4 * g + 1], cacc[dt][4 * g + 2], cacc[dt][4 * g + 3]};
+    }
+  };
+  auto flush_colsums = [&](int slot, int head) {  // waves 0..2: one part each, lane = column
+    if (wave < 3) {
+      const float* src = cs_s + (slot * 3 + wave) * 4 * 64;
+      const int n = head / H, h = head - n * H;
+      bias_part[(size_t)n * 3 * D + (size_t)wave * D + h * HD + lane] = src[lane] + src[64 + lane] + src[128 + lane] + src[192 + lane];
+    }
+  };
   const size_t ld3 = 3 * (size_t)D;
   // LDS-DMA: one instruction = 64 lanes x 16 bytes = 8 tile rows, written linearly; lane (lr = lane / 8, pc = lane % 8) therefore
   // fetches the chunk that AttnTile::off places at physical position pc of row 8 p + lr: pc ^ ((row >> 1) & 7).
@@ -322,7 +347,8 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __re
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the first head's tiles
     put_stats(0);
   }
-  for (; it < items; it = nx, buf ^= 1, ++iter) {
+  int prev = 0;  // the head of the previous iteration (DBIAS)
+  for (; it < items; prev = it, it = nx, buf ^= 1, ++iter) {
     const char* Qs = smem + (size_t)buf * 4 * TILE;
     const char* Ks = Qs + TILE;
     const char* Vs = Ks + TILE;
@@ -331,6 +357,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __re
     const float* del_b = del_s + buf * T;
     // every wave has waited for its own pieces of this head and written its statistics; the other buffers are free from here on
     __syncthreads();
+    if (DBIAS && iter > 0) flush_colsums((iter - 1) & 1, prev);
     if (iter > 0) nx = queue != nullptr ? 2 * G + __builtin_amdgcn_readfirstlane((int)tword[iter & 1]) : it + G;  // (iteration 0: b + G)
     uint32_t tk = 0;
     if (ticket_lane) tk = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -359,7 +386,15 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __re
         put_stats(buf ^ 1);
       }
       if (ticket_lane) tword[(iter + 1) & 1] = tk;  // (the ticket has had the whole pass to return)
-      if (!(OSUD_ATTN_EXP & 1)) store_rows_patch(patch, orows, ld3, dq, lane);
+      if (DBIAS) {
+        f32x16 cacc[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) cacc[i][r] = 0.f;
+        store_rows_patch<true>(patch, orows, ld3, dq, lane, cacc);
+        put_colsums(cacc, iter & 1, 0);
+      } else if (!(OSUD_ATTN_EXP & 1)) store_rows_patch(patch, orows, ld3, dq, lane);
       else if (dq[0][0] == 12345.f) orow[0] = 1;
     } else {
       f32x16 dk[DT], dv[DT];
@@ -375,10 +410,27 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __re
         put_stats(buf ^ 1);
       }
       if (!(OSUD_ATTN_EXP & 1)) {
+      if (DBIAS) {
+        f32x16 cacc[2];
+#pragma unroll
+        for (int part = 1; part < 3; ++part) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cacc[i][r] = 0.f;
+          store_rows_patch<true>(patch, orows + part * D, ld3, part == 1 ? dk : dv, lane, cacc);
+          put_colsums(cacc, iter & 1, part);
+        }
+      } else {
       store_rows_patch(patch, orows + D, ld3, dk, lane);
       store_rows_patch(patch, orows + 2 * D, ld3, dv, lane);
+      }
       } else if (dk[0][0] + dv[0][0] == 12345.f) orow[D] = 1;
     }
+  }
+  if (DBIAS && iter > 0) {  // the last head's column sums
+    __syncthreads();
+    flush_colsums((iter - 1) & 1, prev);
   }
   if (ticket_lane) {  // the last workgroup out re-arms the counters
     const unsigned done = __hip_atomic_fetch_add(queue + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -900,7 +952,8 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_f32_kernel(const float* __res
 }  // namespace
 
 int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* O, const float* lse, void* dqkv, int N,
-                         int T, int heads, int head_dim, hipStream_t st, float* delta_ws, float* dbias) {
+                         int T, int heads, int head_dim, hipStream_t st, float* delta_ws, float* dbias, float* bias_scratch,
+                         size_t bias_scratch_elems) {
   OSUD_CHECK_ARG(N > 0 && T > 0 && T % 64 == 0, "attention backward: T=%d must be a multiple of 64", T);
   const int D = heads * head_dim;
   const float scale = 1.0f / sqrtf((float)head_dim);
@@ -954,26 +1007,41 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
     const float c1 = scale * 1.4426950408889634f;
     const char* stream_env = getenv("OSUD_ATTN_BWD_STREAM");  // "0": the one-workgroup-per-head kernel (A/B runs, tests)
     const bool stream_on = !(stream_env && stream_env[0] == '0');
-    if (head_dim == 64 && T == 128 && dbias == nullptr && stream_on) {
-      constexpr size_t slds = (size_t)8 * 128 * AttnTile<64>::RS + 4 * 128 * 4 + 8 * 2048 + 16;
-      OSUD_BIG_LDS_ONCE(attn_bwd_stream_kernel<128>);
+    if (head_dim == 64 && T == 128 && stream_on) {
+      constexpr size_t slds = (size_t)8 * 128 * AttnTile<64>::RS + 4 * 128 * 4 + 8 * 2048 + 16 + 2 * 3 * 4 * 64 * 4;
       const int cus = device_cus();
       const int items = N * heads;
-      hipLaunchKernelGGL((attn_bwd_stream_kernel<128>), dim3(items < cus ? items : cus), dim3(512), slds, st, (const bf16_t*)qkv,
-                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, D, heads, items, c1, scale,
-                         (gemm_dynamic_tiles_on() && items > 2 * cus) ? gemm_ticket_slot() : nullptr);
+      unsigned* queue = (gemm_dynamic_tiles_on() && items > 2 * cus) ? gemm_ticket_slot() : nullptr;
+      const bool fuse_bias = dbias != nullptr && bias_scratch != nullptr && (size_t)N * 3 * D <= bias_scratch_elems && N >= 64;
+      if (fuse_bias) {
+        OSUD_BIG_LDS_ONCE((attn_bwd_stream_kernel<128, true>));
+        hipLaunchKernelGGL((attn_bwd_stream_kernel<128, true>), dim3(items < cus ? items : cus), dim3(512), slds, st, (const bf16_t*)qkv,
+                           (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, D, heads, items, c1, scale, queue, bias_scratch);
+        OSUD_HIP(hipGetLastError());
+        return launch_colsum_f32(bias_scratch, N, 3 * D, dbias, st);  // fixed-order sum over the samples
+      }
+      OSUD_BIG_LDS_ONCE((attn_bwd_stream_kernel<128, false>));
+      hipLaunchKernelGGL((attn_bwd_stream_kernel<128, false>), dim3(items < cus ? items : cus), dim3(512), slds, st, (const bf16_t*)qkv,
+                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, D, heads, items, c1, scale, queue, nullptr);
       OSUD_HIP(hipGetLastError());
+      if (dbias != nullptr) OSUD_TRY(launch_colsum_bf16(dqkv, 3 * D, N * T, 3 * D, dbias, st));
       return OSUD_OK;
     }
+    // (OSUD_FUSE_BQKV=1: the bias gradient by lane butterflies inside these kernels -- measured slower than the column-sum pass)
+    static const bool butterfly = [] { const char* e = getenv("OSUD_FUSE_BQKV"); return e && e[0] == '1'; }();
+    float* kbias = butterfly ? dbias : nullptr;
     if (head_dim == 64 && T <= 128)
       hipLaunchKernelGGL((attn_bwd_bf16_kernel<64, 64, 256>), dim3(heads, N), dim3(256), lds, st, (const bf16_t*)qkv,
-                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale, dbias);
+                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale, kbias);
     else if (head_dim == 64)
       hipLaunchKernelGGL((attn_bwd_bf16_kernel<64, 64, 512>), dim3(heads, N), dim3(512), lds, st, (const bf16_t*)qkv,
-                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale, dbias);
+                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale, kbias);
     else
       hipLaunchKernelGGL((attn_bwd_bf16_kernel<72, 96, 256>), dim3(heads, N), dim3(256), lds, st, (const bf16_t*)qkv,
-                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale, dbias);
+                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale, kbias);
+    OSUD_HIP(hipGetLastError());
+    if (dbias != nullptr && !butterfly) OSUD_TRY(launch_colsum_bf16(dqkv, 3 * D, N * T, 3 * D, dbias, st));
+    return OSUD_OK;
   } else {
     const dim3 grid(T / 64, heads, N);
 #define OSUD_ABWD(HD)                                                                                                   \

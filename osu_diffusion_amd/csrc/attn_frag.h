@@ -64,7 +64,13 @@ __device__ __forceinline__ u32x4 pack8(const f32x16& v, int base) {
 // a lane owns a ROW of the accumulators, so a direct store instruction touches 32 rows with 16 bytes each -- 24 such
 // instructions per head and wave were 56 of the streamed backward kernel's 132 us (tools/attn_bench.py, stores compiled out).  Sixteen rows at a time go to the patch (16-byte chunks XOR-swizzled with
 // the row) and come back as 16 bytes per lane, eight lanes per 128-byte row: every store instruction writes eight full lines.
-__device__ __forceinline__ void store_rows_patch(char* patch, bf16_t* rows, size_t ld, const f32x16 (&acc)[2], int lane) {
+// COLSUM: the column sums of the 32 rows ride along -- the 16 rows that sit in the patch (the AttnTile<64> layout, so trfrag reads
+// it) are contracted with a ones operand on the matrix pipe: D[d][*] += sum_rows bf16(row)[d].  Every lane ends with 16 of the
+// 64 column sums per accumulator (row index of the MFMA result = column d); lanes 0 and 32 together hold all of them.
+template <bool COLSUM = false>
+__device__ __forceinline__ void store_rows_patch(char* patch, bf16_t* rows, size_t ld, const f32x16 (&acc)[2], int lane,
+                                                 f32x16* cacc = nullptr) {
+  if constexpr (COLSUM) asm volatile("" : "+v"(lane));  // (opaque: per-lane offsets recomputed here, not held in registers by the caller's loop)
   const int frow = lane & 31, fhalf = lane >> 5;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -77,15 +83,20 @@ __device__ __forceinline__ void store_rows_patch(char* patch, bf16_t* rows, size
           u32x2 v;
           v[0] = pack_bf2(acc[dt][4 * g], acc[dt][4 * g + 1]);
           v[1] = pack_bf2(acc[dt][4 * g + 2], acc[dt][4 * g + 3]);
-          *reinterpret_cast<u32x2*>(patch + r * 128 + (((dt * 4 + g) ^ (r & 7)) << 4) + fhalf * 8) = v;
+          *reinterpret_cast<u32x2*>(patch + AttnTile<64>::off(r, dt * 4 + g) + fhalf * 8) = v;
         }
     }
     asm volatile("" ::: "memory");  // (LDS operations of a wave execute in order; this only pins the compiler's order)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int rr = (lane >> 3) + 8 * j, c = lane & 7;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(patch + rr * 128 + ((c ^ (rr & 7)) << 4));
+      const u32x4 v = *reinterpret_cast<const u32x4*>(patch + AttnTile<64>::off(rr, c));
       *reinterpret_cast<u32x4*>(rows + (size_t)(16 * half + rr) * ld + c * 8) = v;
+    }
+    if constexpr (COLSUM) {
+      const u32x4 ones = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};  // bf16 1.0 x 8
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) cacc[dt] = mfma_bf16(trfrag<64>(patch, 0, dt * 32, lane), ones, cacc[dt]);
     }
     asm volatile("" ::: "memory");
   }

@@ -48,7 +48,9 @@ int launch_mask_tiles(const uint8_t* mask, int T, int Tp, uint8_t* kb_class, hip
 // delta_ws: [N][heads][T] fp32 scratch, needed when the sequence of one head does not fit the LDS (streamed variant)
 // dbias (optional, bf16 tier): [3 * hidden] fp32, += column sums of dqkv over all tokens (the in_proj bias gradient)
 int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* O, const float* lse, void* dqkv, int N,
-                         int T, int heads, int head_dim, hipStream_t st, float* delta_ws = nullptr, float* dbias = nullptr);
+                         int T, int heads, int head_dim, hipStream_t st, float* delta_ws = nullptr, float* dbias = nullptr,
+                         float* bias_scratch = nullptr /* N x 3 hidden floats: the streamed kernel's per-sample column sums */,
+                         size_t bias_scratch_elems = 0);  // dbias != nullptr (bf16 tier): column sums of dqkv are ADDED to / written into it
 
 // kernels_bwd.hip
 int launch_transpose(int prec, const void* in, int ld_in, void* out, int ld_out, int R, int C, float* colsum,

@@ -265,12 +265,11 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dbr, D, bw.w_o_t, D, Mp, D, D, w.dao, D, nullptr, st));
     OSUD_TRY(weight_grad(m, w.dbr, D, sv.ao, D, D, D, Mp, G(p + "attn.out_proj.weight"), nullptr, st));
     OSUD_TRY(dbg_sync(st, "wgrad out_proj"));
-    // (the in_proj bias gradient can ride in the attention backward kernel -- column sums of dQ | dK | dV by 96 five-step lane
-    // butterflies per wave -- but that made the kernel 0.74 ms per step slower to save a 0.29 ms column-sum pass: off)
-    static const bool fuse_env = [] { const char* e = getenv("OSUD_FUSE_BQKV"); return e && e[0] == '1'; }();
-    const bool fused_bqkv = prec == OSUD_PREC_BF16 && fuse_env;
+    // (bf16 tier: the in_proj bias gradient is the attention backward's job -- inside the streamed kernel at T = 128, a column-sum
+    //  pass over dqkv behind the other kernels; scratch: the split-K slab area, idle between two weight gradients)
+    const bool fused_bqkv = prec == OSUD_PREC_BF16;
     OSUD_TRY(launch_attention_bwd(prec, sv.qk, w.dao, sv.ao, sv.lse, w.dqkv, N, T, m->H, m->hd, st, w.attn_delta,
-                                  fused_bqkv ? g_bqkv : nullptr));
+                                  fused_bqkv ? g_bqkv : nullptr, w.splitk, w.splitk_elems));
     OSUD_TRY(dbg_sync(st, "attention bwd"));
     if (f8_train) OSUD_TRY(launch_f8_quantize(w.dqkv, f8_live ? m->q8b : nullptr, (size_t)Mp * 3 * D, slot(5), st));
     if (f8_live) OSUD_TRY(gemm8(m, EPI_NONE_TE, m->q8b, bw.w_qkv_t8, Mp, D, 3 * D, w.du, D, nullptr, bw.dq_qkv_t, 0.f, st, nullptr, 0, 0, 0, 0.f,

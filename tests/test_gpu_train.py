@@ -368,3 +368,30 @@ def test_queued_tiles_and_chunks_give_the_same_gradients():
     scale = float(grads[0].abs().max())
     assert maxdiff(grads[0], grads[1]) < 2e-5 * scale and maxdiff(grads[1], grads[2]) < 2e-5 * scale
     assert float(grads[1].abs().sum()) > 0
+
+
+def test_in_proj_bias_gradient_from_the_streamed_attention_backward(monkeypatch):
+    """At T = 128 the persistent attention backward produces the in_proj bias gradient itself (column sums of dQ | dK | dV by an MFMA
+    against ones on the rows in its store patches, one partial row per sample, a fixed-order sum over the samples).  Against the
+    one-workgroup-per-head kernel + the column-sum pass over dqkv (OSUD_ATTN_BWD_STREAM=0) on the same step: the same bf16 values
+    summed in a different order; and two runs of the fused form are bit-identical (no atomics)."""
+    shape = mo.DitShape(depth=2, hidden=768, heads=12, num_classes=16)
+    sd = mo.seeded_state_dict(shape, 5)
+    d = create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True)
+    (x, o, c), y = synthetic_windows(64, 128, 16, seed=2)
+    g = torch.Generator().manual_seed(3)
+    kw = dict(t=torch.randint(0, 1000, (64,), generator=g), noise=torch.randn(64, 2, 128, generator=g), drop_ids=torch.zeros(64).long())
+    got = []
+    for flag in ("0", "1", "1"):
+        monkeypatch.setenv("OSUD_ATTN_BWD_STREAM", flag)
+        tr = NativeTrainer(native_model(shape, sd, "bf16", train=True), d)
+        tr.lr = 0.0
+        tr.step(x, o, c, y, **kw)
+        gv = tr.arena.grad_views()
+        got.append({k: gv[k].clone().cpu() for k in ("blocks.0.attn.in_proj_bias", "blocks.1.attn.in_proj_bias", "blocks.1.attn.in_proj_weight")})
+    for k in got[0]:
+        scale = float(got[0][k].abs().max())
+        assert scale > 0 and maxdiff(got[0][k], got[1][k]) < 3e-3 * scale, k   # (dqkv itself differs in its last bf16 bit: other delta sums)
+    assert torch.equal(got[1]["blocks.0.attn.in_proj_bias"], got[2]["blocks.0.attn.in_proj_bias"])
+    assert torch.equal(got[1]["blocks.1.attn.in_proj_bias"], got[2]["blocks.1.attn.in_proj_bias"])
+
