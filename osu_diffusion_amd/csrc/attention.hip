@@ -420,7 +420,7 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const bf16_t* __re
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][2 heads][K | V][TILE] | store patches [8][2 KiB]
   char* patch = smem + 8 * TILE + (threadIdx.x >> 6) * 2048;
   // shared-GPU mode (queue != nullptr): pairs b, b + G, then 2 G + ticket, drawn one pair ahead -- see attn_bwd_stream_kernel
-  volatile uint32_t* tword = reinterpret_cast<volatile uint32_t*>(smem + 8 * TILE + 8 * 2048);
+  volatile lds_u32* tword = reinterpret_cast<volatile lds_u32*>((lds_void*)(smem + 8 * TILE + 8 * 2048));
   const uint32_t lds0 = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 31, fhalf = lane >> 5;
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const bf16_t* __re
     const char* Vs = Ks + TILE;
     __syncthreads();  // every wave has waited for its pieces of this pair; the other buffer is free from here on
     if (iter > 0) nx = queue != nullptr ? 2 * G + __builtin_amdgcn_readfirstlane((int)tword[iter & 1]) : it + G;  // (iteration 0: b + G)
-    uint32_t tk = 0;
+    uint32_t tk;  // (no initialiser: writing the register at the loop top would first wait for last head's ticket AND stores)
     if (ticket_lane) tk = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (nx < npairs) {
       issue(nx, buf ^ 1);

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __re
   // two heads are b and b + G, every later one is 2 G + a ticket drawn one head ahead (requested behind the barrier of head i,
   // published through LDS for the barrier of head i + 1, where the DMA of head i + 2 is issued) -- a late workgroup finds the queue
   // drained instead of doubling the launch.  Which workgroup computes a head does not change its result.
-  volatile uint32_t* tword = reinterpret_cast<volatile uint32_t*>(smem + 8 * TILE + 4 * T * 4 + 8 * 2048);
+  volatile lds_u32* tword = reinterpret_cast<volatile lds_u32*>((lds_void*)(smem + 8 * TILE + 4 * T * 4 + 8 * 2048));
   const uint32_t lds0 = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 31, fhalf = lane >> 5;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __re
     __syncthreads();
     if (DBIAS && iter > 0) flush_colsums((iter - 1) & 1, prev);
     if (iter > 0) nx = queue != nullptr ? 2 * G + __builtin_amdgcn_readfirstlane((int)tword[iter & 1]) : it + G;  // (iteration 0: b + G)
-    uint32_t tk = 0;
+    uint32_t tk;  // (no initialiser: writing the register at the loop top would first wait for last head's ticket AND stores)
     if (ticket_lane) tk = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (nx < items && !(OSUD_ATTN_EXP & 8)) {
       issue(nx, buf ^ 1);
@@ -639,7 +639,7 @@ template <int T>
 __global__ __launch_bounds__(512, 2) void attn_bwd_stream72_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                                    const float* __restrict__ lse, const float* __restrict__ delta,
                                                                    bf16_t* __restrict__ dqkv, int D, int H, int items, float c1,
-                                                                   float scale) {
+                                                                   float scale, unsigned* __restrict__ queue) {
   constexpr int HD = 72, HDP = 96, KS = 5, DT = 3, BLK = 128;  // KS: 16-column k-steps that hold real columns (72 -> 5; the sixth is all pad)
   using TL = AttnTile<HDP>;
   constexpr int TILE = BLK * TL::RS, STAGE = 2 * TILE;  // 26 624 / 53 248 bytes
@@ -648,6 +648,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream72_kernel(const bf16_t*
   float* lse_s = reinterpret_cast<float*>(smem + 2 * STAGE);
   float* del_s = lse_s + 2 * T;
   char* patch = reinterpret_cast<char*>(del_s + 2 * T) + (threadIdx.x >> 6) * (16 * 208);
+  // shared-GPU mode (queue != nullptr): heads b, b + G, then 2 G + ticket, requested one head ahead in step 2 (it has returned by the
+  // vmcnt(0) of step 3 and does not enter any of the counted waits) and published through LDS for the next head's first barrier
+  volatile lds_u32* tword = reinterpret_cast<volatile lds_u32*>((lds_void*)(smem + 2 * STAGE + 4 * T * 4 + 8 * 16 * 208));
   const uint32_t lds0 = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 31, fhalf = lane >> 5;
@@ -715,7 +718,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream72_kernel(const bf16_t*
     }
   };
 
-  int it = blockIdx.x, hb = 0;  // hb: statistics buffer of this head
+  const int G = gridDim.x;
+  const bool ticket_lane = queue != nullptr && tid == 0;
+  int it = blockIdx.x, nx = blockIdx.x + G, iter = 0, hb = 0;  // hb: statistics buffer of this head
   if (it < items) {
     issue(it, 0, 0);
     fetch_frags(it, qkv, ld3, 0, dO, (size_t)D, 0, qf, of);
@@ -724,8 +729,8 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream72_kernel(const bf16_t*
     settle_frags(qf, of);
     put_stats(0);
   }
-  for (; it < items; it += gridDim.x, hb ^= 1) {
-    const int nx = it + gridDim.x;
+  uint32_t tk;  // (no initialiser: see attn_bwd_stream_kernel)
+  for (; it < items; it = nx, hb ^= 1, ++iter) {
     const int n = it / H, h = it - n * H;
     const float* lse_b = lse_s + hb * T;
     const float* del_b = del_s + hb * T;
@@ -752,6 +757,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream72_kernel(const bf16_t*
           OSUD_VM_WAIT(10);
         }
         __syncthreads();
+        if (step == 0 && iter > 0) nx = queue != nullptr ? 2 * G + __builtin_amdgcn_readfirstlane((int)tword[iter & 1]) : it + G;
         if (step == 0) {
           my_lse = lse_b[own + frow];
           my_del = del_b[own + frow];
@@ -799,8 +805,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream72_kernel(const bf16_t*
         __syncthreads();
         if (step == 2) {
           settle_frags(kf, vf);
+          if (ticket_lane) tk = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           issue(it, 3, 1);
         } else {
+          if (ticket_lane) tword[(iter + 1) & 1] = tk;  // (returned: the wait above was vmcnt(0))
           issue(nx < items ? nx : it, 0, 0);  // (past the last head: a harmless re-read into the free stage)
         }
         const char* Xs = smem + (step & 1) * STAGE;
@@ -844,6 +852,13 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream72_kernel(const bf16_t*
       fetch_stats(nx < items ? nx : it);
       store_rows_patch72(patch, orows + D, ld3, dk, lane);      // 6 stores
       store_rows_patch72(patch, orows + 2 * D, ld3, dv, lane);  // 6 stores
+    }
+  }
+  if (ticket_lane) {  // the last workgroup out re-arms the counters
+    const unsigned done = __hip_atomic_fetch_add(queue + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (unsigned)G - 1) {
+      __hip_atomic_store(queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(queue + 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -972,16 +987,16 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
       const int rows = N * T * heads;
       const dim3 grid((T + 127) / 128, heads, N);
       const char* s72_env = getenv("OSUD_ATTN_BWD_STREAM");
-      if (head_dim == 72 && T == 256 && !force_tiled && !(s72_env && s72_env[0] == '0') &&
-          !gemm_dynamic_tiles_on()) {  // DiT-XL: persistent streamed kernel (fixed head stride: not while collectives hold compute units)
+      if (head_dim == 72 && T == 256 && !force_tiled && !(s72_env && s72_env[0] == '0')) {  // DiT-XL: persistent streamed kernel
         hipLaunchKernelGGL((attn_delta_kernel<72>), dim3((rows + 255) / 256), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O,
                            delta_ws, N, T, heads);
-        constexpr size_t lds72 = (size_t)4 * 128 * AttnTile<96>::RS + 4 * 256 * 4 + 8 * 16 * 208;
+        constexpr size_t lds72 = (size_t)4 * 128 * AttnTile<96>::RS + 4 * 256 * 4 + 8 * 16 * 208 + 16;
         OSUD_BIG_LDS_ONCE(attn_bwd_stream72_kernel<256>);
         const int cus = device_cus();
         const int items = N * heads;
         hipLaunchKernelGGL((attn_bwd_stream72_kernel<256>), dim3(items < cus ? items : cus), dim3(512), lds72, st, (const bf16_t*)qkv,
-                           (const bf16_t*)dO, lse, delta_ws, (bf16_t*)dqkv, D, heads, items, c1t, scale);
+                           (const bf16_t*)dO, lse, delta_ws, (bf16_t*)dqkv, D, heads, items, c1t, scale,
+                           (gemm_dynamic_tiles_on() && items > 2 * cus) ? gemm_ticket_slot() : nullptr);
         OSUD_HIP(hipGetLastError());
         if (dbias != nullptr) OSUD_TRY(launch_colsum_bf16(dqkv, 3 * D, N * T, 3 * D, dbias, st));
         return OSUD_OK;

@@ -7,6 +7,9 @@ namespace osud {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;  // (a word read through an LDS pointer is a ds_read; through a generic
+                                                             //  pointer it is a flat load, which also counts as vector memory)
 
 // Tile geometry by padded head width HDP (head_dim rounded up to a multiple of 32; the pad columns hold zeros):
 //   HDP = 64 : 128-byte rows, 16-byte chunk index XOR-swizzled with (row>>1)&7 (conflict-free ds_read_b128)
