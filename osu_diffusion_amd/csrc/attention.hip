@@ -568,13 +568,17 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const bf16_t* __re
 //   per wave and head:  step 0: P DMA pieces | step 1: P pieces ... 5 fragment loads (next head's Q rows), 6 stores (+1: lse)
 template <int T>
 __global__ __launch_bounds__(512, 2) void attn_fwd_stream72_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                   float* __restrict__ lse, int D, int H, int items, float c1) {
+                                                                   float* __restrict__ lse, int D, int H, int items, float c1,
+                                                                   unsigned* __restrict__ queue) {
   constexpr int HD = 72, HDP = 96, KS = 5, DT = 3, BLK = 128;
   using TL = AttnTile<HDP>;
   constexpr int TILE = BLK * TL::RS, STAGE = 2 * TILE;
   static_assert(T == 256 && TL::RS == 208, "eight waves x 32 queries, two 128-key blocks");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K | V][TILE] | patches [8][16 x 208]
   char* patch = smem + 2 * STAGE + (threadIdx.x >> 6) * (16 * 208);
+  // shared-GPU mode (queue != nullptr): heads b, b + G, then 2 G + ticket, requested one head ahead in step 0 (returned by the
+  // vmcnt(0) of step 1, outside the counted wait) and published through LDS for the next head's first barrier
+  volatile lds_u32* tword = reinterpret_cast<volatile lds_u32*>((lds_void*)(smem + 2 * STAGE + 8 * 16 * 208));
   const uint32_t lds0 = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)smem;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 31, fhalf = lane >> 5;
@@ -613,14 +617,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_stream72_kernel(const bf16_t*
     for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]));
     if (fhalf) qf[4] = zero4;  // chunk 9: pad columns 72..79
   };
-  int it = blockIdx.x;
+  const int G = gridDim.x;
+  const bool ticket_lane = queue != nullptr && tid == 0;
+  int it = blockIdx.x, nx = blockIdx.x + G, iter = 0;
+  uint32_t tk;  // (no initialiser: see attn_bwd_stream_kernel)
   if (it < items) {
     issue(it, 0, 0);
     fetch_q(it);
     OSUD_VM_WAIT(0);
   }
-  for (; it < items; it += gridDim.x) {
-    const int nx = it + gridDim.x;
+  for (; it < items; it = nx, ++iter) {
     const int n = it / H, h = it - n * H;
     f32x16 o[DT];
 #pragma unroll
@@ -635,8 +641,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_stream72_kernel(const bf16_t*
       if (step == 0) { OSUD_VM_WAIT(6); } else { OSUD_VM_WAIT(0); }
       if (step == 0) settle_q();
       __syncthreads();
-      if (step == 0) issue(it, 1, 1);
-      else issue(nx < items ? nx : it, 0, 0);  // (past the last head: a harmless re-read into the free stage)
+      if (step == 0 && iter > 0) nx = queue != nullptr ? 2 * G + __builtin_amdgcn_readfirstlane((int)tword[iter & 1]) : it + G;
+      if (step == 0) {
+        if (ticket_lane) tk = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        issue(it, 1, 1);
+      } else {
+        if (ticket_lane) tword[(iter + 1) & 1] = tk;  // (returned: the wait above was vmcnt(0))
+        issue(nx < items ? nx : it, 0, 0);  // (past the last head: a harmless re-read into the free stage)
+      }
       const char* Ks = smem + step * STAGE;
       const char* Vs = Ks + TILE;
       f32x16 s[4];
@@ -691,6 +703,13 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_stream72_kernel(const bf16_t*
       for (int r = 0; r < 16; ++r) o[i][r] *= inv;
     store_rows_patch72(patch, out + ((size_t)n * T + own) * D + h * HD, (size_t)D, o, lane);
     if (lse != nullptr && fhalf == 0) lse[((size_t)n * H + h) * T + own + frow] = m_run + __builtin_amdgcn_logf(l_run);
+  }
+  if (ticket_lane) {  // the last workgroup out re-arms the counters
+    const unsigned done = __hip_atomic_fetch_add(queue + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (unsigned)G - 1) {
+      __hip_atomic_store(queue, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(queue + 8, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
 }
 
@@ -794,14 +813,14 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
       OSUD_HIP(hipGetLastError());
       return OSUD_OK;
     }
-    if (head_dim == 72 && T == 256 && Tp == 256 && mask == nullptr && fp8_scale <= 0.f && ld_qk == 3 * D && !(stream_env && stream_env[0] == '0') &&
-        !gemm_dynamic_tiles_on()) {  // (fixed head stride: not while collectives hold compute units)
-      constexpr size_t lds72 = (size_t)4 * 128 * AttnTile<96>::RS + 8 * 16 * 208;
+    if (head_dim == 72 && T == 256 && Tp == 256 && mask == nullptr && fp8_scale <= 0.f && ld_qk == 3 * D && !(stream_env && stream_env[0] == '0')) {
+      constexpr size_t lds72 = (size_t)4 * 128 * AttnTile<96>::RS + 8 * 16 * 208 + 16;
       OSUD_BIG_LDS_ONCE(attn_fwd_stream72_kernel<256>);
       const int cus = device_cus();
       const int items = N * heads;
       hipLaunchKernelGGL((attn_fwd_stream72_kernel<256>), dim3(items < cus ? items : cus), dim3(512), lds72, st, (const bf16_t*)qk,
-                         (bf16_t*)out, lse, D, heads, items, scale * 1.4426950408889634f);
+                         (bf16_t*)out, lse, D, heads, items, scale * 1.4426950408889634f,
+                         (gemm_dynamic_tiles_on() && items > 2 * cus) ? gemm_ticket_slot() : nullptr);
       OSUD_HIP(hipGetLastError());
       return OSUD_OK;
     }

@@ -175,11 +175,11 @@ def test_attention_core_backward(prec, tol, N, H, T_, stream, hd, monkeypatch):
     assert maxdiff(g.cpu(), ref.cpu()) < tol * max(1.0, float(ref.abs().max())), (N, H, T_)
 
 
-def test_attention_head_queue_equals_fixed_stride():
+@pytest.mark.parametrize("N,H,T_,hd", [(96, 12, 128, 64), (34, 16, 256, 72)])
+def test_attention_head_queue_equals_fixed_stride(N, H, T_, hd):
     """Shared-GPU mode (osud_set_gemm_dynamic_tiles(1), what data-parallel trainers switch on): the persistent attention kernels draw
-    their heads from a ticket queue instead of a fixed stride.  1152 heads (576 pairs) are more than two per compute unit, so the
-    queue is live; which workgroup computes a head must not change a bit of the result."""
-    N, H, T_, hd = 96, 12, 128, 64
+    their heads from a ticket queue instead of a fixed stride.  1152 heads (576 pairs) at T = 128 / 544 heads of DiT-XL's shape are
+    more than two per compute unit, so the queue is live; which workgroup computes a head must not change a bit of the result."""
     D, M = H * hd, N * T_
     torch.manual_seed(5)
     qkc = to_elem(0, torch.randn(M, 3 * D, device=DEV))
@@ -193,8 +193,9 @@ def test_attention_head_queue_equals_fixed_stride():
             out = torch.zeros(M * D * 2, dtype=torch.uint8, device=DEV)
             dq = torch.zeros(M * 3 * D * 2, dtype=torch.uint8, device=DEV)
             _lib.check(L.osud_op_attention(0, _lib.ptr(qkc), 3 * D, None, _lib.ptr(out), N, T_, T_, M, H, hd, None))
+            ws = torch.zeros(N * H * T_, device=DEV)
             _lib.check(L.osud_op_attention_bwd(0, _lib.ptr(qkc), _lib.ptr(doc), _lib.ptr(out), _lib.ptr(lse), _lib.ptr(dq), N, T_, H, hd,
-                                               None, None))
+                                               _lib.ptr(ws), None))
             torch.cuda.synchronize()
             res.append((out.clone(), dq.clone()))
     finally:
