@@ -122,6 +122,12 @@ struct WgradP {
   // the workgroups of a tile meet on its counter and each sums its share of the tile's rows over all partial slabs into `final`
   unsigned* arrive;
   float* final;
+  // one (tile, split) unit per workgroup, plain mode: units in split-major order, one contiguous run per XCD (workgroup L runs on
+  // XCD L % 8), so that the ~32 workgroups of an XCD walk the SAME token rows -- one or two splits, all of their tiles -- and share
+  // every stage's operand rows through that XCD's L2.  With blockIdx = (tile, split) an XCD held 4-5 tiles of each of the splits
+  // and read the Q operand 8x and the P operand 1.5x from memory: 579 MB of L2 fills per launch for 251 MB of operands
+  // (profiles/r02_pmc_hbm.json), at 5.9 TB/s the bound of the kernel.
+  int xcd_units;
 };
 
 template <int WY, int WX, int RY, int RX>
@@ -138,12 +144,20 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
   const int ntx = (p.Nx + G::BN - 1) / G::BN, ntiles = ((p.Ny + G::BM - 1) / G::BM) * ntx;
   // this split's share of the token axis (any split count: ranges differ by at most one stage)
   const int st_total = p.M / BKT;
-  const int st_begin = (int)((long)blockIdx.y * st_total / p.split_k);
-  const int nst = (int)((long)(blockIdx.y + 1) * st_total / p.split_k) - st_begin;
+  int sidx = blockIdx.y, bx = blockIdx.x;  // split, tile-block index
+  if (p.xcd_units) {
+    const int total = gridDim.x * gridDim.y, L = blockIdx.x + blockIdx.y * gridDim.x;
+    const int q = total >> 3, r = total & 7, xcd = L & 7, idx = L >> 3;
+    const int u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    sidx = u / (int)gridDim.x;
+    bx = u - sidx * (int)gridDim.x;
+  }
+  const int st_begin = (int)((long)sidx * st_total / p.split_k);
+  const int nst = (int)((long)(sidx + 1) * st_total / p.split_k) - st_begin;
   const size_t ldp_b = (size_t)p.ldp * 2, ldq_b = (size_t)p.ldq * 2;
   const char* gp0 = reinterpret_cast<const char*>(p.P) + (size_t)st_begin * BKT * ldp_b;
   const char* gq0 = reinterpret_cast<const char*>(p.Q) + (size_t)st_begin * BKT * ldq_b;
-  float* outp = p.out + (size_t)blockIdx.y * p.split_stride;
+  float* outp = p.out + (size_t)sidx * p.split_stride;
 
   // per-lane LDS byte addresses (stage 0, k-substep 0, first of the two transposing reads):
   //   token row = 8*fhalf + ((lane&15)>>2), feature = block + 32*i + 16*((lane>>4)&1) + 4*(lane&3)
@@ -307,6 +321,7 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
   {
     const int b = blockIdx.x, q = G8 >> 3, r = G8 & 7, xcd = b & 7, idx = b >> 3;
     first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if (p.xcd_units) first = bx;  // (already placed by the unit remap above)
   }
   int ic_tile = first, ic_st = 0, issued = 0, consumed = 0;
   auto issue_next = [&]() {
@@ -346,8 +361,7 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
     // Publish: every wave drains its slab stores, one lane releases at agent scope and counts in; consume: ONE relaxed poll
     // loop, ONE agent acquire, then plain loads (cdna_hip_programming.md Guideline 16: the per-XCD L2s are not coherent and
     // a CU's L1 is never refreshed by other CUs' stores).  The sum runs over the splits in index order: deterministic.
-    const int tile = first /* the one tile this workgroup computed: the XCD-remapped index of blockIdx.x */, ty = tile / ntx, tx = tile % ntx, S = p.split_k,
-              sidx = blockIdx.y;
+    const int tile = first /* the one tile this workgroup computed: the XCD-remapped index of blockIdx.x */, ty = tile / ntx, tx = tile % ntx, S = p.split_k;  // (sidx: this workgroup's split, see the top)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -552,6 +566,10 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
   if (S > 1 && p.queue == nullptr && combine_on && !capturing && tiles < 255 && tiles * S <= num_cus_w()) {
     p.arrive = arrive_slot();
     p.final = out;
+  }
+  {  // one unit per workgroup in the plain mode: XCD-contiguous unit order (OSUD_WGRAD_XCD=0: the (tile, split) grid order)
+    static const bool xcd_on = [] { const char* e = getenv("OSUD_WGRAD_XCD"); return !(e && e[0] == '0'); }();
+    p.xcd_units = (xcd_on && S > 1 && p.queue == nullptr && p.arrive == nullptr) ? 1 : 0;
   }
   if (geo == 0) OSUD_TRY((launch_wg<2, 4, 4, 2>(p, st)));
   else if (geo == 1) OSUD_TRY((launch_wg<4, 2, 2, 3>(p, st)));
