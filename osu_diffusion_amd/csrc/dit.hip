@@ -352,7 +352,9 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   m->Kp = round_up(cfg->in_channels * 128 + 128 + cfg->context, 128);  // 528 -> 640
   {  // OSUD_SPLIT_FIRST=0: plain bf16 first linear (A/B measurements of the fast tier's deviation)
     const char* e = getenv("OSUD_SPLIT_FIRST");
-    m->split_first = m->prec == OSUD_PREC_BF16 && !(e && e[0] == '0');
+    // (embed_kernel stages 16 rows of [hi | lo | hi] in LDS: 16 * Kp * 6 bytes must fit 64 KiB, i.e. context sizes up to 256;
+    //  wider contexts keep the plain bf16 first linear)
+    m->split_first = m->prec == OSUD_PREC_BF16 && !(e && e[0] == '0') && (size_t)16 * m->Kp * 6 <= 64 * 1024;
   }
   m->Ke = m->split_first ? 3 * m->Kp : m->Kp;
   m->ada_cols = 6 * m->D * m->L + 2 * m->D;

@@ -497,7 +497,8 @@ int launch_embed(int prec, const float* x, const float* o, const float* c, const
     Kp = 256;
   }
   OSUD_CHECK_ARG(Tp % 16 == 0 && Mp % 16 == 0 && Kp >= (mode == 1 ? 256 : 384 + E) && (Kp * elem_size(prec)) % 16 == 0, "embed: bad sizes");
-  OSUD_CHECK_ARG(!split || (prec == OSUD_PREC_BF16 && (size_t)16 * Kp * 6 <= 64 * 1024), "embed: the split row form is bf16 only");
+  OSUD_CHECK_ARG(!split || prec == OSUD_PREC_BF16, "embed: the split row form is bf16 only");
+  OSUD_CHECK_ARG(!split || (size_t)16 * Kp * 6 <= 64 * 1024, "embed: a split row of %d columns does not fit the 64 KiB LDS tile (context too wide)", Kp);
   if (split) return embed_t<bf16_t, true>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode);
   return prec == OSUD_PREC_BF16 ? embed_t<bf16_t, false>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode)
                                 : embed_t<float, false>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode);

@@ -637,8 +637,9 @@ extern "C" int osud_adamw_ema_step(float* params, const float* grads, float* exp
                     ((reinterpret_cast<uintptr_t>(params) ^ reinterpret_cast<uintptr_t>(exp_avg)) & 15) == 0 &&
                     ((reinterpret_cast<uintptr_t>(params) ^ reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0 &&
                     (ema == nullptr || ((reinterpret_cast<uintptr_t>(params) ^ reinterpret_cast<uintptr_t>(ema)) & 15) == 0);
-  if (!same || head > n) head = n;  // differently aligned buffers (never the trainer's arenas): everything on the scalar path
-  const size_t work = (n - head) / 4 + 8;
+  if (!same || head > n) head = n;  // differently aligned buffers: everything on the one-element-per-thread path
+  // (the grid follows whichever path carries the elements: a misaligned call must still use the whole chip)
+  const size_t work = head == n ? n : (n - head) / 4 + 8;
   const int grid = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
   const AdamC c{lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, ema_decay, grad_scale};
   hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, ema, n, c,

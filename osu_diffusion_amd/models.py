@@ -268,8 +268,20 @@ class DiT(nn.Module):
             from .training import dit_forward_autograd  # backward through the native kernels
 
             return dit_forward_autograd(self, x, t, o, c, y, attn_mask)
-        # Inference path.  A masked forward is always inference: the reference trains without a mask (train.py:255), the
-        # native backward has none, so with grad mode on the result simply carries no grad_fn.
+        # Inference path.  A masked forward is always inference: the reference trains without a mask (train.py:255) and the native
+        # backward has none.  Asked for with grad mode on, a training-mode module refuses (a masked fine-tune would otherwise fail
+        # later at backward() with an unrelated autograd error, or train on silently missing gradients); an eval-mode module --
+        # sampling code that forgot no_grad -- gets its result with a one-time warning that it carries no grad_fn.
+        if attn_mask is not None and torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            if self.training:
+                raise NotImplementedError("DiT.forward(attn_mask=...) has no native backward: the masked forward is inference only "
+                                          "(call it under torch.no_grad(), or train without a mask as the reference does)")
+            if not getattr(self, "_warned_masked_grad", False):
+                import warnings
+
+                warnings.warn("DiT.forward(attn_mask=...) with grad mode on returns a tensor without grad_fn (the native path has no "
+                              "masked backward); wrap sampling in torch.no_grad()", stacklevel=2)
+                self.__dict__["_warned_masked_grad"] = True
         return self._run(x, t, o, c, y, attn_mask, -1.0)
 
     def forward_with_cfg(self, x, t, o, c, y, cfg_scale, attn_mask=None):

@@ -61,9 +61,17 @@ class ParamArena:
         dev = params[0][1].device
         self.names = [n for n, _ in params]
         self.sizes = [p.numel() for _, p in params]
-        self.offsets = np.concatenate([[0], np.cumsum(self.sizes)]).astype(np.int64)
-        self.total = int(self.offsets[-1])
-        self.flat = torch.empty(self.total, dtype=torch.float32, device=dev)
+        # every tensor starts on a 16-byte boundary (4 fp32 elements): the 2-element playfield_size comes first, and unpadded it
+        # left every later offset at 2 mod 4 -- shards, moments and EMA 8 bytes off the (aligned) scatter buffer, which put the
+        # whole sharded optimizer step on the kernel's scalar path.  The pad elements stay zero (zero gradient: AdamW keeps them)
+        self.align = 4
+        starts, pos = [], 0
+        for n in self.sizes:
+            starts.append(pos)
+            pos += -(-n // self.align) * self.align
+        self.offsets = np.asarray(starts + [pos], dtype=np.int64)
+        self.total = int(pos)
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(self.total, dtype=torch.float32, device=dev)
         for (name, p), off, n in zip(params, self.offsets[:-1], self.sizes):
             view = self.flat[off:off + n].view_as(p)
@@ -652,7 +660,16 @@ class NativeTrainer:
                 self.step_count = int(float(st["step"]))
 
     def checkpoint(self, args=None):
-        self.sync_sharded_state()
+        """The reference's checkpoint dict (train.py:287-293).  With the sharded optimizer the state of the other ranks' shards
+        must have been gathered by `sync_sharded_state()` -- a collective that EVERY rank has to enter -- before one rank alone
+        calls this; a stale state here is an error, not something to fix up with a collective only this rank would join."""
+        if self.shard_optimizer and self._ema_stale:
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+                raise RuntimeError("NativeTrainer.checkpoint(): sharded optimizer state is stale -- call sync_sharded_state() on "
+                                   "EVERY rank first (it all-gathers moments and EMA), then checkpoint() on the saving rank")
+            self.sync_sharded_state()  # one rank: a local no-op gather
         scaler = {"scale": 65536.0, "growth_factor": 2.0, "backoff_factor": 0.5, "growth_interval": 2000,
                   "_growth_tracker": 0}  # bf16 needs no loss scaling; key kept for layout compatibility
         return {"model": {k: v.detach().cpu().clone() for k, v in self.model.state_dict().items()},

@@ -115,6 +115,7 @@ def main(args):
     else:
         class_labels = [args.num_classes]  # null class (sample.py:91-93)
     n_all = len(class_labels)
+    class_labels_all = list(class_labels)
     lo, hi = shard_rows(n_all, rank, world)  # this rank's variants (rows are independent: no exchange while sampling)
     n = hi - lo
     class_labels = class_labels[lo:hi]
@@ -135,10 +136,21 @@ def main(args):
     y = torch.cat([y, torch.tensor([args.num_classes] * n, device=device)], 0)
     model_kwargs = dict(o=o, c=c, y=y, cfg_scale=args.cfg_scale, attn_mask=attn_mask)
 
-    if args.precision == "fp8" and n:  # e4m3 activation scales measured on this beatmap (first, middle and last timestep of the run)
+    if args.precision == "fp8" and n:
+        # e4m3 activation scales measured on this beatmap at the first, middle and last timestep of the run -- on ALL variants, on
+        # every rank, so that the scales (and with them the fp8 tier's results) do not depend on the number of ranks.  The state at
+        # step i is stood in for by q_sample-like mixtures of the initial noise with a flat playfield (x_t ~ sqrt(ac) x0 +
+        # sqrt(1 - ac) z): N(0, 1) only at the first step, nearly the data range at the last.
+        za = z_all.to(device)
+        oa, ca = seq_o.repeat(n_all, 1).to(device), seq_c.repeat(n_all, 1, 1).to(device)
+        ya = torch.tensor(class_labels_all, device=device)
+        za, oa, ca = torch.cat([za, za], 0), torch.cat([oa, oa], 0), torch.cat([ca, ca], 0)
+        ya = torch.cat([ya, torch.tensor([args.num_classes] * n_all, device=device)], 0)
         for k, step in enumerate((diffusion.num_timesteps - 1, diffusion.num_timesteps // 2, 0)):
-            t_cal = torch.full((2 * n,), int(diffusion._model_timestep_map[step]), device=device)
-            model.calibrate_fp8(z, t_cal, o, c, y, cfg_scale=args.cfg_scale, attn_mask=attn_mask, accumulate=k > 0)
+            ac = float(diffusion.alphas_cumprod[step])
+            x_cal = (ac ** 0.5) * 0.5 + ((1.0 - ac) ** 0.5) * za
+            t_cal = torch.full((2 * n_all,), int(diffusion._model_timestep_map[step]), device=device)
+            model.calibrate_fp8(x_cal, t_cal, oa, ca, ya, cfg_scale=args.cfg_scale, attn_mask=attn_mask, accumulate=k > 0)
 
     def to_seq(samples):  # normalised positions + the source's time / type rows (sample.py:110-112)
         samples, _ = samples.chunk(2, dim=0)

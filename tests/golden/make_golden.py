@@ -619,6 +619,57 @@ def g6_long_loops():
              wsum=checksum(sd), pos_gain=pos_gain, o=o, c=c, y=y, **out)
 
 
+def g6_loop_p1000_dit_b():
+    """BASELINE configs[3] end to end against the reference (reference: sample.py:174-182, gaussian_diffusion.py:469-561): DiT-B
+    (12 blocks, D = 768, 12 heads; seeded non-zero weights), n = 2 windows -> N = 4 rows [cond; uncond], T = 128, "1000" steps,
+    cfg 4.0, the reference's own p_sample_loop_progressive with torch's CPU generator seeded right before the loop.  Stored: the
+    final coordinates and the state after 250 / 500 / 750 executed steps.  The per-step noise is NOT stored (4 MB): tests redraw it
+    from the same seed in the same order (one randn_like per step) and check it against the stored checksum and first values.
+    An fp64 evaluation of the same loop is stored next to it: its distance from the reference's fp32 result is the accuracy any
+    fp32-class implementation can claim on these weights."""
+    print("G6 1000-step CFG-4 loop, DiT-B geometry (minutes of CPU)")
+    shape, wseed, n, T, steps, nseed = BASE, 16, 2, 128, 1000, 24
+    (x0, o, c), y = synthetic_windows(n, T, shape.num_classes, seed=7, train_offsets=False)
+    o, c = torch.cat([o, o]), torch.cat([c, c])
+    y = torch.cat([y, torch.full_like(y, shape.num_classes)])
+    kw = dict(o=o, c=c, y=y, cfg_scale=4.0, attn_mask=None)
+    sd = mo.seeded_state_dict(shape, wseed)
+    ref = ref_model_for(shape, sd)
+    dref = ref_create_diffusion(str(steps), noise_schedule="squaredcos_cap_v2")
+    ora = do.create_schedule(str(steps), "squaredcos_cap_v2")
+    torch.manual_seed(23)
+    z = torch.randn(n, 2, T)
+    z = torch.cat([z, z])
+    snaps = {}
+    torch.manual_seed(nseed)
+    k = 0
+    final = None
+    for out in dref.p_sample_loop_progressive(ref.forward_with_cfg, z.shape, z, clip_denoised=True, model_kwargs=kw, device="cpu"):
+        k += 1
+        final = out["sample"]
+        if k in (250, 500, 750):
+            snaps[f"after_{k}"] = final.clone()
+    assert k == steps
+    torch.manual_seed(nseed)
+    noises = torch.stack([torch.randn_like(z) for _ in range(steps)])
+    fn = lambda xx, tt: mo.forward_with_cfg(sd, shape, xx, tt, o, c, y, 4.0)  # noqa: E731
+    mine = do.sample_loop(ora, fn, z, noises)
+    d32 = (mine - final).abs().max().item()
+    print(f"  p1000 dit_b: oracle fp32 vs reference {d32:.3e}")
+    assert d32 <= 5e-4, d32
+    extra = {}
+    if os.environ.get("OSUD_GOLDEN_FP64", "1") != "0":
+        sd64 = mo.to_dtype(sd, torch.float64)
+        fn64 = lambda xx, tt: mo.forward_with_cfg(sd64, shape, xx.double(), tt, o.double(), c.double(), y, 4.0).float()  # noqa: E731
+        f64 = do.sample_loop(ora, fn64, z, noises)
+        print(f"  p1000 dit_b: fp64 evaluation vs reference fp32 {(f64 - final).abs().max().item():.3e}")
+        extra["final_fp64"] = f64
+    save("g6_loop_p1000_dit_b", shape=np.array([shape.depth, shape.hidden, shape.heads, shape.num_classes]), wseed=wseed,
+         wsum=checksum(sd), z=z, o=o, c=c, y=y, final=final, noise_seed=nseed, noise_sum=float(noises.double().sum()),
+         noise_abs_sum=float(noises.double().abs().sum()), noise_head=noises[0, 0, 0, :8], noise_tail=noises[-1, -1, -1, -8:],
+         respacing=str(steps), cfg_scale=4.0, oracle_fp32_vs_reference=d32, **snaps, **extra)
+
+
 def g12_cli_toy():
     """What `sample.py --noise cpu` must reproduce: the reference's own sampling call sequence (sample.py:39-108,174-182 --
     torch.manual_seed(seed); z = randn(n, 2, T); doubled [cond; null] batch; banded mask; p_sample_loop with randn_like per
@@ -825,7 +876,7 @@ def g14_timestep_sampler():
 
 if __name__ == "__main__":
     steps = [g1_schedules, g2_embeddings, g3_forward, g5_step, g6_loop, g7_training, g9_init_and_keys, g9_windows, g10_curves, g11_inpaint,
-             g3_forward_dit_b, g7_training_dit_b, g6_long_loops, g12_cli_toy, g13_export, g14_timestep_sampler]
+             g3_forward_dit_b, g7_training_dit_b, g6_long_loops, g6_loop_p1000_dit_b, g12_cli_toy, g13_export, g14_timestep_sampler]
     only = set(sys.argv[1:])  # e.g. `make_golden.py g10_curves` regenerates one family
     for fn in steps:
         if not only or fn.__name__ in only:

@@ -51,6 +51,32 @@ if __name__ == "__main__":
     dist.init_process_group(os.environ.get("OSUD_DIST_BACKEND", "gloo"))
     rank, world = dist.get_rank(), dist.get_world_size()
     mode = os.environ.get("OSUD_TEST_MODE", "allreduce")  # allreduce | zero1 | zero1_bf16
+    if mode == "zero1_ckpt":
+        # train.py's save path with the sharded optimizer: checkpoint() alone on the saving rank must refuse (it would enter an
+        # all-gather nobody else joins); after the collective sync on EVERY rank, rank 0 alone writes the file, then the barrier
+        model = build(100 + rank)
+        tr = NativeTrainer(model, create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True), lr=1e-3, shard_optimizer=True)
+        x, o, c, y, t, noise = batch()
+        per = 8 // world
+        sl = slice(rank * per, (rank + 1) * per)
+        for _ in range(2):
+            tr.step(x[sl], o[sl], c[sl], y[sl], t=t[sl], noise=noise[sl])
+        refused = False
+        if rank == 0:
+            try:
+                tr.checkpoint()
+            except RuntimeError as e:
+                refused = "sync_sharded_state" in str(e)
+        tr.sync_sharded_state()
+        if rank == 0:
+            ck = tr.checkpoint({"note": "zero1"})
+            ck["refused"] = refused
+            torch.save(ck, os.path.join(out_dir, "ckpt.pt"))
+        dist.barrier()
+        torch.save({"exp_avg": tr.exp_avg.cpu(), "ema": tr.ema_arena.flat.cpu()}, os.path.join(out_dir, f"rank{rank}.pt"))
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0)
     if mode == "allreduce":
         flat, ema = run(rank, world)
         torch.save({"flat": flat, "ema": ema}, os.path.join(out_dir, f"rank{rank}.pt"))

@@ -231,3 +231,102 @@ def test_loss_aware_sampler_synchronises_over_gloo():
     ref = create_named_schedule_sampler("loss-second-moment", create_diffusion("20", noise_schedule="squaredcos_cap_v2"))
     ref.update_with_all_losses(t0.tolist() + t1.tolist(), l0.tolist() + l1.tolist())
     assert np.array_equal(ref._loss_counts, c0) and np.allclose(np.sort(ref._loss_history, axis=1), h0)
+
+
+# ------------------------------------------------------------------ world = 8 (the node the job targets): shard arithmetic
+def test_param_arena_offsets_are_16_byte_aligned():
+    """Every tensor of the flat arena starts on a 4-element boundary (the 2-element playfield_size comes first): the sharded
+    optimizer's shards, moments and EMA are then aligned like its (aligned) scatter buffer and take the 16-byte path."""
+    from osu_diffusion_amd.models import DiT
+    from osu_diffusion_amd.training import ParamArena, overlap_slices, shard_plan
+
+    m = DiT(depth=3, hidden_size=128, num_heads=2, context_size=144, num_classes=5)
+    want = {n: p.detach().clone() for n, p in m.named_parameters()}
+    arena = ParamArena(m)
+    assert all(int(o) % 4 == 0 for o in arena.offsets) and arena.total % 4 == 0
+    assert arena.total >= sum(arena.sizes) and arena.total - sum(arena.sizes) < 4 * len(arena.sizes)
+    for n, p in m.named_parameters():  # re-homed, values and Parameter objects intact
+        assert torch.equal(p.detach(), want[n]) and p.data_ptr() == arena.view(arena.flat, n).data_ptr()
+    blocks, tail = overlap_slices(arena, 3)
+    _, _, f_lo, f_hi = next(s for s in tail if s[0] == "final")
+    for W in (2, 8):
+        for lo, hi in [(f_lo, f_hi)] + [(b[2], b[3]) for b in blocks]:
+            per, bulk_hi = shard_plan(lo, hi, W)
+            assert lo % 4 == 0 and per % 4 == 0 and all((lo + r * per) % 4 == 0 for r in range(W))
+            assert lo + W * per == bulk_hi <= hi and hi - bulk_hi < 4 * W
+
+
+def _zero1_world8_worker(rank, world, port, out):
+    """_backward_sharded's exchange arithmetic at world = 8 on a real arena layout (CPU tensors, gloo): every slice of the phased
+    backward is reduce-scattered (bulk) + all-reduced (remainder), the own shard and the replicated parts are updated, the shards
+    are gathered back; the class table travels as rows.  Must equal: dense all-reduce of everything, update everywhere."""
+    from osu_diffusion_amd.models import DiT
+    from osu_diffusion_amd.training import (ParamArena, _all_gather_into, _complement, _reduce_scatter_sum, exchange_table_rows,
+                                            overlap_slices, shard_plan)
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(5)
+        m = DiT(depth=2, hidden_size=128, num_heads=2, context_size=144, num_classes=37)  # 38 table rows
+        arena = ParamArena(m)
+        g = torch.Generator().manual_seed(11 + rank)
+        grads = torch.randn(arena.total, generator=g)
+        t_lo, t_hi = [(lo, hi) for k, _, lo, hi in overlap_slices(arena, 2)[1] if k == "table"][0]
+        rows = (t_hi - t_lo) // 128
+        labels = torch.randint(0, rows, (6,), generator=g)  # duplicates inside a rank, overlaps across ranks, untouched rows
+        tg = torch.zeros(rows, 128)
+        tg.index_add_(0, labels, torch.randn(6, 128, generator=g))
+        grads[t_lo:t_hi] = tg.reshape(-1)
+        params = arena.flat.clone()
+        ref = grads.clone()
+        dist.all_reduce(ref)
+        want = params - 0.1 * ref / world
+        blocks, tail = overlap_slices(arena, 2)
+        _, _, f_lo, f_hi = next(s for s in tail if s[0] == "final")
+        order = [(f_lo, f_hi)] + [(b[2], b[3]) for b in reversed(blocks)]
+        plans = [(lo, hi) + shard_plan(lo, hi, world) for lo, hi in order]
+        buf = torch.empty(sum(p[2] for p in plans))
+        pending, off = [], 0
+        for lo, hi, per, bulk_hi in plans:
+            if per > 0:
+                pending.append(_reduce_scatter_sum(buf[off:off + per], grads[lo:bulk_hi], None))
+            if bulk_hi < hi:
+                pending.append((dist.all_reduce(grads[bulk_hi:hi], async_op=True), None))
+            off += per
+        for kind, _, lo, hi in tail:
+            if kind == "tail":
+                pending.append((dist.all_reduce(grads[lo:hi], async_op=True), None))
+        for h, fin in pending:
+            h.wait()
+            if fin is not None:
+                fin()
+        exchange_table_rows(grads[t_lo:t_hi].view(rows, 128), labels)
+        off, own, gathers = 0, [], []
+        for lo, hi, per, bulk_hi in plans:
+            if per > 0:
+                a, b = lo + rank * per, lo + (rank + 1) * per
+                params[a:b] -= 0.1 * buf[off:off + per] / world
+                own.append((lo, bulk_hi))
+                gathers.append(_all_gather_into(params[lo:bulk_hi], params[a:b], None))
+            off += per
+        for lo, hi in _complement(own, arena.total):
+            params[lo:hi] -= 0.1 * grads[lo:hi] / world
+        for h, fin in gathers:
+            h.wait()
+            if fin is not None:
+                fin()
+        out[rank] = (float((params - want).abs().max()), params)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_exchange_eight_ranks_gloo():
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_zero1_world8_worker, args=(8, port, out), nprocs=8, join=True)
+        res = dict(out)
+    assert sorted(res) == list(range(8))
+    assert max(v[0] for v in res.values()) <= 2e-6, {k: v[0] for k, v in res.items()}
+    assert all(torch.equal(res[0][1], res[r][1]) for r in range(1, 8))  # replicas bit-identical after the gather

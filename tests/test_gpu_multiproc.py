@@ -68,6 +68,21 @@ def test_sharded_optimizer_two_ranks_equal_the_allreduce_path():
     assert float((z0["ema"] - a0["ema"]).abs().max()) <= 2e-6 * scale
 
 
+def test_rank0_only_checkpoint_with_sharded_optimizer():
+    """train.py:285-297 with OSUD_ZERO1: the moments / EMA gather is a collective every rank enters, then rank 0 alone saves and
+    everybody meets at the barrier.  checkpoint() on one rank with stale shards refuses instead of hanging in an all-gather."""
+    with tempfile.TemporaryDirectory() as d:
+        _torchrun(2, [os.path.join(ROOT, "tests", "mp_worker.py"), d], dict(OSUD_DIST_BACKEND="gloo", OSUD_TEST_MODE="zero1_ckpt"), timeout=600)
+        ck = torch.load(os.path.join(d, "ckpt.pt"), weights_only=False)
+        r0, r1 = torch.load(os.path.join(d, "rank0.pt")), torch.load(os.path.join(d, "rank1.pt"))
+    assert ck["refused"] is True
+    assert set(ck) >= {"model", "ema", "opt", "scaler", "args"}
+    assert torch.equal(r0["exp_avg"], r1["exp_avg"]) and torch.equal(r0["ema"], r1["ema"])  # full state on both ranks
+    # the saved optimizer state is the gathered one: the moment of a block tensor owned by rank 1's shard is non-zero
+    st = ck["opt"]["state"]
+    assert all(float(v["exp_avg"].abs().sum()) > 0 for k, v in st.items() if v["exp_avg"].numel() > 4096)
+
+
 def test_rccl_is_executed_world_size_one():
     """The process group the 8-GPU job uses -- backend "nccl" = RCCL -- initialised with one rank on this box: the phased backward
     with its per-slice all-reduces, the row exchange of the class table, and the reduce-scatter / all-gather of the sharded

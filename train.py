@@ -137,6 +137,9 @@ def main(args):
                 running_loss.zero_()
                 log_steps, start_time = 0, time()
             if train_steps % args.ckpt_every == 0 and train_steps > 0:
+                # sharded optimizer (OSUD_ZERO1=1): the moments / EMA of the other ranks' shards are all-gathered first -- a
+                # COLLECTIVE, so every rank takes part before rank 0 alone writes the file (train.py:285-297)
+                trainer.sync_sharded_state()
                 if rank == 0:
                     path = f"{checkpoint_dir}/{train_steps:07d}.pt"
                     torch.save(trainer.checkpoint(args), path)
