@@ -50,6 +50,11 @@ extern "C" {
 #define OSUD_PREC_FP8 2  /* inference only: the bf16 tier with the four big per-block GEMMs on OCP e4m3 operands
                             (v_mfma_scale_f32_32x32x64_f8f6f4, per-output-channel weight scales, static activation scales) */
 
+#define OSUD_PREC_BF16X3 3 /* tolerance tier, inference only: every GEMM and the attention products on split-bf16 operands
+                            (v = hi + lo, two bf16 each; three bf16 MFMAs per product: hi*hi + lo*hi + hi*lo, fp32 accumulate) --
+                            16 significand bits per operand, finer than the TF32 matmuls of the reference's sampling path
+                            (sample.py:25-26), at a third of the bf16 tier's MFMA rate instead of the f32 tier's sixteenth */
+
 typedef struct osud_dit osud_dit;
 typedef struct osud_sched osud_sched;
 typedef void* osud_stream; /* hipStream_t */

@@ -59,30 +59,40 @@ __global__ __launch_bounds__(256) void mask_tiles_kernel(const uint8_t* __restri
 // alternating runs: sampling step 4.41 vs 4.21 ms, training step 28.91 vs 28.59 ms): 32 KiB of LDS per workgroup and eight
 // staging loads per thread cost more occupancy-side latency hiding than the saved round trip buys.  KB = 1 stays the default
 // (OSUD_ATTN_KB=2 selects the other form for A/B runs).
-template <int HD, int HDP, int KB>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 4 : 2))) void attn_bf16_kernel(const bf16_t* __restrict__ qk,
+// X3 (split-bf16 tier): qk and out are plane pairs (rows [hi | lo], see common.h): ld_qk and D count LOGICAL columns, the lo plane
+// sits ld_qk (resp. D) elements behind the hi plane inside a row of twice that length.  Both products take the three-term form
+//   S = K_hi.q_hi + K_lo.q_hi + K_hi.q_lo        O += V_hi.p_hi + V_lo.p_hi + V_hi.p_lo      (p = exp2(..) in fp32, split in registers)
+// with K / V tiles of both planes in LDS; softmax statistics in fp32 as before.
+template <int HD, int HDP, int KB, bool X3 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HD == 64 && !X3) ? 4 : 2))) void attn_bf16_kernel(const bf16_t* __restrict__ qk,
                                                         const uint8_t* __restrict__ mask, bf16_t* __restrict__ out,
                                                         float* __restrict__ lse, int T, int Tp, int Mp, int D,
                                                         int ld_qk, float c1 /* scale*log2(e) */,
                                                         const uint8_t* __restrict__ kb_class, float fp8_scale) {
   using TL = AttnTile<HDP>;
   constexpr int KS = HDP / 16, DT = HDP / 32, CPR = TL::CPR;
-  __shared__ __attribute__((aligned(16))) char Ks_all[KB * 64 * TL::RS];
-  __shared__ __attribute__((aligned(16))) char Vs_all[KB * 64 * TL::RS];
+  constexpr int NP = X3 ? 2 : 1;  // planes
+  constexpr int TILE = 64 * TL::RS;
+  __shared__ __attribute__((aligned(16))) char Ks_all[KB * NP * TILE];
+  __shared__ __attribute__((aligned(16))) char Vs_all[KB * NP * TILE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 31, fhalf = lane >> 5;
   const int n = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * 128 + wave * 32 + frow;
   const int qc = q < Tp ? q : Tp - 1;
-  const size_t ldq = (size_t)ld_qk;  // 3D (Q|K|V)
+  const size_t ldq = (size_t)ld_qk * NP;  // row stride: 3D (Q|K|V), twice that for a plane pair
+  const size_t lo_q = (size_t)ld_qk;      // X3: distance of the lo plane inside a row
   const size_t mrow = (size_t)n * Tp + qc;
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
   // Q fragments (B operand of S^T = K.Q^T): 8 consecutive d per lane and k-step
-  u32x4 qf[KS];
+  u32x4 qf[KS], ql[X3 ? KS : 1];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
+  for (int ks = 0; ks < KS; ++ks) {
     qf[ks] = (ks * 16 + fhalf * 8) < HD ? *reinterpret_cast<const u32x4*>(qk + mrow * ldq + h * HD + ks * 16 + fhalf * 8) : zero4;
+    if constexpr (X3)
+      ql[ks] = (ks * 16 + fhalf * 8) < HD ? *reinterpret_cast<const u32x4*>(qk + mrow * ldq + lo_q + h * HD + ks * 16 + fhalf * 8) : zero4;
+  }
 
   f32x16 o[DT];
 #pragma unroll
@@ -120,8 +130,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
         const int r = idx / CPR, cp = idx % CPR;
         const bf16_t* src = qk + ((size_t)n * Tp + (kb0 + j) * 64 + r) * ldq + h * HD + cp * 8;
         const bool real = cp * 8 < HD;
-        *reinterpret_cast<u32x4*>(Ks_all + j * 64 * TL::RS + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(src + D) : zero4;
-        *reinterpret_cast<u32x4*>(Vs_all + j * 64 * TL::RS + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(src + 2 * D) : zero4;
+        *reinterpret_cast<u32x4*>(Ks_all + j * NP * TILE + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(src + D) : zero4;
+        *reinterpret_cast<u32x4*>(Vs_all + j * NP * TILE + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(src + 2 * D) : zero4;
+        if constexpr (X3) {
+          *reinterpret_cast<u32x4*>(Ks_all + j * NP * TILE + TILE + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(src + lo_q + D) : zero4;
+          *reinterpret_cast<u32x4*>(Vs_all + j * NP * TILE + TILE + TL::off(r, cp)) = real ? *reinterpret_cast<const u32x4*>(src + lo_q + 2 * D) : zero4;
+        }
       }
     }
     __syncthreads();
@@ -130,8 +144,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
     if (!live[j]) continue;
     const int kb = kb0 + j;
     const bool check_mask = chk[j];
-    const char* Ks = Ks_all + j * 64 * TL::RS;
-    const char* Vs = Vs_all + j * 64 * TL::RS;
+    const char* Ks = Ks_all + j * NP * TILE;
+    const char* Vs = Vs_all + j * NP * TILE;
 
     // ---- S^T tiles: s[kt][4g+i] = score(key = kb*64 + kt*32 + 8g + 4*fhalf + i, query q)
     f32x16 s[2];
@@ -140,7 +154,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) s[kt] = mfma_bf16(rowfrag<HDP>(Ks, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s[kt]);
+      for (int ks = 0; ks < KS; ++ks) {
+        const u32x4 kh = rowfrag<HDP>(Ks, kt * 32 + frow, 2 * ks + fhalf);
+        if constexpr (X3) {  // small terms first
+          s[kt] = mfma_bf16(rowfrag<HDP>(Ks + TILE, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s[kt]);
+          s[kt] = mfma_bf16(kh, ql[ks], s[kt]);
+        }
+        s[kt] = mfma_bf16(kh, qf[ks], s[kt]);
+      }
     }
     // ---- scale, mask, block max
     float mx = -INFINITY;
@@ -201,8 +222,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
         const u32x4 pf = pack8(s[kt], 8 * ss);
+        if constexpr (X3) {
+          const u32x4 pl = pack8_lo(s[kt], 8 * ss, pf);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const u32x4 vh = trfrag<HDP>(Vs, kt * 32 + 16 * ss, dt * 32, lane);
+            o[dt] = mfma_bf16(trfrag<HDP>(Vs + TILE, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
+            o[dt] = mfma_bf16(vh, pl, o[dt]);
+            o[dt] = mfma_bf16(vh, pf, o[dt]);
+          }
+        } else {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[dt] = mfma_bf16(trfrag<HDP>(Vs, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
+        }
       }
     }  // blocks of the round
   }
@@ -211,7 +243,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
     if (lse != nullptr && fhalf == 0)  // log2-domain logsumexp of the scaled scores, for the backward pass
       lse[((size_t)n * gridDim.y + h) * Tp + q] = m_run + __builtin_amdgcn_logf(l_run);
     const float inv = (fp8_scale > 0.f ? fp8_scale : 1.0f) / l_run;
-    bf16_t* orow = out + ((size_t)n * Tp + q) * D + h * HD;
+    bf16_t* orow = out + ((size_t)n * Tp + q) * D * NP + h * HD;
     fp8_t* orow8 = reinterpret_cast<fp8_t*>(out) + ((size_t)n * Tp + q) * D + h * HD;  // fp8 tier: e4m3 operand of out_proj
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
@@ -219,7 +251,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HD == 64 ? 
       for (int g = 0; g < 4; ++g) {
         const int d = dt * 32 + 8 * g + 4 * fhalf;
         if (d < HD) {
-          if (fp8_scale > 0.f) store4(orow8 + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+          if constexpr (X3) store4_x3(orow + d, (size_t)D, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+          else if (fp8_scale > 0.f) store4(orow8 + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
           else store4(orow + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
         }
       }
@@ -842,6 +875,19 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
     else
       hipLaunchKernelGGL((attn_bf16_kernel<72, 96, 1>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
                          Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr, fp8_scale);
+  } else if (prec == OSUD_PREC_BF16X3) {
+    OSUD_CHECK_ARG(lse == nullptr && fp8_scale <= 0.f, "attention: the split-bf16 tier is inference only");
+    dim3 grid((Tp + 127) / 128, heads, N);
+    if (head_dim == 64)
+      hipLaunchKernelGGL((attn_bf16_kernel<64, 64, 1, true>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
+                         Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr, 0.f);
+    else if (head_dim == 72)
+      hipLaunchKernelGGL((attn_bf16_kernel<72, 96, 1, true>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
+                         Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr, 0.f);
+    else {
+      set_error("attention: head_dim %d not built (64, 72)", head_dim);
+      return OSUD_ERR_UNSUPPORTED;
+    }
   } else {
     dim3 grid(Tp / 64, heads, N);
     if (head_dim == 64)

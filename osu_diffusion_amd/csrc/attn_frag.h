@@ -63,6 +63,15 @@ __device__ __forceinline__ u32x4 pack8(const f32x16& v, int base) {
   return r;
 }
 
+// split-bf16 tier: the lo halves of the same 8 values, given their packed hi halves: bf16(v - float(hi))
+__device__ __forceinline__ u32x4 pack8_lo(const f32x16& v, int base, const u32x4& hi) {
+  u32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    r[i] = pack_bf2(v[base + 2 * i] - __uint_as_float(hi[i] << 16), v[base + 2 * i + 1] - __uint_as_float(hi[i] & 0xffff0000u));
+  return r;
+}
+
 // 32 accumulator rows of a wave (lane = row, 64 columns) -> bf16 rows in global memory through a 2 KiB LDS patch of the wave:
 // a lane owns a ROW of the accumulators, so a direct store instruction touches 32 rows with 16 bytes each -- 24 such
 // instructions per head and wave were 56 of the streamed backward kernel's 132 us (tools/attn_bench.py, stores compiled out).  Sixteen rows at a time go to the patch (16-byte chunks XOR-swizzled with

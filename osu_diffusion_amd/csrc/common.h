@@ -36,6 +36,11 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
 // ---- element types of the two arithmetic tiers ---------------------------------------
 typedef uint16_t bf16_t;  // storage only
 struct fp8_t { uint8_t v; };  // OCP e4m3 storage (experimental GEMM operand type: osud_op_gemm precision 2)
+// Split-bf16 tier (OSUD_PREC_BF16X3): an fp32 value v travels as the pair hi = bf16(v), lo = bf16(v - hi), i.e. 16 significand bits
+// (2^-17 relative, finer than the TF32 the reference's matmuls use); a product is three bf16 MFMAs: hi*hi + lo*hi + hi*lo.
+// LAYOUT: a matrix with logical leading dimension ld is a bf16 array whose rows are 2 * ld long -- the hi plane in columns
+// [0, ld), the lo plane in [ld, 2 ld).  x3_t is the element type of such a matrix in templates (one plane element = one bf16).
+struct x3_t { uint16_t v; };
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -51,6 +56,10 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// planes per row of a TE matrix (row stride = kPlanes * ld elements)
+template <typename TE> struct Planes { static constexpr int k = 1; };
+template <> struct Planes<x3_t> { static constexpr int k = 2; };
 
 template <typename TE> struct ElemTraits;
 template <> struct ElemTraits<bf16_t> {
@@ -130,6 +139,52 @@ __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
   v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
+// ---- split-bf16 rows: W consecutive logical elements at `p` (hi plane), their lo halves `ld` elements further on
+__device__ __forceinline__ void split_hi_lo(float v0, float v1, uint32_t& hi, uint32_t& lo) {
+  hi = pack_bf2(v0, v1);
+  lo = pack_bf2(v0 - __uint_as_float(hi << 16), v1 - __uint_as_float(hi & 0xffff0000u));  // (both differences are exact in fp32)
+}
+__device__ __forceinline__ void store2_x3(bf16_t* p, size_t ld, float a, float b) {
+  uint32_t hi, lo;
+  split_hi_lo(a, b, hi, lo);
+  *reinterpret_cast<uint32_t*>(p) = hi;
+  *reinterpret_cast<uint32_t*>(p + ld) = lo;
+}
+__device__ __forceinline__ void store4_x3(bf16_t* p, size_t ld, float a, float b, float c, float d) {
+  uint2 hi, lo;
+  split_hi_lo(a, b, hi.x, lo.x);
+  split_hi_lo(c, d, hi.y, lo.y);
+  *reinterpret_cast<uint2*>(p) = hi;
+  *reinterpret_cast<uint2*>(p + ld) = lo;
+}
+__device__ __forceinline__ void store8_x3(bf16_t* p, size_t ld, const float (&v)[8]) {
+  uint4 hi, lo;
+  split_hi_lo(v[0], v[1], hi.x, lo.x);
+  split_hi_lo(v[2], v[3], hi.y, lo.y);
+  split_hi_lo(v[4], v[5], hi.z, lo.z);
+  split_hi_lo(v[6], v[7], hi.w, lo.w);
+  *reinterpret_cast<uint4*>(p) = hi;
+  *reinterpret_cast<uint4*>(p + ld) = lo;
+}
+__device__ __forceinline__ void store_elem_x3(bf16_t* p, size_t ld, float v) {
+  const bf16_t hi = f2bf(v);
+  p[0] = hi;
+  p[ld] = f2bf(v - bf2f(hi));
+}
+// x3_t tensors are written through the *_x3 helpers above (they need the plane distance) and never read back element-wise by the
+// row-wise kernels: these overloads only let the shared templates compile -- reaching one is a bug
+__device__ __forceinline__ void store8(x3_t*, const float (&)[8]) { __builtin_trap(); }
+__device__ __forceinline__ void store4(x3_t*, float, float, float, float) { __builtin_trap(); }
+__device__ __forceinline__ void store2(x3_t*, float, float) { __builtin_trap(); }
+__device__ __forceinline__ void store_elem(x3_t*, float) { __builtin_trap(); }
+__device__ __forceinline__ void load8(const x3_t*, float (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  __builtin_trap();
+}
+__device__ __forceinline__ void load2(const x3_t*, float& a, float& b) { a = b = 0.f; __builtin_trap(); }
+__device__ __forceinline__ float load_elem(const x3_t*) { __builtin_trap(); return 0.f; }
+
 // 2 consecutive elements (4 B bf16 / 8 B f32)
 __device__ __forceinline__ void store2(bf16_t* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = pack_bf2(a, b); }
 __device__ __forceinline__ void store2(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
@@ -168,6 +223,16 @@ template <int W> __device__ __forceinline__ void loadw(const bf16_t* p, float* v
 template <int W> __device__ __forceinline__ void loadw(const fp8_t*, float* v) {  // fp8 tensors are never read back by these kernels
 #pragma unroll
   for (int e = 0; e < W; ++e) v[e] = 0.f;
+}
+template <int W> __device__ __forceinline__ void loadw(const x3_t*, float* v) {  // (see the note at store8(x3_t*))
+#pragma unroll
+  for (int e = 0; e < W; ++e) v[e] = 0.f;
+  __builtin_trap();
+}
+template <int W> __device__ __forceinline__ void storew(x3_t*, const float*) { __builtin_trap(); }
+template <int W> __device__ __forceinline__ void storew_x3(bf16_t* p, size_t ld, const float* v) {
+  if constexpr (W == 4) store4_x3(p, ld, v[0], v[1], v[2], v[3]);
+  else store2_x3(p, ld, v[0], v[1]);
 }
 template <int W> __device__ __forceinline__ void storew(float* p, const float* v) {
   if constexpr (W == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
@@ -231,6 +296,7 @@ template <bool FAST> __device__ __forceinline__ void gelu_tanh_both_t(float z, f
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+// bytes per LOGICAL element (the split-bf16 tier stores two bf16 planes)
 static inline size_t elem_size(int prec) { return prec == OSUD_PREC_BF16 ? 2 : (prec == 2 ? 1 : 4); }
 
 // wave-level reductions (wave = 64 lanes)

@@ -77,6 +77,7 @@ struct osud_dit {
   bool split_first = false;
   int device = -1;
   bool training = false;
+  bool x3 = false;   // OSUD_PREC_BF16X3: prec == BF16X3, every TE matrix a plane pair [hi | lo] (common.h); inference only
   bool fp8 = false;  // OSUD_PREC_FP8: prec == BF16 everywhere except the e4m3 operands of qkv / out_proj / fc1 / fc2
 
   // weights

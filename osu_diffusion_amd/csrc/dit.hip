@@ -36,8 +36,9 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
   const int Tp = round_up(nT, 64), Mp = round_up(nN * Tp, 128), Np = round_up(nN, 128);
   const size_t es = m->esz, D = m->D;
   auto& W = m->ws_owned;
+  OSUD_CHECK_ARG(!(training && m->x3), "reserve: the split-bf16 tier is inference only (train in bf16 or fp32)");
   OSUD_TRY(dev_alloc(W, &m->e0, (size_t)Mp * m->Ke * es));
-  if (m->split_first) OSUD_TRY(dev_alloc(W, &m->h0c, (size_t)Mp * D * 4));
+  if (m->split_first || m->x3) OSUD_TRY(dev_alloc(W, &m->h0c, (size_t)Mp * D * 4));
   OSUD_TRY(dev_alloc(W, &m->temb, (size_t)Np * 256 * es));
   OSUD_TRY(dev_alloc(W, &m->th, (size_t)Np * D * es));
   OSUD_TRY(dev_alloc(W, &m->sb, (size_t)Np * D * es));
@@ -181,8 +182,9 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
   // (bf16 tier: rows and weights in the split [hi | lo | hi] x [w_hi | w_hi | w_lo] form, Ke = 3 Kp -- see embed_kernel)
   float* h = m->training ? m->saved[0].h_in : m->h;
   if (m->embed_const_on) {  // inside a sampler loop: h = h0c (made by embed_const_prepare) + coordinate features x their 256 columns
+    const int kx = m->x3 ? 256 : 768;  // 256 coordinate features: a plane pair (split-bf16 tier) or [hi | lo | hi] (bf16 tier's split first linear)
     OSUD_TRY(launch_embed(prec, x, o, c, m->freqs64, m->pf[0], m->pf[1], m->e0, N, T, Tp, Mp, m->E, m->Kp, cfg ? N / 2 : 0, st, true, 1));
-    OSUD_TRY(gemm(m, EPI_GATE_RES, m->e0, 768, m->w_ex, 768, Mp, D, 768, h, D, m->b_e, st, m->ones_d, 0, Tp, N, nullptr, m->h0c));
+    OSUD_TRY(gemm(m, EPI_GATE_RES, m->e0, kx, m->w_ex, kx, Mp, D, kx, h, D, m->b_e, st, m->ones_d, 0, Tp, N, nullptr, m->h0c));
   } else {
   OSUD_TRY(launch_embed(prec, x, o, c, m->freqs64, m->pf[0], m->pf[1], m->e0, N, T, Tp, Mp, m->E, m->Kp, cfg ? N / 2 : 0, st,
                         m->split_first));
@@ -322,7 +324,9 @@ static int upload_f32(osud_dit* m, float** dst, const float* src, size_t n, hipS
   return OSUD_OK;
 }
 // fp32 master -> TE copy of a weight (n % 4 == 0 for every DiT weight)
-static int convert_w(osud_dit* m, const float* src, void* dst, size_t n, hipStream_t st) {
+static int convert_w(osud_dit* m, const float* src, void* dst, size_t rows, size_t cols, hipStream_t st) {
+  const size_t n = rows * cols;
+  if (m->x3) return launch_pack_rows_x3(src, (int)cols, (int)cols, dst, (int)cols, (int)rows, st);  // rows of [w_hi | w_lo]
   if (m->defer_convert && n % 4 == 0) return m->defer_convert->add(src, dst, n / 4);
   return launch_convert(m->prec, src, dst, n, st);
 }
@@ -335,7 +339,8 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
                  cfg->heads, cfg->hidden);
   OSUD_CHECK_ARG(cfg->depth > 0 && cfg->context > 0 && cfg->in_channels == 2 && cfg->table_rows > 0,
                  "dit_create: bad depth/context/in_channels/table_rows");
-  OSUD_CHECK_ARG(cfg->precision == OSUD_PREC_BF16 || cfg->precision == OSUD_PREC_F32 || cfg->precision == OSUD_PREC_FP8,
+  OSUD_CHECK_ARG(cfg->precision == OSUD_PREC_BF16 || cfg->precision == OSUD_PREC_F32 || cfg->precision == OSUD_PREC_FP8 ||
+                     cfg->precision == OSUD_PREC_BF16X3,
                  "dit_create: unknown precision %d", cfg->precision);
   const int hd = cfg->hidden / cfg->heads;
   if (hd != 64 && hd != 72) {
@@ -348,6 +353,7 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   m->C = cfg->in_channels; m->C2 = cfg->learn_sigma ? 2 * cfg->in_channels : cfg->in_channels;
   m->fp8 = cfg->precision == OSUD_PREC_FP8;
   m->prec = m->fp8 ? OSUD_PREC_BF16 : cfg->precision;
+  m->x3 = m->prec == OSUD_PREC_BF16X3;  // every TE matrix is a plane pair [hi | lo] (common.h): esz = 4 bytes per logical element
   m->esz = (int)elem_size(m->prec);
   m->Kp = round_up(cfg->in_channels * 128 + 128 + cfg->context, 128);  // 528 -> 640
   {  // OSUD_SPLIT_FIRST=0: plain bf16 first linear (A/B measurements of the fast tier's deviation)
@@ -367,6 +373,7 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   auto A = [&](auto** p, size_t bytes) { if (rc == OSUD_OK) rc = dev_alloc(m->owned, p, bytes); };
   A(&m->w_e, D * m->Ke * es); A(&m->b_e, D * 4);
   if (m->split_first) { A(&m->w_ex, D * 768 * es); A(&m->ones_d, D * 4); }
+  if (m->x3) { A(&m->w_ex, D * 256 * es); A(&m->ones_d, D * 4); }
   A(&m->w_t0, D * 256 * es);  A(&m->b_t0, D * 4);
   A(&m->w_t2, D * D * es);    A(&m->b_t2, D * 4);
   A(&m->table, (size_t)cfg->table_rows * D * 4);
@@ -460,13 +467,15 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
     OSUD_HIP(hipMemcpy(m->pf, src, 8, hipMemcpyDeviceToHost));
   } else if (k == "xoc_embedder.mlp.0.weight") {
     SHAPE(D, 384 + m->E);
-    rc = m->split_first ? launch_pack_rows_split(src, 384 + m->E, 384 + m->E, m->w_e, m->Kp, (int)D, st)
-                        : launch_pack_rows(prec, src, 384 + m->E, 384 + m->E, m->w_e, m->Kp, m->Kp, (int)D, st);
+    rc = m->x3 ? launch_pack_rows_x3(src, 384 + m->E, 384 + m->E, m->w_e, m->Kp, (int)D, st)
+         : m->split_first ? launch_pack_rows_split(src, 384 + m->E, 384 + m->E, m->w_e, m->Kp, (int)D, st)
+                          : launch_pack_rows(prec, src, 384 + m->E, 384 + m->E, m->w_e, m->Kp, m->Kp, (int)D, st);
     if (rc == OSUD_OK && m->split_first) rc = launch_pack_rows_split(src, 384 + m->E, 256, m->w_ex, 256, (int)D, st);  // coordinate columns
+    if (rc == OSUD_OK && m->x3) rc = launch_pack_rows_x3(src, 384 + m->E, 256, m->w_ex, 256, (int)D, st);
   } else if (k == "xoc_embedder.mlp.0.bias") { SHAPE(D); rc = upload_f32(m, &m->b_e, src, D, st);
-  } else if (k == "t_embedder.mlp.0.weight") { SHAPE(D, 256); rc = convert_w(m, src, m->w_t0, D * 256, st);
+  } else if (k == "t_embedder.mlp.0.weight") { SHAPE(D, 256); rc = convert_w(m, src, m->w_t0, D, 256, st);
   } else if (k == "t_embedder.mlp.0.bias") { SHAPE(D); rc = upload_f32(m, &m->b_t0, src, D, st);
-  } else if (k == "t_embedder.mlp.2.weight") { SHAPE(D, D); rc = convert_w(m, src, m->w_t2, D * D, st);
+  } else if (k == "t_embedder.mlp.2.weight") { SHAPE(D, D); rc = convert_w(m, src, m->w_t2, D, D, st);
   } else if (k == "t_embedder.mlp.2.bias") { SHAPE(D); rc = upload_f32(m, &m->b_t2, src, D, st);
   } else if (k == "y_embedder.embedding_table.weight") {
     SHAPE(m->cfg.table_rows, D);
@@ -480,7 +489,7 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
   } else if (k == "final_layer.linear.bias") { SHAPE(m->C2); rc = upload_f32(m, &m->b_f, src, m->C2, st);
   } else if (k == "final_layer.adaLN_modulation.1.weight") {
     SHAPE(2 * D, D);
-    rc = convert_w(m, src, (char*)m->w_ada + (size_t)m->L * 6 * D * D * m->esz, 2 * D * D, st);
+    rc = convert_w(m, src, (char*)m->w_ada + (size_t)m->L * 6 * D * D * m->esz, 2 * D, D, st);
   } else if (k == "final_layer.adaLN_modulation.1.bias") {
     SHAPE(2 * D);
     float* dst = m->b_ada + (size_t)m->L * 6 * D;
@@ -493,29 +502,29 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
     const size_t es = m->esz;
     if (name == "attn.in_proj_weight") {
       SHAPE(3 * D, D);  // rows [Wq; Wk; Wv]
-      rc = convert_w(m, src, b.w_qkv, 3 * D * D, st);
+      rc = convert_w(m, src, b.w_qkv, 3 * D, D, st);
       if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)(3 * D), (int)D, b.w8_qkv, b.dq_qkv, 1.0f, st);
     } else if (name == "attn.in_proj_bias") {
       SHAPE(3 * D);
       rc = upload_f32(m, &b.b_qkv, src, 3 * D, st);
     } else if (name == "attn.out_proj.weight") {
       SHAPE(D, D);
-      rc = convert_w(m, src, b.w_o, D * D, st);
+      rc = convert_w(m, src, b.w_o, D, D, st);
       if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)D, (int)D, b.w8_o, b.dq_o, 1.0f, st);
     } else if (name == "attn.out_proj.bias") { SHAPE(D); rc = upload_f32(m, &b.b_o, src, D, st);
     } else if (name == "mlp.fc1.weight") {
       SHAPE(4 * D, D);
-      rc = convert_w(m, src, b.w1, 4 * D * D, st);
+      rc = convert_w(m, src, b.w1, 4 * D, D, st);
       if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)(4 * D), (int)D, b.w8_1, b.dq_1, 1.0f, st);
     } else if (name == "mlp.fc1.bias") { SHAPE(4 * D); rc = upload_f32(m, &b.b1, src, 4 * D, st);
     } else if (name == "mlp.fc2.weight") {
       SHAPE(D, 4 * D);
-      rc = convert_w(m, src, b.w2, 4 * D * D, st);
+      rc = convert_w(m, src, b.w2, D, 4 * D, st);
       if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)D, (int)(4 * D), b.w8_2, b.dq_2, 1.0f, st);
     } else if (name == "mlp.fc2.bias") { SHAPE(D); rc = upload_f32(m, &b.b2, src, D, st);
     } else if (name == "adaLN_modulation.1.weight") {
       SHAPE(6 * D, D);
-      rc = convert_w(m, src, (char*)m->w_ada + (size_t)l * 6 * D * D * es, 6 * D * D, st);
+      rc = convert_w(m, src, (char*)m->w_ada + (size_t)l * 6 * D * D * es, 6 * D, D, st);
     } else if (name == "adaLN_modulation.1.bias") {
       SHAPE(6 * D);
       float* dst = m->b_ada + (size_t)l * 6 * D;
@@ -618,7 +627,7 @@ extern "C" int osud_sample_loop_inpaint(osud_dit* m, const osud_sched* s, int mo
   }
   {
     const char* ec = getenv("OSUD_EMBED_CONST");
-    if (m->split_first && m->h0c != nullptr && !(ec && ec[0] == '0')) {
+    if ((m->split_first || m->x3) && m->h0c != nullptr && !(ec && ec[0] == '0')) {
       OSUD_TRY(embed_const_prepare(m, x, o, c, N, T, cfg_scale >= 0.f, st));
       m->embed_const_on = true;  // (consulted while the step is captured / run eagerly; replays of the graph read h0c)
     }
@@ -700,7 +709,8 @@ extern "C" int osud_set_gemm_dynamic_tiles(int on) {
 extern "C" int osud_op_gemm(int precision, int epilogue, const void* Y, int ldy, const void* X, int ldx, int My, int Nx,
                             int K, void* out, int ldo, const float* bias, const float* gate, int ld_gate,
                             int rows_per_sample, int n_samples, osud_stream stream) {
-  OSUD_CHECK_ARG(precision == OSUD_PREC_BF16 || precision == OSUD_PREC_F32 || precision == 2 /* experimental fp8 e4m3 operands */,
+  OSUD_CHECK_ARG(precision == OSUD_PREC_BF16 || precision == OSUD_PREC_F32 || precision == 2 /* experimental fp8 e4m3 operands */ ||
+                     precision == OSUD_PREC_BF16X3 /* plane pairs [hi | lo]: ld counts logical columns */,
                  "op_gemm: unknown precision");
   GemmP p{};
   p.Y = Y; p.X = X; p.ldy = ldy; p.ldx = ldx; p.My = My; p.Nx = Nx; p.K = K; p.out = out; p.ldo = ldo; p.bias = bias;

@@ -1,0 +1,967 @@
+// The GEMM kernel template and its launch-side tile choice (see gemm.h for the design).  Included by one translation unit per
+// operand element type (gemm_bf16.hip, gemm_f32.hip, gemm_fp8.hip, gemm_x3.hip) so that the instantiations build in parallel;
+// the process-wide host state (CU count, tile-queue counter pool, switches) lives in gemm.hip.  gfx950 only.
+#pragma once
+#include <stdlib.h>
+
+#include <string>
+#include <type_traits>
+
+#include "gemm.h"
+
+namespace osud {
+
+// host state shared by the translation units (defined in gemm.hip)
+int gemm_num_cus();
+unsigned* gemm_sched_slot();       // next counter set of the dynamic tile queue, nullptr before gemm_sched_init()
+bool gemm_dynamic_tiles_wanted();  // osud_set_gemm_dynamic_tiles / OSUD_GEMM_DYNAMIC
+
+namespace {
+
+constexpr int SLAB = 128;  // bytes of K per pipeline stage row (SB = 64: half slabs, a deeper ring -- see Geo)
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Fragment reads are inline asm on purpose: hipcc cannot prove that a compiler-visible
+// ds_read does not alias the in-flight LDS-DMA of later slabs and would put
+// `s_waitcnt vmcnt(0)` in front of every read, serialising load and MFMA.  The asm reads are
+// ordered by the counted vmcnt + barrier at the top of each slab and by counted lgkmcnt.
+template <int OFF> __device__ __forceinline__ u32x4 ds_read16(uint32_t addr) {
+  u32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+
+template <int OFF> __device__ __forceinline__ f32x4 ds_read16f(uint32_t addr) {
+  f32x4 v;
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+__device__ __forceinline__ void ds_write16(uint32_t addr, const f32x4& v) {
+  asm volatile("ds_write_b128 %0, %1" : : "v"(addr), "v"(v) : "memory");
+}
+
+template <typename TE> __device__ __forceinline__ void mma(f32x16& acc, const u32x4& a, const u32x4& b);
+template <> __device__ __forceinline__ void mma<bf16_t>(f32x16& acc, const u32x4& a, const u32x4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0,
+                                                0, 0);
+}
+template <> __device__ __forceinline__ void mma<x3_t>(f32x16& acc, const u32x4& a, const u32x4& b) {  // a plane pair: one bf16 MFMA
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0,
+                                                0, 0);
+}
+template <> __device__ __forceinline__ void mma<float>(f32x16& acc, const u32x4& a, const u32x4& b) {
+  const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[j], acc, 0, 0, 0);
+}
+
+// fp8 (e4m3) operands: one v_mfma_scale_f32_32x32x64_f8f6f4 with unit block scales (E8M0 127) consumes TWO 16-byte chunks per
+// lane and operand -- K = 64 per instruction at twice the bf16 rate.  Which 32 of the 64 k-slots a lane half feeds does not matter
+// as long as A and B agree, so the fragments of two consecutive sub-steps (chunks 2s+h and 2s+2+h) are simply concatenated.
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void mma_f8(f32x16& acc, const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1) {
+  i32x8 a, b;
+  a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3]; a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
+  b[0] = b0[0]; b[1] = b0[1]; b[2] = b0[2]; b[3] = b0[3]; b[4] = b1[0]; b[5] = b1[1]; b[6] = b1[2]; b[7] = b1[3];
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+template <> __device__ __forceinline__ void mma<fp8_t>(f32x16&, const u32x4&, const u32x4&) {}  // fp8 goes through mma_f8
+
+#define OSUD_LGKM_WAIT(n)                                  \
+  asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
+  __builtin_amdgcn_sched_barrier(0)
+
+// Per-wave register block: (RY x 32) rows of Y by (RX x 32) rows of X -> RY x RX MFMA 32x32 accumulators.
+template <int RY, int RX> struct FragSet {
+  u32x4 y[RY], x[RX];
+};
+// ya/xa: this lane's LDS byte address of (first Y / X row of the wave, k-substep s) in the current stage
+template <int RY, int RX, int SB = SLAB> __device__ __forceinline__ void read_set(FragSet<RY, RX>& f, uint32_t ya, uint32_t xa) {
+  f.y[0] = ds_read16<0>(ya);
+  if constexpr (RY >= 2) f.y[1] = ds_read16<32 * SB>(ya);
+  if constexpr (RY >= 3) f.y[2] = ds_read16<64 * SB>(ya);
+  if constexpr (RY == 4) f.y[3] = ds_read16<96 * SB>(ya);
+  f.x[0] = ds_read16<0>(xa);
+  f.x[1] = ds_read16<32 * SB>(xa);
+  if constexpr (RX >= 3) f.x[2] = ds_read16<64 * SB>(xa);
+  if constexpr (RX == 4) f.x[3] = ds_read16<96 * SB>(xa);
+}
+template <typename TE, int RY, int RX>
+__device__ __forceinline__ void mma_set(f32x16 (&acc)[RY][RX], const FragSet<RY, RX>& f) {
+#pragma unroll
+  for (int i = 0; i < RY; ++i)
+#pragma unroll
+    for (int j = 0; j < RX; ++j) mma<TE>(acc[i][j], f.x[j], f.y[i]);
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() {
+  if constexpr (N == 3) { OSUD_LGKM_WAIT(3); }
+  else if constexpr (N == 4) { OSUD_LGKM_WAIT(4); }
+  else if constexpr (N == 5) { OSUD_LGKM_WAIT(5); }
+  else if constexpr (N == 6) { OSUD_LGKM_WAIT(6); }
+  else if constexpr (N == 8) { OSUD_LGKM_WAIT(8); }
+  else { OSUD_LGKM_WAIT(0); }
+}
+// One 128-byte K slab from the LDS stage at byte offset `so`: 4 sub-steps, reads of sub-step s+1 in
+// flight under the MFMAs of sub-step s (LDS returns in order, so lgkmcnt(R) == "all but the newest R").
+// experiments (-DOSUD_EXP_MODE=<flags>, one build per variant: run-time flags here cost registers and spill): 64 = fragment reads without the MFMAs, 128 = no
+// LDS-DMA (stale stages), 256 = MFMAs on stale fragments (no reads), 512 = neither reads nor MFMAs (LDS-DMA only)
+template <typename TE, int RY, int RX, int SB = SLAB>
+__device__ __forceinline__ void compute_slab(f32x16 (&acc)[RY][RX], const uint32_t (&ya)[4], const uint32_t (&xa)[4],
+                                             uint32_t so) {
+  FragSet<RY, RX> f0, f1;
+  if constexpr (SB == 64) {  // half slab: two sub-steps (bf16 / f32) or one K = 64 instruction (fp8)
+    read_set<RY, RX, SB>(f0, ya[0] + so, xa[0] + so);
+    read_set<RY, RX, SB>(f1, ya[1] + so, xa[1] + so);
+    if constexpr (sizeof(TE) == 1) {
+      wait_lgkm<0>();
+#pragma unroll
+      for (int i = 0; i < RY; ++i)
+#pragma unroll
+        for (int j = 0; j < RX; ++j) mma_f8(acc[i][j], f0.x[j], f1.x[j], f0.y[i], f1.y[i]);
+    } else {
+      wait_lgkm<RY + RX>();
+      mma_set<TE, RY, RX>(acc, f0);
+      wait_lgkm<0>();
+      mma_set<TE, RY, RX>(acc, f1);
+    }
+    return;
+  }
+#ifdef OSUD_EXP_MODE
+  constexpr int g_exp_flags = OSUD_EXP_MODE;
+  if (sizeof(TE) == 2 && (g_exp_flags & 512)) return;  // LDS-DMA only
+  if (sizeof(TE) == 2 && (g_exp_flags & (64 | 256))) {
+    if (g_exp_flags & 64) {  // reads only
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        read_set<RY, RX>(f0, ya[s2] + so, xa[s2] + so);
+        wait_lgkm<0>();
+#pragma unroll
+        for (int i = 0; i < RY; ++i) asm volatile("" ::"v"(f0.y[i]));
+#pragma unroll
+        for (int j = 0; j < RX; ++j) asm volatile("" ::"v"(f0.x[j]));
+      }
+    } else {  // MFMAs only, on whatever the registers hold
+#pragma unroll
+      for (int j = 0; j < RX; ++j) asm volatile("" : "=v"(f0.x[j]));
+#pragma unroll
+      for (int i = 0; i < RY; ++i) asm volatile("" : "=v"(f0.y[i]));
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) mma_set<TE, RY, RX>(acc, f0);
+    }
+    return;
+  }
+#endif
+  if constexpr (sizeof(TE) == 1) {  // fp8: two K = 64 instructions per accumulator block and slab (128 bytes = 128 k)
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      read_set<RY, RX>(f0, ya[2 * half] + so, xa[2 * half] + so);
+      read_set<RY, RX>(f1, ya[2 * half + 1] + so, xa[2 * half + 1] + so);
+      wait_lgkm<0>();
+#pragma unroll
+      for (int i = 0; i < RY; ++i)
+#pragma unroll
+        for (int j = 0; j < RX; ++j) mma_f8(acc[i][j], f0.x[j], f1.x[j], f0.y[i], f1.y[i]);
+    }
+    return;
+  }
+  read_set<RY, RX>(f0, ya[0] + so, xa[0] + so);
+  read_set<RY, RX>(f1, ya[1] + so, xa[1] + so);
+  wait_lgkm<RY + RX>();
+  mma_set<TE, RY, RX>(acc, f0);
+  read_set<RY, RX>(f0, ya[2] + so, xa[2] + so);
+  wait_lgkm<RY + RX>();
+  mma_set<TE, RY, RX>(acc, f1);
+  read_set<RY, RX>(f1, ya[3] + so, xa[3] + so);
+  wait_lgkm<RY + RX>();
+  mma_set<TE, RY, RX>(acc, f0);
+  wait_lgkm<0>();
+  mma_set<TE, RY, RX>(acc, f1);
+}
+
+// 8 consecutive output elements of row `row` at column x of a TO matrix with logical leading dimension ldo
+template <typename TO> __device__ __forceinline__ void store8_out(void* base, size_t row, int ldo, int x, const float (&v)[8]) {
+  if constexpr (std::is_same<TO, x3_t>::value) store8_x3(reinterpret_cast<bf16_t*>(base) + row * (size_t)(2 * ldo) + x, (size_t)ldo, v);
+  else store8(reinterpret_cast<TO*>(base) + row * (size_t)ldo + x, v);
+}
+
+// Tile geometry: WY x WX waves, each wave (RY*32) x (RX*32) outputs: BM = WY*RY*32 rows of Y, BN = WX*RX*32 rows of X.
+// A stage holds one K slab of both operands as ONE (BM+BN)-row x 128-byte image.
+// SB = bytes of K per stage row.  128: the classic form (two 64 KiB stages for the 256-wide tiles: ONE slab in flight while one is
+// consumed).  64: half slabs in a ring of four with the epilogue patches in their own 32 KiB behind the ring -- three half slabs
+// in flight, because the component experiments (tools/gemm_exp.py) showed the LDS-DMA fill of a 64 KiB slab to take ~2800 cycles
+// issue-to-landed against 2048 cycles of MFMA work on it: with one slab of lead the fill IS the critical path.
+template <int WY, int WX, int RY, int RX, int SB = SLAB> struct Geo {
+  static constexpr int BM = WY * RY * 32, BN = WX * RX * 32, NW = WY * WX, NT = 64 * NW;
+  static constexpr int STAGE = (BM + BN) * SB;
+  static constexpr int RPP = 1024 / SB;        // rows per 1 KiB LDS-DMA piece
+  static constexpr bool PATCH_OUT = SB == 64;  // epilogue patches outside the ring
+  // One persistent workgroup per CU owns all 160 KiB.  (Tried and dropped: two 4-wave workgroups per CU on 128x192 tiles so that
+  // one's epilogue runs under the other's main loop, 25-45 % slower; four waves of 128x128 with one wave per SIMD and 512
+  // registers, 20-60 % slower under hipcc's scheduling.)
+  static constexpr int WGS = 1;
+  static constexpr int LDS_MAX = 160 * 1024 / WGS;
+  static constexpr int RING_MAX = PATCH_OUT ? LDS_MAX - NW * 4096 : LDS_MAX;
+  static constexpr int NSTAGE = STAGE * 5 <= RING_MAX ? 5 : (STAGE * 4 <= RING_MAX ? 4 : (STAGE * 3 <= RING_MAX ? 3 : 2));
+  static constexpr int PIECES = STAGE / 1024, PPW = PIECES / NW;  // 1 KiB LDS-DMA pieces per slab, per wave
+  static_assert(PIECES % NW == 0 && BM % RPP == 0, "pieces must divide evenly over the waves and not straddle the operands");
+  static_assert(NSTAGE * STAGE <= RING_MAX && (PATCH_OUT || NW * 4096 <= STAGE), "stage ring must fit the LDS; the epilogue patches live in one stage or behind the ring");
+};
+
+// HBM -> LDS: this wave's share of one K slab (PPW pieces of 8 rows x 128 bytes).  The 16-byte chunk index
+// is XOR-swizzled with (row>>1)&7 on the SOURCE side (the LDS side of an LDS-DMA is lane-linear).  The address is split as
+// SGPR base (the tile's Y or X panel at this slab) + a per-lane 32-bit offset computed once per kernel (`dma_off`), so the
+// loop carries no per-piece 64-bit VALU address arithmetic (-24...-32 VGPRs, -1.5 % per sampling step vs the builtin with
+// per-lane 64-bit pointers).  M0 (the LDS destination) is written in the same asm statement that uses it.
+template <typename G>
+__device__ __forceinline__ void stage_slab(const char* gy, const char* gx, uint32_t stage_lds, const uint32_t (&voff)[G::PPW],
+                                           int wave) {
+#ifdef OSUD_EXP_MODE
+  if (OSUD_EXP_MODE & 128) return;
+#endif
+#pragma unroll
+  for (int q = 0; q < G::PPW; ++q) {
+    const int piece = wave * G::PPW + q;  // wave-uniform
+    const char* sbase = (piece * G::RPP < G::BM) ? gy : gx;
+    const uint32_t dst = stage_lds + (uint32_t)__builtin_amdgcn_readfirstlane(piece * 1024);
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff[q]), "s"(sbase), "s"(dst) : "memory");
+  }
+}
+
+// Linear tile index -> (ty, tx).  Workgroup b runs on XCD b % 8 and walks tiles first, first + G, ...; `first`
+// is chosen so that in every round each XCD holds a run of G/8 consecutive indices.  Plain order (x fastest)
+// makes every XCD sweep ALL weight panels each round (the PMC pass showed 5x the operand bytes being fetched).
+// Banded order (tile_order = 2): XCD k owns the row band [k*nty/8, (k+1)*nty/8) and walks it column-block by column-block
+// (CBW tile columns at a time, rows inside), so CBW weight panels stay L2-resident across consecutive rounds
+// while the activation panels stream.  Measured on fc1 (M=32768): fetched bytes -22 %, time +2 % (the re-reads are
+// Infinity-Cache hits, not the limiter) -> the plain order stays the default.
+struct TileMap {
+  int ntx, nty, G, banded, rb, cbw;
+  __device__ __forceinline__ void coords(int t, int& ty, int& tx) const {
+    if (!banded) {
+      ty = t / ntx;
+      tx = t % ntx;
+      return;
+    }
+    const int per = G >> 3;                       // tiles per XCD per round
+    const int round = t / G, in_round = t % G;
+    const int xcd = in_round / per, li = round * per + in_round % per;  // index inside the XCD's band
+    const int blk = rb * cbw;                     // tiles per column block
+    const int cb = li / blk, rem = li % blk;
+    ty = xcd * rb + rem / cbw;
+    tx = cb * cbw + rem % cbw;
+  }
+};
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+  else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)" ::: "memory");
+  else static_assert(N < 0, "add the literal");
+}
+
+// ROLES (8-wave geometries, static tile schedule): the two waves of every SIMD alternate between feeding the matrix pipe and
+// issuing the LDS-DMA of the next slab instead of doing both in lock step -- see the main loop.
+template <typename TE, int EPI, int WY, int WX, int RY, int RX, bool ROLES, int SB = SLAB>
+__global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(GemmP p) {
+  using G = Geo<WY, WX, RY, RX, SB>;
+  static_assert(!ROLES || SB == SLAB, "the role split is built on the two-stage 128-byte form");
+  constexpr int BN = G::BN;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr bool FAST = sizeof(TE) <= 2;
+  constexpr bool kF8 = sizeof(TE) == 1;  // fp8 operands: outputs are bf16 (EPI_BIAS_TE), fp8 (EPI_BIAS_GELU_TE) or fp32
+  using TO = typename std::conditional<kF8, typename std::conditional<EPI == EPI_BIAS_GELU_TE, fp8_t, bf16_t>::type, TE>::type;
+  constexpr bool kGelu = EPI == EPI_BIAS_GELU_TE || EPI == EPI_BIAS_GELU_BF;  // _BF: fp8 operands with bf16 outputs (training)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wy = wave / WX, wx = wave % WX;
+  const int frow = lane & 31, fhalf = lane >> 5;
+
+  const int ntx = p.Nx / BN, ntiles = (p.My / G::BM) * ntx;
+  // split-bf16 operands (x3_t): rows are [hi plane | lo plane], each ld long; the contraction walks three segments of nk0 slabs --
+  // Y_hi.X_hi, Y_lo.X_hi, Y_hi.X_lo -- into the same fp32 accumulators: the product of (hi + lo) pairs without the lo.lo term
+  constexpr bool kX3 = std::is_same<TE, x3_t>::value;
+  constexpr int kPlanes = Planes<TE>::k;
+  const int nk0 = (int)((size_t)p.K * sizeof(TE) / SB);
+  int nk = kX3 ? 3 * nk0 : nk0;
+  const size_t ldy_b = (size_t)p.ldy * sizeof(TE) * kPlanes, ldx_b = (size_t)p.ldx * sizeof(TE) * kPlanes;
+  const char* gy0 = reinterpret_cast<const char*>(p.Y);
+  const char* gx0 = reinterpret_cast<const char*>(p.X);
+  if (p.split_k > 1) {  // this workgroup's share of the contraction (ranges differ by at most one slab)
+    const int k0 = (int)((long)blockIdx.y * nk / p.split_k), k1 = (int)((long)(blockIdx.y + 1) * nk / p.split_k);
+    nk = k1 - k0;
+    gy0 += (size_t)k0 * SB;
+    gx0 += (size_t)k0 * SB;
+    p.out = reinterpret_cast<char*>(p.out) + (size_t)blockIdx.y * p.split_stride * (EPI == EPI_NONE_F32 ? 4 : sizeof(TE));
+  }
+  // Persistent workgroups: gridDim.x <= #CUs.  Blocks are dispatched round-robin over the 8 XCDs (b % 8);
+  // in every round give each XCD a contiguous run of tiles (x fastest) so its private L2 sees whole panels.
+  const int G8 = gridDim.x;
+  int first;
+  {
+    const int b = blockIdx.x, q = G8 >> 3, r = G8 & 7, xcd = b & 7, idx = b >> 3;
+    first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  TileMap tm;
+  tm.ntx = ntx; tm.nty = p.My / G::BM; tm.G = G8;
+  tm.rb = tm.nty >> 3;
+  tm.cbw = ntx % 6 == 0 ? 6 : (ntx % 4 == 0 ? 4 : (ntx % 3 == 0 ? 3 : ntx));
+  tm.banded = (p.tile_order == 2) && tm.nty % 8 == 0 && G8 % 8 == 0 && ntiles % G8 == 0 && tm.rb >= 2 && ntx >= 2;
+  auto tile_ptrs = [&](int tile, int kt, const char*& gy, const char*& gx) {
+    int ty, tx;
+    tm.coords(tile, ty, tx);
+#ifdef OSUD_GEMM_TIMING
+    if (p.tile_order == 4) ty = tx = 0;           // experiment: every workgroup streams the SAME panels (all L2 hits)
+    if (p.tile_order == 5) { ty = ty % 8; tx = 0; }
+#endif
+    size_t ky = (size_t)kt * SB, kx = ky;
+    if constexpr (kX3) {  // (32-bit scalar arithmetic + readfirstlane: the panel bases feed "s" operands of the LDS-DMA asm)
+      const int seg = kt >= 2 * nk0 ? 2 : (kt >= nk0 ? 1 : 0), r = kt - seg * nk0;
+      ky = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(r * SB + (seg == 1 ? p.ldy * (int)sizeof(TE) : 0));  // the lo plane starts ld elements into the row
+      kx = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(r * SB + (seg == 2 ? p.ldx * (int)sizeof(TE) : 0));
+    }
+    gy = gy0 + (size_t)ty * G::BM * ldy_b + ky;
+    gx = gx0 + (size_t)tx * BN * ldx_b + kx;
+  };
+
+  // per-lane LDS byte addresses of the wave's first Y/X row for the 4 k-substeps (stage 0)
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_void*)smem;
+  uint32_t ya[4], xa[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {  // (SB = 64: sub-steps 0 and 1 exist; the 4 chunks of a 64-byte row are swizzled with (row>>2)&3)
+    const uint32_t sw = SB == 128 ? (uint32_t)(((2 * s + fhalf) ^ ((frow >> 1) & 7)) << 4)
+                                  : (uint32_t)((((2 * s + fhalf) & 3) ^ ((frow >> 2) & 3)) << 4);
+    ya[s] = lds0 + (wy * RY * 32 + frow) * SB + sw;
+    xa[s] = lds0 + (G::BM + wx * RX * 32 + frow) * SB + sw;
+  }
+
+  // epilogue patch (4 KiB per wave, inside whichever stage is free when the epilogue runs): write address per
+  // register group g and read address, relative to that stage
+  const uint32_t patch = lds0 + (G::PATCH_OUT ? G::NSTAGE * G::STAGE : 0) + wave * 4096;
+  uint32_t pw[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) pw[g] = patch + frow * 128 + (((2 * g + fhalf) ^ (frow & 7)) << 4);
+  // read-back: lane l takes rows (l>>2) and 16 + (l>>2), 8 consecutive x = two 16-byte slots 2*(l&3), 2*(l&3)+1
+  const uint32_t pr0 = patch + (lane >> 2) * 128 + (((2 * (lane & 3)) ^ ((lane >> 2) & 7)) << 4);
+  const uint32_t pr1 = patch + (lane >> 2) * 128 + (((2 * (lane & 3) + 1) ^ ((lane >> 2) & 7)) << 4);
+
+  // per-lane byte offsets of this wave's LDS-DMA pieces inside a (Y panel | X panel) slab; < 2^32 is checked by the launcher
+  uint32_t dma_off[G::PPW];
+#pragma unroll
+  for (int q = 0; q < G::PPW; ++q) {
+    const int piece = wave * G::PPW + q;
+    const int R = piece * G::RPP + (SB == 128 ? (lane >> 3) : (lane >> 2));
+    const int c = SB == 128 ? ((lane & 7) ^ ((R >> 1) & 7)) : ((lane & 3) ^ ((R >> 2) & 3));
+    dma_off[q] = (uint32_t)((piece * G::RPP < G::BM ? (size_t)R * ldy_b : (size_t)(R - G::BM) * ldx_b) + c * 16);
+  }
+  // ---- ROLES: who stages what.  Waves w and w + 4 share a SIMD; group 0 = waves 0-3 owns the top half of the Y rows, group 1
+  // the bottom half.  Per slab: group 1 issues the pieces group 0 needs first -- Y top + all of X (the EARLY set) -- while group 0
+  // computes; then group 0 issues Y bottom (the LATE set, only group 1 needs it, a whole period later) while group 1 computes.
+  constexpr int kNE = G::BM / 16 + G::BN / 8, kPE = ROLES ? kNE / 4 : 1, kPL = ROLES ? G::BM / 64 : 1, kPR = kPE > kPL ? kPE : kPL;
+  static_assert(!ROLES || (G::NW == 8 && kNE % 4 == 0 && (G::BM / 16) % 4 == 0), "role split needs 8 waves and evenly divisible piece sets");
+  const int grp = wave >> 2, wi = wave & 3;
+  uint32_t roff[kPR];
+  if constexpr (ROLES) {
+#pragma unroll
+    for (int q = 0; q < kPR; ++q) {
+      int piece = 0;
+      if (grp == 1) { const int e = wi * kPE + q; piece = e < G::BM / 16 ? e : G::BM / 8 + (e - G::BM / 16); }
+      else piece = G::BM / 16 + wi * kPL + (q < kPL ? q : 0);
+      const int R = piece * 8 + (lane >> 3);
+      const int c = (lane & 7) ^ ((R >> 1) & 7);
+      roff[q] = (uint32_t)((piece * 8 < G::BM ? (size_t)R * ldy_b : (size_t)(R - G::BM) * ldx_b) + c * 16);
+    }
+  }
+  auto role_issue = [&](const char* gy, const char* gx, uint32_t stage_lds) {  // this wave's share of its group's set
+    const int cnt = grp == 1 ? kPE : kPL;
+#pragma unroll
+    for (int q = 0; q < kPR; ++q) {
+      if (q < cnt) {
+        int piece;
+        if (grp == 1) { const int e = wi * kPE + q; piece = e < G::BM / 16 ? e : G::BM / 8 + (e - G::BM / 16); }
+        else piece = G::BM / 16 + wi * kPL + q;
+        piece = __builtin_amdgcn_readfirstlane(piece);
+        const char* sbase = (piece * 8 < G::BM) ? gy : gx;
+        const uint32_t dst = stage_lds + (uint32_t)(piece * 8 * SLAB);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(roff[q]), "s"(sbase), "s"(dst) : "memory");
+      }
+    }
+  };
+
+  // ---- tile sequence.  The first tile of a workgroup is static (`first`: XCD-contiguous runs).  Launches with more tiles
+  // than workgroups draw every later tile from a ticket counter (p.sched), two tiles ahead of the one being computed, so that a
+  // workgroup that starts late or runs slowly -- a collective's or an optimizer's kernel holding its compute unit -- takes fewer
+  // tiles instead of stretching the launch (measured: 8 held CUs cost a static launch 1.5x).  The ticket for tile j+2 is
+  // requested (wave 0, lane 0) at the top of tile j, has returned by the vmcnt(0) before tile j's epilogue, and is published
+  // through LDS across the epilogue barrier; the ticket for the second tile is requested before the prologue, is older than
+  // every LDS-DMA piece and so has returned after the first slab's wait.
+  constexpr bool kDynFits = G::NSTAGE * G::STAGE + (G::PATCH_OUT ? G::NW * 4096 : 0) + 64 <= G::LDS_MAX;
+  const bool dyn = kDynFits && p.sched != nullptr;
+  volatile __attribute__((address_space(3))) uint32_t* sched_lds =
+      reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>((lds_void*)smem) + (G::NSTAGE * G::STAGE + (G::PATCH_OUT ? G::NW * 4096 : 0)) / 4;
+  const bool ticket_lane = dyn && wave == 0 && lane == 0;
+  // One queue per XCD (16-bit fields of p.sched[0..3], two per word; [8] counts finished workgroups): ticket k of XCD x is the
+  // k-th tile of the runs a static schedule would give that XCD in rounds 1, 2, ... -- undisturbed, every XCD's L2 keeps seeing
+  // the same contiguous panels (one global queue scattered them: the K = 3072 launches got 25 % slower).  Queues are not
+  // stolen from: tickets run two tiles ahead of the arithmetic, so a workgroup that finds its queue empty cannot tell a
+  // neighbour in trouble from one about to finish (stealing on a snapshot of the counters made undisturbed launches 15-30 %
+  // slower); kernels that share the GPU spread over the XCDs round-robin like these workgroups do.
+  const int xcd = blockIdx.x & 7, per = G8 >> 3;
+  auto id_of = [&](uint32_t word) -> int {
+    const uint32_t k = (word >> (16 * (xcd & 1))) & 0xffffu;
+    return (int)((uint32_t)G8 * (1u + k / (uint32_t)per) + (uint32_t)(xcd * per) + k % (uint32_t)per);  // >= ntiles: queue empty
+  };
+  uint32_t tk_start = 0, tk = 0;
+  // (compiler-visible atomics, not inline asm: an asm result may be copied to another register before it has returned.  The
+  // compiler knows nothing of the asm-issued LDS-DMA pieces, so where it needs the ticket it waits for vmcnt(0) -- both
+  // places of use sit right behind a drain of this wave's queue anyway.  gemm.hip is built with LLVM's atomic optimizer off:
+  // it rewrites a uniform-address atomic into "one lane + readfirstlane" and reads the result at once)
+  auto take_ticket = [&](uint32_t& dst) {
+    if (ticket_lane)
+      dst = __hip_atomic_fetch_add(p.sched + (xcd >> 1), 1u << (16 * (xcd & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto resolve = [&](uint32_t word) -> int {
+    const int id = id_of(word);
+    return id < ntiles ? id : 0x7fffffff;
+  };
+  take_ticket(tk_start);
+  int t_cur = first, t_nxt = dyn ? 0x7fffffff : first + G8;
+  int ic_rel = 0, ic_kt = 0;  // issue cursor: which of (t_cur, t_nxt) it is in, and the slab
+  int issued = 0, consumed = 0;
+  auto issue_next = [&]() {
+    const int ic_tile = ic_rel == 0 ? t_cur : t_nxt;
+    if (ic_rel < 2 && ic_tile < ntiles) {
+      const char *gy, *gx;
+      tile_ptrs(ic_tile, ic_kt, gy, gx);
+      stage_slab<G>(gy, gx, lds0 + (uint32_t)((issued % G::NSTAGE) * G::STAGE), dma_off, wave);
+      ++issued;
+      if (++ic_kt == nk) {
+        ic_kt = 0;
+        ++ic_rel;
+      }
+    }
+  };
+  int cs = 0;  // ROLES: slabs consumed so far by this workgroup (stage = cs & 1)
+  if constexpr (ROLES) {
+    if (t_cur < ntiles) {  // the very first slab: both groups stage their sets, everybody waits
+      const char *gy, *gx;
+      tile_ptrs(t_cur, 0, gy, gx);
+      role_issue(gy, gx, lds0);
+    }
+    wait_vm<0>();
+    __builtin_amdgcn_s_barrier();
+  } else {
+#pragma unroll
+    for (int i = 0; i < G::NSTAGE - 1; ++i) issue_next();
+  }
+  int landed = 0;  // slabs known to have landed already (waited for before the previous epilogue)
+
+#ifdef OSUD_GEMM_TIMING
+  uint64_t tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const uint64_t tk0 = __builtin_readcyclecounter();
+#endif
+#ifdef OSUD_GEMM_EXP
+  if (p.exp_delay > 0 && ((blockIdx.x >> 3) & 1)) {  // experiment: every other workgroup of each XCD starts late (de-phased epilogues)
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < (uint64_t)p.exp_delay) __builtin_amdgcn_s_sleep(8);
+  }
+  const bool exp_nostore = (p.tile_order & 16) != 0, exp_nomath = (p.tile_order & 32) != 0;
+#endif
+  float q_amax = 0.f;  // fp8 training: running max |value| of this lane's share of the e4m3 output
+  bool first_tile = true;
+  while (t_cur < ntiles) {
+    int ty, tx;
+    tm.coords(t_cur, ty, tx);
+    take_ticket(tk);  // for the tile after next
+    f32x16 acc[RY][RX];
+#pragma unroll
+    for (int i = 0; i < RY; ++i)
+#pragma unroll
+      for (int j = 0; j < RX; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint32_t pso;
+    int t_nxt2 = t_nxt + G8;
+    if constexpr (ROLES) {
+      // ---- role-split main loop: two half-periods per slab, a barrier after each.
+      //   H1: group 0 runs the slab's MFMAs | group 1 issues the EARLY set of the NEXT slab (Y top + X) into the other stage
+      //   H2: group 1 runs the slab's MFMAs | group 0 issues the LATE set of the next slab (Y bottom)
+      // A SIMD's matrix pipe is fed by one of its two waves in each half while the other one pays the LDS-DMA issue cost
+      // (~100 cycles per 1 KiB piece, 64 pieces per slab: in lock step that was ~1000 cycles per slab with the pipe idle).
+      // Readiness: what a group computes on in its half was issued at least one half-period earlier by the OTHER group, which
+      // waits for its own pieces (vmcnt(0)) at the end of its computing half, just before the barrier -- no wave ever waits
+      // for a piece it has only just issued.  Two 64 KiB stages as before.
+      for (int kt = 0; kt < nk; ++kt) {
+        const bool last = kt + 1 == nk;
+        const int n_tile = last ? t_nxt : t_cur, n_kt = last ? 0 : kt + 1;
+        const bool has_next = n_tile < ntiles;
+        const char *gy = nullptr, *gx = nullptr;
+        if (has_next) tile_ptrs(n_tile, n_kt, gy, gx);
+        const uint32_t so = (uint32_t)((cs & 1) * G::STAGE), so_next = lds0 + (uint32_t)(((cs + 1) & 1) * G::STAGE);
+        if (grp == 0) {
+          compute_slab<TE, RY, RX>(acc, ya, xa, so);
+          wait_vm<0>();  // its LATE pieces of this slab's successor... issued in the previous H2: landed before group 1 reads them
+        } else if (has_next) {
+          role_issue(gy, gx, so_next);
+        }
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) {
+          compute_slab<TE, RY, RX>(acc, ya, xa, so);
+          wait_vm<0>();  // the EARLY pieces issued in H1: landed before group 0 reads them in the next H1
+        } else if (has_next) {
+          role_issue(gy, gx, so_next);
+        }
+        __builtin_amdgcn_s_barrier();
+        ++cs;
+      }
+      pso = (uint32_t)(((cs - 1) & 1) * G::STAGE);  // the stage consumed last: free, becomes the epilogue patch area
+    } else {
+    for (int kt = 0; kt < nk; ++kt) {
+#ifdef OSUD_GEMM_TIMING
+      const uint64_t tt0 = __builtin_readcyclecounter();
+#endif
+      // slab `consumed` must have landed; up to NSTAGE-2 later slabs may stay in flight (loads return in order)
+      // (stores of an epilogue may sit in the queue too; they only make the counted wait conservative)
+      const int ahead = issued - consumed - 1;
+      if (landed > 0) --landed;
+      else if (ahead <= 0 || G::NSTAGE == 2) wait_vm<0>();
+      else if (ahead == 1) wait_vm<G::PPW>();
+      else {
+        if constexpr (SB == 64 && G::NSTAGE >= 5) {
+          if (ahead == 2) wait_vm<2 * G::PPW>();
+          else wait_vm<3 * G::PPW>();
+        } else {
+          wait_vm<(G::NSTAGE > 3 ? 2 * G::PPW : 0)>();
+        }
+      }
+#ifdef OSUD_GEMM_TIMING
+      const uint64_t tt1 = __builtin_readcyclecounter();
+#endif
+      if (dyn && first_tile && kt == 0) {  // the second tile's ticket (older than every piece waited for above)
+        if (ticket_lane) sched_lds[1] = (uint32_t)resolve(tk_start);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();  // every wave's share landed; the stage consumed last round is free again
+      if (dyn && first_tile && kt == 0) t_nxt = __builtin_amdgcn_readfirstlane((int)sched_lds[1]);
+#ifdef OSUD_GEMM_TIMING
+      const uint64_t tt2 = __builtin_readcyclecounter();
+#endif
+      // (Measured with -DOSUD_GEMM_TIMING, ticks calibrated at 1.67 per ns = the clock the chip holds under this load: a slab
+      // costs ~2900 cycles against 2 x 1024 cycles of MFMA issue per SIMD (71 % pipe utilisation); the rest is the barrier,
+      // the LDS-DMA issue (~90-160 cycles per 1 KiB piece) and the first fragment reads.  Not L2/HBM -- all workgroups
+      // streaming the SAME panels run no faster -- and not LDS bandwidth either: with the X operand neither staged nor read
+      // (half the DMA, 2/3 of the reads; timing experiment) the slab only drops to ~2700.  Issuing half the waves' pieces mid-slab instead of here changes nothing; touching the
+      // lines of the slab 2-4 ahead with one plain load per wave (L2 warm-up) costs 4-7 % end to end.)
+      issue_next();
+#ifdef OSUD_GEMM_TIMING
+      const uint64_t tt3 = __builtin_readcyclecounter();
+#endif
+      compute_slab<TE, RY, RX, SB>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
+#ifdef OSUD_GEMM_TIMING
+      {
+        const uint64_t tt4 = __builtin_readcyclecounter();
+        tsum[0] += tt1 - tt0; tsum[1] += tt2 - tt1; tsum[2] += tt3 - tt2; tsum[3] += tt4 - tt3; tsum[4] += 1;
+      }
+#endif
+      ++consumed;
+    }
+    // The next tile's first slabs are already in flight: make sure they landed NOW, while no store is
+    // queued behind them, so the next tile can start right after the epilogue without draining its stores.
+#ifdef OSUD_GEMM_TIMING
+    const uint64_t te0 = __builtin_readcyclecounter();
+#endif
+    wait_vm<0>();
+    landed = issued - consumed;
+    if (dyn) {  // the ticket requested at the top of this tile has returned: publish it across the epilogue barrier
+      if (ticket_lane) sched_lds[0] = (uint32_t)resolve(tk);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    // The stage consumed last holds nothing the next tile needs (its prefetch sits in the other stages): it becomes
+    // the epilogue patch area, once every wave has finished reading the last slab from it.  The barrier at the top
+    // of the next tile's first slab orders the patch reads before the LDS-DMA that refills the stage.
+#ifdef OSUD_GEMM_TIMING
+    const uint64_t te1 = __builtin_readcyclecounter();
+#endif
+    __builtin_amdgcn_s_barrier();
+    if (dyn) t_nxt2 = __builtin_amdgcn_readfirstlane((int)sched_lds[0]);
+#ifdef OSUD_GEMM_TIMING
+    const uint64_t te2 = __builtin_readcyclecounter();
+    tsum[6] += te1 - te0;  // drain wait before the epilogue
+    tsum[7] += te2 - te1;  // epilogue barrier
+#endif
+    pso = G::PATCH_OUT ? 0u : (uint32_t)(((consumed + G::NSTAGE - 1) % G::NSTAGE) * G::STAGE);
+    }
+
+
+    // ---- epilogue -------------------------------------------------------------------------------
+    // The MFMA leaves lane (frow, fhalf) with y = frow and x = 8g + 4*fhalf + {0..3}: stored as is, one store
+    // instruction touches 32 rows with 8..32 bytes each and the epilogue is bound by the L2 REQUEST rate
+    // (measured: ~9 us per 256x256 tile, a third of the kernel).  So every 32x32 block takes a round trip
+    // through a wave-private 4 KiB LDS patch (16-byte slot index XOR-swizzled with row&7, conflict free both
+    // ways) and comes back row-major: lane l holds rows (l>>2) and 16 + (l>>2) and x = 8*(l&3) + {0..7} -- 4 lanes
+    // cover one 128-byte (f32) / 64-byte (bf16) row segment with 16-byte (bf16) / 2 x 16-byte (f32) stores per lane, which
+    // halves the number of store instructions of a bf16 output (the TA spends ~16 cycles per vector-memory instruction
+    // whatever its width); the operand loads (residual, saved pre-activation) are coalesced the same way.
+    // All loads of a block are issued BEFORE its stores: vmcnt counts stores too, so a load waited for
+    // between stores would drain every earlier store.
+    constexpr bool kBias = EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_TE || EPI == EPI_BIAS_SILU_TE ||
+                           kGelu || EPI == EPI_GATE_RES;
+    const int lrow = lane >> 2, lcol = 8 * (lane & 3);
+    const int xw = tx * BN + wx * RX * 32 + lcol;  // + j*32
+    float csv[RX][8];
+    if (kF8) {
+#pragma unroll
+      for (int j = 0; j < RX; ++j) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csv[j][e] = 1.0f;
+        if (p.colscale != nullptr) load8(p.colscale + xw + j * 32, csv[j]);
+        if (p.act_inv != nullptr || p.act_inv_host != 0.f) {  // the activation's de-quantisation factor: static (host) or dynamic
+          const float ai = (p.act_inv != nullptr ? *p.act_inv : 1.0f) * (p.act_inv_host != 0.f ? p.act_inv_host : 1.0f);  // (device: fp8 training)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) csv[j][e] *= ai;
+        }
+      }
+    }
+    float bv[RX][8];
+    if (kBias) {
+#pragma unroll
+      for (int j = 0; j < RX; ++j) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + xw + j * 32);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + xw + j * 32 + 4);
+        bv[j][0] = b0.x; bv[j][1] = b0.y; bv[j][2] = b0.z; bv[j][3] = b0.w;
+        bv[j][4] = b1.x; bv[j][5] = b1.y; bv[j][6] = b1.z; bv[j][7] = b1.w;
+      }
+    }
+    // The blocks are software-pipelined: block b+1 enters the patch (4 writes + 4 reads) before block b is finished, so
+    // the LDS round trip hides under block b's arithmetic and stores.  One wave's LDS operations execute in order: the
+    // reads of b are done once at most the 8 newer operations are outstanding, and the writes of b+1 cannot overtake them.
+    constexpr int NB = RY * RX;
+    auto patch_trip = [&](int b, f32x4 (&t)[4]) {
+      const int i = b / RX, j = b % RX;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+        v[0] = acc[i][j][4 * g + 0]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
+        ds_write16(pw[g] + pso, v);
+      }
+      t[0] = ds_read16f<0>(pr0 + pso);      // rows 0..15 : x 0..3 | 4..7 of this lane's 8
+      t[1] = ds_read16f<0>(pr1 + pso);
+      t[2] = ds_read16f<2048>(pr0 + pso);   // rows 16..31
+      t[3] = ds_read16f<2048>(pr1 + pso);
+    };
+    // fp8 training: the e4m3 twin of a bf16 output (the operand of the NEXT fp8 GEMM) written here instead of by a separate pass
+    constexpr bool kOut8 = kF8 && (EPI == EPI_BIAS_GELU_BF || EPI == EPI_GELUGRAD_TE);
+    const bool out8_on = kOut8 && p.out8 != nullptr;
+    const float q_scale = out8_on ? p.out8_slot[0] : 1.0f;
+    constexpr bool kColsum = EPI == EPI_GELUGRAD_TE;
+    float cs[kColsum ? RX : 1][8];
+    if (kColsum) {
+#pragma unroll
+      for (int j = 0; j < RX; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[j][e] = 0.f;
+    }
+    f32x4 tq[2][4];
+    patch_trip(0, tq[0]);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int i = b / RX, j = b % RX;
+      const int yb = ty * G::BM + wy * RY * 32 + i * 32;  // wave-uniform first row of the block
+      const int y0 = yb + lrow;                           // + 16q
+      int sample = 0;
+      if (EPI == EPI_GATE_RES) {  // rows_per_sample % 32 == 0: one sample per 32-row block
+        sample = __builtin_amdgcn_readfirstlane(yb) / p.rows_per_sample;
+        if (sample >= p.n_samples) sample = p.n_samples - 1;  // padding rows
+      }
+      f32x4 (&t)[4] = tq[b & 1];
+      const int x = xw + j * 32;
+      float gv[8], rv[2][8];
+      float rb[2];
+      if (EPI == EPI_GATE_RES) {
+        const float* rsrc = p.res ? p.res : reinterpret_cast<const float*>(p.out);
+        load8(p.gate + (size_t)sample * p.ld_gate + x, gv);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) load8(rsrc + (size_t)(y0 + 16 * q) * p.ldo + x, rv[q]);
+      }
+      if (EPI == EPI_ACCUM_F32) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) load8(reinterpret_cast<const float*>(p.out) + (size_t)(y0 + 16 * q) * p.ldo + x, rv[q]);
+      }
+      if (EPI == EPI_GELUGRAD_TE) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) load8(reinterpret_cast<const TO*>(p.aux) + (size_t)(y0 + 16 * q) * p.ldo + x, rv[q]);
+      }
+      if (EPI == EPI_ROWBIAS_TE) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) rb[q] = p.bias[y0 + 16 * q];
+      }
+      if (b + 1 < NB) {
+        patch_trip(b + 1, tq[(b + 1) & 1]);
+        OSUD_LGKM_WAIT(8);
+      } else {
+        OSUD_LGKM_WAIT(0);
+      }
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        float v[8], w[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[e] = t[2 * q][e];
+          v[4 + e] = t[2 * q + 1][e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (kF8) v[e] *= csv[j][e];
+          if (kBias) v[e] += bv[j][e];
+          if (EPI == EPI_ROWBIAS_TE) v[e] += rb[q];
+        }
+        const size_t orow = (size_t)(y0 + 16 * q);
+        const size_t o = orow * p.ldo + x;  // (fp32 outputs and the single-plane TE forms)
+#ifdef OSUD_GEMM_EXP
+        if (exp_nostore || exp_nomath) {  // timing experiments: (16) the epilogue's arithmetic without its stores, (32) its stores without the arithmetic
+          if (exp_nomath) {
+            store8(reinterpret_cast<TO*>(p.out) + o, v);
+            if (kGelu && p.out2) store8(reinterpret_cast<TO*>(p.out2) + o, v);
+          } else {
+            float dg[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gelu_tanh_both_t<FAST>(v[e], w[e], dg[e]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(w[e]), "v"(dg[e]));
+          }
+          continue;
+        }
+#endif
+        if (EPI == EPI_NONE_F32 && p.seg_rows > 0) {  // (a 32-row block never straddles two segments: seg_rows % 32 == 0)
+          const int sg = __builtin_amdgcn_readfirstlane(yb / p.seg_rows);
+          store8(p.seg_out[sg] + (size_t)(y0 + 16 * q - sg * p.seg_rows) * p.ldo + x, v);
+        } else if (EPI == EPI_BIAS_F32 || EPI == EPI_NONE_F32) {
+          store8(reinterpret_cast<float*>(p.out) + o, v);
+        } else if (EPI == EPI_ACCUM_F32) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = rv[q][e] + v[e];
+          store8(reinterpret_cast<float*>(p.out) + o, w);
+        } else if (EPI == EPI_GATE_RES) {
+          if (p.out2) store8_out<TO>(p.out2, orow, p.ldo, x, v);  // branch output (training)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = rv[q][e] + gv[e] * v[e];
+          store8(reinterpret_cast<float*>(p.out) + o, w);
+        } else if (EPI == EPI_BIAS_SILU_TE) {
+          if (p.out2) store8_out<TO>(p.out2, orow, p.ldo, x, v);  // pre-activation (training)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = silu_t<FAST>(v[e]);
+          store8_out<TO>(p.out, orow, p.ldo, x, w);
+        } else if (kGelu) {
+          if (p.out2) {  // training: the DERIVATIVE goes out (same exp/rcp as the value), so that the backward epilogue
+                         // is a plain multiply instead of two more quarter-rate transcendentals per element
+            float dg[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gelu_tanh_both_t<FAST>(v[e], w[e], dg[e]);
+            store8_out<TO>(p.out2, orow, p.ldo, x, dg);
+            if constexpr (kOut8) {
+              if (out8_on) {
+                float q8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                  q_amax = fmaxf(q_amax, fabsf(w[e]));
+                  q8[e] = w[e] * q_scale;
+                }
+                store8(reinterpret_cast<fp8_t*>(p.out8) + o, q8);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = gelu_tanh_t<FAST>(v[e]) * ((kF8 && EPI == EPI_BIAS_GELU_TE) ? p.out_scale : 1.0f);
+          }
+          store8_out<TO>(p.out, orow, p.ldo, x, w);
+        } else if (EPI == EPI_GELUGRAD_TE) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = v[e] * rv[q][e];
+          if constexpr (kOut8) {
+            if (out8_on) {
+              float q8[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                q_amax = fmaxf(q_amax, fabsf(w[e]));
+                q8[e] = w[e] * q_scale;
+              }
+              store8(reinterpret_cast<fp8_t*>(p.out8) + o, q8);
+            }
+          }
+          if (kColsum) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) cs[j][e] += w[e];
+          }
+          store8(reinterpret_cast<TO*>(p.out) + o, w);
+        } else {  // EPI_BIAS_TE, EPI_ROWBIAS_TE, EPI_NONE_TE
+          store8_out<TO>(p.out, orow, p.ldo, x, v);
+        }
+      }
+    }
+    if (kColsum && p.colpart != nullptr) {
+      // bias gradient riding along: this wave's RY*32 rows are summed per column -- over the lane's own rows above, over
+      // the 16 lane-rows here (fixed butterfly: deterministic) -- and stored as one row of partial sums
+#pragma unroll
+      for (int j = 0; j < RX; ++j) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float v = cs[j][e];
+          v += __shfl_xor(v, 4, 64);
+          v += __shfl_xor(v, 8, 64);
+          v += __shfl_xor(v, 16, 64);
+          v += __shfl_xor(v, 32, 64);
+          cs[j][e] = v;
+        }
+        if (lane < 4) store8(p.colpart + (size_t)(ty * WY + wy) * p.Nx + xw + j * 32, cs[j]);
+      }
+    }
+#ifdef OSUD_GEMM_TIMING
+    tsum[5] += __builtin_readcyclecounter() - te0;  // epilogue (incl. the drain wait and barrier)
+#endif
+    if constexpr (ROLES) {  // every wave's patch reads done before the next H1 refills that stage by LDS-DMA
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    t_cur = t_nxt;
+    t_nxt = t_nxt2;
+    if (ic_rel > 0) --ic_rel;
+    first_tile = false;
+  }  // tile loop
+  if (p.out8 != nullptr && p.out8_slot != nullptr) {  // one amax atomic per workgroup (through LDS: the ring is idle by now)
+    q_amax = wave_max(q_amax);
+    __syncthreads();
+    volatile float* red = reinterpret_cast<volatile float*>(smem);
+    if (lane == 0) red[wave] = q_amax;
+    __syncthreads();
+    if (tid == 0) {
+      float mx = 0.f;
+      for (int w2 = 0; w2 < G::NW; ++w2) mx = fmaxf(mx, red[w2]);
+      if (mx > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.out8_slot) + 2, __float_as_uint(mx));
+    }
+  }
+  if (ticket_lane) {  // the last workgroup out re-arms the counters for the next launch that borrows this slot
+    const unsigned done = __hip_atomic_fetch_add(p.sched + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x - 1) {
+#pragma unroll
+      for (int y = 0; y < 9; ++y) __hip_atomic_store(p.sched + y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+#ifdef OSUD_GEMM_TIMING
+  if (p.gate != nullptr && lane == 0 && blockIdx.x < 16) {
+    float* dbg = const_cast<float*>(p.gate) + (blockIdx.x * G::NW + wave) * 8;
+    for (int i = 0; i < 6; ++i) dbg[i] = (float)tsum[i];
+    dbg[6] = (float)tsum[6];
+    dbg[7] = (float)(__builtin_readcyclecounter() - tk0);  // whole kernel, in the same ticks (calibrates ticks per ns)
+  }
+#endif
+}
+
+template <typename TE, int EPI, int WY, int WX, int RY, int RX, int SB = SLAB> int launch_w(const GemmP& p_in, hipStream_t st) {
+  using G = Geo<WY, WX, RY, RX, SB>;
+  GemmP p = p_in;
+  const size_t ring = (size_t)G::NSTAGE * G::STAGE;  // stage ring (the epilogue patches borrow the free stage)
+  constexpr bool kDynFits = G::NSTAGE * G::STAGE + (G::PATCH_OUT ? G::NW * 4096 : 0) + 64 <= G::LDS_MAX;
+  const size_t lds = ring + (G::PATCH_OUT ? (size_t)G::NW * 4096 : 0) + (kDynFits ? 64 : 0);
+  // the role-split main loop: 8-wave geometries with two stages (the 64 KiB-per-stage tiles), piece sets divisible by 4 waves
+  constexpr bool kRolesOk = SB == SLAB && G::NW == 8 && G::NSTAGE == 2 && (G::BM / 16 + G::BN / 8) % 4 == 0 && (G::BM / 16) % 4 == 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX, false, SB>),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if constexpr (kRolesOk)
+      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX, true, SB>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  if (p.colpart_rows != nullptr) *p.colpart_rows = p.My / (RY * 32);
+  const int ntiles = (p.My / G::BM) * (p.Nx / G::BN), splits = p.split_k > 1 ? p.split_k : 1;
+  int grid = gemm_num_cus() * G::WGS / splits;  // persistent workgroups: WGS per CU (LDS-limited), shared by the K splits
+  if (grid < 1) grid = 1;
+  if (grid > ntiles) grid = ntiles;
+  {
+    const bool dyn_on = gemm_dynamic_tiles_wanted();
+    const int nk = (int)((size_t)p.K * sizeof(TE) / SB);
+    p.sched = (dyn_on && kDynFits && splits == 1 && ntiles > grid && grid % 8 == 0 && nk >= G::NSTAGE && ntiles / 8 + 2 * grid < 60000) ? gemm_sched_slot() : nullptr;
+  }
+  // OSUD_GEMM_ROLES=1 selects the role-split main loop.  Built, bit-identical results, and measured EQUAL to the lock-step loop
+  // within run-to-run noise on every shape (fc1 168.7 vs 170.6 us, 4096^3 1179 vs 1169 TFLOP/s, training step 28.3 vs 28.2 ms):
+  // two schedules this different landing on the same throughput says the main loop is not issue-bound but clock-bound -- the chip
+  // trades any saved cycle against frequency under this MFMA + LDS load.  The lock-step loop stays the default.
+  static const bool roles_env = [] { const char* e = getenv("OSUD_GEMM_ROLES"); return e && e[0] == '1'; }();
+  if constexpr (kRolesOk) {
+    if (roles_env && p.sched == nullptr) {  // (the tile queues of shared-GPU mode keep the lock-step loop)
+      hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY, RX, true, SB>), dim3(grid, splits), dim3(G::NT), lds, st, p);
+      OSUD_HIP(hipGetLastError());
+      return OSUD_OK;
+    }
+  }
+  hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY, RX, false, SB>), dim3(grid, splits), dim3(G::NT), lds, st, p);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+// Tile choice.  Geometries (all 8 waves = 2 per SIMD, except the 128x128 fallback):
+//   256x256: 2x4 waves of 128x64   least LDS traffic per MFMA; needs Nx % 256 == 0
+//   256x192: 4x2 waves of 64x96    for Nx = 768-like widths (3 x 256 would leave 1.5 rounds of tiles)
+//   192x256: 2x4 waves of 96x64    the same for My = 768-like heights (V^T projection, weight gradients)
+//   128x128: 2x2 waves of 64x64    small problems
+//    64x128: 2x2 waves of 32x64    problems with fewer 128x128 tiles than 3/4 of the CUs
+// Pick by the fraction of CU-rounds doing useful work, preferring the larger tile on ties.
+template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
+  const int cus = gemm_num_cus(), splits = p.split_k > 1 ? p.split_k : 1;
+  auto eff = [&](int bm, int bn) -> double {
+    if (p.My % bm || p.Nx % bn) return 0.0;
+    const long tiles = (long)(p.My / bm) * (p.Nx / bn) * splits;
+    const long rounds = (tiles + cus - 1) / cus;
+    return (double)tiles / (double)(rounds * cus);
+  };
+  const double e[4] = {eff(128, 128), eff(256, 192), eff(256, 256), eff(192, 256)};
+  int pick = 0;
+  if (e[1] > 0 && e[1] + 0.05 >= e[0]) pick = 1;
+  if (e[3] > 0 && e[3] + 0.05 >= e[pick] && pick == 0) pick = 3;
+  if (e[2] > 0 && e[2] + 0.05 >= e[pick]) pick = 2;
+  // few tiles (one beatmap, few variants: M ~ 2-4 K tokens): halve the tile height to double the workgroups in flight
+  {
+    static const int thr = [] { const char* e = getenv("OSUD_GEMM_SMALL_PCT"); return e ? atoi(e) : 75; }();
+    if (pick == 0 && (long)(p.My / 128) * (p.Nx / 128) * splits * 100 < (long)cus * thr) pick = 6;
+  }
+  // one row of 128-row tiles and a wide output (the adaLN product of a sampling step: 128 x 56 832 x 768 streams 87 MB of weights):
+  // 128x256 tiles make it one round instead of 1.7 (28.1 -> 23.9 us)
+  if (pick == 0 && p.My == 128 && p.Nx % 256 == 0 && splits == 1 && (long)(p.Nx / 128) > cus) pick = 8;
+  if (const char* force = getenv("OSUD_GEMM_TILE")) {  // "64" | "128" | "192" | "256": tuning / A-B runs
+    const std::string f(force);
+    if (f == "128") pick = 0;
+    else if (f == "64") pick = 6;
+    else if (f == "192" && e[1] > 0) pick = 1;
+    else if (f == "256" && e[2] > 0) pick = 2;
+    else if (f == "192y" && e[3] > 0) pick = 3;
+    else if (f == "256x128" && p.My % 256 == 0) pick = 7;  // experiment: three 48 KiB stages instead of two 64 KiB ones
+    else if (f == "128x256" && p.Nx % 256 == 0) pick = 8;
+  }
+  {  // half slabs + deeper ring for the 256x256 geometry (OSUD_GEMM_SLAB=128 selects the two-stage form for A/B runs)
+    static const bool half_slabs = [] { const char* e = getenv("OSUD_GEMM_SLAB"); return e && atoi(e) == 64; }();
+    if (pick == 2 && half_slabs) return launch_w<TE, EPI, 2, 4, 4, 2, 64>(p, st);
+  }
+  if (pick == 2) return launch_w<TE, EPI, 2, 4, 4, 2>(p, st);
+  if (pick == 1) return launch_w<TE, EPI, 4, 2, 2, 3>(p, st);
+  if (pick == 3) return launch_w<TE, EPI, 2, 4, 3, 2>(p, st);
+  if (pick == 6) return launch_w<TE, EPI, 2, 2, 1, 2>(p, st);
+  if (pick == 7) return launch_w<TE, EPI, 4, 2, 2, 2>(p, st);
+  if (pick == 8) return launch_w<TE, EPI, 2, 4, 2, 2>(p, st);
+  return launch_w<TE, EPI, 2, 2, 2, 2>(p, st);
+}
+
+
+}  // namespace
+}  // namespace osud

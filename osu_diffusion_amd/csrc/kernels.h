@@ -36,6 +36,8 @@ int launch_cfg_combine(float* out, int N, int C, int C2, int T, float s, hipStre
 int launch_convert(int prec, const float* src, void* dst, size_t n, hipStream_t st);
 int launch_pack_rows(int prec, const float* src, int ld_src, int cols_src, void* dst, int ld_dst, int cols_dst, int rows,
                      hipStream_t st);
+// split-bf16 tier: dst [rows][2 * cols_dst] = [w_hi | w_lo] (zero padded to cols_dst per plane)
+int launch_pack_rows_x3(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, hipStream_t st);
 // first linear of the bf16 tier: dst [rows][3 * cols_dst] = [w_hi | w_hi | w_lo]
 int launch_pack_rows_split(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, hipStream_t st);
 // qkv: packed in_proj output [Mp][ld_qkv], Q | K | V in columns [0,D) [D,2D) [2D,3D)

@@ -3,6 +3,8 @@
 //
 // Activation row layout: row m = n * Tp + t, Tp = tokens per sample rounded up to 64, rows
 // with t >= T (and rows >= N*Tp up to Mp) are padding: finite, never read back by the caller.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace osud {
@@ -22,7 +24,9 @@ namespace {
 // bf16_error_budget.py: as much as all 48 trunk GEMMs of DiT-S together).  The row is therefore written as
 // [hi | lo | hi] (3 x Kp columns, hi = bf16(v), lo = bf16(v - hi)) against weights packed as [w_hi | w_hi | w_lo]: one bf16
 // GEMM with K = 3 Kp computes hi*w_hi + lo*w_hi + hi*w_lo, i.e. the fp32 product to ~2^-17 relative.
-template <typename TE, bool SPLIT>
+// SPLIT = 2 (split-bf16 tier): the row is the tier's plane pair [hi | lo] (2 x Kp columns) against weights packed [w_hi | w_lo]; the
+// GEMM forms the three products itself (gemm_kernel.h).
+template <typename TE, int SPLIT>
 __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x, const float* __restrict__ o,
                                                     const float* __restrict__ c, const float* __restrict__ freqs64,
                                                     float pf0, float pf1, TE* __restrict__ out, int N, int T, int Tp,
@@ -32,7 +36,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x,
   // of the 256 coordinate features only, Kp = 256, E = 0: 40 % of the columns and of the sincos work per step)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int TOK = 16;
-  const int ldr = SPLIT ? 3 * Kp : Kp;       // row length in elements
+  const int ldr = SPLIT == 1 ? 3 * Kp : (SPLIT == 2 ? 2 * Kp : Kp);  // row length in elements
   TE* tile = reinterpret_cast<TE*>(smem_raw);  // [TOK][ldr]
   const int tid = threadIdx.x;
   const int m0 = blockIdx.x * TOK;
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ x,
     if (SPLIT) {
       const float hi = load_elem(r + col);
       store_elem(r + Kp + col, v - hi);
-      r[2 * Kp + col] = r[col];
+      if (SPLIT == 1) r[2 * Kp + col] = r[col];
     }
   };
   const int nx = (x_dup_half > 0 && n >= x_dup_half) ? n - x_dup_half : n;  // forward_with_cfg: cat([half, half])
@@ -95,8 +99,14 @@ __global__ void temb_kernel(const int64_t* __restrict__ t, const float* __restri
   const int n = blockIdx.x, k = threadIdx.x;  // 128 threads
   float cs = 0.f, sn = 0.f;
   if (n < N) sincosf((float)t[n] * freqs128[k], &sn, &cs);
+  if constexpr (std::is_same<TE, x3_t>::value) {
+    bf16_t* row = reinterpret_cast<bf16_t*>(out) + (size_t)n * 512;
+    store_elem_x3(row + k, 256, cs);
+    store_elem_x3(row + 128 + k, 256, sn);
+  } else {
   store_elem(out + (size_t)n * 256 + k, cs);
   store_elem(out + (size_t)n * 256 + 128 + k, sn);
+  }
 }
 
 // b = t_emb + table[y]; keep b (fp32, for backward) and silu(b) (TE, operand of every adaLN GEMM).
@@ -105,12 +115,17 @@ __global__ void cond_kernel(const float* __restrict__ tvec, const float* __restr
                             const int64_t* __restrict__ y, int table_rows, float* __restrict__ b_out,
                             TE* __restrict__ sb_out, int N, int D, const int64_t* __restrict__ t_index) {
   // t_index != nullptr (sampler loops): tvec is a table with one row per schedule index, made once per loop; row n reads its step's
-  constexpr bool FAST = sizeof(TE) == 2;
+  constexpr bool kX3 = std::is_same<TE, x3_t>::value;
+  constexpr bool FAST = sizeof(TE) == 2 && !kX3;
   const int n = blockIdx.x;
+  auto put_sb = [&](int d, float v) {
+    if constexpr (kX3) store_elem_x3(reinterpret_cast<bf16_t*>(sb_out) + (size_t)n * 2 * D + d, (size_t)D, v);
+    else store_elem(sb_out + (size_t)n * D + d, v);
+  };
   if (n >= N) {
     for (int d = threadIdx.x; d < D; d += blockDim.x) {
       b_out[(size_t)n * D + d] = 0.f;
-      store_elem(sb_out + (size_t)n * D + d, 0.f);
+      put_sb(d, 0.f);
     }
     return;
   }
@@ -120,7 +135,7 @@ __global__ void cond_kernel(const float* __restrict__ tvec, const float* __restr
   for (int d = threadIdx.x; d < D; d += blockDim.x) {
     const float b = trow[d] + table[(size_t)cls * D + d];  // models.py:320
     b_out[(size_t)n * D + d] = b;
-    store_elem(sb_out + (size_t)n * D + d, silu_t<FAST>(b));
+    put_sb(d, silu_t<FAST>(b));
   }
 }
 
@@ -187,7 +202,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* h, const float
   }
   const float* sh = ada + (size_t)n * ld_ada + off_shift;
   const float* sc = ada + (size_t)n * ld_ada + off_scale;
-  TE* orow = out + (size_t)m * D;
+  TE* orow = out + (size_t)m * D * Planes<TE>::k;
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
     const int d = W * lane + 64 * W * g;
@@ -199,7 +214,8 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* h, const float
       r[e] = (v[g * W + e] - mu) * rstd * (1.0f + s4[e]) + h4[e];
       if (sizeof(TE) == 1) r[e] *= out_scale;  // fp8 operand of the next GEMM, statically scaled
     }
-    storew<W>(orow + d, r);
+    if constexpr (std::is_same<TE, x3_t>::value) storew_x3<W>(reinterpret_cast<bf16_t*>(orow) + d, (size_t)D, r);
+    else storew<W>(orow + d, r);
     if constexpr (TWIN) {
       float q[W];
 #pragma unroll
@@ -361,6 +377,16 @@ __global__ void pack_rows_split_kernel(const float* __restrict__ src, int ld_src
   }
 }
 
+// split-bf16 tier: dst row = [w_hi | w_lo], each plane cols_dst wide (zero padded)
+__global__ void pack_rows_x3_kernel(const float* __restrict__ src, int ld_src, int cols_src, bf16_t* __restrict__ dst,
+                                    int cols_dst, int rows) {
+  const size_t total = (size_t)rows * cols_dst;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / cols_dst), cc = (int)(i % cols_dst);
+    store_elem_x3(dst + (size_t)r * 2 * cols_dst + cc, (size_t)cols_dst, cc < cols_src ? src[(size_t)r * ld_src + cc] : 0.f);
+  }
+}
+
 // fp8 tier: one weight row (output channel) per block -> e4m3 with the row's own scale 448 / max|w|;
 // dequant[x] = max|w_x| / (448 * act_scale) is what the GEMM epilogue multiplies the accumulator with
 __global__ __launch_bounds__(256) void quantize_rows_kernel(const float* __restrict__ w, int cols, fp8_t* __restrict__ q,
@@ -480,10 +506,10 @@ int launch_f8_update(float* slots, int n_slots, hipStream_t st, float* parts) {
 }
 
 // ---------------------------------------------------------------------------------- launchers
-template <typename TE, bool SPLIT>
+template <typename TE, int SPLIT>
 static int embed_t(const float* x, const float* o, const float* c, const float* freqs64, float pf0, float pf1, void* out,
                    int N, int T, int Tp, int Mp, int E, int Kp, int x_dup_half, hipStream_t st, int mode) {
-  const size_t lds = (size_t)16 * Kp * sizeof(TE) * (SPLIT ? 3 : 1);
+  const size_t lds = (size_t)16 * Kp * sizeof(TE) * (SPLIT == 1 ? 3 : (SPLIT == 2 ? 2 : 1));
   hipLaunchKernelGGL((embed_kernel<TE, SPLIT>), dim3(Mp / 16), dim3(256), lds, st, x, o, c, freqs64, pf0, pf1, (TE*)out, N, T,
                      Tp, E, Kp, x_dup_half, mode);
   OSUD_HIP(hipGetLastError());
@@ -491,17 +517,31 @@ static int embed_t(const float* x, const float* o, const float* c, const float* 
 }
 int launch_embed(int prec, const float* x, const float* o, const float* c, const float* freqs64, float pf0, float pf1,
                  void* out, int N, int T, int Tp, int Mp, int E, int Kp, int x_dup_half, hipStream_t st, bool split, int mode) {
-  if (mode == 1) {  // coordinate features only: a compact row of 256 (x 3 in the split form) columns
-    OSUD_CHECK_ARG(split && prec == OSUD_PREC_BF16, "embed: the coordinate-only row exists in the split bf16 form");
+  const bool x3 = prec == OSUD_PREC_BF16X3;
+  if (mode == 1) {  // coordinate features only: a compact row of 256 (x 3 in the split form, x 2 planes in the split-bf16 tier) columns
+    OSUD_CHECK_ARG(x3 || (split && prec == OSUD_PREC_BF16), "embed: the coordinate-only row exists in the split forms");
     E = 0;
     Kp = 256;
   }
   OSUD_CHECK_ARG(Tp % 16 == 0 && Mp % 16 == 0 && Kp >= (mode == 1 ? 256 : 384 + E) && (Kp * elem_size(prec)) % 16 == 0, "embed: bad sizes");
+  if (x3) {
+    OSUD_CHECK_ARG((size_t)16 * Kp * 4 <= 64 * 1024, "embed: a plane-pair row of %d columns does not fit the 64 KiB LDS tile (context too wide)", Kp);
+    return embed_t<bf16_t, 2>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode);
+  }
   OSUD_CHECK_ARG(!split || prec == OSUD_PREC_BF16, "embed: the split row form is bf16 only");
   OSUD_CHECK_ARG(!split || (size_t)16 * Kp * 6 <= 64 * 1024, "embed: a split row of %d columns does not fit the 64 KiB LDS tile (context too wide)", Kp);
-  if (split) return embed_t<bf16_t, true>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode);
-  return prec == OSUD_PREC_BF16 ? embed_t<bf16_t, false>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode)
-                                : embed_t<float, false>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode);
+  if (split) return embed_t<bf16_t, 1>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode);
+  return prec == OSUD_PREC_BF16 ? embed_t<bf16_t, 0>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode)
+                                : embed_t<float, 0>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode);
+}
+
+int launch_pack_rows_x3(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, hipStream_t st) {
+  const size_t total = (size_t)rows * cols_dst;
+  if (total == 0) return OSUD_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  hipLaunchKernelGGL(pack_rows_x3_kernel, dim3(grid), dim3(256), 0, st, src, ld_src, cols_src, (bf16_t*)dst, cols_dst, rows);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
 }
 
 int launch_pack_rows_split(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, hipStream_t st) {
@@ -516,6 +556,8 @@ int launch_pack_rows_split(const float* src, int ld_src, int cols_src, void* dst
 int launch_temb(int prec, const int64_t* t, const float* freqs128, void* out, int N, int Np, hipStream_t st) {
   if (prec == OSUD_PREC_BF16)
     hipLaunchKernelGGL((temb_kernel<bf16_t>), dim3(Np), dim3(128), 0, st, t, freqs128, (bf16_t*)out, N);
+  else if (prec == OSUD_PREC_BF16X3)
+    hipLaunchKernelGGL((temb_kernel<x3_t>), dim3(Np), dim3(128), 0, st, t, freqs128, (x3_t*)out, N);
   else
     hipLaunchKernelGGL((temb_kernel<float>), dim3(Np), dim3(128), 0, st, t, freqs128, (float*)out, N);
   OSUD_HIP(hipGetLastError());
@@ -527,6 +569,9 @@ int launch_cond(int prec, const float* tvec, const float* table, const int64_t* 
   if (prec == OSUD_PREC_BF16)
     hipLaunchKernelGGL((cond_kernel<bf16_t>), dim3(Np), dim3(256), 0, st, tvec, table, y, table_rows, b_out,
                        (bf16_t*)sb_out, N, D, t_index);
+  else if (prec == OSUD_PREC_BF16X3)
+    hipLaunchKernelGGL((cond_kernel<x3_t>), dim3(Np), dim3(256), 0, st, tvec, table, y, table_rows, b_out,
+                       (x3_t*)sb_out, N, D, t_index);
   else
     hipLaunchKernelGGL((cond_kernel<float>), dim3(Np), dim3(256), 0, st, tvec, table, y, table_rows, b_out,
                        (float*)sb_out, N, D, t_index);
@@ -580,6 +625,10 @@ int launch_ln_mod(int prec, const float* h, const float* ada, int ld_ada, int of
                   float fp8_scale) {
   if (fp8_scale > 0.f)  // fp8 tier: the LayerNorm output is the e4m3 operand of the next GEMM
     return ln_mod_t<fp8_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, br, off_gate, h_out, fp8_scale);
+  if (prec == OSUD_PREC_BF16X3) {
+    OSUD_CHECK_ARG(br == nullptr, "ln_mod: the split-bf16 tier is inference only (no pending branch operand)");
+    return ln_mod_t<x3_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, nullptr, 0, h_out);
+  }
   return prec == OSUD_PREC_BF16
              ? ln_mod_t<bf16_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, br, off_gate, h_out)
              : ln_mod_t<float>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, br, off_gate, h_out);
@@ -589,6 +638,10 @@ int launch_final(const float* h, const float* ada, int ld_ada, int off_shift, in
                  const float* bias, float* out, float* u_save, float* stats, int N, int T, int Tp, int D, int C,
                  hipStream_t st, int prec, const void* br, int off_gate, float* h_out) {
   OSUD_CHECK_ARG(C >= 1 && C <= 4 && Tp % 16 == 0, "final layer: out channels %d not in 1..4 / Tp %% 16", C);
+  if (prec == OSUD_PREC_BF16X3) {  // (the kernel reads fp32 h; only the pending-branch operand has the tier's type, and inference has none)
+    OSUD_CHECK_ARG(br == nullptr, "final layer: the split-bf16 tier is inference only");
+    prec = OSUD_PREC_F32;
+  }
   const dim3 grid(N * Tp / 16), block(256);
 #define OSUD_FIN(V)                                                                                                     \
   do {                                                                                                                  \
