@@ -485,7 +485,7 @@ def parity_tier_and_drift(args, dev):
     # moved by 1e-6 (a few fp32 ulps of a coordinate).  The third run is the yardstick: it shows how far the sampler map itself
     # carries a rounding-sized difference on these (random, untrained) weights, i.e. what ANY two implementations may differ by.
     marks = [k for k in (1, 10, 50, 100, 250, 500, 1000) if k < S] + [S]
-    runs = (("bf16", "bf16", 0.0), ("fp32", "fp32", 0.0), ("fp32_moved", "fp32", 1e-6))
+    runs = (("bf16", "bf16", 0.0), ("bf16x3", "bf16x3", 0.0), ("fp32", "fp32", 0.0), ("fp32_moved", "fp32", 1e-6))
     states, sec = {}, {}
     pert = torch.randn(n, 2, T, device=dev, generator=g)
     for name, prec, eps in runs:
@@ -530,6 +530,23 @@ def parity_tier_and_drift(args, dev):
                    "sampler map on these weights amplifies rounding-sized differences to full scale, and the end-to-end distance "
                    "between two arithmetic tiers stops measuring their accuracy (the teacher-forced per-step error does: tests)",
         "bf16_loop_ms_per_step": round(sec["bf16"] / S * 1e3, 4)})
+    # The tier that meets the 1e-3 tolerance at MFMA speed: split-bf16 operands (hi + lo planes, three bf16 MFMAs per product).
+    tol = dict(dev_stats(states["bf16x3"][S], states["fp32"][S]))
+    x3_flops = S / sec["bf16x3"] * M * FLOP_PER_TOKEN_FWD / 1e12 if args.model == "DiT-B" and T == 128 else None
+    out["tolerance_tier"] = {
+        "value": round(S / sec["bf16x3"], 3), "unit": "steps/s", "ms_per_step": round(sec["bf16x3"] / S * 1e3, 4), "steps": S,
+        "dtype": "bf16x3 (split-bf16 operands: v = hi + lo, three v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate / residual / statistics)",
+        "tier": "precision=bf16x3: 16 significand bits per GEMM / attention operand (the reference's sampling matmuls are TF32: 11 bits, "
+                "sample.py:25-26); meets the 1e-3 tolerance on final coordinates (tests/test_gpu_x3.py) at a third of the bf16 tier's MFMA rate",
+        "drift_vs_fp32_tier": {"max": tol["max"], "p99": tol["p99"], "mean": tol["mean"], "steps": S,
+                               "after_steps": {str(k): dev_stats(states["bf16x3"][k], states["fp32"][k]) for k in marks},
+                               "what": "same loop, windows and noise as bf16_drift: |x_t(bf16x3 tier) - x_t(fp32 tier)| of the conditional rows"},
+        "meets_1e-3": bool(tol["max"] <= 1e-3),
+        # algorithmic FLOPs (one product per multiply-add of the model) against the bf16 MFMA peak, and the MFMA work actually
+        # issued (three bf16 MFMAs per product) against the same peak
+        "algorithmic_tflops": round(x3_flops, 1) if x3_flops else None,
+        "mfma_frac_algorithmic": round(x3_flops / PEAK_BF16_TFLOPS, 4) if x3_flops else None,
+        "mfma_frac_issued": round(3 * x3_flops / PEAK_BF16_TFLOPS, 4) if x3_flops else None}
     return out, drift
 
 
@@ -574,6 +591,7 @@ def main():
                                                 "roofline", "cpu_baseline") if k in samp}
         if world == 1 and args.precision == "bf16" and not args.no_parity_tier:
             res["parity_tier"], res["bf16_drift"] = parity_tier_and_drift(args, dev)
+            res["sampling"]["tolerance_tier"] = res["parity_tier"].pop("tolerance_tier")
             # the fp8 inference tier on the same sampling workload (reduced precision: 0.7 % rms from the fp32 oracle, tests/test_gpu_fp8.py)
             fargs = argparse.Namespace(**vars(args))
             fargs.precision, fargs.steps, fargs.warmup, fargs.no_roofline, fargs.no_cpu_baseline = "fp8", 300, 30, True, True

@@ -19,6 +19,8 @@ from osu_diffusion_amd.training import NativeTrainer
 from tests.helpers import T, load, maxdiff, weights_for
 
 pytestmark = pytest.mark.gpu
+# bf16 tier against REFERENCE gradients: bounds = 3x what MI355X measured (printed as MEASURED ... by the tests)
+BF16_GRAD_REL, BF16_NORM_REL = 6e-2, 8e-2
 DEV = "cuda:0"
 
 
@@ -75,6 +77,7 @@ def test_training_step_gradients_match_reference(loss, precision):
     for row, key in enumerate(("main", "vb", "loss")):  # vb reaches ~7e2 at t=999: relative tolerance
         assert float(((terms[row] - T(fx[key])).abs() / T(fx[key]).abs().clamp_min(1.0)).max()) < tol, key
     gv = {k: v.cpu() for k, v in tr.arena.grad_views().items()}
+    worst_rel = worst_norm = 0.0
     for k in fx:
         if not k.startswith("grad:"):
             continue
@@ -83,11 +86,14 @@ def test_training_step_gradients_match_reference(loss, precision):
             assert maxdiff(got, ref) < 2e-5 + 1e-3 * float(ref.abs().max()), k
         else:
             rel = float((got - ref).norm() / ref.norm().clamp_min(1e-12))
-            assert rel < 6e-2, (k, rel)
+            worst_rel = max(worst_rel, rel)
+            assert rel < BF16_GRAD_REL, (k, rel)
     norms = dict(zip((str(s) for s in fx["grad_keys"]), fx["grad_norms"]))
     for k, n in norms.items():  # every one of the 30+ gradient tensors, by norm
         got = float(gv[k].double().norm())
-        assert abs(got - n) <= (2e-3 if precision == "fp32" else 8e-2) * max(n, 1e-4), (k, got, n)
+        worst_norm = max(worst_norm, abs(got - n) / max(n, 1e-4))
+        assert abs(got - n) <= (2e-3 if precision == "fp32" else BF16_NORM_REL) * max(n, 1e-4), (k, got, n)
+    print(f"MEASURED train_step[{loss},{precision}]: worst per-tensor relative gradient error {worst_rel:.3e}, worst norm deviation {worst_norm:.3e}")
     assert float(gv["xoc_embedder.playfield_size"].abs().sum()) == 0.0
 
 
@@ -116,7 +122,7 @@ def test_training_step_at_dit_b_width_matches_reference(precision):
         assert float(((terms[row] - T(fx[key])).abs() / T(fx[key]).abs().clamp_min(1.0)).max()) < tol, key
     gv = tr.arena.grad_views()
     keys = [str(k) for k in fx["grad_keys"]]
-    worst = 0.0
+    worst = worst_n = 0.0
     for k, n_ref, p_ref in zip(keys, fx["grad_norms"], fx["grad_projs"]):
         n, pr, smp = _probe(k, gv[k])
         ref = T(fx["sample:" + k])
@@ -127,10 +133,11 @@ def test_training_step_at_dit_b_width_matches_reference(precision):
         else:
             rel = float((smp - ref).norm() / ref.norm().clamp_min(1e-12))
             worst = max(worst, rel)
-            assert rel < 6e-2, (k, rel)
-            assert abs(n - n_ref) <= 8e-2 * max(n_ref, 1e-4), (k, n, n_ref)
+            worst_n = max(worst_n, abs(n - n_ref) / max(n_ref, 1e-4))
+            assert rel < BF16_GRAD_REL, (k, rel)
+            assert abs(n - n_ref) <= BF16_NORM_REL * max(n_ref, 1e-4), (k, n, n_ref)
     if precision == "bf16":
-        print(f"bf16 tier, D=768: worst per-tensor relative gradient error {worst:.3e}")
+        print(f"MEASURED train_dit_b[bf16]: worst per-tensor relative gradient error {worst:.3e}, worst norm deviation {worst_n:.3e}")
 
 
 def _check_first_adam_step(after, before, ref_after, ref_grad, key):
