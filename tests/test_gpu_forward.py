@@ -23,6 +23,12 @@ from osu_diffusion_amd.synthetic import banded_attn_mask, synthetic_windows
 from tests.helpers import T, load, maxdiff, weights_for
 
 pytestmark = pytest.mark.gpu
+# bf16 tier bounds: 3x what MI355X measured (the tests print MEASURED ... lines).  Forward: max|d| / max|ref| per fixture for the plain
+# and the cfg-4 outputs (round 3, gpurun_out/r3b: deeper / wider / rougher models round more)
+BF16_FWD_MEASURED = {"tiny_T64": (2.74e-4, 7.87e-4), "tiny_T128": (2.60e-4, 8.73e-4), "tiny_T200_band": (2.45e-4, 9.86e-4),
+                     "tiny_T128_allfalse": (2.29e-4, 7.86e-4), "small_T128": (6.81e-4, 2.70e-3), "tiny_T128_rough": (5.32e-4, 1.89e-3),
+                     "dit_b_T128": (1.33e-3, 3.91e-3), "dit_b_T128_rough": (4.32e-3, 1.75e-2)}
+BF16_P20_DRIFT = 5e-3  # measured 1.53e-3
 
 DEV = "cuda:0"
 
@@ -222,11 +228,14 @@ def test_forward_matches_reference_golden(tag, precision):
         cfg4 = m.forward_with_cfg(*args, 4.0, attn_mask=mask)
         cfg1 = m.forward_with_cfg(*args, 1.0, attn_mask=mask)
     scale = float(np.abs(fx["out"]).max())
-    tol = 2e-4 * max(scale, 1.0) if precision == "fp32" else 1e-2 * scale
+    tol = 2e-4 * max(scale, 1.0) if precision == "fp32" else 3 * BF16_FWD_MEASURED[tag][0] * scale
     assert out.shape == (len(args[0]), 4, args[0].shape[2]) and out.dtype == torch.float32
-    assert maxdiff(out.cpu(), fx["out"]) < tol
-    assert maxdiff(cfg4.cpu(), fx["out_cfg4"]) < 7 * tol  # guidance amplifies cond-uncond differences by 4 (+3)
-    assert maxdiff(cfg1.cpu(), fx["out_cfg1"]) < tol
+    e_out, e_cfg4, e_cfg1 = maxdiff(out.cpu(), fx["out"]), maxdiff(cfg4.cpu(), fx["out_cfg4"]), maxdiff(cfg1.cpu(), fx["out_cfg1"])
+    print(f"MEASURED forward[{tag},{precision}]: scale {scale:.3f}, out {e_out:.3e} ({e_out / scale:.2e} x scale), cfg4 {e_cfg4:.3e} "
+          f"({e_cfg4 / scale:.2e} x scale), cfg1 {e_cfg1:.3e}")
+    assert e_out < tol
+    assert e_cfg4 < (7 * tol if precision == "fp32" else 3 * BF16_FWD_MEASURED[tag][1] * scale)  # guidance amplifies cond-uncond differences by 4 (+3)
+    assert e_cfg1 < tol
     n = len(cfg4) // 2
     assert torch.equal(cfg4[:n, :2], cfg4[n:, :2])  # same guided eps in both halves (models.py:342)
 
@@ -392,8 +401,8 @@ def test_chained_loop_bf16_drift_is_bounded():
     kw = dict(o=T(fx["o"]).to(DEV), c=T(fx["c"]).to(DEV), y=T(fx["y"]).to(DEV), cfg_scale=4.0, attn_mask=None)
     fin = d.p_sample_loop(m.forward_with_cfg, z.shape, z, model_kwargs=kw, step_noise=T(fx["noises"])).cpu()
     drift = maxdiff(fin, fx["final"])
-    print(f"bf16 tier end-to-end drift after 20 CFG-4 steps: {drift:.3e}")
-    assert drift < 5e-2
+    print(f"MEASURED loop_p20[bf16]: end-to-end drift after 20 CFG-4 steps {drift:.3e}")
+    assert drift < BF16_P20_DRIFT
 
 
 def test_loop_with_split_off_constant_first_linear_part(monkeypatch):

@@ -40,9 +40,11 @@ def test_fp8_forward_stays_close_to_the_fp32_oracle(hidden, heads, T_):
         assert torch.isfinite(got).all()
         errs[prec] = float((got - ref).pow(2).mean().sqrt())
     scale = float(ref.pow(2).mean().sqrt())
-    print(f"rms deviation from the fp32 oracle (rms of the output {scale:.3f}): bf16 tier {errs['bf16']:.3e}, fp8 tier {errs['fp8']:.3e}")
-    assert errs["fp8"] < 2e-2 * scale, (errs, scale)          # ~0.7 % rms measured
-    assert errs["bf16"] < 3e-3 * scale, (errs, scale)         # the bf16 tier (split first linear) sits an order of magnitude below
+    print(f"MEASURED fp8_forward[T={T_}]: rms deviation from the fp32 oracle / rms of the output: bf16 tier {errs['bf16'] / scale:.3e}, fp8 tier {errs['fp8'] / scale:.3e}")
+    # bounds = 3x measured (round 3): fp8 4.4e-3 / 4.1e-3 / 7.3e-3 of the output's rms, bf16 3.3e-4 / 3.1e-4 / 6.0e-4
+    b8, b16 = {384: (1.35e-2, 1.0e-3), 128: (1.25e-2, 1.0e-3), 1152: (2.2e-2, 1.8e-3)}[hidden]
+    assert errs["fp8"] < b8 * scale, (errs, scale)
+    assert errs["bf16"] < b16 * scale, (errs, scale)         # the bf16 tier (split first linear) sits an order of magnitude below
 
 
 def test_fp8_inference_scales_can_be_calibrated_from_data():
@@ -96,7 +98,7 @@ def test_fp8_training_step_tracks_the_fp32_oracle():
     """BASELINE config 5's tier on a two-block model of DiT-XL's geometry (D = 1152, 16 heads of 72, T = 256): qkv / fc1 / fc2
     and their data-gradient products on e4m3 operands with delayed per-tensor scaling (the first step runs in bf16 and records the
     amax history), weight gradients in bf16.  With the learning rate at 0 the second step sees the same weights and batch: its
-    loss must be within 2 % of the fp32 oracle's and every gradient tensor within 25 % relative Frobenius error (measured:
+    loss must be within 2 % of the fp32 oracle's and every gradient tensor within 15 % relative Frobenius error (3x the measured 4.9 %) (measured:
     printed; the bf16 tier's bound in test_gpu_train.py is 6 %)."""
     from oracle import diffusion_oracle as do
 
@@ -120,9 +122,9 @@ def test_fp8_training_step_tracks_the_fp32_oracle():
         rel = {k: float((gv[k].cpu() - v.grad).norm() / v.grad.norm().clamp_min(1e-12)) for k, v in osd.items() if v.grad is not None}
         worst[prec] = max(rel.items(), key=lambda kv: kv[1])
         assert all(torch.isfinite(g).all() for g in gv.values())
-    print(f"relative Frobenius error of the worst gradient tensor vs the fp32 oracle: bf16 tier {worst['bf16'][1]:.3e} ({worst['bf16'][0]}), "
+    print(f"MEASURED fp8_train: relative Frobenius error of the worst gradient tensor vs the fp32 oracle: bf16 tier {worst['bf16'][1]:.3e} ({worst['bf16'][0]}), "
           f"fp8 tier {worst['fp8'][1]:.3e} ({worst['fp8'][0]})")
-    assert worst["fp8"][1] < 0.25, worst
+    assert worst["fp8"][1] < 0.15 and worst["bf16"][1] < 1.4e-2, worst  # 3x measured: 4.9e-2 (fp8), 4.4e-3 (bf16)
 
 
 def test_fp8_training_reduces_the_loss_like_bf16():

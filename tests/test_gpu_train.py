@@ -20,7 +20,7 @@ from tests.helpers import T, load, maxdiff, weights_for
 
 pytestmark = pytest.mark.gpu
 # bf16 tier against REFERENCE gradients: bounds = 3x what MI355X measured (printed as MEASURED ... by the tests)
-BF16_GRAD_REL, BF16_NORM_REL = 6e-2, 8e-2
+BF16_GRAD_REL, BF16_NORM_REL = 1.3e-2, 1.5e-3  # measured (round 3): 4.1-4.3e-3 per-tensor relative error, 3.6-4.7e-4 norm deviation
 DEV = "cuda:0"
 
 
@@ -111,7 +111,7 @@ def test_training_step_at_dit_b_width_matches_reference(precision):
     """D = 768, 12 heads, K = 768 / 3072: the GEMM tiles (256x256, 256x192), the split-K weight-gradient kernel and the 12-head
     attention backward that bench.py times, against gradients of the REFERENCE (fixture g7_train_dit_b: per-tensor norm, a
     random projection and a strided sample of every gradient tensor).  fp32 tier: sample max|d| <= 2e-5 + 1e-3 max|g|, norms and
-    projections to 2e-3; bf16 tier: relative error of the sample <= 6e-2, norms to 8e-2."""
+    projections to 2e-3; bf16 tier: relative error of the sample <= 1.3e-2, norms to 1.5e-3 (3x measured)."""
     fx = load("g7_train_dit_b")
     shape, sd = weights_for(fx)
     tr = NativeTrainer(native_model(shape, sd, precision), create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True))

@@ -161,3 +161,47 @@ def test_chained_loop_final_coordinates_split_bf16(tag):
     err = maxdiff(got.cpu(), fx["final"])
     print(f"split-bf16 loop {tag}: final max|d| = {err:.3e}")
     assert err < 2e-4  # measured 1.8e-5 (p20), 6.2e-5 (ddim20), 2.2e-5 (p250); the north star's bound is 1e-3
+
+
+# ------------------------------------------------------------------ BASELINE configs[3] end to end against the reference
+def _p1000_inputs():
+    fx = load("g6_loop_p1000_dit_b")
+    shape, sd = weights_for(fx)
+    z = T(fx["z"])
+    # the per-step noise is not stored (4 MB): redrawn from the reference run's seed in its order (one randn_like per step,
+    # gaussian_diffusion.py:454) and pinned by the fixture's checksum and first / last values
+    torch.manual_seed(int(fx["noise_seed"]))
+    noises = torch.stack([torch.randn_like(z) for _ in range(1000)])
+    assert abs(float(noises.double().sum()) - float(fx["noise_sum"])) < 1e-6 and torch.equal(noises[0, 0, 0, :8], T(fx["noise_head"]))
+    assert torch.equal(noises[-1, -1, -1, -8:], T(fx["noise_tail"]))
+    return fx, shape, sd, z, noises
+
+
+@pytest.mark.parametrize("precision,bound", [("fp32", 1e-3), ("bf16x3", 1e-3), ("bf16", None)])
+def test_dit_b_1000_step_cfg4_loop_matches_the_reference(precision, bound):
+    """sample.py's headline shape end to end (sample.py:174-182, gaussian_diffusion.py:469-561): DiT-B, 12 blocks, "1000" steps,
+    cfg 4.0, N = 4 rows, T = 128, the reference's own p_sample_loop on CPU with recorded seeds (fixture g6_loop_p1000_dit_b).  The
+    state after 250 / 500 / 750 executed steps and the final coordinates must be within 1e-3 of the reference in the exact-f32 tier
+    AND in the split-bf16 tier (the reference's own fp32 result is 3.5e-4 from an fp64 evaluation of the same loop: fixture field
+    final_fp64); the bf16 tier is measured and bounded at 3x what MI355X showed."""
+    fx, shape, sd, z, noises = _p1000_inputs()
+    m = native_model(shape, sd, precision)
+    d = create_diffusion("1000", noise_schedule="squaredcos_cap_v2")
+    kw = dict(o=T(fx["o"]).to(DEV), c=T(fx["c"]).to(DEV), y=T(fx["y"]).to(DEV), cfg_scale=4.0, attn_mask=None)
+    x = z.to(DEV).clone()
+    nz = noises.to(DEV)
+    errs, done = {}, 0
+    for k in (250, 500, 750, 1000):  # steps 999 - done .. 1000 - k
+        d.run_steps(m.forward_with_cfg, x, kw, first_step=999 - done, last_step=1000 - k, step_noise=nz[done:k])
+        errs[k] = maxdiff(x.cpu(), fx["final"] if k == 1000 else fx[f"after_{k}"])
+        done = k
+    ref64 = maxdiff(fx["final"], fx["final_fp64"])
+    print(f"MEASURED p1000_dit_b[{precision}]: max|d| vs reference after 250/500/750/1000 steps = "
+          + " / ".join(f"{errs[k]:.3e}" for k in (250, 500, 750, 1000)) + f" (reference fp32 vs fp64 evaluation: {ref64:.3e})")
+    if bound is not None:
+        assert max(errs.values()) < bound, errs
+    else:
+        assert max(errs.values()) < BF16_P1000_BOUND, errs
+
+
+BF16_P1000_BOUND = 2.6e-2  # bf16 tier, 1000 steps: 3x the measured 8.75e-3 (fp32 tier 9.8e-5, split-bf16 tier 1.18e-4, round 3)

@@ -87,7 +87,7 @@ def test_native_step_with_inpaint_mask():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 5e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 1e-3), ("bf16", 2.1e-3)])  # measured 1.9e-5 / 7.0e-4 (bf16 bound = 3x)
 def test_native_loop_with_inpaint_mask(precision, tol):
     """test_toy.py's use: every object of the window given except the last; 20 fused steps with `model.forward`."""
     from osu_diffusion_amd.models import DiT
@@ -113,6 +113,7 @@ def test_native_loop_with_inpaint_mask(precision, tol):
             os.environ["OSUD_NO_GRAPH"] = "0"
     assert torch.equal(finals["graph"], finals["eager"])
     fin = finals["graph"]
+    print(f"MEASURED inpaint_loop[{precision}]: final max|d| vs reference {maxdiff(fin, FX['loop_final']):.3e}")
     assert maxdiff(fin, FX["loop_final"]) < tol
     given = ~T(FX["loop_mask"])
     assert torch.equal(fin[given], T(FX["loop_x0"])[given].clamp(-1, 2))   # the given coordinates come out untouched

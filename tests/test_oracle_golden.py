@@ -180,3 +180,26 @@ def test_registry_keys_match_reference():
     shp = mo.param_shapes(mo.shape_of("DiT-S", num_classes=10))
     assert [str(k) for k in fx["keys"]] == list(shp.keys())
     assert [str(s) for s in fx["shapes"]] == [str(tuple(v)) for v in shp.values()]
+
+
+def test_p1000_dit_b_fixture_is_self_consistent():
+    """g6_loop_p1000_dit_b (the reference's 1000-step CFG-4 loop at DiT-B's geometry): seeded weights match the pinned checksum, the
+    per-step noise redrawn from the stored seed matches the stored checksum and samples (what the GPU test feeds the native loop),
+    the oracle's own run of the loop was within 5e-4 of the reference when the fixture was made, and the recorded states are sane.
+    (The loop itself -- 7 minutes of CPU in the oracle -- is replayed on the GPU: tests/test_gpu_x3.py.)"""
+    fx = load("g6_loop_p1000_dit_b")
+    shape, _ = weights_for(fx)
+    assert (shape.depth, shape.hidden, shape.heads) == (12, 768, 12) and str(fx["respacing"]) == "1000" and float(fx["cfg_scale"]) == 4.0
+    z = T(fx["z"])
+    assert z.shape == (4, 2, 128) and torch.equal(z[:2], z[2:])  # [cond; uncond] start from the same noise (sample.py:97-100)
+    torch.manual_seed(int(fx["noise_seed"]))
+    noises = torch.stack([torch.randn_like(z) for _ in range(1000)])
+    assert abs(float(noises.double().sum()) - float(fx["noise_sum"])) < 1e-6
+    assert abs(float(noises.double().abs().sum()) - float(fx["noise_abs_sum"])) < 1e-5
+    assert torch.equal(noises[0, 0, 0, :8], T(fx["noise_head"])) and torch.equal(noises[-1, -1, -1, -8:], T(fx["noise_tail"]))
+    assert float(fx["oracle_fp32_vs_reference"]) < 5e-4
+    final = T(fx["final"])
+    assert torch.isfinite(final).all() and float(final.min()) >= -1.0 and float(final.max()) <= 2.0  # clamp of the last step (x0 range)
+    assert maxdiff(final, fx["final_fp64"]) < 1e-3  # how far the reference's fp32 arithmetic itself is from exact: 3.5e-4
+    for k in (250, 500, 750):
+        assert T(fx[f"after_{k}"]).shape == final.shape
