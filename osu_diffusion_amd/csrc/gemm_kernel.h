@@ -187,6 +187,39 @@ template <typename TO> __device__ __forceinline__ void store8_out(void* base, si
   else store8(reinterpret_cast<TO*>(base) + row * (size_t)ldo + x, v);
 }
 
+// Split-bf16 operands: a stage row holds BOTH planes of 32 logical k -- chunks 0..3 = hi, 4..7 = lo (the LDS-DMA gathers the two
+// 64-byte halves of a row from the two planes) -- so a fragment pair is read once and used by all of its products:
+//   k-step j (16 k):  acc += X_hi.Y_hi + X_lo.Y_hi + X_hi.Y_lo        (sub-steps: hi_j = j, lo_j = 2 + j)
+// 48 MFMAs and 4 fragment sets per slab and wave, against 32 and 4 of the plain bf16 form on the same 64 KiB of operands: the
+// slab's MFMA time (2 waves x 48 x 32 cycles per SIMD) now exceeds its LDS-DMA fill (~2800 cycles), so the matrix pipe, not
+// operand delivery, bounds the loop.  Three fragment sets live at a time: the lo set of k-step 0 is dead before the lo set of
+// k-step 1 is read into its registers (the sched_barrier pins that order).
+template <int RY, int RX> __device__ __forceinline__ void mma_cross(f32x16 (&acc)[RY][RX], const FragSet<RY, RX>& fx, const FragSet<RY, RX>& fy) {
+#pragma unroll
+  for (int i = 0; i < RY; ++i)
+#pragma unroll
+    for (int j = 0; j < RX; ++j) mma<x3_t>(acc[i][j], fx.x[j], fy.y[i]);
+}
+template <int RY, int RX>
+__device__ __forceinline__ void compute_slab_x3(f32x16 (&acc)[RY][RX], const uint32_t (&ya)[4], const uint32_t (&xa)[4], uint32_t so) {
+  FragSet<RY, RX> h0, lo, h1;
+  read_set<RY, RX>(h0, ya[0] + so, xa[0] + so);
+  read_set<RY, RX>(lo, ya[2] + so, xa[2] + so);
+  wait_lgkm<RY + RX>();  // h0 (lo still in flight)
+  mma_cross<RY, RX>(acc, h0, h0);
+  read_set<RY, RX>(h1, ya[1] + so, xa[1] + so);
+  wait_lgkm<RY + RX>();  // lo of k-step 0
+  mma_cross<RY, RX>(acc, lo, h0);
+  mma_cross<RY, RX>(acc, h0, lo);
+  __builtin_amdgcn_sched_barrier(0);  // the lo registers are re-used: their last readers are issued
+  read_set<RY, RX>(lo, ya[3] + so, xa[3] + so);
+  wait_lgkm<RY + RX>();  // h1
+  mma_cross<RY, RX>(acc, h1, h1);
+  wait_lgkm<0>();
+  mma_cross<RY, RX>(acc, lo, h1);
+  mma_cross<RY, RX>(acc, h1, lo);
+}
+
 // Tile geometry: WY x WX waves, each wave (RY*32) x (RX*32) outputs: BM = WY*RY*32 rows of Y, BN = WX*RX*32 rows of X.
 // A stage holds one K slab of both operands as ONE (BM+BN)-row x 128-byte image.
 // SB = bytes of K per stage row.  128: the classic form (two 64 KiB stages for the 256-wide tiles: ONE slab in flight while one is
@@ -288,20 +321,21 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
   const int frow = lane & 31, fhalf = lane >> 5;
 
   const int ntx = p.Nx / BN, ntiles = (p.My / G::BM) * ntx;
-  // split-bf16 operands (x3_t): rows are [hi plane | lo plane], each ld long; the contraction walks three segments of nk0 slabs --
-  // Y_hi.X_hi, Y_lo.X_hi, Y_hi.X_lo -- into the same fp32 accumulators: the product of (hi + lo) pairs without the lo.lo term
+  // split-bf16 operands (x3_t): global rows are [hi plane | lo plane], each ld long; a slab is 64 bytes of BOTH planes (32 logical
+  // k), gathered into one 128-byte stage row by the LDS-DMA's per-lane source addresses (see compute_slab_x3)
   constexpr bool kX3 = std::is_same<TE, x3_t>::value;
   constexpr int kPlanes = Planes<TE>::k;
-  const int nk0 = (int)((size_t)p.K * sizeof(TE) / SB);
-  int nk = kX3 ? 3 * nk0 : nk0;
+  constexpr int kSlabGlobal = kX3 ? SB / 2 : SB;  // bytes a slab advances along a (plane's) row
+  static_assert(!kX3 || SB == SLAB, "the split-bf16 form is built on 128-byte stage rows");
+  int nk = (int)((size_t)p.K * sizeof(TE) / kSlabGlobal);
   const size_t ldy_b = (size_t)p.ldy * sizeof(TE) * kPlanes, ldx_b = (size_t)p.ldx * sizeof(TE) * kPlanes;
   const char* gy0 = reinterpret_cast<const char*>(p.Y);
   const char* gx0 = reinterpret_cast<const char*>(p.X);
   if (p.split_k > 1) {  // this workgroup's share of the contraction (ranges differ by at most one slab)
     const int k0 = (int)((long)blockIdx.y * nk / p.split_k), k1 = (int)((long)(blockIdx.y + 1) * nk / p.split_k);
     nk = k1 - k0;
-    gy0 += (size_t)k0 * SB;
-    gx0 += (size_t)k0 * SB;
+    gy0 += (size_t)k0 * kSlabGlobal;
+    gx0 += (size_t)k0 * kSlabGlobal;
     p.out = reinterpret_cast<char*>(p.out) + (size_t)blockIdx.y * p.split_stride * (EPI == EPI_NONE_F32 ? 4 : sizeof(TE));
   }
   // Persistent workgroups: gridDim.x <= #CUs.  Blocks are dispatched round-robin over the 8 XCDs (b % 8);
@@ -324,14 +358,8 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
     if (p.tile_order == 4) ty = tx = 0;           // experiment: every workgroup streams the SAME panels (all L2 hits)
     if (p.tile_order == 5) { ty = ty % 8; tx = 0; }
 #endif
-    size_t ky = (size_t)kt * SB, kx = ky;
-    if constexpr (kX3) {  // (32-bit scalar arithmetic + readfirstlane: the panel bases feed "s" operands of the LDS-DMA asm)
-      const int seg = kt >= 2 * nk0 ? 2 : (kt >= nk0 ? 1 : 0), r = kt - seg * nk0;
-      ky = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(r * SB + (seg == 1 ? p.ldy * (int)sizeof(TE) : 0));  // the lo plane starts ld elements into the row
-      kx = (size_t)(uint32_t)__builtin_amdgcn_readfirstlane(r * SB + (seg == 2 ? p.ldx * (int)sizeof(TE) : 0));
-    }
-    gy = gy0 + (size_t)ty * G::BM * ldy_b + ky;
-    gx = gx0 + (size_t)tx * BN * ldx_b + kx;
+    gy = gy0 + (size_t)ty * G::BM * ldy_b + (size_t)kt * kSlabGlobal;
+    gx = gx0 + (size_t)tx * BN * ldx_b + (size_t)kt * kSlabGlobal;
   };
 
   // per-lane LDS byte addresses of the wave's first Y/X row for the 4 k-substeps (stage 0)
@@ -362,7 +390,10 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
     const int piece = wave * G::PPW + q;
     const int R = piece * G::RPP + (SB == 128 ? (lane >> 3) : (lane >> 2));
     const int c = SB == 128 ? ((lane & 7) ^ ((R >> 1) & 7)) : ((lane & 3) ^ ((R >> 2) & 3));
-    dma_off[q] = (uint32_t)((piece * G::RPP < G::BM ? (size_t)R * ldy_b : (size_t)(R - G::BM) * ldx_b) + c * 16);
+    const bool isy = piece * G::RPP < G::BM;
+    // (split-bf16: source chunks 0..3 come from the hi plane, 4..7 from the same columns of the lo plane, ld elements further on)
+    const size_t cb = kX3 ? (size_t)(c & 3) * 16 + (c >= 4 ? (size_t)(isy ? p.ldy : p.ldx) * sizeof(TE) : 0) : (size_t)c * 16;
+    dma_off[q] = (uint32_t)((isy ? (size_t)R * ldy_b : (size_t)(R - G::BM) * ldx_b) + cb);
   }
   // ---- ROLES: who stages what.  Waves w and w + 4 share a SIMD; group 0 = waves 0-3 owns the top half of the Y rows, group 1
   // the bottom half.  Per slab: group 1 issues the pieces group 0 needs first -- Y top + all of X (the EARLY set) -- while group 0
@@ -567,7 +598,8 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
 #ifdef OSUD_GEMM_TIMING
       const uint64_t tt3 = __builtin_readcyclecounter();
 #endif
-      compute_slab<TE, RY, RX, SB>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
+      if constexpr (kX3) compute_slab_x3<RY, RX>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
+      else compute_slab<TE, RY, RX, SB>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
 #ifdef OSUD_GEMM_TIMING
       {
         const uint64_t tt4 = __builtin_readcyclecounter();
@@ -874,7 +906,7 @@ template <typename TE, int EPI, int WY, int WX, int RY, int RX, int SB = SLAB> i
   constexpr bool kDynFits = G::NSTAGE * G::STAGE + (G::PATCH_OUT ? G::NW * 4096 : 0) + 64 <= G::LDS_MAX;
   const size_t lds = ring + (G::PATCH_OUT ? (size_t)G::NW * 4096 : 0) + (kDynFits ? 64 : 0);
   // the role-split main loop: 8-wave geometries with two stages (the 64 KiB-per-stage tiles), piece sets divisible by 4 waves
-  constexpr bool kRolesOk = SB == SLAB && G::NW == 8 && G::NSTAGE == 2 && (G::BM / 16 + G::BN / 8) % 4 == 0 && (G::BM / 16) % 4 == 0;
+  constexpr bool kRolesOk = !std::is_same<TE, x3_t>::value && SB == SLAB && G::NW == 8 && G::NSTAGE == 2 && (G::BM / 16 + G::BN / 8) % 4 == 0 && (G::BM / 16) % 4 == 0;
   static bool attr_set = false;
   if (!attr_set) {
     OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX, false, SB>),
@@ -891,7 +923,7 @@ template <typename TE, int EPI, int WY, int WX, int RY, int RX, int SB = SLAB> i
   if (grid > ntiles) grid = ntiles;
   {
     const bool dyn_on = gemm_dynamic_tiles_wanted();
-    const int nk = (int)((size_t)p.K * sizeof(TE) / SB);
+    const int nk = (int)((size_t)p.K * sizeof(TE) / (std::is_same<TE, x3_t>::value ? SB / 2 : SB));
     p.sched = (dyn_on && kDynFits && splits == 1 && ntiles > grid && grid % 8 == 0 && nk >= G::NSTAGE && ntiles / 8 + 2 * grid < 60000) ? gemm_sched_slot() : nullptr;
   }
   // OSUD_GEMM_ROLES=1 selects the role-split main loop.  Built, bit-identical results, and measured EQUAL to the lock-step loop
@@ -951,7 +983,8 @@ template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
   }
   {  // half slabs + deeper ring for the 256x256 geometry (OSUD_GEMM_SLAB=128 selects the two-stage form for A/B runs)
     static const bool half_slabs = [] { const char* e = getenv("OSUD_GEMM_SLAB"); return e && atoi(e) == 64; }();
-    if (pick == 2 && half_slabs) return launch_w<TE, EPI, 2, 4, 4, 2, 64>(p, st);
+    if constexpr (!std::is_same<TE, x3_t>::value)
+      if (pick == 2 && half_slabs) return launch_w<TE, EPI, 2, 4, 4, 2, 64>(p, st);
   }
   if (pick == 2) return launch_w<TE, EPI, 2, 4, 4, 2>(p, st);
   if (pick == 1) return launch_w<TE, EPI, 4, 2, 2, 3>(p, st);
