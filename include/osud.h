@@ -191,6 +191,33 @@ int osud_adamw_ema_step(float* params, const float* grads, float* exp_avg, float
                         float lr, float beta1, float beta2, float eps, float weight_decay, int step, float ema_decay,
                         size_t skip_begin, size_t skip_end, float grad_scale, osud_stream stream);
 
+/* ------------------------------------------------------------------ data-parallel exchange (RCCL over xGMI)
+ * The collectives of train.py's DDP wrapper on the library's own RCCL communicator (one per process = per GPU):
+ *   train.py:106  dist.init_process_group     -> osud_comm_unique_id (rank 0) + osud_comm_init (every rank)
+ *   train.py:152  DDP(...) parameter broadcast -> osud_broadcast_params on the flat parameter arena
+ *   train.py:257  gradient all-reduce (mean)   -> osud_allreduce_grads per finished slice of the flat gradient arena (SUM; the
+ *                                                 1/world goes into osud_adamw_ema_step's grad_scale), or the sharded form
+ *                                                 osud_reduce_scatter_grads -> optimizer on the own shard -> osud_allgather_params
+ *   train.py:274  loss all-reduce, :297 barrier -> osud_allreduce_grads on a 1-element buffer
+ * The 128-byte id is created by rank 0 and handed to every rank by the host (torchrun's store, a file, MPI).  Collectives are
+ * enqueued on the given stream; overlap with the backward phases (osud_dit_backward_phases) is the host's choice of streams.
+ * librccl is loaded at run time (the process's own copy, e.g. PyTorch-ROCm's): without it these calls return
+ * OSUD_ERR_UNSUPPORTED and everything else works. */
+#define OSUD_COMM_UID_BYTES 128
+#define OSUD_WIRE_F32 0
+#define OSUD_WIRE_BF16 1 /* gradients rounded to bf16 for the exchange (half the bytes; opt-in) */
+typedef struct osud_comm osud_comm;
+int osud_comm_unique_id(void* uid128);
+int osud_comm_init(int rank, int world, const void* uid128, osud_comm** out);
+void osud_comm_destroy(osud_comm* c);
+int osud_comm_rank(const osud_comm* c);
+int osud_comm_world(const osud_comm* c);
+int osud_comm_rccl_version(void); /* 0 if librccl is not available */
+int osud_allreduce_grads(osud_comm* c, void* buf, size_t n, int wire, osud_stream stream);
+int osud_broadcast_params(osud_comm* c, float* buf, size_t n, int root, osud_stream stream);
+int osud_reduce_scatter_grads(osud_comm* c, const void* in, void* out_shard, size_t n_per_rank, int wire, osud_stream stream);
+int osud_allgather_params(osud_comm* c, const float* shard, float* full, size_t n_per_rank, osud_stream stream);
+
 /* ------------------------------------------------------------------ op-level entry points
  * (the fused building blocks, exported so each can be parity-tested on its own) */
 /* Process-wide switch for multi-round GEMM launches (more output tiles than compute units): 1 = workgroups draw their tiles
@@ -211,6 +238,12 @@ int osud_op_convert(int precision, const float* src, void* dst, size_t n, osud_s
 /* Attention core on the packed in_proj output qkv [Mp][ld_qkv] (Q | K | V, head h = hd columns): out [Mp][hidden]. */
 int osud_op_attention(int precision, const void* qkv, int ld_qkv, const uint8_t* mask, void* out, int N, int T, int Tp,
                       int Mp, int heads, int head_dim, osud_stream stream);
+
+/* Weight gradient of a Linear without operand transposes (bf16 tier): out[y][x] = sum_m P[m][y] * Q[m][x] over M token rows
+ * (P = gradient of the Linear's output [M][ldp], Q = its input [M][ldq], both bf16 row-major; out fp32 [Ny][Nx]).  `ws` holds the
+ * fp32 partial slabs of the split over the token axis (ws_elems floats; at least Ny * Nx * (CUs / tiles) for a full split). */
+int osud_op_wgrad(const void* P, int ldp, const void* Q, int ldq, int Ny, int Nx, int M, float* out, float* ws, size_t ws_elems,
+                  osud_stream stream);
 
 /* Backward of the attention core in the training layout (T == Tp, T % 64 == 0, no mask): qkv [N*T][3*hidden], d_out / out [N*T][hidden],
  * lse [N][heads][T] as saved by the training forward (log2 domain in the bf16 tier, natural log in the f32 tier) -> dqkv [N*T][3*hidden].

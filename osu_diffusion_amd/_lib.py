@@ -65,10 +65,21 @@ _SIGNATURES = {
     "osud_q_sample": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "osud_train_loss": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "osud_adamw_ema_step": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _f, _f, _f, _f, _f, _i, _f, _sz, _sz, _f, _vp]),
+    "osud_comm_unique_id": (_i, [_vp]),
+    "osud_comm_init": (_i, [_i, _i, _vp, C.POINTER(_vp)]),
+    "osud_comm_destroy": (None, [_vp]),
+    "osud_comm_rank": (_i, [_vp]),
+    "osud_comm_world": (_i, [_vp]),
+    "osud_comm_rccl_version": (_i, []),
+    "osud_allreduce_grads": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "osud_broadcast_params": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "osud_reduce_scatter_grads": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
+    "osud_allgather_params": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "osud_op_gemm": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "osud_op_convert": (_i, [_i, _vp, _vp, _sz, _vp]),
     "osud_set_gemm_dynamic_tiles": (_i, [_i]),
     "osud_op_attention": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "osud_op_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "osud_op_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }
 

@@ -726,6 +726,11 @@ extern "C" int osud_op_attention_bwd(int precision, const void* qkv, const void*
   OSUD_CHECK_ARG(qkv && d_out && out && lse && dqkv, "op_attention_bwd: null argument");
   return launch_attention_bwd(precision, qkv, d_out, out, lse, dqkv, N, T, heads, head_dim, (hipStream_t)stream, delta_ws, nullptr);
 }
+extern "C" int osud_op_wgrad(const void* P, int ldp, const void* Q, int ldq, int Ny, int Nx, int M, float* out, float* ws, size_t ws_elems,
+                             osud_stream stream) {
+  OSUD_CHECK_ARG(P && Q && out && ws, "op_wgrad: null argument");
+  return launch_wgrad_tr(P, ldp, Q, ldq, Ny, Nx, M, out, ws, ws_elems, (hipStream_t)stream);
+}
 extern "C" int osud_op_attention(int precision, const void* qkv, int ld_qkv, const uint8_t* mask, void* out, int N,
                                  int T, int Tp, int Mp, int heads, int head_dim, osud_stream stream) {
   OSUD_CHECK_ARG(qkv && out, "op_attention: null argument");

@@ -197,11 +197,12 @@ def exchange_table_rows(table_grad, labels, group=None):
     return table_grad
 
 
-def backward_with_overlapped_allreduce(model, dout, group=None, force=False, on_blocks_reduced=None):
+def backward_with_overlapped_allreduce(model, dout, group=None, force=False, on_blocks_reduced=None, comm=None):
     """Backward in phases; each block's gradient slice is SUM-all-reduced (async, RCCL's own stream) as soon
     as its phase is enqueued, overlapping the exchange with the remaining backward compute — the role of
     DDP's bucketed reducer (train.py:152,257).  `on_blocks_reduced()` (optional) is called once every block slice has
     been reduced, while the tail exchange is still in flight (the optimizer uses that window).
+    `comm` (a comm.NativeComm): the slices travel through the C ABI's osud_allreduce_grads instead of torch.distributed.
     Returns the 1/world factor for the optimizer."""
     import torch.distributed as dist
 
@@ -212,7 +213,10 @@ def backward_with_overlapped_allreduce(model, dout, group=None, force=False, on_
         return 1.0
     arena, depth = model._arena, model.depth
     blocks, tail = overlap_slices(arena, depth)
-    reduce = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)) if active else (lambda t: None)
+    if comm is not None and active:  # the library's own RCCL communicator (C ABI: osud_allreduce_grads on its side stream)
+        reduce = lambda t: comm.all_reduce_(t, async_op=True)  # noqa: E731
+    else:
+        reduce = (lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=True)) if active else (lambda t: None)
     handles = []
     dout = native_backward(model, dout, phases=(0, 0))
     _, _, f_lo, f_hi = next(s for s in tail if s[0] == "final")
@@ -251,11 +255,13 @@ def shard_plan(lo, hi, world, align=4):
     return per, lo + per * world
 
 
-def _reduce_scatter_sum(out, inp, group):
+def _reduce_scatter_sum(out, inp, group, comm=None):
     """SUM reduce-scatter of `inp` (world x out.numel()) into `out`; async handle.  RCCL: one reduce_scatter_tensor; backends
-    without it (gloo, used by the CPU / one-GPU tests): all-reduce, then keep the own shard."""
+    without it (gloo, used by the CPU / one-GPU tests): all-reduce, then keep the own shard.  `comm`: through the C ABI."""
     import torch.distributed as dist
 
+    if comm is not None:
+        return comm.reduce_scatter(out, inp, async_op=True), None
     if dist.get_backend(group) == "nccl":
         return dist.reduce_scatter_tensor(out, inp, op=dist.ReduceOp.SUM, group=group, async_op=True), None
     h = dist.all_reduce(inp, op=dist.ReduceOp.SUM, group=group, async_op=True)
@@ -263,10 +269,12 @@ def _reduce_scatter_sum(out, inp, group):
     return h, (lambda: out.copy_(inp[r * n:(r + 1) * n]))
 
 
-def _all_gather_into(full, shard, group):
+def _all_gather_into(full, shard, group, comm=None):
     """all-gather equal shards into `full` (shard may be full's own slice: in place); async handle + finisher."""
     import torch.distributed as dist
 
+    if comm is not None:
+        return comm.all_gather(full, shard, async_op=True), None
     if dist.get_backend(group) == "nccl":
         return dist.all_gather_into_tensor(full, shard, group=group, async_op=True), None
     W = dist.get_world_size(group)
@@ -379,8 +387,19 @@ class NativeTrainer:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and "OSUD_GEMM_DYNAMIC" not in os.environ:
             # collectives will share the compute units with the backward: let multi-round GEMM launches queue their tiles
             _lib.check(_lib.lib().osud_set_gemm_dynamic_tiles(1))
+        # OSUD_NATIVE_COMM=1: the gradient / parameter exchange goes through the library's own RCCL communicator (C ABI:
+        # osud_comm_init, osud_allreduce_grads, ...), bootstrapped once over torch's process group; the class-table row exchange
+        # and the scalar bookkeeping stay on torch.distributed.  (world 1 with OSUD_FORCE_PHASED=1 exercises every call.)
+        self.comm = None
+        if os.environ.get("OSUD_NATIVE_COMM", "0") == "1" and dist.is_available() and dist.is_initialized():
+            from .comm import NativeComm
+
+            self.comm = NativeComm.from_torch_distributed(group, device=self.arena.flat.device)
         if broadcast_init and dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.broadcast(self.arena.flat, 0, group=group)  # DDP ctor: rank 0's init wins (train.py:152)
+            if self.comm is not None:
+                self.comm.broadcast_(self.arena.flat, 0)
+            else:
+                dist.broadcast(self.arena.flat, 0, group=group)  # DDP ctor: rank 0's init wins (train.py:152)
         self.ema_arena.flat.copy_(self.arena.flat)  # update_ema(ema, model, decay=0), train.py:194-198
         self._tmap = torch.from_numpy(np.asarray(diffusion._model_timestep_map)).to(self.arena.flat.device)
 
@@ -437,7 +456,8 @@ class NativeTrainer:
             if self.shard_optimizer and (not single or self.force_phased) and dist.is_available() and dist.is_initialized():
                 self._backward_sharded(dout)
                 return terms
-            scale = backward_with_overlapped_allreduce(model, dout, self.group, force=self.force_phased, on_blocks_reduced=early)
+            scale = backward_with_overlapped_allreduce(model, dout, self.group, force=self.force_phased, on_blocks_reduced=early,
+                                                       comm=self.comm)
             if done:
                 self._adamw(_complement(done, self.arena.total), scale)
                 self._refresh()
@@ -497,14 +517,14 @@ class NativeTrainer:
             out = self._shard_buf[off:off + per]
             if per > 0:
                 src = arena.grads[lo:bulk_hi] if wire is None else arena.grads[lo:bulk_hi].to(wire)
-                pending.append(_reduce_scatter_sum(out, src, group) + (src,))  # (handle, finisher, keep-alive)
+                pending.append(_reduce_scatter_sum(out, src, group, self.comm) + (src,))  # (handle, finisher, keep-alive)
             if bulk_hi < hi:
-                pending.append((dist.all_reduce(arena.grads[bulk_hi:hi], op=dist.ReduceOp.SUM, group=group, async_op=True), None, None))
+                pending.append((self._allreduce_async(arena.grads[bulk_hi:hi]), None, None))
             off += per
         native_backward(model, dout, phases=(depth + 1, depth + 1))
         for kind, _, lo, hi in tail:
             if kind == "tail":
-                pending.append((dist.all_reduce(arena.grads[lo:hi], op=dist.ReduceOp.SUM, group=group, async_op=True), None, None))
+                pending.append((self._allreduce_async(arena.grads[lo:hi]), None, None))
         for h, fin, _keep in pending:
             h.wait()
             if fin is not None:
@@ -521,7 +541,7 @@ class NativeTrainer:
                 g = self._shard_buf[off:off + per]
                 self._adamw_range(a, b, g if wire is None else g.float(), scale)
                 own.append((lo, bulk_hi))
-                gathers.append(_all_gather_into(arena.flat[lo:bulk_hi], arena.flat[a:b], group))
+                gathers.append(_all_gather_into(arena.flat[lo:bulk_hi], arena.flat[a:b], group, self.comm))
             off += per
         self._adamw(_complement(own, arena.total), scale)
         for h, fin in gathers:
@@ -530,6 +550,13 @@ class NativeTrainer:
                 fin()
         self._ema_stale = True  # every rank's EMA is current only on its own shards (and the replicated parts)
         self._refresh()
+
+    def _allreduce_async(self, t):
+        import torch.distributed as dist
+
+        if self.comm is not None:
+            return self.comm.all_reduce_(t, async_op=True)
+        return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _adamw_range(self, lo, hi, grads, grad_scale):
         """AdamW + EMA on arena elements [lo, hi) with the gradient taken from `grads` (hi - lo elements, e.g. a scattered shard)."""
@@ -555,7 +582,7 @@ class NativeTrainer:
             if per == 0:
                 continue
             for buf in (self.exp_avg, self.exp_avg_sq, self.ema_arena.flat):
-                h, fin = _all_gather_into(buf[lo:bulk_hi], buf[lo + r * per:lo + (r + 1) * per], self.group)
+                h, fin = _all_gather_into(buf[lo:bulk_hi], buf[lo + r * per:lo + (r + 1) * per], self.group, self.comm)
                 h.wait()
                 if fin is not None:
                     fin()

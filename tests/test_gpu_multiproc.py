@@ -101,6 +101,47 @@ def test_rccl_is_executed_world_size_one():
         assert err <= max(tol, 2e-6) * scale, (mode, err)
 
 
+def test_native_rccl_communicator_through_the_c_abi():
+    """osud_comm_unique_id / osud_comm_init / osud_allreduce_grads / osud_broadcast_params / osud_reduce_scatter_grads /
+    osud_allgather_params (include/osud.h: the collectives of train.py:106,152,257 on the library's own RCCL communicator), with
+    the one rank this box has: a 1-rank collective is a copy, but the library load (dlopen of the process's librccl), the
+    communicator, every call and the side-stream hand-over are the real ones."""
+    from osu_diffusion_amd.comm import NativeComm
+
+    assert NativeComm.rccl_version() > 20000
+    c = NativeComm(0, 1, NativeComm.unique_id(), device="cuda:0")
+    x = torch.randn(1 << 20, device="cuda:0")
+    want = x.clone()
+    c.all_reduce_(x)
+    h = c.all_reduce_(x, async_op=True)
+    h.wait()
+    xb = x.to(torch.bfloat16)
+    c.all_reduce_(xb)  # bf16 wire
+    c.broadcast_(x, 0)
+    shard = torch.empty(1 << 18, device="cuda:0")
+    c.reduce_scatter(shard, x[: 1 << 18].contiguous())
+    full = torch.zeros(1 << 18, device="cuda:0")
+    c.all_gather(full, shard, async_op=True).wait()
+    torch.cuda.synchronize()
+    assert torch.equal(x, want) and torch.equal(xb, want.to(torch.bfloat16)) and torch.equal(full, want[: 1 << 18])
+    c.close()
+
+
+def test_trainer_exchanges_gradients_through_the_native_communicator():
+    """OSUD_NATIVE_COMM=1 under torchrun (one rank, phased backward forced): the per-slice all-reduces, the init broadcast and the
+    sharded optimizer's reduce-scatter / all-gather run through libosud's RCCL calls; results equal the run without a process group."""
+    from tests import mp_worker
+
+    want_flat, _ = mp_worker.run(0, 1)
+    for mode in ("allreduce", "zero1"):
+        with tempfile.TemporaryDirectory() as d:
+            _torchrun(1, [os.path.join(ROOT, "tests", "mp_worker.py"), d],
+                      dict(OSUD_DIST_BACKEND="gloo", OSUD_TEST_MODE=mode, OSUD_FORCE_PHASED="1", OSUD_NATIVE_COMM="1"))
+            got = torch.load(os.path.join(d, "rank0.pt"))
+        err = float((got["flat"] - want_flat).abs().max())
+        assert err <= 2e-6 * float(want_flat.abs().max()), (mode, err)
+
+
 def test_bench_two_ranks_over_gloo():
     """bench.py's N > 1 code path (rank set-up, barriers, max-over-ranks timing, one JSON line from rank 0) with both ranks on
     GPU 0; once with the all-reduce exchange, once with the sharded optimizer."""
