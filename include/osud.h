@@ -218,6 +218,16 @@ int osud_broadcast_params(osud_comm* c, float* buf, size_t n, int root, osud_str
 int osud_reduce_scatter_grads(osud_comm* c, const void* in, void* out_shard, size_t n_per_rank, int wire, osud_stream stream);
 int osud_allgather_params(osud_comm* c, const float* shard, float* full, size_t n_per_rank, osud_stream stream);
 
+/* Row exchange of the class-table gradient (52 671 x D; only the step's label rows are non-zero, the reference's DDP reduces it
+ * densely: train.py:257).  pack: labels (B, as fed to the forward) -> idx_out (B, sorted) + rows_out (B x D: the gradient row of
+ * every label's first occurrence, zeros for duplicates).  The host all-gathers both; apply: all_idx (W x B) / all_rows (W x B x D)
+ * in rank order -> every touched row of table_grad becomes the sum of the ranks' rows added in rank order (bit-identical on
+ * every rank).  scratch: W * B + 1 int64.  At most 4096 labels over all ranks. */
+int osud_table_rows_pack(const float* table_grad, int rows, int D, const int64_t* labels, int B, int64_t* idx_out, float* rows_out,
+                         osud_stream stream);
+int osud_table_rows_apply(float* table_grad, int rows, int D, const int64_t* all_idx, const float* all_rows, int W, int B,
+                          int64_t* scratch, osud_stream stream);
+
 /* ------------------------------------------------------------------ op-level entry points
  * (the fused building blocks, exported so each can be parity-tested on its own) */
 /* Process-wide switch for multi-round GEMM launches (more output tiles than compute units): 1 = workgroups draw their tiles

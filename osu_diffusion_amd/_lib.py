@@ -75,6 +75,8 @@ _SIGNATURES = {
     "osud_broadcast_params": (_i, [_vp, _vp, _sz, _i, _vp]),
     "osud_reduce_scatter_grads": (_i, [_vp, _vp, _vp, _sz, _i, _vp]),
     "osud_allgather_params": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "osud_table_rows_pack": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "osud_table_rows_apply": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "osud_op_gemm": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "osud_op_convert": (_i, [_i, _vp, _vp, _sz, _vp]),
     "osud_set_gemm_dynamic_tiles": (_i, [_i]),

@@ -182,6 +182,26 @@ def exchange_table_rows(table_grad, labels, group=None):
     import torch.distributed as dist
 
     W = dist.get_world_size(group)
+    if table_grad.is_cuda and labels.numel() * W <= 4096:
+        # GPU: two native launches per side (csrc/exchange.hip) instead of ~25 tensor-library ones -- same sums, same order
+        L = _lib.lib()
+        rows_n, D = table_grad.shape
+        B = labels.numel()
+        lab = labels.to(device=table_grad.device, dtype=torch.int64).reshape(-1).contiguous()
+        ys = torch.empty(B, dtype=torch.int64, device=table_grad.device)
+        rows = torch.empty(B, D, dtype=torch.float32, device=table_grad.device)
+        st = _lib.stream_ptr(table_grad.device)
+        with torch.cuda.device(table_grad.device):
+            _lib.check(L.osud_table_rows_pack(_lib.ptr(table_grad), rows_n, D, _lib.ptr(lab), B, _lib.ptr(ys), _lib.ptr(rows), st))
+        all_idx = torch.empty(W, B, dtype=torch.int64, device=table_grad.device)
+        all_rows = torch.empty(W, B, D, dtype=torch.float32, device=table_grad.device)
+        dist.all_gather_into_tensor(all_idx, ys, group=group) if dist.get_backend(group) == "nccl" else dist.all_gather(list(all_idx.unbind(0)), ys, group=group)
+        dist.all_gather_into_tensor(all_rows, rows, group=group) if dist.get_backend(group) == "nccl" else dist.all_gather(list(all_rows.unbind(0)), rows, group=group)
+        scratch = torch.empty(W * B + 1, dtype=torch.int64, device=table_grad.device)
+        with torch.cuda.device(table_grad.device):
+            _lib.check(L.osud_table_rows_apply(_lib.ptr(table_grad), rows_n, D, _lib.ptr(all_idx), _lib.ptr(all_rows), W, B,
+                                               _lib.ptr(scratch), _lib.stream_ptr(table_grad.device)))
+        return table_grad
     ys, _ = torch.sort(labels.to(torch.int64).reshape(-1))
     first = torch.ones_like(ys, dtype=torch.bool)
     first[1:] = ys[1:] != ys[:-1]
