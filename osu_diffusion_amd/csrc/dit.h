@@ -52,6 +52,8 @@ struct BwdWs {
   size_t splitk_elems = 0;
   float** seg_tbl = nullptr;       // device: the per-block adaLN weight-gradient tensors (GemmP::seg_out), 32 entries
   float* seg_tbl_host[32] = {};    // what the device table holds (uploaded again when a gradient tensor is re-bound)
+  void* dbr2 = nullptr;  // d(attention branch output): its own buffer, so that the MLP branch's `dbr` lives to the end of the block's
+                         // phase (all four weight gradients of a block are formed there in one grouped launch)
   void *dbr = nullptr, *dz1 = nullptr, *dqkv = nullptr, *dao = nullptr, *tA = nullptr, *tB = nullptr, *dada_te = nullptr,
        *db_te = nullptr, *dz0 = nullptr, *small_t1 = nullptr, *small_t2 = nullptr, *sb_t = nullptr /* silu(b)^T [D][Np] */;
 };

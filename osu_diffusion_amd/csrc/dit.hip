@@ -103,6 +103,7 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
     OSUD_TRY(dev_alloc(W, &b.dhB, (size_t)Mp * D * 4));
     OSUD_TRY(dev_alloc(W, &b.du, (size_t)Mp * D * 4));
     OSUD_TRY(dev_alloc(W, &b.dbr, (size_t)Mp * D * es));
+    OSUD_TRY(dev_alloc(W, &b.dbr2, (size_t)Mp * D * es));
     OSUD_TRY(dev_alloc(W, &b.dz1, (size_t)Mp * 4 * D * es));
     OSUD_TRY(dev_alloc(W, &b.dqkv, (size_t)Mp * 3 * D * es));
     OSUD_TRY(dev_alloc(W, &b.dao, (size_t)Mp * D * es));

@@ -83,6 +83,14 @@ int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_
 int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int Nx, int M, float* out, float* ws,
                     size_t ws_elems, hipStream_t st);
 int launch_colsum_bf16(const void* a, int ld, int M, int N, float* out, hipStream_t st);
+// up to four weight-gradient products over the same M token rows in one launch (+ one combine launch); *done = false: not taken
+struct WgradItem {
+  const void* P;
+  const void* Q;
+  float* out;
+  int ldp, ldq, Ny, Nx;
+};
+int launch_wgrad_group(const WgradItem* items, int n, int M, float* ws, size_t ws_elems, hipStream_t st, bool* done);
 
 // batch.hip: one launch for a list of small buffers (passed by value in the kernel arguments)
 enum SegOp { SEG_ZERO = 0, SEG_COPY = 1, SEG_CONVERT = 2 };

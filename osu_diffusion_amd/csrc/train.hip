@@ -252,19 +252,44 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     else
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dz1, 4 * D, bw.w1_t, 4 * D, Mp, D, 4 * D, w.du, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "dgrad fc1"));
+    // The weight gradients of the block are formed two at a time in grouped launches (wgrad.hip: wgrad_group_kernel -- equal runs
+    // of stages per workgroup over the pair's tiles instead of launches split 7 to 28 ways, a third of the partial-slab bytes, one
+    // combine launch per pair) where the group qualifies (bf16 tier, sides multiples of 256, GPU not shared); otherwise each
+    // follows its data-gradient product as before.  out_proj's weight gradient waits for in_proj's: the attention branch's
+    // gradient has its own buffer (dbr2) so that it is still there.
+    const bool group_wg = prec == OSUD_PREC_BF16 && fused_b1 && D % 256 == 0 && !gemm_dynamic_tiles_on() &&
+                          (getenv("OSUD_WGRAD_GROUP") && getenv("OSUD_WGRAD_GROUP")[0] == '1');  // opt-in: measured neutral (wgrad.hip)
+    // (two groups per block, each right behind the data-gradient product that made its big operand: dz1 -- 201 MB -- and dqkv
+    //  are then still in the Infinity Cache; ONE group of all four at the end of the phase found them cold and ran 2.05 instead
+    //  of 1.85 us per stage: with two 64 KiB stages a slab's fill has one slab of lead, and an HBM fill does not make it)
+    auto wgrad_pair = [&](const WgradItem (&items)[2], const char* what) -> int {
+      bool done = false;
+      OSUD_TRY(launch_wgrad_group(items, 2, Mp, w.splitk, w.splitk_elems, st, &done));
+      if (!done)  // (did not qualify after all, e.g. the partial tiles do not fit the slab area: one by one)
+        for (const WgradItem& it : items) OSUD_TRY(weight_grad(m, it.P, it.ldp, it.Q, it.ldq, it.Ny, it.Nx, Mp, it.out, nullptr, st));
+      return dbg_sync(st, what);
+    };
+    if (group_wg) {
+      const WgradItem items[2] = {{w.dz1, sv.u2, G(p + "mlp.fc1.weight"), 4 * D, D, 4 * D, D},
+                                  {w.dbr, sv.g, G(p + "mlp.fc2.weight"), D, 4 * D, D, 4 * D}};
+      OSUD_TRY(wgrad_pair(items, "wgrad fc1 + fc2 (grouped)"));
+    } else {
     OSUD_TRY(weight_grad(m, w.dz1, 4 * D, sv.u2, D, 4 * D, D, Mp, G(p + "mlp.fc1.weight"), fused_b1 ? nullptr : g_b1, st));
     OSUD_TRY(dbg_sync(st, "wgrad fc1"));
     OSUD_TRY(weight_grad(m, w.dbr, D, sv.g, 4 * D, D, 4 * D, Mp, G(p + "mlp.fc2.weight"), nullptr, st));
     OSUD_TRY(dbg_sync(st, "wgrad fc2"));
+    }
     // LN2 backward -> dh = grad wrt h_mid, and on the same rows the gate step of the attention branch
     // (h_mid = h_in + g1 * (attn(u1) Wo^T + bo)): dbr = g1 * dh, dg1, dbo
     OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_mid, sv.stats2, w.du, m->ada, AC, base + 3 * D, base + 4 * D, dh, dh_other, w.dada,
-                               M, Tp, D, st, sv.br1, base + 2 * D, w.dbr, g_bo));
+                               M, Tp, D, st, sv.br1, base + 2 * D, w.dbr2, g_bo));
     OSUD_TRY(dbg_sync(st, "ln2 bwd + gate_bwd attn"));
     std::swap(dh, dh_other);
-    OSUD_TRY(gemm(m, EPI_NONE_TE, w.dbr, D, bw.w_o_t, D, Mp, D, D, w.dao, D, nullptr, st));
-    OSUD_TRY(weight_grad(m, w.dbr, D, sv.ao, D, D, D, Mp, G(p + "attn.out_proj.weight"), nullptr, st));
+    OSUD_TRY(gemm(m, EPI_NONE_TE, w.dbr2, D, bw.w_o_t, D, Mp, D, D, w.dao, D, nullptr, st));
+    if (!group_wg) {
+    OSUD_TRY(weight_grad(m, w.dbr2, D, sv.ao, D, D, D, Mp, G(p + "attn.out_proj.weight"), nullptr, st));
     OSUD_TRY(dbg_sync(st, "wgrad out_proj"));
+    }
     // (bf16 tier: the in_proj bias gradient is the attention backward's job -- inside the streamed kernel at T = 128, a column-sum
     //  pass over dqkv behind the other kernels; scratch: the split-K slab area, idle between two weight gradients)
     const bool fused_bqkv = prec == OSUD_PREC_BF16;
@@ -277,8 +302,14 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     else
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dqkv, 3 * D, bw.w_qkv_t, 3 * D, Mp, D, 3 * D, w.du, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "dgrad qkv"));
+    if (group_wg) {
+      const WgradItem items[2] = {{w.dqkv, sv.u1, G(p + "attn.in_proj_weight"), 3 * D, D, 3 * D, D},
+                                  {w.dbr2, sv.ao, G(p + "attn.out_proj.weight"), D, D, D, D}};
+      OSUD_TRY(wgrad_pair(items, "wgrad in_proj + out_proj (grouped)"));
+    } else {
     OSUD_TRY(weight_grad(m, w.dqkv, 3 * D, sv.u1, D, 3 * D, D, Mp, G(p + "attn.in_proj_weight"), fused_bqkv ? nullptr : g_bqkv, st));
     OSUD_TRY(dbg_sync(st, "wgrad qkv"));
+    }
     // LN1 backward -> dh = grad wrt h_in = grad wrt the output of block l-1, whose MLP gate step rides along
     if (l > 0) {
       const LayerSaved& svp = m->saved[(size_t)l - 1];
