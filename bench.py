@@ -134,9 +134,12 @@ def gemm_roofline(M, N, K, dev, iters=50):
     flops = 2.0 * M * N * K
     traffic, src = None, None
     try:  # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (not measurable in-process)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_fc1.json")))
-        traffic = pmc[f"M={M}"]["hbm_bytes_per_launch"]
-        src = "profiles/r02_pmc_fc1.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2 per the gfx950 note)"
+        if M == 32768:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["fc1_forward"]["hbm_bytes_per_launch"]
+            src = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2 per the gfx950 note)"
+        else:
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_fc1.json")))[f"M={M}"]["hbm_bytes_per_launch"]
+            src = "profiles/r02_pmc_fc1.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2 per the gfx950 note)"
     except Exception:
         pass
     return {"bound": "mfma", "kernel": "gemm_kernel<bf16, EPI_BIAS_GELU_TE> (fc1 %dx%dx%d)" % (M, N, K),
@@ -173,9 +176,17 @@ def wgrad_roofline(M, Ny, Nx, dev, iters=30):
     torch.cuda.synchronize()
     sec = e0.elapsed_time(e1) / 1e3 / iters
     flops = 2.0 * M * Ny * Nx
+    traffic, src = None, None
+    try:  # HBM bytes per launch (kernel + combine pass) from the committed rocprofv3 --pmc passes (not measurable in-process)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["wgrad_fc1"]
+        if pmc["M"] == M:
+            traffic = pmc["hbm_bytes_per_launch"]
+            src = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/wgrad_only.py, separate passes, read side x2 per the gfx950 note)"
+    except Exception:
+        pass
     return {"bound": "mfma", "kernel": "wgrad_kernel<2,4,4,2> + splitk_reduce_kernel (fc1 weight gradient %dx%d over %d tokens)" % (Ny, Nx, M),
             "achieved": round(flops / sec / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(flops / sec / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "frac": round(flops / sec / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
             "algorithmic_bytes": 2 * M * (Ny + Nx) + 4 * Ny * Nx, "flop_per_launch": flops, "avg_launch_us": round(sec * 1e6, 2)}
 
 
