@@ -60,15 +60,17 @@ def _cli_fixture(tmp_path):
     return fx, str(ckpt), str(idx)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("tag", ["full100", "trim250"])
-def test_sample_cli_with_cpu_noise_reproduces_the_reference_run(tmp_path, tag):
+def test_sample_cli_with_cpu_noise_reproduces_the_reference_run(tmp_path, tag, precision):
     """north_star: identical (seed, beatmap, num-sampling-steps) -> final (x, y) within 1e-3 of the reference's CPU path.
-    `sample.py --noise cpu --precision fp32` against fixture g12_cli_toy (the reference's sampling flow on the toy beatmap:
-    the whole 757-object map with 100 steps, and a 128-object window from t = 30 s with 250 steps; DiT-S, cfg-scale 4)."""
+    `sample.py --noise cpu --precision fp32 | bf16x3` against fixture g12_cli_toy (the reference's sampling flow on the toy beatmap:
+    the whole 757-object map with 100 steps -- banded attention mask, T not a multiple of 64 -- and a 128-object window from
+    t = 30 s with 250 steps; DiT-S, cfg-scale 4).  Both the exact-f32 tier and the split-bf16 tier (the MFMA-speed one) meet it."""
     fx, ckpt, idx = _cli_fixture(tmp_path)
     args = [os.path.join(ROOT, "sample.py"), "--beatmap", TOY, "--ckpt", ckpt, "--model", "DiT-S", "--num-classes", "10",
             "--num-sampling-steps", str(int(fx[tag + ":steps"])), "--cfg-scale", "4.0", "--seed", "0", "--seq-len", "128",
-            "--style-id", str(int(fx["style_id"])), "--beatmap-idx", idx, "--noise", "cpu", "--precision", "fp32"]
+            "--style-id", str(int(fx["style_id"])), "--beatmap-idx", idx, "--noise", "cpu", "--precision", precision]
     if tag + ":plot_time" in fx:
         args += ["--plot-time", str(float(fx[tag + ":plot_time"]))]
     out = run(args, str(tmp_path))
@@ -76,7 +78,7 @@ def test_sample_cli_with_cpu_noise_reproduces_the_reference_run(tmp_path, tag):
     saved = torch.load(glob.glob(os.path.join(str(tmp_path), "results", "*", "result.pt"))[0])  # (1, 19, T), positions in osu! pixels
     got = saved[:, :2] / torch.tensor([512.0, 384.0]).view(1, 2, 1)
     err = float((got - torch.from_numpy(fx[tag + ":final"])).abs().max())
-    print(f"sample.py --noise cpu --precision fp32 vs reference [{tag}]: max|d| = {err:.3e} (normalised coordinates)")
+    print(f"MEASURED cli[{tag},{precision}]: sample.py --noise cpu vs the reference's CPU run: max|d| = {err:.3e} (normalised coordinates)")
     assert err < 1e-3
 
 
