@@ -602,8 +602,9 @@ def parity_tier_and_drift(args, dev):
 XL_TIERS = ["bf16", "fp8"]
 PEAK_FP8_TFLOPS = 5000.0
 # share of a DiT block's GEMM FLOPs (forward + data gradients + weight gradients = 3 x 24 M D^2) the fp8 training tier runs on e4m3
-# operands: in_proj, fc1, fc2 forward and data-gradient products = 2 x 22 / 72; out_proj and the weight gradients stay bf16
-F8_SHARE = round(44.0 / 72.0, 4)
+# operands: in_proj, out_proj, fc1, fc2 -- forward, data-gradient AND weight-gradient products (round 3) = all of them; the attention
+# core, the adaLN product and the first linear (2 % of the FLOPs) stay bf16 and are not counted in the share
+F8_SHARE = 1.0
 FLOP_PER_TOKEN_TRAIN_XL = 2783.5e6  # DiT-XL, T=256
 
 

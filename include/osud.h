@@ -255,6 +255,11 @@ int osud_op_attention(int precision, const void* qkv, int ld_qkv, const uint8_t*
 int osud_op_wgrad(const void* P, int ldp, const void* Q, int ldq, int Ny, int Nx, int M, float* out, float* ws, size_t ws_elems,
                   osud_stream stream);
 
+/* The same product on OCP e4m3 operands (fp8 training, BASELINE config 5): P8 / Q8 are one byte per element, quantised with
+ * per-tensor scales; out = inv_p[0] * inv_q[0] * P8^T . Q8 with inv_* the operands' 1 / scale (DEVICE scalars).  M % 128 == 0. */
+int osud_op_wgrad8(const void* P8, int ldp, const void* Q8, int ldq, int Ny, int Nx, int M, float* out, float* ws, size_t ws_elems,
+                   const float* inv_p, const float* inv_q, osud_stream stream);
+
 /* Backward of the attention core in the training layout (T == Tp, T % 64 == 0, no mask): qkv [N*T][3*hidden], d_out / out [N*T][hidden],
  * lse [N][heads][T] as saved by the training forward (log2 domain in the bf16 tier, natural log in the f32 tier) -> dqkv [N*T][3*hidden].
  * delta_ws: [N][heads][T] floats of scratch, needed when a head's sequence does not fit the LDS (T > 256); may be NULL otherwise. */

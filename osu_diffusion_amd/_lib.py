@@ -82,6 +82,7 @@ _SIGNATURES = {
     "osud_set_gemm_dynamic_tiles": (_i, [_i]),
     "osud_op_attention": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "osud_op_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "osud_op_wgrad8": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
     "osud_op_attention_bwd": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
 }
 

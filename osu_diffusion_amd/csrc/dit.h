@@ -30,8 +30,8 @@ struct BlockWeights {
   // transposed copies ([in][out]) for the data-gradient products (training only)
   void *w_qkv_t = nullptr, *w_o_t = nullptr, *w1_t = nullptr, *w2_t = nullptr;
   // fp8 training: e4m3 copies of the transposed weights (quantised per row = per output column of the data-gradient product)
-  void *w_qkv_t8 = nullptr, *w1_t8 = nullptr, *w2_t8 = nullptr;
-  float *dq_qkv_t = nullptr, *dq_1_t = nullptr, *dq_2_t = nullptr;
+  void *w_qkv_t8 = nullptr, *w1_t8 = nullptr, *w2_t8 = nullptr, *w_o_t8 = nullptr;
+  float *dq_qkv_t = nullptr, *dq_1_t = nullptr, *dq_2_t = nullptr, *dq_o_t = nullptr;
 };
 
 // per-layer activations kept for the backward pass (training only)
@@ -43,7 +43,13 @@ struct LayerSaved {
   void *u1 = nullptr, *qk = nullptr /* [Mp][3D] q|k|v */, *ao = nullptr, *u2 = nullptr, *z1 = nullptr /* gelu'(fc1 pre-activation) */,
        *g = nullptr, *br1 = nullptr /* attention branch output */, *br2 = nullptr /* MLP branch output */;
   float* lse = nullptr;  // [N][H][Tp]
+  // fp8 training: the e4m3 twins of this layer's GEMM inputs, kept for the weight-gradient products of the backward pass
+  // (u1 -> in_proj, ao -> out_proj, u2 -> fc1, g -> fc2); each quantised with its slot's delayed scale of THIS step
+  void *u1_8 = nullptr, *ao_8 = nullptr, *u2_8 = nullptr, *g_8 = nullptr;
 };
+// fp8 training: quantised tensors (= delayed-scale slots) per block:
+//   0 u1 (LN1 out)  1 u2 (LN2 out)  2 g (GELU out)  3 d(MLP branch)  4 d(fc1 pre-activation)  5 dqkv  6 ao (attention out)  7 d(attention branch)
+constexpr int kF8Slots = 8;
 
 // workspaces of the backward pass
 struct BwdWs {
@@ -131,7 +137,7 @@ struct osud_dit {
   // dqkv), each with a slot {scale in use, 1/scale, amax seen this step, -}; e4m3 staging buffers [Mp][D] and [Mp][4D]
   float* f8_slots = nullptr;
   float* f8_parts = nullptr;  // [slots][f8_amax_parts()] per-workgroup partial maxima of producers that do not use the slot's atomic word
-  void *q8a = nullptr, *q8b = nullptr;
+  void *q8a = nullptr, *q8b = nullptr, *q8c = nullptr;  // q8c [Mp][D]: d(attention branch)
   // fp8 INFERENCE: per-block activation scales {LN1 out, attention out, LN2 out, GELU out}; defaults are the static constants, 
   // osud_dit_calibrate_fp8 replaces them by 448 / (2 * amax) measured on the caller's batch
   std::vector<float> f8_inf;

@@ -83,15 +83,22 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
       OSUD_TRY(dev_alloc(W, &s.br1, (size_t)Mp * D * es));
       OSUD_TRY(dev_alloc(W, &s.br2, (size_t)Mp * D * es));
       OSUD_TRY(dev_alloc(W, &s.lse, (size_t)nN * m->H * Tp * 4));
+      if (m->fp8) {
+        OSUD_TRY(dev_alloc(W, &s.u1_8, (size_t)Mp * D));
+        OSUD_TRY(dev_alloc(W, &s.ao_8, (size_t)Mp * D));
+        OSUD_TRY(dev_alloc(W, &s.u2_8, (size_t)Mp * D));
+        OSUD_TRY(dev_alloc(W, &s.g_8, (size_t)Mp * 4 * D));
+      }
     }
     m->h = m->saved[0].h_in;
     m->training = true;
     if (m->fp8) {  // fp8 training: e4m3 staging of the GEMM operands + the scale slots (scale 1 until a history exists)
       OSUD_TRY(dev_alloc(W, &m->q8a, (size_t)Mp * D));
       OSUD_TRY(dev_alloc(W, &m->q8b, (size_t)Mp * 4 * D));
-      OSUD_TRY(dev_alloc(W, &m->f8_slots, (size_t)m->L * 6 * 4 * sizeof(float)));
-      OSUD_TRY(dev_alloc(W, &m->f8_parts, (size_t)m->L * 6 * f8_amax_parts() * sizeof(float)));  // (zeroed)
-      std::vector<float> init((size_t)m->L * 6 * 4, 0.f);
+      OSUD_TRY(dev_alloc(W, &m->q8c, (size_t)Mp * D));
+      OSUD_TRY(dev_alloc(W, &m->f8_slots, (size_t)m->L * kF8Slots * 4 * sizeof(float)));
+      OSUD_TRY(dev_alloc(W, &m->f8_parts, (size_t)m->L * kF8Slots * f8_amax_parts() * sizeof(float)));  // (zeroed)
+      std::vector<float> init((size_t)m->L * kF8Slots * 4, 0.f);
       for (size_t i = 0; i < init.size(); i += 4) init[i] = init[i + 1] = 1.0f;
       OSUD_HIP(hipMemcpy(m->f8_slots, init.data(), init.size() * sizeof(float), hipMemcpyHostToDevice));
       m->f8_steps = 0;
@@ -156,15 +163,16 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
   OSUD_CHECK_ARG(!cfg || N % 2 == 0, "forward_with_cfg: batch must be [cond; uncond] halves, got N=%d", N);
   OSUD_CHECK_ARG(!save || m->training, "forward(save): workspaces were not reserved for training");
   OSUD_TRY(dit_ensure_ws(m, N, T, m->training));
-  // fp8 TRAINING (BASELINE config 5): qkv / fc1 / fc2 of every block on e4m3 operands with delayed per-tensor scaling -- a
-  // tensor is quantised with the scale derived from the amax it showed in the previous step (launch_f8_update, once per
-  // forward).  The very first training forward has no history: it runs its GEMMs in bf16 and only records.  Weights carry
-  // per-output-channel scales.  out_proj (1/12 of a block's FLOPs) and every weight gradient stay bf16.
+  // fp8 TRAINING (BASELINE config 5): in_proj / out_proj / fc1 / fc2 of every block on e4m3 operands with delayed per-tensor
+  // scaling -- a tensor is quantised with the scale derived from the amax it showed in the previous step (launch_f8_update,
+  // once per forward).  The very first training forward has no history: it runs its GEMMs in bf16 and only records.  Weights
+  // carry per-output-channel scales.  The e4m3 twins of the four GEMM inputs stay in per-layer buffers: the backward pass
+  // forms the weight gradients from them (wgrad8_kernel).
   const bool f8_train = m->fp8 && save;
   const bool f8_live = f8_train && m->f8_steps > 0;
-  if (f8_train) OSUD_TRY(launch_f8_update(m->f8_slots, m->L * 6, st, m->f8_parts));
-  auto slot = [&](int l, int which) { return m->f8_slots + ((size_t)l * 6 + which) * 4; };
-  auto parts = [&](int l, int which) { return m->f8_parts + ((size_t)l * 6 + which) * f8_amax_parts(); };
+  if (f8_train) OSUD_TRY(launch_f8_update(m->f8_slots, m->L * kF8Slots, st, m->f8_parts));
+  auto slot = [&](int l, int which) { return m->f8_slots + ((size_t)l * kF8Slots + which) * 4; };
+  auto parts = [&](int l, int which) { return m->f8_parts + ((size_t)l * kF8Slots + which) * f8_amax_parts(); };
   // fp8 inference: per-block activation scales (static defaults, or calibrated: osud_dit_calibrate_fp8)
   if (m->fp8 && m->f8_inf.empty()) {
     m->f8_inf.resize((size_t)m->L * 4);
@@ -235,12 +243,12 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
       // (fp8 training: LayerNorm writes the e4m3 twin of its output and this step's amax itself)
       if (f8_train)
         OSUD_TRY(launch_ln_mod_twin(h, m->ada, AC, base, base + D, u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st, pend, pend_gate,
-                                    pend ? h_in : nullptr, f8_live ? m->q8a : nullptr, slot(l, 0), parts(l, 0)));
+                                    pend ? h_in : nullptr, f8_live ? sv->u1_8 : nullptr, slot(l, 0), parts(l, 0)));
       else
       OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base, base + D, u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st, pend,
                              pend_gate, pend ? h_in : nullptr));
       // packed in_proj: one 3D-wide product, Q | K | V row-major (the attention kernels transpose V on the LDS read)
-      if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_TE, m->q8a, w.w8_qkv, Mp, qcols, D, qk, qcols, w.b_qkv, w.dq_qkv, 0.f, st, nullptr, 0, 0, 0, 0.f,
+      if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_TE, sv->u1_8, w.w8_qkv, Mp, qcols, D, qk, qcols, w.b_qkv, w.dq_qkv, 0.f, st, nullptr, 0, 0, 0, 0.f,
                                   slot(l, 0) + 1));
       else
       OSUD_TRY(gemm(m, EPI_BIAS_TE, u1, D, w.w_qkv, D, Mp, qcols, D, qk, qcols, w.b_qkv, st));
@@ -269,22 +277,27 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
       OSUD_TRY(gemm(m, EPI_GATE_RES, g, 4 * D, w.w2, 4 * D, Mp, D, 4 * D, h, D, w.b2, st, m->ada + base + 5 * D, AC, Tp, N));
       continue;
     }
+    if (f8_train) {  // attention output: e4m3 twin for out_proj (forward here, weight gradient in the backward pass) + this step's amax
+      OSUD_TRY(launch_f8_quantize(ao, f8_live ? sv->ao_8 : nullptr, (size_t)Mp * D, slot(l, 6), st));
+    }
+    if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_TE, sv->ao_8, w.w8_o, Mp, D, D, br1, D, w.b_o, w.dq_o, 0.f, st, nullptr, 0, 0, 0, 0.f, slot(l, 6) + 1));
+    else
     OSUD_TRY(gemm(m, EPI_BIAS_TE, ao, D, w.w_o, D, Mp, D, D, br1, D, w.b_o, st));
     if (f8_train)
       OSUD_TRY(launch_ln_mod_twin(h_in, m->ada, AC, base + 3 * D, base + 4 * D, u2, sv->stats2, Mp, Tp, N, D, st, br1, base + 2 * D,
-                                  h_mid, f8_live ? m->q8a : nullptr, slot(l, 1), parts(l, 1)));
+                                  h_mid, f8_live ? sv->u2_8 : nullptr, slot(l, 1), parts(l, 1)));
     else
     OSUD_TRY(launch_ln_mod(prec, h_in, m->ada, AC, base + 3 * D, base + 4 * D, u2, sv->stats2, Mp, Tp, N, D, st, br1,
                            base + 2 * D, h_mid));
     if (f8_train) {
       // (live steps: the fc1 epilogue writes the e4m3 twin of its GELU output and records its amax itself)
-      if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_GELU_BF, m->q8a, w.w8_1, Mp, 4 * D, D, g, 4 * D, w.b1, w.dq_1, 0.f, st, nullptr, 0, 0, 0, 0.f,
-                                  slot(l, 1) + 1, sv->z1, nullptr, nullptr, nullptr, m->q8b, slot(l, 2)));
+      if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_GELU_BF, sv->u2_8, w.w8_1, Mp, 4 * D, D, g, 4 * D, w.b1, w.dq_1, 0.f, st, nullptr, 0, 0, 0, 0.f,
+                                  slot(l, 1) + 1, sv->z1, nullptr, nullptr, nullptr, sv->g_8, slot(l, 2)));
       else {
         OSUD_TRY(gemm(m, EPI_BIAS_GELU_TE, u2, D, w.w1, D, Mp, 4 * D, D, g, 4 * D, w.b1, st, nullptr, 0, 0, 0, sv->z1));
         OSUD_TRY(launch_f8_quantize(g, nullptr, (size_t)Mp * 4 * D, slot(l, 2), st));
       }
-      if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_TE, m->q8b, w.w8_2, Mp, D, 4 * D, br2, D, w.b2, w.dq_2, 0.f, st, nullptr, 0, 0, 0, 0.f,
+      if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_TE, sv->g_8, w.w8_2, Mp, D, 4 * D, br2, D, w.b2, w.dq_2, 0.f, st, nullptr, 0, 0, 0, 0.f,
                                   slot(l, 2) + 1));
       else OSUD_TRY(gemm(m, EPI_BIAS_TE, g, 4 * D, w.w2, 4 * D, Mp, D, 4 * D, br2, D, w.b2, st));
     } else {
@@ -731,6 +744,11 @@ extern "C" int osud_op_wgrad(const void* P, int ldp, const void* Q, int ldq, int
                              osud_stream stream) {
   OSUD_CHECK_ARG(P && Q && out && ws, "op_wgrad: null argument");
   return launch_wgrad_tr(P, ldp, Q, ldq, Ny, Nx, M, out, ws, ws_elems, (hipStream_t)stream);
+}
+extern "C" int osud_op_wgrad8(const void* P8, int ldp, const void* Q8, int ldq, int Ny, int Nx, int M, float* out, float* ws, size_t ws_elems,
+                              const float* inv_p, const float* inv_q, osud_stream stream) {
+  OSUD_CHECK_ARG(P8 && Q8 && out && ws, "op_wgrad8: null argument");
+  return launch_wgrad8_tr(P8, ldp, Q8, ldq, Ny, Nx, M, out, ws, ws_elems, inv_p, inv_q, (hipStream_t)stream);
 }
 extern "C" int osud_op_attention(int precision, const void* qkv, int ld_qkv, const uint8_t* mask, void* out, int N,
                                  int T, int Tp, int Mp, int heads, int head_dim, osud_stream stream) {

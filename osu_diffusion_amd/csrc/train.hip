@@ -57,6 +57,7 @@ int build_transposed(osud_dit* m, hipStream_t st) {
         return launch_quantize_rows_bf16(src, rows, cols, *q, *dq, st);
       };
       OSUD_TRY(Q8(b.w_qkv_t, D, 3 * D, &b.w_qkv_t8, &b.dq_qkv_t));
+      OSUD_TRY(Q8(b.w_o_t, D, D, &b.w_o_t8, &b.dq_o_t));
       OSUD_TRY(Q8(b.w1_t, D, 4 * D, &b.w1_t8, &b.dq_1_t));
       OSUD_TRY(Q8(b.w2_t, 4 * D, D, &b.w2_t8, &b.dq_2_t));
     }
@@ -223,7 +224,12 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     // fp8 training: the data-gradient products of fc2, fc1 and in_proj run on e4m3 operands (gradient tensors quantised with the
     // scale from their previous step's amax, transposed weights per row); the very first step only records (see dit_forward_impl)
     const bool f8_train = m->fp8, f8_live = m->fp8 && m->f8_steps > 1;
-    auto slot = [&](int which) { return m->f8_slots + ((size_t)l * 6 + which) * 4; };
+    auto slot = [&](int which) { return m->f8_slots + ((size_t)l * kF8Slots + which) * 4; };
+    // fp8 training, live steps: a weight gradient from the e4m3 twins of its two operands (twice the bf16 kernel's rate); dW is
+    // de-quantised by the two slots' 1 / scale.  P8: the gradient twin in its staging buffer, Q8: the layer's saved activation twin
+    auto weight_grad8 = [&](const void* P8, int ldp, int slot_p, const void* Q8, int ldq, int slot_q, int Ny, int Nx, float* dW) -> int {
+      return launch_wgrad8_tr(P8, ldp, Q8, ldq, Ny, Nx, Mp, dW, w.splitk, w.splitk_elems, slot(slot_p) + 1, slot(slot_q) + 1, st);
+    };
     {
       int part_rows = 0;
       // (the e4m3 twin of dbr and its amax come from the kernel that produced dbr -- the LN1 backward of block l + 1 -- except
@@ -269,7 +275,11 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
         for (const WgradItem& it : items) OSUD_TRY(weight_grad(m, it.P, it.ldp, it.Q, it.ldq, it.Ny, it.Nx, Mp, it.out, nullptr, st));
       return dbg_sync(st, what);
     };
-    if (group_wg) {
+    if (f8_live && fused_b1 && Mp % 128 == 0) {  // (q8b = dz1's twin, q8a = the MLP branch gradient's: both still in place)
+      OSUD_TRY(weight_grad8(m->q8b, 4 * D, 4, sv.u2_8, D, 1, 4 * D, D, G(p + "mlp.fc1.weight")));
+      OSUD_TRY(weight_grad8(m->q8a, D, 3, sv.g_8, 4 * D, 2, D, 4 * D, G(p + "mlp.fc2.weight")));
+      OSUD_TRY(dbg_sync(st, "wgrad fc1, fc2 (e4m3)"));
+    } else if (group_wg) {
       const WgradItem items[2] = {{w.dz1, sv.u2, G(p + "mlp.fc1.weight"), 4 * D, D, 4 * D, D},
                                   {w.dbr, sv.g, G(p + "mlp.fc2.weight"), D, 4 * D, D, 4 * D}};
       OSUD_TRY(wgrad_pair(items, "wgrad fc1 + fc2 (grouped)"));
@@ -281,12 +291,19 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     }
     // LN2 backward -> dh = grad wrt h_mid, and on the same rows the gate step of the attention branch
     // (h_mid = h_in + g1 * (attn(u1) Wo^T + bo)): dbr = g1 * dh, dg1, dbo
+    // (fp8 training: the attention branch's gradient gets its e4m3 twin -- q8c -- and amax from this kernel too)
     OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_mid, sv.stats2, w.du, m->ada, AC, base + 3 * D, base + 4 * D, dh, dh_other, w.dada,
-                               M, Tp, D, st, sv.br1, base + 2 * D, w.dbr2, g_bo));
+                               M, Tp, D, st, sv.br1, base + 2 * D, w.dbr2, g_bo, f8_live ? m->q8c : nullptr, f8_train ? slot(7) : nullptr,
+                               f8_train ? m->f8_parts + ((size_t)l * kF8Slots + 7) * f8_amax_parts() : nullptr));
     OSUD_TRY(dbg_sync(st, "ln2 bwd + gate_bwd attn"));
     std::swap(dh, dh_other);
+    if (f8_live) OSUD_TRY(gemm8(m, EPI_NONE_TE, m->q8c, bw.w_o_t8, Mp, D, D, w.dao, D, nullptr, bw.dq_o_t, 0.f, st, nullptr, 0, 0, 0, 0.f, slot(7) + 1));
+    else
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dbr2, D, bw.w_o_t, D, Mp, D, D, w.dao, D, nullptr, st));
-    if (!group_wg) {
+    if (f8_live && Mp % 128 == 0) {
+      OSUD_TRY(weight_grad8(m->q8c, D, 7, sv.ao_8, D, 6, D, D, G(p + "attn.out_proj.weight")));
+      OSUD_TRY(dbg_sync(st, "wgrad out_proj (e4m3)"));
+    } else if (!group_wg) {
     OSUD_TRY(weight_grad(m, w.dbr2, D, sv.ao, D, D, D, Mp, G(p + "attn.out_proj.weight"), nullptr, st));
     OSUD_TRY(dbg_sync(st, "wgrad out_proj"));
     }
@@ -302,7 +319,10 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     else
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dqkv, 3 * D, bw.w_qkv_t, 3 * D, Mp, D, 3 * D, w.du, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "dgrad qkv"));
-    if (group_wg) {
+    if (f8_live && fused_bqkv && Mp % 128 == 0) {  // (q8b = dqkv's twin)
+      OSUD_TRY(weight_grad8(m->q8b, 3 * D, 5, sv.u1_8, D, 0, 3 * D, D, G(p + "attn.in_proj_weight")));
+      OSUD_TRY(dbg_sync(st, "wgrad in_proj (e4m3)"));
+    } else if (group_wg) {
       const WgradItem items[2] = {{w.dqkv, sv.u1, G(p + "attn.in_proj_weight"), 3 * D, D, 3 * D, D},
                                   {w.dbr2, sv.ao, G(p + "attn.out_proj.weight"), D, D, D, D}};
       OSUD_TRY(wgrad_pair(items, "wgrad in_proj + out_proj (grouped)"));
@@ -314,11 +334,11 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     if (l > 0) {
       const LayerSaved& svp = m->saved[(size_t)l - 1];
       const int basep = (l - 1) * 6 * D;
-      float* slot_prev = m->f8_slots + ((size_t)(l - 1) * 6 + 3) * 4;  // fp8 training: block l - 1's dbr slot
+      float* slot_prev = m->f8_slots + ((size_t)(l - 1) * kF8Slots + 3) * 4;  // fp8 training: block l - 1's dbr slot
       OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_in, sv.stats1, w.du, m->ada, AC, base, base + D, dh, dh_other, w.dada, M, Tp, D,
                                  st, svp.br2, basep + 5 * D, w.dbr, G("blocks." + std::to_string(l - 1) + ".mlp.fc2.bias"),
                                  f8_live ? m->q8a : nullptr, f8_train ? slot_prev : nullptr,
-                                 f8_train ? m->f8_parts + ((size_t)(l - 1) * 6 + 3) * f8_amax_parts() : nullptr));
+                                 f8_train ? m->f8_parts + ((size_t)(l - 1) * kF8Slots + 3) * f8_amax_parts() : nullptr));
     } else {
       OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_in, sv.stats1, w.du, m->ada, AC, base, base + D, dh, dh_other, w.dada, M, Tp, D,
                                  st));

@@ -641,6 +641,183 @@ __global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(WgradGroupP p) 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Weight gradients on e4m3 operands (fp8 training, BASELINE config 5):  out[y][x] = inv_p * inv_q * sum_m P8[m][y0 + y] * Q8[m][x0 + x]
+// P8 / Q8 are the e4m3 twins of the gradient / activation tensors (token-major, one byte per element, each quantised with its
+// slot's delayed scale; inv_p / inv_q = the slots' 1 / scale, device scalars).  Same structure as wgrad_kernel -- stages by
+// LDS-DMA, counted waits, one barrier per stage, 8 waves of 128 x 64 outputs, split over the token axis into fp32 partial slabs --
+// with 128 tokens per 64 KiB stage and the block-scaled K = 64 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, unit scales: twice the
+// bf16 rate).  The MFMA wants 32 consecutive tokens of one feature per lane; gfx950's ds_read_b64_tr_b8 delivers 8 of them from
+// the token-major tile: a 16-lane group reads an 8-token x 16-feature block (lanes 2j, 2j + 1 point at the two 8-byte halves of
+// token j's 16 bytes) and lane i receives feature i's 8 tokens (semantics pinned on hardware by tools/probes/tr8_probe.hip); four
+// such reads make a lane's operand.  Token rows are 256 bytes (256 features); the 16-byte chunk index of a row is XOR-swizzled
+// with (token & 7) << 1 on the source side of the LDS-DMA, so the 8 token rows of a transposing read -- and the neighbouring
+// feature block the other 16-lane group of the same cycle reads -- fall on 16 different chunks: conflict free.
+constexpr int BKT8 = 128;  // tokens per stage
+template <int OFF> __device__ __forceinline__ u32x2 ds_read_tr8(uint32_t addr) {
+  u32x2 v;
+  asm volatile("ds_read_b64_tr_b8 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+typedef int i32x8w __attribute__((ext_vector_type(8)));
+
+struct Wgrad8P {
+  const uint8_t* P;
+  const uint8_t* Q;
+  int ldp, ldq;   // elements = bytes
+  int Ny, Nx, M;
+  float* out;     // [splits][Ny][Nx] fp32 (already multiplied by inv_p * inv_q)
+  int split_k;
+  size_t split_stride;
+  const float* inv_p;
+  const float* inv_q;
+};
+
+__global__ __launch_bounds__(512) void wgrad8_kernel(Wgrad8P p) {
+  constexpr int WX = 4, RY = 4, RX = 2, BM = 256, BN = 256, NW = 8, ROW = 256;
+  constexpr int YB = BKT8 * ROW, STAGE = 2 * YB, NSTAGE = 2, PPW = STAGE / 1024 / NW;  // 32 KiB + 32 KiB per stage, 8 pieces per wave
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wy = wave / WX, wx = wave % WX;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int ntx = (p.Nx + BN - 1) / BN, ntiles = ((p.Ny + BM - 1) / BM) * ntx;
+  const int st_total = p.M / BKT8;
+  // units in split-major order, one contiguous run per XCD (see WgradP::xcd_units)
+  int sidx, bx;
+  {
+    const int total = gridDim.x * gridDim.y, L = blockIdx.x + blockIdx.y * gridDim.x;
+    const int q = total >> 3, r = total & 7, xcd = L & 7, idx = L >> 3;
+    const int u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    sidx = u / (int)gridDim.x;
+    bx = u - sidx * (int)gridDim.x;
+  }
+  const int st_begin = (int)((long)sidx * st_total / p.split_k);
+  const int nst = (int)((long)(sidx + 1) * st_total / p.split_k) - st_begin;
+  const int ty = bx / ntx, tx = bx - ty * ntx;
+  const size_t ldp_b = (size_t)p.ldp, ldq_b = (size_t)p.ldq;
+  const char* gp0 = reinterpret_cast<const char*>(p.P) + (size_t)st_begin * BKT8 * ldp_b + (size_t)ty * BM;
+  const char* gq0 = reinterpret_cast<const char*>(p.Q) + (size_t)st_begin * BKT8 * ldq_b + (size_t)tx * BN;
+  float* outp = p.out + (size_t)sidx * p.split_stride;
+
+  // fragment addresses: lane (idx = lane & 15, fblock = (lane >> 4) & 1, khalf = lane >> 5) reads, for k-step ks and quarter q,
+  // token ks * 64 + khalf * 32 + 8 q + (idx >> 1), bytes (idx & 1) * 8 .. + 7 of 16-byte chunk (block * 2 + fblock) ^ ((idx >> 1) << 1)
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_void*)smem;
+  const int idx16 = lane & 15, fblock = (lane >> 4) & 1, trow = idx16 >> 1;
+  const uint32_t lane_base = (uint32_t)((fhalf * 32 + trow) * ROW + (idx16 & 1) * 8);
+  uint32_t ya[RY], xa[RX];
+#pragma unroll
+  for (int i = 0; i < RY; ++i) ya[i] = lds0 + lane_base + ((((wy * RY + i) * 2 + fblock) ^ (trow << 1)) << 4);
+#pragma unroll
+  for (int j = 0; j < RX; ++j) xa[j] = lds0 + YB + lane_base + ((((wx * RX + j) * 2 + fblock) ^ (trow << 1)) << 4);
+
+  // LDS-DMA: piece = 1 KiB = 4 token rows; lane l -> row (l >> 4) of the piece, LDS position l & 15, source chunk = position ^ ((token & 7) << 1)
+  uint32_t dma_off[PPW];
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    const int piece = wave * PPW + q;
+    const bool isY = piece * 1024 < YB;
+    const int pb = isY ? piece * 1024 : piece * 1024 - YB;
+    const int tok = pb / ROW + (lane >> 4), pos = lane & 15;
+    const int c = pos ^ ((tok & 7) << 1);
+    dma_off[q] = (uint32_t)((size_t)tok * (isY ? ldp_b : ldq_b) + c * 16);
+  }
+  const uint32_t patch = lds0 + NSTAGE * STAGE + wave * 4096;
+  uint32_t pw[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) pw[g] = patch + frow * 128 + (((2 * g + fhalf) ^ (frow & 7)) << 4);
+  const uint32_t pr = patch + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+
+  int issued = 0, consumed = 0, ic_st = 0;
+  auto issue_next = [&]() {
+    if (ic_st >= nst) return;
+    const char* gp = gp0 + (size_t)ic_st * BKT8 * ldp_b;
+    const char* gq = gq0 + (size_t)ic_st * BKT8 * ldq_b;
+    const uint32_t stage_lds = lds0 + (uint32_t)((issued % NSTAGE) * STAGE);
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const int piece = wave * PPW + q;
+      const char* sbase = (piece * 1024 < YB) ? gp : gq;
+      const uint32_t dst = stage_lds + (uint32_t)__builtin_amdgcn_readfirstlane(piece * 1024);
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(dma_off[q]), "s"(sbase), "s"(dst) : "memory");
+    }
+    ++issued;
+    ++ic_st;
+  };
+  issue_next();
+
+  f32x16 acc[RY][RX];
+#pragma unroll
+  for (int i = 0; i < RY; ++i)
+#pragma unroll
+    for (int j = 0; j < RX; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  for (int st = 0; st < nst; ++st) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue_next();
+    const uint32_t so = (uint32_t)((consumed % NSTAGE) * STAGE);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {  // two K = 64 steps per 128-token stage
+      u32x2 yf[RY][4], xf[RX][4];
+#pragma unroll
+      for (int i = 0; i < RY; ++i) {
+        if (ks == 0) { yf[i][0] = ds_read_tr8<0 * ROW>(ya[i] + so); yf[i][1] = ds_read_tr8<8 * ROW>(ya[i] + so); yf[i][2] = ds_read_tr8<16 * ROW>(ya[i] + so); yf[i][3] = ds_read_tr8<24 * ROW>(ya[i] + so); }
+        else { yf[i][0] = ds_read_tr8<64 * ROW>(ya[i] + so); yf[i][1] = ds_read_tr8<72 * ROW>(ya[i] + so); yf[i][2] = ds_read_tr8<80 * ROW>(ya[i] + so); yf[i][3] = ds_read_tr8<88 * ROW>(ya[i] + so); }
+      }
+#pragma unroll
+      for (int j = 0; j < RX; ++j) {
+        if (ks == 0) { xf[j][0] = ds_read_tr8<0 * ROW>(xa[j] + so); xf[j][1] = ds_read_tr8<8 * ROW>(xa[j] + so); xf[j][2] = ds_read_tr8<16 * ROW>(xa[j] + so); xf[j][3] = ds_read_tr8<24 * ROW>(xa[j] + so); }
+        else { xf[j][0] = ds_read_tr8<64 * ROW>(xa[j] + so); xf[j][1] = ds_read_tr8<72 * ROW>(xa[j] + so); xf[j][2] = ds_read_tr8<80 * ROW>(xa[j] + so); xf[j][3] = ds_read_tr8<88 * ROW>(xa[j] + so); }
+      }
+      OSUD_WG_WAIT(0);
+#pragma unroll
+      for (int i = 0; i < RY; ++i) {
+        i32x8w yv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { yv[2 * q] = (int)yf[i][q][0]; yv[2 * q + 1] = (int)yf[i][q][1]; }
+#pragma unroll
+        for (int j = 0; j < RX; ++j) {
+          i32x8w xv;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { xv[2 * q] = (int)xf[j][q][0]; xv[2 * q + 1] = (int)xf[j][q][1]; }
+          acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(xv, yv, acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        }
+      }
+    }
+    ++consumed;
+  }
+  const float dq = p.inv_p[0] * p.inv_q[0];
+#pragma unroll
+  for (int i = 0; i < RY; ++i) {
+    const int y0 = ty * BM + wy * RY * 32 + i * 32 + (lane >> 3);
+#pragma unroll
+    for (int j = 0; j < RX; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 v;
+        v[0] = acc[i][j][4 * g + 0] * dq; v[1] = acc[i][j][4 * g + 1] * dq; v[2] = acc[i][j][4 * g + 2] * dq; v[3] = acc[i][j][4 * g + 3] * dq;
+        ds_write16(pw[g], v);
+      }
+      f32x4 t[4];
+      t[0] = ds_read16f<0>(pr);
+      t[1] = ds_read16f<1024>(pr);
+      t[2] = ds_read16f<2048>(pr);
+      t[3] = ds_read16f<3072>(pr);
+      OSUD_WG_WAIT(0);
+      const int x = tx * BN + wx * RX * 32 + j * 32 + 4 * (lane & 7);
+      if (x < p.Nx) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (y0 + 8 * q < p.Ny) store4(outp + (size_t)(y0 + 8 * q) * p.Nx + x, t[q][0], t[q][1], t[q][2], t[q][3]);
+      }
+    }
+  }
+}
+
 // column sums of a bf16 [M][N] matrix: out[c] += sum_m a[m][c]   (bias gradients).  HBM-bound: a workgroup sweeps
 // 256 rows x 256 columns with 16-byte loads (32 lanes = one 512-byte row segment, 8 rows per pass, 4 passes in
 // flight), combines its 8 row groups through LDS and issues one atomic per column.
@@ -821,6 +998,34 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
   return OSUD_OK;
 }
 
+
+
+// out[Ny][Nx] (fp32) = inv_p * inv_q * P8[:, 0:Ny]^T . Q8[:, 0:Nx] over M tokens, e4m3 operands (see wgrad8_kernel); `ws`: split-K slabs
+int launch_wgrad8_tr(const void* P8, int ldp, const void* Q8, int ldq, int Ny, int Nx, int M, float* out, float* ws, size_t ws_elems,
+                     const float* inv_p, const float* inv_q, hipStream_t st) {
+  OSUD_CHECK_ARG(Ny % 128 == 0 && Nx % 128 == 0 && M % BKT8 == 0 && ldp % 16 == 0 && ldq % 16 == 0 && inv_p && inv_q,
+                 "wgrad8: Ny=%d Nx=%d must be multiples of 128, M=%d of 128, leading dimensions of 16", Ny, Nx, M);
+  const int cus = num_cus_w();
+  const int tiles = ((Ny + 255) / 256) * ((Nx + 255) / 256);
+  const int stages = M / BKT8;
+  int S = cus / tiles;
+  if (S > 32) S = 32;
+  while (S > 1 && (stages / S < 4 || (size_t)S * Ny * Nx > ws_elems)) --S;
+  if (S < 1) S = 1;
+  Wgrad8P p{};
+  p.P = (const uint8_t*)P8; p.Q = (const uint8_t*)Q8; p.ldp = ldp; p.ldq = ldq; p.Ny = Ny; p.Nx = Nx; p.M = M;
+  p.split_k = S; p.split_stride = (size_t)Ny * Nx; p.out = S > 1 ? ws : out; p.inv_p = inv_p; p.inv_q = inv_q;
+  constexpr size_t lds = 2 * 65536 + 8 * 4096;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(wgrad8_kernel, dim3(tiles, S), dim3(512), lds, st, p);
+  OSUD_HIP(hipGetLastError());
+  if (S > 1) OSUD_TRY(launch_splitk_reduce(ws, S, (size_t)Ny * Nx, out, (size_t)Ny * Nx, st));
+  return OSUD_OK;
+}
 
 // The weight gradients of one block in one launch (see wgrad_group_kernel).  Returns OSUD_OK with *done = false when the group does
 // not qualify (then the caller launches the products one by one): bf16 tier only, every side a multiple of 256, the GPU not

@@ -147,3 +147,36 @@ def test_fp8_training_reduces_the_loss_like_bf16():
     first, last8, last16 = (sum(curves["bf16"][:10]) / 10), sum(curves["fp8"][-10:]) / 10, sum(curves["bf16"][-10:]) / 10
     print(f"L1 term, first 10 steps (bf16) {first:.4f}; last 10 steps: bf16 {last16:.4f}, fp8 {last8:.4f}")
     assert last8 < first and abs(last8 - last16) < 0.05 * last16
+
+
+@pytest.mark.parametrize("M,Ny,Nx,ldp,ldq", [(1024, 256, 256, 256, 256), (4096, 1152, 3456, 3456 + 1152, 3456), (32768, 768, 256, 768, 256),
+                                              (2048, 3456, 1152, 3456, 1152), (512, 128, 384, 128, 384)])
+def test_weight_gradient_on_e4m3_operands(M, Ny, Nx, ldp, ldq):
+    """osud_op_wgrad8 (csrc/wgrad.hip: wgrad8_kernel -- transposing byte reads feeding the K = 64 block-scaled MFMA): the product of
+    the e4m3 values themselves is exact in fp32 up to summation order, so the result must equal an fp64 product of the SAME quantised
+    operands to fp32 noise -- any mistake in the token / feature mapping of the transposing reads shows as O(1) error.  Shapes: edge
+    tiles (1152 = 4.5 x 256, 384), sub-matrix leading dimensions, one and many splits over the token axis, asymmetric operands."""
+    torch.manual_seed(M + Ny)
+    P = torch.randn(M, ldp, device=DEV) * 0.02
+    Q = torch.randn(M, ldq, device=DEV)
+    sp, sq = 448.0 / (2 * float(P.abs().max())), 448.0 / (2 * float(Q.abs().max()))
+    # (one spare row behind each operand: the 256-wide edge tiles stage up to 128 bytes past the last row's end; the library's own
+    #  buffers carry that slack -- csrc/dit.h dev_alloc)
+    P8 = torch.cat([P * sp, P[:1]]).to(torch.float8_e4m3fn)[:M]
+    Q8 = torch.cat([Q * sq, Q[:1]]).to(torch.float8_e4m3fn)[:M]
+    inv_p, inv_q = torch.tensor([1.0 / sp], device=DEV), torch.tensor([1.0 / sq], device=DEV)
+    ref = (P8[:, :Ny].double().T @ Q8[:, :Nx].double()) / (sp * sq)
+    out = torch.zeros(Ny, Nx, device=DEV)
+    ws = torch.empty(32 * Ny * Nx, device=DEV)
+    _lib.check(_lib.lib().osud_op_wgrad8(_lib.ptr(P8), ldp, _lib.ptr(Q8), ldq, Ny, Nx, M, _lib.ptr(out), _lib.ptr(ws), ws.numel(),
+                                         _lib.ptr(inv_p), _lib.ptr(inv_q), None))
+    torch.cuda.synchronize()
+    err = float((out.double() - ref).abs().max())
+    scale = float(ref.abs().max())
+    print(f"MEASURED wgrad8[{M}x{Ny}x{Nx}]: max|d| = {err:.3e} at scale {scale:.3e}")
+    assert err <= 2e-5 * scale, (err, scale)
+    # and it is a usable gradient: within e4m3's rounding of the unquantised product (3 mantissa bits per operand, summed over M tokens)
+    full = P[:, :Ny].double().T @ Q[:, :Nx].double()
+    rel = float((out.double() - full).norm() / full.norm())
+    print(f"MEASURED wgrad8[{M}x{Ny}x{Nx}]: relative Frobenius error vs the unquantised product {rel:.3e}")
+    assert rel < 0.12
