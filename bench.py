@@ -654,7 +654,18 @@ def main():
                                                 "roofline", "cpu_baseline") if k in samp}
         if world == 1 and args.precision == "bf16" and not args.no_parity_tier:
             res["parity_tier"], res["bf16_drift"] = parity_tier_and_drift(args, dev)
-            res["sampling"]["tolerance_tier"] = res["parity_tier"].pop("tolerance_tier")
+            tt = res["parity_tier"].pop("tolerance_tier")
+            res["sampling"]["tolerance_tier"] = tt
+            # which number answers "1000-step CFG sampling steps/s, matching the reference within 1e-3": the fastest tier whose
+            # 1000-step drift from the exact-f32 tier stays below the bound on this very workload
+            bd = res["bf16_drift"]
+            res["sampling"]["tolerance"] = {
+                "bound": 1e-3, "unit": "normalised playfield coordinates, max over the conditional rows after the full loop",
+                "this_line": {"tier": "bf16", "max_drift_vs_fp32_tier": bd["max"], "p99": bd["p99"], "meets": bool(bd["max"] <= 1e-3)},
+                "fastest_tier_meeting_it": ({"tier": "bf16x3", "value": tt["value"], "unit": "steps/s", "max_drift_vs_fp32_tier": tt["drift_vs_fp32_tier"]["max"]}
+                                            if tt["meets_1e-3"] else {"tier": "fp32", "value": res["parity_tier"]["sample"]["value"], "unit": "steps/s"}),
+                "reference_fixture": "tests/golden/g6_loop_p1000_dit_b.npz: the reference's own 1000-step CFG-4 DiT-B loop; tests/test_gpu_x3.py "
+                                     "(fp32 tier 9.8e-5, bf16x3 1.2e-4, bf16 8.8e-3 from it)"}
             # the fp8 inference tier on the same sampling workload (reduced precision: 0.7 % rms from the fp32 oracle, tests/test_gpu_fp8.py)
             fargs = argparse.Namespace(**vars(args))
             fargs.precision, fargs.steps, fargs.warmup, fargs.no_roofline, fargs.no_cpu_baseline = "fp8", 300, 30, True, True

@@ -167,6 +167,13 @@ int osud_dit_bind_grad(osud_dit* m, const char* key, float* grad_f32);
 /* Re-pack every parameter from the fp32 master pointer last passed to osud_dit_set_param
  * (call after the optimizer changed the masters in place). */
 int osud_dit_refresh(osud_dit* m, osud_stream stream);
+/* The same re-pack for the parameters of phases [phase_lo, phase_hi] only (phases as in osud_dit_backward_phases: 0 = embedders and
+ * conditioning path, p = 1..depth = block p - 1 with its adaLN pair, depth + 1 = final layer), e.g. on a side stream as the sharded
+ * optimizer's all-gather delivers them; and a gate: the NEXT forward waits for `hip_event` (a hipEvent_t, recorded behind that
+ * phase's re-pack) before the first kernel of `phase` -- so the gather / re-pack of later blocks overlaps the forward of earlier ones.
+ * Gates are one-shot; NULL clears one. */
+int osud_dit_refresh_phases(osud_dit* m, int phase_lo, int phase_hi, osud_stream stream);
+int osud_dit_forward_gate(osud_dit* m, int phase, void* hip_event);
 /* forward that keeps the per-layer activations (plain forward, no CFG, no mask) */
 int osud_dit_forward_train(osud_dit* m, const float* x, const int64_t* t, const float* o, const float* c,
                            const int64_t* y, int N, int T, float* out, osud_stream stream);

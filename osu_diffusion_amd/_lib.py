@@ -59,6 +59,8 @@ _SIGNATURES = {
     "osud_sample_loop_inpaint": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp, _u64, _vp, _vp]),
     "osud_dit_bind_grad": (_i, [_vp, C.c_char_p, _vp]),
     "osud_dit_refresh": (_i, [_vp, _vp]),
+    "osud_dit_refresh_phases": (_i, [_vp, _i, _i, _vp]),
+    "osud_dit_forward_gate": (_i, [_vp, _i, _vp]),
     "osud_dit_forward_train": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "osud_dit_backward": (_i, [_vp, _vp, _vp]),
     "osud_dit_backward_phases": (_i, [_vp, _vp, _i, _i, _vp]),

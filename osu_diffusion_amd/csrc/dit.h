@@ -153,6 +153,10 @@ struct osud_dit {
   std::vector<LayerSaved> saved;
   std::vector<void*> ws_owned;
 
+  // osud_dit_forward_gate: events the NEXT forward waits for before the first kernel of a phase (0 = embedders / conditioning,
+  // 1..L = block p - 1, L + 1 = final layer); one-shot.  With any gate set the adaLN product runs per phase instead of batched.
+  std::vector<hipEvent_t> gate_ev;
+
   // sample-loop graph cache
   hipStream_t cap_stream = nullptr;
   hipGraphExec_t graph_exec = nullptr;

@@ -186,6 +186,18 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
 
   const int D = m->D, L = m->L, Tp = round_up(T, 64), M = N * Tp, Mp = round_up(M, 128), Np = round_up(N, 128);
   const int prec = m->prec, AC = m->ada_cols;
+  // Gates (osud_dit_forward_gate): the sharded optimizer's all-gather of the updated master weights and their re-pack run on a
+  // side stream while this forward is already under way -- phase p's kernels wait for phase p's event only.
+  bool gated = false;
+  for (hipEvent_t e : m->gate_ev) gated = gated || e != nullptr;
+  auto gate = [&](int phase) -> int {
+    if (phase < (int)m->gate_ev.size() && m->gate_ev[(size_t)phase] != nullptr) {
+      OSUD_HIP(hipStreamWaitEvent(st, m->gate_ev[(size_t)phase], 0));
+      m->gate_ev[(size_t)phase] = nullptr;
+    }
+    return OSUD_OK;
+  };
+  OSUD_TRY(gate(0));
 
   // token embedding + first linear (models.py:315-317)
   // (bf16 tier: rows and weights in the split [hi | lo | hi] x [w_hi | w_hi | w_lo] form, Ke = 3 Kp -- see embed_kernel)
@@ -211,7 +223,13 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
   OSUD_TRY(gemm(m, EPI_BIAS_F32, m->th, D, m->w_t2, D, Np, D, D, m->tvec, D, m->b_t2, st));
   OSUD_TRY(launch_cond(prec, m->tvec, m->table_ref ? m->table_ref : m->table, y, m->cfg.table_rows, m->bvec, m->sb, N, Np, D, st));
   }
-  OSUD_TRY(gemm(m, EPI_BIAS_F32, m->sb, D, m->w_ada, D, Np, AC, D, m->ada, AC, m->b_ada, st));
+  // (gated forward: a block's adaLN weights arrive with the block, so its 6D modulation columns are produced in front of it)
+  auto ada_part = [&](int l) -> int {  // l == L: the final layer's 2D columns
+    const size_t off = (size_t)l * 6 * D;
+    return gemm(m, EPI_BIAS_F32, m->sb, D, (const char*)m->w_ada + off * D * m->esz, D, Np, l < L ? 6 * D : 2 * D, D, m->ada + off, AC,
+                m->b_ada + off, st);
+  };
+  if (!gated) OSUD_TRY(gemm(m, EPI_BIAS_F32, m->sb, D, m->w_ada, D, Np, AC, D, m->ada, AC, m->b_ada, st));
 
   if (mask != nullptr) OSUD_TRY(launch_mask_tiles(mask, T, Tp, m->kb_class, st));  // once per forward, shared by all blocks
   // Training: the gated residual updates (h += gate * branch, models.py:161-175) are folded into the NEXT LayerNorm
@@ -235,6 +253,10 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
     const int base = l * 6 * D;
     const int qcols = 3 * D;
     const float *fs = m->fp8 ? &m->f8_inf[(size_t)l * 4] : nullptr;  // this block's {LN1, attention, LN2, GELU} output scales
+    if (gated) {
+      OSUD_TRY(gate(l + 1));
+      OSUD_TRY(ada_part(l));
+    }
     if (!sv && m->fp8 && !cal) {
       OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base, base + D, m->u8, nullptr, Mp, Tp, N, D, st, nullptr, 0, nullptr, fs[0]));
       OSUD_TRY(gemm8(m, EPI_BIAS_TE, m->u8, w.w8_qkv, Mp, qcols, D, qk, qcols, w.b_qkv, w.dq_qkv, 0.f, st, nullptr, 0, 0, 0, 1.0f / fs[0]));
@@ -307,6 +329,10 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
     pend = br2;
     pend_gate = base + 5 * D;
     h = h_mid;
+  }
+  if (gated) {
+    OSUD_TRY(gate(L + 1));
+    OSUD_TRY(ada_part(L));
   }
   // FinalLayer (models.py:192-196) + swapaxes (:324); adds the last MLP branch first
   OSUD_TRY(launch_final(h, m->ada, AC, L * 6 * D, L * 6 * D + D, m->w_f, m->b_f, out, nullptr,

@@ -587,10 +587,36 @@ extern "C" int osud_dit_bind_grad(osud_dit* m, const char* key, float* grad_f32)
   return OSUD_OK;
 }
 
+// phase of a parameter: 0 = embedders / conditioning path, 1..L = block p - 1 (with its adaLN pair), L + 1 = final layer
+static int phase_of_key(const osud_dit* m, const std::string& k) {
+  if (k.compare(0, 7, "blocks.") == 0) return atoi(k.c_str() + 7) + 1;
+  if (k.compare(0, 12, "final_layer.") == 0) return m->L + 1;
+  return 0;
+}
+
+extern "C" int osud_dit_forward_gate(osud_dit* m, int phase, void* hip_event) {
+  OSUD_CHECK_ARG(m && phase >= 0 && phase <= m->L + 1, "forward_gate: phase outside 0..depth+1");
+  if (m->gate_ev.size() < (size_t)m->L + 2) m->gate_ev.assign((size_t)m->L + 2, nullptr);
+  m->gate_ev[(size_t)phase] = (hipEvent_t)hip_event;
+  return OSUD_OK;
+}
+
 extern "C" int osud_dit_refresh(osud_dit* m, osud_stream stream) {
   OSUD_CHECK_ARG(m, "refresh: null handle");
-  // re-pack every parameter from the caller's fp32 master (after an optimizer step)
-  std::vector<std::pair<std::string, const float*>> items(m->master.begin(), m->master.end());
+  OSUD_TRY(osud_dit_refresh_phases(m, 0, m->L + 1, stream));
+  if (m->training) OSUD_TRY(build_transposed(m, (hipStream_t)stream));
+  return OSUD_OK;
+}
+
+extern "C" int osud_dit_refresh_phases(osud_dit* m, int phase_lo, int phase_hi, osud_stream stream) {
+  OSUD_CHECK_ARG(m && phase_lo >= 0 && phase_hi <= m->L + 1 && phase_lo <= phase_hi, "refresh: phases outside 0..depth+1");
+  // re-pack the parameters of these phases from the caller's fp32 masters (after an optimizer step; the transposed copies of the
+  // data-gradient products are rebuilt lazily by the next backward pass)
+  std::vector<std::pair<std::string, const float*>> items;
+  for (auto& kv : m->master) {
+    const int ph = phase_of_key(m, kv.first);
+    if (ph >= phase_lo && ph <= phase_hi) items.push_back(kv);
+  }
   // set_param only RECORDS its copies / conversions while these are set; each list then goes out as one launch
   SegBatch copies(SEG_COPY, m->prec, (hipStream_t)stream), converts(SEG_CONVERT, m->prec, (hipStream_t)stream);
   struct Guard {
@@ -628,7 +654,6 @@ extern "C" int osud_dit_refresh(osud_dit* m, osud_stream stream) {
   OSUD_TRY(copies.flush());
   OSUD_TRY(converts.flush());
   m->defer_copy = m->defer_convert = nullptr;
-  if (m->training) OSUD_TRY(build_transposed(m, (hipStream_t)stream));
   return OSUD_OK;
 }
 

@@ -402,6 +402,10 @@ class NativeTrainer:
         self.wire_dtype = wire_dtype
         self._shard_buf = None
         self._ema_stale = False
+        # sharded optimizer: gather the updated master shards and re-pack them block by block UNDER the next step's forward
+        # (OSUD_ZERO1_OVERLAP=0: gather everything, then re-pack, then go on)
+        self.overlap_gather = os.environ.get("OSUD_ZERO1_OVERLAP", "1") != "0"
+        self._gate_events = []
         import torch.distributed as dist
 
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and "OSUD_GEMM_DYNAMIC" not in os.environ:
@@ -564,12 +568,53 @@ class NativeTrainer:
                 gathers.append(_all_gather_into(arena.flat[lo:bulk_hi], arena.flat[a:b], group, self.comm))
             off += per
         self._adamw(_complement(own, arena.total), scale)
-        for h, fin in gathers:
-            h.wait()
-            if fin is not None:
-                fin()
         self._ema_stale = True  # every rank's EMA is current only on its own shards (and the replicated parts)
-        self._refresh()
+        if not self.overlap_gather:
+            for h, fin in gathers:
+                h.wait()
+                if fin is not None:
+                    fin()
+            self._refresh()
+            return
+        # ---- the all-gather of the updated masters under the NEXT step's forward.  The gathers were issued above in the order the
+        # phases of the backward finished (final layer, block L-1 .. 0); each one's completion and the re-pack of its phase go to a
+        # side stream, and the next forward waits per phase (osud_dit_forward_gate): block 0's kernels start as soon as block 0's
+        # weights are in place while the later blocks' shards are still on the wire.  Phase 0 (embedders, conditioning path, class
+        # table: replicated, updated by every rank above) is re-packed on the compute stream right away.
+        dev = arena.flat.device
+        L_ = _lib.lib()
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        h_model = self.model._handle
+        with torch.cuda.device(dev):
+            _lib.check(L_.osud_dit_refresh_phases(h_model, 0, 0, _lib.stream_ptr(dev)))
+        self._side.wait_stream(main)  # the optimizer's writes (own shards + replicated parts) precede every re-pack
+        phase_of = [depth + 1] + [depth - p + 1 for p in range(1, depth + 1)]  # plans[i] -> phase: final layer, then blocks L-1 .. 0
+        by_phase = {}
+        gi = 0
+        for i, (lo, hi, per, bulk_hi) in enumerate(plans):
+            if per > 0:
+                by_phase[phase_of[i]] = gathers[gi]
+                gi += 1
+            else:
+                by_phase[phase_of[i]] = None
+        self._gate_events = []
+        with torch.cuda.stream(self._side):
+            for ph in list(range(1, depth + 1)) + [depth + 1]:  # forward order
+                g = by_phase.get(ph)
+                if g is not None:
+                    h, fin = g
+                    h.wait()  # (orders the side stream behind the collective; no host sync)
+                    if fin is not None:
+                        fin()
+                with torch.cuda.device(dev):
+                    _lib.check(L_.osud_dit_refresh_phases(h_model, ph, ph, C.c_void_p(self._side.cuda_stream)))
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+                self._gate_events.append(ev)  # (kept alive until the next exchange)
+                _lib.check(L_.osud_dit_forward_gate(h_model, ph, C.c_void_p(ev.cuda_event)))
+        self.ema._uploaded = {}  # its masters changed behind torch's back
 
     def _allreduce_async(self, t):
         import torch.distributed as dist
@@ -587,10 +632,19 @@ class NativeTrainer:
                 _lib.ptr(self.ema_arena.flat[lo:hi]), hi - lo, self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                 max(self.step_count, 1), self.ema_decay, 0, 0, float(grad_scale), _lib.stream_ptr(dev)))
 
+    def finish_exchange(self):
+        """Order the current stream behind a master all-gather / re-pack still running on the side stream (sharded optimizer with
+        the gather under the next forward).  The next step does this per block through the forward's gates; anything else that
+        reads the masters or the packed weights -- checkpoints, evaluation with the model, tests -- calls this first."""
+        if self._side is not None:
+            torch.cuda.current_stream(self.arena.flat.device).wait_stream(self._side)
+
     def sync_sharded_state(self):
         """Sharded optimizer: bring the moments and the EMA of every shard to every rank (checkpoints and EMA evaluation need the
         whole state; during training nobody reads the other ranks' shards)."""
         import torch.distributed as dist
+
+        self.finish_exchange()
 
         if not (self.shard_optimizer and self._ema_stale and dist.is_available() and dist.is_initialized()):
             return
@@ -707,6 +761,10 @@ class NativeTrainer:
                 self.step_count = int(float(st["step"]))
 
     def checkpoint(self, args=None):
+        self.finish_exchange()
+        return self._checkpoint(args)
+
+    def _checkpoint(self, args=None):
         """The reference's checkpoint dict (train.py:287-293).  With the sharded optimizer the state of the other ranks' shards
         must have been gathered by `sync_sharded_state()` -- a collective that EVERY rank has to enter -- before one rank alone
         calls this; a stale state here is an error, not something to fix up with a collective only this rank would join."""
