@@ -34,6 +34,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0  # dense MFMA bf16, /opt/skills/guides/MI355X_MICROARCH.md
+# What the matrix pipe sustains on FULL-ENTROPY bf16 operands with nothing else running (tools/probes/mfma_peak.hip: back-to-back
+# v_mfma_f32_32x32x16_bf16 from registers; zero operands reach 2340): profiles/r03_mfma_peak_probe.md.  Reported beside `frac`.
+MFMA_RANDOM_OPERAND_CEILING_TFLOPS = 1735.0
 FLOP_PER_TOKEN_FWD = 176.10e6  # DiT-B, T=128
 FLOP_PER_TOKEN_TRAIN = 528.3e6  # forward + backward = 3x forward
 
@@ -144,7 +147,9 @@ def gemm_roofline(M, N, K, dev, iters=50):
         pass
     return {"bound": "mfma", "kernel": "gemm_kernel<bf16, EPI_BIAS_GELU_TE> (fc1 %dx%dx%d)" % (M, N, K),
             "achieved": round(flops / sec / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(flops / sec / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
+            "frac": round(flops / sec / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "frac_of_random_operand_ceiling": round(flops / sec / 1e12 / MFMA_RANDOM_OPERAND_CEILING_TFLOPS, 4),
+            "traffic": traffic, "traffic_source": src,
             "algorithmic_bytes": 2 * (M * K + N * K + M * N),
             "flop_per_launch": flops, "avg_launch_us": round(sec * 1e6, 2)}
 
@@ -186,7 +191,12 @@ def wgrad_roofline(M, Ny, Nx, dev, iters=30):
         pass
     return {"bound": "mfma", "kernel": "wgrad_kernel<2,4,4,2> + splitk_reduce_kernel (fc1 weight gradient %dx%d over %d tokens)" % (Ny, Nx, M),
             "achieved": round(flops / sec / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(flops / sec / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": src,
+            "frac": round(flops / sec / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "frac_of_random_operand_ceiling": round(flops / sec / 1e12 / MFMA_RANDOM_OPERAND_CEILING_TFLOPS, 4),
+            "random_operand_ceiling": {"value": MFMA_RANDOM_OPERAND_CEILING_TFLOPS, "unit": "TFLOP/s",
+                                       "source": "profiles/r03_mfma_peak_probe.md: back-to-back bf16 MFMAs from registers on random operands "
+                                                 "(zero operands: 2340); the chip's power management paces the pipe by operand content"},
+            "traffic": traffic, "traffic_source": src,
             "algorithmic_bytes": 2 * M * (Ny + Nx) + 4 * Ny * Nx, "flop_per_launch": flops, "avg_launch_us": round(sec * 1e6, 2)}
 
 
