@@ -83,6 +83,8 @@ int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_
 int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int Nx, int M, float* out, float* ws,
                     size_t ws_elems, hipStream_t st);
 int launch_colsum_bf16(const void* a, int ld, int M, int N, float* out, hipStream_t st);
+// fp8 training: column sums (+= into out) AND e4m3 twin (x slot[0]; q8 may be null) AND amax (slot[2]) of a dense bf16 [M][N] matrix
+int launch_colsum_quant_bf16(const void* a, int M, int N, float* out, void* q8, float* slot, hipStream_t st);
 // the same product on e4m3 twins (fp8 training): out = inv_p[0] * inv_q[0] * P8^T . Q8 (device scalars: the operands' 1 / scale)
 int launch_wgrad8_tr(const void* P8, int ldp, const void* Q8, int ldq, int Ny, int Nx, int M, float* out, float* ws, size_t ws_elems,
                      const float* inv_p, const float* inv_q, hipStream_t st);

@@ -310,10 +310,12 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     // (bf16 tier: the in_proj bias gradient is the attention backward's job -- inside the streamed kernel at T = 128, a column-sum
     //  pass over dqkv behind the other kernels; scratch: the split-K slab area, idle between two weight gradients)
     const bool fused_bqkv = prec == OSUD_PREC_BF16;
+    // (fp8 training: dqkv's bias gradient, its e4m3 twin and its amax come from ONE pass over it instead of the attention
+    //  backward's column-sum pass + a quantisation pass)
     OSUD_TRY(launch_attention_bwd(prec, sv.qk, w.dao, sv.ao, sv.lse, w.dqkv, N, T, m->H, m->hd, st, w.attn_delta,
-                                  fused_bqkv ? g_bqkv : nullptr, w.splitk, w.splitk_elems));
+                                  (fused_bqkv && !f8_train) ? g_bqkv : nullptr, w.splitk, w.splitk_elems));
     OSUD_TRY(dbg_sync(st, "attention bwd"));
-    if (f8_train) OSUD_TRY(launch_f8_quantize(w.dqkv, f8_live ? m->q8b : nullptr, (size_t)Mp * 3 * D, slot(5), st));
+    if (f8_train) OSUD_TRY(launch_colsum_quant_bf16(w.dqkv, Mp, 3 * D, g_bqkv, f8_live ? m->q8b : nullptr, slot(5), st));
     if (f8_live) OSUD_TRY(gemm8(m, EPI_NONE_TE, m->q8b, bw.w_qkv_t8, Mp, D, 3 * D, w.du, D, nullptr, bw.dq_qkv_t, 0.f, st, nullptr, 0, 0, 0, 0.f,
                                 slot(5) + 1));
     else

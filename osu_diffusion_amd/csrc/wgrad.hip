@@ -821,10 +821,17 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(Wgrad8P p) {
 // column sums of a bf16 [M][N] matrix: out[c] += sum_m a[m][c]   (bias gradients).  HBM-bound: a workgroup sweeps
 // 256 rows x 256 columns with 16-byte loads (32 lanes = one 512-byte row segment, 8 rows per pass, 4 passes in
 // flight), combines its 8 row groups through LDS and issues one atomic per column.
+// QUANT (fp8 training): the same pass also writes the matrix's e4m3 twin (value x slot[0], the slot's delayed scale) and records this
+// step's amax in slot[2] (one atomic per workgroup) -- dqkv is read once for its bias gradient AND its quantisation.
 constexpr int CS_ROWS = 256;
+template <bool QUANT>
 __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ a, int ld, int M, int N,
-                                                          float* __restrict__ out) {
+                                                          float* __restrict__ out, fp8_t* __restrict__ q8 = nullptr,
+                                                          float* __restrict__ slot = nullptr) {
   __shared__ float part[8][256 + 4];
+  __shared__ float red[4];
+  const float q_scale = QUANT ? slot[0] : 1.0f;
+  float amax = 0.f;
   const int cl = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int c = blockIdx.x * 256 + cl * 8;
   const int r0 = blockIdx.y * CS_ROWS, r1 = r0 + CS_ROWS < M ? r0 + CS_ROWS : M;
@@ -839,10 +846,24 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        s[0] += __uint_as_float(v[u].x << 16); s[1] += __uint_as_float(v[u].x & 0xffff0000u);
-        s[2] += __uint_as_float(v[u].y << 16); s[3] += __uint_as_float(v[u].y & 0xffff0000u);
-        s[4] += __uint_as_float(v[u].z << 16); s[5] += __uint_as_float(v[u].z & 0xffff0000u);
-        s[6] += __uint_as_float(v[u].w << 16); s[7] += __uint_as_float(v[u].w & 0xffff0000u);
+        float e[8];
+        e[0] = __uint_as_float(v[u].x << 16); e[1] = __uint_as_float(v[u].x & 0xffff0000u);
+        e[2] = __uint_as_float(v[u].y << 16); e[3] = __uint_as_float(v[u].y & 0xffff0000u);
+        e[4] = __uint_as_float(v[u].z << 16); e[5] = __uint_as_float(v[u].z & 0xffff0000u);
+        e[6] = __uint_as_float(v[u].w << 16); e[7] = __uint_as_float(v[u].w & 0xffff0000u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += e[j];
+        if constexpr (QUANT) {
+          const int rr = r + 8 * u;
+          if (rr < r1) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              amax = fmaxf(amax, fabsf(e[j]));
+              e[j] *= q_scale;
+            }
+            if (q8 != nullptr) store8(q8 + (size_t)rr * ld + c, e);
+          }
+        }
       }
     }
   }
@@ -855,6 +876,15 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 #pragma unroll
     for (int g = 0; g < 8; ++g) sum += part[g][t];
     atomicAdd(out + col, sum);
+  }
+  if constexpr (QUANT) {
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      amax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+      if (amax > 0.f) atomicMax(reinterpret_cast<unsigned*>(slot) + 2, __float_as_uint(amax));
+    }
   }
 }
 
@@ -1081,8 +1111,17 @@ int launch_wgrad_group(const WgradItem* items, int n, int M, float* ws, size_t w
 
 int launch_colsum_bf16(const void* a, int ld, int M, int N, float* out, hipStream_t st) {
   OSUD_CHECK_ARG(N % 8 == 0 && ld % 8 == 0, "colsum: N=%d and ld=%d must be multiples of 8", N, ld);
-  hipLaunchKernelGGL(colsum_bf16_kernel, dim3((N + 255) / 256, (M + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, st,
-                     (const bf16_t*)a, ld, M, N, out);
+  hipLaunchKernelGGL(colsum_bf16_kernel<false>, dim3((N + 255) / 256, (M + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, st,
+                     (const bf16_t*)a, ld, M, N, out, (fp8_t*)nullptr, (float*)nullptr);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+// column sums + e4m3 twin (q8 may be null: record the amax only) + amax of a DENSE bf16 [M][N] matrix (ld == N) in one pass
+int launch_colsum_quant_bf16(const void* a, int M, int N, float* out, void* q8, float* slot, hipStream_t st) {
+  OSUD_CHECK_ARG(N % 8 == 0 && slot != nullptr, "colsum_quant: N=%d must be a multiple of 8 and a scale slot is needed", N);
+  hipLaunchKernelGGL(colsum_bf16_kernel<true>, dim3((N + 255) / 256, (M + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, st,
+                     (const bf16_t*)a, N, M, N, out, (fp8_t*)q8, slot);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }
