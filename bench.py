@@ -154,50 +154,59 @@ def gemm_roofline(M, N, K, dev, iters=50):
             "flop_per_launch": flops, "avg_launch_us": round(sec * 1e6, 2)}
 
 
-def wgrad_roofline(M, Ny, Nx, dev, iters=30):
+def wgrad_roofline(M, D, dev, iters=8):
     """Live HIP-event timing of the kernel with the largest share of a training step's device time -- `wgrad_kernel`, the
-    transpose-free weight-gradient product (csrc/wgrad.hip) -- at its heaviest shape in the step: fc1's dW = dz1^T . u2
-    (Ny x Nx = 4D x D over M tokens), including the deterministic combine of its split-K partial slabs (`splitk_reduce_kernel`),
-    on the current stream, random bf16 operands."""
+    transpose-free weight-gradient product (csrc/wgrad.hip), with the deterministic combine of its split-K partial slabs
+    (`splitk_reduce_kernel`) -- at the four shapes it runs at in every block (in_proj 3D x D, out_proj D x D, fc1 4D x D, fc2
+    D x 4D over M tokens), random bf16 operands, on the current stream.  As in the step, the gradient operand of a launch has
+    just been written by the kernel in front of it (here: a device copy, outside the timed events), the activation operand
+    has not.  Each launch sits between its own pair of events; `avg_launch_us` is the mean over all of them -- the number the
+    kernel trace's `wgrad_kernel` + `splitk_reduce_kernel` rows average to (profiles/r03_train_kernel_trace.md)."""
     from osu_diffusion_amd import _lib
 
     L = _lib.lib()
-    P = (torch.randn(M, Ny, device=dev) * 0.05).to(torch.bfloat16)
-    Q = torch.randn(M, Nx, device=dev).to(torch.bfloat16)
-    out = torch.empty(Ny, Nx, device=dev)
-    ws = torch.empty(16 * Ny * Nx, device=dev)
-
-    def launch():
-        _lib.check(L.osud_op_wgrad(_lib.ptr(P), Ny, _lib.ptr(Q), Nx, Ny, Nx, M, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
-
-    for _ in range(5):
-        launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    shapes = [("in_proj", 3 * D, D), ("out_proj", D, D), ("fc1", 4 * D, D), ("fc2", D, 4 * D)]
+    bufs = []
+    for _, Ny, Nx in shapes:
+        Psrc = (torch.randn(M, Ny, device=dev) * 0.05).to(torch.bfloat16)
+        bufs.append((Psrc, torch.empty_like(Psrc), torch.randn(M, Nx, device=dev).to(torch.bfloat16), torch.empty(Ny, Nx, device=dev)))
+    ws = torch.empty(16 * 4 * D * D, device=dev)
+    pairs = []
+    for it in range(iters + 2):
+        for (name, Ny, Nx), (Psrc, P, Q, out) in zip(shapes, bufs):
+            P.copy_(Psrc)  # the producer's write (not timed)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(L.osud_op_wgrad(_lib.ptr(P), Ny, _lib.ptr(Q), Nx, Ny, Nx, M, _lib.ptr(out), _lib.ptr(ws), ws.numel(), _lib.stream_ptr(dev)))
+            e1.record()
+            if it >= 2:
+                pairs.append((name, e0, e1))
     torch.cuda.synchronize()
-    e0.record()
-    for _ in range(iters):
-        launch()
-    e1.record()
-    torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) / 1e3 / iters
-    flops = 2.0 * M * Ny * Nx
+    per = {}
+    for name, e0, e1 in pairs:
+        per.setdefault(name, []).append(e0.elapsed_time(e1) * 1e3)
+    per_us = {k: sum(v) / len(v) for k, v in per.items()}
+    avg_us = sum(per_us.values()) / len(per_us)
+    flops = sum(2.0 * M * Ny * Nx for _, Ny, Nx in shapes) / len(shapes)  # per launch, averaged like the time
+    ach = flops / (avg_us * 1e-6) / 1e12
     traffic, src = None, None
-    try:  # HBM bytes per launch (kernel + combine pass) from the committed rocprofv3 --pmc passes (not measurable in-process)
+    try:  # HBM bytes per launch (kernel + combine pass, fc1's shape) from the committed rocprofv3 --pmc passes (not measurable in-process)
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["wgrad_fc1"]
-        if pmc["M"] == M:
+        if pmc["M"] == M and D == 768:
             traffic = pmc["hbm_bytes_per_launch"]
-            src = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/wgrad_only.py, separate passes, read side x2 per the gfx950 note)"
+            src = ("profiles/r03_pmc_traffic.json (fc1's shape: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/wgrad_only.py, separate passes, "
+                   "read side x2 per the gfx950 note)")
     except Exception:
         pass
-    return {"bound": "mfma", "kernel": "wgrad_kernel<2,4,4,2> + splitk_reduce_kernel (fc1 weight gradient %dx%d over %d tokens)" % (Ny, Nx, M),
-            "achieved": round(flops / sec / 1e12, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(flops / sec / 1e12 / PEAK_BF16_TFLOPS, 4),
-            "frac_of_random_operand_ceiling": round(flops / sec / 1e12 / MFMA_RANDOM_OPERAND_CEILING_TFLOPS, 4),
+    return {"bound": "mfma", "kernel": "wgrad_kernel<2,4,4,2> + splitk_reduce_kernel (the four weight gradients of a block, %d tokens, D = %d)" % (M, D),
+            "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+            "frac_of_random_operand_ceiling": round(ach / MFMA_RANDOM_OPERAND_CEILING_TFLOPS, 4),
             "random_operand_ceiling": {"value": MFMA_RANDOM_OPERAND_CEILING_TFLOPS, "unit": "TFLOP/s",
                                        "source": "profiles/r03_mfma_peak_probe.md: back-to-back bf16 MFMAs from registers on random operands "
                                                  "(zero operands: 2340); the chip's power management paces the pipe by operand content"},
             "traffic": traffic, "traffic_source": src,
-            "algorithmic_bytes": 2 * M * (Ny + Nx) + 4 * Ny * Nx, "flop_per_launch": flops, "avg_launch_us": round(sec * 1e6, 2)}
+            "algorithmic_bytes": (2 * M * (4 * D + D) + 4 * 4 * D * D) if traffic else None,
+            "flop_per_launch": flops, "avg_launch_us": round(avg_us, 2), "per_shape_us": {k: round(v, 2) for k, v in per_us.items()}}
 
 
 # ---------------------------------------------------------------------------------------------------------------------------
@@ -432,7 +441,7 @@ def bench_train(args, world, rank, dev):
         # the top-level `roofline`; the forward fc1 GEMM -- the heaviest single forward launch, round 1's and 2's entry -- stays
         # next to it.  Both are timed live with HIP events at the step's shapes.
         fc1 = gemm_roofline(B * T, 4 * D, D, dev)
-        res["roofline"] = wgrad_roofline(B * T, 4 * D, D, dev)
+        res["roofline"] = wgrad_roofline(B * T, D, dev)
         res["roofline"]["fc1_forward"] = fc1
         if not args.no_family_table and world == 1:
             def more(n):
