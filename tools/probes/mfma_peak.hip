@@ -41,6 +41,26 @@ __global__ __launch_bounds__(512) void k(const u32x4* __restrict__ src, float* _
   out[tid] = s;
 }
 
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+__global__ __launch_bounds__(512) void k16(const u32x4* __restrict__ src, float* __restrict__ out, int iters) {
+  const int tid = blockIdx.x * 512 + threadIdx.x;
+  u32x4 a[4], b[4];
+  for (int i = 0; i < 4; ++i) { a[i] = src[(tid * 8 + i) & 0xffff]; b[i] = src[(tid * 8 + 4 + i) & 0xffff]; }
+  f32x4 acc[4][4];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+    a[it & 3][it & 3] ^= 0x00010001u * (uint32_t)(it & 7);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) for (int r = 0; r < 4; ++r) s += acc[i][j][r];
+  out[tid] = s;
+}
+
 int main() {
   const int blocks = 256, iters = 4000;
   u32x4* d; float* o;
@@ -56,6 +76,17 @@ int main() {
       }
     }
     hipMemcpy(d, h, 65536 * 16, hipMemcpyHostToDevice);
+    {  // 16x16x32 bf16: 16 independent accumulators, same FLOPs per iteration (16 x 16384 = 8 x 32768)
+      hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+      for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        for (int l = 0; l < 20; ++l) hipLaunchKernelGGL(k16, dim3(blocks), dim3(512), 0, 0, d, o, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double flops = 20.0 * blocks * 8 * (double)iters * 16 * 16384.0;
+        if (rep == 2) printf("%s operands, bf16 16x16x32: %.1f ms for 20 launches -> %.0f TFLOP/s\n", mode ? "random" : "zero  ", ms, flops / ms / 1e9);
+      }
+    }
     for (int fp8 = 0; fp8 < 2; ++fp8) {
       if (fp8 && mode == 1) for (int i = 0; i < 65536 * 4; ++i) { uint32_t r = (uint32_t)rand() ^ ((uint32_t)rand() << 16); h[i] = r & 0xf7f7f7f7u & 0xbfbfbfbfu; }  // e4m3, |v| < 2^1, no NaN
       if (fp8 && mode == 1) hipMemcpy(d, h, 65536 * 16, hipMemcpyHostToDevice);
