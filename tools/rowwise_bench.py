@@ -60,7 +60,8 @@ def main():
 
     def ln_bwd(with_gate):
         lnb(I(0), P(h), P(stats), P(du), P(ada), I(AC), I(0), I(D), P(dh), P(dh2), P(dada), I(M), I(T), I(D), st,
-            P(br if with_gate else None), I(2 * D), P(dbr if with_gate else None), P(db if with_gate else None))
+            P(br if with_gate else None), I(2 * D), P(dbr if with_gate else None), P(db if with_gate else None),
+            P(None), P(None), P(None))  # (no e4m3 twin)
     row = D * (4 + 2 + 4 + 4)
     timeit("ln_mod_bwd (no gate step)", lambda: ln_bwd(False), M * row)
     timeit("ln_mod_bwd + gate step of the next branch", lambda: ln_bwd(True), M * (row + D * 4))
