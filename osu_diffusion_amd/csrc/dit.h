@@ -207,6 +207,16 @@ inline int gemm8(osud_dit* m, int epi, const void* Y, const void* X, int My, int
   return launch_gemm(OSUD_PREC_FP8, epi, p, st);
 }
 
+// fp8 training, live steps (`live`: this step's GEMMs run on e4m3 operands): true when EVERY consumer of the block's GEMM operands
+// -- forward products, data gradients and weight gradients (train.hip: the `weight_grad8` conditions) -- reads their e4m3 twins, so
+// that the bf16 forms of u1 / u2 / gelu(z1) / dz1 / the branch gradients are not written at all (0.9 GB per DiT-XL block and step).
+// OSUD_F8_TWINS_ONLY=0 keeps them (re-measurement).
+inline bool f8_twins_only(const osud_dit* m, bool live, int Mp) {
+  const char* e = getenv("OSUD_F8_TWINS_ONLY");  // (read per call: a test switches it inside one process)
+  const bool off = e && e[0] == '0';
+  return !off && live && m->prec == OSUD_PREC_BF16 && Mp % 128 == 0 && (size_t)(Mp / 32) * 4 * m->D <= m->bw.splitk_elems;
+}
+
 int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float* o, const float* c, const int64_t* y,
                      const uint8_t* mask, int N, int T, float cfg_scale, bool combine_cfg, float* out, bool save,
                      hipStream_t st);

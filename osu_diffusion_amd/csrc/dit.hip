@@ -186,6 +186,7 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
 
   const int D = m->D, L = m->L, Tp = round_up(T, 64), M = N * Tp, Mp = round_up(M, 128), Np = round_up(N, 128);
   const int prec = m->prec, AC = m->ada_cols;
+  const bool f8_slim = f8_twins_only(m, f8_live, Mp);  // the bf16 forms of the GEMM inputs have no reader this step: not written
   // Gates (osud_dit_forward_gate): the sharded optimizer's all-gather of the updated master weights and their re-pack run on a
   // side stream while this forward is already under way -- phase p's kernels wait for phase p's event only.
   bool gated = false;
@@ -264,7 +265,7 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
     } else {
       // (fp8 training: LayerNorm writes the e4m3 twin of its output and this step's amax itself)
       if (f8_train)
-        OSUD_TRY(launch_ln_mod_twin(h, m->ada, AC, base, base + D, u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st, pend, pend_gate,
+        OSUD_TRY(launch_ln_mod_twin(h, m->ada, AC, base, base + D, f8_slim ? nullptr : u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st, pend, pend_gate,
                                     pend ? h_in : nullptr, f8_live ? sv->u1_8 : nullptr, slot(l, 0), parts(l, 0)));
       else
       OSUD_TRY(launch_ln_mod(prec, h, m->ada, AC, base, base + D, u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st, pend,
@@ -306,14 +307,14 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
     else
     OSUD_TRY(gemm(m, EPI_BIAS_TE, ao, D, w.w_o, D, Mp, D, D, br1, D, w.b_o, st));
     if (f8_train)
-      OSUD_TRY(launch_ln_mod_twin(h_in, m->ada, AC, base + 3 * D, base + 4 * D, u2, sv->stats2, Mp, Tp, N, D, st, br1, base + 2 * D,
+      OSUD_TRY(launch_ln_mod_twin(h_in, m->ada, AC, base + 3 * D, base + 4 * D, f8_slim ? nullptr : u2, sv->stats2, Mp, Tp, N, D, st, br1, base + 2 * D,
                                   h_mid, f8_live ? sv->u2_8 : nullptr, slot(l, 1), parts(l, 1)));
     else
     OSUD_TRY(launch_ln_mod(prec, h_in, m->ada, AC, base + 3 * D, base + 4 * D, u2, sv->stats2, Mp, Tp, N, D, st, br1,
                            base + 2 * D, h_mid));
     if (f8_train) {
       // (live steps: the fc1 epilogue writes the e4m3 twin of its GELU output and records its amax itself)
-      if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_GELU_BF, sv->u2_8, w.w8_1, Mp, 4 * D, D, g, 4 * D, w.b1, w.dq_1, 0.f, st, nullptr, 0, 0, 0, 0.f,
+      if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_GELU_BF, sv->u2_8, w.w8_1, Mp, 4 * D, D, f8_slim ? nullptr : g, 4 * D, w.b1, w.dq_1, 0.f, st, nullptr, 0, 0, 0, 0.f,
                                   slot(l, 1) + 1, sv->z1, nullptr, nullptr, nullptr, sv->g_8, slot(l, 2)));
       else {
         OSUD_TRY(gemm(m, EPI_BIAS_GELU_TE, u2, D, w.w1, D, Mp, 4 * D, D, g, 4 * D, w.b1, st, nullptr, 0, 0, 0, sv->z1));

@@ -95,7 +95,9 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
                  "gemm: My=%d Nx=%d must be multiples of 128 and K=%d a multiple of %d", p.My, p.Nx, p.K, SLAB / esz);
   OSUD_CHECK_ARG((p.ldy * esz) % 16 == 0 && (p.ldx * esz) % 16 == 0 && p.ldo % 8 == 0,
                  "gemm: leading dimensions must keep 16-byte alignment (ldy=%d ldx=%d ldo=%d)", p.ldy, p.ldx, p.ldo);
-  OSUD_CHECK_ARG(p.Y && p.X && p.out, "gemm: null operand");
+  // (fp8 training: the two epilogues that write an e4m3 twin may drop their bf16 output when nothing reads it)
+  const bool twin_only = prec == OSUD_PREC_FP8 && p.out8 != nullptr && (epi == EPI_BIAS_GELU_BF || epi == EPI_GELUGRAD_TE);
+  OSUD_CHECK_ARG(p.Y && p.X && (p.out || twin_only), "gemm: null operand");
   OSUD_CHECK_ARG(p.seg_rows == 0 || (epi == EPI_NONE_F32 && p.split_k <= 1 && p.seg_rows % 32 == 0 && p.seg_out != nullptr),
                  "gemm: segmented output needs the plain f32 epilogue, no split-K and a device table of segment pointers");
   OSUD_CHECK_ARG((size_t)p.ldy * esz * 256 < (1ull << 31) && (size_t)p.ldx * esz * 256 < (1ull << 31),

@@ -816,7 +816,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
 #pragma unroll
             for (int e = 0; e < 8; ++e) w[e] = gelu_tanh_t<FAST>(v[e]) * ((kF8 && EPI == EPI_BIAS_GELU_TE) ? p.out_scale : 1.0f);
           }
-          store8_out<TO>(p.out, orow, p.ldo, x, w);
+          if (!kOut8 || p.out != nullptr) store8_out<TO>(p.out, orow, p.ldo, x, w);  // (null: only the e4m3 twin is consumed)
         } else if (EPI == EPI_GELUGRAD_TE) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) w[e] = v[e] * rv[q][e];
@@ -835,7 +835,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
 #pragma unroll
             for (int e = 0; e < 8; ++e) cs[j][e] += w[e];
           }
-          store8(reinterpret_cast<TO*>(p.out) + o, w);
+          if (!kOut8 || p.out != nullptr) store8(reinterpret_cast<TO*>(p.out) + o, w);
         } else {  // EPI_BIAS_TE, EPI_ROWBIAS_TE, EPI_NONE_TE
           store8_out<TO>(p.out, orow, p.ldo, x, v);
         }

@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256, OSUD_LNB_OCC(VPL)) void ln_mod_bwd_kernel(cons
       }
       storew<W>(dh_out + row + d, o);
       if constexpr (GATE) {
-        storew<W>(dbr + row + d, b);
+        if (dbr != nullptr) storew<W>(dbr + row + d, b);  // (null: only the e4m3 twin is consumed this step)
         if (twin) {
           float q[W];
 #pragma unroll
@@ -613,6 +613,7 @@ int launch_ln_mod_bwd(int prec, const float* h, const float* stats, const void* 
   OSUD_CHECK_ARG(dh_skip != nullptr, "ln_mod_bwd: the gradient of the residual stream behind the LayerNorm is required");
   OSUD_CHECK_ARG(slot8 == nullptr || (amax_part != nullptr && br_next != nullptr && prec == OSUD_PREC_BF16 && M / OSUD_LNB_ROWS <= f8_amax_parts()),
                  "ln_mod_bwd: the e4m3 twin rides with the gate step of the bf16 tier");
+  OSUD_CHECK_ARG(br_next == nullptr || dbr != nullptr || dbr8 != nullptr, "ln_mod_bwd: the gate step needs somewhere to put the branch gradient");
   const dim3 grid(M / OSUD_LNB_ROWS), block(256);
 #define ARGS(T) h, stats, (const T*)du, ada, ld_ada, off_shift, off_scale, dh_skip, dh_out, dada, Tp, (const T*)br_next, off_gate_next, (T*)dbr, db_next, (fp8_t*)dbr8, slot8, amax_part
   if (prec == OSUD_PREC_BF16) {

@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* h, const float
       if (sizeof(TE) == 1) r[e] *= out_scale;  // fp8 operand of the next GEMM, statically scaled
     }
     if constexpr (std::is_same<TE, x3_t>::value) storew_x3<W>(reinterpret_cast<bf16_t*>(orow) + d, (size_t)D, r);
-    else storew<W>(orow + d, r);
+    else if (!TWIN || out != nullptr) storew<W>(orow + d, r);  // (twin only: every consumer of this step reads the e4m3 form)
     if constexpr (TWIN) {
       float q[W];
 #pragma unroll

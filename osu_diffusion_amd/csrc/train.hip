@@ -224,6 +224,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     // fp8 training: the data-gradient products of fc2, fc1 and in_proj run on e4m3 operands (gradient tensors quantised with the
     // scale from their previous step's amax, transposed weights per row); the very first step only records (see dit_forward_impl)
     const bool f8_train = m->fp8, f8_live = m->fp8 && m->f8_steps > 1;
+    const bool f8_slim = f8_twins_only(m, f8_live, Mp);  // (implies the three weight_grad8 conditions below)
     auto slot = [&](int which) { return m->f8_slots + ((size_t)l * kF8Slots + which) * 4; };
     // fp8 training, live steps: a weight gradient from the e4m3 twins of its two operands (twice the bf16 kernel's rate); dW is
     // de-quantised by the two slots' 1 / scale.  P8: the gradient twin in its staging buffer, Q8: the layer's saved activation twin
@@ -236,7 +237,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
       //  for the last block, whose gate step is its own kernel)
       if (f8_train && l == L - 1) OSUD_TRY(launch_f8_quantize(w.dbr, f8_live ? m->q8a : nullptr, (size_t)Mp * D, slot(3), st));
       if (f8_live) {
-        OSUD_TRY(gemm8(m, EPI_GELUGRAD_TE, m->q8a, bw.w2_t8, Mp, 4 * D, D, w.dz1, 4 * D, nullptr, bw.dq_2_t, 0.f, st, nullptr, 0, 0, 0, 0.f,
+        OSUD_TRY(gemm8(m, EPI_GELUGRAD_TE, m->q8a, bw.w2_t8, Mp, 4 * D, D, f8_slim ? nullptr : w.dz1, 4 * D, nullptr, bw.dq_2_t, 0.f, st, nullptr, 0, 0, 0, 0.f,
                        slot(3) + 1, nullptr, sv.z1, fused_b1 ? w.splitk : nullptr, fused_b1 ? &part_rows : nullptr, m->q8b, slot(4)));
       } else {
       GemmP gp{};
@@ -293,7 +294,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     // (h_mid = h_in + g1 * (attn(u1) Wo^T + bo)): dbr = g1 * dh, dg1, dbo
     // (fp8 training: the attention branch's gradient gets its e4m3 twin -- q8c -- and amax from this kernel too)
     OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_mid, sv.stats2, w.du, m->ada, AC, base + 3 * D, base + 4 * D, dh, dh_other, w.dada,
-                               M, Tp, D, st, sv.br1, base + 2 * D, w.dbr2, g_bo, f8_live ? m->q8c : nullptr, f8_train ? slot(7) : nullptr,
+                               M, Tp, D, st, sv.br1, base + 2 * D, f8_slim ? nullptr : w.dbr2, g_bo, f8_live ? m->q8c : nullptr, f8_train ? slot(7) : nullptr,
                                f8_train ? m->f8_parts + ((size_t)l * kF8Slots + 7) * f8_amax_parts() : nullptr));
     OSUD_TRY(dbg_sync(st, "ln2 bwd + gate_bwd attn"));
     std::swap(dh, dh_other);
@@ -338,7 +339,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
       const int basep = (l - 1) * 6 * D;
       float* slot_prev = m->f8_slots + ((size_t)(l - 1) * kF8Slots + 3) * 4;  // fp8 training: block l - 1's dbr slot
       OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_in, sv.stats1, w.du, m->ada, AC, base, base + D, dh, dh_other, w.dada, M, Tp, D,
-                                 st, svp.br2, basep + 5 * D, w.dbr, G("blocks." + std::to_string(l - 1) + ".mlp.fc2.bias"),
+                                 st, svp.br2, basep + 5 * D, f8_slim ? nullptr : w.dbr, G("blocks." + std::to_string(l - 1) + ".mlp.fc2.bias"),
                                  f8_live ? m->q8a : nullptr, f8_train ? slot_prev : nullptr,
                                  f8_train ? m->f8_parts + ((size_t)(l - 1) * kF8Slots + 3) * f8_amax_parts() : nullptr));
     } else {

@@ -1,8 +1,8 @@
 """GPU (-m gpu): the fp8 tier (precision="fp8"): the bf16 tier with the big per-block GEMMs on OCP e4m3 operands (unit-scale MX
 MFMA, per-output-channel weight scales).  Inference: all four GEMMs, static activation scales.  Training (BASELINE config 5):
-qkv / fc1 / fc2 forward and their data-gradient products, delayed per-tensor scaling from the previous step's amax; weight
-gradients, out_proj and attention stay bf16.  It is a reduced-precision tier: the tests bound its deviation from the fp32 oracle,
-they do not claim parity."""
+in_proj / out_proj / fc1 / fc2 forward, their data-gradient products and their weight gradients, delayed per-tensor scaling from
+the previous step's amax; attention stays bf16.  It is a reduced-precision tier: the tests bound its deviation from the fp32
+oracle, they do not claim parity."""
 import pytest
 import torch
 
@@ -125,6 +125,29 @@ def test_fp8_training_step_tracks_the_fp32_oracle():
     print(f"MEASURED fp8_train: relative Frobenius error of the worst gradient tensor vs the fp32 oracle: bf16 tier {worst['bf16'][1]:.3e} ({worst['bf16'][0]}), "
           f"fp8 tier {worst['fp8'][1]:.3e} ({worst['fp8'][0]})")
     assert worst["fp8"][1] < 0.15 and worst["bf16"][1] < 1.4e-2, worst  # 3x measured: 4.9e-2 (fp8), 4.4e-3 (bf16)
+
+
+def test_fp8_live_steps_do_not_read_the_bf16_forms_they_no_longer_write(monkeypatch):
+    """Live fp8 steps write only the e4m3 twins of u1 / u2 / gelu(z1) / dz1 / the branch gradients (dit.h: f8_twins_only); with
+    OSUD_F8_TWINS_ONLY=0 the bf16 forms are written as well.  Nothing may read them: the two settings give the same loss terms and
+    gradients up to the arrival order of the bias-gradient atomics."""
+    shape = mo.DitShape(depth=2, hidden=384, heads=6, num_classes=10)
+    sd = mo.seeded_state_dict(shape, 33)
+    (x, o, c), y = synthetic_windows(4, 128, 10, seed=4)
+    t = torch.tensor([40, 700, 3, 999])
+    noise = torch.randn(4, 2, 128, generator=torch.Generator().manual_seed(6))
+    d = create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True)
+    res = {}
+    for setting in ("0", "1"):
+        monkeypatch.setenv("OSUD_F8_TWINS_ONLY", setting)
+        tr = NativeTrainer(build(shape, sd, "fp8").train(), d, lr=1e-4)
+        for _ in range(4):
+            terms = tr.step(x, o, c, y, t=t, noise=noise, drop_ids=torch.zeros(4).long())
+        res[setting] = (terms.cpu().clone(), {k: v.cpu().clone() for k, v in tr.arena.grad_views().items()})
+    assert torch.allclose(res["0"][0], res["1"][0], rtol=1e-5, atol=1e-7)
+    worst = max(float((res["0"][1][k] - g).norm() / g.norm().clamp_min(1e-12)) for k, g in res["1"][1].items())
+    print(f"MEASURED f8_twins_only: worst relative gradient difference between the two settings {worst:.3e}")
+    assert worst < 1e-4
 
 
 def test_fp8_training_reduces_the_loss_like_bf16():
