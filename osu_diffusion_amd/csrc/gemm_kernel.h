@@ -524,6 +524,9 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
 
     uint32_t pso;
     int t_nxt2 = t_nxt + G8;
+#ifdef OSUD_GEMM_TIMING
+    uint64_t te0 = __builtin_readcyclecounter();
+#endif
     if constexpr (ROLES) {
       // ---- role-split main loop: two half-periods per slab, a barrier after each.
       //   H1: group 0 runs the slab's MFMAs | group 1 issues the EARLY set of the NEXT slab (Y top + X) into the other stage
@@ -611,7 +614,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
     // The next tile's first slabs are already in flight: make sure they landed NOW, while no store is
     // queued behind them, so the next tile can start right after the epilogue without draining its stores.
 #ifdef OSUD_GEMM_TIMING
-    const uint64_t te0 = __builtin_readcyclecounter();
+    te0 = __builtin_readcyclecounter();
 #endif
     wait_vm<0>();
     landed = issued - consumed;
