@@ -410,7 +410,7 @@ def bench_train(args, world, rank, dev):
         "metric": f"{args.model} seq{args.seq_len} train tokens/sec (whole job; per-GPU = value / n_gpus)", "value": round(tokens_per_s, 1),
         "unit": "tokens/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"bf16": "bf16", "fp32": "f32", "fp8": "fp8 (e4m3 operands, delayed per-tensor scaling: qkv/fc1/fc2 fwd + dgrad) + bf16 (wgrad, out_proj, attention)"}[args.precision], "data": "synthetic",
+        "dtype": {"bf16": "bf16", "fp32": "f32", "fp8": "fp8 (e4m3 operands, delayed per-tensor scaling: in_proj / out_proj / fc1 / fc2 forward, data-gradient and weight-gradient products) + bf16 (attention, adaLN, embedders)"}[args.precision], "data": "synthetic",
         "config": {"workload": f"train.py step: {args.model} seq-len {T}, per-GPU batch {B} synthetic windows (global {B * world}), "
                                f"L1+vb loss, AdamW lr 1e-4, EMA 0.9999, label dropout 0.2, squaredcos_cap_v2 1000 steps",
                    "per_gpu_batch": B, "global_batch": B * world, "seq_len": T,

@@ -121,6 +121,7 @@ struct osud_dit {
   // here instead of launching them one by one, and refresh sends each list as one batched launch (batch.hip)
   osud::SegBatch* defer_copy = nullptr;
   osud::SegBatch* defer_convert = nullptr;
+  osud::QuantBatch* defer_quant = nullptr;  // fp8: the per-row e4m3 forms of the refreshed weights, one launch per list
   bool transposed_ready = false;
   BwdWs bw;
   int bw_dh_cur = 0;  // which residual-gradient buffer currently holds d(loss)/d(h) (phased backward)

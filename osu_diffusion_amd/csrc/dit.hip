@@ -486,6 +486,12 @@ static bool shape_is(const int64_t* s, int nd, int64_t a, int64_t b = -1) {
   return b < 0 ? (nd == 1 && s[0] == a) : (nd == 2 && s[0] == a && s[1] == b);
 }
 
+// fp8 tier: per-output-channel e4m3 form of a weight; inside a refresh the launch is deferred into the refresh's list
+static int quant_w(osud_dit* m, const float* src, int rows, int cols, void* q, float* dq, hipStream_t st) {
+  if (m->defer_quant && cols % 8 == 0) return m->defer_quant->add(src, rows, cols, q, dq);
+  return launch_quantize_rows(src, rows, cols, q, dq, 1.0f, st);
+}
+
 extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src, const int64_t* shape, int ndim,
                                   osud_stream stream) {
   OSUD_CHECK_ARG(m && key && src && shape, "set_param: null argument");
@@ -544,24 +550,24 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
     if (name == "attn.in_proj_weight") {
       SHAPE(3 * D, D);  // rows [Wq; Wk; Wv]
       rc = convert_w(m, src, b.w_qkv, 3 * D, D, st);
-      if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)(3 * D), (int)D, b.w8_qkv, b.dq_qkv, 1.0f, st);
+      if (rc == OSUD_OK && m->fp8) rc = quant_w(m, src, (int)(3 * D), (int)D, b.w8_qkv, b.dq_qkv, st);
     } else if (name == "attn.in_proj_bias") {
       SHAPE(3 * D);
       rc = upload_f32(m, &b.b_qkv, src, 3 * D, st);
     } else if (name == "attn.out_proj.weight") {
       SHAPE(D, D);
       rc = convert_w(m, src, b.w_o, D, D, st);
-      if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)D, (int)D, b.w8_o, b.dq_o, 1.0f, st);
+      if (rc == OSUD_OK && m->fp8) rc = quant_w(m, src, (int)D, (int)D, b.w8_o, b.dq_o, st);
     } else if (name == "attn.out_proj.bias") { SHAPE(D); rc = upload_f32(m, &b.b_o, src, D, st);
     } else if (name == "mlp.fc1.weight") {
       SHAPE(4 * D, D);
       rc = convert_w(m, src, b.w1, 4 * D, D, st);
-      if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)(4 * D), (int)D, b.w8_1, b.dq_1, 1.0f, st);
+      if (rc == OSUD_OK && m->fp8) rc = quant_w(m, src, (int)(4 * D), (int)D, b.w8_1, b.dq_1, st);
     } else if (name == "mlp.fc1.bias") { SHAPE(4 * D); rc = upload_f32(m, &b.b1, src, 4 * D, st);
     } else if (name == "mlp.fc2.weight") {
       SHAPE(D, 4 * D);
       rc = convert_w(m, src, b.w2, D, 4 * D, st);
-      if (rc == OSUD_OK && m->fp8) rc = launch_quantize_rows(src, (int)D, (int)(4 * D), b.w8_2, b.dq_2, 1.0f, st);
+      if (rc == OSUD_OK && m->fp8) rc = quant_w(m, src, (int)D, (int)(4 * D), b.w8_2, b.dq_2, st);
     } else if (name == "mlp.fc2.bias") { SHAPE(D); rc = upload_f32(m, &b.b2, src, D, st);
     } else if (name == "adaLN_modulation.1.weight") {
       SHAPE(6 * D, D);

@@ -134,6 +134,37 @@ struct SegBatch {
   }
 };
 
+// fp8 tier: per-row e4m3 quantisation (launch_quantize_rows / _bf16) of a whole LIST of weights in one launch; block b finds its
+// matrix by its row range.  224 weights per DiT-XL step were 224 launches of ~9 us (each too short to fill the memory system).
+struct QuantList {
+  static constexpr int kMax = 48;
+  const void* src[kMax];  // fp32 (SRC_BF16 = false) or bf16 rows, dense
+  void* q[kMax];
+  float* dq[kMax];
+  int cols[kMax], row_begin[kMax + 1];
+  int count;
+};
+int launch_quantize_rows_many(bool src_bf16, const QuantList& L, hipStream_t st);
+struct QuantBatch {
+  bool src_bf16;
+  hipStream_t st;
+  QuantList L{};
+  QuantBatch(bool src_bf16_, hipStream_t st_) : src_bf16(src_bf16_), st(st_) {}
+  int flush() {
+    const int rc = launch_quantize_rows_many(src_bf16, L, st);
+    L.count = 0;
+    return rc;
+  }
+  int add(const void* src, int rows, int cols, void* q, float* dq) {
+    if (L.count == QuantList::kMax) OSUD_TRY(flush());
+    if (L.count == 0) L.row_begin[0] = 0;
+    L.src[L.count] = src; L.q[L.count] = q; L.dq[L.count] = dq; L.cols[L.count] = cols;
+    L.row_begin[L.count + 1] = L.row_begin[L.count] + rows;
+    ++L.count;
+    return OSUD_OK;
+  }
+};
+
 // sampler.hip
 struct StepCoefs;  // device table, 8 floats per step
 int launch_sampler_step(const float* coefs, int mode, float eta, const float* model_out, const float* x,

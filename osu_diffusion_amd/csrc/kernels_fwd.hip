@@ -421,6 +421,50 @@ __global__ __launch_bounds__(256) void quantize_rows_bf16_kernel(const bf16_t* _
   if (threadIdx.x == 0) dequant[blockIdx.x] = 1.0f / s;
 }
 
+// the same two kernels over a list of matrices (kernels.h: QuantList); one wave per row, 16 bytes per lane and load
+template <bool SRC_BF16> __global__ __launch_bounds__(256) void quantize_rows_many_kernel(QuantList L) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int grow = blockIdx.x * 4 + wave;
+  if (grow >= L.row_begin[L.count]) return;
+  int s = 0;
+  while (s + 1 < L.count && grow >= L.row_begin[s + 1]) ++s;
+  const int r = grow - L.row_begin[s], cols = L.cols[s];
+  fp8_t* q = reinterpret_cast<fp8_t*>(L.q[s]) + (size_t)r * cols;
+  float amax = 0.f;
+  if constexpr (SRC_BF16) {
+    const bf16_t* row = reinterpret_cast<const bf16_t*>(L.src[s]) + (size_t)r * cols;
+    for (int c = lane * 8; c < cols; c += 512) {
+      float v[8];
+      load8(row + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? 448.0f / amax : 1.0f;
+    for (int c = lane * 8; c < cols; c += 512) {
+      float v[8];
+      load8(row + c, v);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] *= sc;
+      store8(q + c, v);
+    }
+    if (lane == 0) L.dq[s][r] = 1.0f / sc;
+  } else {
+    const float* row = reinterpret_cast<const float*>(L.src[s]) + (size_t)r * cols;
+    for (int c = lane * 4; c < cols; c += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(row + c);
+      amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? 448.0f / amax : 1.0f;
+    for (int c = lane * 4; c < cols; c += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(row + c);
+      store4(q + c, v.x * sc, v.y * sc, v.z * sc, v.w * sc);
+    }
+    if (lane == 0) L.dq[s][r] = 1.0f / sc;
+  }
+}
+
 // fp8 training: bf16 tensor -> e4m3 with the slot's scale (delayed scaling: the scale comes from the previous step's amax),
 // recording this step's amax.  16 bytes in, 8 bytes out per lane; HBM-bound (3 bytes per element).
 __global__ __launch_bounds__(256) void f8_quantize_kernel(const bf16_t* __restrict__ src, fp8_t* __restrict__ dst, size_t n8,
@@ -480,6 +524,18 @@ __global__ __launch_bounds__(256) void f8_update_kernel(float* __restrict__ slot
 int launch_quantize_rows(const float* w, int rows, int cols, void* q, float* dequant, float act_scale, hipStream_t st) {
   OSUD_CHECK_ARG(cols % 4 == 0, "quantize_rows: cols=%d must be a multiple of 4", cols);
   hipLaunchKernelGGL(quantize_rows_kernel, dim3(rows), dim3(256), 0, st, w, cols, (fp8_t*)q, dequant, act_scale);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+int launch_quantize_rows_many(bool src_bf16, const QuantList& L, hipStream_t st) {
+  if (L.count == 0) return OSUD_OK;
+  OSUD_CHECK_ARG(L.count <= QuantList::kMax, "quantize_rows_many: list too long (%d)", L.count);
+  for (int i = 0; i < L.count; ++i)
+    OSUD_CHECK_ARG(L.cols[i] % 8 == 0 && L.src[i] && L.q[i] && L.dq[i], "quantize_rows_many: cols=%d must be a multiple of 8, no null pointers", L.cols[i]);
+  const int rows = L.row_begin[L.count];
+  if (src_bf16) hipLaunchKernelGGL(quantize_rows_many_kernel<true>, dim3((rows + 3) / 4), dim3(256), 0, st, L);
+  else hipLaunchKernelGGL(quantize_rows_many_kernel<false>, dim3((rows + 3) / 4), dim3(256), 0, st, L);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }

@@ -50,10 +50,13 @@ int build_transposed(osud_dit* m, hipStream_t st) {
   OSUD_TRY(T_(m->w_t2, D, D, &m->w_t2_t));
   OSUD_TRY(launch_transpose_many(prec, tl, st));
   if (m->fp8) {  // fp8 training: e4m3 twins of the transposed weights, one scale per row (= per output column of the dgrad product)
+    QuantBatch quants(true, st);
     for (auto& b : m->blk) {
       auto Q8 = [&](void* src, int rows, int cols, void** q, float** dq) -> int {
         if (!*q) OSUD_TRY(dev_alloc(m->owned, q, (size_t)rows * cols, false));
         if (!*dq) OSUD_TRY(dev_alloc(m->owned, dq, (size_t)rows * 4, false));
+        static const bool quant_batched = [] { const char* e = getenv("OSUD_QUANT_BATCH"); return !(e && e[0] == '0'); }();
+        if (cols % 8 == 0 && quant_batched) return quants.add(src, rows, cols, *q, *dq);
         return launch_quantize_rows_bf16(src, rows, cols, *q, *dq, st);
       };
       OSUD_TRY(Q8(b.w_qkv_t, D, 3 * D, &b.w_qkv_t8, &b.dq_qkv_t));
@@ -61,6 +64,7 @@ int build_transposed(osud_dit* m, hipStream_t st) {
       OSUD_TRY(Q8(b.w1_t, D, 4 * D, &b.w1_t8, &b.dq_1_t));
       OSUD_TRY(Q8(b.w2_t, 4 * D, D, &b.w2_t8, &b.dq_2_t));
     }
+    OSUD_TRY(quants.flush());
   }
   m->transposed_ready = true;
   return OSUD_OK;
@@ -624,10 +628,16 @@ extern "C" int osud_dit_refresh_phases(osud_dit* m, int phase_lo, int phase_hi, 
   SegBatch copies(SEG_COPY, m->prec, (hipStream_t)stream), converts(SEG_CONVERT, m->prec, (hipStream_t)stream);
   struct Guard {
     osud_dit* m;
-    ~Guard() { m->defer_copy = m->defer_convert = nullptr; }
+    ~Guard() {
+      m->defer_copy = m->defer_convert = nullptr;
+      m->defer_quant = nullptr;
+    }
   } guard{m};
+  QuantBatch quants(false, (hipStream_t)stream);
   m->defer_copy = &copies;
   m->defer_convert = &converts;
+  static const bool quant_batched = [] { const char* e = getenv("OSUD_QUANT_BATCH"); return !(e && e[0] == '0'); }();
+  if (quant_batched) m->defer_quant = &quants;
   for (auto& kv : items) {
     int64_t shape[2];
     int nd = 0;
@@ -656,7 +666,9 @@ extern "C" int osud_dit_refresh_phases(osud_dit* m, int phase_lo, int phase_hi, 
   }
   OSUD_TRY(copies.flush());
   OSUD_TRY(converts.flush());
+  OSUD_TRY(quants.flush());
   m->defer_copy = m->defer_convert = nullptr;
+  m->defer_quant = nullptr;
   return OSUD_OK;
 }
 
