@@ -55,6 +55,11 @@ extern "C" {
                             16 significand bits per operand, finer than the TF32 matmuls of the reference's sampling path
                             (sample.py:25-26), at a third of the bf16 tier's MFMA rate instead of the f32 tier's sixteenth */
 
+#define OSUD_PREC_F16F8 4 /* the tolerance tier's faster form, inference only: OSUD_PREC_BF16X3 with the four big GEMMs of every block
+                            (in_proj, out_proj, fc1, fc2) on fp16 + e4m3-residual operands: v = hi (fp16) + 2^-12 lo8 (e4m3), product =
+                            hi*hi on v_mfma_f32_32x32x16_f16 + both cross terms in ONE block-scaled v_mfma_scale_f32_32x32x64_f8f6f4
+                            -- 15 significand bits per operand at 2/3 of the split-bf16 form's matrix-pipe passes */
+
 typedef struct osud_dit osud_dit;
 typedef struct osud_sched osud_sched;
 typedef void* osud_stream; /* hipStream_t */
@@ -250,6 +255,9 @@ int osud_set_gemm_dynamic_tiles(int on);
 int osud_op_gemm(int precision, int epilogue, const void* Y, int ldy, const void* X, int ldx, int My, int Nx, int K,
                  void* out, int ldo, const float* bias, const float* gate, int ld_gate, int rows_per_sample,
                  int n_samples, osud_stream stream);
+/* fp16 + e4m3 operand form of OSUD_PREC_F16F8 (csrc/common.h: h8_t): src fp32 [rows][ld_src] (cols_src used, zero padded to cols_dst,
+ * a multiple of 32) -> dst [rows][4 * cols_dst bytes], K-blocked groups of 32; weight = 1 for the weight flavour (planes swapped). */
+int osud_op_pack_h8(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, int weight, osud_stream stream);
 /* Convert n fp32 values to the tier's element type (bf16 round-to-nearest-even or f32 copy). */
 int osud_op_convert(int precision, const float* src, void* dst, size_t n, osud_stream stream);
 /* Attention core on the packed in_proj output qkv [Mp][ld_qkv] (Q | K | V, head h = hd columns): out [Mp][hidden]. */

@@ -18,7 +18,9 @@ SAMPLER_P, SAMPLER_DDIM = 0, 1
 PREC_FP8 = 2  # inference only: bf16 tier with e4m3 operands in the four big per-block GEMMs
 PREC_BF16X3 = 3  # inference only: split-bf16 operands (hi + lo planes), three bf16 MFMAs per product -- the tier that meets the
 #                  reference's 1e-3 tolerance at MFMA speed (the reference's own sampling matmuls are TF32: sample.py:25-26)
-PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32, "fp8": PREC_FP8, "bf16x3": PREC_BF16X3}
+PREC_F16F8 = 4  # inference only: the split-bf16 tier with the four big GEMMs of a block on fp16 + e4m3-residual operands (15
+#                 significand bits per operand; fp16 hi product + ONE block-scaled e4m3 MFMA for both cross terms: 2/3 of the passes)
+PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32, "fp8": PREC_FP8, "bf16x3": PREC_BF16X3, "fp16f8": PREC_F16F8}
 
 # gemm epilogue codes (csrc/gemm.h)
 EPI_BIAS_F32, EPI_BIAS_TE, EPI_BIAS_SILU_TE, EPI_ROWBIAS_TE, EPI_BIAS_GELU_TE, EPI_GATE_RES = range(6)
@@ -81,6 +83,7 @@ _SIGNATURES = {
     "osud_table_rows_apply": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "osud_op_gemm": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "osud_op_convert": (_i, [_i, _vp, _vp, _sz, _vp]),
+    "osud_op_pack_h8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "osud_set_gemm_dynamic_tiles": (_i, [_i]),
     "osud_op_attention": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "osud_op_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),

@@ -41,6 +41,17 @@ struct fp8_t { uint8_t v; };  // OCP e4m3 storage (experimental GEMM operand typ
 // LAYOUT: a matrix with logical leading dimension ld is a bf16 array whose rows are 2 * ld long -- the hi plane in columns
 // [0, ld), the lo plane in [ld, 2 ld).  x3_t is the element type of such a matrix in templates (one plane element = one bf16).
 struct x3_t { uint16_t v; };
+// fp16 + e4m3 residual tier (OSUD_PREC_F16F8, the four big GEMMs of a block inside the split-bf16 tier): an fp32 value v travels as
+//   hi = fp16(v) (11 significand bits), lo8 = e4m3((v - hi) * 2^12) (4 more), hi8 = e4m3(v) (the partner of the OTHER operand's lo8)
+// and a product over 32 k is   hi.hi  (two v_mfma_f32_32x32x16_f16)  +  2^-12 (lo8_a.hi8_w + hi8_a.lo8_w)  (ONE block-scaled
+// v_mfma_scale_f32_32x32x64_f8f6f4 over the K-concatenated e4m3 planes): 32 MFMA passes where the split-bf16 form needs 48, at
+// 15 significand bits per operand (split-bf16: 16; TF32, the reference's sampling arithmetic: 11).
+// LAYOUT (h8_t: 4 bytes per logical element, K-blocked): a row is a sequence of 128-byte groups of 32 logical k --
+//   [ 64 B: 32 x fp16 hi | 32 B: plane P | 32 B: plane Q ],   activations: P = lo8, Q = hi8;  weights: P = hi8, Q = lo8
+// -- exactly one stage row of the GEMM's LDS image, so the operand travels by the plain 128-byte LDS-DMA; P meets P and Q meets Q
+// in the fp8 MFMA, which pairs lo8_a with hi8_w and hi8_a with lo8_w.  Leading dimensions and K are multiples of 32.
+struct h8_t { uint8_t b[4]; };
+constexpr float kH8LoScale = 4096.0f;  // 2^12: lo8 = e4m3((v - hi) * 2^12); the fp8 MFMA's A-side block scale is 2^-12
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -171,6 +182,60 @@ __device__ __forceinline__ void store_elem_x3(bf16_t* p, size_t ld, float v) {
   p[0] = hi;
   p[ld] = f2bf(v - bf2f(hi));
 }
+// ---- fp16 + e4m3 rows (h8_t): 8 (4) consecutive logical elements at column x (x % 8 == 0 (4)) of the row starting at `row`
+typedef _Float16 f16x2_hw __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_h2(float a, float b, float& ra, float& rb) {  // fp16 pair (RNE) and the residuals
+  f32x2_hw v;
+  v[0] = a;
+  v[1] = b;
+  const f16x2_hw h = __builtin_convertvector(v, f16x2_hw);
+  ra = a - (float)h[0];
+  rb = b - (float)h[1];
+  return __builtin_bit_cast(uint32_t, h);
+}
+template <bool WEIGHT> __device__ __forceinline__ void store4_h8(h8_t* row, int x, float a, float b, float c, float d) {
+  char* g = reinterpret_cast<char*>(row) + (size_t)(x >> 5) * 128;
+  const int i = x & 31;
+  float r0, r1, r2, r3;
+  uint2 hi;
+  hi.x = pack_h2(a, b, r0, r1);
+  hi.y = pack_h2(c, d, r2, r3);
+  *reinterpret_cast<uint2*>(g + 2 * i) = hi;
+  const uint32_t lo8 = pack_fp8x4(r0 * kH8LoScale, r1 * kH8LoScale, r2 * kH8LoScale, r3 * kH8LoScale), hi8 = pack_fp8x4(a, b, c, d);
+  *reinterpret_cast<uint32_t*>(g + 64 + i) = WEIGHT ? hi8 : lo8;
+  *reinterpret_cast<uint32_t*>(g + 96 + i) = WEIGHT ? lo8 : hi8;
+}
+template <bool WEIGHT> __device__ __forceinline__ void store8_h8(h8_t* row, int x, const float (&v)[8]) {
+  char* g = reinterpret_cast<char*>(row) + (size_t)(x >> 5) * 128;
+  const int i = x & 31;
+  float r[8];
+  uint4 hi;
+  hi.x = pack_h2(v[0], v[1], r[0], r[1]);
+  hi.y = pack_h2(v[2], v[3], r[2], r[3]);
+  hi.z = pack_h2(v[4], v[5], r[4], r[5]);
+  hi.w = pack_h2(v[6], v[7], r[6], r[7]);
+  *reinterpret_cast<uint4*>(g + 2 * i) = hi;
+  uint2 lo8, hi8;
+  lo8.x = pack_fp8x4(r[0] * kH8LoScale, r[1] * kH8LoScale, r[2] * kH8LoScale, r[3] * kH8LoScale);
+  lo8.y = pack_fp8x4(r[4] * kH8LoScale, r[5] * kH8LoScale, r[6] * kH8LoScale, r[7] * kH8LoScale);
+  hi8.x = pack_fp8x4(v[0], v[1], v[2], v[3]);
+  hi8.y = pack_fp8x4(v[4], v[5], v[6], v[7]);
+  *reinterpret_cast<uint2*>(g + 64 + i) = WEIGHT ? hi8 : lo8;
+  *reinterpret_cast<uint2*>(g + 96 + i) = WEIGHT ? lo8 : hi8;
+}
+// (like x3_t: written through the helpers above, never read back element-wise; these overloads only let shared templates compile)
+__device__ __forceinline__ void store8(h8_t*, const float (&)[8]) { __builtin_trap(); }
+__device__ __forceinline__ void store4(h8_t*, float, float, float, float) { __builtin_trap(); }
+__device__ __forceinline__ void store2(h8_t*, float, float) { __builtin_trap(); }
+__device__ __forceinline__ void store_elem(h8_t*, float) { __builtin_trap(); }
+__device__ __forceinline__ void load8(const h8_t*, float (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  __builtin_trap();
+}
+__device__ __forceinline__ void load2(const h8_t*, float& a, float& b) { a = b = 0.f; __builtin_trap(); }
+__device__ __forceinline__ float load_elem(const h8_t*) { __builtin_trap(); return 0.f; }
+
 // x3_t tensors are written through the *_x3 helpers above (they need the plane distance) and never read back element-wise by the
 // row-wise kernels: these overloads only let the shared templates compile -- reaching one is a bug
 __device__ __forceinline__ void store8(x3_t*, const float (&)[8]) { __builtin_trap(); }
@@ -229,6 +294,12 @@ template <int W> __device__ __forceinline__ void loadw(const x3_t*, float* v) { 
   for (int e = 0; e < W; ++e) v[e] = 0.f;
   __builtin_trap();
 }
+template <int W> __device__ __forceinline__ void loadw(const h8_t*, float* v) {
+#pragma unroll
+  for (int e = 0; e < W; ++e) v[e] = 0.f;
+  __builtin_trap();
+}
+template <int W> __device__ __forceinline__ void storew(h8_t*, const float*) { __builtin_trap(); }
 template <int W> __device__ __forceinline__ void storew(x3_t*, const float*) { __builtin_trap(); }
 template <int W> __device__ __forceinline__ void storew_x3(bf16_t* p, size_t ld, const float* v) {
   if constexpr (W == 4) store4_x3(p, ld, v[0], v[1], v[2], v[3]);

@@ -757,12 +757,17 @@ extern "C" int osud_op_gemm(int precision, int epilogue, const void* Y, int ldy,
                             int K, void* out, int ldo, const float* bias, const float* gate, int ld_gate,
                             int rows_per_sample, int n_samples, osud_stream stream) {
   OSUD_CHECK_ARG(precision == OSUD_PREC_BF16 || precision == OSUD_PREC_F32 || precision == 2 /* experimental fp8 e4m3 operands */ ||
-                     precision == OSUD_PREC_BF16X3 /* plane pairs [hi | lo]: ld counts logical columns */,
+                     precision == OSUD_PREC_BF16X3 /* plane pairs [hi | lo]: ld counts logical columns */ ||
+                     precision == OSUD_PREC_F16F8 /* K-blocked fp16 + e4m3 groups: ld counts logical columns */,
                  "op_gemm: unknown precision");
   GemmP p{};
   p.Y = Y; p.X = X; p.ldy = ldy; p.ldx = ldx; p.My = My; p.Nx = Nx; p.K = K; p.out = out; p.ldo = ldo; p.bias = bias;
   p.gate = gate; p.ld_gate = ld_gate; p.rows_per_sample = rows_per_sample; p.n_samples = n_samples;
   return launch_gemm(precision, epilogue, p, (hipStream_t)stream);
+}
+extern "C" int osud_op_pack_h8(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, int weight, osud_stream stream) {
+  OSUD_CHECK_ARG(src && dst, "op_pack_h8: null argument");
+  return launch_pack_rows_h8(src, ld_src, cols_src, dst, cols_dst, rows, weight != 0, (hipStream_t)stream);
 }
 extern "C" int osud_op_convert(int precision, const float* src, void* dst, size_t n, osud_stream stream) {
   OSUD_CHECK_ARG(src && dst, "op_convert: null argument");

@@ -13,6 +13,7 @@ int launch_gemm_bf16(int epi, const GemmP& p, hipStream_t st);
 int launch_gemm_f32(int epi, const GemmP& p, hipStream_t st);
 int launch_gemm_fp8(int epi, const GemmP& p, hipStream_t st);
 int launch_gemm_x3(int epi, const GemmP& p, hipStream_t st);
+int launch_gemm_h8(int epi, const GemmP& p, hipStream_t st);
 
 namespace {
 constexpr int SLAB = 128;
@@ -118,6 +119,12 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
     OSUD_CHECK_ARG(p.K % 64 == 0 && p.ldy % 8 == 0 && p.ldx % 8 == 0 && p.ldy >= p.K && p.ldx >= p.K,
                    "gemm: split-bf16 operands need K %% 64 == 0 and plane widths (ld) >= K, multiples of 8 (K=%d ldy=%d ldx=%d)", p.K, p.ldy, p.ldx);
     return launch_gemm_x3(epi, p, st);
+  }
+  if (prec == OSUD_PREC_F16F8) {
+    OSUD_CHECK_ARG(p.split_k <= 1, "gemm: the fp16 + e4m3 operand form has no split-K");
+    OSUD_CHECK_ARG(p.K % 32 == 0 && p.ldy % 32 == 0 && p.ldx % 32 == 0 && p.ldy >= p.K && p.ldx >= p.K,
+                   "gemm: fp16 + e4m3 operands are K-blocked in groups of 32 (K=%d ldy=%d ldx=%d)", p.K, p.ldy, p.ldx);
+    return launch_gemm_h8(epi, p, st);
   }
   if (prec == 2) return launch_gemm_fp8(epi, p, st);
   return prec == OSUD_PREC_BF16 ? launch_gemm_bf16(epi, p, st) : launch_gemm_f32(epi, p, st);

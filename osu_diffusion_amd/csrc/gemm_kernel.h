@@ -69,6 +69,18 @@ __device__ __forceinline__ void mma_f8(f32x16& acc, const u32x4& a0, const u32x4
   acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 template <> __device__ __forceinline__ void mma<fp8_t>(f32x16&, const u32x4&, const u32x4&) {}  // fp8 goes through mma_f8
+// fp16 + e4m3 operands (h8_t, common.h): the fp16 hi product, and the two cross terms in ONE e4m3 instruction whose A-side block
+// scale 2^-12 (E8M0 115) undoes the 2^12 the lo8 planes carry
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ void mma_f16(f32x16& acc, const u32x4& a, const u32x4& b) {
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), acc, 0, 0, 0);
+}
+__device__ __forceinline__ void mma_f8_lo(f32x16& acc, const u32x4& a0, const u32x4& a1, const u32x4& b0, const u32x4& b1) {
+  i32x8 a, b;
+  a[0] = a0[0]; a[1] = a0[1]; a[2] = a0[2]; a[3] = a0[3]; a[4] = a1[0]; a[5] = a1[1]; a[6] = a1[2]; a[7] = a1[3];
+  b[0] = b0[0]; b[1] = b0[1]; b[2] = b0[2]; b[3] = b0[3]; b[4] = b1[0]; b[5] = b1[1]; b[6] = b1[2]; b[7] = b1[3];
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, 0x73737373, 0, 0x7f7f7f7f);
+}
 
 #define OSUD_LGKM_WAIT(n)                                  \
   asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory"); \
@@ -184,6 +196,7 @@ __device__ __forceinline__ void compute_slab(f32x16 (&acc)[RY][RX], const uint32
 // 8 consecutive output elements of row `row` at column x of a TO matrix with logical leading dimension ldo
 template <typename TO> __device__ __forceinline__ void store8_out(void* base, size_t row, int ldo, int x, const float (&v)[8]) {
   if constexpr (std::is_same<TO, x3_t>::value) store8_x3(reinterpret_cast<bf16_t*>(base) + row * (size_t)(2 * ldo) + x, (size_t)ldo, v);
+  else if constexpr (std::is_same<TO, h8_t>::value) store8_h8<false>(reinterpret_cast<h8_t*>(base) + row * (size_t)ldo, x, v);  // (an activation)
   else store8(reinterpret_cast<TO*>(base) + row * (size_t)ldo + x, v);
 }
 
@@ -218,6 +231,34 @@ __device__ __forceinline__ void compute_slab_x3(f32x16 (&acc)[RY][RX], const uin
   wait_lgkm<0>();
   mma_cross<RY, RX>(acc, lo, h1);
   mma_cross<RY, RX>(acc, h1, lo);
+}
+
+// fp16 + e4m3 operands (h8_t): a 128-byte stage row is one K-blocked group of 32 logical k -- chunks 0..3 the fp16 hi values (sub-steps
+// 0, 1), chunks 4, 5 plane P and 6, 7 plane Q (sub-steps 2, 3 hand a lane P | Q of its 16 k) -- 16 fp16 MFMAs and 8 K = 64 e4m3 MFMAs per
+// slab and wave: 32 matrix-pipe passes per 32 x 32 x 32 block where the split-bf16 form issues 48.  Three fragment sets live at a time.
+template <int RY, int RX>
+__device__ __forceinline__ void compute_slab_h8(f32x16 (&acc)[RY][RX], const uint32_t (&ya)[4], const uint32_t (&xa)[4], uint32_t so) {
+  FragSet<RY, RX> a, b, c;
+  read_set<RY, RX>(a, ya[0] + so, xa[0] + so);
+  read_set<RY, RX>(b, ya[1] + so, xa[1] + so);
+  wait_lgkm<RY + RX>();  // a (b still in flight)
+#pragma unroll
+  for (int i = 0; i < RY; ++i)
+#pragma unroll
+    for (int j = 0; j < RX; ++j) mma_f16(acc[i][j], a.x[j], a.y[i]);
+  read_set<RY, RX>(c, ya[2] + so, xa[2] + so);
+  wait_lgkm<RY + RX>();  // b
+#pragma unroll
+  for (int i = 0; i < RY; ++i)
+#pragma unroll
+    for (int j = 0; j < RX; ++j) mma_f16(acc[i][j], b.x[j], b.y[i]);
+  __builtin_amdgcn_sched_barrier(0);  // a's registers are re-used: its readers are issued
+  read_set<RY, RX>(a, ya[3] + so, xa[3] + so);
+  wait_lgkm<0>();
+#pragma unroll
+  for (int i = 0; i < RY; ++i)
+#pragma unroll
+    for (int j = 0; j < RX; ++j) mma_f8_lo(acc[i][j], c.x[j], a.x[j], c.y[i], a.y[i]);
 }
 
 // Tile geometry: WY x WX waves, each wave (RY*32) x (RX*32) outputs: BM = WY*RY*32 rows of Y, BN = WX*RX*32 rows of X.
@@ -311,9 +352,14 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
   static_assert(!ROLES || SB == SLAB, "the role split is built on the two-stage 128-byte form");
   constexpr int BN = G::BN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool FAST = sizeof(TE) <= 2;
+  constexpr bool FAST = !std::is_same<TE, float>::value;
   constexpr bool kF8 = sizeof(TE) == 1;  // fp8 operands: outputs are bf16 (EPI_BIAS_TE), fp8 (EPI_BIAS_GELU_TE) or fp32
-  using TO = typename std::conditional<kF8, typename std::conditional<EPI == EPI_BIAS_GELU_TE, fp8_t, bf16_t>::type, TE>::type;
+  // fp16 + e4m3 operands (the trunk GEMMs of the tolerance tier): the bias epilogue (in_proj) feeds the split-bf16 attention kernel and
+  // writes hi | lo planes; the GELU epilogue (fc1) writes the next GEMM's operand form
+  constexpr bool kH8 = std::is_same<TE, h8_t>::value;
+  using TO = typename std::conditional<kF8, typename std::conditional<EPI == EPI_BIAS_GELU_TE, fp8_t, bf16_t>::type,
+                                       typename std::conditional<kH8 && EPI == EPI_BIAS_TE, x3_t, TE>::type>::type;
+  static_assert(!kH8 || SB == SLAB, "the fp16 + e4m3 form is built on 128-byte stage rows");
   constexpr bool kGelu = EPI == EPI_BIAS_GELU_TE || EPI == EPI_BIAS_GELU_BF;  // _BF: fp8 operands with bf16 outputs (training)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -602,6 +648,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
       const uint64_t tt3 = __builtin_readcyclecounter();
 #endif
       if constexpr (kX3) compute_slab_x3<RY, RX>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
+      else if constexpr (kH8) compute_slab_h8<RY, RX>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
       else compute_slab<TE, RY, RX, SB>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
 #ifdef OSUD_GEMM_TIMING
       {
@@ -909,7 +956,7 @@ template <typename TE, int EPI, int WY, int WX, int RY, int RX, int SB = SLAB> i
   constexpr bool kDynFits = G::NSTAGE * G::STAGE + (G::PATCH_OUT ? G::NW * 4096 : 0) + 64 <= G::LDS_MAX;
   const size_t lds = ring + (G::PATCH_OUT ? (size_t)G::NW * 4096 : 0) + (kDynFits ? 64 : 0);
   // the role-split main loop: 8-wave geometries with two stages (the 64 KiB-per-stage tiles), piece sets divisible by 4 waves
-  constexpr bool kRolesOk = !std::is_same<TE, x3_t>::value && SB == SLAB && G::NW == 8 && G::NSTAGE == 2 && (G::BM / 16 + G::BN / 8) % 4 == 0 && (G::BM / 16) % 4 == 0;
+  constexpr bool kRolesOk = !std::is_same<TE, x3_t>::value && !std::is_same<TE, h8_t>::value && SB == SLAB && G::NW == 8 && G::NSTAGE == 2 && (G::BM / 16 + G::BN / 8) % 4 == 0 && (G::BM / 16) % 4 == 0;
   static bool attr_set = false;
   if (!attr_set) {
     OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX, false, SB>),
@@ -986,7 +1033,7 @@ template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
   }
   {  // half slabs + deeper ring for the 256x256 geometry (OSUD_GEMM_SLAB=128 selects the two-stage form for A/B runs)
     static const bool half_slabs = [] { const char* e = getenv("OSUD_GEMM_SLAB"); return e && atoi(e) == 64; }();
-    if constexpr (!std::is_same<TE, x3_t>::value)
+    if constexpr (!std::is_same<TE, x3_t>::value && !std::is_same<TE, h8_t>::value)
       if (pick == 2 && half_slabs) return launch_w<TE, EPI, 2, 4, 4, 2, 64>(p, st);
   }
   if (pick == 2) return launch_w<TE, EPI, 2, 4, 4, 2>(p, st);

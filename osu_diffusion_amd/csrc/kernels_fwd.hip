@@ -387,6 +387,19 @@ __global__ void pack_rows_x3_kernel(const float* __restrict__ src, int ld_src, i
   }
 }
 
+// fp16 + e4m3 tier: dst row = K-blocked groups of 32 logical columns (common.h: h8_t), zero padded to cols_dst
+template <bool WEIGHT> __global__ void pack_rows_h8_kernel(const float* __restrict__ src, int ld_src, int cols_src, h8_t* __restrict__ dst,
+                                                            int cols_dst, int rows) {
+  const size_t total = (size_t)rows * (cols_dst / 4);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / (cols_dst / 4)), cc = (int)(i % (cols_dst / 4)) * 4;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = cc + e < cols_src ? src[(size_t)r * ld_src + cc + e] : 0.f;
+    store4_h8<WEIGHT>(dst + (size_t)r * cols_dst, cc, v[0], v[1], v[2], v[3]);
+  }
+}
+
 // fp8 tier: one weight row (output channel) per block -> e4m3 with the row's own scale 448 / max|w|;
 // dequant[x] = max|w_x| / (448 * act_scale) is what the GEMM epilogue multiplies the accumulator with
 __global__ __launch_bounds__(256) void quantize_rows_kernel(const float* __restrict__ w, int cols, fp8_t* __restrict__ q,
@@ -596,6 +609,17 @@ int launch_pack_rows_x3(const float* src, int ld_src, int cols_src, void* dst, i
   if (total == 0) return OSUD_OK;
   const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   hipLaunchKernelGGL(pack_rows_x3_kernel, dim3(grid), dim3(256), 0, st, src, ld_src, cols_src, (bf16_t*)dst, cols_dst, rows);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+int launch_pack_rows_h8(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, bool weight, hipStream_t st) {
+  OSUD_CHECK_ARG(cols_dst % 32 == 0 && cols_src <= cols_dst, "pack_rows_h8: cols_dst=%d must be a multiple of 32 and >= cols_src=%d", cols_dst, cols_src);
+  const size_t total = (size_t)rows * (cols_dst / 4);
+  if (total == 0) return OSUD_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  if (weight) hipLaunchKernelGGL(pack_rows_h8_kernel<true>, dim3(grid), dim3(256), 0, st, src, ld_src, cols_src, (h8_t*)dst, cols_dst, rows);
+  else hipLaunchKernelGGL(pack_rows_h8_kernel<false>, dim3(grid), dim3(256), 0, st, src, ld_src, cols_src, (h8_t*)dst, cols_dst, rows);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }
