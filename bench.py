@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--xl-precision", choices=["bf16", "fp8"], default=None, help="tier of the DiT-XL line (default: both, bf16 first)")
     ap.add_argument("--batch", type=int, default=256, help="training windows per GPU")
     ap.add_argument("--sample-steps", type=int, default=None, help="timed sampling steps in mode both (default 1000)")
-    ap.add_argument("--precision", choices=["bf16", "fp32", "fp8", "bf16x3"], default="bf16")
+    ap.add_argument("--precision", choices=["bf16", "fp32", "fp8", "bf16x3", "fp16f8"], default="bf16")
     ap.add_argument("--maps", type=int, default=64, help="beatmap windows per GPU (CFG doubles the batch)")
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--model", default="DiT-B")
@@ -503,7 +503,8 @@ def bench_sample(args, world, rank, dev):
         "metric": f"1000-step CFG sample steps/sec ({args.model} seq{args.seq_len})", "value": round(world * steps_per_s, 3),
         "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": {"bf16": "bf16", "fp32": "f32", "fp8": "fp8(e4m3 GEMM operands)+bf16", "bf16x3": "bf16x3(split-bf16 operands, 3 MFMAs per product)"}[args.precision], "data": "synthetic",
+        "dtype": {"bf16": "bf16", "fp32": "f32", "fp8": "fp8(e4m3 GEMM operands)+bf16", "bf16x3": "bf16x3(split-bf16 operands, 3 MFMAs per product)",
+                  "fp16f8": "fp16f8(split-bf16 tier with the four big GEMMs on fp16 + e4m3-residual operands)"}[args.precision], "data": "synthetic",
         "config": {"workload": f"sample.py path: {args.model} seq-len {T}, {n} synthetic beatmap windows x2 (CFG) per GPU, "
                                f"cfg-scale 4.0, 1000-step squaredcos schedule, steps t=999..{999 - K + 1}",
                    "rows_per_gpu": 2 * n, "seq_len": T, "sharding": "rows per rank, no collective"},

@@ -223,6 +223,19 @@ template <bool WEIGHT> __device__ __forceinline__ void store8_h8(h8_t* row, int 
   *reinterpret_cast<uint2*>(g + 64 + i) = WEIGHT ? hi8 : lo8;
   *reinterpret_cast<uint2*>(g + 96 + i) = WEIGHT ? lo8 : hi8;
 }
+template <bool WEIGHT> __device__ __forceinline__ void store2_h8(h8_t* row, int x, float a, float b) {
+  char* g = reinterpret_cast<char*>(row) + (size_t)(x >> 5) * 128;
+  const int i = x & 31;
+  float r0, r1;
+  *reinterpret_cast<uint32_t*>(g + 2 * i) = pack_h2(a, b, r0, r1);
+  const uint16_t lo8 = (uint16_t)(pack_fp8x4(r0 * kH8LoScale, r1 * kH8LoScale, 0.f, 0.f) & 0xffffu), hi8 = (uint16_t)(pack_fp8x4(a, b, 0.f, 0.f) & 0xffffu);
+  *reinterpret_cast<uint16_t*>(g + 64 + i) = WEIGHT ? hi8 : lo8;
+  *reinterpret_cast<uint16_t*>(g + 96 + i) = WEIGHT ? lo8 : hi8;
+}
+template <int W> __device__ __forceinline__ void storew_h8(h8_t* row, int x, const float* v) {  // (an activation row)
+  if constexpr (W == 4) store4_h8<false>(row, x, v[0], v[1], v[2], v[3]);
+  else store2_h8<false>(row, x, v[0], v[1]);
+}
 // (like x3_t: written through the helpers above, never read back element-wise; these overloads only let shared templates compile)
 __device__ __forceinline__ void store8(h8_t*, const float (&)[8]) { __builtin_trap(); }
 __device__ __forceinline__ void store4(h8_t*, float, float, float, float) { __builtin_trap(); }

@@ -85,6 +85,8 @@ struct osud_dit {
   bool split_first = false;
   int device = -1;
   bool training = false;
+  bool h8 = false;   // OSUD_PREC_F16F8: prec == BF16X3 (x3 set), and the four big GEMMs of every block on fp16 + e4m3 operands (h8_t): their
+                     // weights, the LayerNorm / attention / GELU outputs that feed them
   bool x3 = false;   // OSUD_PREC_BF16X3: prec == BF16X3, every TE matrix a plane pair [hi | lo] (common.h); inference only
   bool fp8 = false;  // OSUD_PREC_FP8: prec == BF16 everywhere except the e4m3 operands of qkv / out_proj / fc1 / fc2
 
@@ -182,12 +184,19 @@ template <typename P> inline int dev_alloc(std::vector<void*>& owner, P** out, s
 
 inline int gemm(osud_dit* m, int epi, const void* Y, int ldy, const void* X, int ldx, int My, int Nx, int K, void* out,
                 int ldo, const float* bias, hipStream_t st, const float* gate = nullptr, int ld_gate = 0, int Tp = 0,
-                int N = 0, void* out2 = nullptr, const float* res = nullptr, const void* aux = nullptr) {
+                int N = 0, void* out2 = nullptr, const float* res = nullptr, const void* aux = nullptr, int prec = -1) {
   GemmP p{};
   p.Y = Y; p.X = X; p.ldy = ldy; p.ldx = ldx; p.My = My; p.Nx = Nx; p.K = K;
   p.out = out; p.out2 = out2; p.ldo = ldo; p.bias = bias; p.gate = gate; p.ld_gate = ld_gate;
   p.rows_per_sample = Tp; p.n_samples = N; p.res = res; p.aux = aux;
-  return launch_gemm(m->prec, epi, p, st);
+  return launch_gemm(prec >= 0 ? prec : m->prec, epi, p, st);
+}
+// one of the four big GEMMs of a block (in_proj, out_proj, fc1, fc2): OSUD_PREC_F16F8 runs these -- and only these -- on fp16 + e4m3
+// operands (m->h8; everything else of that tier is the split-bf16 tier)
+inline int gemm_blk(osud_dit* m, int epi, const void* Y, int ldy, const void* X, int ldx, int My, int Nx, int K, void* out,
+                    int ldo, const float* bias, hipStream_t st, const float* gate = nullptr, int ld_gate = 0, int Tp = 0, int N = 0) {
+  return gemm(m, epi, Y, ldy, X, ldx, My, Nx, K, out, ldo, bias, st, gate, ld_gate, Tp, N, nullptr, nullptr, nullptr,
+              m->h8 ? OSUD_PREC_F16F8 : m->prec);
 }
 
 // GEMM on e4m3 operands (fp8 tier): Y [My][K] and X [Nx][K] are fp8, `dequant` the per-column factors, out per epilogue

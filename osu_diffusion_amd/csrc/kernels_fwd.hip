@@ -215,6 +215,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* h, const float
       if (sizeof(TE) == 1) r[e] *= out_scale;  // fp8 operand of the next GEMM, statically scaled
     }
     if constexpr (std::is_same<TE, x3_t>::value) storew_x3<W>(reinterpret_cast<bf16_t*>(orow) + d, (size_t)D, r);
+    else if constexpr (std::is_same<TE, h8_t>::value) storew_h8<W>(orow, d, r);
     else if (!TWIN || out != nullptr) storew<W>(orow + d, r);  // (twin only: every consumer of this step reads the e4m3 form)
     if constexpr (TWIN) {
       float q[W];
@@ -708,6 +709,10 @@ int launch_ln_mod(int prec, const float* h, const float* ada, int ld_ada, int of
   if (prec == OSUD_PREC_BF16X3) {
     OSUD_CHECK_ARG(br == nullptr, "ln_mod: the split-bf16 tier is inference only (no pending branch operand)");
     return ln_mod_t<x3_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, nullptr, 0, h_out);
+  }
+  if (prec == OSUD_PREC_F16F8) {  // (the trunk GEMMs' operand form inside the split-bf16 tier)
+    OSUD_CHECK_ARG(br == nullptr, "ln_mod: the fp16 + e4m3 tier is inference only (no pending branch operand)");
+    return ln_mod_t<h8_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, nullptr, 0, h_out);
   }
   return prec == OSUD_PREC_BF16
              ? ln_mod_t<bf16_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, br, off_gate, h_out)

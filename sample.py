@@ -221,8 +221,8 @@ def parse_args(argv=None):
     p.add_argument("--model", type=str, choices=list(DiT_models.keys()), default="DiT-B")
     # additions of this build
     p.add_argument("--synthetic", type=int, default=0, metavar="T", help="use a synthetic T-token sequence")
-    p.add_argument("--precision", choices=["bf16", "fp32", "fp8", "bf16x3"], default="bf16",
-                   help="bf16: fast tier; bf16x3: split-bf16 operands, meets the 1e-3 tolerance at MFMA speed; fp32: exact-f32 MFMA parity tier; fp8: e4m3 GEMM operands")
+    p.add_argument("--precision", choices=["bf16", "fp32", "fp8", "bf16x3", "fp16f8"], default="bf16",
+                   help="bf16: fast tier; bf16x3: split-bf16 operands, meets the 1e-3 tolerance at MFMA speed; fp16f8: the same tier with the big GEMMs on fp16 + e4m3-residual operands (1.3x faster); fp32: exact-f32 MFMA parity tier; fp8: e4m3 GEMM operands")
     p.add_argument("--sampler", choices=["p", "ddim"], default="p", help="ancestral p_sample loop (reference default) or DDIM")
     p.add_argument("--ddim-eta", type=float, default=0.0)
     p.add_argument("--noise", choices=["gpu", "cpu"], default="gpu",
