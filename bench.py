@@ -554,7 +554,7 @@ def parity_tier_and_drift(args, dev):
     # moved by 1e-6 (a few fp32 ulps of a coordinate).  The third run is the yardstick: it shows how far the sampler map itself
     # carries a rounding-sized difference on these (random, untrained) weights, i.e. what ANY two implementations may differ by.
     marks = [k for k in (1, 10, 50, 100, 250, 500, 1000) if k < S] + [S]
-    runs = (("bf16", "bf16", 0.0), ("bf16x3", "bf16x3", 0.0), ("fp32", "fp32", 0.0), ("fp32_moved", "fp32", 1e-6))
+    runs = (("bf16", "bf16", 0.0), ("bf16x3", "bf16x3", 0.0), ("fp16f8", "fp16f8", 0.0), ("fp32", "fp32", 0.0), ("fp32_moved", "fp32", 1e-6))
     states, sec = {}, {}
     pert = torch.randn(n, 2, T, device=dev, generator=g)
     for name, prec, eps in runs:
@@ -599,23 +599,42 @@ def parity_tier_and_drift(args, dev):
                    "sampler map on these weights amplifies rounding-sized differences to full scale, and the end-to-end distance "
                    "between two arithmetic tiers stops measuring their accuracy (the teacher-forced per-step error does: tests)",
         "bf16_loop_ms_per_step": round(sec["bf16"] / S * 1e3, 4)})
-    # The tier that meets the 1e-3 tolerance at MFMA speed: split-bf16 operands (hi + lo planes, three bf16 MFMAs per product).
-    tol = dict(dev_stats(states["bf16x3"][S], states["fp32"][S]))
-    x3_flops = S / sec["bf16x3"] * M * FLOP_PER_TOKEN_FWD / 1e12 if args.model == "DiT-B" and T == 128 else None
-    out["tolerance_tier"] = {
-        "value": round(S / sec["bf16x3"], 3), "unit": "steps/s", "ms_per_step": round(sec["bf16x3"] / S * 1e3, 4), "steps": S,
-        "dtype": "bf16x3 (split-bf16 operands: v = hi + lo, three v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate / residual / statistics)",
-        "tier": "precision=bf16x3: 16 significand bits per GEMM / attention operand (the reference's sampling matmuls are TF32: 11 bits, "
-                "sample.py:25-26); meets the 1e-3 tolerance on final coordinates (tests/test_gpu_x3.py) at a third of the bf16 tier's MFMA rate",
-        "drift_vs_fp32_tier": {"max": tol["max"], "p99": tol["p99"], "mean": tol["mean"], "steps": S,
-                               "after_steps": {str(k): dev_stats(states["bf16x3"][k], states["fp32"][k]) for k in marks},
-                               "what": "same loop, windows and noise as bf16_drift: |x_t(bf16x3 tier) - x_t(fp32 tier)| of the conditional rows"},
-        "meets_1e-3": bool(tol["max"] <= 1e-3),
-        # algorithmic FLOPs (one product per multiply-add of the model) against the bf16 MFMA peak, and the MFMA work actually
-        # issued (three bf16 MFMAs per product) against the same peak
-        "algorithmic_tflops": round(x3_flops, 1) if x3_flops else None,
-        "mfma_frac_algorithmic": round(x3_flops / PEAK_BF16_TFLOPS, 4) if x3_flops else None,
-        "mfma_frac_issued": round(3 * x3_flops / PEAK_BF16_TFLOPS, 4) if x3_flops else None}
+    # The tiers that meet the 1e-3 tolerance at MFMA speed: split-bf16 operands everywhere (bf16x3: hi + lo planes, three bf16 MFMAs
+    # per product), and the same tier with the four big GEMMs of a block on fp16 + e4m3-residual operands (fp16f8: fp16 hi product +
+    # ONE block-scaled e4m3 MFMA for both cross terms = 2/3 of the matrix-pipe passes).  `tolerance_tier` is the faster one that meets
+    # the bound on this run; the other is listed under "also".
+    DTYPES = {
+        "bf16x3": "bf16x3 (split-bf16 operands: v = hi + lo, three v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate / residual / statistics)",
+        "fp16f8": "fp16f8 (the bf16x3 tier with in_proj / out_proj / fc1 / fc2 on v = fp16 hi + 2^-12 e4m3 lo: two v_mfma_f32_32x32x16_f16 + one "
+                  "v_mfma_scale_f32_32x32x64_f8f6f4 per 32 k, fp32 accumulate / residual / statistics)"}
+    TIERS = {
+        "bf16x3": "precision=bf16x3: 16 significand bits per GEMM / attention operand (the reference's sampling matmuls are TF32: 11 bits, "
+                  "sample.py:25-26); meets the 1e-3 tolerance on final coordinates (tests/test_gpu_x3.py) at a third of the bf16 tier's MFMA rate",
+        "fp16f8": "precision=fp16f8: 15 significand bits per operand of the four big GEMMs of a block (16 elsewhere; the reference's sampling "
+                  "matmuls are TF32: 11 bits, sample.py:25-26); meets the 1e-3 tolerance on final coordinates (tests/test_gpu_h8.py) at "
+                  "2/3 of the bf16x3 tier's matrix-pipe passes"}
+    PASSES = {"bf16x3": 3.0, "fp16f8": 2.0}  # matrix-pipe passes per product, in units of one bf16 MFMA pass (the big GEMMs)
+
+    def tier_record(name):
+        tol = dict(dev_stats(states[name][S], states["fp32"][S]))
+        fl = S / sec[name] * M * FLOP_PER_TOKEN_FWD / 1e12 if args.model == "DiT-B" and T == 128 else None
+        return {
+            "value": round(S / sec[name], 3), "unit": "steps/s", "ms_per_step": round(sec[name] / S * 1e3, 4), "steps": S,
+            "dtype": DTYPES[name], "tier": TIERS[name],
+            "drift_vs_fp32_tier": {"max": tol["max"], "p99": tol["p99"], "mean": tol["mean"], "steps": S,
+                                   "after_steps": {str(k): dev_stats(states[name][k], states["fp32"][k]) for k in marks},
+                                   "what": f"same loop, windows and noise as bf16_drift: |x_t({name} tier) - x_t(fp32 tier)| of the conditional rows"},
+            "meets_1e-3": bool(tol["max"] <= 1e-3),
+            # algorithmic FLOPs (one product per multiply-add of the model) against the bf16 MFMA peak, and the matrix-pipe work
+            # actually issued (in bf16-MFMA passes: 3 per product for split-bf16 operands, 2 for fp16 + e4m3) against the same peak
+            "algorithmic_tflops": round(fl, 1) if fl else None,
+            "mfma_frac_algorithmic": round(fl / PEAK_BF16_TFLOPS, 4) if fl else None,
+            "mfma_frac_issued": round(PASSES[name] * fl / PEAK_BF16_TFLOPS, 4) if fl else None}
+
+    recs = {name: tier_record(name) for name in ("bf16x3", "fp16f8")}
+    meeting = [name for name in recs if recs[name]["meets_1e-3"]] or ["bf16x3"]
+    best = max(meeting, key=lambda name: recs[name]["value"])
+    out["tolerance_tier"] = dict(recs[best], name=best, also={name: r for name, r in recs.items() if name != best})
     return out, drift
 
 
@@ -682,10 +701,10 @@ def main():
             res["sampling"]["tolerance"] = {
                 "bound": 1e-3, "unit": "normalised playfield coordinates, max over the conditional rows after the full loop",
                 "this_line": {"tier": "bf16", "max_drift_vs_fp32_tier": bd["max"], "p99": bd["p99"], "meets": bool(bd["max"] <= 1e-3)},
-                "fastest_tier_meeting_it": ({"tier": "bf16x3", "value": tt["value"], "unit": "steps/s", "max_drift_vs_fp32_tier": tt["drift_vs_fp32_tier"]["max"]}
+                "fastest_tier_meeting_it": ({"tier": tt.get("name", "bf16x3"), "value": tt["value"], "unit": "steps/s", "max_drift_vs_fp32_tier": tt["drift_vs_fp32_tier"]["max"]}
                                             if tt["meets_1e-3"] else {"tier": "fp32", "value": res["parity_tier"]["sample"]["value"], "unit": "steps/s"}),
-                "reference_fixture": "tests/golden/g6_loop_p1000_dit_b.npz: the reference's own 1000-step CFG-4 DiT-B loop; tests/test_gpu_x3.py "
-                                     "(fp32 tier 9.8e-5, bf16x3 1.2e-4, bf16 8.8e-3 from it)"}
+                "reference_fixture": "tests/golden/g6_loop_p1000_dit_b.npz: the reference's own 1000-step CFG-4 DiT-B loop; tests/test_gpu_x3.py, "
+                                     "tests/test_gpu_h8.py (fp32 tier 9.8e-5, bf16x3 1.2e-4, fp16f8 1.2e-4, bf16 8.8e-3 from it)"}
             # the fp8 inference tier on the same sampling workload (reduced precision: 0.7 % rms from the fp32 oracle, tests/test_gpu_fp8.py)
             fargs = argparse.Namespace(**vars(args))
             fargs.precision, fargs.steps, fargs.warmup, fargs.no_roofline, fargs.no_cpu_baseline = "fp8", 300, 30, True, True

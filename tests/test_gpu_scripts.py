@@ -60,7 +60,7 @@ def _cli_fixture(tmp_path):
     return fx, str(ckpt), str(idx)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16f8"])
 @pytest.mark.parametrize("tag", ["full100", "trim250"])
 def test_sample_cli_with_cpu_noise_reproduces_the_reference_run(tmp_path, tag, precision):
     """north_star: identical (seed, beatmap, num-sampling-steps) -> final (x, y) within 1e-3 of the reference's CPU path.
