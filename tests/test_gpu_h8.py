@@ -184,3 +184,28 @@ def test_dit_b_1000_step_cfg4_loop_matches_the_reference_fp16_e4m3():
         done = k
     print("MEASURED p1000_dit_b[fp16f8]: max|d| vs reference after 250/500/750/1000 steps = " + " / ".join(f"{errs[k]:.3e}" for k in (250, 500, 750, 1000)))
     assert max(errs.values()) < 1e-3, errs
+
+
+@pytest.mark.parametrize("hidden,heads,T_", [(1152, 16, 256), (1152, 16, 200), (1024, 16, 128)])
+def test_forward_on_other_geometries_against_the_fp32_oracle(hidden, heads, T_):
+    """DiT-XL's geometry (1152 = 18 columns per lane: the 2-wide row stores; heads of 72 columns, which straddle the 32-column groups of
+    the operand rows) and DiT-L's, masked and not: both tolerance tiers against the fp32 oracle (no reference fixture at these widths)."""
+    from oracle import dit_oracle as mo
+    from osu_diffusion_amd.synthetic import banded_attn_mask, synthetic_windows
+
+    shape = mo.DitShape(depth=2, hidden=hidden, heads=heads, num_classes=10)
+    sd = mo.seeded_state_dict(shape, 78)
+    (x, o, c), y = synthetic_windows(3, T_, 10, seed=6)
+    t = torch.tensor([999, 400, 0])
+    mask = banded_attn_mask(T_, 128) if T_ == 200 else None
+    ref = mo.forward(sd, shape, x, t, o, c, y, attn_mask=mask)
+    scale = max(1.0, float(ref.abs().max()))
+    errs = {}
+    for prec in ("bf16x3", "fp16f8"):
+        with torch.no_grad():
+            got = native_model(shape, sd, prec)(x.to(DEV), t.to(DEV), o.to(DEV), c.to(DEV), y.to(DEV),
+                                                attn_mask=None if mask is None else mask.to(DEV)).cpu()
+        errs[prec] = maxdiff(got, ref)
+    print(f"MEASURED h8_forward_geometry[{hidden},{heads},{T_}]: max|d| vs the fp32 oracle at scale {scale:.2f}: "
+          + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    assert errs["bf16x3"] < 1.5e-5 * scale and errs["fp16f8"] < 1.8e-5 * scale, errs  # 3x measured (4.2-4.9e-6 / 4.6-5.6e-6 per unit of scale)
