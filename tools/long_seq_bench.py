@@ -6,7 +6,8 @@ from osu_diffusion_amd.models import DiT_models
 from osu_diffusion_amd.synthetic import banded_attn_mask, randomize_zero_init, synthetic_windows
 dev = "cuda:0"
 T_, n = int(sys.argv[1]) if len(sys.argv) > 1 else 2048, int(sys.argv[2]) if len(sys.argv) > 2 else 4
-m = randomize_zero_init(DiT_models["DiT-B"](num_classes=52670, context_size=144, precision="bf16").to(dev), seed=0).eval()
+prec = os.environ.get("PRECISION", "bf16")  # bf16 | bf16x3 | fp16f8 | fp32 | fp8
+m = randomize_zero_init(DiT_models["DiT-B"](num_classes=52670, context_size=144, precision=prec).to(dev), seed=0).eval()
 d = create_diffusion("1000", noise_schedule="squaredcos_cap_v2")
 (x, o, c), y = synthetic_windows(1, T_, 52670, seed=1)
 z = torch.randn(n, 2, T_, device=dev); z = torch.cat([z, z]); o = o.repeat(2 * n, 1).to(dev); c = c.repeat(2 * n, 1, 1).to(dev)
@@ -18,4 +19,4 @@ for name, mask in (("banded", banded_attn_mask(T_, 128).to(dev)), ("no mask (T^2
     torch.cuda.synchronize(); t0 = time.time()
     d.run_steps(m.forward_with_cfg, z.clone(), kw, 999, 1000 - K, seed=1)
     torch.cuda.synchronize(); dt = (time.time() - t0) / K
-    print(f"T={T_} rows={2 * n} {name:14s}: {dt * 1e3:7.3f} ms/step = {1 / dt:6.1f} steps/s")
+    print(f"[{prec}] T={T_} rows={2 * n} {name:14s}: {dt * 1e3:7.3f} ms/step = {1 / dt:6.1f} steps/s")
