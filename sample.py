@@ -11,9 +11,9 @@ sequence as the reference does; the matplotlib plot / animation themselves are o
 
 Reproducibility (`--noise cpu`): the noise is drawn from torch's CPU generator seeded by `--seed` in exactly the order the
 reference's CPU path consumes it -- `torch.randn(n, 2, T)` once (sample.py:97), then one `randn_like(x)` of shape (2n, 2, T)
-per sampling step (gaussian_diffusion.py:454 / :589) -- so `sample.py --noise cpu --precision fp32` is comparable with the
-reference run on the same (seed, beatmap, num-sampling-steps): final coordinates within 1e-3 (tests/test_gpu_scripts.py,
-fixture g12_cli_toy).  The default `--noise gpu` draws on the device (like the reference on CUDA, whose stream no CPU run
+per sampling step (gaussian_diffusion.py:454 / :589) -- so `sample.py --noise cpu` (in the default tier `--precision fp16f8`,
+in `bf16x3` and in `fp32`) is comparable with the reference run on the same (seed, beatmap, num-sampling-steps): final
+coordinates within 1e-3 (tests/test_gpu_scripts.py, fixture g12_cli_toy).  The default `--noise gpu` draws on the device (like the reference on CUDA, whose stream no CPU run
 reproduces either).
 
 Several GPUs (`torchrun --nproc-per-node G sample.py ...`): the variants are independent rows, so rank r samples variants
@@ -221,8 +221,11 @@ def parse_args(argv=None):
     p.add_argument("--model", type=str, choices=list(DiT_models.keys()), default="DiT-B")
     # additions of this build
     p.add_argument("--synthetic", type=int, default=0, metavar="T", help="use a synthetic T-token sequence")
-    p.add_argument("--precision", choices=["bf16", "fp32", "fp8", "bf16x3", "fp16f8"], default="bf16",
-                   help="bf16: fast tier; bf16x3: split-bf16 operands, meets the 1e-3 tolerance at MFMA speed; fp16f8: the same tier with the big GEMMs on fp16 + e4m3-residual operands (1.3x faster); fp32: exact-f32 MFMA parity tier; fp8: e4m3 GEMM operands")
+    p.add_argument("--precision", choices=["bf16", "fp32", "fp8", "bf16x3", "fp16f8"], default="fp16f8",
+                   help="fp16f8 (default): the fastest tier whose final coordinates stay within 1e-3 of the reference's for identical "
+                        "(seed, beatmap, steps) -- split-bf16 arithmetic with the big GEMMs on fp16 + e4m3-residual operands; bf16x3: "
+                        "split-bf16 operands everywhere (same tolerance, 0.8x the speed); bf16: fast tier (1.9x the speed, ~1e-2 from "
+                        "the reference after 1000 steps); fp32: exact-f32 MFMA parity tier; fp8: e4m3 GEMM operands")
     p.add_argument("--sampler", choices=["p", "ddim"], default="p", help="ancestral p_sample loop (reference default) or DDIM")
     p.add_argument("--ddim-eta", type=float, default=0.0)
     p.add_argument("--noise", choices=["gpu", "cpu"], default="gpu",
