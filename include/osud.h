@@ -251,7 +251,9 @@ int osud_table_rows_apply(float* table_grad, int rows, int D, const int64_t* all
  * trainers switch it on. */
 int osud_set_gemm_dynamic_tiles(int on);
 
-/* out[y][x] = epilogue(sum_k Y[y][k] * X[x][k]); see csrc/gemm.h for the epilogue codes. */
+/* out[y][x] = epilogue(sum_k Y[y][k] * X[x][k]); see csrc/gemm.h for the epilogue codes.  Operand / output forms per precision: 0 bf16,
+ * 1 f32, 2 e4m3 (experimental), 3 split-bf16 plane pairs [hi | lo] (ld = logical columns), 4 fp16 + e4m3 rows (osud_op_pack_h8; the
+ * bias epilogue writes split-bf16 planes -- the attention kernel's input --, the bias + GELU epilogue writes fp16 + e4m3 rows). */
 int osud_op_gemm(int precision, int epilogue, const void* Y, int ldy, const void* X, int ldx, int My, int Nx, int K,
                  void* out, int ldo, const float* bias, const float* gate, int ld_gate, int rows_per_sample,
                  int n_samples, osud_stream stream);

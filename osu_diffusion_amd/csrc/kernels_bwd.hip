@@ -613,7 +613,8 @@ int launch_ln_mod_bwd(int prec, const float* h, const float* stats, const void* 
   OSUD_CHECK_ARG(dh_skip != nullptr, "ln_mod_bwd: the gradient of the residual stream behind the LayerNorm is required");
   OSUD_CHECK_ARG(slot8 == nullptr || (amax_part != nullptr && br_next != nullptr && prec == OSUD_PREC_BF16 && M / OSUD_LNB_ROWS <= f8_amax_parts()),
                  "ln_mod_bwd: the e4m3 twin rides with the gate step of the bf16 tier");
-  OSUD_CHECK_ARG(br_next == nullptr || dbr != nullptr || dbr8 != nullptr, "ln_mod_bwd: the gate step needs somewhere to put the branch gradient");
+  OSUD_CHECK_ARG(br_next == nullptr || dbr != nullptr || (dbr8 != nullptr && slot8 != nullptr),
+                 "ln_mod_bwd: the gate step needs somewhere to put the branch gradient (bf16 rows, or the e4m3 twin with its scale slot)");
   const dim3 grid(M / OSUD_LNB_ROWS), block(256);
 #define ARGS(T) h, stats, (const T*)du, ada, ld_ada, off_shift, off_scale, dh_skip, dh_out, dada, Tp, (const T*)br_next, off_gate_next, (T*)dbr, db_next, (fp8_t*)dbr8, slot8, amax_part
   if (prec == OSUD_PREC_BF16) {
