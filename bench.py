@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--xl-precision", choices=["bf16", "fp8"], default=None, help="tier of the DiT-XL line (default: both, bf16 first)")
     ap.add_argument("--batch", type=int, default=256, help="training windows per GPU")
     ap.add_argument("--sample-steps", type=int, default=None, help="timed sampling steps in mode both (default 1000)")
-    ap.add_argument("--precision", choices=["bf16", "fp32", "fp8", "bf16x3", "fp16f8"], default="bf16")
+    ap.add_argument("--precision", choices=["bf16", "fp16", "fp32", "fp8", "bf16x3", "fp16f8"], default="bf16")
     ap.add_argument("--maps", type=int, default=64, help="beatmap windows per GPU (CFG doubles the batch)")
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--model", default="DiT-B")
@@ -504,7 +504,8 @@ def bench_sample(args, world, rank, dev):
         "unit": "steps/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(dt / K * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"bf16": "bf16", "fp32": "f32", "fp8": "fp8(e4m3 GEMM operands)+bf16", "bf16x3": "bf16x3(split-bf16 operands, 3 MFMAs per product)",
-                  "fp16f8": "fp16f8(split-bf16 tier with the four big GEMMs on fp16 + e4m3-residual operands)"}[args.precision], "data": "synthetic",
+                  "fp16f8": "fp16f8(split-bf16 tier with the four big GEMMs on fp16 + e4m3-residual operands)",
+                  "fp16": "fp16(IEEE half MFMA operands: the 11 significand bits of the reference's TF32 sampling matmuls)"}[args.precision], "data": "synthetic",
         "config": {"workload": f"sample.py path: {args.model} seq-len {T}, {n} synthetic beatmap windows x2 (CFG) per GPU, "
                                f"cfg-scale 4.0, 1000-step squaredcos schedule, steps t=999..{999 - K + 1}",
                    "rows_per_gpu": 2 * n, "seq_len": T, "sharding": "rows per rank, no collective"},
@@ -554,7 +555,8 @@ def parity_tier_and_drift(args, dev):
     # moved by 1e-6 (a few fp32 ulps of a coordinate).  The third run is the yardstick: it shows how far the sampler map itself
     # carries a rounding-sized difference on these (random, untrained) weights, i.e. what ANY two implementations may differ by.
     marks = [k for k in (1, 10, 50, 100, 250, 500, 1000) if k < S] + [S]
-    runs = (("bf16", "bf16", 0.0), ("bf16x3", "bf16x3", 0.0), ("fp16f8", "fp16f8", 0.0), ("fp32", "fp32", 0.0), ("fp32_moved", "fp32", 1e-6))
+    runs = (("bf16", "bf16", 0.0), ("fp16", "fp16", 0.0), ("bf16x3", "bf16x3", 0.0), ("fp16f8", "fp16f8", 0.0), ("fp32", "fp32", 0.0),
+            ("fp32_moved", "fp32", 1e-6))
     states, sec = {}, {}
     pert = torch.randn(n, 2, T, device=dev, generator=g)
     for name, prec, eps in runs:
@@ -631,6 +633,12 @@ def parity_tier_and_drift(args, dev):
             "mfma_frac_algorithmic": round(fl / PEAK_BF16_TFLOPS, 4) if fl else None,
             "mfma_frac_issued": round(PASSES[name] * fl / PEAK_BF16_TFLOPS, 4) if fl else None}
 
+    # the fast tier on half operands (11 significand bits = the reference's TF32 sampling matmuls) on the same loop
+    f16 = dev_stats(states["fp16"][S], states["fp32"][S])
+    out["fp16_tier"] = {"value": round(S / sec["fp16"], 3), "unit": "steps/s", "ms_per_step": round(sec["fp16"] / S * 1e3, 4), "steps": S,
+                        "dtype": "fp16 (IEEE half MFMA operands, fp32 accumulate / residual / statistics)",
+                        "drift_vs_fp32_tier": dict(f16, after_steps={str(k): dev_stats(states["fp16"][k], states["fp32"][k]) for k in marks}),
+                        "meets_1e-3": bool(f16["max"] <= 1e-3)}
     recs = {name: tier_record(name) for name in ("bf16x3", "fp16f8")}
     meeting = [name for name in recs if recs[name]["meets_1e-3"]] or ["bf16x3"]
     best = max(meeting, key=lambda name: recs[name]["value"])
@@ -695,6 +703,7 @@ def main():
             res["parity_tier"], res["bf16_drift"] = parity_tier_and_drift(args, dev)
             tt = res["parity_tier"].pop("tolerance_tier")
             res["sampling"]["tolerance_tier"] = tt
+            res["sampling"]["fp16_tier"] = res["parity_tier"].pop("fp16_tier")
             # which number answers "1000-step CFG sampling steps/s, matching the reference within 1e-3": the fastest tier whose
             # 1000-step drift from the exact-f32 tier stays below the bound on this very workload
             bd = res["bf16_drift"]

@@ -60,6 +60,10 @@ extern "C" {
                             hi*hi on v_mfma_f32_32x32x16_f16 + both cross terms in ONE block-scaled v_mfma_scale_f32_32x32x64_f8f6f4
                             -- 15 significand bits per operand at 2/3 of the split-bf16 form's matrix-pipe passes */
 
+#define OSUD_PREC_F16 5 /* fast tier of the sampling path, inference only: the bf16 tier's kernels on IEEE half operands
+                          (v_mfma_f32_32x32x16_f16): 11 significand bits -- the precision of the TF32 matmuls the reference's own
+                          sampling path uses (sample.py:25-26) -- at the bf16 tier's speed */
+
 typedef struct osud_dit osud_dit;
 typedef struct osud_sched osud_sched;
 typedef void* osud_stream; /* hipStream_t */

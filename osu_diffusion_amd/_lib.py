@@ -20,7 +20,10 @@ PREC_BF16X3 = 3  # inference only: split-bf16 operands (hi + lo planes), three b
 #                  reference's 1e-3 tolerance at MFMA speed (the reference's own sampling matmuls are TF32: sample.py:25-26)
 PREC_F16F8 = 4  # inference only: the split-bf16 tier with the four big GEMMs of a block on fp16 + e4m3-residual operands (15
 #                 significand bits per operand; fp16 hi product + ONE block-scaled e4m3 MFMA for both cross terms: 2/3 of the passes)
-PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32, "fp8": PREC_FP8, "bf16x3": PREC_BF16X3, "fp16f8": PREC_F16F8}
+PREC_F16 = 5  # inference only: the bf16 tier's kernels on IEEE half operands -- 11 significand bits, the precision of the TF32 matmuls of
+#               the reference's own sampling path (sample.py:25-26) -- at the bf16 tier's speed
+PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32, "fp8": PREC_FP8, "bf16x3": PREC_BF16X3, "fp16f8": PREC_F16F8,
+              "fp16": PREC_F16}
 
 # gemm epilogue codes (csrc/gemm.h)
 EPI_BIAS_F32, EPI_BIAS_TE, EPI_BIAS_SILU_TE, EPI_ROWBIAS_TE, EPI_BIAS_GELU_TE, EPI_GATE_RES = range(6)

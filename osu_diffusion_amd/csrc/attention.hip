@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void mask_tiles_kernel(const uint8_t* __restri
 // sits ld_qk (resp. D) elements behind the hi plane inside a row of twice that length.  Both products take the three-term form
 //   S = K_hi.q_hi + K_lo.q_hi + K_hi.q_lo        O += V_hi.p_hi + V_lo.p_hi + V_hi.p_lo      (p = exp2(..) in fp32, split in registers)
 // with K / V tiles of both planes in LDS; softmax statistics in fp32 as before.
-template <int HD, int HDP, int KB, bool X3 = false>
+template <int HD, int HDP, int KB, bool X3 = false, bool F16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HD == 64 && !X3) ? 4 : 2))) void attn_bf16_kernel(const bf16_t* __restrict__ qk,
                                                         const uint8_t* __restrict__ mask, bf16_t* __restrict__ out,
                                                         float* __restrict__ lse, int T, int Tp, int Mp, int D,
@@ -157,10 +157,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HD == 64 &
       for (int ks = 0; ks < KS; ++ks) {
         const u32x4 kh = rowfrag<HDP>(Ks, kt * 32 + frow, 2 * ks + fhalf);
         if constexpr (X3) {  // small terms first
-          s[kt] = mfma_bf16(rowfrag<HDP>(Ks + TILE, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s[kt]);
-          s[kt] = mfma_bf16(kh, ql[ks], s[kt]);
+          s[kt] = mfma_h<F16>(rowfrag<HDP>(Ks + TILE, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s[kt]);
+          s[kt] = mfma_h<F16>(kh, ql[ks], s[kt]);
         }
-        s[kt] = mfma_bf16(kh, qf[ks], s[kt]);
+        s[kt] = mfma_h<F16>(kh, qf[ks], s[kt]);
       }
     }
     // ---- scale, mask, block max
@@ -221,19 +221,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HD == 64 &
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
-        const u32x4 pf = pack8(s[kt], 8 * ss);
+        const u32x4 pf = pack8_h<F16>(s[kt], 8 * ss);
         if constexpr (X3) {
           const u32x4 pl = pack8_lo(s[kt], 8 * ss, pf);
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
             const u32x4 vh = trfrag<HDP>(Vs, kt * 32 + 16 * ss, dt * 32, lane);
-            o[dt] = mfma_bf16(trfrag<HDP>(Vs + TILE, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
-            o[dt] = mfma_bf16(vh, pl, o[dt]);
-            o[dt] = mfma_bf16(vh, pf, o[dt]);
+            o[dt] = mfma_h<F16>(trfrag<HDP>(Vs + TILE, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
+            o[dt] = mfma_h<F16>(vh, pl, o[dt]);
+            o[dt] = mfma_h<F16>(vh, pf, o[dt]);
           }
         } else {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o[dt] = mfma_bf16(trfrag<HDP>(Vs, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
+        for (int dt = 0; dt < DT; ++dt) o[dt] = mfma_h<F16>(trfrag<HDP>(Vs, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
         }
       }
     }  // blocks of the round
@@ -259,6 +259,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HD == 64 &
             else store4_x3(orow + d, (size_t)D, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
           }
           else if (fp8_scale > 0.f) store4(orow8 + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+          else if (F16) store4(reinterpret_cast<f16_t*>(orow) + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
           else store4(orow + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
         }
       }
@@ -274,6 +275,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HD == 64 &
 // for with a count that leaves the DMA in flight -- a compiler-visible load there would wait for the pieces it cannot see.
 // Mask rows must be 4-byte aligned (T % 4 == 0; other T take the kernel above).  Output rows leave as full lines through the
 // (by then idle) stage memory.
+template <bool F16 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attn_bf16_dma_kernel(
     const bf16_t* __restrict__ qk, const uint8_t* __restrict__ mask, bf16_t* __restrict__ out, float* __restrict__ lse, int T, int Tp,
     int D, int ld_qk, float c1 /* scale*log2(e) */, const uint8_t* __restrict__ kb_class) {
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) s[kt] = mfma_bf16(rowfrag<HDP>(Ks, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s[kt]);
+      for (int ks = 0; ks < KS; ++ks) s[kt] = mfma_h<F16>(rowfrag<HDP>(Ks, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s[kt]);
     }
     if (chk_cur) {
       if (nxt < nkb) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // the mask words; the 4 DMA pieces behind them stay in flight
@@ -419,9 +421,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int ss = 0; ss < 2; ++ss) {
-        const u32x4 pf = pack8(s[kt], 8 * ss);
+        const u32x4 pf = pack8_h<F16>(s[kt], 8 * ss);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) o[dt] = mfma_bf16(trfrag<HDP>(Vs, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
+        for (int dt = 0; dt < DT; ++dt) o[dt] = mfma_h<F16>(trfrag<HDP>(Vs, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
       }
     cur = nxt;
     chk_cur = chk_nxt;
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
     for (int i = 0; i < DT; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[i][r] *= inv;
-    store_rows_patch(smem + wave * 2048, out + ((size_t)n * Tp + blockIdx.x * 128 + wave * 32) * D + h * HD, (size_t)D, o, lane);
+    store_rows_patch<false, F16>(smem + wave * 2048, out + ((size_t)n * Tp + blockIdx.x * 128 + wave * 32) * D + h * HD, (size_t)D, o, lane);
   }
 }
 
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
 // other half of a 128 KiB double buffer while this pair is computed; Q fragments are fetched into registers one pair ahead; the
 // output rows leave through per-wave LDS patches as full 128-byte lines.  All 128 keys are scored before the softmax (four
 // 32 x 32 score tiles in registers), so there is no running maximum to rescale by.
-template <int T>
+template <int T, bool F16 = false>
 __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                               float* __restrict__ lse, int D, int H, int items, float c1,
                                                               unsigned* __restrict__ queue) {
@@ -528,7 +530,7 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const bf16_t* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) s[kt] = mfma_bf16(rowfrag<HDP>(Ks, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s[kt]);
+        for (int ks = 0; ks < KS; ++ks) s[kt] = mfma_h<F16>(rowfrag<HDP>(Ks, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s[kt]);
       }
       float mx = -INFINITY;
 #pragma unroll
@@ -560,9 +562,9 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const bf16_t* __re
       for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
         for (int ss = 0; ss < 2; ++ss) {
-          const u32x4 pf = pack8(s[kt], 8 * ss);
+          const u32x4 pf = pack8_h<F16>(s[kt], 8 * ss);
 #pragma unroll
-          for (int dt = 0; dt < DT; ++dt) o[dt] = mfma_bf16(trfrag<HDP>(Vs, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
+          for (int dt = 0; dt < DT; ++dt) o[dt] = mfma_h<F16>(trfrag<HDP>(Vs, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
         }
       const float inv = 1.0f / l_row;
 #pragma unroll
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const bf16_t* __re
       const int n = item / H, h = item - n * H;
       if (lse != nullptr && fhalf == 0)  // log2-domain logsumexp of the scaled scores, for the backward pass
         lse[((size_t)n * H + h) * T + own + frow] = m_row + __builtin_amdgcn_logf(l_row);
-      store_rows_patch(patch, out + ((size_t)n * T + own) * D + h * HD, (size_t)D, o, lane);
+      store_rows_patch<false, F16>(patch, out + ((size_t)n * T + own) * D + h * HD, (size_t)D, o, lane);
     }
   }
   if (ticket_lane) {  // the last workgroup out re-arms the counters
@@ -866,7 +868,7 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
     dim3 grid((Tp + 127) / 128, heads, N);
     const char* dma_env = getenv("OSUD_ATTN_DMA");  // "0": the register-staged kernel (A/B runs, tests)
     if (head_dim == 64 && fp8_scale <= 0.f && (mask == nullptr || T % 4 == 0) && T >= 4 && !(dma_env && dma_env[0] == '0')) {
-      hipLaunchKernelGGL(attn_bf16_dma_kernel, grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp, D, ld_qk,
+      hipLaunchKernelGGL(attn_bf16_dma_kernel<false>, grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp, D, ld_qk,
                          scale * 1.4426950408889634f, mask ? kb_class : nullptr);
       OSUD_HIP(hipGetLastError());
       return OSUD_OK;
@@ -881,6 +883,38 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
     else
       hipLaunchKernelGGL((attn_bf16_kernel<72, 96, 1>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
                          Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr, fp8_scale);
+  } else if (prec == OSUD_PREC_F16) {
+    // fp16 tier (inference): the bf16 tier's forward kernels on half operands -- the streamed kernel at the window shape, the LDS-DMA
+    // kernel for other lengths and masks at head_dim 64, the general kernel for the rest
+    OSUD_CHECK_ARG(lse == nullptr && fp8_scale <= 0.f, "attention: the fp16 tier is inference only");
+    if (head_dim != 64 && head_dim != 72) {
+      set_error("attention: the fp16 tier is built for head_dim 64 and 72 (got %d); use the f32 tier", head_dim);
+      return OSUD_ERR_UNSUPPORTED;
+    }
+    if (head_dim == 64 && T == 128 && Tp == 128 && mask == nullptr && ld_qk == 3 * D) {
+      constexpr size_t slds = (size_t)8 * 128 * AttnTile<64>::RS + 8 * 2048 + 16;
+      {
+        auto* kern = attn_fwd_stream_kernel<128, true>;
+        OSUD_BIG_LDS_ONCE(kern);
+      }
+      const int cus = device_cus();
+      const int items = N * heads, npairs = (items + 1) / 2;
+      hipLaunchKernelGGL((attn_fwd_stream_kernel<128, true>), dim3(npairs < cus ? npairs : cus), dim3(512), slds, st, (const bf16_t*)qk,
+                         (bf16_t*)out, lse, D, heads, items, scale * 1.4426950408889634f,
+                         (gemm_dynamic_tiles_on() && npairs > 2 * cus) ? gemm_ticket_slot() : nullptr);
+      OSUD_HIP(hipGetLastError());
+      return OSUD_OK;
+    }
+    dim3 grid((Tp + 127) / 128, heads, N);
+    if (head_dim == 64 && (mask == nullptr || T % 4 == 0) && T >= 4)
+      hipLaunchKernelGGL(attn_bf16_dma_kernel<true>, grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp, D, ld_qk,
+                         scale * 1.4426950408889634f, mask ? kb_class : nullptr);
+    else if (head_dim == 64)
+      hipLaunchKernelGGL((attn_bf16_kernel<64, 64, 1, false, true>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
+                         Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr, 0.f);
+    else
+      hipLaunchKernelGGL((attn_bf16_kernel<72, 96, 1, false, true>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
+                         Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr, 0.f);
   } else if (prec == OSUD_PREC_BF16X3 || prec == OSUD_PREC_F16F8) {
     // (F16F8: the split-bf16 kernel on split-bf16 q | k | v, its output written as fp16 + e4m3 rows for out_proj: flag = scale < 0)
     OSUD_CHECK_ARG(lse == nullptr && fp8_scale <= 0.f, "attention: the split-bf16 tier is inference only");

@@ -62,6 +62,22 @@ __device__ __forceinline__ u32x4 pack8(const f32x16& v, int base) {
   r[3] = pack_bf2(v[base + 6], v[base + 7]);
   return r;
 }
+// F16 (the fp16 tier, forward kernels only): the same 16-bit containers hold IEEE half values -- the loads, LDS tiles and transposing
+// reads do not care; the MFMA and the f32 -> 16-bit packs do
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_attn;
+template <bool F16> __device__ __forceinline__ uint32_t pack2_h(float a, float b) { return F16 ? pack_f16x2(a, b) : pack_bf2(a, b); }
+template <bool F16> __device__ __forceinline__ f32x16 mfma_h(const u32x4& a, const u32x4& b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_attn, a), __builtin_bit_cast(f16x8_attn, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <bool F16> __device__ __forceinline__ u32x4 pack8_h(const f32x16& v, int base) {
+  u32x4 r;
+  r[0] = pack2_h<F16>(v[base + 0], v[base + 1]);
+  r[1] = pack2_h<F16>(v[base + 2], v[base + 3]);
+  r[2] = pack2_h<F16>(v[base + 4], v[base + 5]);
+  r[3] = pack2_h<F16>(v[base + 6], v[base + 7]);
+  return r;
+}
 
 // split-bf16 tier: the lo halves of the same 8 values, given their packed hi halves: bf16(v - float(hi))
 __device__ __forceinline__ u32x4 pack8_lo(const f32x16& v, int base, const u32x4& hi) {
@@ -79,9 +95,10 @@ __device__ __forceinline__ u32x4 pack8_lo(const f32x16& v, int base, const u32x4
 // COLSUM: the column sums of the 32 rows ride along -- the 16 rows that sit in the patch (the AttnTile<64> layout, so trfrag reads
 // it) are contracted with a ones operand on the matrix pipe: D[d][*] += sum_rows bf16(row)[d].  Every lane ends with 16 of the
 // 64 column sums per accumulator (row index of the MFMA result = column d); lanes 0 and 32 together hold all of them.
-template <bool COLSUM = false>
+template <bool COLSUM = false, bool F16 = false>
 __device__ __forceinline__ void store_rows_patch(char* patch, bf16_t* rows, size_t ld, const f32x16 (&acc)[2], int lane,
                                                  f32x16* cacc = nullptr) {
+  static_assert(!(COLSUM && F16), "the column sums ride with the bf16 backward pass only");
   if constexpr (COLSUM) asm volatile("" : "+v"(lane));  // (opaque: per-lane offsets recomputed here, not held in registers by the caller's loop)
   const int frow = lane & 31, fhalf = lane >> 5;
 #pragma unroll
@@ -93,8 +110,8 @@ __device__ __forceinline__ void store_rows_patch(char* patch, bf16_t* rows, size
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           u32x2 v;
-          v[0] = pack_bf2(acc[dt][4 * g], acc[dt][4 * g + 1]);
-          v[1] = pack_bf2(acc[dt][4 * g + 2], acc[dt][4 * g + 3]);
+          v[0] = pack2_h<F16>(acc[dt][4 * g], acc[dt][4 * g + 1]);
+          v[1] = pack2_h<F16>(acc[dt][4 * g + 2], acc[dt][4 * g + 3]);
           *reinterpret_cast<u32x2*>(patch + AttnTile<64>::off(r, dt * 4 + g) + fhalf * 8) = v;
         }
     }

@@ -118,6 +118,48 @@ __device__ __forceinline__ void load8(const bf16_t* p, float (&v)[8]) {
   v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
   v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
 }
+// ---- fp16 tier (OSUD_PREC_F16, inference only): the bf16 tier's kernels on IEEE half operands -- 11 significand bits, which is what
+// the TF32 matmuls of the reference's own sampling path carry (sample.py:25-26), at the bf16 tier's MFMA rate (v_mfma_f32_32x32x16_f16).
+// The activations of a forward pass sit far inside half's range (|v| < 65504); the tier is not built for gradients.
+struct f16_t { uint16_t v; };
+typedef _Float16 f16x2_rn __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {  // round-to-nearest-even
+  f32x2_hw v;
+  v[0] = lo;
+  v[1] = hi;
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_rn));
+}
+__device__ __forceinline__ float h2f(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ void unpack_f16x2(uint32_t u, float& lo, float& hi) {
+  const f16x2_rn h = __builtin_bit_cast(f16x2_rn, u);
+  lo = (float)h[0];
+  hi = (float)h[1];
+}
+__device__ __forceinline__ void store_elem(f16_t* p, float v) { p->v = (uint16_t)(pack_f16x2(v, 0.f) & 0xffffu); }
+__device__ __forceinline__ float load_elem(const f16_t* p) { return h2f(p->v); }
+__device__ __forceinline__ void store2(f16_t* p, float a, float b) { *reinterpret_cast<uint32_t*>(p) = pack_f16x2(a, b); }
+__device__ __forceinline__ void store4(f16_t* p, float a, float b, float c, float d) {
+  uint2 v;
+  v.x = pack_f16x2(a, b);
+  v.y = pack_f16x2(c, d);
+  *reinterpret_cast<uint2*>(p) = v;
+}
+__device__ __forceinline__ void store8(f16_t* p, const float (&v)[8]) {
+  uint4 u;
+  u.x = pack_f16x2(v[0], v[1]);
+  u.y = pack_f16x2(v[2], v[3]);
+  u.z = pack_f16x2(v[4], v[5]);
+  u.w = pack_f16x2(v[6], v[7]);
+  *reinterpret_cast<uint4*>(p) = u;
+}
+__device__ __forceinline__ void load2(const f16_t* p, float& a, float& b) { unpack_f16x2(*reinterpret_cast<const uint32_t*>(p), a, b); }
+__device__ __forceinline__ void load8(const f16_t* p, float (&v)[8]) {
+  const uint4 u = *reinterpret_cast<const uint4*>(p);
+  unpack_f16x2(u.x, v[0], v[1]);
+  unpack_f16x2(u.y, v[2], v[3]);
+  unpack_f16x2(u.z, v[4], v[5]);
+  unpack_f16x2(u.w, v[6], v[7]);
+}
 // fp32 -> OCP e4m3 (hardware v_cvt_pk_fp8_f32, round-to-nearest-even), saturating at the format's +-448
 __device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
   a = fminf(fmaxf(a, -448.f), 448.f); b = fminf(fmaxf(b, -448.f), 448.f);
@@ -298,6 +340,19 @@ template <int W> __device__ __forceinline__ void loadw(const bf16_t* p, float* v
     load2(p, v[0], v[1]);
   }
 }
+template <int W> __device__ __forceinline__ void loadw(const f16_t* p, float* v) {
+  if constexpr (W == 4) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    unpack_f16x2(u.x, v[0], v[1]);
+    unpack_f16x2(u.y, v[2], v[3]);
+  } else {
+    load2(p, v[0], v[1]);
+  }
+}
+template <int W> __device__ __forceinline__ void storew(f16_t* p, const float* v) {
+  if constexpr (W == 4) store4(p, v[0], v[1], v[2], v[3]);
+  else store2(p, v[0], v[1]);
+}
 template <int W> __device__ __forceinline__ void loadw(const fp8_t*, float* v) {  // fp8 tensors are never read back by these kernels
 #pragma unroll
   for (int e = 0; e < W; ++e) v[e] = 0.f;
@@ -381,7 +436,7 @@ template <bool FAST> __device__ __forceinline__ void gelu_tanh_both_t(float z, f
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // bytes per LOGICAL element (the split-bf16 tier stores two bf16 planes)
-static inline size_t elem_size(int prec) { return prec == OSUD_PREC_BF16 ? 2 : (prec == 2 ? 1 : 4); }
+static inline size_t elem_size(int prec) { return (prec == OSUD_PREC_BF16 || prec == OSUD_PREC_F16) ? 2 : (prec == 2 ? 1 : 4); }
 
 // wave-level reductions (wave = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {

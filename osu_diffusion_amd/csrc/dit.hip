@@ -37,6 +37,7 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
   const size_t es = m->esz, D = m->D;
   auto& W = m->ws_owned;
   OSUD_CHECK_ARG(!(training && m->x3), "reserve: the split-bf16 tier is inference only (train in bf16 or fp32)");
+  OSUD_CHECK_ARG(!(training && m->prec == OSUD_PREC_F16), "reserve: the fp16 tier is inference only (train in bf16 or fp32)");
   OSUD_TRY(dev_alloc(W, &m->e0, (size_t)Mp * m->Ke * es));
   if (m->split_first || m->x3) OSUD_TRY(dev_alloc(W, &m->h0c, (size_t)Mp * D * 4));
   OSUD_TRY(dev_alloc(W, &m->temb, (size_t)Np * 256 * es));
@@ -383,7 +384,7 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   OSUD_CHECK_ARG(cfg->depth > 0 && cfg->context > 0 && cfg->in_channels == 2 && cfg->table_rows > 0,
                  "dit_create: bad depth/context/in_channels/table_rows");
   OSUD_CHECK_ARG(cfg->precision == OSUD_PREC_BF16 || cfg->precision == OSUD_PREC_F32 || cfg->precision == OSUD_PREC_FP8 ||
-                     cfg->precision == OSUD_PREC_BF16X3 || cfg->precision == OSUD_PREC_F16F8,
+                     cfg->precision == OSUD_PREC_BF16X3 || cfg->precision == OSUD_PREC_F16F8 || cfg->precision == OSUD_PREC_F16,
                  "dit_create: unknown precision %d", cfg->precision);
   const int hd = cfg->hidden / cfg->heads;
   if (hd != 64 && hd != 72) {
@@ -404,7 +405,7 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
     const char* e = getenv("OSUD_SPLIT_FIRST");
     // (embed_kernel stages 16 rows of [hi | lo | hi] in LDS: 16 * Kp * 6 bytes must fit 64 KiB, i.e. context sizes up to 256;
     //  wider contexts keep the plain bf16 first linear)
-    m->split_first = m->prec == OSUD_PREC_BF16 && !(e && e[0] == '0') && (size_t)16 * m->Kp * 6 <= 64 * 1024;
+    m->split_first = (m->prec == OSUD_PREC_BF16 || m->prec == OSUD_PREC_F16) && !(e && e[0] == '0') && (size_t)16 * m->Kp * 6 <= 64 * 1024;
   }
   m->Ke = m->split_first ? 3 * m->Kp : m->Kp;
   m->ada_cols = 6 * m->D * m->L + 2 * m->D;
@@ -518,9 +519,9 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
   } else if (k == "xoc_embedder.mlp.0.weight") {
     SHAPE(D, 384 + m->E);
     rc = m->x3 ? launch_pack_rows_x3(src, 384 + m->E, 384 + m->E, m->w_e, m->Kp, (int)D, st)
-         : m->split_first ? launch_pack_rows_split(src, 384 + m->E, 384 + m->E, m->w_e, m->Kp, (int)D, st)
+         : m->split_first ? launch_pack_rows_split(src, 384 + m->E, 384 + m->E, m->w_e, m->Kp, (int)D, st, m->prec)
                           : launch_pack_rows(prec, src, 384 + m->E, 384 + m->E, m->w_e, m->Kp, m->Kp, (int)D, st);
-    if (rc == OSUD_OK && m->split_first) rc = launch_pack_rows_split(src, 384 + m->E, 256, m->w_ex, 256, (int)D, st);  // coordinate columns
+    if (rc == OSUD_OK && m->split_first) rc = launch_pack_rows_split(src, 384 + m->E, 256, m->w_ex, 256, (int)D, st, m->prec);  // coordinate columns
     if (rc == OSUD_OK && m->x3) rc = launch_pack_rows_x3(src, 384 + m->E, 256, m->w_ex, 256, (int)D, st);
   } else if (k == "xoc_embedder.mlp.0.bias") { SHAPE(D); rc = upload_f32(m, &m->b_e, src, D, st);
   } else if (k == "t_embedder.mlp.0.weight") { SHAPE(D, 256); rc = convert_w(m, src, m->w_t0, D, 256, st);
@@ -761,7 +762,8 @@ extern "C" int osud_op_gemm(int precision, int epilogue, const void* Y, int ldy,
                             int rows_per_sample, int n_samples, osud_stream stream) {
   OSUD_CHECK_ARG(precision == OSUD_PREC_BF16 || precision == OSUD_PREC_F32 || precision == 2 /* experimental fp8 e4m3 operands */ ||
                      precision == OSUD_PREC_BF16X3 /* plane pairs [hi | lo]: ld counts logical columns */ ||
-                     precision == OSUD_PREC_F16F8 /* K-blocked fp16 + e4m3 groups: ld counts logical columns */,
+                     precision == OSUD_PREC_F16F8 /* K-blocked fp16 + e4m3 groups: ld counts logical columns */ ||
+                     precision == OSUD_PREC_F16 /* IEEE half operands */,
                  "op_gemm: unknown precision");
   GemmP p{};
   p.Y = Y; p.X = X; p.ldy = ldy; p.ldx = ldx; p.My = My; p.Nx = Nx; p.K = K; p.out = out; p.ldo = ldo; p.bias = bias;

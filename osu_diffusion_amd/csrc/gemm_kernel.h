@@ -52,6 +52,10 @@ template <> __device__ __forceinline__ void mma<x3_t>(f32x16& acc, const u32x4& 
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), acc, 0,
                                                 0, 0);
 }
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_mma;
+template <> __device__ __forceinline__ void mma<f16_t>(f32x16& acc, const u32x4& a, const u32x4& b) {  // fp16 tier: the same loop, half operands
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_mma, a), __builtin_bit_cast(f16x8_mma, b), acc, 0, 0, 0);
+}
 template <> __device__ __forceinline__ void mma<float>(f32x16& acc, const u32x4& a, const u32x4& b) {
   const f32x4 af = __builtin_bit_cast(f32x4, a), bf = __builtin_bit_cast(f32x4, b);
 #pragma unroll

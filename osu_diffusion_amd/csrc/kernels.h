@@ -41,7 +41,8 @@ int launch_pack_rows_x3(const float* src, int ld_src, int cols_src, void* dst, i
 // fp16 + e4m3 operand form (common.h: h8_t; cols_dst % 32 == 0, zero padded): weight = the weight flavour (hi8 | lo8 planes)
 int launch_pack_rows_h8(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, bool weight, hipStream_t st);
 // first linear of the bf16 tier: dst [rows][3 * cols_dst] = [w_hi | w_hi | w_lo]
-int launch_pack_rows_split(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, hipStream_t st);
+int launch_pack_rows_split(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, hipStream_t st,
+                           int prec = OSUD_PREC_BF16 /* or OSUD_PREC_F16 */);
 // qkv: packed in_proj output [Mp][ld_qkv], Q | K | V in columns [0,D) [D,2D) [2D,3D)
 // kb_class (optional, from launch_mask_tiles): class of every 64-query x 64-key tile of the mask (0 fully masked, 1 mixed,
 // 2 fully open): masked tiles are skipped, open tiles read no mask bytes

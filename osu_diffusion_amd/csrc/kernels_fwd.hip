@@ -364,17 +364,17 @@ __global__ void pack_rows_kernel(const float* __restrict__ src, int ld_src, int 
 
 // bf16 tier, first linear: dst row = [w_hi | w_hi | w_lo], each part cols_dst wide (zero padded) -- the weight side of the
 // split product of embed_kernel<bf16, SPLIT>
-__global__ void pack_rows_split_kernel(const float* __restrict__ src, int ld_src, int cols_src, bf16_t* __restrict__ dst,
+template <typename TE>  // bf16_t, or f16_t (the fp16 tier's first linear: the same three-term form on half operands)
+__global__ void pack_rows_split_kernel(const float* __restrict__ src, int ld_src, int cols_src, TE* __restrict__ dst,
                                        int cols_dst, int rows) {
   const size_t total = (size_t)rows * cols_dst;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(i / cols_dst), cc = (int)(i % cols_dst);
     const float v = cc < cols_src ? src[(size_t)r * ld_src + cc] : 0.f;
-    const bf16_t hi = f2bf(v);
-    bf16_t* d = dst + (size_t)r * 3 * cols_dst + cc;
-    d[0] = hi;
-    d[cols_dst] = hi;
-    d[2 * cols_dst] = f2bf(v - bf2f(hi));
+    TE* d = dst + (size_t)r * 3 * cols_dst + cc;
+    store_elem(d, v);
+    d[cols_dst] = d[0];
+    store_elem(d + 2 * cols_dst, v - load_elem(d));
   }
 }
 
@@ -589,7 +589,7 @@ int launch_embed(int prec, const float* x, const float* o, const float* c, const
                  void* out, int N, int T, int Tp, int Mp, int E, int Kp, int x_dup_half, hipStream_t st, bool split, int mode) {
   const bool x3 = prec == OSUD_PREC_BF16X3;
   if (mode == 1) {  // coordinate features only: a compact row of 256 (x 3 in the split form, x 2 planes in the split-bf16 tier) columns
-    OSUD_CHECK_ARG(x3 || (split && prec == OSUD_PREC_BF16), "embed: the coordinate-only row exists in the split forms");
+    OSUD_CHECK_ARG(x3 || (split && (prec == OSUD_PREC_BF16 || prec == OSUD_PREC_F16)), "embed: the coordinate-only row exists in the split forms");
     E = 0;
     Kp = 256;
   }
@@ -598,9 +598,11 @@ int launch_embed(int prec, const float* x, const float* o, const float* c, const
     OSUD_CHECK_ARG((size_t)16 * Kp * 4 <= 64 * 1024, "embed: a plane-pair row of %d columns does not fit the 64 KiB LDS tile (context too wide)", Kp);
     return embed_t<bf16_t, 2>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode);
   }
-  OSUD_CHECK_ARG(!split || prec == OSUD_PREC_BF16, "embed: the split row form is bf16 only");
+  OSUD_CHECK_ARG(!split || prec == OSUD_PREC_BF16 || prec == OSUD_PREC_F16, "embed: the split row form exists in the 16-bit tiers only");
   OSUD_CHECK_ARG(!split || (size_t)16 * Kp * 6 <= 64 * 1024, "embed: a split row of %d columns does not fit the 64 KiB LDS tile (context too wide)", Kp);
+  if (split && prec == OSUD_PREC_F16) return embed_t<f16_t, 1>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode);
   if (split) return embed_t<bf16_t, 1>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode);
+  if (prec == OSUD_PREC_F16) return embed_t<f16_t, 0>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode);
   return prec == OSUD_PREC_BF16 ? embed_t<bf16_t, 0>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode)
                                 : embed_t<float, 0>(x, o, c, freqs64, pf0, pf1, out, N, T, Tp, Mp, E, Kp, x_dup_half, st, mode);
 }
@@ -625,11 +627,12 @@ int launch_pack_rows_h8(const float* src, int ld_src, int cols_src, void* dst, i
   return OSUD_OK;
 }
 
-int launch_pack_rows_split(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, hipStream_t st) {
+int launch_pack_rows_split(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, hipStream_t st, int prec) {
   const size_t total = (size_t)rows * cols_dst;
   if (total == 0) return OSUD_OK;
   const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
-  hipLaunchKernelGGL(pack_rows_split_kernel, dim3(grid), dim3(256), 0, st, src, ld_src, cols_src, (bf16_t*)dst, cols_dst, rows);
+  if (prec == OSUD_PREC_F16) hipLaunchKernelGGL(pack_rows_split_kernel<f16_t>, dim3(grid), dim3(256), 0, st, src, ld_src, cols_src, (f16_t*)dst, cols_dst, rows);
+  else hipLaunchKernelGGL(pack_rows_split_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, src, ld_src, cols_src, (bf16_t*)dst, cols_dst, rows);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }
@@ -637,6 +640,8 @@ int launch_pack_rows_split(const float* src, int ld_src, int cols_src, void* dst
 int launch_temb(int prec, const int64_t* t, const float* freqs128, void* out, int N, int Np, hipStream_t st) {
   if (prec == OSUD_PREC_BF16)
     hipLaunchKernelGGL((temb_kernel<bf16_t>), dim3(Np), dim3(128), 0, st, t, freqs128, (bf16_t*)out, N);
+  else if (prec == OSUD_PREC_F16)
+    hipLaunchKernelGGL((temb_kernel<f16_t>), dim3(Np), dim3(128), 0, st, t, freqs128, (f16_t*)out, N);
   else if (prec == OSUD_PREC_BF16X3)
     hipLaunchKernelGGL((temb_kernel<x3_t>), dim3(Np), dim3(128), 0, st, t, freqs128, (x3_t*)out, N);
   else
@@ -650,6 +655,9 @@ int launch_cond(int prec, const float* tvec, const float* table, const int64_t* 
   if (prec == OSUD_PREC_BF16)
     hipLaunchKernelGGL((cond_kernel<bf16_t>), dim3(Np), dim3(256), 0, st, tvec, table, y, table_rows, b_out,
                        (bf16_t*)sb_out, N, D, t_index);
+  else if (prec == OSUD_PREC_F16)
+    hipLaunchKernelGGL((cond_kernel<f16_t>), dim3(Np), dim3(256), 0, st, tvec, table, y, table_rows, b_out,
+                       (f16_t*)sb_out, N, D, t_index);
   else if (prec == OSUD_PREC_BF16X3)
     hipLaunchKernelGGL((cond_kernel<x3_t>), dim3(Np), dim3(256), 0, st, tvec, table, y, table_rows, b_out,
                        (x3_t*)sb_out, N, D, t_index);
@@ -710,6 +718,10 @@ int launch_ln_mod(int prec, const float* h, const float* ada, int ld_ada, int of
     OSUD_CHECK_ARG(br == nullptr, "ln_mod: the split-bf16 tier is inference only (no pending branch operand)");
     return ln_mod_t<x3_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, nullptr, 0, h_out);
   }
+  if (prec == OSUD_PREC_F16) {
+    OSUD_CHECK_ARG(br == nullptr, "ln_mod: the fp16 tier is inference only (no pending branch operand)");
+    return ln_mod_t<f16_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, nullptr, 0, h_out);
+  }
   if (prec == OSUD_PREC_F16F8) {  // (the trunk GEMMs' operand form inside the split-bf16 tier)
     OSUD_CHECK_ARG(br == nullptr, "ln_mod: the fp16 + e4m3 tier is inference only (no pending branch operand)");
     return ln_mod_t<h8_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, nullptr, 0, h_out);
@@ -723,8 +735,8 @@ int launch_final(const float* h, const float* ada, int ld_ada, int off_shift, in
                  const float* bias, float* out, float* u_save, float* stats, int N, int T, int Tp, int D, int C,
                  hipStream_t st, int prec, const void* br, int off_gate, float* h_out) {
   OSUD_CHECK_ARG(C >= 1 && C <= 4 && Tp % 16 == 0, "final layer: out channels %d not in 1..4 / Tp %% 16", C);
-  if (prec == OSUD_PREC_BF16X3) {  // (the kernel reads fp32 h; only the pending-branch operand has the tier's type, and inference has none)
-    OSUD_CHECK_ARG(br == nullptr, "final layer: the split-bf16 tier is inference only");
+  if (prec == OSUD_PREC_BF16X3 || prec == OSUD_PREC_F16) {  // (the kernel reads fp32 h; only the pending-branch operand has the tier's type, and inference has none)
+    OSUD_CHECK_ARG(br == nullptr, "final layer: the split-bf16 and fp16 tiers are inference only");
     prec = OSUD_PREC_F32;
   }
   const dim3 grid(N * Tp / 16), block(256);
@@ -763,6 +775,8 @@ int launch_convert(int prec, const float* src, void* dst, size_t n, hipStream_t 
   const int grid = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
   if (prec == OSUD_PREC_BF16)
     hipLaunchKernelGGL((convert_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, src, (bf16_t*)dst, n);
+  else if (prec == OSUD_PREC_F16)
+    hipLaunchKernelGGL((convert_kernel<f16_t>), dim3(grid), dim3(256), 0, st, src, (f16_t*)dst, n);
   else
     hipLaunchKernelGGL((convert_kernel<float>), dim3(grid), dim3(256), 0, st, src, (float*)dst, n);
   OSUD_HIP(hipGetLastError());
@@ -776,6 +790,9 @@ int launch_pack_rows(int prec, const float* src, int ld_src, int cols_src, void*
   const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
   if (prec == OSUD_PREC_BF16)
     hipLaunchKernelGGL((pack_rows_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, src, ld_src, cols_src, (bf16_t*)dst,
+                       ld_dst, cols_dst, rows);
+  else if (prec == OSUD_PREC_F16)
+    hipLaunchKernelGGL((pack_rows_kernel<f16_t>), dim3(grid), dim3(256), 0, st, src, ld_src, cols_src, (f16_t*)dst,
                        ld_dst, cols_dst, rows);
   else
     hipLaunchKernelGGL((pack_rows_kernel<float>), dim3(grid), dim3(256), 0, st, src, ld_src, cols_src, (float*)dst,

@@ -221,11 +221,12 @@ def parse_args(argv=None):
     p.add_argument("--model", type=str, choices=list(DiT_models.keys()), default="DiT-B")
     # additions of this build
     p.add_argument("--synthetic", type=int, default=0, metavar="T", help="use a synthetic T-token sequence")
-    p.add_argument("--precision", choices=["bf16", "fp32", "fp8", "bf16x3", "fp16f8"], default="fp16f8",
+    p.add_argument("--precision", choices=["bf16", "fp16", "fp32", "fp8", "bf16x3", "fp16f8"], default="fp16f8",
                    help="fp16f8 (default): the fastest tier whose final coordinates stay within 1e-3 of the reference's for identical "
                         "(seed, beatmap, steps) -- split-bf16 arithmetic with the big GEMMs on fp16 + e4m3-residual operands; bf16x3: "
-                        "split-bf16 operands everywhere (same tolerance, 0.8x the speed); bf16: fast tier (1.9x the speed, ~1e-2 from "
-                        "the reference after 1000 steps); fp32: exact-f32 MFMA parity tier; fp8: e4m3 GEMM operands")
+                        "split-bf16 operands everywhere (same tolerance, 0.8x the speed); fp16: fast tier on half operands -- the 11 significand "
+                        "bits of the reference's own TF32 sampling matmuls -- 1.9x the speed, ~1e-3 from the reference after 1000 steps; "
+                        "bf16: the training tier's arithmetic, same speed as fp16, ~1e-2; fp32: exact-f32 MFMA parity tier; fp8: e4m3 GEMM operands")
     p.add_argument("--sampler", choices=["p", "ddim"], default="p", help="ancestral p_sample loop (reference default) or DDIM")
     p.add_argument("--ddim-eta", type=float, default=0.0)
     p.add_argument("--noise", choices=["gpu", "cpu"], default="gpu",

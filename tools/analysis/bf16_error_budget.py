@@ -24,8 +24,11 @@ from osu_diffusion_amd.synthetic import synthetic_windows  # noqa: E402
 ROUND = set()
 
 
+DTYPE = {"bf16": torch.bfloat16, "fp16": torch.float16}[os.environ.get("DTYPE", "bf16")]  # operand format that is emulated
+
+
 def r(v, cls):
-    return v.to(torch.bfloat16).float() if cls in ROUND else v
+    return v.to(DTYPE).float() if cls in ROUND else v
 
 
 def forward(sd, s, x, t, o, c, y):
@@ -105,14 +108,16 @@ def main():
     print(f"model={a.model} steps={a.steps} pos_gain={a.pos_gain}: max|out|={ref_out.abs().max():.3f}")
     print(f"{'bf16 operands in':<22}{'one forward max|d|':>20}{'rel':>10}{'loop final max|d|':>20}{'mean|d|':>12}")
     classes = ["first", "temb", "ada", "qkv", "attn", "proj", "fc1", "fc2"]
-    for cfg in [[c_] for c_ in classes] + [["qkv", "attn", "proj", "fc1", "fc2"], classes]:
+    only = os.environ.get("ONLY")  # ONLY=fast: just the fast tier's configuration (everything but the split first linear)
+    cfgs = [classes[1:]] if only == "fast" else [[c_] for c_ in classes] + [["qkv", "attn", "proj", "fc1", "fc2"], classes]
+    for cfg in cfgs:
         ROUND.clear()
         ROUND.update(cfg)
         out = fn(z, tm[t_mid])
         fin = do.sample_loop(sch, fn, z, noises)
         d1 = (out - ref_out).abs().max().item()
         df = (fin - ref_fin).abs()
-        print(f"{'+'.join(cfg) if len(cfg) < 4 else ('trunk' if len(cfg) == 5 else 'all'):<22}{d1:>20.3e}{d1 / ref_out.abs().max().item():>10.1e}"
+        print(f"{'+'.join(cfg) if len(cfg) < 4 else ('trunk' if len(cfg) == 5 else ('all but first' if len(cfg) == 7 else 'all')):<22}{d1:>20.3e}{d1 / ref_out.abs().max().item():>10.1e}"
               f"{df.max().item():>20.3e}{df.mean().item():>12.3e}")
 
 
