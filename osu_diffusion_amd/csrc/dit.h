@@ -56,6 +56,13 @@ struct BwdWs {
   float *dhA = nullptr, *dhB = nullptr, *du = nullptr, *dada = nullptr, *dWada = nullptr, *dbada = nullptr, *dsb = nullptr,
         *db = nullptr, *dth = nullptr, *dWe = nullptr, *splitk = nullptr, *attn_delta = nullptr /* [N][H][Tp] */;
   size_t splitk_elems = 0;
+  // bf16 tier: the weight gradients of a block run on a side stream next to the block's data-gradient chain (train.hip): their own
+  // split-K slab area, the stream, and the events that hand the operands over {fc2 dgrad done, LN2 backward + out_proj dgrad done,
+  // attention backward done, side stream drained}
+  float* splitk2 = nullptr;
+  hipStream_t side = nullptr;
+  hipEvent_t side_ev[4] = {nullptr, nullptr, nullptr, nullptr};  // [0..2] chain -> side, [3] side -> chain
+  bool side_busy = false;  // weight gradients enqueued on the side stream since the chain last joined it
   float** seg_tbl = nullptr;       // device: the per-block adaLN weight-gradient tensors (GemmP::seg_out), 32 entries
   float* seg_tbl_host[32] = {};    // what the device table holds (uploaded again when a gradient tensor is re-bound)
   void* dbr2 = nullptr;  // d(attention branch output): its own buffer, so that the MLP branch's `dbr` lives to the end of the block's

@@ -133,6 +133,7 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
     OSUD_TRY(dev_alloc(W, &b.dWe, (size_t)D * m->Kp * 4));
     b.splitk_elems = (size_t)16 * 4 * D * D;  // up to 16 partial slabs of the largest weight gradient
     OSUD_TRY(dev_alloc(W, &b.splitk, b.splitk_elems * 4, false));
+    OSUD_TRY(dev_alloc(W, &b.splitk2, b.splitk_elems * 4, false));
     OSUD_TRY(dev_alloc(W, &b.attn_delta, (size_t)nN * m->H * Tp * 4));
     OSUD_TRY(dev_alloc(W, &b.seg_tbl, 32 * sizeof(float*)));
     for (float*& q : b.seg_tbl_host) q = nullptr;
@@ -474,6 +475,9 @@ extern "C" void osud_dit_destroy(osud_dit* m) {
   if (!m) return;
   if (m->graph_exec) (void)hipGraphExecDestroy(m->graph_exec);
   if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
+  for (hipEvent_t& e : m->bw.side_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (m->bw.side) (void)hipStreamDestroy(m->bw.side);
   for (void* p : m->owned) (void)hipFree(p);
   for (void* p : m->ws_owned) (void)hipFree(p);
   delete m;

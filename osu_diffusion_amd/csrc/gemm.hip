@@ -63,7 +63,12 @@ unsigned* sched_slot() {
 
 }  // namespace
 
-int gemm_num_cus() { return num_cus(); }
+// OSUD_GEMM_CUS=<n> (experiments): the persistent GEMM / weight-gradient kernels use n workgroups instead of one per compute unit
+int gemm_num_cus() {
+  static const int cap = [] { const char* e = getenv("OSUD_GEMM_CUS"); return e ? atoi(e) : 0; }();
+  const int n = num_cus();
+  return cap > 0 && cap < n ? cap : n;
+}
 unsigned* gemm_sched_slot() { return sched_slot(); }
 bool gemm_dynamic_tiles_wanted() { return gemm_dynamic_tiles_on(); }
 

@@ -104,10 +104,10 @@ int wgrad(osud_dit* m, const void* Y, const void* X, int My, int Nx, int K, floa
 //   bf16 tier: transpose-free kernel (wgrad.hip) + a column-sum pass;
 //   f32 tier : transposes (the column sums ride along) + the generic GEMM.
 int weight_grad(osud_dit* m, const void* dC, int ld_dc, const void* A, int ld_a, int Ny, int Nx, int M, float* dW,
-                float* db, hipStream_t st) {
+                float* db, hipStream_t st, float* slabs = nullptr /* bf16 tier: split-K slab area (default: the main stream's) */) {
   BwdWs& w = m->bw;
   if (m->prec == OSUD_PREC_BF16) {
-    OSUD_TRY(launch_wgrad_tr(dC, ld_dc, A, ld_a, Ny, Nx, M, dW, w.splitk, w.splitk_elems, st));
+    OSUD_TRY(launch_wgrad_tr(dC, ld_dc, A, ld_a, Ny, Nx, M, dW, slabs ? slabs : w.splitk, w.splitk_elems, st));
     if (db) OSUD_TRY(launch_colsum_bf16(dC, ld_dc, M, Ny, db, st));
     return OSUD_OK;
   }
@@ -235,6 +235,48 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     auto weight_grad8 = [&](const void* P8, int ldp, int slot_p, const void* Q8, int ldq, int slot_q, int Ny, int Nx, float* dW) -> int {
       return launch_wgrad8_tr(P8, ldp, Q8, ldq, Ny, Nx, Mp, dW, w.splitk, w.splitk_elems, slot(slot_p) + 1, slot(slot_q) + 1, st);
     };
+    // The weight gradients of the block are formed two at a time in grouped launches (wgrad.hip: wgrad_group_kernel -- equal runs
+    // of stages per workgroup over the pair's tiles instead of launches split 7 to 28 ways, a third of the partial-slab bytes, one
+    // combine launch per pair) where the group qualifies (bf16 tier, sides multiples of 256, GPU not shared); otherwise each
+    // follows its data-gradient product as before.  out_proj's weight gradient waits for in_proj's: the attention branch's
+    // gradient has its own buffer (dbr2) so that it is still there.
+    const bool group_wg = prec == OSUD_PREC_BF16 && fused_b1 && D % 256 == 0 && !gemm_dynamic_tiles_on() &&
+                          (getenv("OSUD_WGRAD_GROUP") && getenv("OSUD_WGRAD_GROUP")[0] == '1');  // opt-in: measured neutral (wgrad.hip)
+    // (two groups per block, each right behind the data-gradient product that made its big operand: dz1 -- 201 MB -- and dqkv
+    //  are then still in the Infinity Cache; ONE group of all four at the end of the phase found them cold and ran 2.05 instead
+    //  of 1.85 us per stage: with two 64 KiB stages a slab's fill has one slab of lead, and an HBM fill does not make it)
+    // bf16 tier: the four weight gradients of the block leave the data-gradient chain and run on a side stream (their own slab
+    // area), each as soon as its gradient operand exists; the chain -- data-gradient GEMMs with the HBM-bound LayerNorm / attention
+    // backward kernels between them -- goes on at once, and waits for the side stream only before the kernel that overwrites the
+    // branch gradients (the LN1 backward).  The weight gradients then run under the chain's HBM-bound kernels, which leave the
+    // matrix pipe -- and the power budget, section 4 of DESIGN.md -- idle: 12 blocks of the pattern with device copies standing in
+    // for the HBM-bound kernels 14.2 -> 13.2 ms (tools/overlap_wgrad_probe.py); the real step 26.2 -> 25.7 ms on one box, 26.0 -> 25.8
+    // on another (five alternating pairs, every one in favour).  Less than the stand-in promised: a LayerNorm backward fills every
+    // compute unit's registers, so a weight-gradient workgroup only starts where its blocks have finished -- the gain is kernel
+    // heads and tails filling each other, not two kernels sharing compute units.  OSUD_WGRAD_SIDE=0 restores the single stream.
+    static const bool side_env = [] { const char* e = getenv("OSUD_WGRAD_SIDE"); return !(e && e[0] == '0'); }();
+    bool side_on = side_env && prec == OSUD_PREC_BF16 && !f8_train && !group_wg;
+    if (side_on && w.side == nullptr) {
+      if (hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking) != hipSuccess) { w.side = nullptr; side_on = false; }
+      for (hipEvent_t& e : w.side_ev)
+        if (side_on && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; side_on = false; }
+    }
+    auto side_after = [&](int e) -> int {  // the side stream continues behind everything the chain has enqueued so far
+      OSUD_HIP(hipEventRecord(w.side_ev[e], st));
+      OSUD_HIP(hipStreamWaitEvent(w.side, w.side_ev[e], 0));
+      w.side_busy = true;
+      return OSUD_OK;
+    };
+    // side -> chain: the chain joins the side stream before the LN1 backward, the first kernel that overwrites an operand of this block's
+    // weight gradients (dbr; the next block then overwrites dz1, dbr2, dqkv).  Measured against per-buffer events that let in_proj's
+    // weight gradient run on under the LN1 backward and the next block's first data gradient: 25.6-25.8 vs 26.0 ms per step (single
+    // stream 26.2) -- two MFMA kernels side by side only take compute units from each other.
+    auto chain_joins_side = [&]() -> int {
+      OSUD_HIP(hipEventRecord(w.side_ev[3], w.side));
+      OSUD_HIP(hipStreamWaitEvent(st, w.side_ev[3], 0));
+      w.side_busy = false;
+      return OSUD_OK;
+    };
     {
       int part_rows = 0;
       // (the e4m3 twin of dbr and its amax come from the kernel that produced dbr -- the LN1 backward of block l + 1 -- except
@@ -256,6 +298,23 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
       if (fused_b1) OSUD_TRY(launch_colsum_f32(w.splitk, part_rows, 4 * D, g_b1, st));
     }
     OSUD_TRY(dbg_sync(st, "dgrad fc2 (gelu grad)"));
+    hipStream_t ws_ = side_on ? w.side : st;
+    float* slabs_ = side_on ? w.splitk2 : nullptr;
+    auto wg_mlp = [&]() -> int {
+      OSUD_TRY(weight_grad(m, w.dz1, 4 * D, sv.u2, D, 4 * D, D, Mp, G(p + "mlp.fc1.weight"), fused_b1 ? nullptr : g_b1, ws_, slabs_));
+      OSUD_TRY(dbg_sync(ws_, "wgrad fc1"));
+      OSUD_TRY(weight_grad(m, w.dbr, D, sv.g, 4 * D, D, 4 * D, Mp, G(p + "mlp.fc2.weight"), nullptr, ws_, slabs_));
+      return dbg_sync(ws_, "wgrad fc2");
+    };
+    auto wg_proj = [&]() -> int {
+      OSUD_TRY(weight_grad(m, w.dbr2, D, sv.ao, D, D, D, Mp, G(p + "attn.out_proj.weight"), nullptr, ws_, slabs_));
+      return dbg_sync(ws_, "wgrad out_proj");
+    };
+    if (side_on) {  // dz1 and this block's dbr exist: fc1 / fc2 weight gradients start next to the fc1 data gradient (starting them
+                    // behind it, under the LN2 backward, measured no better than the single stream)
+      OSUD_TRY(side_after(0));
+      OSUD_TRY(wg_mlp());
+    }
     // consumers of dz1 (201 MB, fresh in the Infinity Cache) first, the fc2 weight gradient (dbr, g) after them
     if (f8_train && !f8_live) OSUD_TRY(launch_f8_quantize(w.dz1, nullptr, (size_t)Mp * 4 * D, slot(4), st));  // live: written by the epilogue above
     if (f8_live) OSUD_TRY(gemm8(m, EPI_NONE_TE, m->q8b, bw.w1_t8, Mp, D, 4 * D, w.du, D, nullptr, bw.dq_1_t, 0.f, st, nullptr, 0, 0, 0, 0.f,
@@ -263,16 +322,6 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     else
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dz1, 4 * D, bw.w1_t, 4 * D, Mp, D, 4 * D, w.du, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "dgrad fc1"));
-    // The weight gradients of the block are formed two at a time in grouped launches (wgrad.hip: wgrad_group_kernel -- equal runs
-    // of stages per workgroup over the pair's tiles instead of launches split 7 to 28 ways, a third of the partial-slab bytes, one
-    // combine launch per pair) where the group qualifies (bf16 tier, sides multiples of 256, GPU not shared); otherwise each
-    // follows its data-gradient product as before.  out_proj's weight gradient waits for in_proj's: the attention branch's
-    // gradient has its own buffer (dbr2) so that it is still there.
-    const bool group_wg = prec == OSUD_PREC_BF16 && fused_b1 && D % 256 == 0 && !gemm_dynamic_tiles_on() &&
-                          (getenv("OSUD_WGRAD_GROUP") && getenv("OSUD_WGRAD_GROUP")[0] == '1');  // opt-in: measured neutral (wgrad.hip)
-    // (two groups per block, each right behind the data-gradient product that made its big operand: dz1 -- 201 MB -- and dqkv
-    //  are then still in the Infinity Cache; ONE group of all four at the end of the phase found them cold and ran 2.05 instead
-    //  of 1.85 us per stage: with two 64 KiB stages a slab's fill has one slab of lead, and an HBM fill does not make it)
     auto wgrad_pair = [&](const WgradItem (&items)[2], const char* what) -> int {
       bool done = false;
       OSUD_TRY(launch_wgrad_group(items, 2, Mp, w.splitk, w.splitk_elems, st, &done));
@@ -289,10 +338,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
                                   {w.dbr, sv.g, G(p + "mlp.fc2.weight"), D, 4 * D, D, 4 * D}};
       OSUD_TRY(wgrad_pair(items, "wgrad fc1 + fc2 (grouped)"));
     } else {
-    OSUD_TRY(weight_grad(m, w.dz1, 4 * D, sv.u2, D, 4 * D, D, Mp, G(p + "mlp.fc1.weight"), fused_b1 ? nullptr : g_b1, st));
-    OSUD_TRY(dbg_sync(st, "wgrad fc1"));
-    OSUD_TRY(weight_grad(m, w.dbr, D, sv.g, 4 * D, D, 4 * D, Mp, G(p + "mlp.fc2.weight"), nullptr, st));
-    OSUD_TRY(dbg_sync(st, "wgrad fc2"));
+    if (!side_on) OSUD_TRY(wg_mlp());  // (side stream: enqueued right behind the fc2 data gradient, above)
     }
     // LN2 backward -> dh = grad wrt h_mid, and on the same rows the gate step of the attention branch
     // (h_mid = h_in + g1 * (attn(u1) Wo^T + bo)): dbr = g1 * dh, dg1, dbo
@@ -302,6 +348,10 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
                                f8_train ? m->f8_parts + ((size_t)l * kF8Slots + 7) * f8_amax_parts() : nullptr));
     OSUD_TRY(dbg_sync(st, "ln2 bwd + gate_bwd attn"));
     std::swap(dh, dh_other);
+    if (side_on) {  // dbr2 exists: out_proj's weight gradient starts next to its data gradient
+      OSUD_TRY(side_after(1));
+      OSUD_TRY(wg_proj());
+    }
     if (f8_live) OSUD_TRY(gemm8(m, EPI_NONE_TE, m->q8c, bw.w_o_t8, Mp, D, D, w.dao, D, nullptr, bw.dq_o_t, 0.f, st, nullptr, 0, 0, 0, 0.f, slot(7) + 1));
     else
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dbr2, D, bw.w_o_t, D, Mp, D, D, w.dao, D, nullptr, st));
@@ -309,8 +359,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
       OSUD_TRY(weight_grad8(m->q8c, D, 7, sv.ao_8, D, 6, D, D, G(p + "attn.out_proj.weight")));
       OSUD_TRY(dbg_sync(st, "wgrad out_proj (e4m3)"));
     } else if (!group_wg) {
-    OSUD_TRY(weight_grad(m, w.dbr2, D, sv.ao, D, D, D, Mp, G(p + "attn.out_proj.weight"), nullptr, st));
-    OSUD_TRY(dbg_sync(st, "wgrad out_proj"));
+    if (!side_on) OSUD_TRY(wg_proj());  // (side stream: enqueued right behind the LN2 backward, above)
     }
     // (bf16 tier: the in_proj bias gradient is the attention backward's job -- inside the streamed kernel at T = 128, a column-sum
     //  pass over dqkv behind the other kernels; scratch: the split-K slab area, idle between two weight gradients)
@@ -320,6 +369,14 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     OSUD_TRY(launch_attention_bwd(prec, sv.qk, w.dao, sv.ao, sv.lse, w.dqkv, N, T, m->H, m->hd, st, w.attn_delta,
                                   (fused_bqkv && !f8_train) ? g_bqkv : nullptr, w.splitk, w.splitk_elems));
     OSUD_TRY(dbg_sync(st, "attention bwd"));
+    auto wg_qkv = [&]() -> int {
+      OSUD_TRY(weight_grad(m, w.dqkv, 3 * D, sv.u1, D, 3 * D, D, Mp, G(p + "attn.in_proj_weight"), fused_bqkv ? nullptr : g_bqkv, ws_, slabs_));
+      return dbg_sync(ws_, "wgrad qkv");
+    };
+    if (side_on) {  // dqkv exists: in_proj's weight gradient starts next to its data gradient
+      OSUD_TRY(side_after(2));
+      OSUD_TRY(wg_qkv());
+    }
     if (f8_train) OSUD_TRY(launch_colsum_quant_bf16(w.dqkv, Mp, 3 * D, g_bqkv, f8_live ? m->q8b : nullptr, slot(5), st));
     if (f8_live) OSUD_TRY(gemm8(m, EPI_NONE_TE, m->q8b, bw.w_qkv_t8, Mp, D, 3 * D, w.du, D, nullptr, bw.dq_qkv_t, 0.f, st, nullptr, 0, 0, 0, 0.f,
                                 slot(5) + 1));
@@ -334,9 +391,9 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
                                   {w.dbr2, sv.ao, G(p + "attn.out_proj.weight"), D, D, D, D}};
       OSUD_TRY(wgrad_pair(items, "wgrad in_proj + out_proj (grouped)"));
     } else {
-    OSUD_TRY(weight_grad(m, w.dqkv, 3 * D, sv.u1, D, 3 * D, D, Mp, G(p + "attn.in_proj_weight"), fused_bqkv ? nullptr : g_bqkv, st));
-    OSUD_TRY(dbg_sync(st, "wgrad qkv"));
+    if (!side_on) OSUD_TRY(wg_qkv());  // (side stream: enqueued right behind the attention backward, above)
     }
+    if (side_on) OSUD_TRY(chain_joins_side());
     // LN1 backward -> dh = grad wrt h_in = grad wrt the output of block l-1, whose MLP gate step rides along
     if (l > 0) {
       const LayerSaved& svp = m->saved[(size_t)l - 1];
@@ -358,6 +415,11 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     }
   }
 
+  if (w.side != nullptr && w.side_busy) {  // (not reached: every block joins) the caller's stream owns every gradient again
+    OSUD_HIP(hipEventRecord(w.side_ev[3], w.side));
+    OSUD_HIP(hipStreamWaitEvent(st, w.side_ev[3], 0));
+    w.side_busy = false;
+  }
   m->bw_dh_cur = dh == w.dhB ? 1 : 0;
   if (phase_hi < L + 1) return OSUD_OK;
 

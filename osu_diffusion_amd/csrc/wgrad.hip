@@ -903,7 +903,9 @@ int num_cus_w() {
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n[dev] = prop.multiProcessorCount;
     if (n[dev] <= 0) n[dev] = 256;
   }
-  return n[dev];
+  // OSUD_WGRAD_CUS=<n> (experiments): size the weight-gradient launches for n compute units (the rest stay free for another stream)
+  static const int cap = [] { const char* e = getenv("OSUD_WGRAD_CUS"); return e ? atoi(e) : 0; }();
+  return cap > 0 && cap < n[dev] ? cap : n[dev];
 }
 
 // counter sets of the chunk queues (64 words each: [tile] tickets, [63] finished workgroups), re-armed by the last workgroup out
