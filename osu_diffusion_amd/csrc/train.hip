@@ -254,7 +254,8 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     // on another (five alternating pairs, every one in favour).  Less than the stand-in promised: a LayerNorm backward fills every
     // compute unit's registers, so a weight-gradient workgroup only starts where its blocks have finished -- the gain is kernel
     // heads and tails filling each other, not two kernels sharing compute units.  OSUD_WGRAD_SIDE=0 restores the single stream.
-    static const bool side_env = [] { const char* e = getenv("OSUD_WGRAD_SIDE"); return !(e && e[0] == '0'); }();
+    const char* side_e = getenv("OSUD_WGRAD_SIDE");  // (read per block: bench.py profiles its per-kernel table on the single stream)
+    const bool side_env = !(side_e && side_e[0] == '0');
     bool side_on = side_env && prec == OSUD_PREC_BF16 && !f8_train && !group_wg;
     if (side_on && w.side == nullptr) {
       if (hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking) != hipSuccess) { w.side = nullptr; side_on = false; }
