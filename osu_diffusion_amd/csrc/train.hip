@@ -232,8 +232,10 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     auto slot = [&](int which) { return m->f8_slots + ((size_t)l * kF8Slots + which) * 4; };
     // fp8 training, live steps: a weight gradient from the e4m3 twins of its two operands (twice the bf16 kernel's rate); dW is
     // de-quantised by the two slots' 1 / scale.  P8: the gradient twin in its staging buffer, Q8: the layer's saved activation twin
-    auto weight_grad8 = [&](const void* P8, int ldp, int slot_p, const void* Q8, int ldq, int slot_q, int Ny, int Nx, float* dW) -> int {
-      return launch_wgrad8_tr(P8, ldp, Q8, ldq, Ny, Nx, Mp, dW, w.splitk, w.splitk_elems, slot(slot_p) + 1, slot(slot_q) + 1, st);
+    auto weight_grad8 = [&](const void* P8, int ldp, int slot_p, const void* Q8, int ldq, int slot_q, int Ny, int Nx, float* dW,
+                            hipStream_t s8 = nullptr /* the side stream (its own slab area) */) -> int {
+      return launch_wgrad8_tr(P8, ldp, Q8, ldq, Ny, Nx, Mp, dW, s8 ? w.splitk2 : w.splitk, w.splitk_elems, slot(slot_p) + 1, slot(slot_q) + 1,
+                              s8 ? s8 : st);
     };
     // The weight gradients of the block are formed two at a time in grouped launches (wgrad.hip: wgrad_group_kernel -- equal runs
     // of stages per workgroup over the pair's tiles instead of launches split 7 to 28 ways, a third of the partial-slab bytes, one
@@ -257,11 +259,17 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     const char* side_e = getenv("OSUD_WGRAD_SIDE");  // (read per block: bench.py profiles its per-kernel table on the single stream)
     const bool side_env = !(side_e && side_e[0] == '0');
     bool side_on = side_env && prec == OSUD_PREC_BF16 && !f8_train && !group_wg;
-    if (side_on && w.side == nullptr) {
-      if (hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking) != hipSuccess) { w.side = nullptr; side_on = false; }
+    // (fp8 training, live steps: the same for the e4m3 weight gradients, with one more join -- the twin of dqkv re-uses the staging
+    //  buffer the fc1 weight gradient reads dz1's twin from)
+    bool side8 = side_env && prec == OSUD_PREC_BF16 && f8_live && fused_b1 && Mp % 128 == 0 && !group_wg;
+    if ((side_on || side8) && w.side == nullptr) {
+      bool ok = hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking) == hipSuccess;
+      if (!ok) w.side = nullptr;
       for (hipEvent_t& e : w.side_ev)
-        if (side_on && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; side_on = false; }
+        if (ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; ok = false; }
+      if (!ok) side_on = side8 = false;
     }
+    if (w.side == nullptr || w.side_ev[3] == nullptr) side_on = side8 = false;
     auto side_after = [&](int e) -> int {  // the side stream continues behind everything the chain has enqueued so far
       OSUD_HIP(hipEventRecord(w.side_ev[e], st));
       OSUD_HIP(hipStreamWaitEvent(w.side, w.side_ev[e], 0));
@@ -316,6 +324,12 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
       OSUD_TRY(side_after(0));
       OSUD_TRY(wg_mlp());
     }
+    if (side8) {  // (q8b = dz1's twin, q8a = the MLP branch gradient's)
+      OSUD_TRY(side_after(0));
+      OSUD_TRY(weight_grad8(m->q8b, 4 * D, 4, sv.u2_8, D, 1, 4 * D, D, G(p + "mlp.fc1.weight"), w.side));
+      OSUD_TRY(weight_grad8(m->q8a, D, 3, sv.g_8, 4 * D, 2, D, 4 * D, G(p + "mlp.fc2.weight"), w.side));
+      OSUD_TRY(dbg_sync(w.side, "wgrad fc1, fc2 (e4m3, side stream)"));
+    }
     // consumers of dz1 (201 MB, fresh in the Infinity Cache) first, the fc2 weight gradient (dbr, g) after them
     if (f8_train && !f8_live) OSUD_TRY(launch_f8_quantize(w.dz1, nullptr, (size_t)Mp * 4 * D, slot(4), st));  // live: written by the epilogue above
     if (f8_live) OSUD_TRY(gemm8(m, EPI_NONE_TE, m->q8b, bw.w1_t8, Mp, D, 4 * D, w.du, D, nullptr, bw.dq_1_t, 0.f, st, nullptr, 0, 0, 0, 0.f,
@@ -330,7 +344,8 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
         for (const WgradItem& it : items) OSUD_TRY(weight_grad(m, it.P, it.ldp, it.Q, it.ldq, it.Ny, it.Nx, Mp, it.out, nullptr, st));
       return dbg_sync(st, what);
     };
-    if (f8_live && fused_b1 && Mp % 128 == 0) {  // (q8b = dz1's twin, q8a = the MLP branch gradient's: both still in place)
+    if (side8) {  // (enqueued on the side stream behind the fc2 data gradient, above)
+    } else if (f8_live && fused_b1 && Mp % 128 == 0) {  // (q8b = dz1's twin, q8a = the MLP branch gradient's: both still in place)
       OSUD_TRY(weight_grad8(m->q8b, 4 * D, 4, sv.u2_8, D, 1, 4 * D, D, G(p + "mlp.fc1.weight")));
       OSUD_TRY(weight_grad8(m->q8a, D, 3, sv.g_8, 4 * D, 2, D, 4 * D, G(p + "mlp.fc2.weight")));
       OSUD_TRY(dbg_sync(st, "wgrad fc1, fc2 (e4m3)"));
@@ -353,10 +368,16 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
       OSUD_TRY(side_after(1));
       OSUD_TRY(wg_proj());
     }
+    if (side8) {
+      OSUD_TRY(side_after(1));
+      OSUD_TRY(weight_grad8(m->q8c, D, 7, sv.ao_8, D, 6, D, D, G(p + "attn.out_proj.weight"), w.side));
+      OSUD_TRY(dbg_sync(w.side, "wgrad out_proj (e4m3, side stream)"));
+    }
     if (f8_live) OSUD_TRY(gemm8(m, EPI_NONE_TE, m->q8c, bw.w_o_t8, Mp, D, D, w.dao, D, nullptr, bw.dq_o_t, 0.f, st, nullptr, 0, 0, 0, 0.f, slot(7) + 1));
     else
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dbr2, D, bw.w_o_t, D, Mp, D, D, w.dao, D, nullptr, st));
-    if (f8_live && Mp % 128 == 0) {
+    if (side8) {  // (enqueued on the side stream behind the LN2 backward, above)
+    } else if (f8_live && Mp % 128 == 0) {
       OSUD_TRY(weight_grad8(m->q8c, D, 7, sv.ao_8, D, 6, D, D, G(p + "attn.out_proj.weight")));
       OSUD_TRY(dbg_sync(st, "wgrad out_proj (e4m3)"));
     } else if (!group_wg) {
@@ -378,13 +399,20 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
       OSUD_TRY(side_after(2));
       OSUD_TRY(wg_qkv());
     }
+    if (side8) OSUD_TRY(chain_joins_side());  // (q8b: dz1's twin, read by fc1's weight gradient, is overwritten by dqkv's twin next)
     if (f8_train) OSUD_TRY(launch_colsum_quant_bf16(w.dqkv, Mp, 3 * D, g_bqkv, f8_live ? m->q8b : nullptr, slot(5), st));
+    if (side8) {  // q8b = dqkv's twin: in_proj's weight gradient starts next to its data gradient
+      OSUD_TRY(side_after(2));
+      OSUD_TRY(weight_grad8(m->q8b, 3 * D, 5, sv.u1_8, D, 0, 3 * D, D, G(p + "attn.in_proj_weight"), w.side));
+      OSUD_TRY(dbg_sync(w.side, "wgrad in_proj (e4m3, side stream)"));
+    }
     if (f8_live) OSUD_TRY(gemm8(m, EPI_NONE_TE, m->q8b, bw.w_qkv_t8, Mp, D, 3 * D, w.du, D, nullptr, bw.dq_qkv_t, 0.f, st, nullptr, 0, 0, 0, 0.f,
                                 slot(5) + 1));
     else
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dqkv, 3 * D, bw.w_qkv_t, 3 * D, Mp, D, 3 * D, w.du, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "dgrad qkv"));
-    if (f8_live && fused_bqkv && Mp % 128 == 0) {  // (q8b = dqkv's twin)
+    if (side8) {  // (enqueued on the side stream behind the dqkv pass, above)
+    } else if (f8_live && fused_bqkv && Mp % 128 == 0) {  // (q8b = dqkv's twin)
       OSUD_TRY(weight_grad8(m->q8b, 3 * D, 5, sv.u1_8, D, 0, 3 * D, D, G(p + "attn.in_proj_weight")));
       OSUD_TRY(dbg_sync(st, "wgrad in_proj (e4m3)"));
     } else if (group_wg) {
@@ -394,7 +422,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     } else {
     if (!side_on) OSUD_TRY(wg_qkv());  // (side stream: enqueued right behind the attention backward, above)
     }
-    if (side_on) OSUD_TRY(chain_joins_side());
+    if (side_on || side8) OSUD_TRY(chain_joins_side());  // (fp8: the LN1 backward also rewrites q8a, the twin fc2's weight gradient reads)
     // LN1 backward -> dh = grad wrt h_in = grad wrt the output of block l-1, whose MLP gate step rides along
     if (l > 0) {
       const LayerSaved& svp = m->saved[(size_t)l - 1];
