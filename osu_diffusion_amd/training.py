@@ -389,6 +389,7 @@ class NativeTrainer:
         # backward of the blocks in front of it (same arithmetic, same result).  Measured worth 0.2 % — off by default, the
         # one-call backward keeps the adaLN weight gradients in a single batched GEMM
         self.overlap_adamw = os.environ.get("OSUD_ADAMW_OVERLAP", "0") == "1"
+        self.gated_optimizer = os.environ.get("OSUD_ADAMW_GATED", "0") == "1"  # (experiment: see _optimizer_under_next_forward)
         self._side = None
         # ZeRO-1 between the two halves of the gradient exchange: every finished slice is reduce-SCATTERED
         # (rank r receives the sum of its 1/world shard), AdamW + EMA run on that shard only (1/world of the 6.1 GB the optimizer
@@ -485,9 +486,42 @@ class NativeTrainer:
             if done:
                 self._adamw(_complement(done, self.arena.total), scale)
                 self._refresh()
+            elif single and self.gated_optimizer and not self.force_phased:
+                self._optimizer_under_next_forward(scale)
             else:
                 self.optimizer_step(scale)
         return terms
+
+    def _optimizer_under_next_forward(self, scale):
+        """One GPU, OSUD_ADAMW_GATED=1 (experiment): the HBM-bound AdamW + EMA and the re-pack of a block's weights run on a side stream
+        in forward order, and the NEXT step's forward waits per block (osud_dit_forward_gate) -- the optimizer of the late blocks runs
+        under the MFMA-bound forward of the early ones.  Same arithmetic, same result."""
+        arena, depth, dev = self.arena, self.model.depth, self.arena.flat.device
+        L_ = _lib.lib()
+        blocks, tail = overlap_slices(arena, depth)
+        _, _, f_lo, f_hi = next(s for s in tail if s[0] == "final")
+        by_phase = {i + 1: (blocks[i][2], blocks[i][3]) for i in range(depth)}
+        by_phase[depth + 1] = (f_lo, f_hi)
+        self._advance()
+        self._adamw(_complement(sorted(by_phase.values()), arena.total), scale)
+        h_model = self.model._handle
+        with torch.cuda.device(dev):
+            _lib.check(L_.osud_dit_refresh_phases(h_model, 0, 0, _lib.stream_ptr(dev)))
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        self._side.wait_stream(main)
+        self._gate_events = []
+        with torch.cuda.stream(self._side):
+            for ph in range(1, depth + 2):
+                self._adamw([by_phase[ph]], scale)
+                with torch.cuda.device(dev):
+                    _lib.check(L_.osud_dit_refresh_phases(h_model, ph, ph, C.c_void_p(self._side.cuda_stream)))
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+                self._gate_events.append(ev)
+                _lib.check(L_.osud_dit_forward_gate(h_model, ph, C.c_void_p(ev.cuda_event)))
+        self.ema._uploaded = {}
 
     def _backward_with_overlapped_adamw(self, dout):
         """Single GPU: phased backward on the current stream; as soon as a block's phase is enqueued its (final) gradient

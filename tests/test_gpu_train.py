@@ -433,3 +433,56 @@ def test_grouped_weight_gradients_equal_the_single_product_launches(batch, monke
         else:  # (bias and modulation gradients are column sums accumulated by atomics: equal up to the order of arrival)
             assert float((g1 - g0).abs().max()) <= 2e-5 * max(1e-6, float(g0.abs().max())), k
     print(f"MEASURED wgrad_group[batch {batch}]: worst relative difference to the single-product launches {worst:.3e}")
+
+
+def test_side_stream_weight_gradients_equal_the_single_stream(monkeypatch):
+    """A block's weight gradients on the library's side stream (default) against OSUD_WGRAD_SIDE=0: the same kernels on the same
+    operands -- every weight gradient bit-equal, the atomically accumulated sums equal up to the order of arrival -- and the parameters
+    after three optimizer steps agree."""
+    shape = mo.DitShape(depth=3, hidden=768, heads=12, num_classes=10)
+    sd = mo.seeded_state_dict(shape, 32)
+    (x, o, c), y = synthetic_windows(16, 128, 10, seed=10)
+    t = torch.randint(0, 1000, (16,), generator=torch.Generator().manual_seed(6))
+    noise = torch.randn(16, 2, 128, generator=torch.Generator().manual_seed(7))
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OSUD_WGRAD_SIDE", mode)
+        tr = NativeTrainer(native_model(shape, sd, "bf16").train(), create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True), lr=1e-4)
+        tr.step(x, o, c, y, t=t, noise=noise, drop_ids=torch.zeros(16).long())
+        g = {k: v.detach().cpu().clone() for k, v in tr.arena.grad_views().items()}
+        for _ in range(2):
+            tr.step(x, o, c, y, t=t, noise=noise, drop_ids=torch.zeros(16).long())
+        res[mode] = (g, tr.arena.flat.detach().cpu().clone())
+    for k, g0 in res["0"][0].items():
+        g1 = res["1"][0][k]
+        if any(s in k for s in ("in_proj_weight", "out_proj.weight", "fc1.weight", "fc2.weight")):
+            assert torch.equal(g0, g1), k
+        else:
+            assert float((g1 - g0).abs().max()) <= 2e-5 * max(1e-6, float(g0.abs().max())), k
+    # (AdamW normalises every gradient: where a bias-like gradient is at the level of its atomics' arrival-order noise, two runs of the SAME
+    #  schedule already differ by up to 2 lr per step in that element -- the test is the mean: a skipped or misordered update shifts
+    #  every element of its block by ~lr)
+    d = (res["0"][1] - res["1"][1]).abs()
+    assert float(d.max()) <= 2 * 1e-4 * 3 + 1e-7 and float(d.mean()) < 1e-4 * 1e-3, (float(d.max()), float(d.mean()))
+
+
+def test_optimizer_under_the_next_forward_equals_the_plain_step(monkeypatch):
+    """OSUD_ADAMW_GATED=1 (one GPU, opt-in): AdamW + EMA and the re-pack of each block on a side stream, the next forward gated per block
+    -- the same arithmetic in the same order per parameter: masters, moments and EMA agree with the plain step after four steps."""
+    shape = mo.DitShape(depth=3, hidden=384, heads=6, num_classes=10)
+    sd = mo.seeded_state_dict(shape, 33)
+    (x, o, c), y = synthetic_windows(8, 128, 10, seed=11)
+    t = torch.randint(0, 1000, (8,), generator=torch.Generator().manual_seed(8))
+    noise = torch.randn(8, 2, 128, generator=torch.Generator().manual_seed(9))
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OSUD_ADAMW_GATED", mode)
+        tr = NativeTrainer(native_model(shape, sd, "bf16").train(), create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True), lr=1e-3)
+        for _ in range(4):
+            terms = tr.step(x, o, c, y, t=t, noise=noise, drop_ids=torch.zeros(8).long())
+        tr.finish_exchange()
+        res[mode] = (terms.cpu().clone(), tr.arena.flat.detach().cpu().clone(), tr.exp_avg.cpu().clone(), tr.ema_arena.flat.detach().cpu().clone())
+    assert maxdiff(res["0"][0], res["1"][0]) < 1e-4  # the loss terms of the fourth step
+    for a, b in zip(res["0"][1:], res["1"][1:]):  # masters, first moments, EMA: see the note in the test above (lr 1e-3, 4 steps)
+        d = (a - b).abs()
+        assert float(d.max()) <= 2 * 1e-3 * 4 + 1e-7 and float(d.mean()) < 1e-3 * 1e-3, (float(d.max()), float(d.mean()))
