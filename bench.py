@@ -390,7 +390,7 @@ def bench_train(args, world, rank, dev):
     for i in range(4):  # a few distinct resident batches, cycled
         (x, o, c), y = synthetic_windows(B, T, num_classes, seed=10_000 * rank + i, train_offsets=True)
         batches.append(((x.to(dev), o.to(dev), c.to(dev)), y.to(dev)))
-    trainer = NativeTrainer(model, diffusion, lr=1e-4, shard_optimizer=True if args.zero1 else None,
+    trainer = NativeTrainer(model, diffusion, lr=1e-4, shard_optimizer=args.zero1,
                             wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None)
     terms = None
     for i in range(W):
@@ -450,19 +450,13 @@ def bench_train(args, world, rank, dev):
                     trainer.step(x, o, c, y)
             # (the timed region runs a block's weight gradients on a side stream next to its data-gradient chain; kernels that
             #  run side by side report stretched durations, so the per-kernel table is taken on the single-stream schedule)
-            prev = os.environ.get("OSUD_WGRAD_SIDE")
-            os.environ["OSUD_WGRAD_SIDE"] = "0"
-            try:
+            from osu_diffusion_amd import _lib as _l
+            with _l.option("wgrad_side_stream", 0):
                 more(1)
                 res["roofline"]["per_family"] = family_table(more, 3, dit_work(D, model.depth, B * T, T, training=True,
                                                                                n_params=trainer.arena.total), dev)
-            finally:
-                if prev is None:
-                    os.environ.pop("OSUD_WGRAD_SIDE", None)
-                else:
-                    os.environ["OSUD_WGRAD_SIDE"] = prev
             if isinstance(res["roofline"]["per_family"], dict) and "source" in res["roofline"]["per_family"]:
-                res["roofline"]["per_family"]["source"] += ("; single-stream schedule (OSUD_WGRAD_SIDE=0): the timed region overlaps a block's weight "
+                res["roofline"]["per_family"]["source"] += ("; single-stream schedule (option wgrad_side_stream = 0): the timed region overlaps a block's weight "
                                                             "gradients with its data-gradient chain on a second stream, which stretches the durations of "
                                                             "kernels that run side by side")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -25,8 +25,15 @@
  *   diffusion/gaussian_diffusion.py:785-874 (+735-783, diffusion_utils.py:9-89)
  *                       training_losses         -> osud_train_loss / osud_dit_backward
  *   train.py:243-261    optimizer + EMA step    -> osud_adamw_ema_step
- *   train.py:152,257    DDP gradient all-reduce -> done by the host over RCCL on the flat
- *                                                  gradient arena
+ *   train.py:106-115,152,257,274  DDP init broadcast / gradient all-reduce
+ *                                               -> osud_comm_init / osud_broadcast_params / osud_allreduce_grads (or
+ *                                                  osud_reduce_scatter_grads + osud_allgather_params) on the flat gradient
+ *                                                  arena: RCCL behind this ABI; the host only decides WHEN a slice is
+ *                                                  final (osud_dit_backward_phases) -- see INTEGRATION.md
+ *
+ * Run-time switches: ONE table, osud_set_option / osud_get_option (below).  The library reads two environment variables and no
+ * others: OSUD_OPTIONS ("name=value,..": initial values of that table, for A/B runs of unmodified scripts) and OSUD_RCCL_LIB (path
+ * of librccl, resolved with dlopen).
  */
 #ifndef OSUD_H
 #define OSUD_H
@@ -168,6 +175,14 @@ int osud_sample_loop_inpaint(osud_dit* m, const osud_sched* s, int mode, float e
                              int clip, int first_step, int last_step, const float* noise, uint64_t seed,
                              const osud_inpaint* inpaint, osud_stream stream);
 
+/* `iters` sampler steps at ONE schedule index `step`, x in/out: the refine pass of sample.py:186-205 (p_sample at t = 0, refine_iters
+ * times, after the weights of --refine-ckpt were loaded) without a host round trip per iteration -- the captured step of
+ * osud_sample_loop replayed with its device-side step counter standing still.  noise: (iters, N, 2, T) or NULL (in-kernel Philox;
+ * unused at step 0, where the sampler adds none).  inpaint may be NULL. */
+int osud_sample_repeat(osud_dit* m, const osud_sched* s, int mode, float eta, float* x, const float* o, const float* c,
+                       const int64_t* y, const uint8_t* attn_mask, int N, int T, float cfg_scale, int clip, int step, int iters,
+                       const float* noise, uint64_t seed, const osud_inpaint* inpaint, osud_stream stream);
+
 /* ------------------------------------------------------------------ training
  * Sizes must satisfy T % 64 == 0 and N*T % 128 == 0 (no padding rows in the gradient products). */
 /* Where the backward pass writes the gradient of parameter `key` (fp32, same shape as the
@@ -250,10 +265,28 @@ int osud_table_rows_apply(float* table_grad, int rows, int D, const int64_t* all
  * from per-XCD ticket queues instead of a fixed stride, so that a launch does not wait for workgroups whose compute unit is
  * held by another kernel (RCCL collectives overlapped with the backward: 8 held CUs stretch a fixed-stride launch 1.5x, a
  * queued one 1.1x), and the split-K weight-gradient kernel draws K-chunks from per-tile queues; 0 = fixed schedules (0.3 %
- * faster per training step, 2 % per sampling step, when the GPU is not shared); -1 = follow the environment variable OSUD_GEMM_DYNAMIC (default 0).
- * GEMM results are identical either way; weight gradients differ by the order the chunks are summed in.  Data-parallel
+ * faster per training step, 2 % per sampling step, when the GPU is not shared: the default).
+ * GEMM results are identical either way; weight gradients differ by the order the chunks are summed in (the only place where
+ * two runs of the backward pass may differ in the last bits: everything else is summed in a fixed order).  Data-parallel
  * trainers switch it on. */
 int osud_set_gemm_dynamic_tiles(int on);
+
+/* Process-wide options: every run-time choice between two built and tested forms of the same computation.  value -1 restores the
+ * default.  Unknown names / out-of-range values: OSUD_ERR_ARG.
+ *   name                default  values
+ *   wgrad_side_stream   1        1: a block's weight gradients run on the library's side stream next to the block's data-gradient
+ *                                chain (bf16 and fp8 training tiers); 0: single stream.  Same bits.
+ *   sample_graph        1        1: osud_sample_loop captures one step as a hipGraph and replays it; 0: eager launches.  Same bits.
+ *   embed_const         1        sampler loops: the offset / context part of the first linear is multiplied once per loop
+ *   tvec_table          1        sampler loops: the timestep-embedding MLP is evaluated once per loop for every schedule index
+ *   split_first         1        bf16 / fp16 tiers: first linear at fp32 accuracy ([hi | lo | hi] rows); read by osud_dit_create
+ *   attn_fwd_kernel     0        0 auto; 1: never the streamed window kernels; 2: the register-staged general kernel
+ *   attn_bwd_kernel     0        0 auto; 1: never the streamed kernels; 2: the tiled kernel (any T)
+ *   gemm_tile           0        0 auto; 64 | 128 | 192 | 256 | 1192 (192 x 256) | 1256 (128 x 256): force a geometry where it divides
+ *   f8_twins_only       1        fp8 training: tensors whose bf16 form has no reader are written as e4m3 only
+ *   debug_sync          0        1: synchronise after every stage of the backward pass and name it on stderr (fault triage) */
+int osud_set_option(const char* name, int value);
+int osud_get_option(const char* name, int* value);
 
 /* out[y][x] = epilogue(sum_k Y[y][k] * X[x][k]); see csrc/gemm.h for the epilogue codes.  Operand / output forms per precision: 0 bf16,
  * 1 f32, 2 e4m3 (experimental), 3 split-bf16 plane pairs [hi | lo] (ld = logical columns), 4 fp16 + e4m3 rows (osud_op_pack_h8; the

@@ -62,6 +62,7 @@ _SIGNATURES = {
     "osud_sample_loop": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp, _u64, _vp]),
     "osud_sampler_step_inpaint": (_i, [_vp, _i, _f, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp, _vp, _vp, _vp]),
     "osud_sample_loop_inpaint": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp, _u64, _vp, _vp]),
+    "osud_sample_repeat": (_i, [_vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _i, _vp, _u64, _vp, _vp]),
     "osud_dit_bind_grad": (_i, [_vp, C.c_char_p, _vp]),
     "osud_dit_refresh": (_i, [_vp, _vp]),
     "osud_dit_refresh_phases": (_i, [_vp, _i, _i, _vp]),
@@ -88,6 +89,8 @@ _SIGNATURES = {
     "osud_op_convert": (_i, [_i, _vp, _vp, _sz, _vp]),
     "osud_op_pack_h8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "osud_set_gemm_dynamic_tiles": (_i, [_i]),
+    "osud_set_option": (_i, [C.c_char_p, _i]),
+    "osud_get_option": (_i, [C.c_char_p, C.POINTER(_i)]),
     "osud_op_attention": (_i, [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "osud_op_wgrad": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "osud_op_wgrad8": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _sz, _vp, _vp, _vp]),
@@ -128,6 +131,33 @@ def check(rc: int):
     if rc == ERR_ARG:  # the reference raises AssertionError / IndexError on bad shapes
         raise AssertionError(msg)
     raise NativeError(f"libosud error {rc}: {msg}")
+
+
+def set_option(name: str, value: int) -> None:
+    """osud_set_option (include/osud.h): the library's one table of run-time switches; value -1 = the default."""
+    check(lib().osud_set_option(name.encode(), int(value)))
+
+
+def get_option(name: str) -> int:
+    v = C.c_int(0)
+    check(lib().osud_get_option(name.encode(), C.byref(v)))
+    return int(v.value)
+
+
+class option:
+    """`with _lib.option("sample_graph", 0): ...` -- an option set for a block and put back afterwards."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.prev = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.prev)
+        return False
 
 
 def ptr(t):

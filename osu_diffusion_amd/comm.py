@@ -5,7 +5,7 @@ data-parallel gradient exchange of train.py (reference: train.py:106 init_proces
 `NativeComm.from_torch_distributed()` bootstraps it inside a torchrun job: rank 0 makes the 128-byte unique id, torch's
 process group (any backend) carries it to the other ranks once, and from then on the heavy traffic -- the per-slice
 all-reduce / reduce-scatter / all-gather of the flat gradient and parameter arenas -- goes through libosud's RCCL calls on a
-side stream, overlapped with the backward phases.  `OSUD_NATIVE_COMM=1` makes `NativeTrainer` use it.
+side stream, overlapped with the backward phases.  `NativeTrainer(native_comm=True)` (train.py --native-comm) uses it.
 """
 from __future__ import annotations
 

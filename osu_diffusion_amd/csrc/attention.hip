@@ -842,8 +842,8 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
       set_error("attention: the bf16 tier is built for head_dim 64 and 72 (got %d); use the f32 tier", head_dim);
       return OSUD_ERR_UNSUPPORTED;
     }
-    const char* stream_env = getenv("OSUD_ATTN_FWD_STREAM");  // "0": the general kernel (A/B runs, tests)
-    if (head_dim == 64 && T == 128 && Tp == 128 && mask == nullptr && fp8_scale <= 0.f && ld_qk == 3 * D && !(stream_env && stream_env[0] == '0')) {
+    const bool stream_ok = opt(OPT_ATTN_FWD_KERNEL) == 0;  // osud_set_option("attn_fwd_kernel", 1 | 2): the general kernels on this shape too (tests)
+    if (head_dim == 64 && T == 128 && Tp == 128 && mask == nullptr && fp8_scale <= 0.f && ld_qk == 3 * D && stream_ok) {
       constexpr size_t slds = (size_t)8 * 128 * AttnTile<64>::RS + 8 * 2048 + 16;
       OSUD_BIG_LDS_ONCE(attn_fwd_stream_kernel<128>);
       const int cus = device_cus();
@@ -854,7 +854,7 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
       OSUD_HIP(hipGetLastError());
       return OSUD_OK;
     }
-    if (head_dim == 72 && T == 256 && Tp == 256 && mask == nullptr && fp8_scale <= 0.f && ld_qk == 3 * D && !(stream_env && stream_env[0] == '0')) {
+    if (head_dim == 72 && T == 256 && Tp == 256 && mask == nullptr && fp8_scale <= 0.f && ld_qk == 3 * D && stream_ok) {
       constexpr size_t lds72 = (size_t)4 * 128 * AttnTile<96>::RS + 8 * 16 * 208 + 16;
       OSUD_BIG_LDS_ONCE(attn_fwd_stream72_kernel<256>);
       const int cus = device_cus();
@@ -866,19 +866,16 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
       return OSUD_OK;
     }
     dim3 grid((Tp + 127) / 128, heads, N);
-    const char* dma_env = getenv("OSUD_ATTN_DMA");  // "0": the register-staged kernel (A/B runs, tests)
-    if (head_dim == 64 && fp8_scale <= 0.f && (mask == nullptr || T % 4 == 0) && T >= 4 && !(dma_env && dma_env[0] == '0')) {
+    const bool dma_ok = opt(OPT_ATTN_FWD_KERNEL) < 2;  // (2: the register-staged kernel)
+    if (head_dim == 64 && fp8_scale <= 0.f && (mask == nullptr || T % 4 == 0) && T >= 4 && dma_ok) {
       hipLaunchKernelGGL(attn_bf16_dma_kernel<false>, grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp, D, ld_qk,
                          scale * 1.4426950408889634f, mask ? kb_class : nullptr);
       OSUD_HIP(hipGetLastError());
       return OSUD_OK;
     }
-    static const bool one_block = [] { const char* e = getenv("OSUD_ATTN_KB"); return !(e && e[0] == '2'); }();
-    if (head_dim == 64 && one_block)
+    // (two key blocks per round trip -- attn_bf16_kernel<.., 2> -- measured slower, 4.41 vs 4.21 ms per sampling step: not instantiated)
+    if (head_dim == 64)
       hipLaunchKernelGGL((attn_bf16_kernel<64, 64, 1>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
-                         Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr, fp8_scale);
-    else if (head_dim == 64)
-      hipLaunchKernelGGL((attn_bf16_kernel<64, 64, 2>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
                          Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr, fp8_scale);
     else
       hipLaunchKernelGGL((attn_bf16_kernel<72, 96, 1>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,

@@ -133,7 +133,7 @@ template <int HD, int HDP, int NT>
 __global__ __launch_bounds__(NT) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ dO,
                                                             const bf16_t* __restrict__ O, const float* __restrict__ lse,
                                                             bf16_t* __restrict__ dqkv, int T, int D, float c1,
-                                                            float scale, float* __restrict__ dbias) {
+                                                            float scale) {
   using TL = AttnTile<HDP>;
   constexpr int DT = HDP / 32, CPR = TL::CPR, NWV = NT / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -143,26 +143,6 @@ __global__ __launch_bounds__(NT) void attn_bwd_bf16_kernel(const bf16_t* __restr
   char* Os = Vs + T * TL::RS;  // dO rows
   float* lse_s = reinterpret_cast<float*>(Os + T * TL::RS);
   float* del_s = lse_s + T;
-  // in_proj bias gradient riding along (dbias != nullptr): column sums of this head's dQ | dK | dV over the workgroup's
-  // tokens, [3][waves][HDP] partial sums here, one atomic per column at the end (replaces a separate pass over dqkv)
-  float* cs_s = del_s + T;
-  // sum over the 32 rows a wave owns: lane (frow, fhalf) holds row frow; after the butterfly every lane of a half holds the sum
-  auto colsum_store = [&](const f32x16 (&acc)[DT], int part) {
-    if (dbias == nullptr) return;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float v = acc[dt][r];
-        v += __shfl_xor(v, 1, 64);
-        v += __shfl_xor(v, 2, 64);
-        v += __shfl_xor(v, 4, 64);
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 16, 64);
-        if ((threadIdx.x & 31) == 0) cs_s[(part * NWV + (threadIdx.x >> 6)) * HDP + dt * 32 + 8 * (r >> 2) + 4 * ((threadIdx.x >> 5) & 1) + (r & 3)] = v;
-      }
-  };
-
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 31, fhalf = lane >> 5;
   const int h = blockIdx.x, n = blockIdx.y, H = gridDim.x;
@@ -206,25 +186,12 @@ __global__ __launch_bounds__(NT) void attn_bwd_bf16_kernel(const bf16_t* __restr
       f32x16 dq[DT];
       attn_bwd_pass_a<HDP>(Qs, Ks, Vs, Os, lse_s, del_s, T, own, lane, c1, scale, dq);
       attn_bwd_store<HD, HDP>(orow, dq, fhalf);
-      colsum_store(dq, 0);
     }
     {
       f32x16 dk[DT], dv[DT];
       attn_bwd_pass_b<HDP>(Qs, Ks, Vs, Os, lse_s, del_s, T, own, lane, c1, scale, dk, dv);
       attn_bwd_store<HD, HDP>(orow + D, dk, fhalf);
       attn_bwd_store<HD, HDP>(orow + 2 * D, dv, fhalf);
-      colsum_store(dk, 1);
-      colsum_store(dv, 2);
-    }
-  }
-  if (dbias != nullptr) {
-    __syncthreads();
-    const int nw = T / 32 < NWV ? T / 32 : NWV;  // waves that own rows
-    for (int i = tid; i < 3 * HD; i += NT) {
-      const int part = i / HD, d = i % HD;
-      float v = 0.f;
-      for (int w = 0; w < nw; ++w) v += cs_s[(part * NWV + w) * HDP + d];
-      atomicAdd(dbias + (size_t)part * D + h * HD + d, v);
     }
   }
 }
@@ -975,19 +942,19 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
   if (prec == OSUD_PREC_BF16) {
     // a workgroup keeps the whole sequence of one (sample, head) in LDS: 4 tiles of T rows (one wave per 32 rows)
     const int rs = head_dim == 64 ? AttnTile<64>::RS : AttnTile<96>::RS;
-    const size_t lds = (size_t)4 * T * rs + (size_t)2 * T * 4 + (size_t)3 * 8 * 96 * 4;  // + column-sum partials [3][<= 8 waves][HDP]
+    const size_t lds = (size_t)4 * T * rs + (size_t)2 * T * 4;
     if (head_dim != 64 && head_dim != 72) {
       set_error("attention backward (bf16 tier) is built for head_dim 64 and 72 (got %d)", head_dim);
       return OSUD_ERR_UNSUPPORTED;
     }
     const float c1t = scale * 1.4426950408889634f;
-    static const bool force_tiled = [] { const char* e = getenv("OSUD_ATTN_BWD_TILED"); return e && e[0] == '1'; }();
+    const int kernel_opt = opt(OPT_ATTN_BWD_KERNEL);  // osud_set_option("attn_bwd_kernel", 1: no streamed kernels | 2: the tiled kernel) -- tests
+    const bool force_tiled = kernel_opt == 2;
     if (T > 256 || lds > 160 * 1024 || force_tiled) {  // the sequence of a head does not fit the LDS: streamed variant
       OSUD_CHECK_ARG(delta_ws != nullptr, "attention backward: T=%d needs the delta workspace", T);
       const int rows = N * T * heads;
       const dim3 grid((T + 127) / 128, heads, N);
-      const char* s72_env = getenv("OSUD_ATTN_BWD_STREAM");
-      if (head_dim == 72 && T == 256 && !force_tiled && !(s72_env && s72_env[0] == '0')) {  // DiT-XL: persistent streamed kernel
+      if (head_dim == 72 && T == 256 && kernel_opt == 0) {  // DiT-XL: persistent streamed kernel
         hipLaunchKernelGGL((attn_delta_kernel<72>), dim3((rows + 255) / 256), dim3(256), 0, st, (const bf16_t*)dO, (const bf16_t*)O,
                            delta_ws, N, T, heads);
         constexpr size_t lds72 = (size_t)4 * 128 * AttnTile<96>::RS + 4 * 256 * 4 + 8 * 16 * 208 + 16;
@@ -998,7 +965,7 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
                            (const bf16_t*)dO, lse, delta_ws, (bf16_t*)dqkv, D, heads, items, c1t, scale,
                            (gemm_dynamic_tiles_on() && items > 2 * cus) ? gemm_ticket_slot() : nullptr);
         OSUD_HIP(hipGetLastError());
-        if (dbias != nullptr) OSUD_TRY(launch_colsum_bf16(dqkv, 3 * D, N * T, 3 * D, dbias, st));
+        if (dbias != nullptr) OSUD_TRY(launch_colsum_bf16(dqkv, 3 * D, N * T, 3 * D, dbias, st, bias_scratch, bias_scratch_elems));
         return OSUD_OK;
       }
       if (head_dim == 64) {
@@ -1013,15 +980,14 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
                            delta_ws, (bf16_t*)dqkv, T, D, c1t, scale);
       }
       OSUD_HIP(hipGetLastError());
-      if (dbias != nullptr) OSUD_TRY(launch_colsum_bf16(dqkv, 3 * D, N * T, 3 * D, dbias, st));  // streamed variant: separate pass
+      if (dbias != nullptr) OSUD_TRY(launch_colsum_bf16(dqkv, 3 * D, N * T, 3 * D, dbias, st, bias_scratch, bias_scratch_elems));  // streamed variant: separate pass
       return OSUD_OK;
     }
     OSUD_BIG_LDS_ONCE((attn_bwd_bf16_kernel<64, 64, 256>));
     OSUD_BIG_LDS_ONCE((attn_bwd_bf16_kernel<64, 64, 512>));
     OSUD_BIG_LDS_ONCE((attn_bwd_bf16_kernel<72, 96, 256>));
     const float c1 = scale * 1.4426950408889634f;
-    const char* stream_env = getenv("OSUD_ATTN_BWD_STREAM");  // "0": the one-workgroup-per-head kernel (A/B runs, tests)
-    const bool stream_on = !(stream_env && stream_env[0] == '0');
+    const bool stream_on = kernel_opt == 0;  // (else: the one-workgroup-per-head kernel)
     if (head_dim == 64 && T == 128 && stream_on) {
       constexpr size_t slds = (size_t)8 * 128 * AttnTile<64>::RS + 4 * 128 * 4 + 8 * 2048 + 16 + 2 * 3 * 4 * 64 * 4;
       const int cus = device_cus();
@@ -1039,23 +1005,21 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
       hipLaunchKernelGGL((attn_bwd_stream_kernel<128, false>), dim3(items < cus ? items : cus), dim3(512), slds, st, (const bf16_t*)qkv,
                          (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, D, heads, items, c1, scale, queue, nullptr);
       OSUD_HIP(hipGetLastError());
-      if (dbias != nullptr) OSUD_TRY(launch_colsum_bf16(dqkv, 3 * D, N * T, 3 * D, dbias, st));
+      if (dbias != nullptr) OSUD_TRY(launch_colsum_bf16(dqkv, 3 * D, N * T, 3 * D, dbias, st, bias_scratch, bias_scratch_elems));
       return OSUD_OK;
     }
-    // (OSUD_FUSE_BQKV=1: the bias gradient by lane butterflies inside these kernels -- measured slower than the column-sum pass)
-    static const bool butterfly = [] { const char* e = getenv("OSUD_FUSE_BQKV"); return e && e[0] == '1'; }();
-    float* kbias = butterfly ? dbias : nullptr;
+    // (the in_proj bias gradient by lane butterflies inside these kernels measured slower than the column-sum pass behind them)
     if (head_dim == 64 && T <= 128)
       hipLaunchKernelGGL((attn_bwd_bf16_kernel<64, 64, 256>), dim3(heads, N), dim3(256), lds, st, (const bf16_t*)qkv,
-                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale, kbias);
+                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale);
     else if (head_dim == 64)
       hipLaunchKernelGGL((attn_bwd_bf16_kernel<64, 64, 512>), dim3(heads, N), dim3(512), lds, st, (const bf16_t*)qkv,
-                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale, kbias);
+                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale);
     else
       hipLaunchKernelGGL((attn_bwd_bf16_kernel<72, 96, 256>), dim3(heads, N), dim3(256), lds, st, (const bf16_t*)qkv,
-                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale, kbias);
+                         (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, T, D, c1, scale);
     OSUD_HIP(hipGetLastError());
-    if (dbias != nullptr && !butterfly) OSUD_TRY(launch_colsum_bf16(dqkv, 3 * D, N * T, 3 * D, dbias, st));
+    if (dbias != nullptr) OSUD_TRY(launch_colsum_bf16(dqkv, 3 * D, N * T, 3 * D, dbias, st, bias_scratch, bias_scratch_elems));
     return OSUD_OK;
   } else {
     const dim3 grid(T / 64, heads, N);

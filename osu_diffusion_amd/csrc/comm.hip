@@ -12,6 +12,9 @@
 #include <string.h>
 #include <rccl/rccl.h>
 
+#include <mutex>
+#include <string>
+
 #include "common.h"
 
 struct osud_comm {
@@ -35,43 +38,61 @@ struct Rccl {
   decltype(&ncclGetVersion) GetVersion = nullptr;
 };
 
-Rccl* rccl() {
-  static Rccl r;
-  static bool tried = false;
-  if (tried) return r.lib ? &r : nullptr;
-  tried = true;
-  const char* override_path = getenv("OSUD_RCCL_LIB");
-  const char* names[] = {override_path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-  for (const char* n : names) {
-    if (!n) continue;
-    r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-    if (r.lib) break;
-  }
-  if (!r.lib) return nullptr;
-#define OSUD_SYM(field, name)                                        \
-  r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name)); \
-  if (!r.field) {                                                    \
-    r.lib = nullptr;                                                 \
-    return nullptr;                                                  \
-  }
-  OSUD_SYM(GetUniqueId, "ncclGetUniqueId")
-  OSUD_SYM(CommInitRank, "ncclCommInitRank")
-  OSUD_SYM(CommDestroy, "ncclCommDestroy")
-  OSUD_SYM(AllReduce, "ncclAllReduce")
-  OSUD_SYM(Broadcast, "ncclBroadcast")
-  OSUD_SYM(ReduceScatter, "ncclReduceScatter")
-  OSUD_SYM(AllGather, "ncclAllGather")
-  OSUD_SYM(GetErrorString, "ncclGetErrorString")
-  OSUD_SYM(GetVersion, "ncclGetVersion")
+// Loaded once (std::call_once: the first collective may come from any thread); why a load failed is kept for the error message
+// (dlerror() hands its string out once and then forgets it).
+struct RcclLoad {
+  Rccl r;
+  std::string why;
+  bool ok = false;
+};
+
+RcclLoad& rccl_load() {
+  static RcclLoad L;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    Rccl& r = L.r;
+    const char* override_path = getenv("OSUD_RCCL_LIB");
+    const char* names[] = {override_path, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+      if (!n) continue;
+      r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+      const char* e = dlerror();
+      L.why += std::string(L.why.empty() ? "" : "; ") + n + ": " + (e ? e : "dlopen failed");
+    }
+    if (!r.lib) return;
+#define OSUD_SYM(field, name)                                          \
+    r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, name)); \
+    if (!r.field) {                                                    \
+      const char* e = dlerror();                                       \
+      L.why = std::string("symbol ") + name + ": " + (e ? e : "missing"); \
+      return;                                                          \
+    }
+    OSUD_SYM(GetUniqueId, "ncclGetUniqueId")
+    OSUD_SYM(CommInitRank, "ncclCommInitRank")
+    OSUD_SYM(CommDestroy, "ncclCommDestroy")
+    OSUD_SYM(AllReduce, "ncclAllReduce")
+    OSUD_SYM(Broadcast, "ncclBroadcast")
+    OSUD_SYM(ReduceScatter, "ncclReduceScatter")
+    OSUD_SYM(AllGather, "ncclAllGather")
+    OSUD_SYM(GetErrorString, "ncclGetErrorString")
+    OSUD_SYM(GetVersion, "ncclGetVersion")
 #undef OSUD_SYM
-  return &r;
+    L.ok = true;
+  });
+  return L;
+}
+
+Rccl* rccl() {
+  RcclLoad& L = rccl_load();
+  return L.ok ? &L.r : nullptr;
 }
 
 int need(Rccl** out) {
   *out = rccl();
   if (!*out) {
-    set_error("osud_comm: librccl could not be loaded (tried OSUD_RCCL_LIB, librccl.so.1, librccl.so, /opt/rocm/lib/librccl.so.1): %s",
-              dlerror() ? dlerror() : "symbol missing");
+    set_error("osud_comm: librccl could not be loaded (OSUD_RCCL_LIB, librccl.so.1, librccl.so, /opt/rocm/lib/librccl.so.1): %s",
+              rccl_load().why.c_str());
     return OSUD_ERR_UNSUPPORTED;
   }
   return OSUD_OK;

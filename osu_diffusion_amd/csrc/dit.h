@@ -56,6 +56,10 @@ struct BwdWs {
   float *dhA = nullptr, *dhB = nullptr, *du = nullptr, *dada = nullptr, *dWada = nullptr, *dbada = nullptr, *dsb = nullptr,
         *db = nullptr, *dth = nullptr, *dWe = nullptr, *splitk = nullptr, *attn_delta = nullptr /* [N][H][Tp] */;
   size_t splitk_elems = 0;
+  // deterministic reductions (kernels.h): per-workgroup partial rows of the LayerNorm / gate / final-layer backward kernels, one slot
+  // per launch of a backward pass ([2 L + 2][M / 64][6 D + 64]), and scratch for the row blocks' shares of a column sum (main / side stream)
+  float *rowpart = nullptr, *colpart = nullptr, *colpart2 = nullptr;
+  size_t colpart_elems = 0;
   // bf16 tier: the weight gradients of a block run on a side stream next to the block's data-gradient chain (train.hip): their own
   // split-K slab area, the stream, and the events that hand the operands over {fc2 dgrad done, LN2 backward + out_proj dgrad done,
   // attention backward done, side stream drained}
@@ -227,10 +231,9 @@ inline int gemm8(osud_dit* m, int epi, const void* Y, const void* X, int My, int
 // fp8 training, live steps (`live`: this step's GEMMs run on e4m3 operands): true when EVERY consumer of the block's GEMM operands
 // -- forward products, data gradients and weight gradients (train.hip: the `weight_grad8` conditions) -- reads their e4m3 twins, so
 // that the bf16 forms of u1 / u2 / gelu(z1) / dz1 / the branch gradients are not written at all (0.9 GB per DiT-XL block and step).
-// OSUD_F8_TWINS_ONLY=0 keeps them (re-measurement).
+// osud_set_option("f8_twins_only", 0) keeps them (a test holds the two settings to 1e-7).
 inline bool f8_twins_only(const osud_dit* m, bool live, int Mp) {
-  const char* e = getenv("OSUD_F8_TWINS_ONLY");  // (read per call: a test switches it inside one process)
-  const bool off = e && e[0] == '0';
+  const bool off = opt(OPT_F8_TWINS_ONLY) == 0;  // (read per call: a test switches it inside one process)
   return !off && live && m->prec == OSUD_PREC_BF16 && Mp % 128 == 0 && (size_t)(Mp / 32) * 4 * m->D <= m->bw.splitk_elems;
 }
 

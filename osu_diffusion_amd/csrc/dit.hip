@@ -134,6 +134,13 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
     b.splitk_elems = (size_t)16 * 4 * D * D;  // up to 16 partial slabs of the largest weight gradient
     OSUD_TRY(dev_alloc(W, &b.splitk, b.splitk_elems * 4, false));
     OSUD_TRY(dev_alloc(W, &b.splitk2, b.splitk_elems * 4, false));
+    OSUD_TRY(dev_alloc(W, &b.rowpart, (size_t)(2 * m->L + 2) * (Mp / 64) * (6 * D + 64) * 4, false));
+    {  // the widest column sum: a transpose's (rows / 64) shares of 4 D (or the padded first-layer width) columns, or (Np / 64) x AC
+      const size_t a = (size_t)(Mp / 64) * tcols, c = (size_t)(Np / 64) * AC;
+      b.colpart_elems = a > c ? a : c;
+      OSUD_TRY(dev_alloc(W, &b.colpart, b.colpart_elems * 4, false));
+      OSUD_TRY(dev_alloc(W, &b.colpart2, b.colpart_elems * 4, false));
+    }
     OSUD_TRY(dev_alloc(W, &b.attn_delta, (size_t)nN * m->H * Tp * 4));
     OSUD_TRY(dev_alloc(W, &b.seg_tbl, 32 * sizeof(float*)));
     for (float*& q : b.seg_tbl_host) q = nullptr;
@@ -402,11 +409,10 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   m->x3 = m->prec == OSUD_PREC_BF16X3;  // every TE matrix is a plane pair [hi | lo] (common.h): esz = 4 bytes per logical element
   m->esz = (int)elem_size(m->prec);
   m->Kp = round_up(cfg->in_channels * 128 + 128 + cfg->context, 128);  // 528 -> 640
-  {  // OSUD_SPLIT_FIRST=0: plain bf16 first linear (A/B measurements of the fast tier's deviation)
-    const char* e = getenv("OSUD_SPLIT_FIRST");
+  {  // osud_set_option("split_first", 0) before the handle is created: plain bf16 first linear (A/B measurements of the fast tier's deviation)
     // (embed_kernel stages 16 rows of [hi | lo | hi] in LDS: 16 * Kp * 6 bytes must fit 64 KiB, i.e. context sizes up to 256;
     //  wider contexts keep the plain bf16 first linear)
-    m->split_first = (m->prec == OSUD_PREC_BF16 || m->prec == OSUD_PREC_F16) && !(e && e[0] == '0') && (size_t)16 * m->Kp * 6 <= 64 * 1024;
+    m->split_first = (m->prec == OSUD_PREC_BF16 || m->prec == OSUD_PREC_F16) && opt(OPT_SPLIT_FIRST) != 0 && (size_t)16 * m->Kp * 6 <= 64 * 1024;
   }
   m->Ke = m->split_first ? 3 * m->Kp : m->Kp;
   m->ada_cols = 6 * m->D * m->L + 2 * m->D;
@@ -651,44 +657,64 @@ extern "C" int osud_sample_loop(osud_dit* m, const osud_sched* s, int mode, floa
                                   noise, seed, nullptr, stream);
 }
 
+// n_steps sampler steps from schedule index first_step, the index going down by `dec` per step (1: a sampling loop; 0: the same
+// step again and again)
+static int sample_steps(osud_dit* m, const osud_sched* s, int mode, float eta, float* x, const float* o, const float* c, const int64_t* y,
+                        const uint8_t* attn_mask, int N, int T, float cfg_scale, int clip, int first_step, int n_steps, int dec,
+                        const float* noise, uint64_t seed, const osud_inpaint* inpaint_in, osud_stream stream);
+
 extern "C" int osud_sample_loop_inpaint(osud_dit* m, const osud_sched* s, int mode, float eta, float* x, const float* o,
                                         const float* c, const int64_t* y, const uint8_t* attn_mask, int N, int T,
                                         float cfg_scale, int clip, int first_step, int last_step, const float* noise,
                                         uint64_t seed, const osud_inpaint* inpaint_in, osud_stream stream) {
+  OSUD_CHECK_ARG(s != nullptr, "sample_loop: null argument");
+  OSUD_CHECK_ARG(first_step < osud_sched_num_timesteps(s) && last_step >= 0 && first_step >= last_step,
+                 "sample_loop: steps %d..%d outside the schedule's %d steps", first_step, last_step, osud_sched_num_timesteps(s));
+  return sample_steps(m, s, mode, eta, x, o, c, y, attn_mask, N, T, cfg_scale, clip, first_step, first_step - last_step + 1, 1, noise, seed,
+                      inpaint_in, stream);
+}
+
+// The refine pass of sample.py:186-205 -- `refine_iters` calls of p_sample at t = 0 on the weights of a second checkpoint -- and in
+// general `iters` sampler steps at ONE schedule index: the captured step of osud_sample_loop replayed with a step counter that
+// stands still (the step index lives in device memory, so it is the very same graph).
+extern "C" int osud_sample_repeat(osud_dit* m, const osud_sched* s, int mode, float eta, float* x, const float* o, const float* c,
+                                  const int64_t* y, const uint8_t* attn_mask, int N, int T, float cfg_scale, int clip, int step,
+                                  int iters, const float* noise, uint64_t seed, const osud_inpaint* inpaint, osud_stream stream) {
+  OSUD_CHECK_ARG(s != nullptr, "sample_repeat: null argument");
+  OSUD_CHECK_ARG(step >= 0 && step < osud_sched_num_timesteps(s) && iters >= 0, "sample_repeat: step %d (of %d), %d iterations", step,
+                 osud_sched_num_timesteps(s), iters);
+  if (iters == 0) return OSUD_OK;
+  return sample_steps(m, s, mode, eta, x, o, c, y, attn_mask, N, T, cfg_scale, clip, step, iters, 0, noise, seed, inpaint, stream);
+}
+
+static int sample_steps(osud_dit* m, const osud_sched* s, int mode, float eta, float* x, const float* o, const float* c, const int64_t* y,
+                        const uint8_t* attn_mask, int N, int T, float cfg_scale, int clip, int first_step, int n_steps, int dec,
+                        const float* noise, uint64_t seed, const osud_inpaint* inpaint_in, osud_stream stream) {
   OSUD_CHECK_ARG(m && s && x && o && c && y, "sample_loop: null argument");
   OSUD_CHECK_ARG(inpaint_in == nullptr || (inpaint_in->keep && inpaint_in->known),
                  "sample_loop: in-painting needs both the keep mask and the known values");
   const osud_inpaint held = inpaint_in ? *inpaint_in : osud_inpaint{nullptr, nullptr};  // the caller's struct may be a temporary
   const osud_inpaint* inpaint = inpaint_in ? &held : nullptr;
-  const int nt = osud_sched_num_timesteps(s);
-  OSUD_CHECK_ARG(first_step < nt && last_step >= 0 && first_step >= last_step,
-                 "sample_loop: steps %d..%d outside the schedule's %d steps", first_step, last_step, nt);
   hipStream_t st = (hipStream_t)stream;
   OSUD_TRY(sched_upload(const_cast<osud_sched*>(s)));
   OSUD_TRY(dit_ensure_ws(m, N, T, m->training));
-  OSUD_TRY(launch_step_init(m->step_state, first_step, seed, st));  // the seed travels in device memory, not in the graph
-  const int n_steps = first_step - last_step + 1;
+  OSUD_TRY(launch_step_init(m->step_state, first_step, seed, st, dec));  // the seed travels in device memory, not in the graph
   // o and c do not change over the steps of a loop: their share of the first linear is computed here, once (OSUD_EMBED_CONST=0: off)
   struct ConstGuard {
     osud_dit* m;
     ~ConstGuard() { m->embed_const_on = m->tvec_table_on = false; }
   } const_guard{m};
-  {
-    const char* tt = getenv("OSUD_TVEC_TABLE");
-    if (!(tt && tt[0] == '0')) {
-      OSUD_TRY(tvec_table_prepare(m, s, st));
-      m->tvec_table_on = true;
-    }
+  if (opt(OPT_TVEC_TABLE)) {
+    OSUD_TRY(tvec_table_prepare(m, s, st));
+    m->tvec_table_on = true;
   }
   {
-    const char* ec = getenv("OSUD_EMBED_CONST");
-    if ((m->split_first || m->x3) && m->h0c != nullptr && !(ec && ec[0] == '0')) {
+    if ((m->split_first || m->x3) && m->h0c != nullptr && opt(OPT_EMBED_CONST)) {
       OSUD_TRY(embed_const_prepare(m, x, o, c, N, T, cfg_scale >= 0.f, st));
       m->embed_const_on = true;  // (consulted while the step is captured / run eagerly; replays of the graph read h0c)
     }
   }
-  const char* ng = getenv("OSUD_NO_GRAPH");
-  if (ng && ng[0] == '1') {
+  if (!opt(OPT_SAMPLE_GRAPH)) {  // eager launches: the same kernels on the same arguments (tests hold the two to bit equality)
     for (int k = 0; k < n_steps; ++k)
       OSUD_TRY(loop_body(m, s, mode, eta, x, o, c, y, attn_mask, N, T, cfg_scale, clip, noise, seed, inpaint, st));
     return OSUD_OK;
@@ -759,6 +785,8 @@ extern "C" int osud_set_gemm_dynamic_tiles(int on) {
   gemm_set_dynamic_tiles(on);
   return OSUD_OK;
 }
+extern "C" int osud_set_option(const char* name, int value) { return opt_set(name, value); }
+extern "C" int osud_get_option(const char* name, int* value) { return opt_get(name, value); }
 
 // ---- op-level exports ---------------------------------------------------------------------
 extern "C" int osud_op_gemm(int precision, int epilogue, const void* Y, int ldy, const void* X, int ldx, int My, int Nx,

@@ -66,12 +66,31 @@ struct GemmP {
   float* const* seg_out;  //   (DEVICE table) -- one product whose row panels land in different tensors: the adaLN weight gradients of all blocks
   unsigned* sched;    // set by the launcher for multi-round launches: {ticket, done} counters of the dynamic tile queue
   int exp_delay;   // experiments only (-DOSUD_GEMM_EXP): odd workgroup groups start this many 100 MHz ticks late
-  int tile_order;  // 0/1 = plain x-fastest runs per XCD (default), 2 = banded per XCD (fewer weight re-reads, not faster)
+  int tile_order;  // experiments only (-DOSUD_GEMM_EXP / -DOSUD_GEMM_TIMING builds): flag bits of the timing variants
 };
 
 int launch_gemm(int prec, int epi, const GemmP& p, hipStream_t st);
 bool gemm_dynamic_tiles_on();            // the effective setting
-void gemm_set_dynamic_tiles(int on);  // 1 / 0, -1 = follow the OSUD_GEMM_DYNAMIC environment variable (default off)
+void gemm_set_dynamic_tiles(int on);  // 1 / 0 (default off; -1 = back to the default)
+
+// Process-wide options (include/osud.h: osud_set_option).  Everything that selects between two BUILT AND TESTED forms of the same
+// computation lives here -- one table, one setter, one getter; there are no other run-time switches in the library.
+enum Opt {
+  OPT_WGRAD_SIDE_STREAM = 0,  // 1: a block's weight gradients on the library's side stream next to its data-gradient chain (train.hip)
+  OPT_SAMPLE_GRAPH,           // 1: osud_sample_loop replays one captured hipGraph per step; 0: eager launches (same bits)
+  OPT_EMBED_CONST,            // 1: sampler loops multiply the offset / context part of the first linear once per loop
+  OPT_TVEC_TABLE,             // 1: sampler loops make the timestep-embedding MLP once per loop for every schedule index
+  OPT_SPLIT_FIRST,            // 1: bf16 / fp16 tiers keep the first linear at fp32 accuracy ([hi | lo | hi] rows); read at osud_dit_create
+  OPT_ATTN_FWD_KERNEL,        // 0 auto; 1: never the streamed T = 128 kernel; 2: neither that nor the LDS-DMA kernel (register-staged)
+  OPT_ATTN_BWD_KERNEL,        // 0 auto; 1: never the streamed kernels (one workgroup per head / tiled); 2: the tiled kernel
+  OPT_GEMM_TILE,              // 0 auto; 64 / 128 / 192 / 256 / 1192 (192 x 256) / 1256 (128 x 256): force a tile geometry where it divides
+  OPT_F8_TWINS_ONLY,          // 1: fp8 training writes only the e4m3 forms of tensors whose bf16 forms have no reader
+  OPT_DEBUG_SYNC,             // 1: synchronise and name every stage of the backward pass (fault triage)
+  OPT_COUNT
+};
+int opt(Opt o);
+int opt_set(const char* name, int value);   // OSUD_OK / OSUD_ERR_ARG (unknown name or value out of range)
+int opt_get(const char* name, int* value);
 // one 16-word counter set {[0] tickets, [8] finished workgroups} of the same pool, for other persistent kernels that draw their
 // work items from a queue while the GPU is shared (the attention kernels); zero on entry, re-armed by the kernel's last workgroup
 unsigned* gemm_ticket_slot();

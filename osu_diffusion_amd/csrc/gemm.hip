@@ -1,8 +1,12 @@
 // Host side of the GEMM: argument checks, dispatch to the per-element-type translation units, the process-wide state of the
 // dynamic tile queues, and the split-K combine.  See gemm.h for the design, gemm_kernel.h for the kernel.  gfx950 only.
 #include <atomic>
+#include <mutex>
+#include <string>
 
+#include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "gemm.h"
 
@@ -44,7 +48,7 @@ int num_cus() {
 constexpr int kSchedSlots = 256;
 // Off by default: alone on the GPU the queue costs 0.7 % of a training step (a one-off drain for the first ticket, less regular
 // tile order).  Data-parallel training switches it on (osud_set_gemm_dynamic_tiles), where collectives share the compute units.
-std::atomic<int> g_dynamic_tiles{-1};  // -1: follow OSUD_GEMM_DYNAMIC
+std::atomic<int> g_dynamic_tiles{0};
 unsigned* g_sched_pool[kMaxDevices] = {};
 int gemm_sched_init_impl() {
   const int dev = cur_device();
@@ -63,12 +67,80 @@ unsigned* sched_slot() {
 
 }  // namespace
 
-// OSUD_GEMM_CUS=<n> (experiments): the persistent GEMM / weight-gradient kernels use n workgroups instead of one per compute unit
-int gemm_num_cus() {
-  static const int cap = [] { const char* e = getenv("OSUD_GEMM_CUS"); return e ? atoi(e) : 0; }();
-  const int n = num_cus();
-  return cap > 0 && cap < n ? cap : n;
+// ---- options ------------------------------------------------------------------------------------------------------------
+namespace {
+struct OptDef {
+  const char* name;
+  int def, lo, hi;
+};
+constexpr OptDef kOpts[OPT_COUNT] = {
+    {"wgrad_side_stream", 1, 0, 1}, {"sample_graph", 1, 0, 1},    {"embed_const", 1, 0, 1},  {"tvec_table", 1, 0, 1},
+    {"split_first", 1, 0, 1},       {"attn_fwd_kernel", 0, 0, 2}, {"attn_bwd_kernel", 0, 0, 2}, {"gemm_tile", 0, 0, 1256},
+    {"f8_twins_only", 1, 0, 1},     {"debug_sync", 0, 0, 1},
+};
+std::atomic<int> g_opt[OPT_COUNT];
+// The defaults, overridden ONCE by the environment variable OSUD_OPTIONS="name=value,name=value" (for command-line A/B runs of an
+// unmodified script; tests and hosts call osud_set_option).  Unknown names there are an error on stderr, not silently ignored.
+void opt_init() {
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (int i = 0; i < OPT_COUNT; ++i) g_opt[i].store(kOpts[i].def, std::memory_order_relaxed);
+    const char* e = getenv("OSUD_OPTIONS");
+    if (!e) return;
+    std::string s(e);
+    size_t pos = 0;
+    while (pos < s.size()) {
+      size_t end = s.find(',', pos);
+      if (end == std::string::npos) end = s.size();
+      const std::string item = s.substr(pos, end - pos);
+      const size_t eq = item.find('=');
+      bool ok = false;
+      if (eq != std::string::npos)
+        for (int i = 0; i < OPT_COUNT; ++i)
+          if (item.substr(0, eq) == kOpts[i].name) {
+            const int v = atoi(item.c_str() + eq + 1);
+            if (v >= kOpts[i].lo && v <= kOpts[i].hi) {
+              g_opt[i].store(v, std::memory_order_relaxed);
+              ok = true;
+            }
+          }
+      if (!ok && !item.empty()) fprintf(stderr, "[osud] OSUD_OPTIONS: ignoring '%s' (unknown option or value out of range)\n", item.c_str());
+      pos = end + 1;
+    }
+  });
 }
+}  // namespace
+
+int opt(Opt o) {
+  opt_init();
+  return g_opt[o].load(std::memory_order_relaxed);
+}
+int opt_set(const char* name, int value) {
+  opt_init();
+  OSUD_CHECK_ARG(name != nullptr, "set_option: null name");
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (strcmp(name, kOpts[i].name) == 0) {
+      OSUD_CHECK_ARG(value == -1 || (value >= kOpts[i].lo && value <= kOpts[i].hi), "set_option: %s takes %d..%d (or -1 = default), got %d", name,
+                     kOpts[i].lo, kOpts[i].hi, value);
+      g_opt[i].store(value == -1 ? kOpts[i].def : value, std::memory_order_relaxed);
+      return OSUD_OK;
+    }
+  set_error("set_option: unknown option '%s'", name);
+  return OSUD_ERR_ARG;
+}
+int opt_get(const char* name, int* value) {
+  opt_init();
+  OSUD_CHECK_ARG(name != nullptr && value != nullptr, "get_option: null argument");
+  for (int i = 0; i < OPT_COUNT; ++i)
+    if (strcmp(name, kOpts[i].name) == 0) {
+      *value = g_opt[i].load(std::memory_order_relaxed);
+      return OSUD_OK;
+    }
+  set_error("get_option: unknown option '%s'", name);
+  return OSUD_ERR_ARG;
+}
+
+int gemm_num_cus() { return num_cus(); }
 unsigned* gemm_sched_slot() { return sched_slot(); }
 bool gemm_dynamic_tiles_wanted() { return gemm_dynamic_tiles_on(); }
 
@@ -77,12 +149,8 @@ unsigned* gemm_ticket_slot() {
   if (!g_sched_pool[cur_device()] && gemm_sched_init_impl() != OSUD_OK) return nullptr;
   return sched_slot();
 }
-bool gemm_dynamic_tiles_on() {
-  static const bool dyn_env = [] { const char* e = getenv("OSUD_GEMM_DYNAMIC"); return e && e[0] == '1'; }();
-  const int v = g_dynamic_tiles.load(std::memory_order_relaxed);
-  return v >= 0 ? v != 0 : dyn_env;
-}
-void gemm_set_dynamic_tiles(int on) { g_dynamic_tiles.store(on < 0 ? -1 : (on != 0), std::memory_order_relaxed); }
+bool gemm_dynamic_tiles_on() { return g_dynamic_tiles.load(std::memory_order_relaxed) != 0; }
+void gemm_set_dynamic_tiles(int on) { g_dynamic_tiles.store(on > 0 ? 1 : 0, std::memory_order_relaxed); }
 
 int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
   if (!g_sched_pool[cur_device()]) {  // normally done at handle creation; never reached while a stream is being captured
@@ -90,13 +158,6 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
     if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) OSUD_TRY(gemm_sched_init_impl());
   }
   GemmP p = p_in;
-  {
-    static const int order = [] { const char* e = getenv("OSUD_GEMM_ORDER"); return e ? atoi(e) : 0; }();
-    if (order) p.tile_order = order;
-    static const int delay = [] { const char* e = getenv("OSUD_GEMM_DELAY"); return e ? atoi(e) : 0; }();
-    p.exp_delay = delay;
-
-  }
   const int esz = (int)elem_size(prec);
   OSUD_CHECK_ARG(p.My > 0 && p.Nx > 0 && p.K > 0 && p.My % 128 == 0 && p.Nx % 128 == 0 && (p.K * esz) % SLAB == 0,
                  "gemm: My=%d Nx=%d must be multiples of 128 and K=%d a multiple of %d", p.My, p.Nx, p.K, SLAB / esz);

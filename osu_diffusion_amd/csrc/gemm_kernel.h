@@ -14,11 +14,11 @@ namespace osud {
 // host state shared by the translation units (defined in gemm.hip)
 int gemm_num_cus();
 unsigned* gemm_sched_slot();       // next counter set of the dynamic tile queue, nullptr before gemm_sched_init()
-bool gemm_dynamic_tiles_wanted();  // osud_set_gemm_dynamic_tiles / OSUD_GEMM_DYNAMIC
+bool gemm_dynamic_tiles_wanted();  // osud_set_gemm_dynamic_tiles
 
 namespace {
 
-constexpr int SLAB = 128;  // bytes of K per pipeline stage row (SB = 64: half slabs, a deeper ring -- see Geo)
+constexpr int SLAB = 128;  // bytes of K per pipeline stage row
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
@@ -95,7 +95,8 @@ template <int RY, int RX> struct FragSet {
   u32x4 y[RY], x[RX];
 };
 // ya/xa: this lane's LDS byte address of (first Y / X row of the wave, k-substep s) in the current stage
-template <int RY, int RX, int SB = SLAB> __device__ __forceinline__ void read_set(FragSet<RY, RX>& f, uint32_t ya, uint32_t xa) {
+template <int RY, int RX> __device__ __forceinline__ void read_set(FragSet<RY, RX>& f, uint32_t ya, uint32_t xa) {
+  constexpr int SB = SLAB;
   f.y[0] = ds_read16<0>(ya);
   if constexpr (RY >= 2) f.y[1] = ds_read16<32 * SB>(ya);
   if constexpr (RY >= 3) f.y[2] = ds_read16<64 * SB>(ya);
@@ -124,27 +125,10 @@ template <int N> __device__ __forceinline__ void wait_lgkm() {
 // flight under the MFMAs of sub-step s (LDS returns in order, so lgkmcnt(R) == "all but the newest R").
 // experiments (-DOSUD_EXP_MODE=<flags>, one build per variant: run-time flags here cost registers and spill): 64 = fragment reads without the MFMAs, 128 = no
 // LDS-DMA (stale stages), 256 = MFMAs on stale fragments (no reads), 512 = neither reads nor MFMAs (LDS-DMA only)
-template <typename TE, int RY, int RX, int SB = SLAB>
+template <typename TE, int RY, int RX>
 __device__ __forceinline__ void compute_slab(f32x16 (&acc)[RY][RX], const uint32_t (&ya)[4], const uint32_t (&xa)[4],
                                              uint32_t so) {
   FragSet<RY, RX> f0, f1;
-  if constexpr (SB == 64) {  // half slab: two sub-steps (bf16 / f32) or one K = 64 instruction (fp8)
-    read_set<RY, RX, SB>(f0, ya[0] + so, xa[0] + so);
-    read_set<RY, RX, SB>(f1, ya[1] + so, xa[1] + so);
-    if constexpr (sizeof(TE) == 1) {
-      wait_lgkm<0>();
-#pragma unroll
-      for (int i = 0; i < RY; ++i)
-#pragma unroll
-        for (int j = 0; j < RX; ++j) mma_f8(acc[i][j], f0.x[j], f1.x[j], f0.y[i], f1.y[i]);
-    } else {
-      wait_lgkm<RY + RX>();
-      mma_set<TE, RY, RX>(acc, f0);
-      wait_lgkm<0>();
-      mma_set<TE, RY, RX>(acc, f1);
-    }
-    return;
-  }
 #ifdef OSUD_EXP_MODE
   constexpr int g_exp_flags = OSUD_EXP_MODE;
   if (sizeof(TE) == 2 && (g_exp_flags & 512)) return;  // LDS-DMA only
@@ -266,26 +250,26 @@ __device__ __forceinline__ void compute_slab_h8(f32x16 (&acc)[RY][RX], const uin
 }
 
 // Tile geometry: WY x WX waves, each wave (RY*32) x (RX*32) outputs: BM = WY*RY*32 rows of Y, BN = WX*RX*32 rows of X.
-// A stage holds one K slab of both operands as ONE (BM+BN)-row x 128-byte image.
-// SB = bytes of K per stage row.  128: the classic form (two 64 KiB stages for the 256-wide tiles: ONE slab in flight while one is
-// consumed).  64: half slabs in a ring of four with the epilogue patches in their own 32 KiB behind the ring -- three half slabs
-// in flight, because the component experiments (tools/gemm_exp.py) showed the LDS-DMA fill of a 64 KiB slab to take ~2800 cycles
-// issue-to-landed against 2048 cycles of MFMA work on it: with one slab of lead the fill IS the critical path.
-template <int WY, int WX, int RY, int RX, int SB = SLAB> struct Geo {
+// A stage holds one K slab of both operands as ONE (BM+BN)-row x 128-byte image (two 64 KiB stages for the 256-wide tiles: one slab
+// in flight while one is consumed).  (Built, measured slower and removed: 64-byte half slabs in a ring of four with the epilogue
+// patches behind the ring -- fc1 183 vs 168 us, the doubled barrier count costs more than the extra lead buys; a role-split main
+// loop in which the two waves of a SIMD alternate between MFMAs and LDS-DMA issue -- equal time at a proportionally lower clock.
+// DESIGN.md section 4 has both write-ups.)
+template <int WY, int WX, int RY, int RX> struct Geo {
+  static constexpr int SB = SLAB;
   static constexpr int BM = WY * RY * 32, BN = WX * RX * 32, NW = WY * WX, NT = 64 * NW;
   static constexpr int STAGE = (BM + BN) * SB;
   static constexpr int RPP = 1024 / SB;        // rows per 1 KiB LDS-DMA piece
-  static constexpr bool PATCH_OUT = SB == 64;  // epilogue patches outside the ring
   // One persistent workgroup per CU owns all 160 KiB.  (Tried and dropped: two 4-wave workgroups per CU on 128x192 tiles so that
   // one's epilogue runs under the other's main loop, 25-45 % slower; four waves of 128x128 with one wave per SIMD and 512
   // registers, 20-60 % slower under hipcc's scheduling.)
   static constexpr int WGS = 1;
   static constexpr int LDS_MAX = 160 * 1024 / WGS;
-  static constexpr int RING_MAX = PATCH_OUT ? LDS_MAX - NW * 4096 : LDS_MAX;
+  static constexpr int RING_MAX = LDS_MAX;
   static constexpr int NSTAGE = STAGE * 5 <= RING_MAX ? 5 : (STAGE * 4 <= RING_MAX ? 4 : (STAGE * 3 <= RING_MAX ? 3 : 2));
   static constexpr int PIECES = STAGE / 1024, PPW = PIECES / NW;  // 1 KiB LDS-DMA pieces per slab, per wave
   static_assert(PIECES % NW == 0 && BM % RPP == 0, "pieces must divide evenly over the waves and not straddle the operands");
-  static_assert(NSTAGE * STAGE <= RING_MAX && (PATCH_OUT || NW * 4096 <= STAGE), "stage ring must fit the LDS; the epilogue patches live in one stage or behind the ring");
+  static_assert(NSTAGE * STAGE <= RING_MAX && NW * 4096 <= STAGE, "stage ring must fit the LDS; the epilogue patches live in the free stage");
 };
 
 // HBM -> LDS: this wave's share of one K slab (PPW pieces of 8 rows x 128 bytes).  The 16-byte chunk index
@@ -348,13 +332,10 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else static_assert(N < 0, "add the literal");
 }
 
-// ROLES (8-wave geometries, static tile schedule): the two waves of every SIMD alternate between feeding the matrix pipe and
-// issuing the LDS-DMA of the next slab instead of doing both in lock step -- see the main loop.
-template <typename TE, int EPI, int WY, int WX, int RY, int RX, bool ROLES, int SB = SLAB>
-__global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(GemmP p) {
-  using G = Geo<WY, WX, RY, RX, SB>;
-  static_assert(!ROLES || SB == SLAB, "the role split is built on the two-stage 128-byte form");
-  constexpr int BN = G::BN;
+template <typename TE, int EPI, int WY, int WX, int RY, int RX>
+__global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p) {
+  using G = Geo<WY, WX, RY, RX>;
+  constexpr int BN = G::BN, SB = SLAB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr bool FAST = !std::is_same<TE, float>::value;
   constexpr bool kF8 = sizeof(TE) == 1;  // fp8 operands: outputs are bf16 (EPI_BIAS_TE), fp8 (EPI_BIAS_GELU_TE) or fp32
@@ -363,7 +344,6 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
   constexpr bool kH8 = std::is_same<TE, h8_t>::value;
   using TO = typename std::conditional<kF8, typename std::conditional<EPI == EPI_BIAS_GELU_TE, fp8_t, bf16_t>::type,
                                        typename std::conditional<kH8 && EPI == EPI_BIAS_TE, x3_t, TE>::type>::type;
-  static_assert(!kH8 || SB == SLAB, "the fp16 + e4m3 form is built on 128-byte stage rows");
   constexpr bool kGelu = EPI == EPI_BIAS_GELU_TE || EPI == EPI_BIAS_GELU_BF;  // _BF: fp8 operands with bf16 outputs (training)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -376,7 +356,6 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
   constexpr bool kX3 = std::is_same<TE, x3_t>::value;
   constexpr int kPlanes = Planes<TE>::k;
   constexpr int kSlabGlobal = kX3 ? SB / 2 : SB;  // bytes a slab advances along a (plane's) row
-  static_assert(!kX3 || SB == SLAB, "the split-bf16 form is built on 128-byte stage rows");
   int nk = (int)((size_t)p.K * sizeof(TE) / kSlabGlobal);
   const size_t ldy_b = (size_t)p.ldy * sizeof(TE) * kPlanes, ldx_b = (size_t)p.ldx * sizeof(TE) * kPlanes;
   const char* gy0 = reinterpret_cast<const char*>(p.Y);
@@ -416,16 +395,15 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
   const uint32_t lds0 = (uint32_t)(size_t)(lds_void*)smem;
   uint32_t ya[4], xa[4];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) {  // (SB = 64: sub-steps 0 and 1 exist; the 4 chunks of a 64-byte row are swizzled with (row>>2)&3)
-    const uint32_t sw = SB == 128 ? (uint32_t)(((2 * s + fhalf) ^ ((frow >> 1) & 7)) << 4)
-                                  : (uint32_t)((((2 * s + fhalf) & 3) ^ ((frow >> 2) & 3)) << 4);
+  for (int s = 0; s < 4; ++s) {
+    const uint32_t sw = (uint32_t)(((2 * s + fhalf) ^ ((frow >> 1) & 7)) << 4);
     ya[s] = lds0 + (wy * RY * 32 + frow) * SB + sw;
     xa[s] = lds0 + (G::BM + wx * RX * 32 + frow) * SB + sw;
   }
 
   // epilogue patch (4 KiB per wave, inside whichever stage is free when the epilogue runs): write address per
   // register group g and read address, relative to that stage
-  const uint32_t patch = lds0 + (G::PATCH_OUT ? G::NSTAGE * G::STAGE : 0) + wave * 4096;
+  const uint32_t patch = lds0 + wave * 4096;
   uint32_t pw[4];
 #pragma unroll
   for (int g = 0; g < 4; ++g) pw[g] = patch + frow * 128 + (((2 * g + fhalf) ^ (frow & 7)) << 4);
@@ -438,47 +416,13 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
 #pragma unroll
   for (int q = 0; q < G::PPW; ++q) {
     const int piece = wave * G::PPW + q;
-    const int R = piece * G::RPP + (SB == 128 ? (lane >> 3) : (lane >> 2));
-    const int c = SB == 128 ? ((lane & 7) ^ ((R >> 1) & 7)) : ((lane & 3) ^ ((R >> 2) & 3));
+    const int R = piece * G::RPP + (lane >> 3);
+    const int c = (lane & 7) ^ ((R >> 1) & 7);
     const bool isy = piece * G::RPP < G::BM;
     // (split-bf16: source chunks 0..3 come from the hi plane, 4..7 from the same columns of the lo plane, ld elements further on)
     const size_t cb = kX3 ? (size_t)(c & 3) * 16 + (c >= 4 ? (size_t)(isy ? p.ldy : p.ldx) * sizeof(TE) : 0) : (size_t)c * 16;
     dma_off[q] = (uint32_t)((isy ? (size_t)R * ldy_b : (size_t)(R - G::BM) * ldx_b) + cb);
   }
-  // ---- ROLES: who stages what.  Waves w and w + 4 share a SIMD; group 0 = waves 0-3 owns the top half of the Y rows, group 1
-  // the bottom half.  Per slab: group 1 issues the pieces group 0 needs first -- Y top + all of X (the EARLY set) -- while group 0
-  // computes; then group 0 issues Y bottom (the LATE set, only group 1 needs it, a whole period later) while group 1 computes.
-  constexpr int kNE = G::BM / 16 + G::BN / 8, kPE = ROLES ? kNE / 4 : 1, kPL = ROLES ? G::BM / 64 : 1, kPR = kPE > kPL ? kPE : kPL;
-  static_assert(!ROLES || (G::NW == 8 && kNE % 4 == 0 && (G::BM / 16) % 4 == 0), "role split needs 8 waves and evenly divisible piece sets");
-  const int grp = wave >> 2, wi = wave & 3;
-  uint32_t roff[kPR];
-  if constexpr (ROLES) {
-#pragma unroll
-    for (int q = 0; q < kPR; ++q) {
-      int piece = 0;
-      if (grp == 1) { const int e = wi * kPE + q; piece = e < G::BM / 16 ? e : G::BM / 8 + (e - G::BM / 16); }
-      else piece = G::BM / 16 + wi * kPL + (q < kPL ? q : 0);
-      const int R = piece * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((R >> 1) & 7);
-      roff[q] = (uint32_t)((piece * 8 < G::BM ? (size_t)R * ldy_b : (size_t)(R - G::BM) * ldx_b) + c * 16);
-    }
-  }
-  auto role_issue = [&](const char* gy, const char* gx, uint32_t stage_lds) {  // this wave's share of its group's set
-    const int cnt = grp == 1 ? kPE : kPL;
-#pragma unroll
-    for (int q = 0; q < kPR; ++q) {
-      if (q < cnt) {
-        int piece;
-        if (grp == 1) { const int e = wi * kPE + q; piece = e < G::BM / 16 ? e : G::BM / 8 + (e - G::BM / 16); }
-        else piece = G::BM / 16 + wi * kPL + q;
-        piece = __builtin_amdgcn_readfirstlane(piece);
-        const char* sbase = (piece * 8 < G::BM) ? gy : gx;
-        const uint32_t dst = stage_lds + (uint32_t)(piece * 8 * SLAB);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(roff[q]), "s"(sbase), "s"(dst) : "memory");
-      }
-    }
-  };
-
   // ---- tile sequence.  The first tile of a workgroup is static (`first`: XCD-contiguous runs).  Launches with more tiles
   // than workgroups draw every later tile from a ticket counter (p.sched), two tiles ahead of the one being computed, so that a
   // workgroup that starts late or runs slowly -- a collective's or an optimizer's kernel holding its compute unit -- takes fewer
@@ -486,10 +430,10 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
   // requested (wave 0, lane 0) at the top of tile j, has returned by the vmcnt(0) before tile j's epilogue, and is published
   // through LDS across the epilogue barrier; the ticket for the second tile is requested before the prologue, is older than
   // every LDS-DMA piece and so has returned after the first slab's wait.
-  constexpr bool kDynFits = G::NSTAGE * G::STAGE + (G::PATCH_OUT ? G::NW * 4096 : 0) + 64 <= G::LDS_MAX;
+  constexpr bool kDynFits = G::NSTAGE * G::STAGE + 64 <= G::LDS_MAX;
   const bool dyn = kDynFits && p.sched != nullptr;
   volatile __attribute__((address_space(3))) uint32_t* sched_lds =
-      reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>((lds_void*)smem) + (G::NSTAGE * G::STAGE + (G::PATCH_OUT ? G::NW * 4096 : 0)) / 4;
+      reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>((lds_void*)smem) + (G::NSTAGE * G::STAGE) / 4;
   const bool ticket_lane = dyn && wave == 0 && lane == 0;
   // One queue per XCD (16-bit fields of p.sched[0..3], two per word; [8] counts finished workgroups): ticket k of XCD x is the
   // k-th tile of the runs a static schedule would give that XCD in rounds 1, 2, ... -- undisturbed, every XCD's L2 keeps seeing
@@ -532,19 +476,8 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
       }
     }
   };
-  int cs = 0;  // ROLES: slabs consumed so far by this workgroup (stage = cs & 1)
-  if constexpr (ROLES) {
-    if (t_cur < ntiles) {  // the very first slab: both groups stage their sets, everybody waits
-      const char *gy, *gx;
-      tile_ptrs(t_cur, 0, gy, gx);
-      role_issue(gy, gx, lds0);
-    }
-    wait_vm<0>();
-    __builtin_amdgcn_s_barrier();
-  } else {
 #pragma unroll
-    for (int i = 0; i < G::NSTAGE - 1; ++i) issue_next();
-  }
+  for (int i = 0; i < G::NSTAGE - 1; ++i) issue_next();
   int landed = 0;  // slabs known to have landed already (waited for before the previous epilogue)
 
 #ifdef OSUD_GEMM_TIMING
@@ -577,40 +510,6 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
 #ifdef OSUD_GEMM_TIMING
     uint64_t te0 = __builtin_readcyclecounter();
 #endif
-    if constexpr (ROLES) {
-      // ---- role-split main loop: two half-periods per slab, a barrier after each.
-      //   H1: group 0 runs the slab's MFMAs | group 1 issues the EARLY set of the NEXT slab (Y top + X) into the other stage
-      //   H2: group 1 runs the slab's MFMAs | group 0 issues the LATE set of the next slab (Y bottom)
-      // A SIMD's matrix pipe is fed by one of its two waves in each half while the other one pays the LDS-DMA issue cost
-      // (~100 cycles per 1 KiB piece, 64 pieces per slab: in lock step that was ~1000 cycles per slab with the pipe idle).
-      // Readiness: what a group computes on in its half was issued at least one half-period earlier by the OTHER group, which
-      // waits for its own pieces (vmcnt(0)) at the end of its computing half, just before the barrier -- no wave ever waits
-      // for a piece it has only just issued.  Two 64 KiB stages as before.
-      for (int kt = 0; kt < nk; ++kt) {
-        const bool last = kt + 1 == nk;
-        const int n_tile = last ? t_nxt : t_cur, n_kt = last ? 0 : kt + 1;
-        const bool has_next = n_tile < ntiles;
-        const char *gy = nullptr, *gx = nullptr;
-        if (has_next) tile_ptrs(n_tile, n_kt, gy, gx);
-        const uint32_t so = (uint32_t)((cs & 1) * G::STAGE), so_next = lds0 + (uint32_t)(((cs + 1) & 1) * G::STAGE);
-        if (grp == 0) {
-          compute_slab<TE, RY, RX>(acc, ya, xa, so);
-          wait_vm<0>();  // its LATE pieces of this slab's successor... issued in the previous H2: landed before group 1 reads them
-        } else if (has_next) {
-          role_issue(gy, gx, so_next);
-        }
-        __builtin_amdgcn_s_barrier();
-        if (grp == 1) {
-          compute_slab<TE, RY, RX>(acc, ya, xa, so);
-          wait_vm<0>();  // the EARLY pieces issued in H1: landed before group 0 reads them in the next H1
-        } else if (has_next) {
-          role_issue(gy, gx, so_next);
-        }
-        __builtin_amdgcn_s_barrier();
-        ++cs;
-      }
-      pso = (uint32_t)(((cs - 1) & 1) * G::STAGE);  // the stage consumed last: free, becomes the epilogue patch area
-    } else {
     for (int kt = 0; kt < nk; ++kt) {
 #ifdef OSUD_GEMM_TIMING
       const uint64_t tt0 = __builtin_readcyclecounter();
@@ -621,14 +520,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
       if (landed > 0) --landed;
       else if (ahead <= 0 || G::NSTAGE == 2) wait_vm<0>();
       else if (ahead == 1) wait_vm<G::PPW>();
-      else {
-        if constexpr (SB == 64 && G::NSTAGE >= 5) {
-          if (ahead == 2) wait_vm<2 * G::PPW>();
-          else wait_vm<3 * G::PPW>();
-        } else {
-          wait_vm<(G::NSTAGE > 3 ? 2 * G::PPW : 0)>();
-        }
-      }
+      else wait_vm<(G::NSTAGE > 3 ? 2 * G::PPW : 0)>();
 #ifdef OSUD_GEMM_TIMING
       const uint64_t tt1 = __builtin_readcyclecounter();
 #endif
@@ -653,7 +545,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
 #endif
       if constexpr (kX3) compute_slab_x3<RY, RX>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
       else if constexpr (kH8) compute_slab_h8<RY, RX>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
-      else compute_slab<TE, RY, RX, SB>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
+      else compute_slab<TE, RY, RX>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
 #ifdef OSUD_GEMM_TIMING
       {
         const uint64_t tt4 = __builtin_readcyclecounter();
@@ -686,8 +578,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
     tsum[6] += te1 - te0;  // drain wait before the epilogue
     tsum[7] += te2 - te1;  // epilogue barrier
 #endif
-    pso = G::PATCH_OUT ? 0u : (uint32_t)(((consumed + G::NSTAGE - 1) % G::NSTAGE) * G::STAGE);
-    }
+    pso = (uint32_t)(((consumed + G::NSTAGE - 1) % G::NSTAGE) * G::STAGE);
 
 
     // ---- epilogue -------------------------------------------------------------------------------
@@ -915,10 +806,6 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
 #ifdef OSUD_GEMM_TIMING
     tsum[5] += __builtin_readcyclecounter() - te0;  // epilogue (incl. the drain wait and barrier)
 #endif
-    if constexpr (ROLES) {  // every wave's patch reads done before the next H1 refills that stage by LDS-DMA
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-    }
     t_cur = t_nxt;
     t_nxt = t_nxt2;
     if (ic_rel > 0) --ic_rel;
@@ -953,21 +840,16 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX, SB>::NT)) void gemm_kernel(Gem
 #endif
 }
 
-template <typename TE, int EPI, int WY, int WX, int RY, int RX, int SB = SLAB> int launch_w(const GemmP& p_in, hipStream_t st) {
-  using G = Geo<WY, WX, RY, RX, SB>;
+template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(const GemmP& p_in, hipStream_t st) {
+  using G = Geo<WY, WX, RY, RX>;
   GemmP p = p_in;
   const size_t ring = (size_t)G::NSTAGE * G::STAGE;  // stage ring (the epilogue patches borrow the free stage)
-  constexpr bool kDynFits = G::NSTAGE * G::STAGE + (G::PATCH_OUT ? G::NW * 4096 : 0) + 64 <= G::LDS_MAX;
-  const size_t lds = ring + (G::PATCH_OUT ? (size_t)G::NW * 4096 : 0) + (kDynFits ? 64 : 0);
-  // the role-split main loop: 8-wave geometries with two stages (the 64 KiB-per-stage tiles), piece sets divisible by 4 waves
-  constexpr bool kRolesOk = !std::is_same<TE, x3_t>::value && !std::is_same<TE, h8_t>::value && SB == SLAB && G::NW == 8 && G::NSTAGE == 2 && (G::BM / 16 + G::BN / 8) % 4 == 0 && (G::BM / 16) % 4 == 0;
+  constexpr bool kDynFits = G::NSTAGE * G::STAGE + 64 <= G::LDS_MAX;
+  const size_t lds = ring + (kDynFits ? 64 : 0);
   static bool attr_set = false;
   if (!attr_set) {
-    OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX, false, SB>),
+    OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX>),
                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    if constexpr (kRolesOk)
-      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<TE, EPI, WY, WX, RY, RX, true, SB>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
   if (p.colpart_rows != nullptr) *p.colpart_rows = p.My / (RY * 32);
@@ -977,22 +859,10 @@ template <typename TE, int EPI, int WY, int WX, int RY, int RX, int SB = SLAB> i
   if (grid > ntiles) grid = ntiles;
   {
     const bool dyn_on = gemm_dynamic_tiles_wanted();
-    const int nk = (int)((size_t)p.K * sizeof(TE) / (std::is_same<TE, x3_t>::value ? SB / 2 : SB));
+    const int nk = (int)((size_t)p.K * sizeof(TE) / (std::is_same<TE, x3_t>::value ? SLAB / 2 : SLAB));
     p.sched = (dyn_on && kDynFits && splits == 1 && ntiles > grid && grid % 8 == 0 && nk >= G::NSTAGE && ntiles / 8 + 2 * grid < 60000) ? gemm_sched_slot() : nullptr;
   }
-  // OSUD_GEMM_ROLES=1 selects the role-split main loop.  Built, bit-identical results, and measured EQUAL to the lock-step loop
-  // within run-to-run noise on every shape (fc1 168.7 vs 170.6 us, 4096^3 1179 vs 1169 TFLOP/s, training step 28.3 vs 28.2 ms):
-  // two schedules this different landing on the same throughput says the main loop is not issue-bound but clock-bound -- the chip
-  // trades any saved cycle against frequency under this MFMA + LDS load.  The lock-step loop stays the default.
-  static const bool roles_env = [] { const char* e = getenv("OSUD_GEMM_ROLES"); return e && e[0] == '1'; }();
-  if constexpr (kRolesOk) {
-    if (roles_env && p.sched == nullptr) {  // (the tile queues of shared-GPU mode keep the lock-step loop)
-      hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY, RX, true, SB>), dim3(grid, splits), dim3(G::NT), lds, st, p);
-      OSUD_HIP(hipGetLastError());
-      return OSUD_OK;
-    }
-  }
-  hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY, RX, false, SB>), dim3(grid, splits), dim3(G::NT), lds, st, p);
+  hipLaunchKernelGGL((gemm_kernel<TE, EPI, WY, WX, RY, RX>), dim3(grid, splits), dim3(G::NT), lds, st, p);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }
@@ -1018,33 +888,22 @@ template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
   if (e[3] > 0 && e[3] + 0.05 >= e[pick] && pick == 0) pick = 3;
   if (e[2] > 0 && e[2] + 0.05 >= e[pick]) pick = 2;
   // few tiles (one beatmap, few variants: M ~ 2-4 K tokens): halve the tile height to double the workgroups in flight
-  {
-    static const int thr = [] { const char* e = getenv("OSUD_GEMM_SMALL_PCT"); return e ? atoi(e) : 75; }();
-    if (pick == 0 && (long)(p.My / 128) * (p.Nx / 128) * splits * 100 < (long)cus * thr) pick = 6;
-  }
+  if (pick == 0 && (long)(p.My / 128) * (p.Nx / 128) * splits * 100 < (long)cus * 75) pick = 6;
   // one row of 128-row tiles and a wide output (the adaLN product of a sampling step: 128 x 56 832 x 768 streams 87 MB of weights):
   // 128x256 tiles make it one round instead of 1.7 (28.1 -> 23.9 us)
   if (pick == 0 && p.My == 128 && p.Nx % 256 == 0 && splits == 1 && (long)(p.Nx / 128) > cus) pick = 8;
-  if (const char* force = getenv("OSUD_GEMM_TILE")) {  // "64" | "128" | "192" | "256": tuning / A-B runs
-    const std::string f(force);
-    if (f == "128") pick = 0;
-    else if (f == "64") pick = 6;
-    else if (f == "192" && e[1] > 0) pick = 1;
-    else if (f == "256" && e[2] > 0) pick = 2;
-    else if (f == "192y" && e[3] > 0) pick = 3;
-    else if (f == "256x128" && p.My % 256 == 0) pick = 7;  // experiment: three 48 KiB stages instead of two 64 KiB ones
-    else if (f == "128x256" && p.Nx % 256 == 0) pick = 8;
-  }
-  {  // half slabs + deeper ring for the 256x256 geometry (OSUD_GEMM_SLAB=128 selects the two-stage form for A/B runs)
-    static const bool half_slabs = [] { const char* e = getenv("OSUD_GEMM_SLAB"); return e && atoi(e) == 64; }();
-    if constexpr (!std::is_same<TE, x3_t>::value && !std::is_same<TE, h8_t>::value)
-      if (pick == 2 && half_slabs) return launch_w<TE, EPI, 2, 4, 4, 2, 64>(p, st);
+  if (const int force = opt(OPT_GEMM_TILE)) {  // osud_set_option("gemm_tile", ..): tests of every geometry on one shape, tuning runs
+    if (force == 128) pick = 0;
+    else if (force == 64) pick = 6;
+    else if (force == 192 && e[1] > 0) pick = 1;
+    else if (force == 256 && e[2] > 0) pick = 2;
+    else if (force == 1192 && e[3] > 0) pick = 3;
+    else if (force == 1256 && p.Nx % 256 == 0) pick = 8;
   }
   if (pick == 2) return launch_w<TE, EPI, 2, 4, 4, 2>(p, st);
   if (pick == 1) return launch_w<TE, EPI, 4, 2, 2, 3>(p, st);
   if (pick == 3) return launch_w<TE, EPI, 2, 4, 3, 2>(p, st);
   if (pick == 6) return launch_w<TE, EPI, 2, 2, 1, 2>(p, st);
-  if (pick == 7) return launch_w<TE, EPI, 4, 2, 2, 2>(p, st);
   if (pick == 8) return launch_w<TE, EPI, 2, 4, 2, 2>(p, st);
   return launch_w<TE, EPI, 2, 2, 2, 2>(p, st);
 }

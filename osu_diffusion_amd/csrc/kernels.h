@@ -58,48 +58,61 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
                          size_t bias_scratch_elems = 0);  // dbias != nullptr (bf16 tier): column sums of dqkv are ADDED to / written into it
 
 // kernels_bwd.hip
+// No kernel of the backward pass adds floats atomically: sums that several workgroups contribute to are written as per-workgroup
+// partial rows and added by a fixed-order pass, so a gradient is the same bits on every run and under every stream schedule.
+// colsum (optional) = column sums of `in` (a bias gradient), written; needs colpart: (R / 64) x C floats of scratch
 int launch_transpose(int prec, const void* in, int ld_in, void* out, int ld_out, int R, int C, float* colsum,
-                     hipStream_t st);
+                     hipStream_t st, float* colpart = nullptr, size_t colpart_elems = 0);
 int launch_transpose_f32(int prec, const float* in, int ld_in, void* out, int ld_out, int R, int C, float* colsum,
-                         hipStream_t st);
-// db (optional) += column sums of dbr = the branch Linear's bias gradient
-int launch_gate_bwd(int prec, const float* dh, const void* br, const float* gate, int ld_ada, void* dbr, float* dgate,
-                    int M, int Tp, int D, hipStream_t st, float* db = nullptr);
+                         hipStream_t st, float* colpart = nullptr, size_t colpart_elems = 0);
+// Descriptor list of launch_row_reduce (kernels_bwd.hip: row_reduce_kernel): item i = the per-block partial rows one gate_bwd /
+// ln_mod_bwd / final_bwd launch left behind; rows q < nq_sample become dada[n][off[q]..] (sum over the sample's bps blocks), row
+// nq_sample -- if bias is set -- becomes bias[..] (sum over all blocks)
+struct RowRedList {
+  static constexpr int kMax = 40;
+  const float* part[kMax];
+  float* dada[kMax];
+  float* bias[kMax];
+  int off[kMax][3];
+  int stride[kMax], blocks[kMax], bps[kMax], nq_sample[kMax];
+  int count, D, ld_ada;
+};
+int launch_row_reduce(const RowRedList& L, hipStream_t st);
+// part: (M / 64) x 2 D floats, rows {dgate share, share of db = the branch Linear's bias gradient}
+int launch_gate_bwd(int prec, const float* dh, const void* br, const float* gate, int ld_ada, void* dbr, float* part,
+                    int M, int Tp, int D, hipStream_t st);
 // du is TE.  br_next != nullptr: also run the gate_bwd of the branch added in front of this LayerNorm on the fresh dh_out
-// rows (dbr = gate * dh_out, dada[n][off_gate_next..] += sum_t dh_out * br_next, db_next += column sums of dbr)
+// rows (dbr = gate * dh_out).  part: (M / 64) x Q D floats, rows {dshift, dscale} and with the gate step (Q = 4) {dgate of the next
+// branch, its bias gradient}: the block's shares, to be summed by launch_row_reduce
 int launch_ln_mod_bwd(int prec, const float* h, const float* stats, const void* du, const float* ada, int ld_ada,
-                      int off_shift, int off_scale, const float* dh_skip, float* dh_out, float* dada, int M, int Tp, int D,
+                      int off_shift, int off_scale, const float* dh_skip, float* dh_out, float* part, int M, int Tp, int D,
                       hipStream_t st, const void* br_next = nullptr, int off_gate_next = 0, void* dbr = nullptr,
-                      float* db_next = nullptr, void* dbr8 = nullptr,
-                      const float* slot8 = nullptr, float* amax_part = nullptr);
+                      void* dbr8 = nullptr, const float* slot8 = nullptr, float* amax_part = nullptr);
+// part: (N Tp / 64) x (6 D + 64) floats; dw / dbias are written here, the dshift | dscale rows (at + 4 D + 64 of a block's row) are
+// left for launch_row_reduce
 int launch_final_bwd(const float* h, const float* stats, const float* dout, const float* w, const float* ada, int ld_ada,
-                     int off_shift, int off_scale, float* dh_out, float* dada, float* dw, float* dbias, int N, int T, int Tp,
-                     int D, int C, hipStream_t st, float* scratch = nullptr, size_t scratch_elems = 0);
+                     int off_shift, int off_scale, float* dh_out, float* dw, float* dbias, int N, int T, int Tp,
+                     int D, int C, hipStream_t st, float* part);
 int launch_cond_bwd(int prec, const float* dsb, const float* b, const int64_t* y, int table_rows, float* db_out,
                     void* db_te, float* dtable, int N, int Np, int D, hipStream_t st);
 int launch_silu_bwd(int prec, const float* dth, const void* z, void* dz, size_t n, hipStream_t st);
 int launch_mask_rows(int prec, float* a, void* a_te, int N, int Np, int C, hipStream_t st, int ld = 0);  // ld > C: a column slice
 int launch_unpad_rows(const float* src, int ld_src, float* dst, int cols, int rows, hipStream_t st);
-int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_t st, int split = 0, float* out2 = nullptr, int n2 = 0);
+// out[c] = sum_r a[r][c] in a fixed order (columns >= split go to out2[c - split], n2 of them); ld: row stride when only the first C
+// columns of wider rows are summed
+int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_t st, int split = 0, float* out2 = nullptr, int n2 = 0,
+                      int ld = 0);
 
 // wgrad.hip (bf16 tier): transpose-free weight-gradient product and bias-gradient column sums
 int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int Nx, int M, float* out, float* ws,
                     size_t ws_elems, hipStream_t st);
-int launch_colsum_bf16(const void* a, int ld, int M, int N, float* out, hipStream_t st);
-// fp8 training: column sums (+= into out) AND e4m3 twin (x slot[0]; q8 may be null) AND amax (slot[2]) of a dense bf16 [M][N] matrix
-int launch_colsum_quant_bf16(const void* a, int M, int N, float* out, void* q8, float* slot, hipStream_t st);
+// out[c] = sum_m a[m][c] (written; fixed order); part: ceil(M / 256) x N floats of scratch for the row blocks' shares
+int launch_colsum_bf16(const void* a, int ld, int M, int N, float* out, hipStream_t st, float* part, size_t part_elems);
+// fp8 training: column sums AND e4m3 twin (x slot[0]; q8 may be null) AND amax (slot[2]) of a dense bf16 [M][N] matrix
+int launch_colsum_quant_bf16(const void* a, int M, int N, float* out, void* q8, float* slot, hipStream_t st, float* part, size_t part_elems);
 // the same product on e4m3 twins (fp8 training): out = inv_p[0] * inv_q[0] * P8^T . Q8 (device scalars: the operands' 1 / scale)
 int launch_wgrad8_tr(const void* P8, int ldp, const void* Q8, int ldq, int Ny, int Nx, int M, float* out, float* ws, size_t ws_elems,
                      const float* inv_p, const float* inv_q, hipStream_t st);
-// up to four weight-gradient products over the same M token rows in one launch (+ one combine launch); *done = false: not taken
-struct WgradItem {
-  const void* P;
-  const void* Q;
-  float* out;
-  int ldp, ldq, Ny, Nx;
-};
-int launch_wgrad_group(const WgradItem* items, int n, int M, float* ws, size_t ws_elems, hipStream_t st, bool* done);
-
 // batch.hip: one launch for a list of small buffers (passed by value in the kernel arguments)
 enum SegOp { SEG_ZERO = 0, SEG_COPY = 1, SEG_CONVERT = 2 };
 struct SegList {
@@ -174,7 +187,8 @@ int launch_sampler_step(const float* coefs, int mode, float eta, const float* mo
                         const int64_t* t_index, const int* step_state, const float* noise, size_t noise_step_stride,
                         uint64_t seed, int N, int T, float cfg_scale, int clip, const osud_inpaint* inpaint, float* x_out,
                         float* pred_xstart, hipStream_t st);
-int launch_step_init(int* step_state, int first, uint64_t seed, hipStream_t st);  // step_state: 8 ints
+// step_state: 8 ints {next index, current index, k-th step of the loop (current), k (next), seed lo, seed hi, decrement per step, -}
+int launch_step_init(int* step_state, int first, uint64_t seed, hipStream_t st, int dec = 1);
 int launch_step_begin(int* step_state, const int64_t* tmap_dev, int64_t* t_model, int64_t* t_index, int N,
                       hipStream_t st);
 

@@ -9,9 +9,10 @@ namespace osud {
 namespace {
 
 // ------------------------------------------------------------------------------------------
-// out[c][r] = in[r][c] for a [R][C] TE matrix (R, C multiples of 64), plus optional column sums
-// colsum[c] += sum_r in[r][c] (bias gradients: one pass over dC feeds both the transposed
-// operand of the weight-gradient GEMM and db).  64x64 tile through LDS, padded rows.
+// out[c][r] = in[r][c] for a [R][C] TE matrix (R, C multiples of 64), plus optional column sums (bias gradients: one pass
+// over dC feeds both the transposed operand of the weight-gradient GEMM and db): row block y writes its 64-row partial sums to
+// colpart[y][C]; the launcher's fixed-order column pass over the R / 64 partial rows makes the sum -- no float atomics, so a
+// gradient never depends on the order in which workgroups arrive.  64x64 tile through LDS, padded rows.
 template <typename TE>
 __global__ __launch_bounds__(256) void transpose_kernel(const TE* __restrict__ in, int ld_in, TE* __restrict__ out,
                                                         int ld_out, float* __restrict__ colsum) {
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const TE* __restrict__ i
     __shared__ float part[4][64];
     part[ty][tx] = s;
     __syncthreads();
-    if (ty == 0) atomicAdd(colsum + c0 + tx, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+    if (ty == 0) colsum[(size_t)blockIdx.y * (gridDim.x * 64) + c0 + tx] = part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx];
   }
 }
 
@@ -66,21 +67,21 @@ __global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restr
     __shared__ float part[4][64];
     part[ty][tx] = s;
     __syncthreads();
-    if (ty == 0) atomicAdd(colsum + c0 + tx, part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+    if (ty == 0) colsum[(size_t)blockIdx.y * (gridDim.x * 64) + c0 + tx] = part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx];
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // Gated residual branch backward:  h_out = h_in + gate[n] * br   (models.py:161-175)
 //   dbr[m][d]  = gate[n][d] * dh[m][d]                       (TE, operand of the next GEMMs)
-//   dgate[n][d] += sum_t dh[m][d] * br[m][d]
-//   db[d]      += gate[n][d] * sum_t dh[m][d]                (= column sums of dbr: the branch Linear's bias gradient)
-// Block = 64 consecutive rows (one sample: Tp % 64 == 0), wave w takes rows w, w+4, ...
+//   dgate[n][d] = sum_t dh[m][d] * br[m][d]
+//   db[d]      = sum_n gate[n][d] * sum_t dh[m][d]           (= column sums of dbr: the branch Linear's bias gradient)
+// Block = 64 consecutive rows (one sample: Tp % 64 == 0), wave w takes rows w, w+4, ...  The block's share of the two sums goes
+// to part[block][2][D] (row 0: dgate, row 1: db); row_reduce_kernel adds the blocks' rows in a fixed order.
 template <typename TE, int VPL>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dh, const TE* __restrict__ br,
                                                        const float* __restrict__ gate, int ld_ada,
-                                                       TE* __restrict__ dbr, float* __restrict__ dgate, int Tp,
-                                                       float* __restrict__ db) {
+                                                       TE* __restrict__ dbr, float* __restrict__ part, int Tp) {
   constexpr int D = VPL * 64;
   __shared__ float red[4][D];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -114,27 +115,28 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
     red[wave][2 * lane + 128 * i + 1] = acc[2 * i + 1];
   }
   __syncthreads();
-  for (int d = threadIdx.x; d < D; d += 256)
-    atomicAdd(dgate + (size_t)n * ld_ada + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
-  if (db != nullptr) {
-    __syncthreads();
+  float* prow = part + (size_t)blockIdx.x * 2 * D;
+  for (int d = threadIdx.x; d < D; d += 256) prow[d] = red[0][d] + red[1][d] + red[2][d] + red[3][d];
+  __syncthreads();
 #pragma unroll
-    for (int i = 0; i < VPL / 2; ++i) {
-      red[wave][2 * lane + 128 * i] = gv[2 * i] * cs[2 * i];
-      red[wave][2 * lane + 128 * i + 1] = gv[2 * i + 1] * cs[2 * i + 1];
-    }
-    __syncthreads();
-    for (int d = threadIdx.x; d < D; d += 256) atomicAdd(db + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
+  for (int i = 0; i < VPL / 2; ++i) {
+    red[wave][2 * lane + 128 * i] = gv[2 * i] * cs[2 * i];
+    red[wave][2 * lane + 128 * i + 1] = gv[2 * i + 1] * cs[2 * i + 1];
   }
+  __syncthreads();
+  for (int d = threadIdx.x; d < D; d += 256) prow[D + d] = red[0][d] + red[1][d] + red[2][d] + red[3][d];
 }
 
 // ------------------------------------------------------------------------------------------
 // LayerNorm + modulate backward:  u = xhat * (1 + sc[n]) + sh[n],  xhat = (h - mu) * rstd
-//   dsh[n] += sum_t du ; dsc[n] += sum_t du * xhat ; dy = du * (1 + sc)
+//   dsh[n] = sum_t du ; dsc[n] = sum_t du * xhat ; dy = du * (1 + sc)
 //   dh_out = dh_skip + rstd * (dy - mean(dy) - xhat * mean(dy * xhat))
 // dh_out is the gradient of the residual stream in front of this LayerNorm, i.e. exactly the input of the gate_bwd of the
 // branch that was added just before it; with br_next != nullptr that step is done here on the rows still in registers
 // (dbr, dgate, db as in gate_bwd_kernel), saving a second pass over dh.
+// The block's share of the per-sample / per-column sums goes to part[block][Q][D] (Q = 2: dshift, dscale; with the gate step Q = 4:
+// + dgate of the next branch, + its bias gradient); row_reduce_kernel adds the blocks' rows in a fixed order (no float atomics:
+// two runs of any schedule give the same bits).
 #ifndef OSUD_LNB_ROWS
 #define OSUD_LNB_ROWS 64
 #endif
@@ -196,8 +198,8 @@ __global__ __launch_bounds__(256, OSUD_LNB_OCC(VPL)) void ln_mod_bwd_kernel(cons
                                                          const TE* __restrict__ du, const float* __restrict__ ada,
                                                          int ld_ada, int off_shift, int off_scale,
                                                          const float* __restrict__ dh_skip, float* __restrict__ dh_out,
-                                                         float* __restrict__ dada, int Tp, const TE* __restrict__ br_next,
-                                                         int off_gate_next, TE* __restrict__ dbr, float* __restrict__ db_next,
+                                                         float* __restrict__ part, int Tp, const TE* __restrict__ br_next,
+                                                         int off_gate_next, TE* __restrict__ dbr,
                                                          fp8_t* __restrict__ dbr8, const float* __restrict__ slot8,
                                                          float* __restrict__ amax_part) {
   // lane l owns columns W*l + 64*W*g + {0..W-1}, g < NG: 16-byte fp32 / 8-byte bf16 accesses where VPL allows (W = 4)
@@ -315,10 +317,10 @@ __global__ __launch_bounds__(256, OSUD_LNB_OCC(VPL)) void ln_mod_bwd_kernel(cons
       red[1][wave][d] = a_sc[g * W + e];
     }
   __syncthreads();
-  float* dn = dada + (size_t)n * ld_ada;
+  float* prow = part + (size_t)blockIdx.x * (GATE ? 4 : 2) * D;
   for (int d = threadIdx.x; d < D; d += 256) {
-    atomicAdd(dn + off_shift + d, red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d]);
-    atomicAdd(dn + off_scale + d, red[1][0][d] + red[1][1][d] + red[1][2][d] + red[1][3][d]);
+    prow[d] = red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d];
+    prow[D + d] = red[1][0][d] + red[1][1][d] + red[1][2][d] + red[1][3][d];
   }
   if constexpr (GATE) {
     __syncthreads();
@@ -332,8 +334,8 @@ __global__ __launch_bounds__(256, OSUD_LNB_OCC(VPL)) void ln_mod_bwd_kernel(cons
       }
     __syncthreads();
     for (int d = threadIdx.x; d < D; d += 256) {
-      atomicAdd(dn + off_gate_next + d, red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d]);
-      if (db_next != nullptr) atomicAdd(db_next + d, red[1][0][d] + red[1][1][d] + red[1][2][d] + red[1][3][d]);
+      prow[2 * D + d] = red[0][0][d] + red[0][1][d] + red[0][2][d] + red[0][3][d];
+      prow[3 * D + d] = red[1][0][d] + red[1][1][d] + red[1][2][d] + red[1][3][d];
     }
     if (twin) {
       __syncthreads();
@@ -350,16 +352,15 @@ __global__ __launch_bounds__(256, OSUD_LNB_OCC(VPL)) void ln_mod_bwd_kernel(cons
 //   duF = sum_ch dout * Wf ; dWf[ch][d] += sum_m dout * uF ; dbf[ch] += sum_m dout
 // then the same LN+modulate backward as above (dh_skip = 0), all in one pass over h.
 // Per-column constants (1 + scale, shift, the C weight rows) live in LDS, the next row's h is in flight while this one is
-// reduced, and the weight- and bias-gradient partial sums of a block go to `dw_part` [blocks][4 D + 64] (summed by a fixed-order
-// column pass: 512 blocks adding atomically into the same addresses made the result depend on arrival order, and slow).
+// reduced, and every partial sum of a block goes to its row of `part` [blocks][6 D + 64] = [dW rows 4 D | bias 4 (+ 60 pad) |
+// dshift D | dscale D]: a fixed-order column pass makes dW and the bias gradient, row_reduce_kernel the per-sample modulation
+// gradients (512 blocks adding atomically into the same addresses made the result depend on arrival order, and slow).
 template <int VPL>
 __global__ __launch_bounds__(256, 2) void final_bwd_kernel(const float* __restrict__ h, const float* __restrict__ stats,
                                                            const float* __restrict__ dout, const float* __restrict__ w,
                                                            const float* __restrict__ ada, int ld_ada, int off_shift,
-                                                           int off_scale, float* __restrict__ dh_out,
-                                                           float* __restrict__ dada, float* __restrict__ dw,
-                                                           float* __restrict__ dbias, int T, int Tp, int C,
-                                                           float* __restrict__ dw_part) {
+                                                           int off_scale, float* __restrict__ dh_out, int T, int Tp, int C,
+                                                           float* __restrict__ part) {
   constexpr int D = VPL * 64;
   __shared__ float red[4][D];  // one quantity at a time (6 of them)
   __shared__ float cst[6][D];  // 1 + scale | shift | weight rows (zero beyond C)
@@ -449,56 +450,65 @@ __global__ __launch_bounds__(256, 2) void final_bwd_kernel(const float* __restri
     if (r + 8 < 64) load_row(ra, m0 + r + 8);
     process_row(rb, m0 + r + 4);
   }
-  float* dn = dada + (size_t)n * ld_ada;
+  float* prow = part + (size_t)blockIdx.x * (6 * D + 64);
 #pragma unroll
-  for (int q = 0; q < 6; ++q) {  // 0: dshift, 1: dscale, 2..5: dW rows
-    if (q >= 2 && q - 2 >= C) break;
+  for (int q = 0; q < 6; ++q) {  // 0: dshift, 1: dscale, 2..5: dW rows (zero beyond C: their dout is)
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int d = 2 * lane + 128 * (i >> 1) + (i & 1);
       red[wave][d] = q == 0 ? a_sh[i] : (q == 1 ? a_sc[i] : a_w[q >= 2 ? q - 2 : 0][i]);
     }
     __syncthreads();
-    if (q >= 2 && dw_part != nullptr) {
-      float* dst = dw_part + (size_t)blockIdx.x * (4 * D + 64) + (size_t)(q - 2) * D;
-      for (int d = threadIdx.x; d < D; d += 256) dst[d] = red[0][d] + red[1][d] + red[2][d] + red[3][d];
-    } else {
-      float* dst = q == 0 ? dn + off_shift : (q == 1 ? dn + off_scale : dw + (size_t)(q - 2) * D);
-      for (int d = threadIdx.x; d < D; d += 256) atomicAdd(dst + d, red[0][d] + red[1][d] + red[2][d] + red[3][d]);
-    }
+    float* dst = q < 2 ? prow + 4 * D + 64 + (size_t)q * D : prow + (size_t)(q - 2) * D;
+    for (int d = threadIdx.x; d < D; d += 256) dst[d] = red[0][d] + red[1][d] + red[2][d] + red[3][d];
     __syncthreads();
   }
-  if (dw_part != nullptr) {  // bias partial sums behind the weight rows of the slab: [4 D + 0..3], the pad columns are never read back
-    if (lane == 0) {
+  // bias partial sums behind the weight rows: [4 D + 0..3], the pad columns are never read back
+  if (lane == 0) {
 #pragma unroll
-      for (int ch = 0; ch < 4; ++ch) red[wave][ch] = a_b[ch];  // every lane of a wave carries the same a_b
-    }
-    __syncthreads();
-    if (threadIdx.x < 4)
-      dw_part[(size_t)blockIdx.x * (4 * D + 64) + 4 * D + threadIdx.x] =
-          red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-  } else if (lane == 0) {
-    for (int ch = 0; ch < C; ++ch) atomicAdd(dbias + ch, a_b[ch]);
+    for (int ch = 0; ch < 4; ++ch) red[wave][ch] = a_b[ch];  // every lane of a wave carries the same a_b
   }
+  __syncthreads();
+  if (threadIdx.x < 4) prow[4 * D + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------
 // Conditioning path backward.  sb = silu(b), b = tvec + table[y]  (models.py:318-320):
 //   db = dsb * silu'(b) ; dtvec = db (TE copy for the GEMMs + f32) ; dtable[y[n]] += db[n]
+// Samples that share a label: the FIRST of them owns the table row and adds the others' rows in sample order (the label list is
+// a few hundred entries: every block scans it), so that a duplicated label gives the same bits whichever block runs first.
 template <typename TE>
 __global__ void cond_bwd_kernel(const float* __restrict__ dsb, const float* __restrict__ b, const int64_t* __restrict__ y,
                                 int table_rows, float* __restrict__ db_out, TE* __restrict__ db_te,
                                 float* __restrict__ dtable, int N, int D) {
   const int n = blockIdx.x;
+  auto label = [&](int i) {
+    const int64_t cls = y[i];
+    return cls < 0 ? (int64_t)0 : (cls >= table_rows ? (int64_t)table_rows - 1 : cls);
+  };
+  auto grad = [&](int i, int d) {
+    const float bv = b[(size_t)i * D + d];
+    const float s = 1.0f / (1.0f + expf(-bv));
+    return dsb[(size_t)i * D + d] * (s + bv * s * (1.0f - s));
+  };
+  const int64_t cls = n < N ? label(n) : 0;
+  int before = 0, after = 0;
+  if (n < N)
+    for (int i = threadIdx.x; i < N; i += blockDim.x)
+      if (i != n && label(i) == cls) (i < n ? before : after) = 1;
+  const bool owner = !__syncthreads_or(before) && n < N;
+  const bool shared_row = __syncthreads_or(after) != 0;
   for (int d = threadIdx.x; d < D; d += blockDim.x) {
     float g = 0.f;
     if (n < N) {
-      const float bv = b[(size_t)n * D + d];
-      const float s = 1.0f / (1.0f + expf(-bv));
-      g = dsb[(size_t)n * D + d] * (s + bv * s * (1.0f - s));
-      int64_t cls = y[n];
-      cls = cls < 0 ? 0 : (cls >= table_rows ? table_rows - 1 : cls);
-      atomicAdd(dtable + (size_t)cls * D + d, g);
+      g = grad(n, d);
+      if (owner) {
+        float row = g;
+        if (shared_row)
+          for (int i = n + 1; i < N; ++i)
+            if (label(i) == cls) row += grad(i, d);
+        dtable[(size_t)cls * D + d] += row;  // (the only writer of this row)
+      }
     }
     db_out[(size_t)n * D + d] = g;
     store_elem(db_te + (size_t)n * D + d, g);
@@ -549,32 +559,79 @@ __global__ void colsum_f32_kernel(const float* __restrict__ a, int R_valid, int 
   out[c] = s;
 }
 
+// ------------------------------------------------------------------------------------------
+// The fixed-order sums behind gate_bwd / ln_mod_bwd / final_bwd: item i holds per-block partial rows part[block][..] (row q of
+// block b at part + b * stride + q * D), `bps` consecutive blocks per sample.  Rows q < nq_sample are per-sample sums:
+//   dada[n][off[q] + d] = sum_{j < bps} part[n * bps + j][q][d]                      (written, not added: every slot has one writer)
+// and row nq_sample (bias != nullptr) is summed over ALL blocks: bias[d] = sum_b part[b][nq_sample][d].
+// Grid (D / 64, items); 16 sample groups x 16 float4 columns per block: group g walks samples g, g + 16, ... and their blocks in
+// order, the 16 groups' bias shares meet in LDS and are added in group order.  One launch per backward call for all the
+// LayerNorm / gate kernels of the call (the descriptor list travels in the kernel arguments).
+__global__ __launch_bounds__(256) void row_reduce_kernel(const RowRedList L) {
+  __shared__ float4 sh[16][16];
+  const int it = blockIdx.y;
+  const float* part = L.part[it];
+  const int stride = L.stride[it], bps = L.bps[it], nqs = L.nq_sample[it], samples = L.blocks[it] / bps, D = L.D;
+  const int tx = threadIdx.x & 15, tg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + tx * 4;
+  float* bias = L.bias[it];
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int n = tg; n < samples; n += 16) {
+    const float* p0 = part + (size_t)n * bps * stride + c;
+    for (int q = 0; q < nqs + (bias != nullptr ? 1 : 0); ++q) {
+      float4 s = *reinterpret_cast<const float4*>(p0 + (size_t)q * D);
+      for (int j = 1; j < bps; ++j) {
+        const float4 v = *reinterpret_cast<const float4*>(p0 + (size_t)j * stride + (size_t)q * D);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      if (q < nqs) *reinterpret_cast<float4*>(L.dada[it] + (size_t)n * L.ld_ada + L.off[it][q] + c) = s;
+      else { bsum.x += s.x; bsum.y += s.y; bsum.z += s.z; bsum.w += s.w; }
+    }
+  }
+  if (bias != nullptr) {
+    sh[tg][tx] = bsum;
+    __syncthreads();
+    if (tg == 0) {
+      float4 t = sh[0][tx];
+#pragma unroll
+      for (int g = 1; g < 16; ++g) { t.x += sh[g][tx].x; t.y += sh[g][tx].y; t.z += sh[g][tx].z; t.w += sh[g][tx].w; }
+      *reinterpret_cast<float4*>(bias + c) = t;
+    }
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------- launchers
 int launch_transpose(int prec, const void* in, int ld_in, void* out, int ld_out, int R, int C, float* colsum,
-                     hipStream_t st) {
+                     hipStream_t st, float* colpart, size_t colpart_elems) {
   OSUD_CHECK_ARG(R % 64 == 0 && C % 64 == 0, "transpose: %dx%d must be multiples of 64", R, C);
+  OSUD_CHECK_ARG(colsum == nullptr || (colpart != nullptr && (size_t)(R / 64) * C <= colpart_elems),
+                 "transpose: the column sums need %d x %d floats of scratch for their partial rows", R / 64, C);
   const dim3 grid(C / 64, R / 64);
+  float* cp = colsum != nullptr ? colpart : nullptr;
   if (prec == OSUD_PREC_BF16)
-    hipLaunchKernelGGL((transpose_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out,
-                       colsum);
+    hipLaunchKernelGGL((transpose_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)in, ld_in, (bf16_t*)out, ld_out, cp);
   else
-    hipLaunchKernelGGL((transpose_kernel<float>), grid, dim3(256), 0, st, (const float*)in, ld_in, (float*)out, ld_out,
-                       colsum);
+    hipLaunchKernelGGL((transpose_kernel<float>), grid, dim3(256), 0, st, (const float*)in, ld_in, (float*)out, ld_out, cp);
   OSUD_HIP(hipGetLastError());
+  if (colsum != nullptr) return launch_colsum_f32(colpart, R / 64, C, colsum, st);  // fixed-order sum of the row blocks' shares
   return OSUD_OK;
 }
 
 int launch_transpose_f32(int prec, const float* in, int ld_in, void* out, int ld_out, int R, int C, float* colsum,
-                         hipStream_t st) {
+                         hipStream_t st, float* colpart, size_t colpart_elems) {
   OSUD_CHECK_ARG(R % 64 == 0 && C % 64 == 0, "transpose: %dx%d must be multiples of 64", R, C);
+  OSUD_CHECK_ARG(colsum == nullptr || (colpart != nullptr && (size_t)(R / 64) * C <= colpart_elems),
+                 "transpose: the column sums need %d x %d floats of scratch for their partial rows", R / 64, C);
   const dim3 grid(C / 64, R / 64);
+  float* cp = colsum != nullptr ? colpart : nullptr;
   if (prec == OSUD_PREC_BF16)
-    hipLaunchKernelGGL((transpose_f32_kernel<bf16_t>), grid, dim3(256), 0, st, in, ld_in, (bf16_t*)out, ld_out, colsum);
+    hipLaunchKernelGGL((transpose_f32_kernel<bf16_t>), grid, dim3(256), 0, st, in, ld_in, (bf16_t*)out, ld_out, cp);
   else
-    hipLaunchKernelGGL((transpose_f32_kernel<float>), grid, dim3(256), 0, st, in, ld_in, (float*)out, ld_out, colsum);
+    hipLaunchKernelGGL((transpose_f32_kernel<float>), grid, dim3(256), 0, st, in, ld_in, (float*)out, ld_out, cp);
   OSUD_HIP(hipGetLastError());
+  if (colsum != nullptr) return launch_colsum_f32(colpart, R / 64, C, colsum, st);
   return OSUD_OK;
 }
 
@@ -588,16 +645,17 @@ int launch_transpose_f32(int prec, const float* in, int ld_in, void* out, int ld
     default: set_error("hidden size %d not built", D); return OSUD_ERR_UNSUPPORTED;    \
   }
 
-int launch_gate_bwd(int prec, const float* dh, const void* br, const float* gate, int ld_ada, void* dbr, float* dgate,
-                    int M, int Tp, int D, hipStream_t st, float* db) {
+int launch_gate_bwd(int prec, const float* dh, const void* br, const float* gate, int ld_ada, void* dbr, float* part,
+                    int M, int Tp, int D, hipStream_t st) {
   OSUD_CHECK_ARG(M % 64 == 0 && Tp % 64 == 0, "gate_bwd: rows must come in blocks of 64");
+  OSUD_CHECK_ARG(part != nullptr, "gate_bwd: no room for the partial rows");
   const dim3 grid(M / 64), block(256);
   if (prec == OSUD_PREC_BF16) {
-#define CALL(V) hipLaunchKernelGGL((gate_bwd_kernel<bf16_t, V>), grid, block, 0, st, dh, (const bf16_t*)br, gate, ld_ada, (bf16_t*)dbr, dgate, Tp, db)
+#define CALL(V) hipLaunchKernelGGL((gate_bwd_kernel<bf16_t, V>), grid, block, 0, st, dh, (const bf16_t*)br, gate, ld_ada, (bf16_t*)dbr, part, Tp)
     OSUD_BY_D(D, CALL)
 #undef CALL
   } else {
-#define CALL(V) hipLaunchKernelGGL((gate_bwd_kernel<float, V>), grid, block, 0, st, dh, (const float*)br, gate, ld_ada, (float*)dbr, dgate, Tp, db)
+#define CALL(V) hipLaunchKernelGGL((gate_bwd_kernel<float, V>), grid, block, 0, st, dh, (const float*)br, gate, ld_ada, (float*)dbr, part, Tp)
     OSUD_BY_D(D, CALL)
 #undef CALL
   }
@@ -606,9 +664,10 @@ int launch_gate_bwd(int prec, const float* dh, const void* br, const float* gate
 }
 
 int launch_ln_mod_bwd(int prec, const float* h, const float* stats, const void* du, const float* ada, int ld_ada,
-                      int off_shift, int off_scale, const float* dh_skip, float* dh_out, float* dada, int M, int Tp, int D,
-                      hipStream_t st, const void* br_next, int off_gate_next, void* dbr, float* db_next, void* dbr8, const float* slot8,
+                      int off_shift, int off_scale, const float* dh_skip, float* dh_out, float* part, int M, int Tp, int D,
+                      hipStream_t st, const void* br_next, int off_gate_next, void* dbr, void* dbr8, const float* slot8,
                       float* amax_part) {
+  OSUD_CHECK_ARG(part != nullptr, "ln_mod_bwd: no room for the partial rows");
   OSUD_CHECK_ARG(M % 64 == 0 && Tp % 64 == 0, "ln_mod_bwd: rows must come in blocks of 64");
   OSUD_CHECK_ARG(dh_skip != nullptr, "ln_mod_bwd: the gradient of the residual stream behind the LayerNorm is required");
   OSUD_CHECK_ARG(slot8 == nullptr || (amax_part != nullptr && br_next != nullptr && prec == OSUD_PREC_BF16 && M / OSUD_LNB_ROWS <= f8_amax_parts()),
@@ -616,7 +675,7 @@ int launch_ln_mod_bwd(int prec, const float* h, const float* stats, const void* 
   OSUD_CHECK_ARG(br_next == nullptr || dbr != nullptr || (dbr8 != nullptr && slot8 != nullptr),
                  "ln_mod_bwd: the gate step needs somewhere to put the branch gradient (bf16 rows, or the e4m3 twin with its scale slot)");
   const dim3 grid(M / OSUD_LNB_ROWS), block(256);
-#define ARGS(T) h, stats, (const T*)du, ada, ld_ada, off_shift, off_scale, dh_skip, dh_out, dada, Tp, (const T*)br_next, off_gate_next, (T*)dbr, db_next, (fp8_t*)dbr8, slot8, amax_part
+#define ARGS(T) h, stats, (const T*)du, ada, ld_ada, off_shift, off_scale, dh_skip, dh_out, part, Tp, (const T*)br_next, off_gate_next, (T*)dbr, (fp8_t*)dbr8, slot8, amax_part
   if (prec == OSUD_PREC_BF16) {
 #define CALL(V)                                                                                                      \
   if (br_next != nullptr) hipLaunchKernelGGL((ln_mod_bwd_kernel<bf16_t, V, true>), grid, block, 0, st, ARGS(bf16_t)); \
@@ -636,19 +695,18 @@ int launch_ln_mod_bwd(int prec, const float* h, const float* stats, const void* 
 }
 
 int launch_final_bwd(const float* h, const float* stats, const float* dout, const float* w, const float* ada, int ld_ada,
-                     int off_shift, int off_scale, float* dh_out, float* dada, float* dw, float* dbias, int N, int T, int Tp,
-                     int D, int C, hipStream_t st, float* scratch, size_t scratch_elems) {
-  OSUD_CHECK_ARG(Tp % 64 == 0 && C <= 4, "final_bwd: bad sizes");
+                     int off_shift, int off_scale, float* dh_out, float* dw, float* dbias, int N, int T, int Tp,
+                     int D, int C, hipStream_t st, float* part) {
+  OSUD_CHECK_ARG(Tp % 64 == 0 && C == 4, "final_bwd: bad sizes (Tp=%d, %d output channels; built for 4)", Tp, C);
+  OSUD_CHECK_ARG(part != nullptr, "final_bwd: no room for the partial rows");
   const dim3 grid(N * Tp / 64), block(256);
-  // weight- and bias-gradient partial sums per block -> fixed-order column sums (scratch: [blocks][4 D + 64] floats: 512 blocks
-  // adding atomically into the same addresses serialised, 8192 of them on the bias's one cache line); without scratch: atomics
-  float* part = (scratch != nullptr && (size_t)grid.x * (4 * D + 64) <= scratch_elems && grid.x >= 64 && C == 4) ? scratch : nullptr;
-#define CALL(V) hipLaunchKernelGGL((final_bwd_kernel<V>), grid, block, 0, st, h, stats, dout, w, ada, ld_ada, off_shift, off_scale, dh_out, dada, dw, dbias, T, Tp, C, part)
+  // every partial sum of a block -> its row of part [blocks][6 D + 64]; dW and the bias gradient by a fixed-order column pass over
+  // the first 4 D + 64 columns here, the per-sample dshift / dscale rows by the caller's row_reduce item
+#define CALL(V) hipLaunchKernelGGL((final_bwd_kernel<V>), grid, block, 0, st, h, stats, dout, w, ada, ld_ada, off_shift, off_scale, dh_out, T, Tp, C, part)
   OSUD_BY_D(D, CALL)
 #undef CALL
   OSUD_HIP(hipGetLastError());
-  if (part != nullptr) return launch_colsum_f32(part, (int)grid.x, 4 * D + 64, dw, st, 4 * D, dbias, 4);
-  return OSUD_OK;
+  return launch_colsum_f32(part, (int)grid.x, 4 * D + 64, dw, st, 4 * D, dbias, 4, 6 * D + 64);
 }
 
 int launch_cond_bwd(int prec, const float* dsb, const float* b, const int64_t* y, int table_rows, float* db_out,
@@ -695,7 +753,7 @@ int launch_unpad_rows(const float* src, int ld_src, float* dst, int cols, int ro
 
 // the same for tall partial-sum slabs (R in the hundreds): 16 row groups x 16 float4 columns per block, fixed-order combine
 // (columns >= split go to out2[c - split], of which only n2 exist: the final layer's bias gradient rides behind its weight gradient)
-__global__ __launch_bounds__(256) void colsum_f32_tall_kernel(const float* __restrict__ a, int R, int C, float* __restrict__ out,
+__global__ __launch_bounds__(256) void colsum_f32_tall_kernel(const float* __restrict__ a, int R, int C /* row stride */, float* __restrict__ out,
                                                               int split, float* __restrict__ out2, int n2) {
   __shared__ float4 part[16][16];
   const int tx = threadIdx.x & 15, tg = threadIdx.x >> 4;
@@ -722,15 +780,25 @@ __global__ __launch_bounds__(256) void colsum_f32_tall_kernel(const float* __res
   }
 }
 
-int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_t st, int split, float* out2, int n2) {
+int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_t st, int split, float* out2, int n2, int ld) {
+  if (ld <= 0) ld = C;
   if (out2 == nullptr) split = C;
-  OSUD_CHECK_ARG(out2 == nullptr || (R_valid >= 64 && C % 64 == 0 && split % 4 == 0 && n2 % 4 == 0), "colsum: bad split");
-  if (R_valid >= 64 && C % 64 == 0) {
-    hipLaunchKernelGGL(colsum_f32_tall_kernel, dim3(C / 64), dim3(256), 0, st, a, R_valid, C, out, split, out2, n2);
+  OSUD_CHECK_ARG(out2 == nullptr || (C % 64 == 0 && split % 4 == 0 && n2 % 4 == 0), "colsum: bad split");
+  OSUD_CHECK_ARG(ld == C || (C % 64 == 0 && ld % 4 == 0), "colsum: a column window needs 64-column blocks");
+  if (C % 64 == 0 && ld % 4 == 0 && (R_valid >= 64 || out2 != nullptr || ld != C)) {
+    hipLaunchKernelGGL(colsum_f32_tall_kernel, dim3(C / 64), dim3(256), 0, st, a, R_valid, ld, out, split, out2, n2);
     OSUD_HIP(hipGetLastError());
     return OSUD_OK;
   }
   hipLaunchKernelGGL(colsum_f32_kernel, dim3((C + 255) / 256), dim3(256), 0, st, a, R_valid, C, out);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+int launch_row_reduce(const RowRedList& L, hipStream_t st) {
+  if (L.count == 0) return OSUD_OK;
+  OSUD_CHECK_ARG(L.D % 64 == 0 && L.ld_ada % 4 == 0, "row_reduce: D=%d, ld=%d", L.D, L.ld_ada);
+  hipLaunchKernelGGL(row_reduce_kernel, dim3(L.D / 64, L.count), dim3(256), 0, st, L);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }

@@ -169,24 +169,25 @@ __global__ void step_begin_kernel(int* state, const int64_t* __restrict__ tmap, 
   if (threadIdx.x == 0) {
     state[1] = cur;
     state[2] = k;
-    state[0] = cur - 1;
+    state[0] = cur - state[6];  // (1: the next step of a loop; 0: the same step again -- osud_sample_repeat)
     state[3] = k + 1;
   }
 }
 
-__global__ void step_init_kernel(int* state, int first, uint64_t seed) {
+__global__ void step_init_kernel(int* state, int first, uint64_t seed, int dec) {
   state[0] = first;
   state[1] = first;
   state[2] = 0;
   state[3] = 0;
   state[4] = (int)(uint32_t)seed;
   state[5] = (int)(uint32_t)(seed >> 32);
+  state[6] = dec;
 }
 
 }  // namespace
 
-int launch_step_init(int* step_state, int first, uint64_t seed, hipStream_t st) {
-  hipLaunchKernelGGL(step_init_kernel, dim3(1), dim3(1), 0, st, step_state, first, seed);
+int launch_step_init(int* step_state, int first, uint64_t seed, hipStream_t st, int dec) {
+  hipLaunchKernelGGL(step_init_kernel, dim3(1), dim3(1), 0, st, step_state, first, seed, dec);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }

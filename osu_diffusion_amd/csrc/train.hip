@@ -55,8 +55,7 @@ int build_transposed(osud_dit* m, hipStream_t st) {
       auto Q8 = [&](void* src, int rows, int cols, void** q, float** dq) -> int {
         if (!*q) OSUD_TRY(dev_alloc(m->owned, q, (size_t)rows * cols, false));
         if (!*dq) OSUD_TRY(dev_alloc(m->owned, dq, (size_t)rows * 4, false));
-        static const bool quant_batched = [] { const char* e = getenv("OSUD_QUANT_BATCH"); return !(e && e[0] == '0'); }();
-        if (cols % 8 == 0 && quant_batched) return quants.add(src, rows, cols, *q, *dq);
+        if (cols % 8 == 0) return quants.add(src, rows, cols, *q, *dq);
         return launch_quantize_rows_bf16(src, rows, cols, *q, *dq, st);
       };
       OSUD_TRY(Q8(b.w_qkv_t, D, 3 * D, &b.w_qkv_t8, &b.dq_qkv_t));
@@ -70,10 +69,9 @@ int build_transposed(osud_dit* m, hipStream_t st) {
   return OSUD_OK;
 }
 
-// OSUD_DEBUG_SYNC=1: synchronise after every stage of the backward pass and name it (fault triage)
+// osud_set_option("debug_sync", 1): synchronise after every stage of the backward pass and name it (fault triage)
 int dbg_sync(hipStream_t st, const char* stage) {
-  static const bool on = [] { const char* e = getenv("OSUD_DEBUG_SYNC"); return e && e[0] == '1'; }();
-  if (!on) return OSUD_OK;
+  if (!opt(OPT_DEBUG_SYNC)) return OSUD_OK;
   fprintf(stderr, "[osud] %s ...", stage);
   fflush(stderr);
   const hipError_t e = hipStreamSynchronize(st);
@@ -108,10 +106,11 @@ int weight_grad(osud_dit* m, const void* dC, int ld_dc, const void* A, int ld_a,
   BwdWs& w = m->bw;
   if (m->prec == OSUD_PREC_BF16) {
     OSUD_TRY(launch_wgrad_tr(dC, ld_dc, A, ld_a, Ny, Nx, M, dW, slabs ? slabs : w.splitk, w.splitk_elems, st));
-    if (db) OSUD_TRY(launch_colsum_bf16(dC, ld_dc, M, Ny, db, st));
+    // (a call on the side stream -- it brings its own slab area -- gets its own scratch for the column sums' partial rows too)
+    if (db) OSUD_TRY(launch_colsum_bf16(dC, ld_dc, M, Ny, db, st, slabs ? w.colpart2 : w.colpart, w.colpart_elems));
     return OSUD_OK;
   }
-  OSUD_TRY(launch_transpose(m->prec, dC, ld_dc, w.tB, M, M, Ny, db, st));
+  OSUD_TRY(launch_transpose(m->prec, dC, ld_dc, w.tB, M, M, Ny, db, st, w.colpart, w.colpart_elems));
   OSUD_TRY(launch_transpose(m->prec, A, ld_a, w.tA, M, M, Nx, nullptr, st));
   return wgrad(m, w.tB, w.tA, Ny, Nx, M, dW, Nx, st);
 }
@@ -158,47 +157,50 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     const int rows = l < L ? 6 * D : 2 * D;
     const size_t off = (size_t)l * 6 * D;
     OSUD_TRY(launch_mask_rows(prec, w.dada + off, dada_te + off * es, N, Np, rows, st, AC));
-    OSUD_TRY(launch_transpose(prec, dada_te + off * es, AC, dada_t + off * Np * es, Np, Np, rows, w.dbada + off, st));
+    OSUD_TRY(launch_transpose(prec, dada_te + off * es, AC, dada_t + off * Np * es, Np, Np, rows, w.dbada + off, st, w.colpart, w.colpart_elems));
     OSUD_TRY(gemm(m, EPI_NONE_F32, dada_t + off * Np * es, Np, w.sb_t, Np, rows, D, Np, G(key + "weight"), D, nullptr, st));
     SegBatch cb(SEG_COPY, prec, st);
     OSUD_TRY(cb.add(w.dbada + off, G(key + "bias"), (size_t)rows / 4));
     return cb.flush();
   };
 
+  // Per-workgroup partial rows of the LayerNorm / gate kernels (kernels.h: RowRedList): slot 2 l = block l's LN1 backward,
+  // 2 l + 1 = its LN2 backward, 2 L = the final layer, 2 L + 1 = the last block's gate step; each (M / 64) x (6 D + 64) floats.  The
+  // fixed-order sums over them are deferred to ONE launch per call (or per phase where a block's adaLN slice needs them at once).
+  const size_t rowpart_stride = (size_t)(M / 64) * (6 * D + 64);
+  auto rowpart = [&](int slot) { return w.rowpart + (size_t)slot * rowpart_stride; };
+  RowRedList rr{};
+  rr.D = D; rr.ld_ada = AC;
+  auto rr_flush = [&]() -> int {
+    const int rc = launch_row_reduce(rr, st);
+    rr.count = 0;
+    return rc;
+  };
+  auto rr_add = [&](const float* part, int stride, int nq_sample, int off0, int off1, int off2, float* bias) -> int {
+    if (rr.count == RowRedList::kMax) OSUD_TRY(rr_flush());
+    const int i = rr.count++;
+    rr.part[i] = part; rr.dada[i] = w.dada; rr.bias[i] = bias; rr.stride[i] = stride; rr.blocks[i] = M / 64; rr.bps[i] = Tp / 64;
+    rr.nq_sample[i] = nq_sample; rr.off[i][0] = off0; rr.off[i][1] = off1; rr.off[i][2] = off2;
+    return OSUD_OK;
+  };
+
   float* dh = m->bw_dh_cur ? w.dhB : w.dhA;
   float* dh_other = m->bw_dh_cur ? w.dhA : w.dhB;
   if (phase_lo == 0) {
-  // ---- accumulators that are filled by atomics
-  // (every phase's small accumulators in ONE launch; the two big ones as plain memsets)
-  OSUD_TRY(zero(w.dada, (size_t)Np * AC * 4));
+  // ---- nothing is accumulated by atomics (kernels.h): every gradient element has one writer -- a GEMM, or a fixed-order sum of
+  // per-workgroup partial rows -- so nothing needs zeroing but the class table, to which the conditioning path ADDS the step's
+  // label rows (one writer per row there too)
   OSUD_TRY(zero(G("y_embedder.embedding_table.weight"), (size_t)m->cfg.table_rows * D * 4));
-  {
-    SegBatch zb(SEG_ZERO, prec, st);
-    OSUD_TRY(zb.add(nullptr, G("final_layer.linear.weight"), (size_t)m->C2 * D / 4));
-    OSUD_TRY(zb.add(nullptr, G("final_layer.linear.bias"), (size_t)m->C2 / 4));
-    for (int l = 0; l < L; ++l) {
-      const std::string p = "blocks." + std::to_string(l) + ".";
-      OSUD_TRY(zb.add(nullptr, G(p + "mlp.fc2.bias"), (size_t)D / 4));
-      OSUD_TRY(zb.add(nullptr, G(p + "mlp.fc1.bias"), (size_t)D));
-      OSUD_TRY(zb.add(nullptr, G(p + "attn.out_proj.bias"), (size_t)D / 4));
-      OSUD_TRY(zb.add(nullptr, G(p + "attn.in_proj_bias"), (size_t)3 * D / 4));
-    }
-    OSUD_TRY(zb.add(nullptr, G("xoc_embedder.mlp.0.bias"), (size_t)D / 4));
-    OSUD_TRY(zb.add(nullptr, G("t_embedder.mlp.2.bias"), (size_t)D / 4));
-    OSUD_TRY(zb.add(nullptr, G("t_embedder.mlp.0.bias"), (size_t)D / 4));
-    OSUD_TRY(zb.add(nullptr, w.dbada, (size_t)AC / 4));
-    OSUD_TRY(zb.flush());
-  }
-
   // ---- final layer
   const LayerSaved& fin = m->saved[(size_t)L];
   dh = w.dhA;
   dh_other = w.dhB;
-  OSUD_TRY(launch_final_bwd(fin.h_in, fin.stats1, dout, m->w_f, m->ada, AC, L * 6 * D, L * 6 * D + D, dh, w.dada,
-                            G("final_layer.linear.weight"), G("final_layer.linear.bias"), N, T, Tp, D, m->C2, st, w.splitk,
-                            w.splitk_elems));  // (the split-K slab area is free until the first weight gradient)
+  OSUD_TRY(launch_final_bwd(fin.h_in, fin.stats1, dout, m->w_f, m->ada, AC, L * 6 * D, L * 6 * D + D, dh,
+                            G("final_layer.linear.weight"), G("final_layer.linear.bias"), N, T, Tp, D, m->C2, st, rowpart(2 * L)));
+    OSUD_TRY(rr_add(rowpart(2 * L) + 4 * D + 64, 6 * D + 64, 2, L * 6 * D, L * 6 * D + D, 0, nullptr));
     OSUD_TRY(dbg_sync(st, "final_bwd"));
     if (per_block_ada) {
+      OSUD_TRY(rr_flush());
       OSUD_TRY(launch_transpose(prec, m->sb, D, w.sb_t, Np, Np, D, nullptr, st));  // silu(b)^T [D][Np], shared by every slice
       OSUD_TRY(ada_slice(L));
       OSUD_TRY(dbg_sync(st, "wgrad ada (final layer)"));
@@ -219,7 +221,8 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     // MLP branch: h_out = h_mid + g2 * (gelu(u2 W1^T + b1) W2^T + b2).  Its gate step (dbr = g2 * dh, dg2, db2) was done
     // by the kernel that produced dh: final_bwd's successor below for the last block, the LN1 backward of block l+1 otherwise.
     if (l == L - 1) {
-      OSUD_TRY(launch_gate_bwd(prec, dh, sv.br2, m->ada + base + 5 * D, AC, w.dbr, w.dada + base + 5 * D, M, Tp, D, st, g_b2));
+      OSUD_TRY(launch_gate_bwd(prec, dh, sv.br2, m->ada + base + 5 * D, AC, w.dbr, rowpart(2 * L + 1), M, Tp, D, st));
+      OSUD_TRY(rr_add(rowpart(2 * L + 1), 2 * D, 1, base + 5 * D, 0, 0, g_b2));
       OSUD_TRY(dbg_sync(st, "gate_bwd mlp"));
     }
     // dz1 = (dbr . W2) * gelu'(z1); in the bf16 tier the fc1 bias gradient (column sums of dz1) rides in the same epilogue
@@ -237,16 +240,6 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
       return launch_wgrad8_tr(P8, ldp, Q8, ldq, Ny, Nx, Mp, dW, s8 ? w.splitk2 : w.splitk, w.splitk_elems, slot(slot_p) + 1, slot(slot_q) + 1,
                               s8 ? s8 : st);
     };
-    // The weight gradients of the block are formed two at a time in grouped launches (wgrad.hip: wgrad_group_kernel -- equal runs
-    // of stages per workgroup over the pair's tiles instead of launches split 7 to 28 ways, a third of the partial-slab bytes, one
-    // combine launch per pair) where the group qualifies (bf16 tier, sides multiples of 256, GPU not shared); otherwise each
-    // follows its data-gradient product as before.  out_proj's weight gradient waits for in_proj's: the attention branch's
-    // gradient has its own buffer (dbr2) so that it is still there.
-    const bool group_wg = prec == OSUD_PREC_BF16 && fused_b1 && D % 256 == 0 && !gemm_dynamic_tiles_on() &&
-                          (getenv("OSUD_WGRAD_GROUP") && getenv("OSUD_WGRAD_GROUP")[0] == '1');  // opt-in: measured neutral (wgrad.hip)
-    // (two groups per block, each right behind the data-gradient product that made its big operand: dz1 -- 201 MB -- and dqkv
-    //  are then still in the Infinity Cache; ONE group of all four at the end of the phase found them cold and ran 2.05 instead
-    //  of 1.85 us per stage: with two 64 KiB stages a slab's fill has one slab of lead, and an HBM fill does not make it)
     // bf16 tier: the four weight gradients of the block leave the data-gradient chain and run on a side stream (their own slab
     // area), each as soon as its gradient operand exists; the chain -- data-gradient GEMMs with the HBM-bound LayerNorm / attention
     // backward kernels between them -- goes on at once, and waits for the side stream only before the kernel that overwrites the
@@ -255,13 +248,15 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     // for the HBM-bound kernels 14.2 -> 13.2 ms (tools/overlap_wgrad_probe.py); the real step 26.2 -> 25.7 ms on one box, 26.0 -> 25.8
     // on another (five alternating pairs, every one in favour).  Less than the stand-in promised: a LayerNorm backward fills every
     // compute unit's registers, so a weight-gradient workgroup only starts where its blocks have finished -- the gain is kernel
-    // heads and tails filling each other, not two kernels sharing compute units.  OSUD_WGRAD_SIDE=0 restores the single stream.
-    const char* side_e = getenv("OSUD_WGRAD_SIDE");  // (read per block: bench.py profiles its per-kernel table on the single stream)
-    const bool side_env = !(side_e && side_e[0] == '0');
-    bool side_on = side_env && prec == OSUD_PREC_BF16 && !f8_train && !group_wg;
+    // heads and tails filling each other, not two kernels sharing compute units.  osud_set_option("wgrad_side_stream", 0) restores
+    // the single stream (same bits: tests/test_gpu_train.py; bench.py takes its per-kernel table there).
+    // (Built, gradients equal to 2e-7, measured neutral and removed: the four products of a block in one or two GROUPED launches --
+    //  equal runs of stages per workgroup, one combine pass per group; DESIGN.md section 4 "round 3".)
+    const bool side_env = opt(OPT_WGRAD_SIDE_STREAM) != 0;  // (read per block)
+    bool side_on = side_env && prec == OSUD_PREC_BF16 && !f8_train;
     // (fp8 training, live steps: the same for the e4m3 weight gradients, with one more join -- the twin of dqkv re-uses the staging
     //  buffer the fc1 weight gradient reads dz1's twin from)
-    bool side8 = side_env && prec == OSUD_PREC_BF16 && f8_live && fused_b1 && Mp % 128 == 0 && !group_wg;
+    bool side8 = side_env && prec == OSUD_PREC_BF16 && f8_live && fused_b1 && Mp % 128 == 0;
     if ((side_on || side8) && w.side == nullptr) {
       bool ok = hipStreamCreateWithFlags(&w.side, hipStreamNonBlocking) == hipSuccess;
       if (!ok) w.side = nullptr;
@@ -337,31 +332,21 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     else
     OSUD_TRY(gemm(m, EPI_NONE_TE, w.dz1, 4 * D, bw.w1_t, 4 * D, Mp, D, 4 * D, w.du, D, nullptr, st));
     OSUD_TRY(dbg_sync(st, "dgrad fc1"));
-    auto wgrad_pair = [&](const WgradItem (&items)[2], const char* what) -> int {
-      bool done = false;
-      OSUD_TRY(launch_wgrad_group(items, 2, Mp, w.splitk, w.splitk_elems, st, &done));
-      if (!done)  // (did not qualify after all, e.g. the partial tiles do not fit the slab area: one by one)
-        for (const WgradItem& it : items) OSUD_TRY(weight_grad(m, it.P, it.ldp, it.Q, it.ldq, it.Ny, it.Nx, Mp, it.out, nullptr, st));
-      return dbg_sync(st, what);
-    };
     if (side8) {  // (enqueued on the side stream behind the fc2 data gradient, above)
     } else if (f8_live && fused_b1 && Mp % 128 == 0) {  // (q8b = dz1's twin, q8a = the MLP branch gradient's: both still in place)
       OSUD_TRY(weight_grad8(m->q8b, 4 * D, 4, sv.u2_8, D, 1, 4 * D, D, G(p + "mlp.fc1.weight")));
       OSUD_TRY(weight_grad8(m->q8a, D, 3, sv.g_8, 4 * D, 2, D, 4 * D, G(p + "mlp.fc2.weight")));
       OSUD_TRY(dbg_sync(st, "wgrad fc1, fc2 (e4m3)"));
-    } else if (group_wg) {
-      const WgradItem items[2] = {{w.dz1, sv.u2, G(p + "mlp.fc1.weight"), 4 * D, D, 4 * D, D},
-                                  {w.dbr, sv.g, G(p + "mlp.fc2.weight"), D, 4 * D, D, 4 * D}};
-      OSUD_TRY(wgrad_pair(items, "wgrad fc1 + fc2 (grouped)"));
-    } else {
-    if (!side_on) OSUD_TRY(wg_mlp());  // (side stream: enqueued right behind the fc2 data gradient, above)
+    } else if (!side_on) {
+      OSUD_TRY(wg_mlp());  // (side stream: enqueued right behind the fc2 data gradient, above)
     }
     // LN2 backward -> dh = grad wrt h_mid, and on the same rows the gate step of the attention branch
     // (h_mid = h_in + g1 * (attn(u1) Wo^T + bo)): dbr = g1 * dh, dg1, dbo
     // (fp8 training: the attention branch's gradient gets its e4m3 twin -- q8c -- and amax from this kernel too)
-    OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_mid, sv.stats2, w.du, m->ada, AC, base + 3 * D, base + 4 * D, dh, dh_other, w.dada,
-                               M, Tp, D, st, sv.br1, base + 2 * D, f8_slim ? nullptr : w.dbr2, g_bo, f8_live ? m->q8c : nullptr, f8_train ? slot(7) : nullptr,
+    OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_mid, sv.stats2, w.du, m->ada, AC, base + 3 * D, base + 4 * D, dh, dh_other, rowpart(2 * l + 1),
+                               M, Tp, D, st, sv.br1, base + 2 * D, f8_slim ? nullptr : w.dbr2, f8_live ? m->q8c : nullptr, f8_train ? slot(7) : nullptr,
                                f8_train ? m->f8_parts + ((size_t)l * kF8Slots + 7) * f8_amax_parts() : nullptr));
+    OSUD_TRY(rr_add(rowpart(2 * l + 1), 4 * D, 3, base + 3 * D, base + 4 * D, base + 2 * D, g_bo));
     OSUD_TRY(dbg_sync(st, "ln2 bwd + gate_bwd attn"));
     std::swap(dh, dh_other);
     if (side_on) {  // dbr2 exists: out_proj's weight gradient starts next to its data gradient
@@ -380,8 +365,8 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     } else if (f8_live && Mp % 128 == 0) {
       OSUD_TRY(weight_grad8(m->q8c, D, 7, sv.ao_8, D, 6, D, D, G(p + "attn.out_proj.weight")));
       OSUD_TRY(dbg_sync(st, "wgrad out_proj (e4m3)"));
-    } else if (!group_wg) {
-    if (!side_on) OSUD_TRY(wg_proj());  // (side stream: enqueued right behind the LN2 backward, above)
+    } else if (!side_on) {
+      OSUD_TRY(wg_proj());  // (side stream: enqueued right behind the LN2 backward, above)
     }
     // (bf16 tier: the in_proj bias gradient is the attention backward's job -- inside the streamed kernel at T = 128, a column-sum
     //  pass over dqkv behind the other kernels; scratch: the split-K slab area, idle between two weight gradients)
@@ -400,7 +385,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
       OSUD_TRY(wg_qkv());
     }
     if (side8) OSUD_TRY(chain_joins_side());  // (q8b: dz1's twin, read by fc1's weight gradient, is overwritten by dqkv's twin next)
-    if (f8_train) OSUD_TRY(launch_colsum_quant_bf16(w.dqkv, Mp, 3 * D, g_bqkv, f8_live ? m->q8b : nullptr, slot(5), st));
+    if (f8_train) OSUD_TRY(launch_colsum_quant_bf16(w.dqkv, Mp, 3 * D, g_bqkv, f8_live ? m->q8b : nullptr, slot(5), st, w.colpart, w.colpart_elems));
     if (side8) {  // q8b = dqkv's twin: in_proj's weight gradient starts next to its data gradient
       OSUD_TRY(side_after(2));
       OSUD_TRY(weight_grad8(m->q8b, 3 * D, 5, sv.u1_8, D, 0, 3 * D, D, G(p + "attn.in_proj_weight"), w.side));
@@ -415,12 +400,8 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     } else if (f8_live && fused_bqkv && Mp % 128 == 0) {  // (q8b = dqkv's twin)
       OSUD_TRY(weight_grad8(m->q8b, 3 * D, 5, sv.u1_8, D, 0, 3 * D, D, G(p + "attn.in_proj_weight")));
       OSUD_TRY(dbg_sync(st, "wgrad in_proj (e4m3)"));
-    } else if (group_wg) {
-      const WgradItem items[2] = {{w.dqkv, sv.u1, G(p + "attn.in_proj_weight"), 3 * D, D, 3 * D, D},
-                                  {w.dbr2, sv.ao, G(p + "attn.out_proj.weight"), D, D, D, D}};
-      OSUD_TRY(wgrad_pair(items, "wgrad in_proj + out_proj (grouped)"));
-    } else {
-    if (!side_on) OSUD_TRY(wg_qkv());  // (side stream: enqueued right behind the attention backward, above)
+    } else if (!side_on) {
+      OSUD_TRY(wg_qkv());  // (side stream: enqueued right behind the attention backward, above)
     }
     if (side_on || side8) OSUD_TRY(chain_joins_side());  // (fp8: the LN1 backward also rewrites q8a, the twin fc2's weight gradient reads)
     // LN1 backward -> dh = grad wrt h_in = grad wrt the output of block l-1, whose MLP gate step rides along
@@ -428,21 +409,25 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
       const LayerSaved& svp = m->saved[(size_t)l - 1];
       const int basep = (l - 1) * 6 * D;
       float* slot_prev = m->f8_slots + ((size_t)(l - 1) * kF8Slots + 3) * 4;  // fp8 training: block l - 1's dbr slot
-      OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_in, sv.stats1, w.du, m->ada, AC, base, base + D, dh, dh_other, w.dada, M, Tp, D,
-                                 st, svp.br2, basep + 5 * D, f8_slim ? nullptr : w.dbr, G("blocks." + std::to_string(l - 1) + ".mlp.fc2.bias"),
+      OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_in, sv.stats1, w.du, m->ada, AC, base, base + D, dh, dh_other, rowpart(2 * l), M, Tp, D,
+                                 st, svp.br2, basep + 5 * D, f8_slim ? nullptr : w.dbr,
                                  f8_live ? m->q8a : nullptr, f8_train ? slot_prev : nullptr,
                                  f8_train ? m->f8_parts + ((size_t)(l - 1) * kF8Slots + 3) * f8_amax_parts() : nullptr));
+      OSUD_TRY(rr_add(rowpart(2 * l), 4 * D, 3, base, base + D, basep + 5 * D, G("blocks." + std::to_string(l - 1) + ".mlp.fc2.bias")));
     } else {
-      OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_in, sv.stats1, w.du, m->ada, AC, base, base + D, dh, dh_other, w.dada, M, Tp, D,
+      OSUD_TRY(launch_ln_mod_bwd(prec, sv.h_in, sv.stats1, w.du, m->ada, AC, base, base + D, dh, dh_other, rowpart(2 * l), M, Tp, D,
                                  st));
+      OSUD_TRY(rr_add(rowpart(2 * l), 2 * D, 2, base, base + D, 0, nullptr));
     }
     OSUD_TRY(dbg_sync(st, "ln1 bwd"));
     std::swap(dh, dh_other);  // dh = grad wrt h_in
     if (per_block_ada) {
+      OSUD_TRY(rr_flush());  // (the slice's modulation-gradient columns are final now; the two bias gradients travel with the phase)
       OSUD_TRY(ada_slice(l));
       OSUD_TRY(dbg_sync(st, "wgrad ada (block)"));
     }
   }
+  OSUD_TRY(rr_flush());  // one launch for every LayerNorm / gate kernel of this call
 
   if (w.side != nullptr && w.side_busy) {  // (not reached: every block joins) the caller's stream owns every gradient again
     OSUD_HIP(hipEventRecord(w.side_ev[3], w.side));
@@ -455,7 +440,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
   // ---- token embedding linear: h0 = e0 We^T + be   (inputs need no gradient)
   {
     float* g_be = G("xoc_embedder.mlp.0.bias");
-    OSUD_TRY(launch_transpose_f32(prec, dh, D, w.tB, Mp, Mp, D, g_be, st));
+    OSUD_TRY(launch_transpose_f32(prec, dh, D, w.tB, Mp, Mp, D, g_be, st, w.colpart, w.colpart_elems));
     OSUD_TRY(launch_transpose(prec, m->e0, m->Ke, w.tA, Mp, Mp, m->Kp, nullptr, st));  // the hi part of a split row
     OSUD_TRY(wgrad(m, w.tB, w.tA, D, m->Kp, Mp, w.dWe, m->Kp, st));
     OSUD_TRY(launch_unpad_rows(w.dWe, m->Kp, G("xoc_embedder.mlp.0.weight"), 384 + m->E, D, st));
@@ -466,7 +451,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
   {
     if (!per_block_ada) {
     OSUD_TRY(launch_mask_rows(prec, w.dada, dada_te, N, Np, AC, st));
-    OSUD_TRY(launch_transpose(prec, dada_te, AC, dada_t, Np, Np, AC, w.dbada, st));
+    OSUD_TRY(launch_transpose(prec, dada_te, AC, dada_t, Np, Np, AC, w.dbada, st, w.colpart, w.colpart_elems));
     OSUD_TRY(launch_transpose(prec, m->sb, D, w.small_t1, Np, Np, D, nullptr, st));  // sb^T [D][Np]
     {
       // one product for every block's adaLN weight gradient; its 6D-row panels land straight in the per-block gradient tensors
@@ -502,12 +487,12 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     OSUD_TRY(dbg_sync(st, "cond bwd"));
     // TimestepEmbedder: tvec = silu(temb W0^T + b0) W2^T + b2
     float *g_bt2 = G("t_embedder.mlp.2.bias"), *g_bt0 = G("t_embedder.mlp.0.bias");
-    OSUD_TRY(launch_transpose(prec, w.db_te, D, w.small_t1, Np, Np, D, g_bt2, st));  // db^T [D][Np]
+    OSUD_TRY(launch_transpose(prec, w.db_te, D, w.small_t1, Np, Np, D, g_bt2, st, w.colpart, w.colpart_elems));  // db^T [D][Np]
     OSUD_TRY(launch_transpose(prec, m->th, D, w.small_t2, Np, Np, D, nullptr, st));  // th^T [D][Np]
     OSUD_TRY(gemm(m, EPI_NONE_F32, w.small_t1, Np, w.small_t2, Np, D, D, Np, G("t_embedder.mlp.2.weight"), D, nullptr, st));
     OSUD_TRY(gemm(m, EPI_NONE_F32, w.db_te, D, m->w_t2_t, D, Np, D, D, w.dth, D, nullptr, st));
     OSUD_TRY(launch_silu_bwd(prec, w.dth, m->z0, w.dz0, (size_t)Np * D, st));
-    OSUD_TRY(launch_transpose(prec, w.dz0, D, w.small_t1, Np, Np, D, g_bt0, st));       // dz0^T [D][Np]
+    OSUD_TRY(launch_transpose(prec, w.dz0, D, w.small_t1, Np, Np, D, g_bt0, st, w.colpart, w.colpart_elems));  // dz0^T [D][Np]
     OSUD_TRY(launch_transpose(prec, m->temb, 256, w.small_t2, Np, Np, 256, nullptr, st));  // temb^T [256][Np]
     OSUD_TRY(gemm(m, EPI_NONE_F32, w.small_t1, Np, w.small_t2, Np, D, 256, Np, G("t_embedder.mlp.0.weight"), 256, nullptr, st));
     OSUD_TRY(dbg_sync(st, "t-embedder"));
@@ -727,7 +712,7 @@ extern "C" int osud_dit_refresh_phases(osud_dit* m, int phase_lo, int phase_hi, 
   QuantBatch quants(false, (hipStream_t)stream);
   m->defer_copy = &copies;
   m->defer_convert = &converts;
-  static const bool quant_batched = [] { const char* e = getenv("OSUD_QUANT_BATCH"); return !(e && e[0] == '0'); }();
+  const bool quant_batched = true;
   if (quant_batched) m->defer_quant = &quants;
   for (auto& kv : items) {
     int64_t shape[2];

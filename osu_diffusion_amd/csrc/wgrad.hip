@@ -119,10 +119,8 @@ struct WgradP {
   size_t split_stride;
   unsigned* queue;  // shared-GPU mode (256x256 geometry, splits > 1): [tile] chunk tickets, [63] finished workgroups; else null
   int chunk;        // chunks per tile (a multiple of split_k)
-  // in-launch split-K combine (GPU not shared, splits > 1): `arrive` = [tile] arrival counters + [255] finished workgroups;
-  // the workgroups of a tile meet on its counter and each sums its share of the tile's rows over all partial slabs into `final`
-  unsigned* arrive;
-  float* final;
+  // (built, the same bits, measured slower and removed: the split-K combine inside this launch -- the workgroups of a tile meeting
+  //  on an arrival counter -- 29.99 vs 28.73 ms per training step: DESIGN.md section 4 "round 2")
   // one (tile, split) unit per workgroup, plain mode: units in split-major order, one contiguous run per XCD (workgroup L runs on
   // XCD L % 8), so that the ~32 workgroups of an XCD walk the SAME token rows -- one or two splits, all of their tiles -- and share
   // every stage's operand rows through that XCD's L2.  With blockIdx = (tile, split) an XCD held 4-5 tiles of each of the splits
@@ -356,289 +354,6 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
     }
     store_tile(ty, tx);
   }
-  if (p.arrive != nullptr) {
-    // ---- in-launch split-K combine (replaces the separate splitk_reduce launch and its kernel boundary).  One tile per
-    // workgroup here (gridDim.x == ntiles), all gridDim.x * split_k <= #CUs workgroups resident (one per CU by LDS).
-    // Publish: every wave drains its slab stores, one lane releases at agent scope and counts in; consume: ONE relaxed poll
-    // loop, ONE agent acquire, then plain loads (cdna_hip_programming.md Guideline 16: the per-XCD L2s are not coherent and
-    // a CU's L1 is never refreshed by other CUs' stores).  The sum runs over the splits in index order: deterministic.
-    const int tile = first /* the one tile this workgroup computed: the XCD-remapped index of blockIdx.x */, ty = tile / ntx, tx = tile % ntx, S = p.split_k;  // (sidx: this workgroup's split, see the top)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // restated behind the write-back where the compiler cannot drop it
-      __hip_atomic_fetch_add(p.arrive + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      unsigned spins = 0;
-      while (__hip_atomic_load(p.arrive + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)S) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++spins > (1u << 26)) __builtin_trap();  // a workgroup of this tile never ran: fail loudly, never hang
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
-    __syncthreads();
-    const int r0 = (int)((long)sidx * G::BM / S), r1 = (int)((long)(sidx + 1) * G::BM / S);
-    constexpr int C4 = G::BN / 4;  // float4 columns per tile row
-    const float* slab0 = p.out + (size_t)(ty * G::BM) * p.Nx + (size_t)tx * G::BN;
-    float* fin = p.final + (size_t)(ty * G::BM) * p.Nx + (size_t)tx * G::BN;
-    for (int idx = tid; idx < (r1 - r0) * C4; idx += G::NT) {
-      const int row = r0 + idx / C4, c4 = idx % C4;
-      if (ty * G::BM + row >= p.Ny || tx * G::BN + c4 * 4 >= p.Nx) continue;  // edge tile
-      const size_t o = (size_t)row * p.Nx + (size_t)c4 * 4;
-      float4 a = *reinterpret_cast<const float4*>(slab0 + o);
-      for (int s2 = 1; s2 < S; ++s2) {
-        const float4 b = *reinterpret_cast<const float4*>(slab0 + (size_t)s2 * p.split_stride + o);
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-      }
-      *reinterpret_cast<float4*>(fin + o) = a;
-    }
-    if (tid == 0) {  // the last workgroup out re-arms the counters for the next launch that borrows this slot
-      const unsigned done = __hip_atomic_fetch_add(p.arrive + 255, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (done == gridDim.x * gridDim.y - 1)
-        for (int i = 0; i < 256; ++i) __hip_atomic_store(p.arrive + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------------
-// Grouped weight gradients: the (up to four) weight-gradient products of one DiT block -- in_proj, out_proj, fc1, fc2: 27 + 9 +
-// 36 + 36 = 108 tiles of 256 x 256 for DiT-B, all contracting over the same M token rows -- in ONE launch whose workgroups all
-// run the same number of stages.  Launched one by one, each product is split over the token axis until it fills the chip (7 to
-// 28 ways: 18 to 73 stages per workgroup, one prologue / epilogue / 256 KiB partial slab each, 262 MB of partial slabs per block
-// and a combine launch per product).  Here the flattened work -- tiles x (M / 64) stages -- is cut into runs of U = ceil(total /
-// #CUs) stages:
-//   * "full ranges": range r < nfull covers stages [r U, (r + 1) U) of EVERY tile, one workgroup per (range, tile): the
-//     workgroups of a range walk the same token rows in step, in XCD-contiguous runs of tiles, and share each stage's operand
-//     rows through their XCD's L2 exactly like the split-major order of the single-product launch;
-//   * the remaining rem = M / 64 - nfull U stages of every tile are strung together tile after tile and cut into runs of U again
-//     (a workgroup there finishes one tile's tail and continues with the next tile's: up to segmax partial tiles).
-// Every (workgroup, tile) piece leaves one fp32 partial tile in `ws`; wgrad_group_reduce_kernel sums a tile's pieces in a fixed
-// order (ranges first, then the tail pieces by workgroup) and writes the rows that exist: deterministic, one combine launch.
-struct WgradProb {
-  const bf16_t* P;
-  const bf16_t* Q;
-  float* out;
-  int ldp, ldq, Ny, Nx, tile0, ntx;  // tile0: index of the problem's first tile in the group's flattened tile list
-};
-struct WgradGroupP {
-  WgradProb prob[4];
-  int nprob, M, ntiles, U, nfull, rem, segmax;
-  float* ws;
-};
-
-template <int WY, int WX, int RY, int RX>
-__global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_group_kernel(WgradGroupP p) {
-  using G = WGeo<WY, WX, RY, RX>;
-  static_assert(G::BM == 256 && G::BN == 256 && G::NSTAGE == 2, "grouped form: 256 x 256 tiles, two 64 KiB stages");
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wy = wave / WX, wx = wave % WX;
-  const int frow = lane & 31, fhalf = lane >> 5;
-  // workgroup -> run index: XCD-contiguous (block b runs on XCD b % 8; consecutive runs = consecutive tiles of one range)
-  int w;
-  {
-    const int total = gridDim.x, L = blockIdx.x, q = total >> 3, r = total & 7, xcd = L & 7, idx = L >> 3;
-    w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int nfull_w = p.nfull * p.ntiles;
-  // ---- this workgroup's segments: (tile, first stage, stage count), k = 0 .. nseg - 1
-  const int v = w - nfull_w;                       // run index inside the tail space (w >= nfull_w)
-  const long ubeg = (long)v * p.U, uend_all = (long)p.ntiles * p.rem;
-  const long uend = ubeg + p.U < uend_all ? ubeg + p.U : uend_all;
-  const int t0 = w < nfull_w ? w % p.ntiles : (p.rem > 0 ? (int)(ubeg / p.rem) : 0);
-  auto seg = [&](int k, int& tile, int& st0, int& nst) -> bool {
-    if (w < nfull_w) {
-      tile = t0; st0 = (w / p.ntiles) * p.U; nst = p.U;
-      return k == 0;
-    }
-    tile = t0 + k;
-    if (tile >= p.ntiles) return false;
-    const long lo = ubeg > (long)tile * p.rem ? ubeg : (long)tile * p.rem;
-    const long hi = uend < (long)(tile + 1) * p.rem ? uend : (long)(tile + 1) * p.rem;
-    st0 = p.nfull * p.U + (int)(lo - (long)tile * p.rem);
-    nst = (int)(hi - lo);
-    return hi > lo;
-  };
-  auto prob_of = [&](int tile) -> int {
-    int q = 0;
-#pragma unroll
-    for (int i = 1; i < 4; ++i)
-      if (i < p.nprob && tile >= p.prob[i].tile0) q = i;
-    return q;
-  };
-
-  const uint32_t lds0 = (uint32_t)(size_t)(lds_void*)smem;
-  const int tok0 = 8 * fhalf + ((lane & 15) >> 2);
-  const int swy = G::swz(G::ROWY, tok0), swx = G::swz(G::ROWX, tok0);
-  const int fbyte = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
-  uint32_t ya[RY], xa[RX];
-#pragma unroll
-  for (int i = 0; i < RY; ++i) ya[i] = lds0 + tok0 * G::ROWY + (((wy * RY + i) ^ swy)) * 64 + fbyte;
-#pragma unroll
-  for (int j = 0; j < RX; ++j) xa[j] = lds0 + G::YB + tok0 * G::ROWX + (((wx * RX + j) ^ swx)) * 64 + fbyte;
-  const uint32_t patch = lds0 + G::NSTAGE * G::STAGE + wave * 4096;
-  uint32_t pw[4];
-#pragma unroll
-  for (int g = 0; g < 4; ++g) pw[g] = patch + frow * 128 + (((2 * g + fhalf) ^ (frow & 7)) << 4);
-  const uint32_t pr = patch + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
-
-  // ---- issue cursor (runs NSTAGE - 1 stages ahead of the arithmetic, across segment boundaries)
-  // per-lane source position of this wave's LDS-DMA pieces inside a 64-token stage: (token row, 16-byte chunk) -- the byte offset
-  // depends on the problem's leading dimensions, so it is formed per issue (one multiply-add per piece) instead of being held
-  uint32_t dma_tok[G::PPW], dma_chk[G::PPW];
-#pragma unroll
-  for (int qq = 0; qq < G::PPW; ++qq) {
-    const int piece = wave * G::PPW + qq;
-    const bool isY = piece * 1024 < G::YB;
-    const int rowb = isY ? G::ROWY : G::ROWX;
-    const int pb2 = isY ? piece * 1024 : piece * 1024 - G::YB;
-    const int lpr = rowb / 16, cidx = pb2 / 16 + lane;
-    const int tok = cidx / lpr, pos = cidx - tok * lpr;
-    dma_tok[qq] = (uint32_t)tok;
-    dma_chk[qq] = (uint32_t)((pos ^ (G::swz(rowb, tok) << 2)) * 16);
-  }
-  int ik = 0, is = 0, i_tile = 0, i_st0 = 0, i_nst = 0;
-  const char *i_gp = nullptr, *i_gq = nullptr;
-  uint32_t i_ldp = 0, i_ldq = 0;
-  bool i_valid = seg(0, i_tile, i_st0, i_nst);
-  auto bind_issue = [&]() {  // the issue cursor entered segment ik: panel bases and leading dimensions of its problem
-    const int q = prob_of(i_tile);
-    const bf16_t* P = p.prob[0].P; const bf16_t* Q = p.prob[0].Q;
-    int ldp = p.prob[0].ldp, ldq = p.prob[0].ldq, tile0 = p.prob[0].tile0, ntx = p.prob[0].ntx;
-#pragma unroll
-    for (int i = 1; i < 4; ++i)
-      if (q == i) { P = p.prob[i].P; Q = p.prob[i].Q; ldp = p.prob[i].ldp; ldq = p.prob[i].ldq; tile0 = p.prob[i].tile0; ntx = p.prob[i].ntx; }
-    const int lt = i_tile - tile0, ty = lt / ntx, tx = lt - ty * ntx;
-    i_ldp = (uint32_t)__builtin_amdgcn_readfirstlane(ldp * 2);
-    i_ldq = (uint32_t)__builtin_amdgcn_readfirstlane(ldq * 2);
-    // (wave-uniform by construction; readfirstlane makes it provable: the panel bases are "s" operands of the LDS-DMA asm)
-    auto uniform = [](const char* ptr) {
-      const uint64_t vv = (uint64_t)(size_t)ptr;
-      const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)vv), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(vv >> 32));
-      return reinterpret_cast<const char*>((size_t)(((uint64_t)hi << 32) | lo));
-    };
-    i_gp = uniform(reinterpret_cast<const char*>(P) + (size_t)i_st0 * BKT * i_ldp + (size_t)ty * G::BM * 2);
-    i_gq = uniform(reinterpret_cast<const char*>(Q) + (size_t)i_st0 * BKT * i_ldq + (size_t)tx * G::BN * 2);
-  };
-  if (i_valid) bind_issue();
-  int issued = 0, consumed = 0;
-  auto issue_next = [&]() {
-    if (!i_valid) return;
-    {
-      const char* gp = i_gp + (size_t)is * BKT * i_ldp;
-      const char* gq = i_gq + (size_t)is * BKT * i_ldq;
-      const uint32_t stage_lds = lds0 + (uint32_t)((issued % G::NSTAGE) * G::STAGE);
-#pragma unroll
-      for (int qq = 0; qq < G::PPW; ++qq) {
-        const int piece = wave * G::PPW + qq;  // wave-uniform
-        const bool isY = piece * 1024 < G::YB;
-        const char* sbase = isY ? gp : gq;
-        const uint32_t voff = dma_tok[qq] * (isY ? i_ldp : i_ldq) + dma_chk[qq];
-        const uint32_t dst = stage_lds + (uint32_t)__builtin_amdgcn_readfirstlane(piece * 1024);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(dst) : "memory");
-      }
-    }
-    ++issued;
-    if (++is == i_nst) {
-      is = 0;
-      ++ik;
-      i_valid = seg(ik, i_tile, i_st0, i_nst);
-      if (i_valid) bind_issue();
-    }
-  };
-  issue_next();  // NSTAGE - 1 = 1 stage ahead
-
-  f32x16 acc[RY][RX];
-  int c_tile, c_st0, c_nst;
-  for (int k = 0; seg(k, c_tile, c_st0, c_nst); ++k) {
-#pragma unroll
-    for (int i = 0; i < RY; ++i)
-#pragma unroll
-      for (int j = 0; j < RX; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int st = 0; st < c_nst; ++st) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      issue_next();
-      const uint32_t so = (uint32_t)((consumed % G::NSTAGE) * G::STAGE);
-      TFrag<RY, RX> f0, f1;
-      read_frags<RY, RX, 0, G::ROWY, G::ROWX>(f0, ya, xa, so);
-      read_frags<RY, RX, 1, G::ROWY, G::ROWX>(f1, ya, xa, so);
-      OSUD_WG_WAIT(12);
-      mma_frags<RY, RX>(acc, f0);
-      read_frags<RY, RX, 2, G::ROWY, G::ROWX>(f0, ya, xa, so);
-      OSUD_WG_WAIT(12);
-      mma_frags<RY, RX>(acc, f1);
-      read_frags<RY, RX, 3, G::ROWY, G::ROWX>(f1, ya, xa, so);
-      OSUD_WG_WAIT(12);
-      mma_frags<RY, RX>(acc, f0);
-      OSUD_WG_WAIT(0);
-      mma_frags<RY, RX>(acc, f1);
-      ++consumed;
-    }
-    // partial tile -> ws slot (whole 256 x 256 tile, row-major with ld 256; the reduce pass knows which rows / columns exist)
-    const int slot = w < nfull_w ? w : nfull_w + v * p.segmax + k;
-    float* outp = p.ws + (size_t)slot * (G::BM * G::BN);
-#pragma unroll
-    for (int i = 0; i < RY; ++i) {
-      const int y0 = wy * RY * 32 + i * 32 + (lane >> 3);
-#pragma unroll
-      for (int j = 0; j < RX; ++j) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 vv;
-          vv[0] = acc[i][j][4 * g + 0]; vv[1] = acc[i][j][4 * g + 1]; vv[2] = acc[i][j][4 * g + 2]; vv[3] = acc[i][j][4 * g + 3];
-          ds_write16(pw[g], vv);
-        }
-        f32x4 t[4];
-        t[0] = ds_read16f<0>(pr);
-        t[1] = ds_read16f<1024>(pr);
-        t[2] = ds_read16f<2048>(pr);
-        t[3] = ds_read16f<3072>(pr);
-        OSUD_WG_WAIT(0);
-        const int x = wx * RX * 32 + j * 32 + 4 * (lane & 7);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) store4(outp + (size_t)(y0 + 8 * q) * G::BN + x, t[q][0], t[q][1], t[q][2], t[q][3]);
-      }
-    }
-  }
-}
-
-// one workgroup per (tile, sixteenth of its rows): out = sum of the tile's partial tiles in a fixed order
-__global__ __launch_bounds__(256) void wgrad_group_reduce_kernel(WgradGroupP p) {
-  const int tile = blockIdx.x, part = blockIdx.y;  // part: 16 rows of 256
-  int q = 0;
-#pragma unroll
-  for (int i = 1; i < 4; ++i)
-    if (i < p.nprob && tile >= p.prob[i].tile0) q = i;
-  const WgradProb& pb = p.prob[q];
-  const int lt = tile - pb.tile0, ty = lt / pb.ntx, tx = lt - ty * pb.ntx;
-  const int nfull_w = p.nfull * p.ntiles;
-  int w0 = 0, w1 = -1;
-  if (p.rem > 0) {
-    w0 = (int)(((long)tile * p.rem) / p.U);
-    w1 = (int)((((long)tile + 1) * p.rem - 1) / p.U);
-  }
-  for (int e = threadIdx.x; e < 16 * 64; e += 256) {  // float4 elements of this part
-    const int row = part * 16 + e / 64, c4 = e % 64;
-    const int y = ty * 256 + row, x = tx * 256 + c4 * 4;
-    if (y >= pb.Ny || x >= pb.Nx) continue;
-    const size_t o = (size_t)row * 256 + (size_t)c4 * 4;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = 0; r < p.nfull; ++r) {
-      const float4 b = *reinterpret_cast<const float4*>(p.ws + (size_t)(r * p.ntiles + tile) * 65536 + o);
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
-    for (int vv = w0; vv <= w1; ++vv) {
-      const int first_tile = (int)(((long)vv * p.U) / p.rem);
-      const float4 b = *reinterpret_cast<const float4*>(p.ws + (size_t)(nfull_w + vv * p.segmax + (tile - first_tile)) * 65536 + o);
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
-    *reinterpret_cast<float4*>(pb.out + (size_t)y * pb.Nx + x) = a;
-  }
 }
 
 
@@ -818,9 +533,10 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(Wgrad8P p) {
   }
 }
 
-// column sums of a bf16 [M][N] matrix: out[c] += sum_m a[m][c]   (bias gradients).  HBM-bound: a workgroup sweeps
+// column sums of a bf16 [M][N] matrix: out[c] = sum_m a[m][c]   (bias gradients).  HBM-bound: a workgroup sweeps
 // 256 rows x 256 columns with 16-byte loads (32 lanes = one 512-byte row segment, 8 rows per pass, 4 passes in
-// flight), combines its 8 row groups through LDS and issues one atomic per column.
+// flight), combines its 8 row groups through LDS and writes its share to out[row block][N]: the launcher's fixed-order
+// column pass adds the row blocks (float atomics made the sum depend on the order of arrival).
 // QUANT (fp8 training): the same pass also writes the matrix's e4m3 twin (value x slot[0], the slot's delayed scale) and records this
 // step's amax in slot[2] (one atomic per workgroup) -- dqkv is read once for its bias gradient AND its quantisation.
 constexpr int CS_ROWS = 256;
@@ -875,7 +591,7 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
     float sum = 0.f;
 #pragma unroll
     for (int g = 0; g < 8; ++g) sum += part[g][t];
-    atomicAdd(out + col, sum);
+    out[(size_t)blockIdx.y * N + col] = sum;
   }
   if constexpr (QUANT) {
     amax = wave_max(amax);
@@ -903,9 +619,7 @@ int num_cus_w() {
     if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n[dev] = prop.multiProcessorCount;
     if (n[dev] <= 0) n[dev] = 256;
   }
-  // OSUD_WGRAD_CUS=<n> (experiments): size the weight-gradient launches for n compute units (the rest stay free for another stream)
-  static const int cap = [] { const char* e = getenv("OSUD_WGRAD_CUS"); return e ? atoi(e) : 0; }();
-  return cap > 0 && cap < n[dev] ? cap : n[dev];
+  return n[dev];
 }
 
 // counter sets of the chunk queues (64 words each: [tile] tickets, [63] finished workgroups), re-armed by the last workgroup out
@@ -921,21 +635,6 @@ unsigned* queue_slot() {
     g_queue_pool[dev] = pool;
   }
   return g_queue_pool[dev] + 64 * (seq.fetch_add(1) % kQueueSlots);
-}
-
-// counter sets of the in-launch combine (256 words: [tile] arrivals, [255] finished workgroups), re-armed by the last workgroup out
-constexpr int kArriveSlots = 64;
-unsigned* g_arrive_pool[kMaxDevices] = {};
-unsigned* arrive_slot() {
-  static std::atomic<unsigned> seq{0};
-  const int dev = cur_device_w();
-  if (!g_arrive_pool[dev]) {
-    unsigned* pool = nullptr;
-    if (hipMalloc(&pool, kArriveSlots * 256 * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemset(pool, 0, kArriveSlots * 256 * sizeof(unsigned)) != hipSuccess) return nullptr;
-    g_arrive_pool[dev] = pool;
-  }
-  return g_arrive_pool[dev] + 256 * (seq.fetch_add(1) % kArriveSlots);
 }
 
 template <int WY, int WX, int RY, int RX> int launch_wg(const WgradP& p, hipStream_t st) {
@@ -984,8 +683,7 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
     return (double)Ny * Nx / ((double)t * bm * bn) * ((double)t * s / ((double)rounds * cus));
   };
   int geo = big ? 0 : 3, tiles = big ? t256 : (Ny / 128) * (Nx / 128);  // 0: 256x256, 1: 256x192, 2: 192x256, 3: 128x128
-  static const bool narrow_on = [] { const char* e = getenv("OSUD_WGRAD_192"); return !(e && e[0] == '0'); }();
-  if (big && narrow_on && !gemm_dynamic_tiles_on()) {
+  if (big && !gemm_dynamic_tiles_on()) {
     int t0 = 0, t1 = 0, t2 = 0;
     const double s0 = score(256, 256, &t0);
     const double s1 = Nx % 192 == 0 ? score(256, 192, &t1) : 0.0, s2 = Ny % 192 == 0 ? score(192, 256, &t2) : 0.0;
@@ -1006,27 +704,13 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
     p.chunk = S * per_wg;
     p.queue = queue_slot();
   }
-  // OSUD_WGRAD_COMBINE=1: combine the partial slabs inside the launch (the workgroups of a tile meet on an arrival counter and each
-  // sums its share of the rows) instead of the separate splitk_reduce launch.  Built, correct (same bits) and measured SLOWER:
-  // 29.99 vs 28.73 ms per DiT-B training step (+26 us per launch: the tile's workgroups finish their slabs at different times and
-  // the early ones sit in the poll, the release/acquire pair costs ~3.5 us, and the reduce has lost its own full-chip launch).
-  // The separate launch stays the default; this matches the guide's "cut at every split-K seam" verdict.
-  static const bool combine_on = [] { const char* e = getenv("OSUD_WGRAD_COMBINE"); return e && e[0] == '1'; }();
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  const bool capturing = hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
-  if (S > 1 && p.queue == nullptr && combine_on && !capturing && tiles < 255 && tiles * S <= num_cus_w()) {
-    p.arrive = arrive_slot();
-    p.final = out;
-  }
-  {  // one unit per workgroup in the plain mode: XCD-contiguous unit order (OSUD_WGRAD_XCD=0: the (tile, split) grid order)
-    static const bool xcd_on = [] { const char* e = getenv("OSUD_WGRAD_XCD"); return !(e && e[0] == '0'); }();
-    p.xcd_units = (xcd_on && S > 1 && p.queue == nullptr && p.arrive == nullptr) ? 1 : 0;
-  }
+  // one unit per workgroup in the plain mode: XCD-contiguous unit order (WgradP::xcd_units)
+  p.xcd_units = (S > 1 && p.queue == nullptr) ? 1 : 0;
   if (geo == 0) OSUD_TRY((launch_wg<2, 4, 4, 2>(p, st)));
   else if (geo == 1) OSUD_TRY((launch_wg<4, 2, 2, 3>(p, st)));
   else if (geo == 2) OSUD_TRY((launch_wg<2, 4, 3, 2>(p, st)));
   else OSUD_TRY((launch_wg<2, 2, 2, 2>(p, st)));
-  if (S > 1 && p.arrive == nullptr) OSUD_TRY(launch_splitk_reduce(ws, S, (size_t)Ny * Nx, out, (size_t)Ny * Nx, st));
+  if (S > 1) OSUD_TRY(launch_splitk_reduce(ws, S, (size_t)Ny * Nx, out, (size_t)Ny * Nx, st));
   return OSUD_OK;
 }
 
@@ -1059,73 +743,25 @@ int launch_wgrad8_tr(const void* P8, int ldp, const void* Q8, int ldq, int Ny, i
   return OSUD_OK;
 }
 
-// The weight gradients of one block in one launch (see wgrad_group_kernel).  Returns OSUD_OK with *done = false when the group does
-// not qualify (then the caller launches the products one by one): bf16 tier only, every side a multiple of 256, the GPU not
-// shared with collectives (the ticket-queue schedules live in the single-product kernel), the partial tiles fit `ws`.
-int launch_wgrad_group(const WgradItem* items, int n, int M, float* ws, size_t ws_elems, hipStream_t st, bool* done) {
-  *done = false;
-  // OSUD_WGRAD_GROUP=1 selects the grouped form (read per call: A/B runs, tests).  Built, tested (gradients equal the single
-  // launches to 2e-7) and measured NEUTRAL on MI355X, in both groupings tried -- all four products of a block in one launch at
-  // the end of its phase: 444 + 23 us (kernel + combine) per block; two pairs, each behind the data-gradient product that made
-  // its big operand: 2 x 216 + 2 x 19 us -- against 4 launches + 4 combines = ~468 us: 26.36 / 26.41 vs 26.40 / 26.25 ms per
-  // training step in alternating runs.  Every product of this kind settles at ~1.07-1.1 PFLOP/s whatever its decomposition
-  // (DESIGN.md section 4, round 3), so the single-product launches, which also know the shared-GPU ticket queues, stay the default.
-  const char* env = getenv("OSUD_WGRAD_GROUP");
-  if (!(env && env[0] == '1') || n < 1 || n > 4 || M % BKT != 0 || gemm_dynamic_tiles_on()) return OSUD_OK;
-  WgradGroupP p{};
-  int tiles = 0;
-  for (int i = 0; i < n; ++i) {
-    const WgradItem& it = items[i];
-    if (it.Ny % 256 || it.Nx % 256 || it.ldp % 8 || it.ldq % 8) return OSUD_OK;
-    p.prob[i] = WgradProb{(const bf16_t*)it.P, (const bf16_t*)it.Q, it.out, it.ldp, it.ldq, it.Ny, it.Nx, tiles, it.Nx / 256};
-    tiles += (it.Ny / 256) * (it.Nx / 256);
-  }
-  const int cus = num_cus_w(), ST = M / BKT;
-  if (tiles < 8 || tiles > 2 * cus) return OSUD_OK;  // (tiny groups: the single launches do as well; huge ones need no split)
-  const long total = (long)tiles * ST;
-  int U = (int)((total + cus - 1) / cus);
-  if (U < 8) U = 8;
-  int nfull, rem, tailw;
-  for (;; ++U) {  // the run count must not exceed the CUs (one persistent workgroup per CU)
-    nfull = ST / U;
-    rem = ST - nfull * U;
-    tailw = rem > 0 ? (int)(((long)tiles * rem + U - 1) / U) : 0;
-    if (nfull * tiles + tailw <= cus) break;
-  }
-  const int segmax = rem > 0 ? (U + rem - 1) / rem + 1 : 1;
-  const size_t slots = (size_t)nfull * tiles + (size_t)tailw * segmax;
-  if (slots * 65536 > ws_elems) return OSUD_OK;
-  p.nprob = n; p.M = M; p.ntiles = tiles; p.U = U; p.nfull = nfull; p.rem = rem; p.segmax = segmax; p.ws = ws;
-  using G = WGeo<2, 4, 4, 2>;
-  const size_t lds = (size_t)G::NSTAGE * G::STAGE + (size_t)G::NW * 4096;
-  static bool attr_set = false;
-  if (!attr_set) {
-    OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_group_kernel<2, 4, 4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((wgrad_group_kernel<2, 4, 4, 2>), dim3(nfull * tiles + tailw), dim3(G::NT), lds, st, p);
-  OSUD_HIP(hipGetLastError());
-  hipLaunchKernelGGL(wgrad_group_reduce_kernel, dim3(tiles, 16), dim3(256), 0, st, p);
-  OSUD_HIP(hipGetLastError());
-  *done = true;
-  return OSUD_OK;
-}
-
-int launch_colsum_bf16(const void* a, int ld, int M, int N, float* out, hipStream_t st) {
+int launch_colsum_bf16(const void* a, int ld, int M, int N, float* out, hipStream_t st, float* part, size_t part_elems) {
   OSUD_CHECK_ARG(N % 8 == 0 && ld % 8 == 0, "colsum: N=%d and ld=%d must be multiples of 8", N, ld);
-  hipLaunchKernelGGL(colsum_bf16_kernel<false>, dim3((N + 255) / 256, (M + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, st,
-                     (const bf16_t*)a, ld, M, N, out, (fp8_t*)nullptr, (float*)nullptr);
+  const int rb = (M + CS_ROWS - 1) / CS_ROWS;
+  OSUD_CHECK_ARG(part != nullptr && (size_t)rb * N <= part_elems, "colsum: %d x %d floats of scratch needed for the row blocks' shares", rb, N);
+  hipLaunchKernelGGL(colsum_bf16_kernel<false>, dim3((N + 255) / 256, rb), dim3(256), 0, st,
+                     (const bf16_t*)a, ld, M, N, part, (fp8_t*)nullptr, (float*)nullptr);
   OSUD_HIP(hipGetLastError());
-  return OSUD_OK;
+  return launch_colsum_f32(part, rb, N, out, st);
 }
 
 // column sums + e4m3 twin (q8 may be null: record the amax only) + amax of a DENSE bf16 [M][N] matrix (ld == N) in one pass
-int launch_colsum_quant_bf16(const void* a, int M, int N, float* out, void* q8, float* slot, hipStream_t st) {
+int launch_colsum_quant_bf16(const void* a, int M, int N, float* out, void* q8, float* slot, hipStream_t st, float* part, size_t part_elems) {
   OSUD_CHECK_ARG(N % 8 == 0 && slot != nullptr, "colsum_quant: N=%d must be a multiple of 8 and a scale slot is needed", N);
-  hipLaunchKernelGGL(colsum_bf16_kernel<true>, dim3((N + 255) / 256, (M + CS_ROWS - 1) / CS_ROWS), dim3(256), 0, st,
-                     (const bf16_t*)a, N, M, N, out, (fp8_t*)q8, slot);
+  const int rb = (M + CS_ROWS - 1) / CS_ROWS;
+  OSUD_CHECK_ARG(part != nullptr && (size_t)rb * N <= part_elems, "colsum_quant: %d x %d floats of scratch needed for the row blocks' shares", rb, N);
+  hipLaunchKernelGGL(colsum_bf16_kernel<true>, dim3((N + 255) / 256, rb), dim3(256), 0, st,
+                     (const bf16_t*)a, N, M, N, part, (fp8_t*)q8, slot);
   OSUD_HIP(hipGetLastError());
-  return OSUD_OK;
+  return launch_colsum_f32(part, rb, N, out, st);
 }
 
 }  // namespace osud

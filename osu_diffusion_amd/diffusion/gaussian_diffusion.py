@@ -404,15 +404,16 @@ class GaussianDiffusion:
 
     # ------------------------------------------------------------------ loops
     def _native_loop(self, dit, use_cfg, mode, eta, img, clip_denoised, model_kwargs, step_noise, seed,
-                     first_step=None, last_step=0, in_place=False, inpaint=None):
-        """Steps first_step..last_step in the library: one captured hipGraph replayed per step."""
+                     first_step=None, last_step=0, in_place=False, inpaint=None, repeat=None):
+        """Steps first_step..last_step in the library: one captured hipGraph replayed per step.  repeat=k: the step at index
+        first_step k times over (osud_sample_repeat) instead of a descending run."""
         kw = dict(model_kwargs or {})
         cfg_scale = float(kw.pop("cfg_scale")) if use_cfg else -1.0
         mask = kw.pop("attn_mask", None)
         o, c, y = kw.pop("o"), kw.pop("c"), kw.pop("y")
         assert not kw, f"unexpected model kwargs {sorted(kw)}"
         first_step = self.num_timesteps - 1 if first_step is None else int(first_step)
-        n_steps = first_step - int(last_step) + 1
+        n_steps = first_step - int(last_step) + 1 if repeat is None else int(repeat)
         x = img if in_place else img.detach().clone().float().contiguous()
         assert x.is_cuda and x.dtype == th.float32 and x.is_contiguous()
         N, T = dit._check_inputs(x, th.zeros(x.shape[0], dtype=th.long, device=x.device), o, c, y, mask)
@@ -424,12 +425,34 @@ class GaussianDiffusion:
         ip, ip_keep = inpaint.native(x) if inpaint is not None else (None, None)
         keep = (x, o, c, y, m, step_noise, ip_keep)  # alive until the stream has consumed them
         with th.cuda.device(x.device):
-            _lib.check(_lib.lib().osud_sample_loop_inpaint(
-                handle, self._sched.handle, mode, float(eta), _lib.ptr(x), _lib.ptr(o), _lib.ptr(c), _lib.ptr(y), _lib.ptr(m),
-                N, T, cfg_scale, int(bool(clip_denoised)), first_step, int(last_step), _lib.ptr(step_noise), int(seed), ip,
-                _lib.stream_ptr(x.device)))
+            if repeat is None:
+                _lib.check(_lib.lib().osud_sample_loop_inpaint(
+                    handle, self._sched.handle, mode, float(eta), _lib.ptr(x), _lib.ptr(o), _lib.ptr(c), _lib.ptr(y), _lib.ptr(m),
+                    N, T, cfg_scale, int(bool(clip_denoised)), first_step, int(last_step), _lib.ptr(step_noise), int(seed), ip,
+                    _lib.stream_ptr(x.device)))
+            else:
+                _lib.check(_lib.lib().osud_sample_repeat(
+                    handle, self._sched.handle, mode, float(eta), _lib.ptr(x), _lib.ptr(o), _lib.ptr(c), _lib.ptr(y), _lib.ptr(m),
+                    N, T, cfg_scale, int(bool(clip_denoised)), first_step, int(repeat), _lib.ptr(step_noise), int(seed), ip,
+                    _lib.stream_ptr(x.device)))
         self._keepalive = keep
         return x
+
+    def p_sample_repeat(self, model, x, iters, t=0, clip_denoised=True, denoised_fn=None, model_kwargs=None, step_noise=None, seed=0):
+        """`iters` applications of p_sample at the SAME step index t, i.e. the reference's refine pass (sample.py:186-205:
+        `for _ in range(refine_iters): img = diffusion.p_sample(model.forward_with_cfg, img, t=0, ...)["sample"]`, run after the
+        weights of --refine-ckpt were loaded) as ONE native call: the captured sampler step replayed with the step counter held
+        still.  Returns the new image; `x` is left alone.  Falls back to the per-call loop where the native path does not apply
+        (a Python denoised_fn other than InPaintMask, a module that is not the native DiT)."""
+        dit, use_cfg = self._native_ok(model, x, denoised_fn, None)
+        if dit is None or th.is_grad_enabled():
+            img = x
+            for _ in range(int(iters)):
+                tt = th.full((img.shape[0],), int(t), device=img.device, dtype=th.long)
+                img = self.p_sample(model, img, tt, clip_denoised=clip_denoised, denoised_fn=denoised_fn, model_kwargs=model_kwargs)["sample"]
+            return img
+        return self._native_loop(dit, use_cfg, _lib.SAMPLER_P, 0.0, x, clip_denoised, model_kwargs, step_noise, seed or 0,
+                                 first_step=int(t), inpaint=denoised_fn, repeat=int(iters))
 
     def run_steps(self, model, x, model_kwargs, first_step, last_step=0, sampler="p", eta=0.0, clip_denoised=True,
                   step_noise=None, seed=None, denoised_fn=None):

@@ -182,7 +182,7 @@ def exchange_table_rows(table_grad, labels, group=None):
     import torch.distributed as dist
 
     W = dist.get_world_size(group)
-    if table_grad.is_cuda and labels.numel() * W <= 4096:
+    if table_grad.is_cuda and labels.numel() * W <= 4096 and W <= 64:  # (osud_table_rows_apply merges at most 64 rank lists)
         # GPU: two native launches per side (csrc/exchange.hip) instead of ~25 tensor-library ones -- same sums, same order
         L = _lib.lib()
         rows_n, D = table_grad.shape
@@ -255,6 +255,14 @@ def backward_with_overlapped_allreduce(model, dout, group=None, force=False, on_
             h.wait()
     if on_blocks_reduced is not None:
         on_blocks_reduced([(lo, hi) for _, _, lo, hi in blocks] + [(f_lo, f_hi)])
+    if comm is not None:
+        # the library's communicator and torch's process group are two RCCL communicators on one device: their kernels must not be
+        # in flight together (ranks could schedule them in different orders and deadlock), so the tail reductions are joined
+        # BEFORE torch's group runs the row all-gathers below
+        for h in tail_handles:
+            if h is not None:
+                h.wait()
+        tail_handles = []
     if active:
         _, _, t_lo, t_hi = next(s for s in tail if s[0] == "table")
         rows = dict(model.named_parameters())["y_embedder.embedding_table.weight"].shape[0]
@@ -360,7 +368,13 @@ class NativeTrainer:
     made here unless given) tracks it with decay 0.9999."""
 
     def __init__(self, model, diffusion, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ema_decay=0.9999,
-                 ema=None, group=None, broadcast_init=True, shard_optimizer=None, wire_dtype=None):
+                 ema=None, group=None, broadcast_init=True, shard_optimizer=False, wire_dtype=None, force_phased=False,
+                 overlap_gather=True, native_comm=False):
+        """shard_optimizer: ZeRO-1 exchange (reduce-scatter / sharded AdamW + EMA / all-gather) instead of the all-reduce.
+        wire_dtype=torch.bfloat16: gradients rounded to bf16 for the reduce-scatter.  overlap_gather: with the sharded optimizer,
+        the master all-gather runs under the next step's forward.  native_comm: the exchange goes through the library's own RCCL
+        communicator (C ABI) instead of torch.distributed.  force_phased: run the multi-GPU schedule (phased backward, per-slice
+        collectives) even on one rank -- tests and one-GPU rehearsals of the distributed path."""
         from .diffusion import gaussian_diffusion as gd
 
         assert diffusion.model_mean_type == gd.ModelMeanType.EPSILON
@@ -384,39 +398,33 @@ class NativeTrainer:
         self.step_count = 0
         self.table_step = 0
         self.embed_only = False
-        self.force_phased = os.environ.get("OSUD_FORCE_PHASED", "0") == "1"  # exercise the phased path on 1 GPU
-        # one GPU, OSUD_ADAMW_OVERLAP=1: the HBM-bound AdamW+EMA of a block's slice runs on a side stream under the MFMA-bound
-        # backward of the blocks in front of it (same arithmetic, same result).  Measured worth 0.2 % — off by default, the
-        # one-call backward keeps the adaLN weight gradients in a single batched GEMM
-        self.overlap_adamw = os.environ.get("OSUD_ADAMW_OVERLAP", "0") == "1"
-        self.gated_optimizer = os.environ.get("OSUD_ADAMW_GATED", "0") == "1"  # (experiment: see _optimizer_under_next_forward)
+        self.force_phased = bool(force_phased)
         self._side = None
         # ZeRO-1 between the two halves of the gradient exchange: every finished slice is reduce-SCATTERED
         # (rank r receives the sum of its 1/world shard), AdamW + EMA run on that shard only (1/world of the 6.1 GB the optimizer
         # streams per step), and the updated master weights are all-GATHERED.  Same bytes on the wire as the all-reduce, same
-        # results (the sum of a shard is formed once instead of world times).  OSUD_ZERO1=1 / shard_optimizer=True.
-        # wire_dtype=torch.bfloat16 (OSUD_GRAD_WIRE=bf16) halves the reduce-scatter bytes: gradients are rounded to bf16 for
-        # the exchange and summed by RCCL in bf16 (reduced precision of the AVERAGED gradient, 2^-9 relative: opt-in).
-        self.shard_optimizer = (os.environ.get("OSUD_ZERO1", "0") == "1") if shard_optimizer is None else bool(shard_optimizer)
-        if wire_dtype is None and os.environ.get("OSUD_GRAD_WIRE", "") == "bf16":
-            wire_dtype = torch.bfloat16
+        # results (the sum of a shard is formed once instead of world times).
+        # wire_dtype=torch.bfloat16 halves the reduce-scatter bytes: gradients are rounded to bf16 for the exchange and summed by
+        # RCCL in bf16 (reduced precision of the AVERAGED gradient, 2^-9 relative: opt-in).
+        self.shard_optimizer = bool(shard_optimizer)
         self.wire_dtype = wire_dtype
         self._shard_buf = None
         self._ema_stale = False
         # sharded optimizer: gather the updated master shards and re-pack them block by block UNDER the next step's forward
-        # (OSUD_ZERO1_OVERLAP=0: gather everything, then re-pack, then go on)
-        self.overlap_gather = os.environ.get("OSUD_ZERO1_OVERLAP", "1") != "0"
+        # (False: gather everything, then re-pack, then go on)
+        self.overlap_gather = bool(overlap_gather)
         self._gate_events = []
+        self._gates_set = False
         import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 and "OSUD_GEMM_DYNAMIC" not in os.environ:
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             # collectives will share the compute units with the backward: let multi-round GEMM launches queue their tiles
             _lib.check(_lib.lib().osud_set_gemm_dynamic_tiles(1))
-        # OSUD_NATIVE_COMM=1: the gradient / parameter exchange goes through the library's own RCCL communicator (C ABI:
-        # osud_comm_init, osud_allreduce_grads, ...), bootstrapped once over torch's process group; the class-table row exchange
-        # and the scalar bookkeeping stay on torch.distributed.  (world 1 with OSUD_FORCE_PHASED=1 exercises every call.)
+        # native_comm: the gradient / parameter exchange goes through the library's own RCCL communicator (C ABI: osud_comm_init,
+        # osud_allreduce_grads, ...), bootstrapped once over torch's process group; the class-table row exchange and the scalar
+        # bookkeeping stay on torch.distributed.  (world 1 with force_phased exercises every call.)
         self.comm = None
-        if os.environ.get("OSUD_NATIVE_COMM", "0") == "1" and dist.is_available() and dist.is_initialized():
+        if native_comm and dist.is_available() and dist.is_initialized():
             from .comm import NativeComm
 
             self.comm = NativeComm.from_torch_distributed(group, device=self.arena.flat.device)
@@ -475,9 +483,6 @@ class NativeTrainer:
 
             import torch.distributed as dist
             single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1)
-            if single and self.overlap_adamw and not self.force_phased:
-                self._backward_with_overlapped_adamw(dout)
-                return terms
             if self.shard_optimizer and (not single or self.force_phased) and dist.is_available() and dist.is_initialized():
                 self._backward_sharded(dout)
                 return terms
@@ -486,67 +491,9 @@ class NativeTrainer:
             if done:
                 self._adamw(_complement(done, self.arena.total), scale)
                 self._refresh()
-            elif single and self.gated_optimizer and not self.force_phased:
-                self._optimizer_under_next_forward(scale)
             else:
                 self.optimizer_step(scale)
         return terms
-
-    def _optimizer_under_next_forward(self, scale):
-        """One GPU, OSUD_ADAMW_GATED=1 (experiment): the HBM-bound AdamW + EMA and the re-pack of a block's weights run on a side stream
-        in forward order, and the NEXT step's forward waits per block (osud_dit_forward_gate) -- the optimizer of the late blocks runs
-        under the MFMA-bound forward of the early ones.  Same arithmetic, same result."""
-        arena, depth, dev = self.arena, self.model.depth, self.arena.flat.device
-        L_ = _lib.lib()
-        blocks, tail = overlap_slices(arena, depth)
-        _, _, f_lo, f_hi = next(s for s in tail if s[0] == "final")
-        by_phase = {i + 1: (blocks[i][2], blocks[i][3]) for i in range(depth)}
-        by_phase[depth + 1] = (f_lo, f_hi)
-        self._advance()
-        self._adamw(_complement(sorted(by_phase.values()), arena.total), scale)
-        h_model = self.model._handle
-        with torch.cuda.device(dev):
-            _lib.check(L_.osud_dit_refresh_phases(h_model, 0, 0, _lib.stream_ptr(dev)))
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
-        main = torch.cuda.current_stream(dev)
-        self._side.wait_stream(main)
-        self._gate_events = []
-        with torch.cuda.stream(self._side):
-            for ph in range(1, depth + 2):
-                self._adamw([by_phase[ph]], scale)
-                with torch.cuda.device(dev):
-                    _lib.check(L_.osud_dit_refresh_phases(h_model, ph, ph, C.c_void_p(self._side.cuda_stream)))
-                ev = torch.cuda.Event()
-                ev.record(self._side)
-                self._gate_events.append(ev)
-                _lib.check(L_.osud_dit_forward_gate(h_model, ph, C.c_void_p(ev.cuda_event)))
-        self.ema._uploaded = {}
-
-    def _backward_with_overlapped_adamw(self, dout):
-        """Single GPU: phased backward on the current stream; as soon as a block's phase is enqueued its (final) gradient
-        slice is handed to AdamW+EMA on a side stream.  The masters / moments / EMA of a block are touched by nothing else
-        until the re-pack at the end, which waits for the side stream."""
-        model, dev = self.model, self.arena.flat.device
-        if self._side is None:
-            self._side = torch.cuda.Stream(device=dev)
-        main = torch.cuda.current_stream(dev)
-        blocks, _ = overlap_slices(self.arena, model.depth)
-        self._advance()
-        dout = native_backward(model, dout, phases=(0, 0))
-        done = []
-        for p in range(1, model.depth + 1):
-            native_backward(model, dout, phases=(p, p))
-            _, _, lo, hi = blocks[model.depth - p]
-            ev = main.record_event()
-            with torch.cuda.stream(self._side):
-                self._side.wait_event(ev)
-                self._adamw([(lo, hi)], 1.0)
-            done.append((lo, hi))
-        native_backward(model, dout, phases=(model.depth + 1, model.depth + 1))
-        self._adamw(_complement(done, self.arena.total), 1.0)
-        main.wait_stream(self._side)
-        self._refresh()
 
     def _backward_sharded(self, dout):
         """Phased backward with the sharded optimizer in the middle of the gradient exchange:
@@ -590,31 +537,39 @@ class NativeTrainer:
         _, _, t_lo, t_hi = next(s for s in tail if s[0] == "table")
         rows = dict(model.named_parameters())["y_embedder.embedding_table.weight"].shape[0]
         exchange_table_rows(arena.grads[t_lo:t_hi].view(rows, -1), model._train_keep[4], group)
-        # ---- optimizer: own shards from the scatter buffer, everything else replicated
+        # ---- optimizer: own shards from the scatter buffer, everything else replicated.  Every update is enqueued before the first
+        # gather: collectives of one communicator complete in issue order, so the gathers below are issued in FORWARD order (block 0
+        # .. L-1, then the final layer) and phase p's weights depend on the gathers up to p only
         self._advance()
-        scale, off, own, gathers = 1.0 / W, 0, [], []
-        for lo, hi, per, bulk_hi in plans:
+        scale, off, own, shards = 1.0 / W, 0, [], {}
+        phase_of = [depth + 1] + [depth - p + 1 for p in range(1, depth + 1)]  # plans[i] -> phase: final layer, then blocks L-1 .. 0
+        for i, (lo, hi, per, bulk_hi) in enumerate(plans):
             if per > 0:
                 a, b = lo + r * per, lo + (r + 1) * per
                 g = self._shard_buf[off:off + per]
                 self._adamw_range(a, b, g if wire is None else g.float(), scale)
                 own.append((lo, bulk_hi))
-                gathers.append(_all_gather_into(arena.flat[lo:bulk_hi], arena.flat[a:b], group, self.comm))
+                shards[phase_of[i]] = (lo, bulk_hi, a, b)
             off += per
         self._adamw(_complement(own, arena.total), scale)
         self._ema_stale = True  # every rank's EMA is current only on its own shards (and the replicated parts)
+        forward_order = list(range(1, depth + 1)) + [depth + 1]
+        by_phase = {}
+        for ph in forward_order:
+            if ph in shards:
+                lo, bulk_hi, a, b = shards[ph]
+                by_phase[ph] = _all_gather_into(arena.flat[lo:bulk_hi], arena.flat[a:b], group, self.comm)
         if not self.overlap_gather:
-            for h, fin in gathers:
+            for h, fin in by_phase.values():
                 h.wait()
                 if fin is not None:
                     fin()
             self._refresh()
             return
-        # ---- the all-gather of the updated masters under the NEXT step's forward.  The gathers were issued above in the order the
-        # phases of the backward finished (final layer, block L-1 .. 0); each one's completion and the re-pack of its phase go to a
-        # side stream, and the next forward waits per phase (osud_dit_forward_gate): block 0's kernels start as soon as block 0's
-        # weights are in place while the later blocks' shards are still on the wire.  Phase 0 (embedders, conditioning path, class
-        # table: replicated, updated by every rank above) is re-packed on the compute stream right away.
+        # ---- the all-gather of the updated masters under the NEXT step's forward: each gather's completion and the re-pack of its
+        # phase go to a side stream, and the next forward waits per phase (osud_dit_forward_gate): block 0's kernels start as soon as
+        # block 0's weights are in place while the later blocks' shards are still on the wire.  Phase 0 (embedders, conditioning path,
+        # class table: replicated, updated by every rank above) is re-packed on the compute stream right away.
         dev = arena.flat.device
         L_ = _lib.lib()
         if self._side is None:
@@ -624,18 +579,9 @@ class NativeTrainer:
         with torch.cuda.device(dev):
             _lib.check(L_.osud_dit_refresh_phases(h_model, 0, 0, _lib.stream_ptr(dev)))
         self._side.wait_stream(main)  # the optimizer's writes (own shards + replicated parts) precede every re-pack
-        phase_of = [depth + 1] + [depth - p + 1 for p in range(1, depth + 1)]  # plans[i] -> phase: final layer, then blocks L-1 .. 0
-        by_phase = {}
-        gi = 0
-        for i, (lo, hi, per, bulk_hi) in enumerate(plans):
-            if per > 0:
-                by_phase[phase_of[i]] = gathers[gi]
-                gi += 1
-            else:
-                by_phase[phase_of[i]] = None
         self._gate_events = []
         with torch.cuda.stream(self._side):
-            for ph in list(range(1, depth + 1)) + [depth + 1]:  # forward order
+            for ph in forward_order:
                 g = by_phase.get(ph)
                 if g is not None:
                     h, fin = g
@@ -646,8 +592,9 @@ class NativeTrainer:
                     _lib.check(L_.osud_dit_refresh_phases(h_model, ph, ph, C.c_void_p(self._side.cuda_stream)))
                 ev = torch.cuda.Event()
                 ev.record(self._side)
-                self._gate_events.append(ev)  # (kept alive until the next exchange)
+                self._gate_events.append(ev)  # (kept alive until the gates are cleared: finish_exchange / the next exchange)
                 _lib.check(L_.osud_dit_forward_gate(h_model, ph, C.c_void_p(ev.cuda_event)))
+        self._gates_set = True
         self.ema._uploaded = {}  # its masters changed behind torch's back
 
     def _allreduce_async(self, t):
@@ -672,6 +619,29 @@ class NativeTrainer:
         reads the masters or the packed weights -- checkpoints, evaluation with the model, tests -- calls this first."""
         if self._side is not None:
             torch.cuda.current_stream(self.arena.flat.device).wait_stream(self._side)
+        self._clear_gates()
+
+    def _clear_gates(self):
+        """The forward gates hold raw event handles owned by self._gate_events: once the stream is ordered behind the side stream
+        (or the trainer goes away) they are taken out of the model handle, so that no later forward -- evaluation, sampling, another
+        stream -- waits on an event that has been destroyed."""
+        if getattr(self, "_gates_set", False):
+            h = getattr(self.model, "_handle", None)
+            if h is not None:
+                L_ = _lib.lib()
+                for ph in range(0, self.model.depth + 2):
+                    L_.osud_dit_forward_gate(h, ph, None)
+            self._gates_set = False
+        self._gate_events = []
+
+    def __del__(self):
+        try:
+            if getattr(self, "_gates_set", False):
+                if self._side is not None:
+                    self._side.synchronize()
+                self._clear_gates()
+        except Exception:  # interpreter shutdown: the library may be gone already
+            pass
 
     def sync_sharded_state(self):
         """Sharded optimizer: bring the moments and the EMA of every shard to every rank (checkpoints and EMA evaluation need the

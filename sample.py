@@ -190,10 +190,10 @@ def main(args):
     save_sequence(to_seq(samples))
     if args.refine_ckpt is not None:  # sample.py:186-205: repeated t=0 steps with the refine model
         model.load_state_dict(find_model(args.refine_ckpt))
-        for _ in range(args.refine_iters if n else 0):
-            t = torch.tensor([0] * samples.shape[0], device=device)
-            samples = diffusion.p_sample(model.forward_with_cfg, samples, t, clip_denoised=True,
-                                         model_kwargs=model_kwargs)["sample"]
+        if n:  # (refine_iters x p_sample at t = 0 in one native call: the captured step replayed, no host round trip per iteration)
+            with torch.no_grad():
+                samples = diffusion.p_sample_repeat(model.forward_with_cfg, samples, args.refine_iters, t=0, clip_denoised=True,
+                                                    model_kwargs=model_kwargs)
         save_sequence(to_seq(samples), args.refine_iters)
     if world > 1:
         import torch.distributed as dist

@@ -723,6 +723,19 @@ def g12_cli_toy():
         out.update({tag + ":T": T, tag + ":steps": steps, tag + ":final": samples, tag + ":x": sx, tag + ":o": so, tag + ":c": sc})
         if plot_time is not None:
             out[tag + ":plot_time"] = plot_time
+        if tag == "trim250":
+            # sample.py:186-205 on the same run: --refine-ckpt's weights into the SAME model object, then refine_iters = 10 calls of
+            # p_sample at t = 0 on the loop's result (both halves of the doubled batch, mask and all) -> fixture g15_refine_cli
+            rseed = 22
+            sd_r = mo.seeded_state_dict(shape, rseed)
+            ref.load_state_dict(sd_r)
+            img = final
+            for _ in range(10):
+                img = dref.p_sample(ref.forward_with_cfg, img, torch.tensor([0] * img.shape[0]), clip_denoised=True, model_kwargs=kw)["sample"]
+            print(f"  {tag}: refine pass moved the result by {(img - final).abs().max().item():.3e}")
+            save("g15_refine_cli", shape=np.array([shape.depth, shape.hidden, shape.heads, shape.num_classes]), wseed=wseed, wsum=checksum(sd),
+                 refine_wseed=rseed, refine_wsum=checksum(sd_r), label=label, style_id=5, cfg_scale=4.0, seed=0, steps=steps, plot_time=plot_time,
+                 T=T, final=samples, refined=img.chunk(2, dim=0)[0], refine_iters=10)
     save("g12_cli_toy", shape=np.array([shape.depth, shape.hidden, shape.heads, shape.num_classes]), wseed=wseed, wsum=checksum(sd),
          label=label, style_id=5, cfg_scale=4.0, seed=0, **out)
 
@@ -874,9 +887,55 @@ def g14_timestep_sampler():
     save("g14_timestep_sampler", ts_hist=ts_hist, loss_hist=loss_hist, **out)
 
 
+def g15_refine():
+    """The refine pass of sample.py:186-205: after the sampling loop the model's weights are replaced by a second checkpoint's
+    (`--refine-ckpt`) and the result goes through `refine_iters` = 10 calls of `diffusion.p_sample(model.forward_with_cfg, img,
+    t = 0, clip_denoised=True)` -- the spaced diffusion's step index 0 (model timestep 0), no noise (nonzero_mask = 0).  Two cases:
+    the whole re-enactment on the tiny model ("20"-step loop with weights A, refine with weights B), and the refine pass alone at
+    DiT-B geometry (12 blocks, T = 128) from windows with a little noise.  Stored: the image before the pass and after 1 / 5 / 10
+    iterations."""
+    print("G15 refine pass (p_sample at t = 0, repeated, second weight set)")
+    for tag, shape, wseed, rseed, n, T, resp, with_loop in [("tiny", TINY, 11, 12, 2, 64, "20", True), ("dit_b", BASE, 16, 17, 2, 128, "250", False)]:
+        sd_a, sd_b = mo.seeded_state_dict(shape, wseed), mo.seeded_state_dict(shape, rseed)
+        (x0, o, c), y = synthetic_windows(n, T, shape.num_classes, seed=7, train_offsets=False)
+        o, c = torch.cat([o, o]), torch.cat([c, c])
+        y = torch.cat([y, torch.full_like(y, shape.num_classes)])
+        kw = dict(o=o, c=c, y=y, cfg_scale=4.0, attn_mask=None)
+        dref = ref_create_diffusion(resp, noise_schedule="squaredcos_cap_v2")
+        ora = do.create_schedule(resp, "squaredcos_cap_v2")
+        ref = ref_model_for(shape, sd_a)
+        torch.manual_seed(31)
+        if with_loop:
+            z = torch.randn(n, 2, T)
+            z = torch.cat([z, z])
+            torch.manual_seed(32)
+            img = dref.p_sample_loop(ref.forward_with_cfg, z.shape, z, clip_denoised=True, model_kwargs=kw, device="cpu")
+        else:
+            z = (x0 + 0.05 * torch.randn(n, 2, T)).clamp(-1, 1)
+            z = torch.cat([z, z])
+            img = z
+        start = img.clone()
+        ref.load_state_dict(sd_b)  # sample.py:189-190
+        snaps = {}
+        mine = start.clone()
+        fn = lambda xx, tt: mo.forward_with_cfg(sd_b, shape, xx, tt, o, c, y, 4.0)  # noqa: E731
+        tmap = torch.from_numpy(ora.timestep_map)
+        for it in range(1, 11):
+            t = torch.tensor([0] * img.shape[0])
+            img = dref.p_sample(ref.forward_with_cfg, img, t, clip_denoised=True, model_kwargs=kw)["sample"]
+            mine = do.p_sample_step(ora, fn(mine, tmap[t]), mine, t, torch.zeros_like(mine))["sample"]
+            if it in (1, 5, 10):
+                snaps[f"after_{it}"] = img.clone()
+        close(mine, img, 2e-5, f"refine {tag}")
+        print(f"  refine {tag}: moved by {(img - start).abs().max().item():.3e} over 10 iterations")
+        save(f"g15_refine_{tag}", shape=np.array([shape.depth, shape.hidden, shape.heads, shape.num_classes]), wseed=wseed, wsum=checksum(sd_a),
+             refine_wseed=rseed, refine_wsum=checksum(sd_b), z=z, o=o, c=c, y=y, start=start, respacing=resp, cfg_scale=4.0,
+             loop_noise_seed=32 if with_loop else -1, **snaps)
+
+
 if __name__ == "__main__":
     steps = [g1_schedules, g2_embeddings, g3_forward, g5_step, g6_loop, g7_training, g9_init_and_keys, g9_windows, g10_curves, g11_inpaint,
-             g3_forward_dit_b, g7_training_dit_b, g6_long_loops, g6_loop_p1000_dit_b, g12_cli_toy, g13_export, g14_timestep_sampler]
+             g3_forward_dit_b, g7_training_dit_b, g6_long_loops, g6_loop_p1000_dit_b, g12_cli_toy, g13_export, g14_timestep_sampler, g15_refine]
     only = set(sys.argv[1:])  # e.g. `make_golden.py g10_curves` regenerates one family
     for fn in steps:
         if not only or fn.__name__ in only:

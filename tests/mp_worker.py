@@ -27,11 +27,17 @@ def batch():
     return x, o, c, y, t, noise
 
 
+def trainer_kw():
+    """Schedule switches of the worker's trainer, set by the test that launches it (the library itself reads no such variables)."""
+    return dict(force_phased=os.environ.get("OSUD_TEST_FORCE_PHASED", "0") == "1",
+                native_comm=os.environ.get("OSUD_TEST_NATIVE_COMM", "0") == "1")
+
+
 def run(rank, world, steps=2, zero1=False, wire=None, full_state=False):
     # every rank starts from DIFFERENT weights: the constructor's rank-0 broadcast must make them equal
     model = build(100 + rank)
     tr = NativeTrainer(model, create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True), lr=1e-3,
-                       shard_optimizer=zero1, wire_dtype=wire)
+                       shard_optimizer=zero1, wire_dtype=wire, **trainer_kw())
     x, o, c, y, t, noise = batch()
     per = 8 // world
     sl = slice(rank * per, (rank + 1) * per)
@@ -55,7 +61,8 @@ if __name__ == "__main__":
         # train.py's save path with the sharded optimizer: checkpoint() alone on the saving rank must refuse (it would enter an
         # all-gather nobody else joins); after the collective sync on EVERY rank, rank 0 alone writes the file, then the barrier
         model = build(100 + rank)
-        tr = NativeTrainer(model, create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True), lr=1e-3, shard_optimizer=True)
+        tr = NativeTrainer(model, create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True), lr=1e-3, shard_optimizer=True,
+                           **trainer_kw())
         x, o, c, y, t, noise = batch()
         per = 8 // world
         sl = slice(rank * per, (rank + 1) * per)

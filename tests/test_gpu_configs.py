@@ -149,12 +149,11 @@ def test_full_size_sampling_properties(dit_b):
     noise = torch.randn(6, 2 * n, 2, T_, device=DEV)
     import os
     outs = []
-    for graph in ("0", "1"):
-        os.environ["OSUD_NO_GRAPH"] = graph
-        s = z.clone()
-        d.run_steps(dit_b.forward_with_cfg, s, kw, first_step=999, last_step=994, step_noise=noise)
-        outs.append(s)
-    os.environ["OSUD_NO_GRAPH"] = "0"
+    for graph in (1, 0):
+        with _lib.option("sample_graph", graph):
+            s = z.clone()
+            d.run_steps(dit_b.forward_with_cfg, s, kw, first_step=999, last_step=994, step_noise=noise)
+            outs.append(s)
     assert torch.equal(outs[0], outs[1]) and torch.isfinite(outs[0]).all()  # graph replay == eager
     assert float(outs[0].min()) >= -40 and float(outs[0].max()) <= 40
 

@@ -149,12 +149,12 @@ def test_attention_core(prec, tol, T_, masked, N, H, hd):
 @pytest.mark.parametrize("N,H,T_,stream,hd", [(3, 2, 64, "1", 64), (24, 12, 128, "1", 64), (24, 12, 128, "0", 64), (2, 2, 256, "1", 64),
                                               (2, 2, 320, "1", 64), (2, 3, 256, "1", 72), (2, 3, 256, "0", 72), (34, 16, 256, "1", 72),
                                               (2, 2, 128, "1", 72)])
-def test_attention_core_backward(prec, tol, N, H, T_, stream, hd, monkeypatch):
+def test_attention_core_backward(prec, tol, N, H, T_, stream, hd, osud_option):
     """osud_op_attention_bwd against torch autograd of softmax(q k^T / sqrt(hd)) v on the same (rounded) operands.  N*H = 288 heads
     at T = 128 is more than one per compute unit: the persistent streamed kernel runs its double-buffered loop (a second head on
-    32 of the workgroups); OSUD_ATTN_BWD_STREAM=0 selects the one-workgroup-per-head kernel; T = 320 the tiled one.  head_dim 72 at
+    32 of the workgroups); option attn_bwd_kernel = 1 selects the one-workgroup-per-head kernel; T = 320 the tiled one.  head_dim 72 at
     T = 256 is DiT-XL's shape: its own streamed kernel (34 x 16 = 544 heads: up to three per workgroup), or the tiled one with "0"."""
-    monkeypatch.setenv("OSUD_ATTN_BWD_STREAM", stream)
+    osud_option("attn_bwd_kernel", 0 if stream == "1" else 1)
     D = H * hd
     M = N * T_
     torch.manual_seed(N * 1000 + T_)
@@ -181,6 +181,7 @@ def test_attention_core_backward(prec, tol, N, H, T_, stream, hd, monkeypatch):
     assert maxdiff(g.cpu(), ref.cpu()) < tol * max(1.0, float(ref.abs().max())), (N, H, T_)
 
 
+@pytest.mark.selfcheck
 @pytest.mark.parametrize("N,H,T_,hd", [(96, 12, 128, 64), (34, 16, 256, 72)])
 def test_attention_head_queue_equals_fixed_stride(N, H, T_, hd):
     """Shared-GPU mode (osud_set_gemm_dynamic_tiles(1), what data-parallel trainers switch on): the persistent attention kernels draw
@@ -343,14 +344,14 @@ def test_chained_loop_final_coordinates_fp32(tag):
     eta = float(fx["eta"])
     finals = {}
     for graph in ("graph", "eager"):
-        os.environ["OSUD_NO_GRAPH"] = "0" if graph == "graph" else "1"
+        _lib.set_option("sample_graph", 1 if graph == "graph" else 0)
         try:
             if eta < 0:
                 fin = d.p_sample_loop(m.forward_with_cfg, z.shape, z, model_kwargs=kw, step_noise=T(fx["noises"]))
             else:
                 fin = d.ddim_sample_loop(m.forward_with_cfg, z.shape, z, model_kwargs=kw, eta=eta, step_noise=T(fx["noises"]))
         finally:
-            os.environ["OSUD_NO_GRAPH"] = "0"
+            _lib.set_option("sample_graph", -1)
         finals[graph] = fin.cpu()
         assert maxdiff(finals[graph], fx["final"]) < 1e-3, graph
     assert torch.equal(finals["graph"], finals["eager"])  # graph replay == eager launches, bit for bit
@@ -405,7 +406,7 @@ def test_chained_loop_bf16_drift_is_bounded():
     assert drift < BF16_P20_DRIFT
 
 
-def test_loop_with_split_off_constant_first_linear_part(monkeypatch):
+def test_loop_with_split_off_constant_first_linear_part(osud_option):
     """Inside a sampler loop the offsets / context share of the first linear is multiplied once and only the 256 coordinate features
     every step (bf16 tier).  Same sums in a different order: one step must agree with the one-product form to fp32 rounding carried
     through the bf16 trunk, the 20-step CFG-4 loop stays inside the tier's drift bound against the reference, and a second loop with
@@ -417,7 +418,7 @@ def test_loop_with_split_off_constant_first_linear_part(monkeypatch):
     o, c, y = T(fx["o"]).to(DEV), T(fx["c"]).to(DEV), T(fx["y"]).to(DEV)
     one, fins = {}, {}
     for flag in ("0", "1"):
-        monkeypatch.setenv("OSUD_EMBED_CONST", flag)
+        osud_option("embed_const", int(flag))
         m = native_model(shape, sd, "bf16")
         kw = dict(o=o.clone(), c=c.clone(), y=y, cfg_scale=4.0, attn_mask=None)
         one[flag] = d.run_steps(m.forward_with_cfg, z.clone(), kw, 19, 19, seed=3).cpu()
@@ -487,6 +488,7 @@ def test_in_place_steps_on_one_buffer_follow_the_seed_not_the_cached_graph():
     assert torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.selfcheck
 def test_gemm_tile_queue_equals_fixed_stride():
     """Multi-round launches (more tiles than compute units) with the per-XCD ticket queues switched on give the same bits as the
     fixed-stride schedule, launch after launch (the last workgroup re-arms the counters), and match an fp32 reference."""

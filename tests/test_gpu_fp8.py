@@ -127,10 +127,11 @@ def test_fp8_training_step_tracks_the_fp32_oracle():
     assert worst["fp8"][1] < 0.15 and worst["bf16"][1] < 1.4e-2, worst  # 3x measured: 4.9e-2 (fp8), 4.4e-3 (bf16)
 
 
-def test_fp8_live_steps_do_not_read_the_bf16_forms_they_no_longer_write(monkeypatch):
+@pytest.mark.selfcheck
+def test_fp8_live_steps_do_not_read_the_bf16_forms_they_no_longer_write(osud_option):
     """Live fp8 steps write only the e4m3 twins of u1 / u2 / gelu(z1) / dz1 / the branch gradients (dit.h: f8_twins_only); with
-    OSUD_F8_TWINS_ONLY=0 the bf16 forms are written as well.  Nothing may read them: the two settings give the same loss terms and
-    gradients up to the arrival order of the bias-gradient atomics."""
+    option f8_twins_only = 0 the bf16 forms are written as well.  Nothing may read them: the two settings give the same loss terms and
+    the same gradients, bit for bit (every sum of the backward pass has a fixed order)."""
     shape = mo.DitShape(depth=2, hidden=384, heads=6, num_classes=10)
     sd = mo.seeded_state_dict(shape, 33)
     (x, o, c), y = synthetic_windows(4, 128, 10, seed=4)
@@ -139,7 +140,7 @@ def test_fp8_live_steps_do_not_read_the_bf16_forms_they_no_longer_write(monkeypa
     d = create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True)
     res = {}
     for setting in ("0", "1"):
-        monkeypatch.setenv("OSUD_F8_TWINS_ONLY", setting)
+        osud_option("f8_twins_only", int(setting))
         tr = NativeTrainer(build(shape, sd, "fp8").train(), d, lr=1e-4)
         for _ in range(4):
             terms = tr.step(x, o, c, y, t=t, noise=noise, drop_ids=torch.zeros(4).long())

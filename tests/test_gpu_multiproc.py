@@ -69,7 +69,7 @@ def test_sharded_optimizer_two_ranks_equal_the_allreduce_path():
 
 
 def test_rank0_only_checkpoint_with_sharded_optimizer():
-    """train.py:285-297 with OSUD_ZERO1: the moments / EMA gather is a collective every rank enters, then rank 0 alone saves and
+    """train.py:285-297 with the sharded optimizer (--zero1): the moments / EMA gather is a collective every rank enters, then rank 0 alone saves and
     everybody meets at the barrier.  checkpoint() on one rank with stale shards refuses instead of hanging in an all-gather."""
     with tempfile.TemporaryDirectory() as d:
         _torchrun(2, [os.path.join(ROOT, "tests", "mp_worker.py"), d], dict(OSUD_DIST_BACKEND="gloo", OSUD_TEST_MODE="zero1_ckpt"), timeout=600)
@@ -94,7 +94,7 @@ def test_rccl_is_executed_world_size_one():
     for mode, tol in (("allreduce", 0.0), ("zero1", 0.0), ("zero1_bf16", 2e-3)):
         with tempfile.TemporaryDirectory() as d:
             _torchrun(1, [os.path.join(ROOT, "tests", "mp_worker.py"), d],
-                      dict(OSUD_DIST_BACKEND="nccl", OSUD_TEST_MODE=mode, OSUD_FORCE_PHASED="1"))
+                      dict(OSUD_DIST_BACKEND="nccl", OSUD_TEST_MODE=mode, OSUD_TEST_FORCE_PHASED="1"))
             got = torch.load(os.path.join(d, "rank0.pt"))
         err = float((got["flat"] - want_flat).abs().max())
         scale = float(want_flat.abs().max())
@@ -128,7 +128,7 @@ def test_native_rccl_communicator_through_the_c_abi():
 
 
 def test_trainer_exchanges_gradients_through_the_native_communicator():
-    """OSUD_NATIVE_COMM=1 under torchrun (one rank, phased backward forced): the per-slice all-reduces, the init broadcast and the
+    """native_comm=True under torchrun (one rank, phased backward forced): the per-slice all-reduces, the init broadcast and the
     sharded optimizer's reduce-scatter / all-gather run through libosud's RCCL calls; results equal the run without a process group."""
     from tests import mp_worker
 
@@ -136,7 +136,7 @@ def test_trainer_exchanges_gradients_through_the_native_communicator():
     for mode in ("allreduce", "zero1"):
         with tempfile.TemporaryDirectory() as d:
             _torchrun(1, [os.path.join(ROOT, "tests", "mp_worker.py"), d],
-                      dict(OSUD_DIST_BACKEND="gloo", OSUD_TEST_MODE=mode, OSUD_FORCE_PHASED="1", OSUD_NATIVE_COMM="1"))
+                      dict(OSUD_DIST_BACKEND="gloo", OSUD_TEST_MODE=mode, OSUD_TEST_FORCE_PHASED="1", OSUD_TEST_NATIVE_COMM="1"))
             got = torch.load(os.path.join(d, "rank0.pt"))
         err = float((got["flat"] - want_flat).abs().max())
         assert err <= 2e-6 * float(want_flat.abs().max()), (mode, err)

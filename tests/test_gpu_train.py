@@ -298,21 +298,21 @@ def test_training_rejects_padded_shapes():
         tr.step(x, o, c, y)
 
 
-def test_phased_backward_equals_single_call(monkeypatch):
-    """The phased backward (used to overlap the gradient all-reduce) produces bit-identical gradients."""
+@pytest.mark.selfcheck
+def test_phased_backward_equals_single_call():
+    """The phased backward (used to overlap the gradient all-reduce) against the single call: the same kernels except for the adaLN
+    weight gradients, which a phased run forms block by block instead of in one batched product."""
     fx = load("g7_train_l1")
     shape, sd = weights_for(fx)
     d = create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True)
     args = (T(fx["x"]), T(fx["o"]), T(fx["c"]), T(fx["y"]))
     kw = dict(t=T(fx["t"]), noise=T(fx["noise"]), drop_ids=T(fx["drop"]).long())
     grads = []
-    for phased in ("0", "1"):
-        monkeypatch.setenv("OSUD_FORCE_PHASED", phased)
-        tr = NativeTrainer(native_model(shape, sd, "bf16"), d)
+    for phased in (False, True):
+        tr = NativeTrainer(native_model(shape, sd, "bf16"), d, force_phased=phased)
         tr.lr = 0.0  # keep the weights: compare gradients only
         tr.step(*args, **kw)
         grads.append(tr.arena.grads.clone().cpu())
-    # atomically accumulated tensors (adaLN / final / table / bias sums) may differ in the last bits
     assert maxdiff(grads[0], grads[1]) < 1e-6 * max(1.0, float(grads[0].abs().max()))
 
 
@@ -350,6 +350,7 @@ def test_embed_only_mode_trains_the_class_table_alone():
     assert float(sd_opt[7]["step"]) == 2.0 and float(sd_opt[8]["step"]) == 1.0  # index 7 = class table (train.py:212-215)
 
 
+@pytest.mark.selfcheck
 def test_queued_tiles_and_chunks_give_the_same_gradients():
     """Shared-GPU mode (osud_set_gemm_dynamic_tiles(1): GEMM tiles and weight-gradient K-chunks drawn from ticket queues) against
     the fixed schedule on a DiT-B-wide model, where the 256x256 split-K weight-gradient kernel and multi-round GEMMs are used:
@@ -377,10 +378,10 @@ def test_queued_tiles_and_chunks_give_the_same_gradients():
     assert float(grads[1].abs().sum()) > 0
 
 
-def test_in_proj_bias_gradient_from_the_streamed_attention_backward(monkeypatch):
+def test_in_proj_bias_gradient_from_the_streamed_attention_backward(osud_option):
     """At T = 128 the persistent attention backward produces the in_proj bias gradient itself (column sums of dQ | dK | dV by an MFMA
     against ones on the rows in its store patches, one partial row per sample, a fixed-order sum over the samples).  Against the
-    one-workgroup-per-head kernel + the column-sum pass over dqkv (OSUD_ATTN_BWD_STREAM=0) on the same step: the same bf16 values
+    one-workgroup-per-head kernel + the column-sum pass over dqkv (option attn_bwd_kernel = 1) on the same step: the same bf16 values
     summed in a different order; and two runs of the fused form are bit-identical (no atomics)."""
     shape = mo.DitShape(depth=2, hidden=768, heads=12, num_classes=16)
     sd = mo.seeded_state_dict(shape, 5)
@@ -390,7 +391,7 @@ def test_in_proj_bias_gradient_from_the_streamed_attention_backward(monkeypatch)
     kw = dict(t=torch.randint(0, 1000, (64,), generator=g), noise=torch.randn(64, 2, 128, generator=g), drop_ids=torch.zeros(64).long())
     got = []
     for flag in ("0", "1", "1"):
-        monkeypatch.setenv("OSUD_ATTN_BWD_STREAM", flag)
+        osud_option("attn_bwd_kernel", 0 if flag == "1" else 1)
         tr = NativeTrainer(native_model(shape, sd, "bf16", train=True), d)
         tr.lr = 0.0
         tr.step(x, o, c, y, **kw)
@@ -404,85 +405,54 @@ def test_in_proj_bias_gradient_from_the_streamed_attention_backward(monkeypatch)
 
 
 
-@pytest.mark.parametrize("batch", [64, 24])
-def test_grouped_weight_gradients_equal_the_single_product_launches(batch, monkeypatch):
-    """The four weight gradients of a block in one grouped launch (csrc/wgrad.hip: wgrad_group_kernel + its combine pass) against the
-    same products launched one by one (OSUD_WGRAD_GROUP=0), on a DiT-B-wide model with enough tokens for every kind of run:
-    batch 64 x 128 tokens = 128 stages -> two full ranges (108 workgroups each) + 20-stage tails strung over 40 workgroups that
-    each finish one tile and continue with the next (up to 4 partial tiles); batch 24 = 48 stages -> one range of 48... the sums are
-    formed in a different order, so the gradients agree to fp32 summation noise, every tensor, and the rest is bit-equal."""
-    shape = mo.DitShape(depth=2, hidden=768, heads=12, num_classes=10)
-    sd = mo.seeded_state_dict(shape, 31)
-    (x, o, c), y = synthetic_windows(batch, 128, 10, seed=9)
-    t = torch.randint(0, 1000, (batch,), generator=torch.Generator().manual_seed(4))
-    noise = torch.randn(batch, 2, 128, generator=torch.Generator().manual_seed(5))
-    grads = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("OSUD_WGRAD_GROUP", mode)
-        tr = NativeTrainer(native_model(shape, sd, "bf16"), create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True), lr=0.0)
+def _three_steps(shape, sd, batch, seed, lr=1e-4, labels=None, **trainer_kw):
+    """Gradients of the first step (every tensor) and all arenas after three optimizer steps, on seeded inputs."""
+    (x, o, c), y = synthetic_windows(batch, 128, 10, seed=seed)
+    if labels is not None:
+        y = labels
+    t = torch.randint(0, 1000, (batch,), generator=torch.Generator().manual_seed(6))
+    noise = torch.randn(batch, 2, 128, generator=torch.Generator().manual_seed(7))
+    tr = NativeTrainer(native_model(shape, sd, "bf16").train(), create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True),
+                       lr=lr, **trainer_kw)
+    grads = []
+    for _ in range(3):
         tr.step(x, o, c, y, t=t, noise=noise, drop_ids=torch.zeros(batch).long())
-        grads[mode] = {k: v.detach().cpu().clone() for k, v in tr.arena.grad_views().items()}
-    worst = 0.0
-    for k, g0 in grads["0"].items():
-        g1 = grads["1"][k]
-        if any(s in k for s in ("in_proj_weight", "out_proj.weight", "fc1.weight", "fc2.weight")):
-            rel = float((g1 - g0).norm() / g0.norm().clamp_min(1e-20))
-            worst = max(worst, rel)
-            assert rel < 2e-6, (k, rel)  # measured ~2e-7: fp32 sums over 8 192 tokens in two different orders
-            assert float(g0.abs().max()) > 0
-        else:  # (bias and modulation gradients are column sums accumulated by atomics: equal up to the order of arrival)
-            assert float((g1 - g0).abs().max()) <= 2e-5 * max(1e-6, float(g0.abs().max())), k
-    print(f"MEASURED wgrad_group[batch {batch}]: worst relative difference to the single-product launches {worst:.3e}")
+        grads.append({k: v.detach().cpu().clone() for k, v in tr.arena.grad_views().items()})
+    return grads, {"masters": tr.arena.flat.detach().cpu().clone(), "exp_avg": tr.exp_avg.cpu().clone(),
+                   "exp_avg_sq": tr.exp_avg_sq.cpu().clone(), "ema": tr.ema_arena.flat.detach().cpu().clone()}
 
 
-def test_side_stream_weight_gradients_equal_the_single_stream(monkeypatch):
-    """A block's weight gradients on the library's side stream (default) against OSUD_WGRAD_SIDE=0: the same kernels on the same
-    operands -- every weight gradient bit-equal, the atomically accumulated sums equal up to the order of arrival -- and the parameters
-    after three optimizer steps agree."""
+@pytest.mark.selfcheck
+def test_two_runs_of_a_training_step_give_the_same_bits():
+    """No kernel of the backward pass adds floats atomically (csrc/kernels.h): bias / modulation / class-table gradients are fixed-order
+    sums of per-workgroup partial rows.  Two runs of the same three steps -- 64 row blocks per LayerNorm kernel, 12-head streamed
+    attention, split-K weight gradients on the side stream, labels with duplicates (classes 0..9 over 32 samples: every class-table row
+    has three or four contributors) -- end in bit-identical gradients, masters, moments and EMA."""
     shape = mo.DitShape(depth=3, hidden=768, heads=12, num_classes=10)
     sd = mo.seeded_state_dict(shape, 32)
-    (x, o, c), y = synthetic_windows(16, 128, 10, seed=10)
-    t = torch.randint(0, 1000, (16,), generator=torch.Generator().manual_seed(6))
-    noise = torch.randn(16, 2, 128, generator=torch.Generator().manual_seed(7))
-    res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("OSUD_WGRAD_SIDE", mode)
-        tr = NativeTrainer(native_model(shape, sd, "bf16").train(), create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True), lr=1e-4)
-        tr.step(x, o, c, y, t=t, noise=noise, drop_ids=torch.zeros(16).long())
-        g = {k: v.detach().cpu().clone() for k, v in tr.arena.grad_views().items()}
-        for _ in range(2):
-            tr.step(x, o, c, y, t=t, noise=noise, drop_ids=torch.zeros(16).long())
-        res[mode] = (g, tr.arena.flat.detach().cpu().clone())
-    for k, g0 in res["0"][0].items():
-        g1 = res["1"][0][k]
-        if any(s in k for s in ("in_proj_weight", "out_proj.weight", "fc1.weight", "fc2.weight")):
-            assert torch.equal(g0, g1), k
-        else:
-            assert float((g1 - g0).abs().max()) <= 2e-5 * max(1e-6, float(g0.abs().max())), k
-    # (AdamW normalises every gradient: where a bias-like gradient is at the level of its atomics' arrival-order noise, two runs of the SAME
-    #  schedule already differ by up to 2 lr per step in that element -- the test is the mean: a skipped or misordered update shifts
-    #  every element of its block by ~lr)
-    d = (res["0"][1] - res["1"][1]).abs()
-    assert float(d.max()) <= 2 * 1e-4 * 3 + 1e-7 and float(d.mean()) < 1e-4 * 1e-3, (float(d.max()), float(d.mean()))
+    runs = [_three_steps(shape, sd, 32, seed=10) for _ in range(2)]
+    for step in range(3):
+        for k, g0 in runs[0][0][step].items():
+            assert torch.equal(g0, runs[1][0][step][k]), (step, k)
+    for k, a in runs[0][1].items():
+        assert torch.equal(a, runs[1][1][k]), k
+    table = runs[0][0][0]["y_embedder.embedding_table.weight"]
+    assert int((table.abs().sum(1) > 0).sum()) <= 10 and float(table.abs().max()) > 0  # (rows of the labels only)
 
 
-def test_optimizer_under_the_next_forward_equals_the_plain_step(monkeypatch):
-    """OSUD_ADAMW_GATED=1 (one GPU, opt-in): AdamW + EMA and the re-pack of each block on a side stream, the next forward gated per block
-    -- the same arithmetic in the same order per parameter: masters, moments and EMA agree with the plain step after four steps."""
-    shape = mo.DitShape(depth=3, hidden=384, heads=6, num_classes=10)
-    sd = mo.seeded_state_dict(shape, 33)
-    (x, o, c), y = synthetic_windows(8, 128, 10, seed=11)
-    t = torch.randint(0, 1000, (8,), generator=torch.Generator().manual_seed(8))
-    noise = torch.randn(8, 2, 128, generator=torch.Generator().manual_seed(9))
+@pytest.mark.selfcheck
+def test_side_stream_weight_gradients_equal_the_single_stream(osud_option):
+    """A block's weight gradients on the library's side stream (default) against option wgrad_side_stream = 0: the same kernels on
+    the same operands in another interleaving.  Every gradient of every one of three steps and every arena afterwards is bit-equal
+    -- there is no arrival-order noise to allow for, so a misordered read or a skipped update cannot hide."""
+    shape = mo.DitShape(depth=3, hidden=768, heads=12, num_classes=10)
+    sd = mo.seeded_state_dict(shape, 32)
     res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("OSUD_ADAMW_GATED", mode)
-        tr = NativeTrainer(native_model(shape, sd, "bf16").train(), create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True), lr=1e-3)
-        for _ in range(4):
-            terms = tr.step(x, o, c, y, t=t, noise=noise, drop_ids=torch.zeros(8).long())
-        tr.finish_exchange()
-        res[mode] = (terms.cpu().clone(), tr.arena.flat.detach().cpu().clone(), tr.exp_avg.cpu().clone(), tr.ema_arena.flat.detach().cpu().clone())
-    assert maxdiff(res["0"][0], res["1"][0]) < 1e-4  # the loss terms of the fourth step
-    for a, b in zip(res["0"][1:], res["1"][1:]):  # masters, first moments, EMA: see the note in the test above (lr 1e-3, 4 steps)
-        d = (a - b).abs()
-        assert float(d.max()) <= 2 * 1e-3 * 4 + 1e-7 and float(d.mean()) < 1e-3 * 1e-3, (float(d.max()), float(d.mean()))
+    for mode in (0, 1):
+        osud_option("wgrad_side_stream", mode)
+        res[mode] = _three_steps(shape, sd, 16, seed=10)
+    for step in range(3):
+        for k, g0 in res[0][0][step].items():
+            assert torch.equal(g0, res[1][0][step][k]), (step, k)
+    for k, a in res[0][1].items():
+        assert torch.equal(a, res[1][1][k]), k

@@ -104,13 +104,13 @@ def test_native_loop_with_inpaint_mask(precision, tol):
     z = T(FX["loop_z"]).to(DEV)
     finals = {}
     for graph in ("graph", "eager"):
-        os.environ["OSUD_NO_GRAPH"] = "0" if graph == "graph" else "1"
+        _lib.set_option("sample_graph", 1 if graph == "graph" else 0)
         try:
             with torch.no_grad():
                 finals[graph] = d.p_sample_loop(m.forward, z.shape, z, denoised_fn=fn, clip_denoised=True, model_kwargs=kw,
                                                 step_noise=T(FX["loop_noises"])).cpu()
         finally:
-            os.environ["OSUD_NO_GRAPH"] = "0"
+            _lib.set_option("sample_graph", -1)
     assert torch.equal(finals["graph"], finals["eager"])
     fin = finals["graph"]
     print(f"MEASURED inpaint_loop[{precision}]: final max|d| vs reference {maxdiff(fin, FX['loop_final']):.3e}")

@@ -31,6 +31,35 @@ def test_library_exports_every_declared_symbol():
     assert L.osud_build_arch() == b"gfx950" and L.osud_version() >= 1
 
 
+def test_option_table_is_the_only_switchboard():
+    """include/osud.h: osud_set_option / osud_get_option -- every option the header documents exists with its documented default,
+    takes -1 as "back to the default", rejects unknown names and values out of range; and the library's sources read no environment
+    variable but OSUD_OPTIONS (initial values of this table) and OSUD_RCCL_LIB."""
+    header = open(os.path.join(ROOT, "include", "osud.h")).read()
+    rows = re.findall(r"^ \*   ([a-z0-9_]+) +(-?\d+) +\S", header, flags=re.M)
+    assert len(rows) >= 10, rows
+    for name, default in rows:
+        assert _lib.get_option(name) == int(default), name
+    _lib.set_option("gemm_tile", 256)
+    assert _lib.get_option("gemm_tile") == 256
+    _lib.set_option("gemm_tile", -1)
+    assert _lib.get_option("gemm_tile") == 0
+    with _lib.option("sample_graph", 0):
+        assert _lib.get_option("sample_graph") == 0
+    assert _lib.get_option("sample_graph") == 1
+    with pytest.raises(AssertionError, match="unknown option"):
+        _lib.set_option("no_such_option", 1)
+    with pytest.raises(AssertionError, match="takes 0..1"):
+        _lib.set_option("sample_graph", 7)
+    env_reads = set()
+    for path in glob.glob(os.path.join(ROOT, "osu_diffusion_amd", "csrc", "*.h*")):
+        env_reads |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(path).read()))
+    assert env_reads == {"OSUD_OPTIONS", "OSUD_RCCL_LIB"}, env_reads
+    for path in glob.glob(os.path.join(ROOT, "osu_diffusion_amd", "**", "*.py"), recursive=True):
+        names = set(re.findall(r'environ[^\n]*?"(OSUD_[A-Z0-9_]+)"', open(path).read()))
+        assert names <= {"OSUD_LIB", "OSUD_PRECISION"}, (path, names)  # where the library file is; the default tier of DiT(...)
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "g1_schedule_*.npz"))))
 def test_native_schedule_tables_match_reference(path):
     """osud_sched_create (C++ host code) vs the reference's numpy tables: bit-equal up to libm's

@@ -2,7 +2,7 @@
 """Time the attention core of a DiT-B training step in isolation (HIP events): forward (osud_op_attention) and backward
 (osud_op_attention_bwd) at N = 256 windows x 12 heads x T = 128, next to the bytes each has to move.
 
-  python tools/attn_bench.py [N] [T]        # OSUD_ATTN_BWD_STREAM=0 selects the one-workgroup-per-head backward kernel
+  python tools/attn_bench.py [N] [T]        # OSUD_OPTIONS=attn_bwd_kernel=1 selects the one-workgroup-per-head backward kernel
   H=16 HD=72 python tools/attn_bench.py 128 256     # DiT-XL's shape
 """
 import os, sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Time every GEMM shape of a DiT-B training step (M = 32768) per tile geometry (OSUD_GEMM_TILE)."""
+"""Time every GEMM shape of a DiT-B training step (M = 32768) per tile geometry (option gemm_tile)."""
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,8 +27,7 @@ def bench(epi, My, Nx, K, f32out, iters=24):
 for name, epi, My, Nx, K, f in SHAPES:
     row = []
     for tile in ("", "256", "192", "128"):
-        if tile: os.environ["OSUD_GEMM_TILE"] = tile
-        else: os.environ.pop("OSUD_GEMM_TILE", None)
+        _lib.set_option("gemm_tile", int(tile) if tile else 0)
         us = bench(epi, My, Nx, K, f)
         row.append(f"{tile or 'auto'}:{us:6.1f}us/{2.0 * My * Nx * K / us / 1e6:5.0f}TF")
     print(f"{name:11s} {My}x{Nx}x{K}  " + "  ".join(row), flush=True)

@@ -31,7 +31,8 @@ if n_train:
     del tr, model
     torch.cuda.empty_cache()
 if n_sample:
-    os.environ["OSUD_NO_GRAPH"] = "1"  # plain launches: one counter record per kernel
+    from osu_diffusion_amd import _lib as _l
+    _l.set_option("sample_graph", 0)  # plain launches: one counter record per kernel
     model = randomize_zero_init(DiT_models["DiT-B"](num_classes=52670, context_size=144, precision="bf16").to(dev), seed=0).eval()
     (x, o, c), y = synthetic_windows(64, 128, 52670, seed=2, train_offsets=False)
     o, c = torch.cat([o, o]).to(dev), torch.cat([c, c]).to(dev)

@@ -58,16 +58,18 @@ def main():
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     lnb = fn("launch_ln_mod_bwd")
 
+    part = torch.empty(M // 64, 6 * D + 64, device=dev)  # per-workgroup partial rows (summed by row_reduce_kernel, not timed here)
+
     def ln_bwd(with_gate):
-        lnb(I(0), P(h), P(stats), P(du), P(ada), I(AC), I(0), I(D), P(dh), P(dh2), P(dada), I(M), I(T), I(D), st,
-            P(br if with_gate else None), I(2 * D), P(dbr if with_gate else None), P(db if with_gate else None),
+        lnb(I(0), P(h), P(stats), P(du), P(ada), I(AC), I(0), I(D), P(dh), P(dh2), P(part), I(M), I(T), I(D), st,
+            P(br if with_gate else None), I(2 * D), P(dbr if with_gate else None),
             P(None), P(None), P(None))  # (no e4m3 twin)
     row = D * (4 + 2 + 4 + 4)
     timeit("ln_mod_bwd (no gate step)", lambda: ln_bwd(False), M * row)
     timeit("ln_mod_bwd + gate step of the next branch", lambda: ln_bwd(True), M * (row + D * 4))
 
     gb = fn("launch_gate_bwd")
-    timeit("gate_bwd", lambda: gb(I(0), P(dh), P(br), P(ada), I(AC), P(dbr), P(dada), I(M), I(T), I(D), st, P(db)), M * D * (4 + 2 + 2))
+    timeit("gate_bwd", lambda: gb(I(0), P(dh), P(br), P(ada), I(AC), P(dbr), P(part), I(M), I(T), I(D), st), M * D * (4 + 2 + 2))
 
     u = torch.empty(M, D, device=dev, dtype=bf); stats_o = torch.empty(M, 2, device=dev)
     ln = fn("launch_ln_mod")

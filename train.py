@@ -69,7 +69,9 @@ def main(args):
                                    class_dropout_prob=0.2, precision=args.precision).to(device)
     diffusion = create_diffusion(timestep_respacing="", noise_schedule=args.noise_schedule, use_l1=args.l1_loss)
     logger.info(f"DiT Parameters: {sum(p.numel() for p in model.parameters()):,}")
-    trainer = NativeTrainer(model, diffusion, lr=args.lr)  # AdamW(lr, wd=0) + EMA 0.9999 + init broadcast
+    # AdamW(lr, wd=0) + EMA 0.9999 + init broadcast; the exchange options are flags of this script (--zero1, --grad-wire, --native-comm)
+    trainer = NativeTrainer(model, diffusion, lr=args.lr, shard_optimizer=args.zero1,
+                            wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None, native_comm=args.native_comm)
     model.train()
     if args.ckpt is not None:
         trainer.load_checkpoint(torch.load(args.ckpt, map_location="cpu", weights_only=False), lr=args.lr,
@@ -137,7 +139,7 @@ def main(args):
                 running_loss.zero_()
                 log_steps, start_time = 0, time()
             if train_steps % args.ckpt_every == 0 and train_steps > 0:
-                # sharded optimizer (OSUD_ZERO1=1): the moments / EMA of the other ranks' shards are all-gathered first -- a
+                # sharded optimizer (--zero1): the moments / EMA of the other ranks' shards are all-gathered first -- a
                 # COLLECTIVE, so every rank takes part before rank 0 alone writes the file (train.py:285-297)
                 trainer.sync_sharded_state()
                 if rank == 0:
@@ -177,7 +179,15 @@ def parse_args(argv=None):
                    help="with --synthetic: stream windows from this many synthetic hit-object sequences through the "
                         "reference's loader contract (windows.py) instead of drawing windows directly")
     p.add_argument("--steps-per-epoch", type=int, default=1000)
-    p.add_argument("--precision", choices=["bf16", "fp32"], default="bf16")
+    p.add_argument("--precision", choices=["bf16", "fp32", "fp8"], default="bf16",
+                   help="bf16: the reference's --use-amp tier (bf16 MFMA, fp32 masters); fp32: the parity tier; fp8: the bf16 tier with every "
+                        "Linear product of the blocks (forward, data and weight gradients) on e4m3 operands with delayed scaling "
+                        "(BASELINE config 5: DiT-XL, seq-len 256)")
+    p.add_argument("--zero1", action="store_true",
+                   help="multi-GPU: reduce-scatter / sharded AdamW + EMA / all-gather instead of the gradient all-reduce")
+    p.add_argument("--grad-wire", choices=["fp32", "bf16"], default="fp32", help="--zero1: dtype of the gradients on the wire")
+    p.add_argument("--native-comm", action="store_true",
+                   help="multi-GPU: the exchange through the library's own RCCL communicator (C ABI) instead of torch.distributed")
     return p.parse_args(argv)
 
 
