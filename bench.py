@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--xl-precision", choices=["bf16", "fp8"], default=None, help="tier of the DiT-XL line (default: both, bf16 first)")
     ap.add_argument("--batch", type=int, default=256, help="training windows per GPU")
     ap.add_argument("--sample-steps", type=int, default=None, help="timed sampling steps in mode both (default 1000)")
-    ap.add_argument("--precision", choices=["bf16", "fp16", "fp32", "fp8", "bf16x3", "fp16f8"], default="bf16")
+    ap.add_argument("--precision", choices=["bf16", "fp16", "fp32", "fp8", "bf16x3", "fp16f8", "fp16w8"], default="bf16")
     ap.add_argument("--maps", type=int, default=64, help="beatmap windows per GPU (CFG doubles the batch)")
     ap.add_argument("--seq-len", type=int, default=128)
     ap.add_argument("--model", default="DiT-B")
@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--zero1", action="store_true", help="N > 1: sharded optimizer between reduce-scatter and all-gather instead of all-reduce")
     ap.add_argument("--grad-wire", choices=["fp32", "bf16"], default="fp32", help="--zero1: dtype of the gradients on the wire")
+    ap.add_argument("--native-comm", action="store_true", help="N > 1: the timed exchange goes through the library's own RCCL communicator (C ABI)")
+    ap.add_argument("--no-exchange-ab", action="store_true", help="N > 1: skip the in-run A/B of the exchange schedules (multi_gpu.schedules)")
     ap.add_argument("--no-family-table", action="store_true", help="skip the torch.profiler pass (use under rocprofv3)")
     ap.add_argument("--no-parity-tier", action="store_true", help="skip the fp32 parity-tier throughput and the bf16-vs-fp32 drift run")
     ap.add_argument("--drift-steps", type=int, default=1000, help="length of the CFG-4 loop the bf16 drift is measured on")
@@ -370,6 +372,82 @@ def cpu_baseline_train(model, args, batch, steps=1, cpu_batch=32):
                       f"torch-CPU oracle + autograd + AdamW + EMA, {dt:.1f} s"}
 
 
+def multi_gpu_report(args, world, rank, dev, model, diffusion, batches, timed_ms, timed_name):
+    """What the first multi-GPU run needs to be read (no such node was available while this was written): did RCCL see every rank,
+    how much of the step is exposed communication, how many bytes travel, and which exchange schedule is fastest -- measured in this
+    very run, every schedule on the same model, batches and boxes:
+      allreduce        per-slice async all-reduces under the phased backward (the default; reference: DDP's bucketed reducer, train.py:152,257)
+      zero1            reduce-scatter -> AdamW / EMA on the own 1 / world shard -> all-gather of the masters under the next forward
+      zero1_no_overlap the same, all-gathers joined before the next step
+      native_comm      the all-reduce schedule through the library's own RCCL communicator (C ABI: osud_allreduce_grads)
+      no_exchange      the all-reduce schedule with every collective left out (NOT a training run: the compute floor)
+    exposed_comm_ms_per_step = allreduce - no_exchange."""
+    import torch.distributed as dist
+
+    from osu_diffusion_amd import _lib
+    from osu_diffusion_amd.training import NativeTrainer, overlap_slices
+
+    backend = dist.get_backend()
+    ones = torch.ones(1, device=dev)
+    dist.all_reduce(ones)
+    rep = {"rccl": {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world_size": world, "ranks_seen": int(round(float(ones.item()))),
+                    "version": int(_lib.lib().osud_comm_rccl_version()),
+                    "torch_nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None}}
+    B, T = args.batch, args.seq_len
+    K, W = (6, 2) if args.precision == "fp32" else (max(4, min(args.steps or 20, 20)), 3)
+
+    def leg(**kw):
+        tr = NativeTrainer(model, diffusion, lr=1e-4, **kw)
+        for i in range(W):
+            (x, o, c), y = batches[i % 4]
+            tr.step(x, o, c, y)
+        barrier(world)
+        t0 = time.perf_counter()
+        for i in range(K):
+            (x, o, c), y = batches[i % 4]
+            tr.step(x, o, c, y)
+        tr.finish_exchange()
+        barrier(world)
+        ms = max_over_ranks(time.perf_counter() - t0, world, dev) / K * 1e3
+        del tr
+        torch.cuda.empty_cache()
+        return round(ms, 3)
+
+    legs = {"allreduce": dict(), "zero1": dict(shard_optimizer=True), "zero1_no_overlap": dict(shard_optimizer=True, overlap_gather=False),
+            "native_comm": dict(native_comm=True), "no_exchange": dict(stub_exchange=True)}
+    sched = {}
+    for name, kw in legs.items():
+        if name == "native_comm" and backend != "nccl":  # (the one-GPU rehearsal over gloo: two ranks of ONE device cannot form an RCCL communicator)
+            sched[name] = {"skipped": "needs one GPU per rank (backend nccl)"}
+            continue
+        try:
+            sched[name] = {"ms_per_step": leg(**kw)}
+        except Exception as e:  # a schedule that does not run here (e.g. no librccl for the native communicator) must not sink the line
+            sched[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    for name, v in sched.items():
+        if "ms_per_step" in v:
+            v["tokens_per_s"] = round(world * B * T / v["ms_per_step"] * 1e3, 1)
+    rep["schedules"] = sched
+    rep["schedules_measured_over"] = {"steps": K, "warmup": W, "note": "shorter than the timed region: compare the legs with each other, not with `value`"}
+    ok = {n: v["ms_per_step"] for n, v in sched.items() if "ms_per_step" in v and n != "no_exchange"}
+    if ok:
+        rep["fastest_schedule"] = min(ok, key=ok.get)
+    if "ms_per_step" in sched.get("allreduce", {}) and "ms_per_step" in sched.get("no_exchange", {}):
+        rep["exposed_comm_ms_per_step"] = round(sched["allreduce"]["ms_per_step"] - sched["no_exchange"]["ms_per_step"], 3)
+    rep["timed_schedule"] = {"name": timed_name, "ms_per_step": round(timed_ms, 3)}
+    # bytes one rank hands to the exchange per step, and what a ring moves over its links for them
+    arena = model._arena
+    blocks, tail = overlap_slices(arena, model.depth)
+    dense = sum(hi - lo for _, _, lo, hi in blocks) + sum(hi - lo for kind, _, lo, hi in tail if kind in ("tail", "final"))
+    D = model.hidden_size
+    rows_bytes = world * B * (D * 4 + 8)  # all-gathered label rows + indices
+    rep["wire_bytes_per_step"] = {"dense_slices_payload": int(dense * 4), "class_table_rows_allgather": int(rows_bytes),
+                                  "class_table_dense_would_be": int(next(hi - lo for kind, _, lo, hi in tail if kind == "table") * 4),
+                                  "ring_bytes_sent_per_gpu": int(2 * (world - 1) / world * dense * 4 + (world - 1) / world * rows_bytes),
+                                  "slices": len(blocks) + 1 + sum(1 for kind, *_ in tail if kind == "tail")}
+    return rep
+
+
 def bench_train(args, world, rank, dev):
     from osu_diffusion_amd.diffusion import create_diffusion
     from osu_diffusion_amd.models import DiT_models
@@ -391,7 +469,7 @@ def bench_train(args, world, rank, dev):
         (x, o, c), y = synthetic_windows(B, T, num_classes, seed=10_000 * rank + i, train_offsets=True)
         batches.append(((x.to(dev), o.to(dev), c.to(dev)), y.to(dev)))
     trainer = NativeTrainer(model, diffusion, lr=1e-4, shard_optimizer=args.zero1,
-                            wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None)
+                            wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None, native_comm=args.native_comm)
     terms = None
     for i in range(W):
         (x, o, c), y = batches[i % 4]
@@ -401,6 +479,7 @@ def bench_train(args, world, rank, dev):
     for i in range(K):
         (x, o, c), y = batches[i % 4]
         terms = trainer.step(x, o, c, y)
+    trainer.finish_exchange()  # (sharded optimizer: the last step's master all-gather belongs to the timed region)
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world, dev)
     loss = float(terms[2].mean())
@@ -461,6 +540,12 @@ def bench_train(args, world, rank, dev):
                                                             "kernels that run side by side")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_train(model, args, batches[0])
+    if world > 1 and not args.no_exchange_ab:  # (every rank takes part: the legs are collective)
+        timed_name = ("zero1" if args.zero1 else "allreduce") + (" + native_comm" if args.native_comm else "")
+        del trainer
+        trainer = None
+        torch.cuda.empty_cache()
+        res["multi_gpu"] = multi_gpu_report(args, world, rank, dev, model, diffusion, batches, dt / K * 1e3, timed_name)
     del trainer, model
     torch.cuda.empty_cache()
     from osu_diffusion_amd import _lib
@@ -514,6 +599,7 @@ def bench_sample(args, world, rank, dev):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": {"bf16": "bf16", "fp32": "f32", "fp8": "fp8(e4m3 GEMM operands)+bf16", "bf16x3": "bf16x3(split-bf16 operands, 3 MFMAs per product)",
                   "fp16f8": "fp16f8(split-bf16 tier with the four big GEMMs on fp16 + e4m3-residual operands)",
+                  "fp16w8": "fp16w8(fp16f8 with fp16 activation operands: only the weights carry the e4m3 residual)",
                   "fp16": "fp16(IEEE half MFMA operands: the 11 significand bits of the reference's TF32 sampling matmuls)"}[args.precision], "data": "synthetic",
         "config": {"workload": f"sample.py path: {args.model} seq-len {T}, {n} synthetic beatmap windows x2 (CFG) per GPU, "
                                f"cfg-scale 4.0, 1000-step squaredcos schedule, steps t=999..{999 - K + 1}",
@@ -564,8 +650,8 @@ def parity_tier_and_drift(args, dev):
     # moved by 1e-6 (a few fp32 ulps of a coordinate).  The third run is the yardstick: it shows how far the sampler map itself
     # carries a rounding-sized difference on these (random, untrained) weights, i.e. what ANY two implementations may differ by.
     marks = [k for k in (1, 10, 50, 100, 250, 500, 1000) if k < S] + [S]
-    runs = (("bf16", "bf16", 0.0), ("fp16", "fp16", 0.0), ("bf16x3", "bf16x3", 0.0), ("fp16f8", "fp16f8", 0.0), ("fp32", "fp32", 0.0),
-            ("fp32_moved", "fp32", 1e-6))
+    runs = (("bf16", "bf16", 0.0), ("fp16", "fp16", 0.0), ("bf16x3", "bf16x3", 0.0), ("fp16f8", "fp16f8", 0.0), ("fp16w8", "fp16w8", 0.0),
+            ("fp32", "fp32", 0.0), ("fp32_moved", "fp32", 1e-6))
     states, sec = {}, {}
     pert = torch.randn(n, 2, T, device=dev, generator=g)
     for name, prec, eps in runs:
@@ -617,14 +703,20 @@ def parity_tier_and_drift(args, dev):
     DTYPES = {
         "bf16x3": "bf16x3 (split-bf16 operands: v = hi + lo, three v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate / residual / statistics)",
         "fp16f8": "fp16f8 (the bf16x3 tier with in_proj / out_proj / fc1 / fc2 on v = fp16 hi + 2^-12 e4m3 lo: two v_mfma_f32_32x32x16_f16 + one "
-                  "v_mfma_scale_f32_32x32x64_f8f6f4 per 32 k, fp32 accumulate / residual / statistics)"}
+                  "v_mfma_scale_f32_32x32x64_f8f6f4 per 32 k, fp32 accumulate / residual / statistics)",
+        "fp16w8": "fp16w8 (the fp16f8 tier with the ACTIVATION operand of in_proj / out_proj / fc1 / fc2 rounded to fp16 and only the weight "
+                  "carrying its e4m3 residual: eight v_mfma_f32_32x32x16_f16 + two v_mfma_scale_f32_32x32x64_f8f6f4 per 128 k, fp32 accumulate / "
+                  "residual / statistics)"}
     TIERS = {
         "bf16x3": "precision=bf16x3: 16 significand bits per GEMM / attention operand (the reference's sampling matmuls are TF32: 11 bits, "
                   "sample.py:25-26); meets the 1e-3 tolerance on final coordinates (tests/test_gpu_x3.py) at a third of the bf16 tier's MFMA rate",
         "fp16f8": "precision=fp16f8: 15 significand bits per operand of the four big GEMMs of a block (16 elsewhere; the reference's sampling "
                   "matmuls are TF32: 11 bits, sample.py:25-26); meets the 1e-3 tolerance on final coordinates (tests/test_gpu_h8.py) at "
-                  "2/3 of the bf16x3 tier's matrix-pipe passes"}
-    PASSES = {"bf16x3": 3.0, "fp16f8": 2.0}  # matrix-pipe passes per product, in units of one bf16 MFMA pass (the big GEMMs)
+                  "2/3 of the bf16x3 tier's matrix-pipe passes",
+        "fp16w8": "precision=fp16w8: 15 significand bits per WEIGHT of the four big GEMMs of a block, 11 per activation operand (an activation's "
+                  "rounding is a fresh error per token and step and averages out over the loop; a weight's repeats in every product): meets the "
+                  "1e-3 tolerance on final coordinates (tests/test_gpu_w8.py) at half of the bf16x3 tier's matrix-pipe passes"}
+    PASSES = {"bf16x3": 3.0, "fp16f8": 2.0, "fp16w8": 1.5}  # matrix-pipe passes per product, in units of one bf16 MFMA pass (the big GEMMs)
 
     def tier_record(name):
         tol = dict(dev_stats(states[name][S], states["fp32"][S]))
@@ -648,7 +740,7 @@ def parity_tier_and_drift(args, dev):
                         "dtype": "fp16 (IEEE half MFMA operands, fp32 accumulate / residual / statistics)",
                         "drift_vs_fp32_tier": dict(f16, after_steps={str(k): dev_stats(states["fp16"][k], states["fp32"][k]) for k in marks}),
                         "meets_1e-3": bool(f16["max"] <= 1e-3)}
-    recs = {name: tier_record(name) for name in ("bf16x3", "fp16f8")}
+    recs = {name: tier_record(name) for name in ("bf16x3", "fp16f8", "fp16w8")}
     meeting = [name for name in recs if recs[name]["meets_1e-3"]] or ["bf16x3"]
     best = max(meeting, key=lambda name: recs[name]["value"])
     out["tolerance_tier"] = dict(recs[best], name=best, also={name: r for name, r in recs.items() if name != best})

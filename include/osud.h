@@ -71,6 +71,12 @@ extern "C" {
                           (v_mfma_f32_32x32x16_f16): 11 significand bits -- the precision of the TF32 matmuls the reference's own
                           sampling path uses (sample.py:25-26) -- at the bf16 tier's speed */
 
+#define OSUD_PREC_F16W8 6 /* a faster form of the tolerance tier, inference only: OSUD_PREC_F16F8 with the ACTIVATION operand of the four big
+                            GEMMs rounded to fp16 (11 bits) and only the WEIGHT carrying its e4m3 residual (15 bits): a weight's rounding
+                            error repeats in every product of every step, an activation's is a fresh one each time.  Per 128 k: eight
+                            v_mfma_f32_32x32x16_f16 + two block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 = 3/4 of F16F8's matrix-pipe passes,
+                            3 instead of 4 operand bytes per element */
+
 typedef struct osud_dit osud_dit;
 typedef struct osud_sched osud_sched;
 typedef void* osud_stream; /* hipStream_t */
@@ -297,6 +303,9 @@ int osud_op_gemm(int precision, int epilogue, const void* Y, int ldy, const void
 /* fp16 + e4m3 operand form of OSUD_PREC_F16F8 (csrc/common.h: h8_t): src fp32 [rows][ld_src] (cols_src used, zero padded to cols_dst,
  * a multiple of 32) -> dst [rows][4 * cols_dst bytes], K-blocked groups of 32; weight = 1 for the weight flavour (planes swapped). */
 int osud_op_pack_h8(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, int weight, osud_stream stream);
+/* fp16 x (fp16 + e4m3) operand form of OSUD_PREC_F16W8 (csrc/common.h: w8_t): dst [rows][3 * cols_dst bytes], K-blocked super-groups of
+ * 128 (cols_dst % 128 == 0); weight = 1: the e4m3 plane holds the fp16 residual x 2^12, weight = 0 (an activation): e4m3(v). */
+int osud_op_pack_w8(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, int weight, osud_stream stream);
 /* Convert n fp32 values to the tier's element type (bf16 round-to-nearest-even or f32 copy). */
 int osud_op_convert(int precision, const float* src, void* dst, size_t n, osud_stream stream);
 /* Attention core on the packed in_proj output qkv [Mp][ld_qkv] (Q | K | V, head h = hd columns): out [Mp][hidden]. */

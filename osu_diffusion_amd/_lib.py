@@ -22,8 +22,10 @@ PREC_F16F8 = 4  # inference only: the split-bf16 tier with the four big GEMMs of
 #                 significand bits per operand; fp16 hi product + ONE block-scaled e4m3 MFMA for both cross terms: 2/3 of the passes)
 PREC_F16 = 5  # inference only: the bf16 tier's kernels on IEEE half operands -- 11 significand bits, the precision of the TF32 matmuls of
 #               the reference's own sampling path (sample.py:25-26) -- at the bf16 tier's speed
+PREC_F16W8 = 6  # inference only: fp16f8 with the ACTIVATION operand of the four big GEMMs in plain fp16 (the weight keeps its e4m3
+#                 residual: 15 bits where the error would repeat in every product): 3/4 of fp16f8's matrix-pipe passes
 PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32, "fp8": PREC_FP8, "bf16x3": PREC_BF16X3, "fp16f8": PREC_F16F8,
-              "fp16": PREC_F16}
+              "fp16": PREC_F16, "fp16w8": PREC_F16W8}
 
 # gemm epilogue codes (csrc/gemm.h)
 EPI_BIAS_F32, EPI_BIAS_TE, EPI_BIAS_SILU_TE, EPI_ROWBIAS_TE, EPI_BIAS_GELU_TE, EPI_GATE_RES = range(6)
@@ -88,6 +90,7 @@ _SIGNATURES = {
     "osud_op_gemm": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
     "osud_op_convert": (_i, [_i, _vp, _vp, _sz, _vp]),
     "osud_op_pack_h8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp]),
+    "osud_op_pack_w8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "osud_set_gemm_dynamic_tiles": (_i, [_i]),
     "osud_set_option": (_i, [C.c_char_p, _i]),
     "osud_get_option": (_i, [C.c_char_p, C.POINTER(_i)]),

@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HD == 64 &
     if (lse != nullptr && fhalf == 0)  // log2-domain logsumexp of the scaled scores, for the backward pass
       lse[((size_t)n * gridDim.y + h) * Tp + q] = m_run + __builtin_amdgcn_logf(l_run);
     const float inv = (fp8_scale > 0.f ? fp8_scale : 1.0f) / l_run;
-    const bool h8_out = X3 && fp8_scale < 0.f;  // split-bf16 arithmetic, output in the fp16 + e4m3 operand form
+    const bool h8_out = X3 && fp8_scale < 0.f && fp8_scale > -1.5f;  // split-bf16 arithmetic, output in the fp16 + e4m3 operand form
+    const bool w8_out = X3 && fp8_scale <= -1.5f;                    // ... or as fp16 + e4m3(v) activation rows (OSUD_PREC_F16W8)
     bf16_t* orow = out + ((size_t)n * Tp + q) * D * NP + h * HD;
     fp8_t* orow8 = reinterpret_cast<fp8_t*>(out) + ((size_t)n * Tp + q) * D + h * HD;  // fp8 tier: e4m3 operand of out_proj
 #pragma unroll
@@ -253,7 +254,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HD == 64 &
         const int d = dt * 32 + 8 * g + 4 * fhalf;
         if (d < HD) {
           if constexpr (X3) {
-            if (h8_out)  // (OSUD_PREC_F16F8: out_proj reads fp16 + e4m3 rows)
+            if (w8_out)
+              store4_w8<false>(reinterpret_cast<w8_t*>(out) + ((size_t)n * Tp + q) * D, h * HD + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv,
+                               o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+            else if (h8_out)  // (OSUD_PREC_F16F8: out_proj reads fp16 + e4m3 rows)
               store4_h8<false>(reinterpret_cast<h8_t*>(out) + ((size_t)n * Tp + q) * D, h * HD + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv,
                                o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
             else store4_x3(orow + d, (size_t)D, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
@@ -912,10 +916,10 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
     else
       hipLaunchKernelGGL((attn_bf16_kernel<72, 96, 1, false, true>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,
                          Mp, D, ld_qk, scale * 1.4426950408889634f, mask ? kb_class : nullptr, 0.f);
-  } else if (prec == OSUD_PREC_BF16X3 || prec == OSUD_PREC_F16F8) {
+  } else if (prec == OSUD_PREC_BF16X3 || prec == OSUD_PREC_F16F8 || prec == OSUD_PREC_F16W8) {
     // (F16F8: the split-bf16 kernel on split-bf16 q | k | v, its output written as fp16 + e4m3 rows for out_proj: flag = scale < 0)
     OSUD_CHECK_ARG(lse == nullptr && fp8_scale <= 0.f, "attention: the split-bf16 tier is inference only");
-    const float flag = prec == OSUD_PREC_F16F8 ? -1.0f : 0.f;
+    const float flag = prec == OSUD_PREC_F16F8 ? -1.0f : (prec == OSUD_PREC_F16W8 ? -2.0f : 0.f);  // (the output form of the split-bf16 kernel)
     dim3 grid((Tp + 127) / 128, heads, N);
     if (head_dim == 64)
       hipLaunchKernelGGL((attn_bf16_kernel<64, 64, 1, true>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,

@@ -51,6 +51,17 @@ struct x3_t { uint16_t v; };
 // -- exactly one stage row of the GEMM's LDS image, so the operand travels by the plain 128-byte LDS-DMA; P meets P and Q meets Q
 // in the fp8 MFMA, which pairs lo8_a with hi8_w and hi8_a with lo8_w.  Leading dimensions and K are multiples of 32.
 struct h8_t { uint8_t b[4]; };
+// fp16 activations x (fp16 + e4m3 residual) weights (OSUD_PREC_F16W8; the operand form of GEMMs whose ACTIVATION may be rounded to
+// fp16's 11 bits while the WEIGHT keeps 15): rounding an activation is a fresh random error per token and step, rounding a weight
+// is the same error in every product of every step -- measured on the 1000-step loop: both in fp16 5.5e-3 from the fp32 tier, only
+// the activations 6.6e-4, neither (h8_t) 1.3e-4.  A product over 128 k is
+//   a_hi . w_hi  (eight v_mfma_f32_32x32x16_f16)  +  2^-12 a_hi8 . w_lo8  (two v_mfma_scale_f32_32x32x64_f8f6f4, weight-side scale)
+// = 96 matrix-pipe passes per 32 x 32 block where the h8_t form issues 128 and the split-bf16 form 192.
+// LAYOUT (w8_t: 3 bytes per logical element, K-blocked): a row is a sequence of 384-byte super-groups of 128 logical k --
+//   [ 128 B: fp16 of k 0..63 | 128 B: fp16 of k 64..127 | 128 B: one e4m3 per k 0..127 ],
+//   activations: e4m3 plane = e4m3(v) (the partner of the weight's residual);  weights: e4m3 plane = e4m3((w - fp16(w)) 2^12)
+// -- three stage rows of the GEMM's LDS image (two fp16 slabs, one e4m3 slab).  Leading dimensions and K are multiples of 128.
+struct w8_t { uint8_t b[3]; };
 constexpr float kH8LoScale = 4096.0f;  // 2^12: lo8 = e4m3((v - hi) * 2^12); the fp8 MFMA's A-side block scale is 2^-12
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -274,6 +285,61 @@ template <bool WEIGHT> __device__ __forceinline__ void store2_h8(h8_t* row, int 
   *reinterpret_cast<uint16_t*>(g + 64 + i) = WEIGHT ? hi8 : lo8;
   *reinterpret_cast<uint16_t*>(g + 96 + i) = WEIGHT ? lo8 : hi8;
 }
+// ---- fp16 + one e4m3 plane rows (w8_t): 8 / 4 / 2 consecutive logical elements at column x of the row starting at `row`
+template <bool WEIGHT> __device__ __forceinline__ void store4_w8(w8_t* row, int x, float a, float b, float c, float d) {
+  char* g = reinterpret_cast<char*>(row) + (size_t)(x >> 7) * 384;
+  const int i = x & 127;
+  float r0, r1, r2, r3;
+  uint2 hi;
+  hi.x = pack_h2(a, b, r0, r1);
+  hi.y = pack_h2(c, d, r2, r3);
+  *reinterpret_cast<uint2*>(g + 2 * i) = hi;
+  *reinterpret_cast<uint32_t*>(g + 256 + i) =
+      WEIGHT ? pack_fp8x4(r0 * kH8LoScale, r1 * kH8LoScale, r2 * kH8LoScale, r3 * kH8LoScale) : pack_fp8x4(a, b, c, d);
+}
+template <bool WEIGHT> __device__ __forceinline__ void store8_w8(w8_t* row, int x, const float (&v)[8]) {
+  char* g = reinterpret_cast<char*>(row) + (size_t)(x >> 7) * 384;
+  const int i = x & 127;
+  float r[8];
+  uint4 hi;
+  hi.x = pack_h2(v[0], v[1], r[0], r[1]);
+  hi.y = pack_h2(v[2], v[3], r[2], r[3]);
+  hi.z = pack_h2(v[4], v[5], r[4], r[5]);
+  hi.w = pack_h2(v[6], v[7], r[6], r[7]);
+  *reinterpret_cast<uint4*>(g + 2 * i) = hi;
+  uint2 p8;
+  if constexpr (WEIGHT) {
+    p8.x = pack_fp8x4(r[0] * kH8LoScale, r[1] * kH8LoScale, r[2] * kH8LoScale, r[3] * kH8LoScale);
+    p8.y = pack_fp8x4(r[4] * kH8LoScale, r[5] * kH8LoScale, r[6] * kH8LoScale, r[7] * kH8LoScale);
+  } else {
+    p8.x = pack_fp8x4(v[0], v[1], v[2], v[3]);
+    p8.y = pack_fp8x4(v[4], v[5], v[6], v[7]);
+  }
+  *reinterpret_cast<uint2*>(g + 256 + i) = p8;
+}
+template <bool WEIGHT> __device__ __forceinline__ void store2_w8(w8_t* row, int x, float a, float b) {
+  char* g = reinterpret_cast<char*>(row) + (size_t)(x >> 7) * 384;
+  const int i = x & 127;
+  float r0, r1;
+  *reinterpret_cast<uint32_t*>(g + 2 * i) = pack_h2(a, b, r0, r1);
+  *reinterpret_cast<uint16_t*>(g + 256 + i) =
+      (uint16_t)((WEIGHT ? pack_fp8x4(r0 * kH8LoScale, r1 * kH8LoScale, 0.f, 0.f) : pack_fp8x4(a, b, 0.f, 0.f)) & 0xffffu);
+}
+template <int W> __device__ __forceinline__ void storew_w8(w8_t* row, int x, const float* v) {  // (an activation row)
+  if constexpr (W == 4) store4_w8<false>(row, x, v[0], v[1], v[2], v[3]);
+  else store2_w8<false>(row, x, v[0], v[1]);
+}
+__device__ __forceinline__ void store8(w8_t*, const float (&)[8]) { __builtin_trap(); }
+__device__ __forceinline__ void store4(w8_t*, float, float, float, float) { __builtin_trap(); }
+__device__ __forceinline__ void store2(w8_t*, float, float) { __builtin_trap(); }
+__device__ __forceinline__ void store_elem(w8_t*, float) { __builtin_trap(); }
+__device__ __forceinline__ void load8(const w8_t*, float (&v)[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = 0.f;
+  __builtin_trap();
+}
+__device__ __forceinline__ void load2(const w8_t*, float& a, float& b) { a = b = 0.f; __builtin_trap(); }
+__device__ __forceinline__ float load_elem(const w8_t*) { __builtin_trap(); return 0.f; }
 template <int W> __device__ __forceinline__ void storew_h8(h8_t* row, int x, const float* v) {  // (an activation row)
   if constexpr (W == 4) store4_h8<false>(row, x, v[0], v[1], v[2], v[3]);
   else store2_h8<false>(row, x, v[0], v[1]);
@@ -368,6 +434,12 @@ template <int W> __device__ __forceinline__ void loadw(const h8_t*, float* v) {
   __builtin_trap();
 }
 template <int W> __device__ __forceinline__ void storew(h8_t*, const float*) { __builtin_trap(); }
+template <int W> __device__ __forceinline__ void loadw(const w8_t*, float* v) {
+#pragma unroll
+  for (int e = 0; e < W; ++e) v[e] = 0.f;
+  __builtin_trap();
+}
+template <int W> __device__ __forceinline__ void storew(w8_t*, const float*) { __builtin_trap(); }
 template <int W> __device__ __forceinline__ void storew(x3_t*, const float*) { __builtin_trap(); }
 template <int W> __device__ __forceinline__ void storew_x3(bf16_t* p, size_t ld, const float* v) {
   if constexpr (W == 4) store4_x3(p, ld, v[0], v[1], v[2], v[3]);
@@ -436,7 +508,9 @@ template <bool FAST> __device__ __forceinline__ void gelu_tanh_both_t(float z, f
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // bytes per LOGICAL element (the split-bf16 tier stores two bf16 planes)
-static inline size_t elem_size(int prec) { return (prec == OSUD_PREC_BF16 || prec == OSUD_PREC_F16) ? 2 : (prec == 2 ? 1 : 4); }
+static inline size_t elem_size(int prec) {
+  return (prec == OSUD_PREC_BF16 || prec == OSUD_PREC_F16) ? 2 : (prec == 2 ? 1 : (prec == OSUD_PREC_F16W8 ? 3 : 4));
+}
 
 // wave-level reductions (wave = 64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {

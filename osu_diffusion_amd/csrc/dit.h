@@ -98,6 +98,7 @@ struct osud_dit {
   bool training = false;
   bool h8 = false;   // OSUD_PREC_F16F8: prec == BF16X3 (x3 set), and the four big GEMMs of every block on fp16 + e4m3 operands (h8_t): their
                      // weights, the LayerNorm / attention / GELU outputs that feed them
+  bool w8 = false;   // OSUD_PREC_F16W8: as h8, with the activation operand of those GEMMs rounded to fp16 (w8_t: fp16 + ONE e4m3 plane)
   bool x3 = false;   // OSUD_PREC_BF16X3: prec == BF16X3, every TE matrix a plane pair [hi | lo] (common.h); inference only
   bool fp8 = false;  // OSUD_PREC_FP8: prec == BF16 everywhere except the e4m3 operands of qkv / out_proj / fc1 / fc2
 
@@ -207,7 +208,7 @@ inline int gemm(osud_dit* m, int epi, const void* Y, int ldy, const void* X, int
 inline int gemm_blk(osud_dit* m, int epi, const void* Y, int ldy, const void* X, int ldx, int My, int Nx, int K, void* out,
                     int ldo, const float* bias, hipStream_t st, const float* gate = nullptr, int ld_gate = 0, int Tp = 0, int N = 0) {
   return gemm(m, epi, Y, ldy, X, ldx, My, Nx, K, out, ldo, bias, st, gate, ld_gate, Tp, N, nullptr, nullptr, nullptr,
-              m->h8 ? OSUD_PREC_F16F8 : m->prec);
+              m->h8 ? OSUD_PREC_F16F8 : (m->w8 ? OSUD_PREC_F16W8 : m->prec));
 }
 
 // GEMM on e4m3 operands (fp8 tier): Y [My][K] and X [Nx][K] are fp8, `dequant` the per-column factors, out per epilogue

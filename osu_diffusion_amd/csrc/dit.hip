@@ -195,7 +195,7 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
 
   const int D = m->D, L = m->L, Tp = round_up(T, 64), M = N * Tp, Mp = round_up(M, 128), Np = round_up(N, 128);
   const int prec = m->prec, AC = m->ada_cols;
-  const int bprec = m->h8 ? OSUD_PREC_F16F8 : prec;  // the operand form of the blocks' four big GEMMs (and of what feeds them)
+  const int bprec = m->h8 ? OSUD_PREC_F16F8 : (m->w8 ? OSUD_PREC_F16W8 : prec);  // the operand form of the blocks' four big GEMMs (and of what feeds them)
   const bool f8_slim = f8_twins_only(m, f8_live, Mp);  // the bf16 forms of the GEMM inputs have no reader this step: not written
   // Gates (osud_dit_forward_gate): the sharded optimizer's all-gather of the updated master weights and their re-pack run on a
   // side stream while this forward is already under way -- phase p's kernels wait for phase p's event only.
@@ -378,6 +378,7 @@ static int upload_f32(osud_dit* m, float** dst, const float* src, size_t n, hipS
 static int convert_w(osud_dit* m, const float* src, void* dst, size_t rows, size_t cols, hipStream_t st, bool block_gemm = false) {
   const size_t n = rows * cols;
   if (m->h8 && block_gemm) return launch_pack_rows_h8(src, (int)cols, (int)cols, dst, (int)cols, (int)rows, true, st);  // (same 4 bytes per element)
+  if (m->w8 && block_gemm) return launch_pack_rows_w8(src, (int)cols, (int)cols, dst, (int)cols, (int)rows, true, st);  // (3 of the buffer's 4 bytes per element)
   if (m->x3) return launch_pack_rows_x3(src, (int)cols, (int)cols, dst, (int)cols, (int)rows, st);  // rows of [w_hi | w_lo]
   if (m->defer_convert && n % 4 == 0) return m->defer_convert->add(src, dst, n / 4);
   return launch_convert(m->prec, src, dst, n, st);
@@ -392,7 +393,8 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   OSUD_CHECK_ARG(cfg->depth > 0 && cfg->context > 0 && cfg->in_channels == 2 && cfg->table_rows > 0,
                  "dit_create: bad depth/context/in_channels/table_rows");
   OSUD_CHECK_ARG(cfg->precision == OSUD_PREC_BF16 || cfg->precision == OSUD_PREC_F32 || cfg->precision == OSUD_PREC_FP8 ||
-                     cfg->precision == OSUD_PREC_BF16X3 || cfg->precision == OSUD_PREC_F16F8 || cfg->precision == OSUD_PREC_F16,
+                     cfg->precision == OSUD_PREC_BF16X3 || cfg->precision == OSUD_PREC_F16F8 || cfg->precision == OSUD_PREC_F16 ||
+                     cfg->precision == OSUD_PREC_F16W8,
                  "dit_create: unknown precision %d", cfg->precision);
   const int hd = cfg->hidden / cfg->heads;
   if (hd != 64 && hd != 72) {
@@ -405,7 +407,8 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   m->C = cfg->in_channels; m->C2 = cfg->learn_sigma ? 2 * cfg->in_channels : cfg->in_channels;
   m->fp8 = cfg->precision == OSUD_PREC_FP8;
   m->h8 = cfg->precision == OSUD_PREC_F16F8;
-  m->prec = m->fp8 ? OSUD_PREC_BF16 : (m->h8 ? OSUD_PREC_BF16X3 : cfg->precision);
+  m->w8 = cfg->precision == OSUD_PREC_F16W8;
+  m->prec = m->fp8 ? OSUD_PREC_BF16 : ((m->h8 || m->w8) ? OSUD_PREC_BF16X3 : cfg->precision);
   m->x3 = m->prec == OSUD_PREC_BF16X3;  // every TE matrix is a plane pair [hi | lo] (common.h): esz = 4 bytes per logical element
   m->esz = (int)elem_size(m->prec);
   m->Kp = round_up(cfg->in_channels * 128 + 128 + cfg->context, 128);  // 528 -> 640
@@ -795,12 +798,17 @@ extern "C" int osud_op_gemm(int precision, int epilogue, const void* Y, int ldy,
   OSUD_CHECK_ARG(precision == OSUD_PREC_BF16 || precision == OSUD_PREC_F32 || precision == 2 /* experimental fp8 e4m3 operands */ ||
                      precision == OSUD_PREC_BF16X3 /* plane pairs [hi | lo]: ld counts logical columns */ ||
                      precision == OSUD_PREC_F16F8 /* K-blocked fp16 + e4m3 groups: ld counts logical columns */ ||
+                     precision == OSUD_PREC_F16W8 /* K-blocked super-groups of 128: ld counts logical columns */ ||
                      precision == OSUD_PREC_F16 /* IEEE half operands */,
                  "op_gemm: unknown precision");
   GemmP p{};
   p.Y = Y; p.X = X; p.ldy = ldy; p.ldx = ldx; p.My = My; p.Nx = Nx; p.K = K; p.out = out; p.ldo = ldo; p.bias = bias;
   p.gate = gate; p.ld_gate = ld_gate; p.rows_per_sample = rows_per_sample; p.n_samples = n_samples;
   return launch_gemm(precision, epilogue, p, (hipStream_t)stream);
+}
+extern "C" int osud_op_pack_w8(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, int weight, osud_stream stream) {
+  OSUD_CHECK_ARG(src && dst, "op_pack_w8: null argument");
+  return launch_pack_rows_w8(src, ld_src, cols_src, dst, cols_dst, rows, weight != 0, (hipStream_t)stream);
 }
 extern "C" int osud_op_pack_h8(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, int weight, osud_stream stream) {
   OSUD_CHECK_ARG(src && dst, "op_pack_h8: null argument");

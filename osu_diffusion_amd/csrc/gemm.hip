@@ -18,6 +18,7 @@ int launch_gemm_f32(int epi, const GemmP& p, hipStream_t st);
 int launch_gemm_fp8(int epi, const GemmP& p, hipStream_t st);
 int launch_gemm_x3(int epi, const GemmP& p, hipStream_t st);
 int launch_gemm_h8(int epi, const GemmP& p, hipStream_t st);
+int launch_gemm_w8(int epi, const GemmP& p, hipStream_t st);
 int launch_gemm_f16(int epi, const GemmP& p, hipStream_t st);
 
 namespace {
@@ -192,6 +193,12 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
     OSUD_CHECK_ARG(p.K % 32 == 0 && p.ldy % 32 == 0 && p.ldx % 32 == 0 && p.ldy >= p.K && p.ldx >= p.K,
                    "gemm: fp16 + e4m3 operands are K-blocked in groups of 32 (K=%d ldy=%d ldx=%d)", p.K, p.ldy, p.ldx);
     return launch_gemm_h8(epi, p, st);
+  }
+  if (prec == OSUD_PREC_F16W8) {
+    OSUD_CHECK_ARG(p.split_k <= 1, "gemm: the fp16 x (fp16 + e4m3) operand form has no split-K");
+    OSUD_CHECK_ARG(p.K % 128 == 0 && p.ldy % 128 == 0 && p.ldx % 128 == 0 && p.ldy >= p.K && p.ldx >= p.K,
+                   "gemm: fp16 x (fp16 + e4m3) operands are K-blocked in super-groups of 128 (K=%d ldy=%d ldx=%d)", p.K, p.ldy, p.ldx);
+    return launch_gemm_w8(epi, p, st);
   }
   if (prec == OSUD_PREC_F16) {
     OSUD_CHECK_ARG(p.split_k <= 1, "gemm: the fp16 operand form is built for the forward pass (no split-K)");

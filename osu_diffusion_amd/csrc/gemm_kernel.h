@@ -73,6 +73,8 @@ __device__ __forceinline__ void mma_f8(f32x16& acc, const u32x4& a0, const u32x4
   acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
 }
 template <> __device__ __forceinline__ void mma<fp8_t>(f32x16&, const u32x4&, const u32x4&) {}  // fp8 goes through mma_f8
+template <> __device__ __forceinline__ void mma<h8_t>(f32x16&, const u32x4&, const u32x4&) {}   // (compute_slab_h8)
+template <> __device__ __forceinline__ void mma<w8_t>(f32x16&, const u32x4&, const u32x4&) {}   // (compute_slab_w8)
 // fp16 + e4m3 operands (h8_t, common.h): the fp16 hi product, and the two cross terms in ONE e4m3 instruction whose A-side block
 // scale 2^-12 (E8M0 115) undoes the 2^12 the lo8 planes carry
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
@@ -185,6 +187,7 @@ __device__ __forceinline__ void compute_slab(f32x16 (&acc)[RY][RX], const uint32
 template <typename TO> __device__ __forceinline__ void store8_out(void* base, size_t row, int ldo, int x, const float (&v)[8]) {
   if constexpr (std::is_same<TO, x3_t>::value) store8_x3(reinterpret_cast<bf16_t*>(base) + row * (size_t)(2 * ldo) + x, (size_t)ldo, v);
   else if constexpr (std::is_same<TO, h8_t>::value) store8_h8<false>(reinterpret_cast<h8_t*>(base) + row * (size_t)ldo, x, v);  // (an activation)
+  else if constexpr (std::is_same<TO, w8_t>::value) store8_w8<false>(reinterpret_cast<w8_t*>(base) + row * (size_t)ldo, x, v);  // (an activation)
   else store8(reinterpret_cast<TO*>(base) + row * (size_t)ldo + x, v);
 }
 
@@ -247,6 +250,51 @@ __device__ __forceinline__ void compute_slab_h8(f32x16 (&acc)[RY][RX], const uin
   for (int i = 0; i < RY; ++i)
 #pragma unroll
     for (int j = 0; j < RX; ++j) mma_f8_lo(acc[i][j], c.x[j], a.x[j], c.y[i], a.y[i]);
+}
+
+// fp16 activations x (fp16 + e4m3 residual) weights (w8_t): the slabs of a row come in threes -- two fp16 slabs (64 k each: the plain
+// half-precision loop) and one e4m3 slab (128 k: two K = 64 block-scaled MFMAs per accumulator, activation e4m3(v) against the weight's
+// residual, whose 2^12 the X-side block scale 2^-12 undoes).  96 matrix-pipe passes per 32 x 32 block and 128 k (h8_t: 128).
+template <int RY, int RX, bool LO>
+__device__ __forceinline__ void compute_slab_w8(f32x16 (&acc)[RY][RX], const uint32_t (&ya)[4], const uint32_t (&xa)[4], uint32_t so) {
+  FragSet<RY, RX> f0, f1;
+  if constexpr (LO) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      read_set<RY, RX>(f0, ya[2 * half] + so, xa[2 * half] + so);
+      read_set<RY, RX>(f1, ya[2 * half + 1] + so, xa[2 * half + 1] + so);
+      wait_lgkm<0>();
+#pragma unroll
+      for (int i = 0; i < RY; ++i)
+#pragma unroll
+        for (int j = 0; j < RX; ++j) mma_f8_lo(acc[i][j], f0.x[j], f1.x[j], f0.y[i], f1.y[i]);
+    }
+  } else {
+    read_set<RY, RX>(f0, ya[0] + so, xa[0] + so);
+    read_set<RY, RX>(f1, ya[1] + so, xa[1] + so);
+    wait_lgkm<RY + RX>();
+#pragma unroll
+    for (int i = 0; i < RY; ++i)
+#pragma unroll
+      for (int j = 0; j < RX; ++j) mma_f16(acc[i][j], f0.x[j], f0.y[i]);
+    read_set<RY, RX>(f0, ya[2] + so, xa[2] + so);
+    wait_lgkm<RY + RX>();
+#pragma unroll
+    for (int i = 0; i < RY; ++i)
+#pragma unroll
+      for (int j = 0; j < RX; ++j) mma_f16(acc[i][j], f1.x[j], f1.y[i]);
+    read_set<RY, RX>(f1, ya[3] + so, xa[3] + so);
+    wait_lgkm<RY + RX>();
+#pragma unroll
+    for (int i = 0; i < RY; ++i)
+#pragma unroll
+      for (int j = 0; j < RX; ++j) mma_f16(acc[i][j], f0.x[j], f0.y[i]);
+    wait_lgkm<0>();
+#pragma unroll
+    for (int i = 0; i < RY; ++i)
+#pragma unroll
+      for (int j = 0; j < RX; ++j) mma_f16(acc[i][j], f1.x[j], f1.y[i]);
+  }
 }
 
 // Tile geometry: WY x WX waves, each wave (RY*32) x (RX*32) outputs: BM = WY*RY*32 rows of Y, BN = WX*RX*32 rows of X.
@@ -341,7 +389,8 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
   constexpr bool kF8 = sizeof(TE) == 1;  // fp8 operands: outputs are bf16 (EPI_BIAS_TE), fp8 (EPI_BIAS_GELU_TE) or fp32
   // fp16 + e4m3 operands (the trunk GEMMs of the tolerance tier): the bias epilogue (in_proj) feeds the split-bf16 attention kernel and
   // writes hi | lo planes; the GELU epilogue (fc1) writes the next GEMM's operand form
-  constexpr bool kH8 = std::is_same<TE, h8_t>::value;
+  constexpr bool kW8 = std::is_same<TE, w8_t>::value;  // (fp16 x (fp16 + e4m3) operands: outputs as for h8_t)
+  constexpr bool kH8 = std::is_same<TE, h8_t>::value || kW8;
   using TO = typename std::conditional<kF8, typename std::conditional<EPI == EPI_BIAS_GELU_TE, fp8_t, bf16_t>::type,
                                        typename std::conditional<kH8 && EPI == EPI_BIAS_TE, x3_t, TE>::type>::type;
   constexpr bool kGelu = EPI == EPI_BIAS_GELU_TE || EPI == EPI_BIAS_GELU_BF;  // _BF: fp8 operands with bf16 outputs (training)
@@ -510,7 +559,10 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
 #ifdef OSUD_GEMM_TIMING
     uint64_t te0 = __builtin_readcyclecounter();
 #endif
-    for (int kt = 0; kt < nk; ++kt) {
+    // one slab: wait for it, barrier, issue a later one, compute.  LO (w8_t operands only): the e4m3 slab of a super-group -- a compile-time
+    // property of the call site, so that the two MFMA bodies never share a function (with a run-time switch between them the register
+    // allocation of the 256 x 256 geometry spilled 500 bytes per lane and the kernel ran 5x slower)
+    auto slab = [&](const int kt, auto LO) {
 #ifdef OSUD_GEMM_TIMING
       const uint64_t tt0 = __builtin_readcyclecounter();
 #endif
@@ -544,6 +596,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
       const uint64_t tt3 = __builtin_readcyclecounter();
 #endif
       if constexpr (kX3) compute_slab_x3<RY, RX>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
+      else if constexpr (kW8) compute_slab_w8<RY, RX, decltype(LO)::value>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
       else if constexpr (kH8) compute_slab_h8<RY, RX>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
       else compute_slab<TE, RY, RX>(acc, ya, xa, (uint32_t)((consumed % G::NSTAGE) * G::STAGE));
 #ifdef OSUD_GEMM_TIMING
@@ -553,6 +606,15 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
       }
 #endif
       ++consumed;
+    };
+    if constexpr (kW8) {  // super-groups of three slabs: fp16, fp16, e4m3 (K % 128 == 0 is the launcher's check)
+      for (int kt = 0; kt < nk; kt += 3) {
+        slab(kt, std::false_type{});
+        slab(kt + 1, std::false_type{});
+        slab(kt + 2, std::true_type{});
+      }
+    } else {
+      for (int kt = 0; kt < nk; ++kt) slab(kt, std::false_type{});
     }
     // The next tile's first slabs are already in flight: make sure they landed NOW, while no store is
     // queued behind them, so the next tile can start right after the epilogue without draining its stores.

@@ -40,6 +40,8 @@ int launch_pack_rows(int prec, const float* src, int ld_src, int cols_src, void*
 int launch_pack_rows_x3(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, hipStream_t st);
 // fp16 + e4m3 operand form (common.h: h8_t; cols_dst % 32 == 0, zero padded): weight = the weight flavour (hi8 | lo8 planes)
 int launch_pack_rows_h8(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, bool weight, hipStream_t st);
+// fp16 x (fp16 + e4m3) operand form (common.h: w8_t; cols_dst % 128 == 0): weight = the flavour whose e4m3 plane is the fp16 residual
+int launch_pack_rows_w8(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, bool weight, hipStream_t st);
 // first linear of the bf16 tier: dst [rows][3 * cols_dst] = [w_hi | w_hi | w_lo]
 int launch_pack_rows_split(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, hipStream_t st,
                            int prec = OSUD_PREC_BF16 /* or OSUD_PREC_F16 */);

@@ -474,44 +474,105 @@ __global__ __launch_bounds__(256, 2) void final_bwd_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------
 // Conditioning path backward.  sb = silu(b), b = tvec + table[y]  (models.py:318-320):
-//   db = dsb * silu'(b) ; dtvec = db (TE copy for the GEMMs + f32) ; dtable[y[n]] += db[n]
-// Samples that share a label: the FIRST of them owns the table row and adds the others' rows in sample order (the label list is
-// a few hundred entries: every block scans it), so that a duplicated label gives the same bits whichever block runs first.
+//   db = dsb * silu'(b) ; dtvec = db (TE copy for the GEMMs + f32) ; dtable[y[n]] = sum of db[n'] over the samples n' with that label
+// Two kernels.  cond_bwd_kernel makes the rows db[n].  table_rows_kernel adds the rows that share a label in a FIXED order (no float
+// atomics: with label dropout a fifth of a training batch carries the null class, and 51 atomic adds per element arrive in any
+// order): block n finds out in parallel whether it is the first sample with its label (the row's owner) and which later samples
+// share it (a bit mask in LDS, turned into an ascending index list); the owner's threads are (column, part) pairs, part p adds rows
+// list[p], list[p + P], ... and the P partial rows meet in LDS and are added in part order.  The table is zeroed by the caller and
+// every touched row has exactly one writer.  (One block walking its 51 rows as a dependent chain per column: 55-100 us; this: ~8.)
 template <typename TE>
-__global__ void cond_bwd_kernel(const float* __restrict__ dsb, const float* __restrict__ b, const int64_t* __restrict__ y,
-                                int table_rows, float* __restrict__ db_out, TE* __restrict__ db_te,
-                                float* __restrict__ dtable, int N, int D) {
+__global__ void cond_bwd_kernel(const float* __restrict__ dsb, const float* __restrict__ b, float* __restrict__ db_out,
+                                TE* __restrict__ db_te, int N, int D) {
+  const int n = blockIdx.x;
+  for (int d = threadIdx.x; d < D; d += blockDim.x) {
+    float g = 0.f;
+    if (n < N) {
+      const float bv = b[(size_t)n * D + d];
+      const float s = 1.0f / (1.0f + expf(-bv));
+      g = dsb[(size_t)n * D + d] * (s + bv * s * (1.0f - s));
+    }
+    db_out[(size_t)n * D + d] = g;
+    store_elem(db_te + (size_t)n * D + d, g);
+  }
+}
+
+constexpr int kTableThreads = 1024;
+__global__ __launch_bounds__(kTableThreads) void table_rows_kernel(const float* __restrict__ db, const int64_t* __restrict__ y, int table_rows,
+                                                                   float* __restrict__ dtable, int N, int D) {
+  constexpr int kMaskWords = 128, kList = 1024;  // batches of up to 4096 samples / 1024 sharers of one label; beyond: the plain walk
+  __shared__ unsigned later[kMaskWords];
+  __shared__ int list[kList];
+  __shared__ int list_n;
+  extern __shared__ float parts[];  // [P][D]
   const int n = blockIdx.x;
   auto label = [&](int i) {
     const int64_t cls = y[i];
     return cls < 0 ? (int64_t)0 : (cls >= table_rows ? (int64_t)table_rows - 1 : cls);
   };
-  auto grad = [&](int i, int d) {
-    const float bv = b[(size_t)i * D + d];
-    const float s = 1.0f / (1.0f + expf(-bv));
-    return dsb[(size_t)i * D + d] * (s + bv * s * (1.0f - s));
-  };
-  const int64_t cls = n < N ? label(n) : 0;
-  int before = 0, after = 0;
-  if (n < N)
-    for (int i = threadIdx.x; i < N; i += blockDim.x)
-      if (i != n && label(i) == cls) (i < n ? before : after) = 1;
-  const bool owner = !__syncthreads_or(before) && n < N;
-  const bool shared_row = __syncthreads_or(after) != 0;
-  for (int d = threadIdx.x; d < D; d += blockDim.x) {
-    float g = 0.f;
-    if (n < N) {
-      g = grad(n, d);
-      if (owner) {
-        float row = g;
-        if (shared_row)
-          for (int i = n + 1; i < N; ++i)
-            if (label(i) == cls) row += grad(i, d);
-        dtable[(size_t)cls * D + d] += row;  // (the only writer of this row)
-      }
+  const int64_t cls = label(n);
+  const bool masked = N <= kMaskWords * 32;
+  for (int w = threadIdx.x; w < kMaskWords; w += blockDim.x) later[w] = 0u;
+  __syncthreads();
+  int before = 0;
+  for (int i = threadIdx.x; i < N; i += blockDim.x)
+    if (i != n && label(i) == cls) {
+      if (i < n) before = 1;
+      else if (masked) atomicOr(&later[i >> 5], 1u << (i & 31));
     }
-    db_out[(size_t)n * D + d] = g;
-    store_elem(db_te + (size_t)n * D + d, g);
+  if (__syncthreads_or(before)) return;  // an earlier sample owns this label's row
+  if (threadIdx.x == 0) {
+    int k = 0;
+    list[k++] = n;
+    if (masked)
+      for (int w = n >> 5; w < (N + 31) / 32; ++w) {
+        unsigned bits = later[w];
+        while (bits) {
+          if (k < kList) list[k] = 32 * w + __builtin_ctz(bits);
+          ++k;
+          bits &= bits - 1;
+        }
+      }
+    list_n = k;
+  }
+  __syncthreads();
+  const int cols4 = D / 4, P = kTableThreads / cols4 > 8 ? 8 : kTableThreads / cols4;
+  const int c4 = threadIdx.x % cols4, part = threadIdx.x / cols4;
+  float* row = dtable + (size_t)cls * D;
+  if (!masked || list_n > kList) {  // (not reached by any realistic batch: the plain walk in sample order)
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+      float s = db[(size_t)n * D + d];
+      for (int i = n + 1; i < N; ++i)
+        if (label(i) == cls) s += db[(size_t)i * D + d];
+      row[d] = s;
+    }
+    return;
+  }
+  const int nl = list_n;
+  if (part < P) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = part;
+    for (; k + 3 * P < nl; k += 4 * P) {  // four rows' loads in flight
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(db + (size_t)list[k + u * P] * D + 4 * c4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+    }
+    for (; k < nl; k += P) {
+      const float4 v = *reinterpret_cast<const float4*>(db + (size_t)list[k] * D + 4 * c4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(parts + (size_t)part * D + 4 * c4) = s;
+  }
+  __syncthreads();
+  if (part == 0) {
+    float4 s = *reinterpret_cast<const float4*>(parts + 4 * c4);
+    for (int p = 1; p < P; ++p) {
+      const float4 v = *reinterpret_cast<const float4*>(parts + (size_t)p * D + 4 * c4);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    *reinterpret_cast<float4*>(row + 4 * c4) = s;
   }
 }
 
@@ -567,25 +628,62 @@ __global__ void colsum_f32_kernel(const float* __restrict__ a, int R_valid, int 
 // Grid (D / 64, items); 16 sample groups x 16 float4 columns per block: group g walks samples g, g + 16, ... and their blocks in
 // order, the 16 groups' bias shares meet in LDS and are added in group order.  One launch per backward call for all the
 // LayerNorm / gate kernels of the call (the descriptor list travels in the kernel arguments).
+// BPS / NQ: compile-time blocks per sample and rows per block (0 = run-time loops): with both known, the 2 x BPS x NQ loads of two
+// samples are issued before the first sum (the kernel is a latency-bound gather of 6 MB: 80 us with one sample's loads in flight)
+template <int BPS, int NQ>
 __global__ __launch_bounds__(256) void row_reduce_kernel(const RowRedList L) {
   __shared__ float4 sh[16][16];
   const int it = blockIdx.y;
   const float* part = L.part[it];
-  const int stride = L.stride[it], bps = L.bps[it], nqs = L.nq_sample[it], samples = L.blocks[it] / bps, D = L.D;
+  const int stride = L.stride[it], bps = BPS ? BPS : L.bps[it], nqs = L.nq_sample[it], samples = L.blocks[it] / bps, D = L.D;
   const int tx = threadIdx.x & 15, tg = threadIdx.x >> 4;
   const int c = blockIdx.x * 64 + tx * 4;
   float* bias = L.bias[it];
+  const int nq = nqs + (bias != nullptr ? 1 : 0);
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int n = tg; n < samples; n += 16) {
-    const float* p0 = part + (size_t)n * bps * stride + c;
-    for (int q = 0; q < nqs + (bias != nullptr ? 1 : 0); ++q) {
-      float4 s = *reinterpret_cast<const float4*>(p0 + (size_t)q * D);
-      for (int j = 1; j < bps; ++j) {
-        const float4 v = *reinterpret_cast<const float4*>(p0 + (size_t)j * stride + (size_t)q * D);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  auto finish = [&](int n, int q, const float4& s) {
+    if (q < nqs) *reinterpret_cast<float4*>(L.dada[it] + (size_t)n * L.ld_ada + L.off[it][q] + c) = s;
+    else { bsum.x += s.x; bsum.y += s.y; bsum.z += s.z; bsum.w += s.w; }
+  };
+  if constexpr (BPS > 0 && NQ > 0) {
+    constexpr int U = 2;  // samples per round
+    for (int n0 = tg; n0 < samples; n0 += 16 * U) {
+      float4 v[U][BPS][NQ];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int n = n0 + 16 * u;
+#pragma unroll
+        for (int j = 0; j < BPS; ++j)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            v[u][j][q] = (n < samples && q < nq) ? *reinterpret_cast<const float4*>(part + ((size_t)n * BPS + j) * stride + (size_t)q * D + c)
+                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      if (q < nqs) *reinterpret_cast<float4*>(L.dada[it] + (size_t)n * L.ld_ada + L.off[it][q] + c) = s;
-      else { bsum.x += s.x; bsum.y += s.y; bsum.z += s.z; bsum.w += s.w; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int n = n0 + 16 * u;
+        if (n >= samples) break;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+          if (q >= nq) break;
+          float4 s = v[u][0][q];
+#pragma unroll
+          for (int j = 1; j < BPS; ++j) { s.x += v[u][j][q].x; s.y += v[u][j][q].y; s.z += v[u][j][q].z; s.w += v[u][j][q].w; }
+          finish(n, q, s);
+        }
+      }
+    }
+  } else {
+    for (int n = tg; n < samples; n += 16) {
+      const float* p0 = part + (size_t)n * bps * stride + c;
+      for (int q = 0; q < nq; ++q) {
+        float4 s = *reinterpret_cast<const float4*>(p0 + (size_t)q * D);
+        for (int j = 1; j < bps; ++j) {
+          const float4 v = *reinterpret_cast<const float4*>(p0 + (size_t)j * stride + (size_t)q * D);
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        finish(n, q, s);
+      }
     }
   }
   if (bias != nullptr) {
@@ -711,12 +809,14 @@ int launch_final_bwd(const float* h, const float* stats, const float* dout, cons
 
 int launch_cond_bwd(int prec, const float* dsb, const float* b, const int64_t* y, int table_rows, float* db_out,
                     void* db_te, float* dtable, int N, int Np, int D, hipStream_t st) {
+  OSUD_CHECK_ARG(D % 4 == 0 && D / 4 <= kTableThreads, "cond_bwd: hidden size %d", D);
   if (prec == OSUD_PREC_BF16)
-    hipLaunchKernelGGL((cond_bwd_kernel<bf16_t>), dim3(Np), dim3(256), 0, st, dsb, b, y, table_rows, db_out,
-                       (bf16_t*)db_te, dtable, N, D);
+    hipLaunchKernelGGL((cond_bwd_kernel<bf16_t>), dim3(Np), dim3(256), 0, st, dsb, b, db_out, (bf16_t*)db_te, N, D);
   else
-    hipLaunchKernelGGL((cond_bwd_kernel<float>), dim3(Np), dim3(256), 0, st, dsb, b, y, table_rows, db_out,
-                       (float*)db_te, dtable, N, D);
+    hipLaunchKernelGGL((cond_bwd_kernel<float>), dim3(Np), dim3(256), 0, st, dsb, b, db_out, (float*)db_te, N, D);
+  OSUD_HIP(hipGetLastError());
+  const int P = kTableThreads / (D / 4) > 8 ? 8 : kTableThreads / (D / 4);
+  hipLaunchKernelGGL(table_rows_kernel, dim3(N), dim3(kTableThreads), (size_t)P * D * sizeof(float), st, db_out, y, table_rows, dtable, N, D);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }
@@ -798,7 +898,14 @@ int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_
 int launch_row_reduce(const RowRedList& L, hipStream_t st) {
   if (L.count == 0) return OSUD_OK;
   OSUD_CHECK_ARG(L.D % 64 == 0 && L.ld_ada % 4 == 0, "row_reduce: D=%d, ld=%d", L.D, L.ld_ada);
-  hipLaunchKernelGGL(row_reduce_kernel, dim3(L.D / 64, L.count), dim3(256), 0, st, L);
+  // (every item of a list comes from the same backward call: the same blocks per sample; rows per block: at most 4 = 3 per-sample + bias)
+  const int bps = L.bps[0];
+  bool uniform = true;
+  for (int i = 1; i < L.count; ++i) uniform = uniform && L.bps[i] == bps;
+  if (uniform && bps == 2) hipLaunchKernelGGL((row_reduce_kernel<2, 4>), dim3(L.D / 64, L.count), dim3(256), 0, st, L);
+  else if (uniform && bps == 4) hipLaunchKernelGGL((row_reduce_kernel<4, 4>), dim3(L.D / 64, L.count), dim3(256), 0, st, L);
+  else if (uniform && bps == 1) hipLaunchKernelGGL((row_reduce_kernel<1, 4>), dim3(L.D / 64, L.count), dim3(256), 0, st, L);
+  else hipLaunchKernelGGL((row_reduce_kernel<0, 0>), dim3(L.D / 64, L.count), dim3(256), 0, st, L);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
 }

@@ -216,6 +216,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* h, const float
     }
     if constexpr (std::is_same<TE, x3_t>::value) storew_x3<W>(reinterpret_cast<bf16_t*>(orow) + d, (size_t)D, r);
     else if constexpr (std::is_same<TE, h8_t>::value) storew_h8<W>(orow, d, r);
+    else if constexpr (std::is_same<TE, w8_t>::value) storew_w8<W>(orow, d, r);
     else if (!TWIN || out != nullptr) storew<W>(orow + d, r);  // (twin only: every consumer of this step reads the e4m3 form)
     if constexpr (TWIN) {
       float q[W];
@@ -398,6 +399,19 @@ template <bool WEIGHT> __global__ void pack_rows_h8_kernel(const float* __restri
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = cc + e < cols_src ? src[(size_t)r * ld_src + cc + e] : 0.f;
     store4_h8<WEIGHT>(dst + (size_t)r * cols_dst, cc, v[0], v[1], v[2], v[3]);
+  }
+}
+
+// fp16 x (fp16 + e4m3) tier: dst row = K-blocked super-groups of 128 logical columns (common.h: w8_t), zero padded to cols_dst
+template <bool WEIGHT> __global__ void pack_rows_w8_kernel(const float* __restrict__ src, int ld_src, int cols_src, w8_t* __restrict__ dst,
+                                                            int cols_dst, int rows) {
+  const size_t total = (size_t)rows * (cols_dst / 4);
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / (cols_dst / 4)), cc = (int)(i % (cols_dst / 4)) * 4;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = cc + e < cols_src ? src[(size_t)r * ld_src + cc + e] : 0.f;
+    store4_w8<WEIGHT>(dst + (size_t)r * cols_dst, cc, v[0], v[1], v[2], v[3]);
   }
 }
 
@@ -627,6 +641,17 @@ int launch_pack_rows_h8(const float* src, int ld_src, int cols_src, void* dst, i
   return OSUD_OK;
 }
 
+int launch_pack_rows_w8(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, bool weight, hipStream_t st) {
+  OSUD_CHECK_ARG(cols_dst % 128 == 0 && cols_src <= cols_dst, "pack_rows_w8: cols_dst=%d must be a multiple of 128 and >= cols_src=%d", cols_dst, cols_src);
+  const size_t total = (size_t)rows * (cols_dst / 4);
+  if (total == 0) return OSUD_OK;
+  const int grid = (int)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+  if (weight) hipLaunchKernelGGL(pack_rows_w8_kernel<true>, dim3(grid), dim3(256), 0, st, src, ld_src, cols_src, (w8_t*)dst, cols_dst, rows);
+  else hipLaunchKernelGGL(pack_rows_w8_kernel<false>, dim3(grid), dim3(256), 0, st, src, ld_src, cols_src, (w8_t*)dst, cols_dst, rows);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
 int launch_pack_rows_split(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, hipStream_t st, int prec) {
   const size_t total = (size_t)rows * cols_dst;
   if (total == 0) return OSUD_OK;
@@ -725,6 +750,10 @@ int launch_ln_mod(int prec, const float* h, const float* ada, int ld_ada, int of
   if (prec == OSUD_PREC_F16F8) {  // (the trunk GEMMs' operand form inside the split-bf16 tier)
     OSUD_CHECK_ARG(br == nullptr, "ln_mod: the fp16 + e4m3 tier is inference only (no pending branch operand)");
     return ln_mod_t<h8_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, nullptr, 0, h_out);
+  }
+  if (prec == OSUD_PREC_F16W8) {
+    OSUD_CHECK_ARG(br == nullptr && D % 128 == 0, "ln_mod: the fp16 x (fp16 + e4m3) form is inference only and K-blocked in groups of 128 (D=%d)", D);
+    return ln_mod_t<w8_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, nullptr, 0, h_out);
   }
   return prec == OSUD_PREC_BF16
              ? ln_mod_t<bf16_t>(h, ada, ld_ada, off_shift, off_scale, out, stats, M, Tp, N, D, st, br, off_gate, h_out)

@@ -217,12 +217,14 @@ def exchange_table_rows(table_grad, labels, group=None):
     return table_grad
 
 
-def backward_with_overlapped_allreduce(model, dout, group=None, force=False, on_blocks_reduced=None, comm=None):
+def backward_with_overlapped_allreduce(model, dout, group=None, force=False, on_blocks_reduced=None, comm=None, stub=False):
     """Backward in phases; each block's gradient slice is SUM-all-reduced (async, RCCL's own stream) as soon
     as its phase is enqueued, overlapping the exchange with the remaining backward compute — the role of
     DDP's bucketed reducer (train.py:152,257).  `on_blocks_reduced()` (optional) is called once every block slice has
     been reduced, while the tail exchange is still in flight (the optimizer uses that window).
     `comm` (a comm.NativeComm): the slices travel through the C ABI's osud_allreduce_grads instead of torch.distributed.
+    `stub`: the same phased schedule with every collective left out (measurement only: bench.py's exposed-communication figure is
+    the step time with the exchange minus the step time of this).
     Returns the 1/world factor for the optimizer."""
     import torch.distributed as dist
 
@@ -233,6 +235,9 @@ def backward_with_overlapped_allreduce(model, dout, group=None, force=False, on_
         return 1.0
     arena, depth = model._arena, model.depth
     blocks, tail = overlap_slices(arena, depth)
+    world_scale = 1.0 / dist.get_world_size(group) if active else 1.0
+    if stub:
+        active = False
     if comm is not None and active:  # the library's own RCCL communicator (C ABI: osud_allreduce_grads on its side stream)
         reduce = lambda t: comm.all_reduce_(t, async_op=True)  # noqa: E731
     else:
@@ -270,7 +275,7 @@ def backward_with_overlapped_allreduce(model, dout, group=None, force=False, on_
     for h in tail_handles:
         if h is not None:
             h.wait()
-    return 1.0 / dist.get_world_size(group) if active else 1.0
+    return world_scale
 
 
 # ------------------------------------------------------------------------------ ZeRO-1 exchange (reduce-scatter / all-gather)
@@ -369,7 +374,7 @@ class NativeTrainer:
 
     def __init__(self, model, diffusion, lr=1e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, ema_decay=0.9999,
                  ema=None, group=None, broadcast_init=True, shard_optimizer=False, wire_dtype=None, force_phased=False,
-                 overlap_gather=True, native_comm=False):
+                 overlap_gather=True, native_comm=False, stub_exchange=False):
         """shard_optimizer: ZeRO-1 exchange (reduce-scatter / sharded AdamW + EMA / all-gather) instead of the all-reduce.
         wire_dtype=torch.bfloat16: gradients rounded to bf16 for the reduce-scatter.  overlap_gather: with the sharded optimizer,
         the master all-gather runs under the next step's forward.  native_comm: the exchange goes through the library's own RCCL
@@ -399,6 +404,7 @@ class NativeTrainer:
         self.table_step = 0
         self.embed_only = False
         self.force_phased = bool(force_phased)
+        self.stub_exchange = bool(stub_exchange)  # measurement only: the multi-GPU schedule with its collectives left out
         self._side = None
         # ZeRO-1 between the two halves of the gradient exchange: every finished slice is reduce-SCATTERED
         # (rank r receives the sum of its 1/world shard), AdamW + EMA run on that shard only (1/world of the 6.1 GB the optimizer
@@ -487,7 +493,7 @@ class NativeTrainer:
                 self._backward_sharded(dout)
                 return terms
             scale = backward_with_overlapped_allreduce(model, dout, self.group, force=self.force_phased, on_blocks_reduced=early,
-                                                       comm=self.comm)
+                                                       comm=self.comm, stub=self.stub_exchange)
             if done:
                 self._adamw(_complement(done, self.arena.total), scale)
                 self._refresh()

@@ -155,3 +155,15 @@ def test_bench_two_ranks_over_gloo():
         res = json.loads(line)
         assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["scaling"] == "weak"
         assert res["config"]["global_batch"] == 32
+        # the self-diagnosing part of a multi-GPU line: ranks seen by the backend, the in-run A/B of the exchange schedules, the
+        # exposed-communication figure and the bytes on the wire
+        mg = res["multi_gpu"]
+        assert mg["rccl"]["ranks_seen"] == 2 and mg["rccl"]["world_size"] == 2 and mg["rccl"]["backend"] == "gloo"
+        for name in ("allreduce", "zero1", "zero1_no_overlap", "no_exchange"):
+            assert mg["schedules"][name]["ms_per_step"] > 0 and mg["schedules"][name]["tokens_per_s"] > 0, (name, mg["schedules"][name])
+        assert "skipped" in mg["schedules"]["native_comm"]
+        assert mg["fastest_schedule"] in ("allreduce", "zero1", "zero1_no_overlap")
+        assert isinstance(mg["exposed_comm_ms_per_step"], float)
+        assert mg["timed_schedule"]["name"] == ("zero1" if extra else "allreduce") and mg["timed_schedule"]["ms_per_step"] > 0
+        wb = mg["wire_bytes_per_step"]
+        assert wb["dense_slices_payload"] > 0 and wb["class_table_rows_allgather"] < wb["class_table_dense_would_be"] and wb["ring_bytes_sent_per_gpu"] > 0

@@ -60,6 +60,37 @@ def _cli_fixture(tmp_path):
     return fx, str(ckpt), str(idx)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16f8"])
+def test_sample_cli_refine_ckpt_reproduces_the_reference_run(tmp_path, precision):
+    """sample.py:186-205 through the CLI: `--refine-ckpt` loads a second checkpoint into the model after the loop and runs
+    `--refine-iters` = 10 p_sample steps at t = 0 (here: ONE native call).  Fixture g15_refine_cli is the reference's own flow on the
+    toy beatmap's 128-object window (250 steps, cfg 4, then 10 refine iterations on the other weights): both files the CLI writes
+    -- result.pt before, result_10.pt after the pass -- land within 1e-3 of it."""
+    from oracle import dit_oracle as mo
+    from tests.helpers import load, shape_from
+
+    fx, ckpt, idx = _cli_fixture(tmp_path)
+    rf = load("g15_refine_cli")
+    sd_r = mo.seeded_state_dict(shape_from(rf), int(rf["refine_wseed"]))
+    assert abs(float(sum(v.double().abs().sum() for v in sd_r.values())) - float(rf["refine_wsum"])) <= 1e-9 * float(rf["refine_wsum"])
+    refine_ckpt = tmp_path / "refine.pt"
+    torch.save({"ema": sd_r, "model": sd_r}, refine_ckpt)
+    args = [os.path.join(ROOT, "sample.py"), "--beatmap", TOY, "--ckpt", ckpt, "--model", "DiT-S", "--num-classes", "10",
+            "--num-sampling-steps", str(int(rf["steps"])), "--cfg-scale", "4.0", "--seed", "0", "--seq-len", "128",
+            "--style-id", str(int(rf["style_id"])), "--beatmap-idx", idx, "--noise", "cpu", "--precision", precision,
+            "--plot-time", str(float(rf["plot_time"])), "--refine-ckpt", str(refine_ckpt), "--refine-iters", str(int(rf["refine_iters"]))]
+    run(args, str(tmp_path))
+    pf = torch.tensor([512.0, 384.0]).view(1, 2, 1)
+    before = torch.load(glob.glob(os.path.join(str(tmp_path), "results", "*", "result.pt"))[0])[:, :2] / pf
+    after = torch.load(glob.glob(os.path.join(str(tmp_path), "results", "*", "result_10.pt"))[0])[:, :2] / pf
+    e0 = float((before - torch.from_numpy(rf["final"])).abs().max())
+    e1 = float((after - torch.from_numpy(rf["refined"])).abs().max())
+    moved = float((torch.from_numpy(rf["refined"]) - torch.from_numpy(rf["final"])).abs().max())
+    print(f"MEASURED cli_refine[{precision}]: loop result {e0:.3e}, refined result {e1:.3e} from the reference's (the pass moves the result by {moved:.3e})")
+    assert e0 < 1e-3 and e1 < 1e-3 and moved > 1e-2
+    assert len(glob.glob(os.path.join(str(tmp_path), "results", "*", "*result 5 0 10.osu"))) == 1  # the refined difficulty is written too
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16f8"])
 @pytest.mark.parametrize("tag", ["full100", "trim250"])
 def test_sample_cli_with_cpu_noise_reproduces_the_reference_run(tmp_path, tag, precision):
@@ -131,3 +162,20 @@ def test_train_script_on_osu_dataset(tmp_path):
     assert set(ck) >= {"model", "ema", "opt", "args"}
     losses = [float(line.split("Train Loss: ")[1].split(",")[0]) for line in out.splitlines() if "Train Loss: " in line]
     assert all(l == l and l < 10 for l in losses)
+
+
+def test_train_script_fp8_tier_from_the_cli(tmp_path):
+    """BASELINE configs[4]'s arithmetic from the command line (reference surface: train.py:249-259,327 `--use-amp`): `train.py --precision
+    fp8` runs every Linear product of the blocks on e4m3 operands with delayed scaling (first step bf16: no amax history yet) and its
+    loss follows the bf16 tier's on the same synthetic stream."""
+    curves = {}
+    for prec in ("bf16", "fp8"):
+        out = run([os.path.join(ROOT, "train.py"), "--synthetic", "--model", "DiT-S", "--num-classes", "10", "--global-batch-size", "8",
+                   "--epochs", "1", "--steps-per-epoch", "12", "--log-every", "3", "--ckpt-every", "1000", "--seq-len", "128",
+                   "--precision", prec, "--results-dir", str(tmp_path / prec)], str(tmp_path))
+        assert f"arithmetic tier: {prec}" in out
+        curves[prec] = [float(line.split("Train Loss: ")[1].split(",")[0]) for line in out.splitlines() if "Train Loss: " in line]
+        assert len(curves[prec]) == 4 and all(l == l and l < 10 for l in curves[prec]), out[-1500:]
+    rel = max(abs(a - b) / max(abs(a), 1e-6) for a, b in zip(curves["bf16"], curves["fp8"]))
+    print(f"MEASURED train_cli_fp8: logged losses bf16 {curves['bf16']} fp8 {curves['fp8']} (worst relative difference {rel:.3e})")
+    assert rel < 0.05

@@ -1,0 +1,211 @@
+"""GPU (-m gpu): fp16 activations x (fp16 + e4m3-residual) weights (precision="fp16w8", OSUD_PREC_F16W8) through the C ABI.
+
+The tolerance tier's cheapest form: the fp16f8 tier (tests/test_gpu_h8.py) with the ACTIVATION operand of in_proj / out_proj / fc1 / fc2
+rounded to fp16 (11 significand bits) while the WEIGHT keeps hi = fp16(w) and lo8 = e4m3((w - hi) 2^12) (15 bits).  The reasoning is
+about how errors add up over a sampling loop, not about one product: an activation is rounded afresh for every token at every step (errors
+of random sign: they average out), a weight's rounding error is the same number in every product of every step (it accumulates).  Measured
+on the 1000-step DiT-B loops (bench.py's drift record and the reference fixture): both operands fp16 5.5e-3 / 2.8e-3, activations only
+6.6e-4 / 3.9e-4, neither (fp16f8) 1.3e-4 / 1.2e-4.  A product over 128 k is a_hi . w_hi on eight v_mfma_f32_32x32x16_f16 plus
+2^-12 e4m3(a) . lo8_w on two block-scaled v_mfma_scale_f32_32x32x64_f8f6f4: 96 matrix-pipe passes where fp16f8 issues 128.  Rows are
+K-blocked in 384-byte super-groups of 128 logical columns [128 B fp16 | 128 B fp16 | 128 B e4m3 plane]: three stage rows of the GEMM.
+
+Tolerances: operators against an fp64 evaluation of the ORIGINAL fp32 operands; model outputs and loops against the fixtures frozen from
+the reference; bounds <= 3x what was measured on MI355X where the north star's 1e-3 is not the bound itself.
+"""
+import numpy as np
+import pytest
+import torch
+
+from osu_diffusion_amd import _lib
+from osu_diffusion_amd.diffusion import create_diffusion
+from tests.helpers import T, load, maxdiff, weights_for
+from tests.test_gpu_forward import FWD_TAGS, native_model
+from tests.test_gpu_x3 import _p1000_inputs, from_x3
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+W8 = _lib.PREC_F16W8
+
+
+def pack_w8_torch(t, weight):
+    """(R, C) fp32, C % 128 == 0 -> (R, 3C) uint8 in the K-blocked layout (a torch restatement of csrc/common.h: store4_w8)."""
+    t = t.detach().cpu().float()
+    R, C = t.shape
+    hi = t.to(torch.float16)
+    plane = (((t - hi.float()) * 4096.0) if weight else t).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8)
+    return torch.cat([hi.view(torch.uint8).view(R, C // 128, 256), plane.view(R, C // 128, 128)], dim=2).reshape(R, 3 * C).contiguous()
+
+
+def pack_w8(t, weight):
+    R, C = t.shape
+    out = torch.empty(R, 3 * C, dtype=torch.uint8, device=DEV)
+    _lib.check(_lib.lib().osud_op_pack_w8(_lib.ptr(t), C, C, _lib.ptr(out), C, R, 1 if weight else 0, None))
+    return out
+
+
+def from_w8(buf, rows, cols):
+    """Decode the fp16 part of a buffer (an activation's value as the next GEMM's hi product sees it)."""
+    g = buf.cpu().view(torch.uint8).view(rows, cols // 128, 384)
+    return g[:, :, :256].contiguous().view(torch.float16).float().view(rows, cols)
+
+
+@pytest.mark.parametrize("weight", [False, True])
+def test_pack_kernel_matches_the_format_restatement(weight):
+    torch.manual_seed(3)
+    a = torch.randn(192, 256, device=DEV) * torch.logspace(-4, 2, 256, device=DEV)  # columns from 1e-4 to 1e2: fp16 / e4m3 subnormals too
+    a[0, :4] = torch.tensor([0.0, -0.0, 500.0, -1000.0])  # beyond e4m3's 448: the 8-bit plane saturates, hi does not
+    d, r = pack_w8(a, weight).cpu(), pack_w8_torch(a, weight)
+    assert int((d != r).sum()) == 0
+    out = torch.empty(8, 3 * 128, dtype=torch.uint8, device=DEV)  # zero padding of a narrower source
+    _lib.check(_lib.lib().osud_op_pack_w8(_lib.ptr(a), 256, 40, _lib.ptr(out), 128, 8, int(weight), None))
+    ref = torch.zeros(8, 128)
+    ref[:, :40] = a[:8, :40].cpu()
+    assert torch.equal(out.cpu(), pack_w8_torch(ref, weight))
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 128), (256, 384, 640), (128, 3072, 768), (256, 768, 3072), (16384, 768, 768)])
+def test_gemm_is_the_exact_product_of_fp16_activations_and_15_bit_weights(shape):
+    """Against fp64: (a) the product of the ROUNDED activation fp16(Y) with the original weight X -- what this operand form computes up to
+    the weight's 15-bit representation and fp32 accumulation: a split-bf16-class error; (b) the original product: an fp16-class error
+    (the activation rounding, by design)."""
+    My, Nx, K = shape
+    torch.manual_seed(My + Nx + K)
+    Y = torch.randn(My, K, device=DEV) * 2.0
+    X = torch.randn(Nx, K, device=DEV) / K ** 0.5  # asymmetric operands: a transposed result cannot pass
+    bias = torch.randn(Nx, device=DEV)
+    ref = (Y.double() @ X.double().T + bias.double()).float()
+    ref_a16 = (Y.half().double() @ X.double().T + bias.double()).float()
+    Yc, Xc = pack_w8(Y, False), pack_w8(X, True)
+    out = torch.zeros(My, Nx, device=DEV)
+    _lib.check(_lib.lib().osud_op_gemm(W8, _lib.EPI_BIAS_F32, _lib.ptr(Yc), K, _lib.ptr(Xc), K, My, Nx, K,
+                                       _lib.ptr(out), Nx, _lib.ptr(bias), None, 0, 0, 0, None))
+    e_fmt, e_all = maxdiff(out.cpu(), ref_a16.cpu()), maxdiff(out.cpu(), ref.cpu())
+    f16 = maxdiff((Y.half().double() @ X.half().double().T + bias.double()).float().cpu(), ref.cpu())
+    print(f"MEASURED w8_gemm{shape}: max|d| = {e_fmt:.3e} from the fp16-activation product, {e_all:.3e} from the exact one, at output "
+          f"scale {float(ref.abs().max()):.1f} (both operands fp16: {f16:.3e})")
+    assert e_fmt < 3.5e-4 and e_all < 1.2 * f16 + 1e-4
+
+
+def test_gemm_fused_epilogues():
+    """in_proj's epilogue writes split-bf16 planes (the attention kernel's input), fc1's writes the next GEMM's activation rows, out_proj /
+    fc2 update the fp32 residual through the gate."""
+    My, Nx, K, Tp, NS = 256, 256, 128, 64, 3
+    torch.manual_seed(5)
+    Y = torch.randn(My, K, device=DEV)
+    X = torch.randn(Nx, K, device=DEV) / K ** 0.5
+    bias = torch.randn(Nx, device=DEV)
+    gate = torch.randn(NS + 1, Nx, device=DEV)
+    res = torch.randn(My, Nx, device=DEV)
+    Yc, Xc = pack_w8(Y, False), pack_w8(X, True)
+    z = (Y.half().double() @ X.double().T + bias.double())  # (the fp16-activation product: the rounding of Y is the format's own)
+    L = _lib.lib()
+
+    def run(epi, out, g=None):
+        _lib.check(L.osud_op_gemm(W8, epi, _lib.ptr(Yc), K, _lib.ptr(Xc), K, My, Nx, K, _lib.ptr(out), Nx, _lib.ptr(bias),
+                                  None if g is None else _lib.ptr(g), Nx, Tp, NS + 1, None))
+        return out
+
+    o1 = run(_lib.EPI_BIAS_TE, torch.zeros(My, 2 * Nx, dtype=torch.bfloat16, device=DEV))
+    e1 = maxdiff(from_x3(o1, My, Nx).cpu(), z.float().cpu())
+    o4 = run(_lib.EPI_BIAS_GELU_TE, torch.zeros(My, 3 * Nx, dtype=torch.uint8, device=DEV))
+    gelu = torch.nn.functional.gelu(z, approximate="tanh").float()
+    e4 = maxdiff(from_w8(o4, My, Nx), gelu.half().float().cpu())
+    plane = o4.cpu().view(torch.uint8).view(My, Nx // 128, 384)[:, :, 256:].contiguous().view(torch.float8_e4m3fn).float().view(My, Nx)
+    assert maxdiff(plane, gelu.cpu()) <= 0.07 * float(gelu.abs().max())  # (the e4m3 plane of an activation: e4m3 of the value itself)
+    o5 = run(_lib.EPI_GATE_RES, res.clone(), gate)
+    want5 = res.double() + gate.double().repeat_interleave(Tp, 0)[:My] * z
+    e5 = maxdiff(o5.cpu(), want5.float().cpu())
+    X2 = torch.randn(128, Nx, device=DEV) / Nx ** 0.5  # the GELU output as the next GEMM's operand
+    out2 = torch.zeros(My, 128, device=DEV)
+    _lib.check(L.osud_op_gemm(W8, _lib.EPI_NONE_F32, _lib.ptr(o4), Nx, _lib.ptr(pack_w8(X2, True)), Nx, My, 128, Nx, _lib.ptr(out2), 128,
+                              None, None, 0, 0, 0, None))
+    e6 = maxdiff(out2.cpu(), (from_w8(o4, My, Nx).double().to(DEV) @ X2.double().T).float().cpu())
+    print(f"MEASURED w8_epilogues: bias -> split-bf16 planes {e1:.2e}, gelu -> fp16 rows {e4:.2e}, gated residual {e5:.2e}, chained product {e6:.2e}")
+    assert e1 < 1.5e-4 and e4 < 3e-3 and e5 < 3e-4 and e6 < 1.5e-4  # (e4: one fp16 ulp at the output's scale)
+
+
+def test_gemm_rejects_what_it_does_not_build():
+    Y = torch.zeros(128, 3 * 256, dtype=torch.uint8, device=DEV)
+    out = torch.zeros(128, 128, device=DEV)
+    L = _lib.lib()
+    rc = L.osud_op_gemm(W8, _lib.EPI_NONE_F32, _lib.ptr(Y), 256, _lib.ptr(Y), 256, 128, 128, 192, _lib.ptr(out), 128, None, None, 0, 0, 0, None)
+    assert rc == _lib.ERR_ARG  # K % 128
+    rc = L.osud_op_gemm(W8, 7, _lib.ptr(Y), 256, _lib.ptr(Y), 256, 128, 128, 256, _lib.ptr(out), 128, None, None, 0, 0, 0, None)
+    assert rc == _lib.ERR_UNSUPPORTED  # a training epilogue
+
+
+W8_FWD = 1.5e-3  # plain forward / max(scale, 1): the activation's fp16 rounding is visible in ONE forward (fp16f8: 2e-4) -- what the tier
+#                  is built on is how that error behaves over a loop (the loop tests below)
+
+
+@pytest.mark.parametrize("tag", FWD_TAGS)
+def test_forward_matches_reference_golden(tag):
+    fx = load(f"g3_forward_{tag}")
+    shape, sd = weights_for(fx)
+    m = native_model(shape, sd, "fp16w8")
+    x, t, o, c, y = (T(fx[k]).to(DEV) for k in ("x", "t", "o", "c", "y"))
+    mask = T(fx["attn_mask"]).to(DEV) if "attn_mask" in fx else None
+    scale = float(np.abs(fx["out"]).max())
+    with torch.no_grad():
+        errs = {"out": maxdiff(m(x, t, o, c, y, attn_mask=mask).cpu(), fx["out"]),
+                "cfg4": maxdiff(m.forward_with_cfg(x, t, o, c, y, 4.0, attn_mask=mask).cpu(), fx["out_cfg4"]),
+                "cfg1": maxdiff(m.forward_with_cfg(x, t, o, c, y, 1.0, attn_mask=mask).cpu(), fx["out_cfg1"])}
+    print(f"MEASURED w8_forward[{tag}]: scale {scale:.2f}, errors {({k: f'{v:.2e}' for k, v in errs.items()})}")
+    assert max(errs["out"], errs["cfg1"]) <= W8_FWD * max(scale, 1.0) and errs["cfg4"] <= 5 * W8_FWD * max(scale, 1.0), errs
+
+
+@pytest.mark.parametrize("tag", ["p20", "ddim20_eta1", "p250"])
+def test_chained_loop_final_coordinates(tag):
+    fx = load(f"g6_loop_{tag}")
+    shape, sd = weights_for(fx)
+    m = native_model(shape, sd, "fp16w8")
+    kw = dict(o=T(fx["o"]).to(DEV), c=T(fx["c"]).to(DEV), y=T(fx["y"]).to(DEV), cfg_scale=4.0, attn_mask=None)
+    d = create_diffusion(str(fx["respacing"]), noise_schedule="squaredcos_cap_v2")
+    z = T(fx["z"]).to(DEV)
+    eta = float(fx["eta"])
+    if eta >= 0:
+        got = d.ddim_sample_loop(m.forward_with_cfg, z.shape, z, model_kwargs=kw, eta=eta, step_noise=T(fx["noises"]))
+    else:
+        got = d.p_sample_loop(m.forward_with_cfg, z.shape, z, model_kwargs=kw, step_noise=T(fx["noises"]))
+    err = maxdiff(got.cpu(), fx["final"])
+    print(f"MEASURED w8_loop[{tag}]: final max|d| = {err:.3e}")
+    assert err < 1e-3  # the north star's bound
+
+
+def test_dit_b_1000_step_cfg4_loop_matches_the_reference():
+    """BASELINE configs[3] end to end (as tests/test_gpu_x3.py::test_dit_b_1000_step_cfg4_loop_matches_the_reference): within 1e-3 of the
+    reference's own 1000-step CFG-4 DiT-B loop at every quarter."""
+    fx, shape, sd, z, noises = _p1000_inputs()
+    m = native_model(shape, sd, "fp16w8")
+    d = create_diffusion("1000", noise_schedule="squaredcos_cap_v2")
+    kw = dict(o=T(fx["o"]).to(DEV), c=T(fx["c"]).to(DEV), y=T(fx["y"]).to(DEV), cfg_scale=4.0, attn_mask=None)
+    x = z.to(DEV).clone()
+    nz = noises.to(DEV)
+    errs, done = {}, 0
+    for k in (250, 500, 750, 1000):
+        d.run_steps(m.forward_with_cfg, x, kw, first_step=999 - done, last_step=1000 - k, step_noise=nz[done:k])
+        errs[k] = maxdiff(x.cpu(), fx["final"] if k == 1000 else fx[f"after_{k}"])
+        done = k
+    print("MEASURED p1000_dit_b[fp16w8]: max|d| vs reference after 250/500/750/1000 steps = " + " / ".join(f"{errs[k]:.3e}" for k in (250, 500, 750, 1000)))
+    assert max(errs.values()) < 1e-3, errs
+
+
+@pytest.mark.parametrize("hidden,heads,T_", [(1152, 16, 256), (1152, 16, 200), (1024, 16, 128)])
+def test_forward_on_other_geometries_against_the_fp32_oracle(hidden, heads, T_):
+    """DiT-XL's geometry (1152 = 9 super-groups of 128; heads of 72 columns straddle them) and DiT-L's, masked and not."""
+    from oracle import dit_oracle as mo
+    from osu_diffusion_amd.synthetic import banded_attn_mask, synthetic_windows
+
+    shape = mo.DitShape(depth=2, hidden=hidden, heads=heads, num_classes=10)
+    sd = mo.seeded_state_dict(shape, 78)
+    (x, o, c), y = synthetic_windows(3, T_, 10, seed=6)
+    t = torch.tensor([999, 400, 0])
+    mask = banded_attn_mask(T_, 128) if T_ == 200 else None
+    ref = mo.forward(sd, shape, x, t, o, c, y, attn_mask=mask)
+    scale = max(1.0, float(ref.abs().max()))
+    with torch.no_grad():
+        got = native_model(shape, sd, "fp16w8")(x.to(DEV), t.to(DEV), o.to(DEV), c.to(DEV), y.to(DEV),
+                                                attn_mask=None if mask is None else mask.to(DEV)).cpu()
+    err = maxdiff(got, ref)
+    print(f"MEASURED w8_forward_geometry[{hidden},{heads},{T_}]: max|d| vs the fp32 oracle at scale {scale:.2f}: {err:.2e}")
+    assert err < 3e-4 * scale

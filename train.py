@@ -69,6 +69,9 @@ def main(args):
                                    class_dropout_prob=0.2, precision=args.precision).to(device)
     diffusion = create_diffusion(timestep_respacing="", noise_schedule=args.noise_schedule, use_l1=args.l1_loss)
     logger.info(f"DiT Parameters: {sum(p.numel() for p in model.parameters()):,}")
+    logger.info(f"arithmetic tier: {args.precision}" + (" (every Linear product of the blocks -- forward, data and weight gradients -- on e4m3 "
+                                                         "operands, delayed per-tensor scaling; attention / adaLN / embedders bf16; fp32 masters)"
+                                                         if args.precision == "fp8" else ""))
     # AdamW(lr, wd=0) + EMA 0.9999 + init broadcast; the exchange options are flags of this script (--zero1, --grad-wire, --native-comm)
     trainer = NativeTrainer(model, diffusion, lr=args.lr, shard_optimizer=args.zero1,
                             wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None, native_comm=args.native_comm)
