@@ -77,6 +77,10 @@ extern "C" {
                             v_mfma_f32_32x32x16_f16 + two block-scaled v_mfma_scale_f32_32x32x64_f8f6f4 = 3/4 of F16F8's matrix-pipe passes,
                             3 instead of 4 operand bytes per element */
 
+#define OSUD_PREC_F16M8 7 /* the tolerance tier with a per-GEMM choice between the two operand forms above: option "f16m8_forms" (read at
+                            osud_dit_create) has bit i set where GEMM i of a block (0 in_proj, 1 out_proj, 2 fc1, 3 fc2) takes fp16 activations
+                            (F16W8's form) and clear where it keeps the activation's residual (F16F8's); default 11 = every big GEMM but fc1 */
+
 typedef struct osud_dit osud_dit;
 typedef struct osud_sched osud_sched;
 typedef void* osud_stream; /* hipStream_t */
@@ -290,7 +294,9 @@ int osud_set_gemm_dynamic_tiles(int on);
  *   attn_bwd_kernel     0        0 auto; 1: never the streamed kernels; 2: the tiled kernel (any T)
  *   gemm_tile           0        0 auto; 64 | 128 | 192 | 256 | 1192 (192 x 256) | 1256 (128 x 256): force a geometry where it divides
  *   f8_twins_only       1        fp8 training: tensors whose bf16 form has no reader are written as e4m3 only
- *   debug_sync          0        1: synchronise after every stage of the backward pass and name it on stderr (fault triage) */
+ *   debug_sync          0        1: synchronise after every stage of the backward pass and name it on stderr (fault triage)
+ *   f16m8_forms         11       OSUD_PREC_F16M8: bit i = 1 puts GEMM i of a block (0 in_proj, 1 out_proj, 2 fc1, 3 fc2) on fp16-activation operands;
+ *                                read by osud_dit_create */
 int osud_set_option(const char* name, int value);
 int osud_get_option(const char* name, int* value);
 

@@ -24,8 +24,9 @@ PREC_F16 = 5  # inference only: the bf16 tier's kernels on IEEE half operands --
 #               the reference's own sampling path (sample.py:25-26) -- at the bf16 tier's speed
 PREC_F16W8 = 6  # inference only: fp16f8 with the ACTIVATION operand of the four big GEMMs in plain fp16 (the weight keeps its e4m3
 #                 residual: 15 bits where the error would repeat in every product): 3/4 of fp16f8's matrix-pipe passes
+PREC_F16M8 = 7  # inference only: per-GEMM mix of the fp16f8 and fp16w8 operand forms (option "f16m8_forms", read when the handle is made)
 PRECISIONS = {"bf16": PREC_BF16, "fp32": PREC_F32, "f32": PREC_F32, "fp8": PREC_FP8, "bf16x3": PREC_BF16X3, "fp16f8": PREC_F16F8,
-              "fp16": PREC_F16, "fp16w8": PREC_F16W8}
+              "fp16": PREC_F16, "fp16w8": PREC_F16W8, "fp16m8": PREC_F16M8}
 
 # gemm epilogue codes (csrc/gemm.h)
 EPI_BIAS_F32, EPI_BIAS_TE, EPI_BIAS_SILU_TE, EPI_ROWBIAS_TE, EPI_BIAS_GELU_TE, EPI_GATE_RES = range(6)

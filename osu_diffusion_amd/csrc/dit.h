@@ -99,6 +99,10 @@ struct osud_dit {
   bool h8 = false;   // OSUD_PREC_F16F8: prec == BF16X3 (x3 set), and the four big GEMMs of every block on fp16 + e4m3 operands (h8_t): their
                      // weights, the LayerNorm / attention / GELU outputs that feed them
   bool w8 = false;   // OSUD_PREC_F16W8: as h8, with the activation operand of those GEMMs rounded to fp16 (w8_t: fp16 + ONE e4m3 plane)
+  // the operand form of each of a block's four big GEMMs {in_proj, out_proj, fc1, fc2} (and of the kernel that writes its activation
+  // operand: LN1, attention, LN2, fc1's GELU epilogue): the handle's prec, OSUD_PREC_F16F8 or OSUD_PREC_F16W8.  OSUD_PREC_F16F8 / _F16W8
+  // set all four alike; OSUD_PREC_F16M8 takes them from the option "f16m8_forms" at create time
+  int bform[4] = {0, 0, 0, 0};
   bool x3 = false;   // OSUD_PREC_BF16X3: prec == BF16X3, every TE matrix a plane pair [hi | lo] (common.h); inference only
   bool fp8 = false;  // OSUD_PREC_FP8: prec == BF16 everywhere except the e4m3 operands of qkv / out_proj / fc1 / fc2
 
@@ -205,10 +209,10 @@ inline int gemm(osud_dit* m, int epi, const void* Y, int ldy, const void* X, int
 }
 // one of the four big GEMMs of a block (in_proj, out_proj, fc1, fc2): OSUD_PREC_F16F8 runs these -- and only these -- on fp16 + e4m3
 // operands (m->h8; everything else of that tier is the split-bf16 tier)
-inline int gemm_blk(osud_dit* m, int epi, const void* Y, int ldy, const void* X, int ldx, int My, int Nx, int K, void* out,
-                    int ldo, const float* bias, hipStream_t st, const float* gate = nullptr, int ld_gate = 0, int Tp = 0, int N = 0) {
-  return gemm(m, epi, Y, ldy, X, ldx, My, Nx, K, out, ldo, bias, st, gate, ld_gate, Tp, N, nullptr, nullptr, nullptr,
-              m->h8 ? OSUD_PREC_F16F8 : (m->w8 ? OSUD_PREC_F16W8 : m->prec));
+inline int gemm_blk(osud_dit* m, int which /* 0 in_proj, 1 out_proj, 2 fc1, 3 fc2 */, int epi, const void* Y, int ldy, const void* X, int ldx, int My,
+                    int Nx, int K, void* out, int ldo, const float* bias, hipStream_t st, const float* gate = nullptr, int ld_gate = 0, int Tp = 0,
+                    int N = 0) {
+  return gemm(m, epi, Y, ldy, X, ldx, My, Nx, K, out, ldo, bias, st, gate, ld_gate, Tp, N, nullptr, nullptr, nullptr, m->bform[which]);
 }
 
 // GEMM on e4m3 operands (fp8 tier): Y [My][K] and X [Nx][K] are fp8, `dequant` the per-column factors, out per epilogue

@@ -195,7 +195,7 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
 
   const int D = m->D, L = m->L, Tp = round_up(T, 64), M = N * Tp, Mp = round_up(M, 128), Np = round_up(N, 128);
   const int prec = m->prec, AC = m->ada_cols;
-  const int bprec = m->h8 ? OSUD_PREC_F16F8 : (m->w8 ? OSUD_PREC_F16W8 : prec);  // the operand form of the blocks' four big GEMMs (and of what feeds them)
+  const int* bf = m->bform;  // the operand forms of the blocks' four big GEMMs (and of what feeds them): dit.h
   const bool f8_slim = f8_twins_only(m, f8_live, Mp);  // the bf16 forms of the GEMM inputs have no reader this step: not written
   // Gates (osud_dit_forward_gate): the sharded optimizer's all-gather of the updated master weights and their re-pack run on a
   // side stream while this forward is already under way -- phase p's kernels wait for phase p's event only.
@@ -278,14 +278,14 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
         OSUD_TRY(launch_ln_mod_twin(h, m->ada, AC, base, base + D, f8_slim ? nullptr : u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st, pend, pend_gate,
                                     pend ? h_in : nullptr, f8_live ? sv->u1_8 : nullptr, slot(l, 0), parts(l, 0)));
       else
-      OSUD_TRY(launch_ln_mod(bprec, h, m->ada, AC, base, base + D, u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st, pend,
+      OSUD_TRY(launch_ln_mod(bf[0], h, m->ada, AC, base, base + D, u1, sv ? sv->stats1 : nullptr, Mp, Tp, N, D, st, pend,
                              pend_gate, pend ? h_in : nullptr));
       // packed in_proj: one 3D-wide product, Q | K | V row-major (the attention kernels transpose V on the LDS read)
       if (f8_live) OSUD_TRY(gemm8(m, EPI_BIAS_TE, sv->u1_8, w.w8_qkv, Mp, qcols, D, qk, qcols, w.b_qkv, w.dq_qkv, 0.f, st, nullptr, 0, 0, 0, 0.f,
                                   slot(l, 0) + 1));
       else
-      OSUD_TRY(gemm_blk(m, EPI_BIAS_TE, u1, D, w.w_qkv, D, Mp, qcols, D, qk, qcols, w.b_qkv, st));
-      OSUD_TRY(launch_attention(bprec, qk, qcols, mask, ao, sv ? sv->lse : nullptr, N, T, Tp, Mp, m->H, m->hd, st, m->kb_class));
+      OSUD_TRY(gemm_blk(m, 0, EPI_BIAS_TE, u1, D, w.w_qkv, D, Mp, qcols, D, qk, qcols, w.b_qkv, st));
+      OSUD_TRY(launch_attention(bf[1], qk, qcols, mask, ao, sv ? sv->lse : nullptr, N, T, Tp, Mp, m->H, m->hd, st, m->kb_class));
       if (cal) {
         OSUD_TRY(launch_f8_quantize(u1, nullptr, (size_t)Mp * D, cslot(l, 0), st));
         OSUD_TRY(launch_f8_quantize(ao, nullptr, (size_t)Mp * D, cslot(l, 1), st));
@@ -300,14 +300,15 @@ int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float*
       continue;
     }
     if (!sv) {
-      OSUD_TRY(gemm_blk(m, EPI_GATE_RES, ao, D, w.w_o, D, Mp, D, D, h, D, w.b_o, st, m->ada + base + 2 * D, AC, Tp, N));
-      OSUD_TRY(launch_ln_mod(bprec, h, m->ada, AC, base + 3 * D, base + 4 * D, u2, nullptr, Mp, Tp, N, D, st));
-      OSUD_TRY(gemm_blk(m, EPI_BIAS_GELU_TE, u2, D, w.w1, D, Mp, 4 * D, D, g, 4 * D, w.b1, st));
+      OSUD_TRY(gemm_blk(m, 1, EPI_GATE_RES, ao, D, w.w_o, D, Mp, D, D, h, D, w.b_o, st, m->ada + base + 2 * D, AC, Tp, N));
+      OSUD_TRY(launch_ln_mod(bf[2], h, m->ada, AC, base + 3 * D, base + 4 * D, u2, nullptr, Mp, Tp, N, D, st));
+      // (fc1's GELU epilogue writes fc2's operand: in the other K-blocked form where the two GEMMs differ)
+      OSUD_TRY(gemm_blk(m, 2, bf[2] == bf[3] ? EPI_BIAS_GELU_TE : EPI_BIAS_GELU_ALT, u2, D, w.w1, D, Mp, 4 * D, D, g, 4 * D, w.b1, st));
       if (cal) {
         OSUD_TRY(launch_f8_quantize(u2, nullptr, (size_t)Mp * D, cslot(l, 2), st));
         OSUD_TRY(launch_f8_quantize(g, nullptr, (size_t)Mp * 4 * D, cslot(l, 3), st));
       }
-      OSUD_TRY(gemm_blk(m, EPI_GATE_RES, g, 4 * D, w.w2, 4 * D, Mp, D, 4 * D, h, D, w.b2, st, m->ada + base + 5 * D, AC, Tp, N));
+      OSUD_TRY(gemm_blk(m, 3, EPI_GATE_RES, g, 4 * D, w.w2, 4 * D, Mp, D, 4 * D, h, D, w.b2, st, m->ada + base + 5 * D, AC, Tp, N));
       continue;
     }
     if (f8_train) {  // attention output: e4m3 twin for out_proj (forward here, weight gradient in the backward pass) + this step's amax
@@ -375,10 +376,11 @@ static int upload_f32(osud_dit* m, float** dst, const float* src, size_t n, hipS
   return OSUD_OK;
 }
 // fp32 master -> TE copy of a weight (n % 4 == 0 for every DiT weight)
-static int convert_w(osud_dit* m, const float* src, void* dst, size_t rows, size_t cols, hipStream_t st, bool block_gemm = false) {
+static int convert_w(osud_dit* m, const float* src, void* dst, size_t rows, size_t cols, hipStream_t st, int block_gemm = -1 /* 0..3: that GEMM's weight */) {
   const size_t n = rows * cols;
-  if (m->h8 && block_gemm) return launch_pack_rows_h8(src, (int)cols, (int)cols, dst, (int)cols, (int)rows, true, st);  // (same 4 bytes per element)
-  if (m->w8 && block_gemm) return launch_pack_rows_w8(src, (int)cols, (int)cols, dst, (int)cols, (int)rows, true, st);  // (3 of the buffer's 4 bytes per element)
+  const int form = block_gemm >= 0 ? m->bform[block_gemm] : m->prec;
+  if (form == OSUD_PREC_F16F8) return launch_pack_rows_h8(src, (int)cols, (int)cols, dst, (int)cols, (int)rows, true, st);  // (same 4 bytes per element)
+  if (form == OSUD_PREC_F16W8) return launch_pack_rows_w8(src, (int)cols, (int)cols, dst, (int)cols, (int)rows, true, st);  // (3 of the buffer's 4 bytes per element)
   if (m->x3) return launch_pack_rows_x3(src, (int)cols, (int)cols, dst, (int)cols, (int)rows, st);  // rows of [w_hi | w_lo]
   if (m->defer_convert && n % 4 == 0) return m->defer_convert->add(src, dst, n / 4);
   return launch_convert(m->prec, src, dst, n, st);
@@ -394,7 +396,7 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
                  "dit_create: bad depth/context/in_channels/table_rows");
   OSUD_CHECK_ARG(cfg->precision == OSUD_PREC_BF16 || cfg->precision == OSUD_PREC_F32 || cfg->precision == OSUD_PREC_FP8 ||
                      cfg->precision == OSUD_PREC_BF16X3 || cfg->precision == OSUD_PREC_F16F8 || cfg->precision == OSUD_PREC_F16 ||
-                     cfg->precision == OSUD_PREC_F16W8,
+                     cfg->precision == OSUD_PREC_F16W8 || cfg->precision == OSUD_PREC_F16M8,
                  "dit_create: unknown precision %d", cfg->precision);
   const int hd = cfg->hidden / cfg->heads;
   if (hd != 64 && hd != 72) {
@@ -408,7 +410,11 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
   m->fp8 = cfg->precision == OSUD_PREC_FP8;
   m->h8 = cfg->precision == OSUD_PREC_F16F8;
   m->w8 = cfg->precision == OSUD_PREC_F16W8;
-  m->prec = m->fp8 ? OSUD_PREC_BF16 : ((m->h8 || m->w8) ? OSUD_PREC_BF16X3 : cfg->precision);
+  const bool m8 = cfg->precision == OSUD_PREC_F16M8;  // per-GEMM choice between the two forms: option "f16m8_forms", bit i = GEMM i on w8_t
+  m->prec = m->fp8 ? OSUD_PREC_BF16 : ((m->h8 || m->w8 || m8) ? OSUD_PREC_BF16X3 : cfg->precision);
+  for (int i = 0; i < 4; ++i)
+    m->bform[i] = m->h8 ? OSUD_PREC_F16F8 : (m->w8 ? OSUD_PREC_F16W8 : (m8 ? (((opt(OPT_F16M8_FORMS) >> i) & 1) ? OSUD_PREC_F16W8 : OSUD_PREC_F16F8) : m->prec));
+  if (m8) m->h8 = m->w8 = true;  // (both forms occur: buffers are sized for the wider one either way)
   m->x3 = m->prec == OSUD_PREC_BF16X3;  // every TE matrix is a plane pair [hi | lo] (common.h): esz = 4 bytes per logical element
   m->esz = (int)elem_size(m->prec);
   m->Kp = round_up(cfg->in_channels * 128 + 128 + cfg->context, 128);  // 528 -> 640
@@ -566,24 +572,24 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
     const size_t es = m->esz;
     if (name == "attn.in_proj_weight") {
       SHAPE(3 * D, D);  // rows [Wq; Wk; Wv]
-      rc = convert_w(m, src, b.w_qkv, 3 * D, D, st, true);
+      rc = convert_w(m, src, b.w_qkv, 3 * D, D, st, 0);
       if (rc == OSUD_OK && m->fp8) rc = quant_w(m, src, (int)(3 * D), (int)D, b.w8_qkv, b.dq_qkv, st);
     } else if (name == "attn.in_proj_bias") {
       SHAPE(3 * D);
       rc = upload_f32(m, &b.b_qkv, src, 3 * D, st);
     } else if (name == "attn.out_proj.weight") {
       SHAPE(D, D);
-      rc = convert_w(m, src, b.w_o, D, D, st, true);
+      rc = convert_w(m, src, b.w_o, D, D, st, 1);
       if (rc == OSUD_OK && m->fp8) rc = quant_w(m, src, (int)D, (int)D, b.w8_o, b.dq_o, st);
     } else if (name == "attn.out_proj.bias") { SHAPE(D); rc = upload_f32(m, &b.b_o, src, D, st);
     } else if (name == "mlp.fc1.weight") {
       SHAPE(4 * D, D);
-      rc = convert_w(m, src, b.w1, 4 * D, D, st, true);
+      rc = convert_w(m, src, b.w1, 4 * D, D, st, 2);
       if (rc == OSUD_OK && m->fp8) rc = quant_w(m, src, (int)(4 * D), (int)D, b.w8_1, b.dq_1, st);
     } else if (name == "mlp.fc1.bias") { SHAPE(4 * D); rc = upload_f32(m, &b.b1, src, 4 * D, st);
     } else if (name == "mlp.fc2.weight") {
       SHAPE(D, 4 * D);
-      rc = convert_w(m, src, b.w2, D, 4 * D, st, true);
+      rc = convert_w(m, src, b.w2, D, 4 * D, st, 3);
       if (rc == OSUD_OK && m->fp8) rc = quant_w(m, src, (int)D, (int)(4 * D), b.w8_2, b.dq_2, st);
     } else if (name == "mlp.fc2.bias") { SHAPE(D); rc = upload_f32(m, &b.b2, src, D, st);
     } else if (name == "adaLN_modulation.1.weight") {

@@ -32,6 +32,8 @@ enum GemmEpilogue {
   EPI_ACCUM_F32 = 8,      // out f32 += acc                      (gradient accumulation)
   EPI_GELUGRAD_TE = 9,    // out TE  = acc * aux[y][x], aux = the saved gelu' of fc1's pre-activation (dgrad through it)
   EPI_BIAS_GELU_BF = 10,  // fp8 operands only (fp8 training): EPI_BIAS_GELU_TE with bf16 outputs: out = gelu, out2 (optional) = gelu'
+  EPI_BIAS_GELU_ALT = 11, // h8_t / w8_t operands only: EPI_BIAS_GELU_TE with the output rows in the OTHER K-blocked form (h8_t operands ->
+                          // w8_t activation rows and vice versa): fc1 and fc2 of the mixed tolerance tier need not share an operand form
   EPI_COUNT
 };
 
@@ -86,6 +88,8 @@ enum Opt {
   OPT_GEMM_TILE,              // 0 auto; 64 / 128 / 192 / 256 / 1192 (192 x 256) / 1256 (128 x 256): force a tile geometry where it divides
   OPT_F8_TWINS_ONLY,          // 1: fp8 training writes only the e4m3 forms of tensors whose bf16 forms have no reader
   OPT_DEBUG_SYNC,             // 1: synchronise and name every stage of the backward pass (fault triage)
+  OPT_F16M8_FORMS,            // OSUD_PREC_F16M8: bit i = 1 puts GEMM i of a block (0 in_proj, 1 out_proj, 2 fc1, 3 fc2) on fp16-activation operands (w8_t),
+                              // 0 on fp16 + e4m3 operands (h8_t); read by osud_dit_create
   OPT_COUNT
 };
 int opt(Opt o);

@@ -77,7 +77,7 @@ struct OptDef {
 constexpr OptDef kOpts[OPT_COUNT] = {
     {"wgrad_side_stream", 1, 0, 1}, {"sample_graph", 1, 0, 1},    {"embed_const", 1, 0, 1},  {"tvec_table", 1, 0, 1},
     {"split_first", 1, 0, 1},       {"attn_fwd_kernel", 0, 0, 2}, {"attn_bwd_kernel", 0, 0, 2}, {"gemm_tile", 0, 0, 1256},
-    {"f8_twins_only", 1, 0, 1},     {"debug_sync", 0, 0, 1},
+    {"f8_twins_only", 1, 0, 1},     {"debug_sync", 0, 0, 1},      {"f16m8_forms", 11, 0, 15},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 // The defaults, overridden ONCE by the environment variable OSUD_OPTIONS="name=value,name=value" (for command-line A/B runs of an
@@ -175,7 +175,7 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
     OSUD_CHECK_ARG(p.gate && p.bias && p.rows_per_sample > 0 && p.rows_per_sample % 32 == 0 && p.n_samples > 0,
                    "gemm: gated epilogue needs gate/bias and rows_per_sample %% 32 == 0");
   if (epi == EPI_BIAS_F32 || epi == EPI_BIAS_TE || epi == EPI_BIAS_SILU_TE || epi == EPI_ROWBIAS_TE ||
-      epi == EPI_BIAS_GELU_TE || epi == EPI_BIAS_GELU_BF)
+      epi == EPI_BIAS_GELU_TE || epi == EPI_BIAS_GELU_BF || epi == EPI_BIAS_GELU_ALT)
     OSUD_CHECK_ARG(p.bias != nullptr, "gemm: epilogue %d needs a bias", epi);
   if (epi == EPI_GELUGRAD_TE) OSUD_CHECK_ARG(p.aux != nullptr, "gemm: epilogue %d needs aux", epi);
   if (p.split_k > 1) {

@@ -11,6 +11,7 @@ int launch_gemm_h8(int epi, const GemmP& p, hipStream_t st) {
     case EPI_BIAS_F32: return launch_t<h8_t, EPI_BIAS_F32>(p, st);
     case EPI_BIAS_TE: return launch_t<h8_t, EPI_BIAS_TE>(p, st);
     case EPI_BIAS_GELU_TE: return launch_t<h8_t, EPI_BIAS_GELU_TE>(p, st);
+    case EPI_BIAS_GELU_ALT: return launch_t<h8_t, EPI_BIAS_GELU_ALT>(p, st);
     case EPI_GATE_RES: return launch_t<h8_t, EPI_GATE_RES>(p, st);
     case EPI_NONE_F32: return launch_t<h8_t, EPI_NONE_F32>(p, st);
   }

@@ -391,9 +391,11 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
   // writes hi | lo planes; the GELU epilogue (fc1) writes the next GEMM's operand form
   constexpr bool kW8 = std::is_same<TE, w8_t>::value;  // (fp16 x (fp16 + e4m3) operands: outputs as for h8_t)
   constexpr bool kH8 = std::is_same<TE, h8_t>::value || kW8;
+  using TOalt = typename std::conditional<kW8, h8_t, w8_t>::type;  // (EPI_BIAS_GELU_ALT: the other K-blocked activation form)
   using TO = typename std::conditional<kF8, typename std::conditional<EPI == EPI_BIAS_GELU_TE, fp8_t, bf16_t>::type,
-                                       typename std::conditional<kH8 && EPI == EPI_BIAS_TE, x3_t, TE>::type>::type;
-  constexpr bool kGelu = EPI == EPI_BIAS_GELU_TE || EPI == EPI_BIAS_GELU_BF;  // _BF: fp8 operands with bf16 outputs (training)
+                                       typename std::conditional<kH8 && EPI == EPI_BIAS_TE, x3_t,
+                                                                 typename std::conditional<kH8 && EPI == EPI_BIAS_GELU_ALT, TOalt, TE>::type>::type>::type;
+  constexpr bool kGelu = EPI == EPI_BIAS_GELU_TE || EPI == EPI_BIAS_GELU_BF || EPI == EPI_BIAS_GELU_ALT;  // _BF: fp8 operands with bf16 outputs (training)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wy = wave / WX, wx = wave % WX;
@@ -527,6 +529,9 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
   };
 #pragma unroll
   for (int i = 0; i < G::NSTAGE - 1; ++i) issue_next();
+  // (Measured and not kept, round 4: `s_setprio 1` around every MFMA cluster -- fc1 168.8 vs 163.7 us, step 26.20 / 26.31 vs 26.17 / 26.27 ms
+  //  -- and a static priority for the later-dispatched half of the waves -- 26.29 / 26.43: with one barrier per slab the waves run
+  //  in lock step and there is nothing for the arbiter to prefer, as the guide says of single-phase loops.)
   int landed = 0;  // slabs known to have landed already (waited for before the previous epilogue)
 
 #ifdef OSUD_GEMM_TIMING

@@ -221,7 +221,7 @@ def parse_args(argv=None):
     p.add_argument("--model", type=str, choices=list(DiT_models.keys()), default="DiT-B")
     # additions of this build
     p.add_argument("--synthetic", type=int, default=0, metavar="T", help="use a synthetic T-token sequence")
-    p.add_argument("--precision", choices=["bf16", "fp16", "fp32", "fp8", "bf16x3", "fp16f8", "fp16w8"], default="fp16f8",
+    p.add_argument("--precision", choices=["bf16", "fp16", "fp32", "fp8", "bf16x3", "fp16f8", "fp16w8", "fp16m8"], default="fp16f8",
                    help="fp16f8 (default): the fastest tier whose final coordinates stay within 1e-3 of the reference's for identical "
                         "(seed, beatmap, steps) -- split-bf16 arithmetic with the big GEMMs on fp16 + e4m3-residual operands; bf16x3: "
                         "split-bf16 operands everywhere (same tolerance, 0.8x the speed); fp16: fast tier on half operands -- the 11 significand "

@@ -209,3 +209,56 @@ def test_forward_on_other_geometries_against_the_fp32_oracle(hidden, heads, T_):
     err = maxdiff(got, ref)
     print(f"MEASURED w8_forward_geometry[{hidden},{heads},{T_}]: max|d| vs the fp32 oracle at scale {scale:.2f}: {err:.2e}")
     assert err < 3e-4 * scale
+
+
+# ------------------------------------------------------------------------------------------ the mixed tier (precision="fp16m8")
+# Option f16m8_forms: bit i = 1 puts GEMM i of a block (1 in_proj, 2 out_proj, 4 fc1, 8 fc2) on fp16-activation operands.  Default 11:
+# every big GEMM but fc1 -- the fastest mix whose worst coordinate stayed inside 1e-3 of the fp32 tier on both draws of the bench
+# shape's 1000-step loop (tools/tier_drift.py: 4.9e-4 / 8.4e-4 at 157.7 steps/s; all four: 1.1e-3 / 1.3e-3 at 168.5; none: 1.3e-4 /
+# 2.0e-4 at 132).
+@pytest.mark.parametrize("mask", [11, 4, 8])
+def test_mixed_forms_forward_matches_reference_golden(mask, osud_option):
+    """Every pairing of fc1's and fc2's forms (mask 11 / 8: fp16 + e4m3 fc1 writes fp16-activation rows for fc2 -- the GELU epilogue's
+    "other form"; mask 4: the reverse) against the DiT-B forward fixture."""
+    osud_option("f16m8_forms", mask)
+    fx = load("g3_forward_dit_b_T128")
+    shape, sd = weights_for(fx)
+    m = native_model(shape, sd, "fp16m8")
+    x, t, o, c, y = (T(fx[k]).to(DEV) for k in ("x", "t", "o", "c", "y"))
+    scale = float(np.abs(fx["out"]).max())
+    with torch.no_grad():
+        errs = {"out": maxdiff(m(x, t, o, c, y).cpu(), fx["out"]), "cfg4": maxdiff(m.forward_with_cfg(x, t, o, c, y, 4.0).cpu(), fx["out_cfg4"])}
+    print(f"MEASURED m8_forward[mask {mask}]: scale {scale:.2f}, errors {({k: f'{v:.2e}' for k, v in errs.items()})}")
+    assert errs["out"] <= W8_FWD * max(scale, 1.0) and errs["cfg4"] <= 5 * W8_FWD * max(scale, 1.0), errs
+
+
+def test_mixed_tier_masks_0_and_15_are_the_two_pure_tiers(osud_option):
+    """fp16m8 with every GEMM on one form is bit-identical to that form's own tier (same kernels, same packed weights)."""
+    fx = load("g3_forward_dit_b_T128")
+    shape, sd = weights_for(fx)
+    x, t, o, c, y = (T(fx[k]).to(DEV) for k in ("x", "t", "o", "c", "y"))
+    with torch.no_grad():
+        for mask, pure in ((0, "fp16f8"), (15, "fp16w8")):
+            osud_option("f16m8_forms", mask)
+            a = native_model(shape, sd, "fp16m8")(x, t, o, c, y)
+            b = native_model(shape, sd, pure)(x, t, o, c, y)
+            assert torch.equal(a, b), (mask, pure)
+
+
+def test_dit_b_1000_step_cfg4_loop_matches_the_reference_mixed_tier():
+    """BASELINE configs[3] end to end in the default mix (every big GEMM but fc1 on fp16 activations): within 1e-3 of the reference's own
+    1000-step CFG-4 DiT-B loop at every quarter."""
+    assert _lib.get_option("f16m8_forms") == 11
+    fx, shape, sd, z, noises = _p1000_inputs()
+    m = native_model(shape, sd, "fp16m8")
+    d = create_diffusion("1000", noise_schedule="squaredcos_cap_v2")
+    kw = dict(o=T(fx["o"]).to(DEV), c=T(fx["c"]).to(DEV), y=T(fx["y"]).to(DEV), cfg_scale=4.0, attn_mask=None)
+    x = z.to(DEV).clone()
+    nz = noises.to(DEV)
+    errs, done = {}, 0
+    for k in (250, 500, 750, 1000):
+        d.run_steps(m.forward_with_cfg, x, kw, first_step=999 - done, last_step=1000 - k, step_noise=nz[done:k])
+        errs[k] = maxdiff(x.cpu(), fx["final"] if k == 1000 else fx[f"after_{k}"])
+        done = k
+    print("MEASURED p1000_dit_b[fp16m8]: max|d| vs reference after 250/500/750/1000 steps = " + " / ".join(f"{errs[k]:.3e}" for k in (250, 500, 750, 1000)))
+    assert max(errs.values()) < 1e-3, errs
