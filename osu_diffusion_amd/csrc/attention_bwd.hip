@@ -935,7 +935,8 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_f32_kernel(const float* __res
 
 int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* O, const float* lse, void* dqkv, int N,
                          int T, int heads, int head_dim, hipStream_t st, float* delta_ws, float* dbias, float* bias_scratch,
-                         size_t bias_scratch_elems) {
+                         size_t bias_scratch_elems, int* bias_rows_pending) {
+  if (bias_rows_pending != nullptr) *bias_rows_pending = 0;
   OSUD_CHECK_ARG(N > 0 && T > 0 && T % 64 == 0, "attention backward: T=%d must be a multiple of 64", T);
   const int D = heads * head_dim;
   const float scale = 1.0f / sqrtf((float)head_dim);
@@ -999,6 +1000,10 @@ int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* 
         hipLaunchKernelGGL((attn_bwd_stream_kernel<128, true>), dim3(items < cus ? items : cus), dim3(512), slds, st, (const bf16_t*)qkv,
                            (const bf16_t*)dO, (const bf16_t*)O, lse, (bf16_t*)dqkv, D, heads, items, c1, scale, queue, bias_scratch);
         OSUD_HIP(hipGetLastError());
+        if (bias_rows_pending != nullptr) {  // (the caller batches the fixed-order sums of a whole backward call into one launch)
+          *bias_rows_pending = N;
+          return OSUD_OK;
+        }
         return launch_colsum_f32(bias_scratch, N, 3 * D, dbias, st);  // fixed-order sum over the samples
       }
       OSUD_BIG_LDS_ONCE((attn_bwd_stream_kernel<128, false>));

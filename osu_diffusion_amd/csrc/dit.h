@@ -60,6 +60,10 @@ struct BwdWs {
   // per launch of a backward pass ([2 L + 2][M / 64][6 D + 64]), and scratch for the row blocks' shares of a column sum (main / side stream)
   float *rowpart = nullptr, *colpart = nullptr, *colpart2 = nullptr;
   size_t colpart_elems = 0;
+  // per-layer partial rows of the two bias gradients that ride in epilogues (fc1: one row per wave-row of the data-gradient GEMM's grid;
+  // in_proj: one row per sample from the streamed attention backward), summed by ONE launch_colsum_many per backward call
+  float *b1part = nullptr, *bqkvpart = nullptr;
+  size_t b1part_stride = 0, bqkvpart_stride = 0;  // floats per layer
   // bf16 tier: the weight gradients of a block run on a side stream next to the block's data-gradient chain (train.hip): their own
   // split-K slab area, the stream, and the events that hand the operands over {fc2 dgrad done, LN2 backward + out_proj dgrad done,
   // attention backward done, side stream drained}
@@ -239,7 +243,7 @@ inline int gemm8(osud_dit* m, int epi, const void* Y, const void* X, int My, int
 // osud_set_option("f8_twins_only", 0) keeps them (a test holds the two settings to 1e-7).
 inline bool f8_twins_only(const osud_dit* m, bool live, int Mp) {
   const bool off = opt(OPT_F8_TWINS_ONLY) == 0;  // (read per call: a test switches it inside one process)
-  return !off && live && m->prec == OSUD_PREC_BF16 && Mp % 128 == 0 && (size_t)(Mp / 32) * 4 * m->D <= m->bw.splitk_elems;
+  return !off && live && m->prec == OSUD_PREC_BF16 && Mp % 128 == 0;
 }
 
 int dit_forward_impl(osud_dit* m, const float* x, const int64_t* t, const float* o, const float* c, const int64_t* y,

@@ -135,6 +135,10 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
     OSUD_TRY(dev_alloc(W, &b.splitk, b.splitk_elems * 4, false));
     OSUD_TRY(dev_alloc(W, &b.splitk2, b.splitk_elems * 4, false));
     OSUD_TRY(dev_alloc(W, &b.rowpart, (size_t)(2 * m->L + 2) * (Mp / 64) * (6 * D + 64) * 4, false));
+    b.b1part_stride = (size_t)(Mp / 32) * 4 * D;
+    b.bqkvpart_stride = (size_t)nN * 3 * D;
+    OSUD_TRY(dev_alloc(W, &b.b1part, (size_t)m->L * b.b1part_stride * 4, false));
+    OSUD_TRY(dev_alloc(W, &b.bqkvpart, (size_t)m->L * b.bqkvpart_stride * 4, false));
     {  // the widest column sum: a transpose's (rows / 64) shares of 4 D (or the padded first-layer width) columns, or (Np / 64) x AC
       const size_t a = (size_t)(Mp / 64) * tcols, c = (size_t)(Np / 64) * AC;
       b.colpart_elems = a > c ? a : c;

@@ -57,7 +57,10 @@ int launch_mask_tiles(const uint8_t* mask, int T, int Tp, uint8_t* kb_class, hip
 int launch_attention_bwd(int prec, const void* qkv, const void* dO, const void* O, const float* lse, void* dqkv, int N,
                          int T, int heads, int head_dim, hipStream_t st, float* delta_ws = nullptr, float* dbias = nullptr,
                          float* bias_scratch = nullptr /* N x 3 hidden floats: the streamed kernel's per-sample column sums */,
-                         size_t bias_scratch_elems = 0);  // dbias != nullptr (bf16 tier): column sums of dqkv are ADDED to / written into it
+                         size_t bias_scratch_elems = 0,
+                         int* bias_rows_pending = nullptr /* optional: where the per-sample sums of the streamed kernel were written to
+                                                             bias_scratch, the final column sum is LEFT TO THE CALLER and *bias_rows_pending =
+                                                             the number of rows (else it is 0 and dbias is complete) */);  // dbias != nullptr (bf16 tier): column sums of dqkv are ADDED to / written into it
 
 // kernels_bwd.hip
 // No kernel of the backward pass adds floats atomically: sums that several workgroups contribute to are written as per-workgroup
@@ -80,6 +83,16 @@ struct RowRedList {
   int count, D, ld_ada;
 };
 int launch_row_reduce(const RowRedList& L, hipStream_t st);
+// A list of fixed-order column sums out[c] = sum_{r < R} src[r][c] (C % 64 == 0 columns, row stride ld) in ONE launch: the bias
+// gradients whose partial rows come out of GEMM / attention epilogues (fc1's, in_proj's), deferred to the end of a backward call
+struct ColsumList {
+  static constexpr int kMax = 64;
+  const float* src[kMax];
+  float* out[kMax];
+  int R[kMax], ld[kMax], blk_begin[kMax + 1];  // blk_begin: first 64-column block of item i in the launch's grid
+  int count;
+};
+int launch_colsum_many(const ColsumList& L, hipStream_t st);
 // part: (M / 64) x 2 D floats, rows {dgate share, share of db = the branch Linear's bias gradient}
 int launch_gate_bwd(int prec, const float* dh, const void* br, const float* gate, int ld_ada, void* dbr, float* part,
                     int M, int Tp, int D, hipStream_t st);

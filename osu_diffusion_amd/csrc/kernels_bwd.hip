@@ -895,6 +895,44 @@ int launch_colsum_f32(const float* a, int R_valid, int C, float* out, hipStream_
   return OSUD_OK;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void colsum_many_kernel(const ColsumList L) {
+  __shared__ float4 part[16][16];
+  int it = 0;
+  while (it + 1 < L.count && (int)blockIdx.x >= L.blk_begin[it + 1]) ++it;
+  const float* a = L.src[it];
+  const int R = L.R[it], ld = L.ld[it];
+  const int tx = threadIdx.x & 15, tg = threadIdx.x >> 4;
+  const int c = ((int)blockIdx.x - L.blk_begin[it]) * 64 + tx * 4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int r = tg; r < R; r += 64) {  // four independent loads in flight per thread (as colsum_f32_tall_kernel: the same order)
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rr = r + 16 * u;
+      v[u] = rr < R ? *reinterpret_cast<const float4*>(a + (size_t)rr * ld + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  part[tg][tx] = s;
+  __syncthreads();
+  if (tg == 0) {
+    float4 t = part[0][tx];
+#pragma unroll
+    for (int g = 1; g < 16; ++g) { t.x += part[g][tx].x; t.y += part[g][tx].y; t.z += part[g][tx].z; t.w += part[g][tx].w; }
+    *reinterpret_cast<float4*>(L.out[it] + c) = t;
+  }
+}
+}  // namespace
+
+int launch_colsum_many(const ColsumList& L, hipStream_t st) {
+  if (L.count == 0) return OSUD_OK;
+  hipLaunchKernelGGL(colsum_many_kernel, dim3(L.blk_begin[L.count]), dim3(256), 0, st, L);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
 int launch_row_reduce(const RowRedList& L, hipStream_t st) {
   if (L.count == 0) return OSUD_OK;
   OSUD_CHECK_ARG(L.D % 64 == 0 && L.ld_ada % 4 == 0, "row_reduce: D=%d, ld=%d", L.D, L.ld_ada);

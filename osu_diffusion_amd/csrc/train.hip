@@ -176,6 +176,21 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     rr.count = 0;
     return rc;
   };
+  // ... and the bias gradients whose partial rows come out of GEMM / attention epilogues (fc1, in_proj): one launch per call too
+  ColsumList cs{};
+  auto cs_flush = [&]() -> int {
+    const int rc = launch_colsum_many(cs, st);
+    cs.count = 0;
+    return rc;
+  };
+  auto cs_add = [&](const float* src, int R, int C, float* out) -> int {
+    if (cs.count == ColsumList::kMax) OSUD_TRY(cs_flush());
+    const int i = cs.count++;
+    if (i == 0) cs.blk_begin[0] = 0;
+    cs.src[i] = src; cs.out[i] = out; cs.R[i] = R; cs.ld[i] = C;
+    cs.blk_begin[i + 1] = cs.blk_begin[i] + C / 64;
+    return OSUD_OK;
+  };
   auto rr_add = [&](const float* part, int stride, int nq_sample, int off0, int off1, int off2, float* bias) -> int {
     if (rr.count == RowRedList::kMax) OSUD_TRY(rr_flush());
     const int i = rr.count++;
@@ -227,7 +242,9 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     }
     // dz1 = (dbr . W2) * gelu'(z1); in the bf16 tier the fc1 bias gradient (column sums of dz1) rides in the same epilogue
     // as per-wave-row partial sums (scratch: the split-K slab area, free until the weight gradients below)
-    const bool fused_b1 = prec == OSUD_PREC_BF16 && (size_t)(Mp / 32) * 4 * D <= w.splitk_elems;
+    const bool fused_b1 = prec == OSUD_PREC_BF16;
+    float* b1part = w.b1part + (size_t)l * w.b1part_stride;        // this layer's partial rows (summed at the end of the call)
+    float* bqkvpart = w.bqkvpart + (size_t)l * w.bqkvpart_stride;
     // fp8 training: the data-gradient products of fc2, fc1 and in_proj run on e4m3 operands (gradient tensors quantised with the
     // scale from their previous step's amax, transposed weights per row); the very first step only records (see dit_forward_impl)
     const bool f8_train = m->fp8, f8_live = m->fp8 && m->f8_steps > 1;
@@ -288,18 +305,18 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
       if (f8_train && l == L - 1) OSUD_TRY(launch_f8_quantize(w.dbr, f8_live ? m->q8a : nullptr, (size_t)Mp * D, slot(3), st));
       if (f8_live) {
         OSUD_TRY(gemm8(m, EPI_GELUGRAD_TE, m->q8a, bw.w2_t8, Mp, 4 * D, D, f8_slim ? nullptr : w.dz1, 4 * D, nullptr, bw.dq_2_t, 0.f, st, nullptr, 0, 0, 0, 0.f,
-                       slot(3) + 1, nullptr, sv.z1, fused_b1 ? w.splitk : nullptr, fused_b1 ? &part_rows : nullptr, m->q8b, slot(4)));
+                       slot(3) + 1, nullptr, sv.z1, fused_b1 ? b1part : nullptr, fused_b1 ? &part_rows : nullptr, m->q8b, slot(4)));
       } else {
       GemmP gp{};
       gp.Y = w.dbr; gp.X = bw.w2_t; gp.ldy = D; gp.ldx = D; gp.My = Mp; gp.Nx = 4 * D; gp.K = D;
       gp.out = w.dz1; gp.ldo = 4 * D; gp.aux = sv.z1;
       if (fused_b1) {
-        gp.colpart = w.splitk;
+        gp.colpart = b1part;
         gp.colpart_rows = &part_rows;
       }
       OSUD_TRY(launch_gemm(prec, EPI_GELUGRAD_TE, gp, st));
       }
-      if (fused_b1) OSUD_TRY(launch_colsum_f32(w.splitk, part_rows, 4 * D, g_b1, st));
+      if (fused_b1) OSUD_TRY(cs_add(b1part, part_rows, 4 * D, g_b1));
     }
     OSUD_TRY(dbg_sync(st, "dgrad fc2 (gelu grad)"));
     hipStream_t ws_ = side_on ? w.side : st;
@@ -373,8 +390,12 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     const bool fused_bqkv = prec == OSUD_PREC_BF16;
     // (fp8 training: dqkv's bias gradient, its e4m3 twin and its amax come from ONE pass over it instead of the attention
     //  backward's column-sum pass + a quantisation pass)
-    OSUD_TRY(launch_attention_bwd(prec, sv.qk, w.dao, sv.ao, sv.lse, w.dqkv, N, T, m->H, m->hd, st, w.attn_delta,
-                                  (fused_bqkv && !f8_train) ? g_bqkv : nullptr, w.splitk, w.splitk_elems));
+    {
+      int pending = 0;  // (T = 128: the streamed kernel leaves one row of column sums per sample; their sum joins the call's batch)
+      OSUD_TRY(launch_attention_bwd(prec, sv.qk, w.dao, sv.ao, sv.lse, w.dqkv, N, T, m->H, m->hd, st, w.attn_delta,
+                                    (fused_bqkv && !f8_train) ? g_bqkv : nullptr, bqkvpart, w.bqkvpart_stride, &pending));
+      if (pending > 0) OSUD_TRY(cs_add(bqkvpart, pending, 3 * D, g_bqkv));
+    }
     OSUD_TRY(dbg_sync(st, "attention bwd"));
     auto wg_qkv = [&]() -> int {
       OSUD_TRY(weight_grad(m, w.dqkv, 3 * D, sv.u1, D, 3 * D, D, Mp, G(p + "attn.in_proj_weight"), fused_bqkv ? nullptr : g_bqkv, ws_, slabs_));
@@ -422,11 +443,13 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     OSUD_TRY(dbg_sync(st, "ln1 bwd"));
     std::swap(dh, dh_other);  // dh = grad wrt h_in
     if (per_block_ada) {
+      OSUD_TRY(cs_flush());
       OSUD_TRY(rr_flush());  // (the slice's modulation-gradient columns are final now; the two bias gradients travel with the phase)
       OSUD_TRY(ada_slice(l));
       OSUD_TRY(dbg_sync(st, "wgrad ada (block)"));
     }
   }
+  OSUD_TRY(cs_flush());
   OSUD_TRY(rr_flush());  // one launch for every LayerNorm / gate kernel of this call
 
   if (w.side != nullptr && w.side_busy) {  // (not reached: every block joins) the caller's stream owns every gradient again
