@@ -136,7 +136,7 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
     OSUD_TRY(dev_alloc(W, &b.splitk2, b.splitk_elems * 4, false));
     OSUD_TRY(dev_alloc(W, &b.rowpart, (size_t)(2 * m->L + 2) * (Mp / 64) * (6 * D + 64) * 4, false));
     b.b1part_stride = (size_t)(Mp / 32) * 4 * D;
-    b.bqkvpart_stride = (size_t)nN * 3 * D;
+    b.bqkvpart_stride = (size_t)(nN > (Mp + 255) / 256 ? nN : (Mp + 255) / 256) * 3 * D;  // one row per sample (streamed kernel) or per 256-token row block (column-sum pass)
     OSUD_TRY(dev_alloc(W, &b.b1part, (size_t)m->L * b.b1part_stride * 4, false));
     OSUD_TRY(dev_alloc(W, &b.bqkvpart, (size_t)m->L * b.bqkvpart_stride * 4, false));
     {  // the widest column sum: a transpose's (rows / 64) shares of 4 D (or the padded first-layer width) columns, or (Np / 64) x AC
