@@ -717,10 +717,12 @@ def parity_tier_and_drift(args, dev):
                   "matmuls are TF32: 11 bits, sample.py:25-26); meets the 1e-3 tolerance on final coordinates (tests/test_gpu_h8.py) at "
                   "2/3 of the bf16x3 tier's matrix-pipe passes",
         "fp16w8": "precision=fp16w8: 15 significand bits per WEIGHT of the four big GEMMs of a block, 11 per activation operand (an activation's "
-                  "rounding is a fresh error per token and step and averages out over the loop; a weight's repeats in every product): meets the "
-                  "1e-3 tolerance on final coordinates (tests/test_gpu_w8.py) at half of the bf16x3 tier's matrix-pipe passes",
-        "fp16m8": "precision=fp16m8: the fastest per-GEMM mix of fp16f8's and fp16w8's operand forms whose worst coordinate stayed inside 1e-3 on "
-                  "two draws of this loop (tools/tier_drift.py): fc1 keeps the activation's residual, the other three big GEMMs drop it"}
+                  "rounding is a fresh error per token and step and averages out over the loop; a weight's repeats in every product): 3-8x closer to "
+                  "the reference than TF32-class arithmetic on both operands (the fp16 tier), the bulk of the coordinates inside 1e-3 (p99.9 3e-4), "
+                  "isolated ones not (1.1-1.3e-3 here, 2.3e-2 on the CLI fixture): not a tolerance tier",
+        "fp16m8": "precision=fp16m8: per-GEMM mix of fp16f8's and fp16w8's operand forms (fc1 keeps the activation's residual, the other three big "
+                  "GEMMs drop it): inside 1e-3 on both draws of this loop (tools/tier_drift.py) but NOT on the CLI fixture (one coordinate of 256 at 2.6e-2): "
+                  "not a tolerance tier"}
     PASSES = {"bf16x3": 3.0, "fp16f8": 2.0, "fp16w8": 1.5, "fp16m8": 1.5 + 0.5 / 3}  # matrix-pipe passes per product, in units of one bf16 MFMA pass (the big GEMMs)
 
     def tier_record(name):
@@ -746,7 +748,14 @@ def parity_tier_and_drift(args, dev):
                         "drift_vs_fp32_tier": dict(f16, after_steps={str(k): dev_stats(states["fp16"][k], states["fp32"][k]) for k in marks}),
                         "meets_1e-3": bool(f16["max"] <= 1e-3)}
     recs = {name: tier_record(name) for name in ("bf16x3", "fp16f8", "fp16m8", "fp16w8")}
-    meeting = [name for name in recs if recs[name]["meets_1e-3"]] or ["bf16x3"]
+    # A tier can be THE tolerance tier only if its 1e-3 claim is also held by every reference fixture of the test suite (the reference's
+    # 1000-step DiT-B loop, the 20- / 250-step loops, both CLI re-enactments).  The fp16-activation forms are not: on the CLI fixture one
+    # coordinate of 256 ends 2-3e-2 away (tests/test_gpu_scripts.py) -- the sampler has coordinates that amplify their ten times larger
+    # rounding a hundredfold -- whatever they show on this run's draw.  They are reported, never selected.
+    VERIFIED = ("bf16x3", "fp16f8")
+    for name, r in recs.items():
+        r["held_by_every_reference_fixture"] = name in VERIFIED
+    meeting = [name for name in VERIFIED if recs[name]["meets_1e-3"]] or ["bf16x3"]
     best = max(meeting, key=lambda name: recs[name]["value"])
     out["tolerance_tier"] = dict(recs[best], name=best, also={name: r for name, r in recs.items() if name != best})
     return out, drift

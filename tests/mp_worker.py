@@ -30,7 +30,8 @@ def batch():
 def trainer_kw():
     """Schedule switches of the worker's trainer, set by the test that launches it (the library itself reads no such variables)."""
     return dict(force_phased=os.environ.get("OSUD_TEST_FORCE_PHASED", "0") == "1",
-                native_comm=os.environ.get("OSUD_TEST_NATIVE_COMM", "0") == "1")
+                native_comm=os.environ.get("OSUD_TEST_NATIVE_COMM", "0") == "1",
+                stub_exchange=os.environ.get("OSUD_TEST_STUB", "0") == "1")
 
 
 def run(rank, world, steps=2, zero1=False, wire=None, full_state=False):

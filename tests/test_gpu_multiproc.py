@@ -142,6 +142,21 @@ def test_trainer_exchanges_gradients_through_the_native_communicator():
         assert err <= 2e-6 * float(want_flat.abs().max()), (mode, err)
 
 
+def test_stubbed_exchange_is_the_same_schedule_without_collectives():
+    """bench.py's exposed-communication figure is (step with the exchange) - (step with `stub_exchange=True`).  With one rank a
+    collective is a copy, so the stubbed schedule must end in the same bits as the real one (RCCL, world 1, phased backward forced) --
+    i.e. the stub removes the collectives and nothing else."""
+    from tests import mp_worker
+
+    outs = {}
+    for stub in ("0", "1"):
+        with tempfile.TemporaryDirectory() as d:
+            _torchrun(1, [os.path.join(ROOT, "tests", "mp_worker.py"), d],
+                      dict(OSUD_DIST_BACKEND="nccl", OSUD_TEST_MODE="allreduce", OSUD_TEST_FORCE_PHASED="1", OSUD_TEST_STUB=stub))
+            outs[stub] = torch.load(os.path.join(d, "rank0.pt"))
+    assert torch.equal(outs["0"]["flat"], outs["1"]["flat"]) and torch.equal(outs["0"]["ema"], outs["1"]["ema"])
+
+
 def test_bench_two_ranks_over_gloo():
     """bench.py's N > 1 code path (rank set-up, barriers, max-over-ranks timing, one JSON line from rank 0) with both ranks on
     GPU 0; once with the all-reduce exchange, once with the sharded optimizer."""

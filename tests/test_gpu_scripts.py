@@ -91,6 +91,29 @@ def test_sample_cli_refine_ckpt_reproduces_the_reference_run(tmp_path, precision
     assert len(glob.glob(os.path.join(str(tmp_path), "results", "*", "*result 5 0 10.osu"))) == 1  # the refined difficulty is written too
 
 
+@pytest.mark.parametrize("precision", ["fp16m8", "fp16w8"])
+def test_sample_cli_fp16_activation_forms_are_close_but_not_inside_the_tolerance(tmp_path, precision):
+    """The tiers whose big GEMMs round the ACTIVATION operand to fp16 (fp16w8: all four, fp16m8: all but fc1) on the same CLI fixture
+    (128-object window, 250 steps): the bulk of the coordinates lands where the tolerance tiers do (p99 < 5e-4, mean ~1e-4), but the
+    sampler has coordinates that amplify a 1e-4-sized perturbation a hundredfold -- ONE of the 256 here ends 2-3e-2 away (fp16f8, whose
+    perturbation is ten times smaller: 7e-5 everywhere).  That is why these tiers are NOT what this build calls "within 1e-3 of the
+    reference" (bench.py's tolerance tier stays fp16f8), however fast they are; the test pins the behaviour so that the claim cannot
+    drift: every coordinate but at most two inside 1e-3, the outliers below 5e-2."""
+    fx, ckpt, idx = _cli_fixture(tmp_path)
+    tag = "trim250"
+    args = [os.path.join(ROOT, "sample.py"), "--beatmap", TOY, "--ckpt", ckpt, "--model", "DiT-S", "--num-classes", "10",
+            "--num-sampling-steps", str(int(fx[tag + ":steps"])), "--cfg-scale", "4.0", "--seed", "0", "--seq-len", "128",
+            "--style-id", str(int(fx["style_id"])), "--beatmap-idx", idx, "--noise", "cpu", "--precision", precision,
+            "--plot-time", str(float(fx[tag + ":plot_time"]))]
+    run(args, str(tmp_path))
+    saved = torch.load(glob.glob(os.path.join(str(tmp_path), "results", "*", "result.pt"))[0])
+    d = (saved[:, :2] / torch.tensor([512.0, 384.0]).view(1, 2, 1) - torch.from_numpy(fx[tag + ":final"])).abs().flatten().double()
+    outside = int((d > 1e-3).sum())
+    print(f"MEASURED cli_fast_forms[{precision}]: max {float(d.max()):.3e}, p99 {float(torch.quantile(d, 0.99)):.3e}, mean {float(d.mean()):.3e}, "
+          f"{outside} of {d.numel()} coordinates outside 1e-3")
+    assert outside <= 2 and float(d.max()) < 5e-2 and float(torch.quantile(d, 0.99)) < 5e-4
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16x3", "fp16f8"])
 @pytest.mark.parametrize("tag", ["full100", "trim250"])
 def test_sample_cli_with_cpu_noise_reproduces_the_reference_run(tmp_path, tag, precision):

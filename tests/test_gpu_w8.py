@@ -1,11 +1,13 @@
 """GPU (-m gpu): fp16 activations x (fp16 + e4m3-residual) weights (precision="fp16w8", OSUD_PREC_F16W8) through the C ABI.
 
-The tolerance tier's cheapest form: the fp16f8 tier (tests/test_gpu_h8.py) with the ACTIVATION operand of in_proj / out_proj / fc1 / fc2
-rounded to fp16 (11 significand bits) while the WEIGHT keeps hi = fp16(w) and lo8 = e4m3((w - hi) 2^12) (15 bits).  The reasoning is
-about how errors add up over a sampling loop, not about one product: an activation is rounded afresh for every token at every step (errors
-of random sign: they average out), a weight's rounding error is the same number in every product of every step (it accumulates).  Measured
-on the 1000-step DiT-B loops (bench.py's drift record and the reference fixture): both operands fp16 5.5e-3 / 2.8e-3, activations only
-6.6e-4 / 3.9e-4, neither (fp16f8) 1.3e-4 / 1.2e-4.  A product over 128 k is a_hi . w_hi on eight v_mfma_f32_32x32x16_f16 plus
+The fp16f8 tier (tests/test_gpu_h8.py) with the ACTIVATION operand of in_proj / out_proj / fc1 / fc2 rounded to fp16 (11 significand bits)
+while the WEIGHT keeps hi = fp16(w) and lo8 = e4m3((w - hi) 2^12) (15 bits).  The reasoning is about how errors add up over a sampling
+loop, not about one product: an activation is rounded afresh for every token at every step (errors of random sign: they average out), a
+weight's rounding error is the same number in every product of every step (it accumulates).  Measured on the 1000-step DiT-B loops (the
+bench's drift record / the reference fixture): both operands fp16 5.5e-3 / 2.8e-3, activations only 1.1e-3 / 2.9e-4, neither (fp16f8)
+1.3e-4 / 1.2e-4.  NOT a tolerance tier: the bulk of the coordinates lands inside 1e-3 (p99.9 3e-4) and every fixture below is met, but the
+sampler has coordinates that amplify a 1e-4-sized perturbation a hundredfold (one of 256 on the CLI fixture: 2.3e-2,
+tests/test_gpu_scripts.py) -- a faster tier between the fp16 tier (TF32-class, the reference's own GPU arithmetic) and fp16f8.  A product over 128 k is a_hi . w_hi on eight v_mfma_f32_32x32x16_f16 plus
 2^-12 e4m3(a) . lo8_w on two block-scaled v_mfma_scale_f32_32x32x64_f8f6f4: 96 matrix-pipe passes where fp16f8 issues 128.  Rows are
 K-blocked in 384-byte super-groups of 128 logical columns [128 B fp16 | 128 B fp16 | 128 B e4m3 plane]: three stage rows of the GEMM.
 
@@ -215,7 +217,7 @@ def test_forward_on_other_geometries_against_the_fp32_oracle(hidden, heads, T_):
 # Option f16m8_forms: bit i = 1 puts GEMM i of a block (1 in_proj, 2 out_proj, 4 fc1, 8 fc2) on fp16-activation operands.  Default 11:
 # every big GEMM but fc1 -- the fastest mix whose worst coordinate stayed inside 1e-3 of the fp32 tier on both draws of the bench
 # shape's 1000-step loop (tools/tier_drift.py: 4.9e-4 / 8.4e-4 at 157.7 steps/s; all four: 1.1e-3 / 1.3e-3 at 168.5; none: 1.3e-4 /
-# 2.0e-4 at 132).
+# 2.0e-4 at 132).  Like fp16w8 it is NOT a tolerance tier (CLI fixture: one coordinate at 2.6e-2).
 @pytest.mark.parametrize("mask", [11, 4, 8])
 def test_mixed_forms_forward_matches_reference_golden(mask, osud_option):
     """Every pairing of fc1's and fc2's forms (mask 11 / 8: fp16 + e4m3 fc1 writes fp16-activation rows for fc2 -- the GELU epilogue's
