@@ -17,7 +17,7 @@ from osu_diffusion_amd.training import NativeTrainer  # noqa: E402
 def build(seed):
     torch.manual_seed(seed)
     m = DiT(depth=2, hidden_size=128, num_heads=2, context_size=144, num_classes=10, class_dropout_prob=0.0, precision="fp32")
-    return randomize_zero_init(m.to("cuda:0"), seed=seed).train()
+    return randomize_zero_init(m.to(f"cuda:{torch.cuda.current_device()}"), seed=seed).train()
 
 
 def batch():
@@ -54,7 +54,8 @@ def run(rank, world, steps=2, zero1=False, wire=None, full_state=False):
 
 if __name__ == "__main__":
     out_dir = sys.argv[1]
-    torch.cuda.set_device(0)
+    # (OSUD_TEST_PER_RANK_DEVICE=1: one GPU per rank -- the only placement RCCL accepts for more than one rank; multi-GPU nodes only)
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) if os.environ.get("OSUD_TEST_PER_RANK_DEVICE", "0") == "1" else 0)
     dist.init_process_group(os.environ.get("OSUD_DIST_BACKEND", "gloo"))
     rank, world = dist.get_rank(), dist.get_world_size()
     mode = os.environ.get("OSUD_TEST_MODE", "allreduce")  # allreduce | zero1 | zero1_bf16

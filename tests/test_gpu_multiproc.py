@@ -157,6 +157,28 @@ def test_stubbed_exchange_is_the_same_schedule_without_collectives():
     assert torch.equal(outs["0"]["flat"], outs["1"]["flat"]) and torch.equal(outs["0"]["ema"], outs["1"]["ema"])
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL accepts one rank per GPU: needs a node with at least two")
+@pytest.mark.parametrize("schedule", ["allreduce", "zero1", "allreduce_native", "zero1_native"])
+def test_two_ranks_over_rccl_equal_one_process(schedule):
+    """The 8-GPU job's own transport with more than one rank (skipped on the one-GPU box): 2 ranks, one GPU each, backend "nccl" =
+    RCCL -- overlapped per-slice all-reduce and the sharded optimizer, through torch's process group and through the library's own
+    communicator (`native_comm=True`: its tail all-reduces are joined before the class-table rows travel on torch's group, the case
+    ADVICE r3 names).  Replicas bit-identical, equal to one process on the whole batch to summation order."""
+    from tests import mp_worker
+
+    mode, _, native = schedule.partition("_")
+    with tempfile.TemporaryDirectory() as d:
+        _torchrun(2, [os.path.join(ROOT, "tests", "mp_worker.py"), d],
+                  dict(OSUD_DIST_BACKEND="nccl", OSUD_TEST_MODE=mode, OSUD_TEST_PER_RANK_DEVICE="1",
+                       OSUD_TEST_NATIVE_COMM="1" if native else "0"))
+        r0, r1 = torch.load(os.path.join(d, "rank0.pt")), torch.load(os.path.join(d, "rank1.pt"))
+    assert torch.equal(r0["flat"], r1["flat"]) and torch.equal(r0["ema"], r1["ema"])
+    flat, ema = mp_worker.run(0, 1)
+    scale = float(flat.abs().max())
+    assert float((flat - r0["flat"]).abs().max()) <= 2e-6 * scale
+    assert float((ema - r0["ema"]).abs().max()) <= 2e-6 * scale
+
+
 def test_bench_two_ranks_over_gloo():
     """bench.py's N > 1 code path (rank set-up, barriers, max-over-ranks timing, one JSON line from rank 0) with both ranks on
     GPU 0; once with the all-reduce exchange, once with the sharded optimizer."""
