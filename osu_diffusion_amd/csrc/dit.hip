@@ -712,7 +712,7 @@ static int sample_steps(osud_dit* m, const osud_sched* s, int mode, float eta, f
   OSUD_TRY(sched_upload(const_cast<osud_sched*>(s)));
   OSUD_TRY(dit_ensure_ws(m, N, T, m->training));
   OSUD_TRY(launch_step_init(m->step_state, first_step, seed, st, dec));  // the seed travels in device memory, not in the graph
-  // o and c do not change over the steps of a loop: their share of the first linear is computed here, once (OSUD_EMBED_CONST=0: off)
+  // o and c do not change over the steps of a loop: their share of the first linear is computed here, once (option embed_const = 0: off)
   struct ConstGuard {
     osud_dit* m;
     ~ConstGuard() { m->embed_const_on = m->tvec_table_on = false; }
