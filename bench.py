@@ -25,6 +25,7 @@ import json
 import math
 import os
 import sys
+import threading
 import time
 
 import torch
@@ -61,12 +62,55 @@ def parse():
     ap.add_argument("--grad-wire", choices=["fp32", "bf16"], default="fp32", help="--zero1: dtype of the gradients on the wire")
     ap.add_argument("--native-comm", action="store_true", help="N > 1: the timed exchange goes through the library's own RCCL communicator (C ABI)")
     ap.add_argument("--no-exchange-ab", action="store_true", help="N > 1: skip the in-run A/B of the exchange schedules (multi_gpu.schedules)")
+    ap.add_argument("--watchdog-s", type=float, default=900.0, help="N > 1: if the collective diagnostics after the timed region have not returned after this "
+                                                                    "many seconds, rank 0 prints the line with what is measured and every rank exits")
+    ap.add_argument("--simulate-hang", action="store_true", help=argparse.SUPPRESS)  # (test of the watchdog: the first diagnostic never returns)
     ap.add_argument("--no-family-table", action="store_true", help="skip the torch.profiler pass (use under rocprofv3)")
     ap.add_argument("--no-parity-tier", action="store_true", help="skip the fp32 parity-tier throughput and the bf16-vs-fp32 drift run")
     ap.add_argument("--drift-steps", type=int, default=1000, help="length of the CFG-4 loop the bf16 drift is measured on")
     ap.add_argument("--h2d", action="store_true", help="also time the training steps with every batch copied from pinned host "
                                                          "memory inside the step (reported as pcie_inclusive, never as value)")
     return ap.parse_args()
+
+
+class Watchdog:
+    """N > 1 only.  Everything after the timed region of a multi-GPU run is collective (the exchange-schedule legs, sharded sampling, the
+    DiT-XL line) and none of it has run on more than one GPU before the first such run: a collective that never returns on some node
+    must not take the timed result with it.  Armed once the line's contract fields exist; if `main` has not disarmed it by the deadline,
+    rank 0 prints the line as it stands -- plus `diagnostics_incomplete` naming the stage -- and every rank leaves with os._exit(0)."""
+
+    def __init__(self):
+        self.lock = threading.Lock()
+        self.res, self.rank, self.deadline, self.done, self.stage = None, 0, None, False, "after the timed region"
+
+    def arm(self, res, rank, seconds):
+        self.res, self.rank, self.deadline = res, rank, time.monotonic() + seconds
+        self.seconds = seconds
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def disarm(self):
+        with self.lock:
+            self.done = True
+
+    def _run(self):
+        while time.monotonic() < self.deadline:
+            time.sleep(0.25)
+            if self.done:
+                return
+        with self.lock:
+            if self.done:
+                return
+            if self.rank == 0:
+                out = {k: v for k, v in self.res.items()}
+                out["diagnostics_incomplete"] = {"stage": self.stage, "after_s": self.seconds,
+                                                 "note": "a diagnostic after the timed region did not return; value / ms_per_step are the completed timed region"}
+                print(json.dumps(out, default=str), flush=True)
+            else:
+                time.sleep(2.0)  # (rank 0's line first)
+            os._exit(0)
+
+
+WATCHDOG = Watchdog()
 
 
 def dist_setup(args):
@@ -387,6 +431,8 @@ def multi_gpu_report(args, world, rank, dev, model, diffusion, batches, timed_ms
     from osu_diffusion_amd import _lib
     from osu_diffusion_amd.training import NativeTrainer, overlap_slices
 
+    if args.simulate_hang:
+        time.sleep(1e9)
     backend = dist.get_backend()
     ones = torch.ones(1, device=dev)
     dist.all_reduce(ones)
@@ -420,6 +466,7 @@ def multi_gpu_report(args, world, rank, dev, model, diffusion, batches, timed_ms
         if name == "native_comm" and backend != "nccl":  # (the one-GPU rehearsal over gloo: two ranks of ONE device cannot form an RCCL communicator)
             sched[name] = {"skipped": "needs one GPU per rank (backend nccl)"}
             continue
+        WATCHDOG.stage = f"multi_gpu.schedules.{name}"
         try:
             sched[name] = {"ms_per_step": leg(**kw)}
         except Exception as e:  # a schedule that does not run here (e.g. no librccl for the native communicator) must not sink the line
@@ -503,6 +550,8 @@ def bench_train(args, world, rank, dev):
         per_gpu = tokens_per_s / world
         res["end_to_end"] = {"flop_per_token": FLOP_PER_TOKEN_TRAIN, "achieved_tflops_per_gpu": round(per_gpu * FLOP_PER_TOKEN_TRAIN / 1e12, 1),
                              "mfma_frac": round(per_gpu * FLOP_PER_TOKEN_TRAIN / 1e12 / PEAK_BF16_TFLOPS, 4)}
+    if world > 1:
+        WATCHDOG.arm(res, rank, args.watchdog_s)
     if args.h2d:  # the loader's hand-over (train.py:244-248): pinned host batch -> device, every step
         host = [tuple(v.cpu().pin_memory() for v in (x, o, c, y)) for (x, o, c), y in batches]
         barrier(world)
@@ -809,6 +858,7 @@ def main():
         res = bench_sample(args, world, rank, dev)
     else:
         res = bench_train(args, world, rank, dev)
+        WATCHDOG.stage = "sampling"
         sargs = argparse.Namespace(**vars(args))
         sargs.steps, sargs.warmup = args.sample_steps, None
         samp = bench_sample(sargs, world, rank, dev)
@@ -835,7 +885,9 @@ def main():
             f8 = bench_sample(fargs, world, rank, dev)
             res["sampling"]["fp8_tier"] = {"value": f8["value"], "unit": "steps/s", "ms_per_step": f8["ms_per_step"], "steps": f8["steps"], "dtype": f8["dtype"]}
         if not args.no_xl and args.precision == "bf16":
+            WATCHDOG.stage = "xl"
             res["xl"] = {p: bench_xl(args, world, rank, dev, p) for p in ([args.xl_precision] if args.xl_precision else XL_TIERS)}
+    WATCHDOG.disarm()
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

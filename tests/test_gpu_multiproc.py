@@ -204,3 +204,19 @@ def test_bench_two_ranks_over_gloo():
         assert mg["timed_schedule"]["name"] == ("zero1" if extra else "allreduce") and mg["timed_schedule"]["ms_per_step"] > 0
         wb = mg["wire_bytes_per_step"]
         assert wb["dense_slices_payload"] > 0 and wb["class_table_rows_allgather"] < wb["class_table_dense_would_be"] and wb["ring_bytes_sent_per_gpu"] > 0
+
+
+def test_bench_line_survives_a_diagnostic_that_never_returns():
+    """Everything after the timed region of an N > 1 run is collective and has never run on more than one GPU: if one of those
+    diagnostics hangs, the watchdog prints the line with the timed result (`diagnostics_incomplete` names the stage) and every rank
+    exits 0.  Two ranks over gloo, the first diagnostic replaced by a sleep that never ends."""
+    import json
+
+    out = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "train", "--steps", "2", "--warmup", "1", "--batch", "16",
+                        "--model", "DiT-S", "--no-cpu-baseline", "--no-roofline", "--simulate-hang", "--watchdog-s", "3"],
+                    dict(OSUD_DIST_BACKEND="gloo", OSUD_SINGLE_DEVICE="1"), timeout=300)
+    lines = [ln for ln in out.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["value"] > 0 and res["ms_per_step"] > 0
+    assert "multi_gpu" not in res and res["diagnostics_incomplete"]["stage"] == "after the timed region"
