@@ -380,22 +380,248 @@ template <int N> __device__ __forceinline__ void wait_vm() {
   else static_assert(N < 0, "add the literal");
 }
 
+// ---- the epilogue of one output tile, shared by the slab loop (gemm_kernel) and the phased loop (gemm_phased.h) -----------------
+template <typename TE, int EPI> struct EpiTraits {
+  static constexpr bool FAST = !std::is_same<TE, float>::value;
+  static constexpr bool kF8 = sizeof(TE) == 1;  // fp8 operands: outputs are bf16 (EPI_BIAS_TE), fp8 (EPI_BIAS_GELU_TE) or fp32
+  // fp16 + e4m3 operands (the trunk GEMMs of the tolerance tier): the bias epilogue (in_proj) feeds the split-bf16 attention kernel and
+  // writes hi | lo planes; the GELU epilogue (fc1) writes the next GEMM's operand form
+  static constexpr bool kW8 = std::is_same<TE, w8_t>::value;  // (fp16 x (fp16 + e4m3) operands: outputs as for h8_t)
+  static constexpr bool kH8 = std::is_same<TE, h8_t>::value || kW8;
+  using TOalt = typename std::conditional<kW8, h8_t, w8_t>::type;  // (EPI_BIAS_GELU_ALT: the other K-blocked activation form)
+  using TO = typename std::conditional<kF8, typename std::conditional<EPI == EPI_BIAS_GELU_TE, fp8_t, bf16_t>::type,
+                                       typename std::conditional<kH8 && EPI == EPI_BIAS_TE, x3_t,
+                                                                 typename std::conditional<kH8 && EPI == EPI_BIAS_GELU_ALT, TOalt, TE>::type>::type>::type;
+  static constexpr bool kGelu = EPI == EPI_BIAS_GELU_TE || EPI == EPI_BIAS_GELU_BF || EPI == EPI_BIAS_GELU_ALT;  // _BF: fp8 operands with bf16 outputs (training)
+};
+
+// acc[i][j]: the wave's 32 x 32 block (Y block i, X block j) as the MFMA left it; (ty, tx) the tile, (wy, wx) the wave inside it;
+// pw / pr0 / pr1: this lane's write / read-back addresses in the wave's 4 KiB LDS patch, pso the patch area's byte offset;
+// q_amax: fp8 training, running max |value| of this lane's share of the e4m3 output
+template <typename TE, int EPI, int WY, int WX, int RY, int RX>
+__device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x16 (&acc)[RY][RX], const int ty, const int tx, const int wy, const int wx,
+                                              const int lane, const uint32_t (&pw)[4], const uint32_t pr0, const uint32_t pr1,
+                                              const uint32_t pso, float& q_amax) {
+  using ET = EpiTraits<TE, EPI>;
+  using TO = typename ET::TO;
+  constexpr bool FAST = ET::FAST, kF8 = ET::kF8, kGelu = ET::kGelu;
+  constexpr int BM = WY * RY * 32, BN = WX * RX * 32;
+  // ---- epilogue -------------------------------------------------------------------------------
+  // The MFMA leaves lane (frow, fhalf) with y = frow and x = 8g + 4*fhalf + {0..3}: stored as is, one store
+  // instruction touches 32 rows with 8..32 bytes each and the epilogue is bound by the L2 REQUEST rate
+  // (measured: ~9 us per 256x256 tile, a third of the kernel).  So every 32x32 block takes a round trip
+  // through a wave-private 4 KiB LDS patch (16-byte slot index XOR-swizzled with row&7, conflict free both
+  // ways) and comes back row-major: lane l holds rows (l>>2) and 16 + (l>>2) and x = 8*(l&3) + {0..7} -- 4 lanes
+  // cover one 128-byte (f32) / 64-byte (bf16) row segment with 16-byte (bf16) / 2 x 16-byte (f32) stores per lane, which
+  // halves the number of store instructions of a bf16 output (the TA spends ~16 cycles per vector-memory instruction
+  // whatever its width); the operand loads (residual, saved pre-activation) are coalesced the same way.
+  // All loads of a block are issued BEFORE its stores: vmcnt counts stores too, so a load waited for
+  // between stores would drain every earlier store.
+  constexpr bool kBias = EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_TE || EPI == EPI_BIAS_SILU_TE ||
+                         kGelu || EPI == EPI_GATE_RES;
+  const int lrow = lane >> 2, lcol = 8 * (lane & 3);
+  const int xw = tx * BN + wx * RX * 32 + lcol;  // + j*32
+  float csv[RX][8];
+  if (kF8) {
+#pragma unroll
+    for (int j = 0; j < RX; ++j) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) csv[j][e] = 1.0f;
+      if (p.colscale != nullptr) load8(p.colscale + xw + j * 32, csv[j]);
+      if (p.act_inv != nullptr || p.act_inv_host != 0.f) {  // the activation's de-quantisation factor: static (host) or dynamic
+        const float ai = (p.act_inv != nullptr ? *p.act_inv : 1.0f) * (p.act_inv_host != 0.f ? p.act_inv_host : 1.0f);  // (device: fp8 training)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) csv[j][e] *= ai;
+      }
+    }
+  }
+  float bv[RX][8];
+  if (kBias) {
+#pragma unroll
+    for (int j = 0; j < RX; ++j) {
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + xw + j * 32);
+      const float4 b1 = *reinterpret_cast<const float4*>(p.bias + xw + j * 32 + 4);
+      bv[j][0] = b0.x; bv[j][1] = b0.y; bv[j][2] = b0.z; bv[j][3] = b0.w;
+      bv[j][4] = b1.x; bv[j][5] = b1.y; bv[j][6] = b1.z; bv[j][7] = b1.w;
+    }
+  }
+  // The blocks are software-pipelined: block b+1 enters the patch (4 writes + 4 reads) before block b is finished, so
+  // the LDS round trip hides under block b's arithmetic and stores.  One wave's LDS operations execute in order: the
+  // reads of b are done once at most the 8 newer operations are outstanding, and the writes of b+1 cannot overtake them.
+  constexpr int NB = RY * RX;
+  auto patch_trip = [&](int b, f32x4 (&t)[4]) {
+    const int i = b / RX, j = b % RX;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 v;
+      v[0] = acc[i][j][4 * g + 0]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
+      ds_write16(pw[g] + pso, v);
+    }
+    t[0] = ds_read16f<0>(pr0 + pso);      // rows 0..15 : x 0..3 | 4..7 of this lane's 8
+    t[1] = ds_read16f<0>(pr1 + pso);
+    t[2] = ds_read16f<2048>(pr0 + pso);   // rows 16..31
+    t[3] = ds_read16f<2048>(pr1 + pso);
+  };
+  // fp8 training: the e4m3 twin of a bf16 output (the operand of the NEXT fp8 GEMM) written here instead of by a separate pass
+  constexpr bool kOut8 = kF8 && (EPI == EPI_BIAS_GELU_BF || EPI == EPI_GELUGRAD_TE);
+  const bool out8_on = kOut8 && p.out8 != nullptr;
+  const float q_scale = out8_on ? p.out8_slot[0] : 1.0f;
+  constexpr bool kColsum = EPI == EPI_GELUGRAD_TE;
+  float cs[kColsum ? RX : 1][8];
+  if (kColsum) {
+#pragma unroll
+    for (int j = 0; j < RX; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) cs[j][e] = 0.f;
+  }
+  f32x4 tq[2][4];
+  patch_trip(0, tq[0]);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int i = b / RX, j = b % RX;
+    const int yb = ty * BM + wy * RY * 32 + i * 32;  // wave-uniform first row of the block
+    const int y0 = yb + lrow;                           // + 16q
+    int sample = 0;
+    if (EPI == EPI_GATE_RES) {  // rows_per_sample % 32 == 0: one sample per 32-row block
+      sample = __builtin_amdgcn_readfirstlane(yb) / p.rows_per_sample;
+      if (sample >= p.n_samples) sample = p.n_samples - 1;  // padding rows
+    }
+    f32x4 (&t)[4] = tq[b & 1];
+    const int x = xw + j * 32;
+    float gv[8], rv[2][8];
+    float rb[2];
+    if (EPI == EPI_GATE_RES) {
+      const float* rsrc = p.res ? p.res : reinterpret_cast<const float*>(p.out);
+      load8(p.gate + (size_t)sample * p.ld_gate + x, gv);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) load8(rsrc + (size_t)(y0 + 16 * q) * p.ldo + x, rv[q]);
+    }
+    if (EPI == EPI_ACCUM_F32) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) load8(reinterpret_cast<const float*>(p.out) + (size_t)(y0 + 16 * q) * p.ldo + x, rv[q]);
+    }
+    if (EPI == EPI_GELUGRAD_TE) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) load8(reinterpret_cast<const TO*>(p.aux) + (size_t)(y0 + 16 * q) * p.ldo + x, rv[q]);
+    }
+    if (EPI == EPI_ROWBIAS_TE) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) rb[q] = p.bias[y0 + 16 * q];
+    }
+    if (b + 1 < NB) {
+      patch_trip(b + 1, tq[(b + 1) & 1]);
+      OSUD_LGKM_WAIT(8);
+    } else {
+      OSUD_LGKM_WAIT(0);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      float v[8], w[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] = t[2 * q][e];
+        v[4 + e] = t[2 * q + 1][e];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (kF8) v[e] *= csv[j][e];
+        if (kBias) v[e] += bv[j][e];
+        if (EPI == EPI_ROWBIAS_TE) v[e] += rb[q];
+      }
+      const size_t orow = (size_t)(y0 + 16 * q);
+      const size_t o = orow * p.ldo + x;  // (fp32 outputs and the single-plane TE forms)
+      if (EPI == EPI_NONE_F32 && p.seg_rows > 0) {  // (a 32-row block never straddles two segments: seg_rows % 32 == 0)
+        const int sg = __builtin_amdgcn_readfirstlane(yb / p.seg_rows);
+        store8(p.seg_out[sg] + (size_t)(y0 + 16 * q - sg * p.seg_rows) * p.ldo + x, v);
+      } else if (EPI == EPI_BIAS_F32 || EPI == EPI_NONE_F32) {
+        store8(reinterpret_cast<float*>(p.out) + o, v);
+      } else if (EPI == EPI_ACCUM_F32) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = rv[q][e] + v[e];
+        store8(reinterpret_cast<float*>(p.out) + o, w);
+      } else if (EPI == EPI_GATE_RES) {
+        if (p.out2) store8_out<TO>(p.out2, orow, p.ldo, x, v);  // branch output (training)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = rv[q][e] + gv[e] * v[e];
+        store8(reinterpret_cast<float*>(p.out) + o, w);
+      } else if (EPI == EPI_BIAS_SILU_TE) {
+        if (p.out2) store8_out<TO>(p.out2, orow, p.ldo, x, v);  // pre-activation (training)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = silu_t<FAST>(v[e]);
+        store8_out<TO>(p.out, orow, p.ldo, x, w);
+      } else if (kGelu) {
+        if (p.out2) {  // training: the DERIVATIVE goes out (same exp/rcp as the value), so that the backward epilogue
+                       // is a plain multiply instead of two more quarter-rate transcendentals per element
+          float dg[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) gelu_tanh_both_t<FAST>(v[e], w[e], dg[e]);
+          store8_out<TO>(p.out2, orow, p.ldo, x, dg);
+          if constexpr (kOut8) {
+            if (out8_on) {
+              float q8[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                q_amax = fmaxf(q_amax, fabsf(w[e]));
+                q8[e] = w[e] * q_scale;
+              }
+              store8(reinterpret_cast<fp8_t*>(p.out8) + o, q8);
+            }
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) w[e] = gelu_tanh_t<FAST>(v[e]) * ((kF8 && EPI == EPI_BIAS_GELU_TE) ? p.out_scale : 1.0f);
+        }
+        if (!kOut8 || p.out != nullptr) store8_out<TO>(p.out, orow, p.ldo, x, w);  // (null: only the e4m3 twin is consumed)
+      } else if (EPI == EPI_GELUGRAD_TE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) w[e] = v[e] * rv[q][e];
+        if constexpr (kOut8) {
+          if (out8_on) {
+            float q8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              q_amax = fmaxf(q_amax, fabsf(w[e]));
+              q8[e] = w[e] * q_scale;
+            }
+            store8(reinterpret_cast<fp8_t*>(p.out8) + o, q8);
+          }
+        }
+        if (kColsum) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) cs[j][e] += w[e];
+        }
+        if (!kOut8 || p.out != nullptr) store8(reinterpret_cast<TO*>(p.out) + o, w);
+      } else {  // EPI_BIAS_TE, EPI_ROWBIAS_TE, EPI_NONE_TE
+        store8_out<TO>(p.out, orow, p.ldo, x, v);
+      }
+    }
+  }
+  if (kColsum && p.colpart != nullptr) {
+    // bias gradient riding along: this wave's RY*32 rows are summed per column -- over the lane's own rows above, over
+    // the 16 lane-rows here (fixed butterfly: deterministic) -- and stored as one row of partial sums
+#pragma unroll
+    for (int j = 0; j < RX; ++j) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = cs[j][e];
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        cs[j][e] = v;
+      }
+      if (lane < 4) store8(p.colpart + (size_t)(ty * WY + wy) * p.Nx + xw + j * 32, cs[j]);
+    }
+  }
+}
+
 template <typename TE, int EPI, int WY, int WX, int RY, int RX>
 __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p) {
   using G = Geo<WY, WX, RY, RX>;
   constexpr int BN = G::BN, SB = SLAB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr bool FAST = !std::is_same<TE, float>::value;
-  constexpr bool kF8 = sizeof(TE) == 1;  // fp8 operands: outputs are bf16 (EPI_BIAS_TE), fp8 (EPI_BIAS_GELU_TE) or fp32
-  // fp16 + e4m3 operands (the trunk GEMMs of the tolerance tier): the bias epilogue (in_proj) feeds the split-bf16 attention kernel and
-  // writes hi | lo planes; the GELU epilogue (fc1) writes the next GEMM's operand form
-  constexpr bool kW8 = std::is_same<TE, w8_t>::value;  // (fp16 x (fp16 + e4m3) operands: outputs as for h8_t)
-  constexpr bool kH8 = std::is_same<TE, h8_t>::value || kW8;
-  using TOalt = typename std::conditional<kW8, h8_t, w8_t>::type;  // (EPI_BIAS_GELU_ALT: the other K-blocked activation form)
-  using TO = typename std::conditional<kF8, typename std::conditional<EPI == EPI_BIAS_GELU_TE, fp8_t, bf16_t>::type,
-                                       typename std::conditional<kH8 && EPI == EPI_BIAS_TE, x3_t,
-                                                                 typename std::conditional<kH8 && EPI == EPI_BIAS_GELU_ALT, TOalt, TE>::type>::type>::type;
-  constexpr bool kGelu = EPI == EPI_BIAS_GELU_TE || EPI == EPI_BIAS_GELU_BF || EPI == EPI_BIAS_GELU_ALT;  // _BF: fp8 operands with bf16 outputs (training)
+  using ET = EpiTraits<TE, EPI>;
+  constexpr bool kW8 = ET::kW8, kH8 = ET::kH8;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wy = wave / WX, wx = wave % WX;
@@ -543,7 +769,6 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
     const uint64_t t0 = wall_clock64();
     while (wall_clock64() - t0 < (uint64_t)p.exp_delay) __builtin_amdgcn_s_sleep(8);
   }
-  const bool exp_nostore = (p.tile_order & 16) != 0, exp_nomath = (p.tile_order & 32) != 0;
 #endif
   float q_amax = 0.f;  // fp8 training: running max |value| of this lane's share of the e4m3 output
   bool first_tile = true;
@@ -648,228 +873,7 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
     pso = (uint32_t)(((consumed + G::NSTAGE - 1) % G::NSTAGE) * G::STAGE);
 
 
-    // ---- epilogue -------------------------------------------------------------------------------
-    // The MFMA leaves lane (frow, fhalf) with y = frow and x = 8g + 4*fhalf + {0..3}: stored as is, one store
-    // instruction touches 32 rows with 8..32 bytes each and the epilogue is bound by the L2 REQUEST rate
-    // (measured: ~9 us per 256x256 tile, a third of the kernel).  So every 32x32 block takes a round trip
-    // through a wave-private 4 KiB LDS patch (16-byte slot index XOR-swizzled with row&7, conflict free both
-    // ways) and comes back row-major: lane l holds rows (l>>2) and 16 + (l>>2) and x = 8*(l&3) + {0..7} -- 4 lanes
-    // cover one 128-byte (f32) / 64-byte (bf16) row segment with 16-byte (bf16) / 2 x 16-byte (f32) stores per lane, which
-    // halves the number of store instructions of a bf16 output (the TA spends ~16 cycles per vector-memory instruction
-    // whatever its width); the operand loads (residual, saved pre-activation) are coalesced the same way.
-    // All loads of a block are issued BEFORE its stores: vmcnt counts stores too, so a load waited for
-    // between stores would drain every earlier store.
-    constexpr bool kBias = EPI == EPI_BIAS_F32 || EPI == EPI_BIAS_TE || EPI == EPI_BIAS_SILU_TE ||
-                           kGelu || EPI == EPI_GATE_RES;
-    const int lrow = lane >> 2, lcol = 8 * (lane & 3);
-    const int xw = tx * BN + wx * RX * 32 + lcol;  // + j*32
-    float csv[RX][8];
-    if (kF8) {
-#pragma unroll
-      for (int j = 0; j < RX; ++j) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) csv[j][e] = 1.0f;
-        if (p.colscale != nullptr) load8(p.colscale + xw + j * 32, csv[j]);
-        if (p.act_inv != nullptr || p.act_inv_host != 0.f) {  // the activation's de-quantisation factor: static (host) or dynamic
-          const float ai = (p.act_inv != nullptr ? *p.act_inv : 1.0f) * (p.act_inv_host != 0.f ? p.act_inv_host : 1.0f);  // (device: fp8 training)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) csv[j][e] *= ai;
-        }
-      }
-    }
-    float bv[RX][8];
-    if (kBias) {
-#pragma unroll
-      for (int j = 0; j < RX; ++j) {
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + xw + j * 32);
-        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + xw + j * 32 + 4);
-        bv[j][0] = b0.x; bv[j][1] = b0.y; bv[j][2] = b0.z; bv[j][3] = b0.w;
-        bv[j][4] = b1.x; bv[j][5] = b1.y; bv[j][6] = b1.z; bv[j][7] = b1.w;
-      }
-    }
-    // The blocks are software-pipelined: block b+1 enters the patch (4 writes + 4 reads) before block b is finished, so
-    // the LDS round trip hides under block b's arithmetic and stores.  One wave's LDS operations execute in order: the
-    // reads of b are done once at most the 8 newer operations are outstanding, and the writes of b+1 cannot overtake them.
-    constexpr int NB = RY * RX;
-    auto patch_trip = [&](int b, f32x4 (&t)[4]) {
-      const int i = b / RX, j = b % RX;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 v;
-        v[0] = acc[i][j][4 * g + 0]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
-        ds_write16(pw[g] + pso, v);
-      }
-      t[0] = ds_read16f<0>(pr0 + pso);      // rows 0..15 : x 0..3 | 4..7 of this lane's 8
-      t[1] = ds_read16f<0>(pr1 + pso);
-      t[2] = ds_read16f<2048>(pr0 + pso);   // rows 16..31
-      t[3] = ds_read16f<2048>(pr1 + pso);
-    };
-    // fp8 training: the e4m3 twin of a bf16 output (the operand of the NEXT fp8 GEMM) written here instead of by a separate pass
-    constexpr bool kOut8 = kF8 && (EPI == EPI_BIAS_GELU_BF || EPI == EPI_GELUGRAD_TE);
-    const bool out8_on = kOut8 && p.out8 != nullptr;
-    const float q_scale = out8_on ? p.out8_slot[0] : 1.0f;
-    constexpr bool kColsum = EPI == EPI_GELUGRAD_TE;
-    float cs[kColsum ? RX : 1][8];
-    if (kColsum) {
-#pragma unroll
-      for (int j = 0; j < RX; ++j)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) cs[j][e] = 0.f;
-    }
-    f32x4 tq[2][4];
-    patch_trip(0, tq[0]);
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      const int i = b / RX, j = b % RX;
-      const int yb = ty * G::BM + wy * RY * 32 + i * 32;  // wave-uniform first row of the block
-      const int y0 = yb + lrow;                           // + 16q
-      int sample = 0;
-      if (EPI == EPI_GATE_RES) {  // rows_per_sample % 32 == 0: one sample per 32-row block
-        sample = __builtin_amdgcn_readfirstlane(yb) / p.rows_per_sample;
-        if (sample >= p.n_samples) sample = p.n_samples - 1;  // padding rows
-      }
-      f32x4 (&t)[4] = tq[b & 1];
-      const int x = xw + j * 32;
-      float gv[8], rv[2][8];
-      float rb[2];
-      if (EPI == EPI_GATE_RES) {
-        const float* rsrc = p.res ? p.res : reinterpret_cast<const float*>(p.out);
-        load8(p.gate + (size_t)sample * p.ld_gate + x, gv);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) load8(rsrc + (size_t)(y0 + 16 * q) * p.ldo + x, rv[q]);
-      }
-      if (EPI == EPI_ACCUM_F32) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) load8(reinterpret_cast<const float*>(p.out) + (size_t)(y0 + 16 * q) * p.ldo + x, rv[q]);
-      }
-      if (EPI == EPI_GELUGRAD_TE) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) load8(reinterpret_cast<const TO*>(p.aux) + (size_t)(y0 + 16 * q) * p.ldo + x, rv[q]);
-      }
-      if (EPI == EPI_ROWBIAS_TE) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) rb[q] = p.bias[y0 + 16 * q];
-      }
-      if (b + 1 < NB) {
-        patch_trip(b + 1, tq[(b + 1) & 1]);
-        OSUD_LGKM_WAIT(8);
-      } else {
-        OSUD_LGKM_WAIT(0);
-      }
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        float v[8], w[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          v[e] = t[2 * q][e];
-          v[4 + e] = t[2 * q + 1][e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          if (kF8) v[e] *= csv[j][e];
-          if (kBias) v[e] += bv[j][e];
-          if (EPI == EPI_ROWBIAS_TE) v[e] += rb[q];
-        }
-        const size_t orow = (size_t)(y0 + 16 * q);
-        const size_t o = orow * p.ldo + x;  // (fp32 outputs and the single-plane TE forms)
-#ifdef OSUD_GEMM_EXP
-        if (exp_nostore || exp_nomath) {  // timing experiments: (16) the epilogue's arithmetic without its stores, (32) its stores without the arithmetic
-          if (exp_nomath) {
-            store8(reinterpret_cast<TO*>(p.out) + o, v);
-            if (kGelu && p.out2) store8(reinterpret_cast<TO*>(p.out2) + o, v);
-          } else {
-            float dg[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) gelu_tanh_both_t<FAST>(v[e], w[e], dg[e]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) asm volatile("" ::"v"(w[e]), "v"(dg[e]));
-          }
-          continue;
-        }
-#endif
-        if (EPI == EPI_NONE_F32 && p.seg_rows > 0) {  // (a 32-row block never straddles two segments: seg_rows % 32 == 0)
-          const int sg = __builtin_amdgcn_readfirstlane(yb / p.seg_rows);
-          store8(p.seg_out[sg] + (size_t)(y0 + 16 * q - sg * p.seg_rows) * p.ldo + x, v);
-        } else if (EPI == EPI_BIAS_F32 || EPI == EPI_NONE_F32) {
-          store8(reinterpret_cast<float*>(p.out) + o, v);
-        } else if (EPI == EPI_ACCUM_F32) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) w[e] = rv[q][e] + v[e];
-          store8(reinterpret_cast<float*>(p.out) + o, w);
-        } else if (EPI == EPI_GATE_RES) {
-          if (p.out2) store8_out<TO>(p.out2, orow, p.ldo, x, v);  // branch output (training)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) w[e] = rv[q][e] + gv[e] * v[e];
-          store8(reinterpret_cast<float*>(p.out) + o, w);
-        } else if (EPI == EPI_BIAS_SILU_TE) {
-          if (p.out2) store8_out<TO>(p.out2, orow, p.ldo, x, v);  // pre-activation (training)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) w[e] = silu_t<FAST>(v[e]);
-          store8_out<TO>(p.out, orow, p.ldo, x, w);
-        } else if (kGelu) {
-          if (p.out2) {  // training: the DERIVATIVE goes out (same exp/rcp as the value), so that the backward epilogue
-                         // is a plain multiply instead of two more quarter-rate transcendentals per element
-            float dg[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) gelu_tanh_both_t<FAST>(v[e], w[e], dg[e]);
-            store8_out<TO>(p.out2, orow, p.ldo, x, dg);
-            if constexpr (kOut8) {
-              if (out8_on) {
-                float q8[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                  q_amax = fmaxf(q_amax, fabsf(w[e]));
-                  q8[e] = w[e] * q_scale;
-                }
-                store8(reinterpret_cast<fp8_t*>(p.out8) + o, q8);
-              }
-            }
-          } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] = gelu_tanh_t<FAST>(v[e]) * ((kF8 && EPI == EPI_BIAS_GELU_TE) ? p.out_scale : 1.0f);
-          }
-          if (!kOut8 || p.out != nullptr) store8_out<TO>(p.out, orow, p.ldo, x, w);  // (null: only the e4m3 twin is consumed)
-        } else if (EPI == EPI_GELUGRAD_TE) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) w[e] = v[e] * rv[q][e];
-          if constexpr (kOut8) {
-            if (out8_on) {
-              float q8[8];
-#pragma unroll
-              for (int e = 0; e < 8; ++e) {
-                q_amax = fmaxf(q_amax, fabsf(w[e]));
-                q8[e] = w[e] * q_scale;
-              }
-              store8(reinterpret_cast<fp8_t*>(p.out8) + o, q8);
-            }
-          }
-          if (kColsum) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) cs[j][e] += w[e];
-          }
-          if (!kOut8 || p.out != nullptr) store8(reinterpret_cast<TO*>(p.out) + o, w);
-        } else {  // EPI_BIAS_TE, EPI_ROWBIAS_TE, EPI_NONE_TE
-          store8_out<TO>(p.out, orow, p.ldo, x, v);
-        }
-      }
-    }
-    if (kColsum && p.colpart != nullptr) {
-      // bias gradient riding along: this wave's RY*32 rows are summed per column -- over the lane's own rows above, over
-      // the 16 lane-rows here (fixed butterfly: deterministic) -- and stored as one row of partial sums
-#pragma unroll
-      for (int j = 0; j < RX; ++j) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float v = cs[j][e];
-          v += __shfl_xor(v, 4, 64);
-          v += __shfl_xor(v, 8, 64);
-          v += __shfl_xor(v, 16, 64);
-          v += __shfl_xor(v, 32, 64);
-          cs[j][e] = v;
-        }
-        if (lane < 4) store8(p.colpart + (size_t)(ty * WY + wy) * p.Nx + xw + j * 32, cs[j]);
-      }
-    }
+    tile_epilogue<TE, EPI, WY, WX, RY, RX>(p, acc, ty, tx, wy, wx, lane, pw, pr0, pr1, pso, q_amax);
 #ifdef OSUD_GEMM_TIMING
     tsum[5] += __builtin_readcyclecounter() - te0;  // epilogue (incl. the drain wait and barrier)
 #endif
@@ -941,6 +945,7 @@ template <typename TE, int EPI, int WY, int WX, int RY, int RX> int launch_w(con
 //   128x128: 2x2 waves of 64x64    small problems
 //    64x128: 2x2 waves of 32x64    problems with fewer 128x128 tiles than 3/4 of the CUs
 // Pick by the fraction of CU-rounds doing useful work, preferring the larger tile on ties.
+template <typename TE, int EPI> int launch_phased_or(const GemmP& p, int pick, hipStream_t st, bool& taken);  // gemm_phased.h
 template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
   const int cus = gemm_num_cus(), splits = p.split_k > 1 ? p.split_k : 1;
   auto eff = [&](int bm, int bn) -> double {
@@ -967,6 +972,11 @@ template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
     else if (force == 1192 && e[3] > 0) pick = 3;
     else if (force == 1256 && p.Nx % 256 == 0) pick = 8;
   }
+  {  // the phased main loop (gemm_phased.h) where it exists; option gemm_loop = 0 keeps every launch on the slab loop
+    bool taken = false;
+    const int rc = launch_phased_or<TE, EPI>(p, pick, st, taken);
+    if (taken) return rc;
+  }
   if (pick == 2) return launch_w<TE, EPI, 2, 4, 4, 2>(p, st);
   if (pick == 1) return launch_w<TE, EPI, 4, 2, 2, 3>(p, st);
   if (pick == 3) return launch_w<TE, EPI, 2, 4, 3, 2>(p, st);
@@ -975,6 +985,7 @@ template <typename TE, int EPI> int launch_t(const GemmP& p, hipStream_t st) {
   return launch_w<TE, EPI, 2, 2, 2, 2>(p, st);
 }
 
-
 }  // namespace
 }  // namespace osud
+
+#include "gemm_phased.h"

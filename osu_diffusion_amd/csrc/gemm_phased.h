@@ -1,0 +1,342 @@
+// The phased main loop for the two 256-row tile geometries of plain 2-byte operands (bf16, fp16): the same product, the same
+// LDS-DMA staging, the same fragment reads, MFMAs and epilogue as gemm_kernel (gemm_kernel.h) -- every accumulator sees its k in
+// the same order, so the results are bit-identical -- in a different SCHEDULE.  gfx950 only.
+//
+// gemm_kernel's loop is one barrier per 128-byte K slab: all eight waves wait for the slab, all issue their eight LDS-DMA pieces
+// of the next one (the vector-memory path takes a piece per ~16 cycles and CU; the issuing wave issues nothing else meanwhile),
+// then all run the slab's 32 MFMAs with the fragment reads interleaved.  Both waves of a SIMD are in the same segment at the same
+// time, so the matrix pipe idles through every DMA burst: ~3000 cycles per slab against 2048 of MFMA issue.
+//
+// Here a K slab is cut into NPH phases.  A phase of one wave is
+//     [fragment reads of the phase's cluster | this phase's share of LDS-DMA pieces | counted vmcnt]  s_barrier
+//     [lgkmcnt(0) | s_setprio 1 | a cluster of 8 MFMAs | s_setprio 0]                                 s_barrier
+// and the two waves of every SIMD (wave w and w + 4: group 0 and group 1) run ONE barrier apart: while a group-0 wave issues its
+// cluster, its group-1 partner on the same SIMD reads fragments and issues DMA, and the other way round in the next interval.
+// The matrix pipe always has one wave feeding it, and no wave ever issues an MFMA behind a DMA burst of its own.
+//
+// Staging is a stream of 1 KiB pieces in the order the phases need them (the LDS image of a slab is laid out in that order:
+// PhSched::y_row / x_row), two slab buffers, AHEAD pieces per wave in flight in front of the consumer, cnt[p] more issued per
+// phase.  Loads return in order, so `vmcnt(W[p])` before the first barrier of phase p retires exactly what phase p + 1 reads;
+// it is never 0 in steady state.  The rules the table is checked against at compile time (sched_ok):
+//   RAW  a piece is read one phase AFTER the phase whose counted wait (+ barrier, which every wave passes after its own wait)
+//        retires it -- one barrier more than lock step needs, because group 1 waits one barrier later than group 0;
+//   WAR  a region of a buffer is restaged at the earliest two phases after the phase that read it.
+// Tiles: persistent workgroups, static XCD-contiguous order as in gemm_kernel; the stream runs across tile boundaries (the next
+// tile's first slab and a half are in flight under the last phases), everything in flight is waited for once before the
+// epilogue's stores join the queue, and the first slab of a tile therefore needs no counted waits.  The stagger is per tile:
+// group 1 enters a tile with one extra barrier, group 0 pays it back after its epilogue; the epilogues of both groups run side
+// by side (patches live behind the ring: no barrier inside).
+#pragma once
+#include <utility>
+// (included at the end of gemm_kernel.h)
+
+namespace osud {
+namespace {
+
+template <int GEO> struct PhSched;
+// 256 x 256: 2 x 4 waves of 128 x 64 (4 x 2 accumulator blocks).  Phases: (Ya, X0) (Ya, X1) (Yb, X1) (Yb, X0), Ya / Yb = Y blocks
+// 0, 1 / 2, 3; the Yb fragments overwrite Ya's registers.  LDS rows of a slab, in need order: Ya | X0 | X1 | Yb, 128 rows each.
+template <> struct PhSched<0> {
+  static constexpr int WY = 2, WX = 4, RY = 4, RX = 2, BN = 256, NPH = 4, PPW = 8, AHEAD = 12;
+  static constexpr int cnt[NPH] = {2, 2, 2, 2};      // pieces per wave issued in phase p
+  static constexpr int need[NPH] = {3, 5, 7, -1};    // highest piece slot the reads of phase p touch (-1: no reads)
+  static constexpr int read_phase[PPW] = {0, 0, 0, 0, 1, 1, 2, 2};
+  static constexpr bool is_y(int m) { return m < 2 || m >= 6; }
+  static constexpr int Y_OFF[RY] = {0, 32 * SLAB, 384 * SLAB, 416 * SLAB};   // byte offsets of the wave's Y blocks from block 0
+  static constexpr int X_OFF[RX] = {0, 128 * SLAB};
+  __device__ static int y_row0(int wy) { return wy * 64; }
+  __device__ static int x_row0(int wx) { return 128 + wx * 32; }
+  // LDS row r of a slab -> row inside the tile's Y (isy) or X panel
+  __device__ static int src_row(int r, bool& isy) {
+    const int q = r >> 7, t = r & 127;
+    isy = q == 0 || q == 3;
+    if (q == 0) return (t >> 6) * 128 + (t & 63);
+    if (q == 3) return (t >> 6) * 128 + 64 + (t & 63);
+    return (t >> 5) * 64 + (q == 2 ? 32 : 0) + (t & 31);
+  }
+};
+// 256 x 192: 4 x 2 waves of 64 x 96 (2 x 3 blocks).  Phases: (Y, X0) (Y, X1) (Y, X2).  LDS rows: Y (256) | X0 | X1 | X2 (64 each:
+// block j of wave column 0, then of wave column 1).
+template <> struct PhSched<1> {
+  static constexpr int WY = 4, WX = 2, RY = 2, RX = 3, BN = 192, NPH = 3, PPW = 7, AHEAD = 12;
+  static constexpr int cnt[NPH] = {1, 1, 5};
+  static constexpr int need[NPH] = {4, 5, 6};
+  static constexpr int read_phase[PPW] = {0, 0, 0, 0, 0, 1, 2};
+  static constexpr bool is_y(int m) { return m < 4; }
+  static constexpr int Y_OFF[RY] = {0, 32 * SLAB};
+  static constexpr int X_OFF[RX] = {0, 64 * SLAB, 128 * SLAB};
+  __device__ static int y_row0(int wy) { return wy * 64; }
+  __device__ static int x_row0(int wx) { return 256 + wx * 32; }
+  __device__ static int src_row(int r, bool& isy) {
+    isy = r < 256;
+    if (isy) return r;
+    const int t = r - 256;
+    return ((t >> 5) & 1) * 96 + (t >> 6) * 32 + (t & 31);
+  }
+};
+
+template <typename S> constexpr int ph_issued_before(int p) {  // pieces per wave issued since the slab's phase 0, before phase p
+  int n = 0;
+  for (int q = 0; q < p; ++q) n += S::cnt[q];
+  return n;
+}
+// the counted wait of phase p: how many of this wave's pieces may still be in flight when phase p + 1's reads must have landed
+template <typename S> constexpr int ph_wait(int p) {
+  const int nxt = (p + 1) % S::NPH;
+  if (S::need[nxt] < 0) return -1;
+  const int needpos = (p + 1 == S::NPH ? S::PPW : 0) + S::need[nxt];
+  return S::AHEAD + ph_issued_before<S>(p + 1) - (needpos + 1);
+}
+template <typename S> constexpr bool sched_ok() {
+  int total = 0;
+  for (int p = 0; p < S::NPH; ++p) total += S::cnt[p];
+  if (total != S::PPW) return false;  // the stream advances one slab per slab
+  for (int p = 0; p < S::NPH; ++p) {
+    if (S::need[(p + 1) % S::NPH] >= 0 && ph_wait<S>(p) < 0) return false;  // RAW: the needed piece must have been ISSUED by then
+    for (int i = 0; i < S::cnt[p]; ++i) {
+      const int pos = S::AHEAD + ph_issued_before<S>(p) + i, d = pos / S::PPW, m = pos % S::PPW;
+      if (d < 1 || d > 2) return false;                        // two buffers: the slab after this one, or the one after that
+      if (d == 2 && p < S::read_phase[m] + 2) return false;    // WAR: same buffer as the slab being consumed
+      if (d == 1 && p + S::NPH < S::read_phase[m] + 2) return false;
+    }
+  }
+  return true;
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
+
+template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+#ifndef OSUD_PHASED_SETPRIO
+#define OSUD_PHASED_SETPRIO 1
+#endif
+
+template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void gemm_phased_kernel(GemmP p) {
+  using S = PhSched<GEO>;
+  static_assert(sizeof(TE) == 2 && Planes<TE>::k == 1, "plain 2-byte operands");
+  static_assert(sched_ok<S>(), "phase table breaks a staging rule");
+  constexpr int WY = S::WY, WX = S::WX, RY = S::RY, RX = S::RX, BM = 256, BN = S::BN, NPH = S::NPH, PPW = S::PPW;
+  constexpr int STAGE = (BM + BN) * SLAB, RING = 2 * STAGE;
+  static_assert(WY * RY * 32 == BM && WX * RX * 32 == BN && STAGE == 8 * PPW * 1024 && RING + 8 * 4096 <= 160 * 1024, "geometry");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wy = wave / WX, wx = wave % WX;
+  const int grp = wave >> 2;  // waves w and w + 4 share a SIMD: one of each group
+  const int frow = lane & 31, fhalf = lane >> 5;
+
+  const int ntx = p.Nx / BN, ntiles = (p.My / BM) * ntx;
+  const int nk = (int)((size_t)p.K * sizeof(TE) / SLAB);
+  const size_t ldy_b = (size_t)p.ldy * sizeof(TE), ldx_b = (size_t)p.ldx * sizeof(TE);
+  const char* const gy0 = reinterpret_cast<const char*>(p.Y);
+  const char* const gx0 = reinterpret_cast<const char*>(p.X);
+  const int G8 = gridDim.x;
+  int first;  // workgroup b runs on XCD b % 8: every XCD walks a contiguous run of tiles per round (as gemm_kernel)
+  {
+    const int b = blockIdx.x, q = G8 >> 3, r = G8 & 7, xcd = b & 7, idx = b >> 3;
+    first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_void*)smem;
+
+  // fragment read addresses (buffer 0): the wave's first Y / X block, k sub-step s; 16-byte chunks swizzled by (row >> 1) & 7
+  uint32_t ya[4], xa[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const uint32_t sw = (uint32_t)(((2 * s + fhalf) ^ ((frow >> 1) & 7)) << 4);
+    ya[s] = lds0 + (uint32_t)((S::y_row0(wy) + frow) * SLAB) + sw;
+    xa[s] = lds0 + (uint32_t)((S::x_row0(wx) + frow) * SLAB) + sw;
+  }
+  // epilogue patches: 4 KiB per wave behind the ring (same addressing as gemm_kernel)
+  const uint32_t patch = lds0 + RING + wave * 4096;
+  uint32_t pw[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) pw[g] = patch + frow * 128 + (((2 * g + fhalf) ^ (frow & 7)) << 4);
+  const uint32_t pr0 = patch + (lane >> 2) * 128 + (((2 * (lane & 3)) ^ ((lane >> 2) & 7)) << 4);
+  const uint32_t pr1 = patch + (lane >> 2) * 128 + (((2 * (lane & 3) + 1) ^ ((lane >> 2) & 7)) << 4);
+
+  // LDS-DMA: wave w owns pieces 8 m + w of a slab (m = 0 .. PPW - 1: its slot m), 8 LDS rows of 128 bytes each; per-lane source
+  // offsets inside the tile's (Y | X) panel, the chunk swizzle on the source side
+  uint32_t voff[PPW];
+#pragma unroll
+  for (int m = 0; m < PPW; ++m) {
+    const int r = (8 * m + wave) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    bool isy;
+    const int gr = S::src_row(r, isy);
+    voff[m] = (uint32_t)((size_t)gr * (isy ? ldy_b : ldx_b) + (size_t)c * 16);
+  }
+
+  // ---- the staging stream: a cursor over (tile, slab, slot) in issue order ----------------------------------------------------
+  int c_tile = first, c_kt = 0;
+  uint32_t c_buf = 0;  // byte offset of the cursor's slab buffer
+  bool c_live = true;  // (grid <= ntiles: every workgroup has a first tile)
+  const char *c_gy, *c_gx;
+  auto tile_base = [&](int t, const char*& gy, const char*& gx) {
+    const int ty = t / ntx, tx = t - ty * ntx;
+    gy = gy0 + (size_t)ty * BM * ldy_b;
+    gx = gx0 + (size_t)tx * BN * ldx_b;
+  };
+  tile_base(c_tile, c_gy, c_gx);
+  auto stage_slot = [&](auto M) {  // the cursor's slab, this wave's slot M
+    constexpr int m = decltype(M)::value;
+    const char* sb = S::is_y(m) ? c_gy : c_gx;
+    const uint32_t dst = lds0 + c_buf + (uint32_t)((8 * m + wave) * 1024);
+    const uint32_t vo = voff[m];  // (named outside the asm statement: an asm operand alone does not capture in a generic lambda)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(sb), "s"(dst) : "memory");
+  };
+  auto advance = [&]() {
+    c_buf = STAGE - c_buf;
+    c_gy += SLAB;
+    c_gx += SLAB;
+    if (++c_kt == nk) {
+      c_kt = 0;
+      c_tile += G8;
+      c_live = c_tile < ntiles;
+      if (c_live) tile_base(c_tile, c_gy, c_gx);
+    }
+  };
+  // stream positions [P0, P0 + N): slot = position % PPW, the cursor moves on behind a slab's last slot
+  auto stage_run = [&](auto P0, auto N) {
+    static_for<decltype(N)::value>([&](auto I) {
+      constexpr int m = (decltype(P0)::value + decltype(I)::value) % PPW;
+      if (c_live) stage_slot(std::integral_constant<int, m>{});
+      if constexpr (m == PPW - 1) {
+        if (c_live) advance();
+      }
+    });
+  };
+
+  // prologue: AHEAD pieces, all landed, everywhere
+  stage_run(std::integral_constant<int, 0>{}, std::integral_constant<int, S::AHEAD>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  uint32_t r_buf = 0;  // the consumer's slab buffer
+  float q_amax = 0.f;  // (fp8 training only: unused by 2-byte operands)
+  for (int t_cur = first; t_cur < ntiles; t_cur += G8) {
+    const int ty = t_cur / ntx, tx = t_cur - ty * ntx;
+    f32x16 acc[RY][RX];
+#pragma unroll
+    for (int i = 0; i < RY; ++i)
+#pragma unroll
+      for (int j = 0; j < RX; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    u32x4 fy[2][4], fx[2][4];  // fragments: two Y blocks x 4 sub-steps; X block(s) x 4 sub-steps (GEO 1 uses fx[0] only)
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger
+
+    for (int k = 0; k < nk; ++k) {
+      const bool counted = k > 0;  // slab 0's pieces were waited for before the previous epilogue (or by the prologue)
+      const bool last = k == nk - 1;
+      static_for<NPH>([&](auto PH) {
+        constexpr int P = decltype(PH)::value;
+        // ---- reads of this phase's cluster
+        if constexpr (GEO == 0) {
+          if constexpr (P == 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              fy[0][s] = ds_read16<S::Y_OFF[0]>(ya[s] + r_buf);
+              fy[1][s] = ds_read16<S::Y_OFF[1]>(ya[s] + r_buf);
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fx[0][s] = ds_read16<S::X_OFF[0]>(xa[s] + r_buf);
+          } else if constexpr (P == 1) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fx[1][s] = ds_read16<S::X_OFF[1]>(xa[s] + r_buf);
+          } else if constexpr (P == 2) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              fy[0][s] = ds_read16<S::Y_OFF[2]>(ya[s] + r_buf);
+              fy[1][s] = ds_read16<S::Y_OFF[3]>(ya[s] + r_buf);
+            }
+          }
+        } else {
+          if constexpr (P == 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              fy[0][s] = ds_read16<S::Y_OFF[0]>(ya[s] + r_buf);
+              fy[1][s] = ds_read16<S::Y_OFF[1]>(ya[s] + r_buf);
+            }
+          }
+#pragma unroll
+          for (int s = 0; s < 4; ++s) fx[0][s] = ds_read16<S::X_OFF[P]>(xa[s] + r_buf);
+        }
+        // ---- this phase's share of the stream, and the counted wait for what the NEXT phase reads
+        stage_run(std::integral_constant<int, S::AHEAD + ph_issued_before<S>(P)>{}, std::integral_constant<int, S::cnt[P]>{});
+        constexpr int W = ph_wait<S>(P);
+        if constexpr (W >= 0) {
+          if (!c_live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stream has ended: nothing younger to count on
+          else if (counted) wait_vmcnt<W>();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        OSUD_LGKM_WAIT(0);
+        // ---- the cluster
+        if (OSUD_PHASED_SETPRIO) __builtin_amdgcn_s_setprio(1);
+        if constexpr (GEO == 0) {
+          constexpr int jb = (P == 0 || P == 3) ? 0 : 1, ib = P < 2 ? 0 : 2;
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            mma<TE>(acc[ib][jb], fx[jb][s], fy[0][s]);
+            mma<TE>(acc[ib + 1][jb], fx[jb][s], fy[1][s]);
+          }
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) {
+            mma<TE>(acc[0][P], fx[0][s], fy[0][s]);
+            mma<TE>(acc[1][P], fx[0][s], fy[1][s]);
+          }
+        }
+        if (OSUD_PHASED_SETPRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (P != NPH - 1 || !last || grp == 0) __builtin_amdgcn_s_barrier();
+      });
+      r_buf = STAGE - r_buf;
+    }
+    // everything in flight is the next tile's first slab and a half: landed before the epilogue's stores queue behind it
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tile_epilogue<TE, EPI, WY, WX, RY, RX>(p, acc, ty, tx, wy, wx, lane, pw, pr0, pr1, 0u, q_amax);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();  // group 0 pays the stagger back; both groups: the next tile's first slab has landed everywhere
+  }
+}
+
+template <typename TE, int EPI, int GEO> int launch_phased(const GemmP& p_in, hipStream_t st) {
+  using S = PhSched<GEO>;
+  GemmP p = p_in;
+  constexpr int STAGE = (256 + S::BN) * SLAB;
+  const size_t lds = 2 * (size_t)STAGE + 8 * 4096;
+  static bool attr_set = false;
+  if (!attr_set) {
+    OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_phased_kernel<TE, EPI, GEO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds));
+    attr_set = true;
+  }
+  if (p.colpart_rows != nullptr) *p.colpart_rows = p.My / (S::RY * 32);
+  const int ntiles = (p.My / 256) * (p.Nx / S::BN);
+  int grid = gemm_num_cus();
+  if (grid > ntiles) grid = ntiles;
+  p.sched = nullptr;
+  hipLaunchKernelGGL((gemm_phased_kernel<TE, EPI, GEO>), dim3(grid), dim3(512), lds, st, p);
+  OSUD_HIP(hipGetLastError());
+  return OSUD_OK;
+}
+
+// launch_t's hook (pick: its geometry choice; 2 = 256 x 256, 1 = 256 x 192): takes the launch where the phased loop is built for it
+template <typename TE, int EPI> int launch_phased_or(const GemmP& p, int pick, hipStream_t st, bool& taken) {
+  taken = false;
+  if constexpr (sizeof(TE) == 2 && Planes<TE>::k == 1) {
+    if (opt(OPT_GEMM_LOOP) != 0 && (pick == 1 || pick == 2) && p.split_k <= 1 && !gemm_dynamic_tiles_wanted() &&
+        (size_t)p.K * sizeof(TE) / SLAB >= 2) {
+      taken = true;
+      return pick == 2 ? launch_phased<TE, EPI, 0>(p, st) : launch_phased<TE, EPI, 1>(p, st);
+    }
+  }
+  return OSUD_OK;
+}
+
+}  // namespace
+}  // namespace osud
