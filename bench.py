@@ -73,11 +73,16 @@ def parse():
     return ap.parse_args()
 
 
+WATCHDOG_EXIT = 3  # exit code of every rank when the watchdog fires (distinct from Python's 1 and from a signal's 128 + n)
+
+
 class Watchdog:
     """N > 1 only.  Everything after the timed region of a multi-GPU run is collective (the exchange-schedule legs, sharded sampling, the
     DiT-XL line) and none of it has run on more than one GPU before the first such run: a collective that never returns on some node
     must not take the timed result with it.  Armed once the line's contract fields exist; if `main` has not disarmed it by the deadline,
-    rank 0 prints the line as it stands -- plus `diagnostics_incomplete` naming the stage -- and every rank leaves with os._exit(0)."""
+    rank 0 prints the line as it stands -- plus `diagnostics_incomplete` naming the stage -- and every rank leaves with
+    os._exit(WATCHDOG_EXIT): a hung collective is a FAILED run to torchrun, the driver and CI (the partial line is there to be read,
+    not to be mistaken for a complete one)."""
 
     def __init__(self):
         self.lock = threading.Lock()
@@ -107,7 +112,7 @@ class Watchdog:
                 print(json.dumps(out, default=str), flush=True)
             else:
                 time.sleep(2.0)  # (rank 0's line first)
-            os._exit(0)
+            os._exit(WATCHDOG_EXIT)
 
 
 WATCHDOG = Watchdog()

@@ -86,8 +86,9 @@ struct GraphKey {
   const void* sched;
   const void *keep = nullptr, *known = nullptr;
   int embed_const = 0;  // the captured step used the split-off constant part of the first linear
+  unsigned opt_epoch = 0;  // the process-wide option table (gemm.h: opt_epoch) picks kernels inside the captured step: a change re-captures
   bool operator==(const GraphKey& r) const {
-    return embed_const == r.embed_const && N == r.N && T == r.T && mode == r.mode && clip == r.clip && has_mask == r.has_mask &&
+    return embed_const == r.embed_const && opt_epoch == r.opt_epoch && N == r.N && T == r.T && mode == r.mode && clip == r.clip && has_mask == r.has_mask &&
            has_noise == r.has_noise && cfg == r.cfg && eta == r.eta && o == r.o && c == r.c && y == r.y &&
            mask == r.mask && x == r.x && noise == r.noise && sched == r.sched && keep == r.keep && known == r.known;
   }

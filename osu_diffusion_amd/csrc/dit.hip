@@ -619,6 +619,9 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
 
 extern "C" int osud_dit_reserve(osud_dit* m, int max_N, int max_T, int training) {
   OSUD_CHECK_ARG(m && max_N > 0 && max_T > 0, "reserve: bad argument");
+  // the final layer's backward writes its weight / bias gradient through a fixed-order column pass built for 4 output channels
+  // (learn_sigma = True: what every script of the reference trains, models.py:243-254); learn_sigma = False runs forward / sampling only
+  OSUD_CHECK_ARG(!training || m->C2 == 4, "reserve: the backward pass is built for learn_sigma=True (4 output channels), this handle has %d", m->C2);
   return dit_ensure_ws(m, max_N, max_T, training != 0);
 }
 
@@ -733,7 +736,7 @@ static int sample_steps(osud_dit* m, const osud_sched* s, int mode, float eta, f
     return OSUD_OK;
   }
   GraphKey key{N, T, mode, clip, attn_mask != nullptr, noise != nullptr, cfg_scale, eta, o, c, y, attn_mask, x, noise, s,
-               held.keep, held.known, (m->embed_const_on ? 1 : 0) | (m->tvec_table_on ? 2 : 0)};
+               held.keep, held.known, (m->embed_const_on ? 1 : 0) | (m->tvec_table_on ? 2 : 0), opt_epoch()};
   if (!(m->graph_valid && m->graph_key == key)) {
     if (m->graph_exec) {
       (void)hipGraphExecDestroy(m->graph_exec);

@@ -67,8 +67,7 @@ struct GemmP {
   int seg_rows;           // EPI_NONE_F32, optional (> 0): output row y goes to seg_out[y / seg_rows] + (y % seg_rows) * ldo instead of `out`
   float* const* seg_out;  //   (DEVICE table) -- one product whose row panels land in different tensors: the adaLN weight gradients of all blocks
   unsigned* sched;    // set by the launcher for multi-round launches: {ticket, done} counters of the dynamic tile queue
-  int exp_delay;   // experiments only (-DOSUD_GEMM_EXP): odd workgroup groups start this many 100 MHz ticks late
-  int tile_order;  // experiments only (-DOSUD_GEMM_EXP / -DOSUD_GEMM_TIMING builds): flag bits of the timing variants
+  int tile_order;  // 2: banded tile order (TileMap); experiments only otherwise (-DOSUD_GEMM_TIMING builds: flag bits of the timing variants)
 };
 
 int launch_gemm(int prec, int epi, const GemmP& p, hipStream_t st);
@@ -94,6 +93,7 @@ enum Opt {
   OPT_COUNT
 };
 int opt(Opt o);
+unsigned opt_epoch();  // bumped by every successful opt_set: whatever caches a kernel choice (a captured sampler step) keys on it
 int opt_set(const char* name, int value);   // OSUD_OK / OSUD_ERR_ARG (unknown name or value out of range)
 int opt_get(const char* name, int* value);
 // one 16-word counter set {[0] tickets, [8] finished workgroups} of the same pool, for other persistent kernels that draw their

@@ -77,9 +77,10 @@ struct OptDef {
 constexpr OptDef kOpts[OPT_COUNT] = {
     {"wgrad_side_stream", 1, 0, 1}, {"sample_graph", 1, 0, 1},    {"embed_const", 1, 0, 1},  {"tvec_table", 1, 0, 1},
     {"split_first", 1, 0, 1},       {"attn_fwd_kernel", 0, 0, 2}, {"attn_bwd_kernel", 0, 0, 2}, {"gemm_tile", 0, 0, 1256},
-    {"f8_twins_only", 1, 0, 1},     {"debug_sync", 0, 0, 1},      {"f16m8_forms", 11, 0, 15},    {"gemm_loop", 0, 0, 1},
+    {"f8_twins_only", 1, 0, 1},     {"debug_sync", 0, 0, 1},      {"f16m8_forms", 11, 0, 15},    {"gemm_loop", 1, 0, 1},
 };
 std::atomic<int> g_opt[OPT_COUNT];
+std::atomic<unsigned> g_opt_epoch{0};
 // The defaults, overridden ONCE by the environment variable OSUD_OPTIONS="name=value,name=value" (for command-line A/B runs of an
 // unmodified script; tests and hosts call osud_set_option).  Unknown names there are an error on stderr, not silently ignored.
 void opt_init() {
@@ -99,13 +100,15 @@ void opt_init() {
       if (eq != std::string::npos)
         for (int i = 0; i < OPT_COUNT; ++i)
           if (item.substr(0, eq) == kOpts[i].name) {
-            const int v = atoi(item.c_str() + eq + 1);
-            if (v >= kOpts[i].lo && v <= kOpts[i].hi) {
-              g_opt[i].store(v, std::memory_order_relaxed);
+            const char* vs = item.c_str() + eq + 1;
+            char* endp = nullptr;
+            const long v = strtol(vs, &endp, 10);  // ("sample_graph=off" or "gemm_tile=" must not become a silent 0)
+            if (endp != vs && *endp == '\0' && v >= kOpts[i].lo && v <= kOpts[i].hi) {
+              g_opt[i].store((int)v, std::memory_order_relaxed);
               ok = true;
             }
           }
-      if (!ok && !item.empty()) fprintf(stderr, "[osud] OSUD_OPTIONS: ignoring '%s' (unknown option or value out of range)\n", item.c_str());
+      if (!ok && !item.empty()) fprintf(stderr, "[osud] OSUD_OPTIONS: ignoring '%s' (unknown option, or a value that is not a number in range)\n", item.c_str());
       pos = end + 1;
     }
   });
@@ -116,6 +119,7 @@ int opt(Opt o) {
   opt_init();
   return g_opt[o].load(std::memory_order_relaxed);
 }
+unsigned opt_epoch() { return g_opt_epoch.load(std::memory_order_relaxed); }
 int opt_set(const char* name, int value) {
   opt_init();
   OSUD_CHECK_ARG(name != nullptr, "set_option: null name");
@@ -124,6 +128,7 @@ int opt_set(const char* name, int value) {
       OSUD_CHECK_ARG(value == -1 || (value >= kOpts[i].lo && value <= kOpts[i].hi), "set_option: %s takes %d..%d (or -1 = default), got %d", name,
                      kOpts[i].lo, kOpts[i].hi, value);
       g_opt[i].store(value == -1 ? kOpts[i].def : value, std::memory_order_relaxed);
+      g_opt_epoch.fetch_add(1, std::memory_order_relaxed);
       return OSUD_OK;
     }
   set_error("set_option: unknown option '%s'", name);

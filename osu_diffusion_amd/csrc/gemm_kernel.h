@@ -764,14 +764,12 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
   uint64_t tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const uint64_t tk0 = __builtin_readcyclecounter();
 #endif
-#ifdef OSUD_GEMM_EXP
-  if (p.exp_delay > 0 && ((blockIdx.x >> 3) & 1)) {  // experiment: every other workgroup of each XCD starts late (de-phased epilogues)
-    const uint64_t t0 = wall_clock64();
-    while (wall_clock64() - t0 < (uint64_t)p.exp_delay) __builtin_amdgcn_s_sleep(8);
-  }
-#endif
   float q_amax = 0.f;  // fp8 training: running max |value| of this lane's share of the e4m3 output
   bool first_tile = true;
+#ifdef OSUD_PH_TIMING   // (tuning builds, tools/gemm_phase_stamps.py: the whole kernel's shader-clock cycles next to the phased loop's)
+  uint64_t ph_t0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_t0));
+#endif
   while (t_cur < ntiles) {
     int ty, tx;
     tm.coords(t_cur, ty, tx);
@@ -901,6 +899,15 @@ __global__ __launch_bounds__((Geo<WY, WX, RY, RX>::NT)) void gemm_kernel(GemmP p
       for (int y = 0; y < 9; ++y) __hip_atomic_store(p.sched + y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+#ifdef OSUD_PH_TIMING
+  if (EPI != EPI_GATE_RES && p.gate != nullptr && lane == 0 && blockIdx.x < 32) {
+    uint64_t ph_t1;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_t1));
+    float* dbg = const_cast<float*>(p.gate) + (blockIdx.x * 8 + wave) * 8;
+    dbg[6] = (float)(ph_t1 - ph_t0);
+    dbg[4] = 0.f;
+  }
+#endif
 #ifdef OSUD_GEMM_TIMING
   if (p.gate != nullptr && lane == 0 && blockIdx.x < 16) {
     float* dbg = const_cast<float*>(p.gate) + (blockIdx.x * G::NW + wave) * 8;

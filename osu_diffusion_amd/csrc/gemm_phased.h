@@ -27,8 +27,11 @@
 // group 1 enters a tile with one extra barrier, group 0 pays it back after its epilogue; the epilogues of both groups run side
 // by side (patches live behind the ring: no barrier inside).
 #pragma once
-#include <utility>
 // (included at the end of gemm_kernel.h)
+#include "phased.h"
+#ifndef OSUD_PH_TABLE
+#define OSUD_PH_TABLE 0
+#endif
 
 namespace osud {
 namespace {
@@ -37,8 +40,17 @@ template <int GEO> struct PhSched;
 // 256 x 256: 2 x 4 waves of 128 x 64 (4 x 2 accumulator blocks).  Phases: (Ya, X0) (Ya, X1) (Yb, X1) (Yb, X0), Ya / Yb = Y blocks
 // 0, 1 / 2, 3; the Yb fragments overwrite Ya's registers.  LDS rows of a slab, in need order: Ya | X0 | X1 | Yb, 128 rows each.
 template <> struct PhSched<0> {
-  static constexpr int WY = 2, WX = 4, RY = 4, RX = 2, BN = 256, NPH = 4, PPW = 8, AHEAD = 12;
+  static constexpr int WY = 2, WX = 4, RY = 4, RX = 2, BN = 256, NPH = 4, PPW = 8;
+#if OSUD_PH_TABLE == 1   // (tuning builds) nothing issued beside the 12 reads of phase 0, four pieces in the read-free phase 3
+  static constexpr int AHEAD = 14;
+  static constexpr int cnt[NPH] = {0, 2, 2, 4};
+#elif OSUD_PH_TABLE == 2
+  static constexpr int AHEAD = 13;
+  static constexpr int cnt[NPH] = {1, 2, 2, 3};
+#else
+  static constexpr int AHEAD = 12;
   static constexpr int cnt[NPH] = {2, 2, 2, 2};      // pieces per wave issued in phase p
+#endif
   static constexpr int need[NPH] = {3, 5, 7, -1};    // highest piece slot the reads of phase p touch (-1: no reads)
   static constexpr int read_phase[PPW] = {0, 0, 0, 0, 1, 1, 2, 2};
   static constexpr bool is_y(int m) { return m < 2 || m >= 6; }
@@ -58,8 +70,14 @@ template <> struct PhSched<0> {
 // 256 x 192: 4 x 2 waves of 64 x 96 (2 x 3 blocks).  Phases: (Y, X0) (Y, X1) (Y, X2).  LDS rows: Y (256) | X0 | X1 | X2 (64 each:
 // block j of wave column 0, then of wave column 1).
 template <> struct PhSched<1> {
-  static constexpr int WY = 4, WX = 2, RY = 2, RX = 3, BN = 192, NPH = 3, PPW = 7, AHEAD = 12;
+  static constexpr int WY = 4, WX = 2, RY = 2, RX = 3, BN = 192, NPH = 3, PPW = 7;
+#if OSUD_PH_TABLE == 1
+  static constexpr int AHEAD = 11;
+  static constexpr int cnt[NPH] = {2, 1, 4};
+#else
+  static constexpr int AHEAD = 12;
   static constexpr int cnt[NPH] = {1, 1, 5};
+#endif
   static constexpr int need[NPH] = {4, 5, 6};
   static constexpr int read_phase[PPW] = {0, 0, 0, 0, 0, 1, 2};
   static constexpr bool is_y(int m) { return m < 4; }
@@ -75,43 +93,13 @@ template <> struct PhSched<1> {
   }
 };
 
-template <typename S> constexpr int ph_issued_before(int p) {  // pieces per wave issued since the slab's phase 0, before phase p
-  int n = 0;
-  for (int q = 0; q < p; ++q) n += S::cnt[q];
-  return n;
-}
-// the counted wait of phase p: how many of this wave's pieces may still be in flight when phase p + 1's reads must have landed
-template <typename S> constexpr int ph_wait(int p) {
-  const int nxt = (p + 1) % S::NPH;
-  if (S::need[nxt] < 0) return -1;
-  const int needpos = (p + 1 == S::NPH ? S::PPW : 0) + S::need[nxt];
-  return S::AHEAD + ph_issued_before<S>(p + 1) - (needpos + 1);
-}
-template <typename S> constexpr bool sched_ok() {
-  int total = 0;
-  for (int p = 0; p < S::NPH; ++p) total += S::cnt[p];
-  if (total != S::PPW) return false;  // the stream advances one slab per slab
-  for (int p = 0; p < S::NPH; ++p) {
-    if (S::need[(p + 1) % S::NPH] >= 0 && ph_wait<S>(p) < 0) return false;  // RAW: the needed piece must have been ISSUED by then
-    for (int i = 0; i < S::cnt[p]; ++i) {
-      const int pos = S::AHEAD + ph_issued_before<S>(p) + i, d = pos / S::PPW, m = pos % S::PPW;
-      if (d < 1 || d > 2) return false;                        // two buffers: the slab after this one, or the one after that
-      if (d == 2 && p < S::read_phase[m] + 2) return false;    // WAR: same buffer as the slab being consumed
-      if (d == 1 && p + S::NPH < S::read_phase[m] + 2) return false;
-    }
-  }
-  return true;
-}
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); }
-
-template <class F, int... I> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-  (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-
 #ifndef OSUD_PHASED_SETPRIO
 #define OSUD_PHASED_SETPRIO 1
+#endif
+// timing experiments (one build per variant, results meaningless): 1 no LDS-DMA after the prologue, 2 no counted waits, 8 the pieces
+// before the fragment reads, 16 no fragment reads (MFMAs on whatever the registers hold), 32 no MFMAs
+#ifndef OSUD_PH_EXP
+#define OSUD_PH_EXP 0
 #endif
 
 template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void gemm_phased_kernel(GemmP p) {
@@ -214,6 +202,20 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+#ifdef OSUD_PH_TIMING
+  // cycle stamps (shader clock, s_memtime) of this wave: [0] read + DMA issue + counted wait, [1] first barrier, [2] lgkmcnt + cluster issue,
+  // [3] second barrier, [4] phases, [5] epilogue (with its drain), [6] whole kernel.  A stamp is an SMEM load: it is consumed only behind
+  // the phase's own lgkmcnt(0), so the stamps add no wait of their own.  Written to p.gate (floats) for the first 32 workgroups.
+  uint64_t tsum[7] = {0, 0, 0, 0, 0, 0, 0};
+  uint64_t ts_k0, ts_d = 0, ts_e = 0, ts_c0 = 0;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_k0));
+#endif
+#if defined(OSUD_PH_TIMING) && OSUD_PH_TIMING >= 2   // (level 1: kernel and epilogue totals only -- the main loop runs unperturbed)
+#define OSUD_PH_STAMP(x) asm volatile("s_memtime %0" : "=s"(x))
+#define OSUD_PH_SEGMENTS 1
+#else
+#define OSUD_PH_STAMP(x)
+#endif
   uint32_t r_buf = 0;  // the consumer's slab buffer
   float q_amax = 0.f;  // (fp8 training only: unused by 2-byte operands)
   for (int t_cur = first; t_cur < ntiles; t_cur += G8) {
@@ -226,6 +228,10 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     u32x4 fy[2][4], fx[2][4];  // fragments: two Y blocks x 4 sub-steps; X block(s) x 4 sub-steps (GEO 1 uses fx[0] only)
+    if constexpr ((OSUD_PH_EXP & 16) != 0) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) asm volatile("" : "=v"(fy[0][s]), "=v"(fy[1][s]), "=v"(fx[0][s]), "=v"(fx[1][s]));
+    }
     if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger
 
     for (int k = 0; k < nk; ++k) {
@@ -233,7 +239,13 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
       const bool last = k == nk - 1;
       static_for<NPH>([&](auto PH) {
         constexpr int P = decltype(PH)::value;
-        // ---- reads of this phase's cluster
+#ifdef OSUD_PH_SEGMENTS
+        uint64_t ts_a, ts_b, ts_c;
+        OSUD_PH_STAMP(ts_a);
+#endif
+        // ---- reads of this phase's cluster, this phase's share of the stream, and the counted wait for what the NEXT phase reads
+        auto reads = [&]() {
+          if constexpr ((OSUD_PH_EXP & 16) != 0) return;
         if constexpr (GEO == 0) {
           if constexpr (P == 0) {
 #pragma unroll
@@ -264,19 +276,30 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
 #pragma unroll
           for (int s = 0; s < 4; ++s) fx[0][s] = ds_read16<S::X_OFF[P]>(xa[s] + r_buf);
         }
-        // ---- this phase's share of the stream, and the counted wait for what the NEXT phase reads
-        stage_run(std::integral_constant<int, S::AHEAD + ph_issued_before<S>(P)>{}, std::integral_constant<int, S::cnt[P]>{});
+        };
+        if constexpr ((OSUD_PH_EXP & 8) == 0) reads();
+        if constexpr ((OSUD_PH_EXP & 1) == 0) stage_run(std::integral_constant<int, S::AHEAD + ph_issued_before<S>(P)>{}, std::integral_constant<int, S::cnt[P]>{});
+        if constexpr ((OSUD_PH_EXP & 8) != 0) reads();
         constexpr int W = ph_wait<S>(P);
         if constexpr (W >= 0) {
           if (!c_live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stream has ended: nothing younger to count on
-          else if (counted) wait_vmcnt<W>();
+          else if (counted && (OSUD_PH_EXP & 2) == 0) wait_vmcnt<W>();
         }
         __builtin_amdgcn_sched_barrier(0);
+        OSUD_PH_STAMP(ts_b);
         __builtin_amdgcn_s_barrier();
+        OSUD_PH_STAMP(ts_c);
         OSUD_LGKM_WAIT(0);
+#ifdef OSUD_PH_SEGMENTS
+        tsum[0] += ts_b - ts_a; tsum[1] += ts_c - ts_b;
+        if (ts_d != 0) { tsum[2] += ts_d - ts_c0; tsum[3] += ts_e - ts_d; }
+        ts_c0 = ts_c;
+        __builtin_amdgcn_sched_barrier(0);
+#endif
         // ---- the cluster
         if (OSUD_PHASED_SETPRIO) __builtin_amdgcn_s_setprio(1);
-        if constexpr (GEO == 0) {
+        if constexpr ((OSUD_PH_EXP & 32) != 0) {
+        } else if constexpr (GEO == 0) {
           constexpr int jb = (P == 0 || P == 3) ? 0 : 1, ib = P < 2 ? 0 : 2;
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
@@ -292,16 +315,41 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
         }
         if (OSUD_PHASED_SETPRIO) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
+        OSUD_PH_STAMP(ts_d);
         if (P != NPH - 1 || !last || grp == 0) __builtin_amdgcn_s_barrier();
+        OSUD_PH_STAMP(ts_e);
       });
       r_buf = STAGE - r_buf;
     }
     // everything in flight is the next tile's first slab and a half: landed before the epilogue's stores queue behind it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef OSUD_PH_TIMING
+    uint64_t ts_f, ts_g;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_f));
+    tsum[4] += (uint64_t)(NPH * nk);
+#ifdef OSUD_PH_SEGMENTS
+    tsum[2] += ts_d - ts_c0; tsum[3] += ts_e - ts_d; ts_d = 0;
+#endif
+#endif
     tile_epilogue<TE, EPI, WY, WX, RY, RX>(p, acc, ty, tx, wy, wx, lane, pw, pr0, pr1, 0u, q_amax);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef OSUD_PH_TIMING
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_g));
+    tsum[5] += ts_g - ts_f;
+#endif
     __builtin_amdgcn_s_barrier();  // group 0 pays the stagger back; both groups: the next tile's first slab has landed everywhere
   }
+#ifdef OSUD_PH_TIMING
+  {
+    uint64_t ts_end;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_end));
+    tsum[6] = ts_end - ts_k0;
+    if (EPI != EPI_GATE_RES && p.gate != nullptr && lane == 0 && blockIdx.x < 32) {
+      float* dbg = const_cast<float*>(p.gate) + (blockIdx.x * 8 + wave) * 8;
+      for (int i = 0; i < 7; ++i) dbg[i] = (float)tsum[i];
+    }
+  }
+#endif
 }
 
 template <typename TE, int EPI, int GEO> int launch_phased(const GemmP& p_in, hipStream_t st) {

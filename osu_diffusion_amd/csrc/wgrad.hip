@@ -18,6 +18,7 @@
 
 #include "gemm.h"
 #include "kernels.h"
+#include "phased.h"
 
 namespace osud {
 
@@ -353,6 +354,188 @@ __global__ __launch_bounds__((WGeo<WY, WX, RY, RX>::NT)) void wgrad_kernel(Wgrad
       ++consumed;
     }
     store_tile(ty, tx);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// The 256 x 256 geometry in the phased schedule (gemm_phased.h has the design; phased.h the table rules): the same staging, the
+// same transposing reads and MFMAs, every accumulator sees its tokens in the same order -- bit-identical partial slabs -- but
+// the two waves of a SIMD run one barrier apart.  The cut is natural here: phase p of a stage is k sub-step p, i.e. tokens
+// 16 p .. 16 p + 15 of BOTH operands (12 transposing reads, 8 MFMAs over all eight accumulators), and the LDS image is token-major
+// already, so a phase needs exactly one quarter of the stage (16 KiB = two pieces per wave: slot 2 p the P rows, slot 2 p + 1 the
+// Q rows) and the stream is in need order as it stands.  vmcnt(10) per phase in steady state: five quarters in flight.
+struct WgSched {
+  static constexpr int NPH = 4, PPW = 8, AHEAD = 12;
+  static constexpr int cnt[NPH] = {2, 2, 2, 2};
+  static constexpr int need[NPH] = {1, 3, 5, 7};
+  static constexpr int read_phase[PPW] = {0, 0, 1, 1, 2, 2, 3, 3};
+};
+
+__global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
+  using G = WGeo<2, 4, 4, 2>;
+  using S = WgSched;
+  static_assert(sched_ok<S>(), "phase table breaks a staging rule");
+  constexpr int WX = 4, RY = 4, RX = 2, NPH = S::NPH, PPW = S::PPW, STAGE = G::STAGE, RING = 2 * STAGE;
+  static_assert(G::NSTAGE == 2 && G::PPW == PPW && G::ROWY == 512 && G::ROWX == 512, "geometry");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wy = wave / WX, wx = wave % WX, grp = wave >> 2;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int ntx = (p.Nx + G::BN - 1) / G::BN, ntiles = ((p.Ny + G::BM - 1) / G::BM) * ntx;
+  const int st_total = p.M / BKT;
+  int sidx = blockIdx.y, bx = blockIdx.x;
+  if (p.xcd_units) {  // (tile, split) units in split-major order, one contiguous run per XCD: see WgradP::xcd_units
+    const int total = gridDim.x * gridDim.y, L = blockIdx.x + blockIdx.y * gridDim.x;
+    const int q = total >> 3, r = total & 7, xcd = L & 7, idx = L >> 3;
+    const int u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    sidx = u / (int)gridDim.x;
+    bx = u - sidx * (int)gridDim.x;
+  }
+  const int st_begin = (int)((long)sidx * st_total / p.split_k);
+  const int nst = (int)((long)(sidx + 1) * st_total / p.split_k) - st_begin;
+  const size_t ldp_b = (size_t)p.ldp * 2, ldq_b = (size_t)p.ldq * 2;
+  const char* const gp0 = reinterpret_cast<const char*>(p.P) + (size_t)st_begin * BKT * ldp_b;
+  const char* const gq0 = reinterpret_cast<const char*>(p.Q) + (size_t)st_begin * BKT * ldq_b;
+  float* const outp = p.out + (size_t)sidx * p.split_stride;
+  const int G8 = gridDim.x;
+  int first;
+  {
+    const int b = blockIdx.x, q = G8 >> 3, r = G8 & 7, xcd = b & 7, idx = b >> 3;
+    first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if (p.xcd_units) first = bx;
+  }
+
+  // fragment addresses (stage 0, sub-step 0), exactly wgrad_kernel's
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_void*)smem;
+  const int tok0 = 8 * fhalf + ((lane & 15) >> 2);
+  const int swz = tok0 & 3;
+  const int fbyte = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+  uint32_t ya[RY], xa[RX];
+#pragma unroll
+  for (int i = 0; i < RY; ++i) ya[i] = lds0 + tok0 * G::ROWY + (((wy * RY + i) ^ swz) * 64) + fbyte;
+#pragma unroll
+  for (int j = 0; j < RX; ++j) xa[j] = lds0 + G::YB + tok0 * G::ROWX + (((wx * RX + j) ^ swz) * 64) + fbyte;
+  // LDS-DMA: slot m = 2 q + h of wave w is piece 8 q + w of the P part (h = 0) or of the Q part (h = 1): token rows 16 q + 2 w, + 1
+  uint32_t voff[PPW];
+#pragma unroll
+  for (int m = 0; m < PPW; ++m) {
+    const bool isY = (m & 1) == 0;
+    const int pb = (8 * (m >> 1) + wave) * 1024;   // byte offset inside the part
+    const int cidx = pb / 16 + lane;                // this lane's 16-byte chunk inside the part (32 chunks per token row)
+    const int tok = cidx >> 5, pos = cidx & 31;
+    const int c = pos ^ ((tok & 3) << 2);
+    voff[m] = (uint32_t)((size_t)tok * (isY ? ldp_b : ldq_b) + (size_t)c * 16);
+  }
+  const uint32_t patch = lds0 + RING + wave * 4096;
+  uint32_t pw[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) pw[g] = patch + frow * 128 + (((2 * g + fhalf) ^ (frow & 7)) << 4);
+  const uint32_t pr = patch + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+
+  // ---- the staging stream
+  int c_tile = first, c_st = 0;
+  uint32_t c_buf = 0;
+  bool c_live = c_tile < ntiles && nst > 0;
+  const char *c_gp, *c_gq;
+  auto tile_base = [&](int t, const char*& gp, const char*& gq) {
+    const int ty = t / ntx, tx = t - ty * ntx;
+    gp = gp0 + (size_t)ty * G::BM * 2;
+    gq = gq0 + (size_t)tx * G::BN * 2;
+  };
+  tile_base(c_tile, c_gp, c_gq);
+  auto stage_slot = [&](auto M) {
+    constexpr int m = decltype(M)::value;
+    const char* sb = (m & 1) == 0 ? c_gp : c_gq;
+    const uint32_t dst = lds0 + c_buf + (uint32_t)(((m & 1) ? G::YB : 0) + (8 * (m >> 1) + wave) * 1024);
+    const uint32_t vo = voff[m];
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(sb), "s"(dst) : "memory");
+  };
+  auto advance = [&]() {
+    c_buf = STAGE - c_buf;
+    c_gp += (size_t)BKT * ldp_b;
+    c_gq += (size_t)BKT * ldq_b;
+    if (++c_st == nst) {
+      c_st = 0;
+      c_tile += G8;
+      c_live = c_tile < ntiles;
+      if (c_live) tile_base(c_tile, c_gp, c_gq);
+    }
+  };
+  auto stage_run = [&](auto P0, auto N) {
+    static_for<decltype(N)::value>([&](auto I) {
+      constexpr int m = (decltype(P0)::value + decltype(I)::value) % PPW;
+      if (c_live) stage_slot(std::integral_constant<int, m>{});
+      if constexpr (m == PPW - 1) {
+        if (c_live) advance();
+      }
+    });
+  };
+  stage_run(std::integral_constant<int, 0>{}, std::integral_constant<int, S::AHEAD>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  uint32_t r_buf = 0;
+  for (int tile = first; tile < ntiles; tile += G8) {
+    const int ty = tile / ntx, tx = tile - ty * ntx;
+    f32x16 acc[RY][RX];
+#pragma unroll
+    for (int i = 0; i < RY; ++i)
+#pragma unroll
+      for (int j = 0; j < RX; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    TFrag<RY, RX> f;
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger
+    for (int st = 0; st < nst; ++st) {
+      const bool counted = st > 0, last = st == nst - 1;
+      static_for<NPH>([&](auto PH) {
+        constexpr int P = decltype(PH)::value;
+        read_frags<RY, RX, P, G::ROWY, G::ROWX>(f, ya, xa, r_buf);
+        stage_run(std::integral_constant<int, S::AHEAD + ph_issued_before<S>(P)>{}, std::integral_constant<int, S::cnt[P]>{});
+        constexpr int W = ph_wait<S>(P);
+        if (!c_live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (counted) wait_vmcnt<W>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        OSUD_WG_WAIT(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma_frags<RY, RX>(acc, f);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (P != NPH - 1 || !last || grp == 0) __builtin_amdgcn_s_barrier();
+      });
+      r_buf = STAGE - r_buf;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- the tile's partial slab (as wgrad_kernel's store_tile)
+#pragma unroll
+    for (int i = 0; i < RY; ++i) {
+      const int y0 = ty * G::BM + wy * RY * 32 + i * 32 + (lane >> 3);
+#pragma unroll
+      for (int j = 0; j < RX; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+          v[0] = acc[i][j][4 * g + 0]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
+          ds_write16(pw[g], v);
+        }
+        f32x4 t[4];
+        t[0] = ds_read16f<0>(pr);
+        t[1] = ds_read16f<1024>(pr);
+        t[2] = ds_read16f<2048>(pr);
+        t[3] = ds_read16f<3072>(pr);
+        OSUD_WG_WAIT(0);
+        const int x = tx * G::BN + wx * RX * 32 + j * 32 + 4 * (lane & 7);
+        if (x < p.Nx) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (y0 + 8 * q < p.Ny) store4(outp + (size_t)(y0 + 8 * q) * p.Nx + x, t[q][0], t[q][1], t[q][2], t[q][3]);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
   }
 }
 
@@ -706,7 +889,19 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
   }
   // one unit per workgroup in the plain mode: XCD-contiguous unit order (WgradP::xcd_units)
   p.xcd_units = (S > 1 && p.queue == nullptr) ? 1 : 0;
-  if (geo == 0) OSUD_TRY((launch_wg<2, 4, 4, 2>(p, st)));
+  if (geo == 0 && p.queue == nullptr && opt(OPT_GEMM_LOOP) != 0 && stages / S >= 2) {  // the phased schedule (same bits)
+    constexpr size_t lds = 2 * (size_t)WGeo<2, 4, 4, 2>::STAGE + 8 * 4096;
+    static bool attr_set = false;
+    if (!attr_set) {
+      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_phased_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    int grid = cus / p.split_k;
+    if (grid < 1) grid = 1;
+    if (grid > tiles || p.split_k > 1) grid = tiles;
+    hipLaunchKernelGGL(wgrad_phased_kernel, dim3(grid, p.split_k), dim3(512), lds, st, p);
+    OSUD_HIP(hipGetLastError());
+  } else if (geo == 0) OSUD_TRY((launch_wg<2, 4, 4, 2>(p, st)));
   else if (geo == 1) OSUD_TRY((launch_wg<4, 2, 2, 3>(p, st)));
   else if (geo == 2) OSUD_TRY((launch_wg<2, 4, 3, 2>(p, st)));
   else OSUD_TRY((launch_wg<2, 2, 2, 2>(p, st)));

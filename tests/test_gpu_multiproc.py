@@ -41,11 +41,14 @@ def test_two_ranks_equal_one_process_on_the_full_batch():
     assert float((ParamArena(start).flat.cpu() - flat).abs().max()) > 1e-4  # the two steps really moved the weights
 
 
-def _torchrun(nproc, script_args, env_extra, timeout=900):
+def _torchrun(nproc, script_args, env_extra, timeout=900, expect_failure=False):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT, **env_extra)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port())] + script_args
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    if expect_failure:  # (torchrun reports a failed worker with its own exit code 1; the workers' codes are in its log)
+        assert r.returncode != 0, r.stdout[-2000:] + r.stderr[-4000:]
+        return r.stdout, r.stderr
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return r.stdout
 
@@ -209,12 +212,14 @@ def test_bench_two_ranks_over_gloo():
 def test_bench_line_survives_a_diagnostic_that_never_returns():
     """Everything after the timed region of an N > 1 run is collective and has never run on more than one GPU: if one of those
     diagnostics hangs, the watchdog prints the line with the timed result (`diagnostics_incomplete` names the stage) and every rank
-    exits 0.  Two ranks over gloo, the first diagnostic replaced by a sleep that never ends."""
+    exits with bench.WATCHDOG_EXIT (3): the run FAILS for torchrun / the driver / CI, the partial line is still on stdout.  Two ranks
+    over gloo, the first diagnostic replaced by a sleep that never ends."""
     import json
 
-    out = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "train", "--steps", "2", "--warmup", "1", "--batch", "16",
-                        "--model", "DiT-S", "--no-cpu-baseline", "--no-roofline", "--simulate-hang", "--watchdog-s", "3"],
-                    dict(OSUD_DIST_BACKEND="gloo", OSUD_SINGLE_DEVICE="1"), timeout=300)
+    out, err = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--mode", "train", "--steps", "2", "--warmup", "1", "--batch", "16",
+                             "--model", "DiT-S", "--no-cpu-baseline", "--no-roofline", "--simulate-hang", "--watchdog-s", "3"],
+                         dict(OSUD_DIST_BACKEND="gloo", OSUD_SINGLE_DEVICE="1"), timeout=300, expect_failure=True)
+    assert "exitcode: 3" in err or "exitcode  : 3" in err or "exitcode 3" in err, err[-3000:]  # torchrun's failure report names the workers' code
     lines = [ln for ln in out.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     res = json.loads(lines[0])

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Variants of the bf16 GEMM translation unit for same-box A/B runs: tools/build_gemm_variants.sh name "flags" [name "flags" ...]
+# -> ab/libosud_<name>.so (everything but gemm_bf16.o is taken from the regular build; run `make -C osu_diffusion_amd/csrc` first)
+set -e
+root=$(cd "$(dirname "$0")/.." && pwd); cs=$root/osu_diffusion_amd/csrc
+mkdir -p $root/ab
+build_one() {
+  name=$1; flags=$2; b=$cs/build_v_$name
+  rm -rf $b && mkdir -p $b && cp $cs/build/*.o $b/ && rm -f $b/gemm_bf16.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-gpu-rdc $flags -mllvm -amdgpu-atomic-optimizer-strategy=None \
+     -c $cs/gemm_bf16.hip -o $b/gemm_bf16.o 2> $b/log.txt || { tail $b/log.txt; exit 1; }
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/ab/libosud_$name.so $b/*.o -ldl
+  echo built ab/libosud_$name.so "($flags)"
+}
+while [ $# -ge 2 ]; do build_one "$1" "$2" & shift 2; if (( $(jobs -r | wc -l) >= 4 )); then wait -n; fi; done
+wait
