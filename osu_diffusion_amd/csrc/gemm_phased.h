@@ -1,65 +1,60 @@
-// The phased main loop for the two 256-row tile geometries of plain 2-byte operands (bf16, fp16): the same product, the same
-// LDS-DMA staging, the same fragment reads, MFMAs and epilogue as gemm_kernel (gemm_kernel.h) -- every accumulator sees its k in
-// the same order, so the results are bit-identical -- in a different SCHEDULE.  gfx950 only.
+// The phased main loop for the two 256-row tile geometries: the same product, the same LDS-DMA staging, the same fragment reads,
+// MFMAs and epilogue as gemm_kernel (gemm_kernel.h) -- every accumulator sees its k in the same order, so the results are
+// bit-identical -- in a different SCHEDULE.  Operands: bf16 / fp16 (training, the bf16 and fp16 sampling tiers), fp16 + e4m3 rows
+// (h8_t: the sampling tier inside the tolerance) and e4m3 (fp8 training).  gfx950 only.
 //
 // gemm_kernel's loop is one barrier per 128-byte K slab: all eight waves wait for the slab, all issue their eight LDS-DMA pieces
 // of the next one (the vector-memory path takes a piece per ~16 cycles and CU; the issuing wave issues nothing else meanwhile),
-// then all run the slab's 32 MFMAs with the fragment reads interleaved.  Both waves of a SIMD are in the same segment at the same
-// time, so the matrix pipe idles through every DMA burst: ~3000 cycles per slab against 2048 of MFMA issue.
+// then all run the slab's MFMAs with the fragment reads interleaved.  Both waves of a SIMD are in the same segment at the same
+// time, so the matrix pipe idles through every DMA burst: ~750 cycles per 8 MFMAs and wave pair where the pipe needs 512.
 //
 // Here a K slab is cut into NPH phases.  A phase of one wave is
 //     [fragment reads of the phase's cluster | this phase's share of LDS-DMA pieces | counted vmcnt]  s_barrier
-//     [lgkmcnt(0) | s_setprio 1 | a cluster of 8 MFMAs | s_setprio 0]                                 s_barrier
+//     [lgkmcnt(0) | s_setprio 1 | a cluster of MFMAs worth ~256 pipe cycles | s_setprio 0]            s_barrier
 // and the two waves of every SIMD (wave w and w + 4: group 0 and group 1) run ONE barrier apart: while a group-0 wave issues its
 // cluster, its group-1 partner on the same SIMD reads fragments and issues DMA, and the other way round in the next interval.
 // The matrix pipe always has one wave feeding it, and no wave ever issues an MFMA behind a DMA burst of its own.
+// Measured (profiles/r05_gemm_phase_stamps.md: s_memtime stamps, kernel totals): 590-690 cycles per phase = 295-345 per interval
+// against 256 of MFMA issue, 20 % fewer cycles per launch than the slab loop on every training shape -- and a shader clock that
+// falls by 8-18 % in exchange (the chip runs these kernels at its power limit: 1.3-1.4 GHz on random operands, 1.9-2.0 on zeros
+// with the SAME cycle counts), so 7-13 % less time stand-alone and 3-16 % per kernel inside a training step.
 //
 // Staging is a stream of 1 KiB pieces in the order the phases need them (the LDS image of a slab is laid out in that order:
-// PhSched::y_row / x_row), two slab buffers, AHEAD pieces per wave in flight in front of the consumer, cnt[p] more issued per
-// phase.  Loads return in order, so `vmcnt(W[p])` before the first barrier of phase p retires exactly what phase p + 1 reads;
-// it is never 0 in steady state.  The rules the table is checked against at compile time (sched_ok):
+// PhGeo::src_row), two slab buffers, AHEAD pieces per wave in flight in front of the consumer, cnt[p] more issued per phase.
+// Loads return in order, so `vmcnt(W[p])` before the first barrier of phase p retires exactly what phase p + 1 reads; with plain
+// operands it is never 0 in steady state (8 pieces = a whole slab stay in flight).  The rules a table is checked against at
+// compile time (phased.h: sched_ok):
 //   RAW  a piece is read one phase AFTER the phase whose counted wait (+ barrier, which every wave passes after its own wait)
 //        retires it -- one barrier more than lock step needs, because group 1 waits one barrier later than group 0;
 //   WAR  a region of a buffer is restaged at the earliest two phases after the phase that read it.
-// Tiles: persistent workgroups, static XCD-contiguous order as in gemm_kernel; the stream runs across tile boundaries (the next
-// tile's first slab and a half are in flight under the last phases), everything in flight is waited for once before the
-// epilogue's stores join the queue, and the first slab of a tile therefore needs no counted waits.  The stagger is per tile:
-// group 1 enters a tile with one extra barrier, group 0 pays it back after its epilogue; the epilogues of both groups run side
-// by side (patches live behind the ring: no barrier inside).
+// Plain operands: a cluster is one quadrant of the wave's block grid over the slab's four k sub-steps, so each phase needs only the
+// rows of its quadrant and a region is free again two phases later: a slab and a half in flight.  K-blocked rows (h8_t: fp16 | e4m3
+// planes of 32 k per 128-byte row; e4m3: 128 k per row) put every k sub-step of a row into the same piece, every phase touches most
+// rows, and a buffer is refilled only while the other one is consumed: all of a slab's pieces are issued in its predecessor's first
+// two phases and waited for (vmcnt(0)) in its last -- the overlap of the two wave groups is the same, the lead is half.
+// Tiles: persistent workgroups, static XCD-contiguous order as in gemm_kernel; the stream runs across tile boundaries, everything in
+// flight is waited for once before the epilogue's stores join the queue, and waits of a tile's first slab that only cover pieces
+// issued before that drain are skipped.  The stagger is per tile: group 1 enters a tile with one extra barrier, group 0 pays it
+// back after its epilogue; the epilogues of both groups run side by side (patches live behind the ring: no barrier inside).
 #pragma once
 // (included at the end of gemm_kernel.h)
 #include "phased.h"
-#ifndef OSUD_PH_TABLE
-#define OSUD_PH_TABLE 0
-#endif
 
 namespace osud {
 namespace {
 
-template <int GEO> struct PhSched;
-// 256 x 256: 2 x 4 waves of 128 x 64 (4 x 2 accumulator blocks).  Phases: (Ya, X0) (Ya, X1) (Yb, X1) (Yb, X0), Ya / Yb = Y blocks
-// 0, 1 / 2, 3; the Yb fragments overwrite Ya's registers.  LDS rows of a slab, in need order: Ya | X0 | X1 | Yb, 128 rows each.
-template <> struct PhSched<0> {
-  static constexpr int WY = 2, WX = 4, RY = 4, RX = 2, BN = 256, NPH = 4, PPW = 8;
-#if OSUD_PH_TABLE == 1   // (tuning builds) nothing issued beside the 12 reads of phase 0, four pieces in the read-free phase 3
-  static constexpr int AHEAD = 14;
-  static constexpr int cnt[NPH] = {0, 2, 2, 4};
-#elif OSUD_PH_TABLE == 2
-  static constexpr int AHEAD = 13;
-  static constexpr int cnt[NPH] = {1, 2, 2, 3};
-#else
-  static constexpr int AHEAD = 12;
-  static constexpr int cnt[NPH] = {2, 2, 2, 2};      // pieces per wave issued in phase p
-#endif
-  static constexpr int need[NPH] = {3, 5, 7, -1};    // highest piece slot the reads of phase p touch (-1: no reads)
-  static constexpr int read_phase[PPW] = {0, 0, 0, 0, 1, 1, 2, 2};
+// ---- geometry: wave grid, LDS image of a slab in need order, fragment offsets ----------------------------------------------------
+template <int GEO> struct PhGeo;
+// 256 x 256: 2 x 4 waves of 128 x 64 (4 x 2 accumulator blocks).  LDS rows of a slab: Ya | X0 | X1 | Yb, 128 rows each (Ya / Yb =
+// Y blocks 0, 1 / 2, 3 of both wave rows; Xj = X block j of the four wave columns): slots 0-1 | 2-3 | 4-5 | 6-7.
+template <> struct PhGeo<0> {
+  static constexpr int WY = 2, WX = 4, RY = 4, RX = 2, BN = 256, PPW = 8;
   static constexpr bool is_y(int m) { return m < 2 || m >= 6; }
-  static constexpr int Y_OFF[RY] = {0, 32 * SLAB, 384 * SLAB, 416 * SLAB};   // byte offsets of the wave's Y blocks from block 0
+  static constexpr int Y_OFF[RY] = {0, 32 * SLAB, 384 * SLAB, 416 * SLAB};  // byte offsets of the wave's Y blocks from block 0
   static constexpr int X_OFF[RX] = {0, 128 * SLAB};
   __device__ static int y_row0(int wy) { return wy * 64; }
   __device__ static int x_row0(int wx) { return 128 + wx * 32; }
-  // LDS row r of a slab -> row inside the tile's Y (isy) or X panel
-  __device__ static int src_row(int r, bool& isy) {
+  __device__ static int src_row(int r, bool& isy) {  // LDS row r of a slab -> row inside the tile's Y (isy) or X panel
     const int q = r >> 7, t = r & 127;
     isy = q == 0 || q == 3;
     if (q == 0) return (t >> 6) * 128 + (t & 63);
@@ -67,19 +62,10 @@ template <> struct PhSched<0> {
     return (t >> 5) * 64 + (q == 2 ? 32 : 0) + (t & 31);
   }
 };
-// 256 x 192: 4 x 2 waves of 64 x 96 (2 x 3 blocks).  Phases: (Y, X0) (Y, X1) (Y, X2).  LDS rows: Y (256) | X0 | X1 | X2 (64 each:
-// block j of wave column 0, then of wave column 1).
-template <> struct PhSched<1> {
-  static constexpr int WY = 4, WX = 2, RY = 2, RX = 3, BN = 192, NPH = 3, PPW = 7;
-#if OSUD_PH_TABLE == 1
-  static constexpr int AHEAD = 11;
-  static constexpr int cnt[NPH] = {2, 1, 4};
-#else
-  static constexpr int AHEAD = 12;
-  static constexpr int cnt[NPH] = {1, 1, 5};
-#endif
-  static constexpr int need[NPH] = {4, 5, 6};
-  static constexpr int read_phase[PPW] = {0, 0, 0, 0, 0, 1, 2};
+// 256 x 192: 4 x 2 waves of 64 x 96 (2 x 3 blocks).  LDS rows: Y (256: slots 0-3) | X0 | X1 | X2 (64 rows each: block j of wave
+// column 0, then of wave column 1: slots 4 | 5 | 6).
+template <> struct PhGeo<1> {
+  static constexpr int WY = 4, WX = 2, RY = 2, RX = 3, BN = 192, PPW = 7;
   static constexpr bool is_y(int m) { return m < 4; }
   static constexpr int Y_OFF[RY] = {0, 32 * SLAB};
   static constexpr int X_OFF[RX] = {0, 64 * SLAB, 128 * SLAB};
@@ -93,18 +79,58 @@ template <> struct PhSched<1> {
   }
 };
 
-#ifndef OSUD_PHASED_SETPRIO
-#define OSUD_PHASED_SETPRIO 1
-#endif
-// timing experiments (one build per variant, results meaningless): 1 no LDS-DMA after the prologue, 2 no counted waits, 8 the pieces
-// before the fragment reads, 16 no fragment reads (MFMAs on whatever the registers hold), 32 no MFMAs
+// ---- phase tables (phased.h has the field meanings) -----------------------------------------------------------------------------
+template <int GEO, bool BLK> struct PhSched;
+// plain operands, 256 x 256: phases (Ya, X0) (Ya, X1) (Yb, X1) (Yb, X0) over the four k sub-steps; the Yb fragments take Ya's registers.
+// (Tuning builds measured {0, 2, 2, 4} / AHEAD 14 and {1, 2, 2, 3} / 13 -- nothing beside the 12 reads of phase 0 -- within +-1 %.)
+template <> struct PhSched<0, false> : PhGeo<0> {
+  static constexpr int NPH = 4, AHEAD = 12;
+  static constexpr int cnt[NPH] = {2, 2, 2, 2};
+  static constexpr int need[NPH] = {3, 5, 7, -1};
+  static constexpr int read_phase[PPW] = {0, 0, 0, 0, 1, 1, 2, 2};
+};
+// plain operands, 256 x 192: phases (Y, X0) (Y, X1) (Y, X2); all of Y is read in phase 0, so its five slots can only be restaged in phase 2
+template <> struct PhSched<1, false> : PhGeo<1> {
+  static constexpr int NPH = 3, AHEAD = 12;
+  static constexpr int cnt[NPH] = {1, 1, 5};
+  static constexpr int need[NPH] = {4, 5, 6};
+  static constexpr int read_phase[PPW] = {0, 0, 0, 0, 0, 1, 2};
+};
+// K-blocked rows, 256 x 256.  h8_t: phases (fp16 k 0-15, all blocks) (fp16 k 16-31, all blocks) (e4m3 planes, Ya x X) (e4m3, Yb x X);
+// e4m3: (k 0-63, Ya x X) (k 0-63, Yb x X) (k 64-127, Ya x X) (k 64-127, Yb x X).  X fragments of the last cluster pair stay in registers.
+template <> struct PhSched<0, true> : PhGeo<0> {
+  static constexpr int NPH = 4, AHEAD = 8;
+  static constexpr int cnt[NPH] = {6, 2, 0, 0};
+  static constexpr int need[NPH] = {7, 7, 5, 7};
+  static constexpr int read_phase[PPW] = {2, 2, 2, 2, 2, 2, 3, 3};
+};
+// K-blocked rows, 256 x 192.  h8_t: (fp16 k 0-15) (fp16 k 16-31) (e4m3, Y x X0, X1) (e4m3, Y x X2); e4m3: (k 0-63, Y x X0, X1) (k 0-63, Y x X2)
+// (k 64-127, Y x X0, X1) (k 64-127, Y x X2): the Y fragments of a half stay in registers for its second cluster
+template <> struct PhSched<1, true> : PhGeo<1> {
+  static constexpr int NPH = 4, AHEAD = 7;
+  static constexpr int cnt[NPH] = {6, 1, 0, 0};
+  static constexpr int need[NPH] = {6, 6, 6, 6};
+  static constexpr int read_phase[PPW] = {2, 2, 2, 2, 2, 2, 3};
+};
+
+// timing builds (tools/build_gemm_variants.sh, tools/gemm_phase_stamps.py): -DOSUD_PH_TIMING=1 stamps the kernel and its epilogues
+// (the main loop runs unperturbed), =2 every segment of every phase.  -DOSUD_PH_EXP=<bits> leaves parts out (results meaningless):
+// 1 no LDS-DMA after the prologue, 2 no counted waits, 16 no fragment reads, 32 no MFMAs.
 #ifndef OSUD_PH_EXP
 #define OSUD_PH_EXP 0
 #endif
+#if defined(OSUD_PH_TIMING) && OSUD_PH_TIMING >= 2
+#define OSUD_PH_STAMP(x) asm volatile("s_memtime %0" : "=s"(x))
+#define OSUD_PH_SEGMENTS 1
+#else
+#define OSUD_PH_STAMP(x)
+#endif
 
 template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void gemm_phased_kernel(GemmP p) {
-  using S = PhSched<GEO>;
-  static_assert(sizeof(TE) == 2 && Planes<TE>::k == 1, "plain 2-byte operands");
+  constexpr bool kPlain = sizeof(TE) == 2 && Planes<TE>::k == 1;
+  constexpr bool kH8 = std::is_same<TE, h8_t>::value, kF8 = sizeof(TE) == 1;
+  static_assert(kPlain || kH8 || kF8, "operand forms of the phased loop: bf16, fp16, fp16 + e4m3 rows, e4m3");
+  using S = PhSched<GEO, !kPlain>;
   static_assert(sched_ok<S>(), "phase table breaks a staging rule");
   constexpr int WY = S::WY, WX = S::WX, RY = S::RY, RX = S::RX, BM = 256, BN = S::BN, NPH = S::NPH, PPW = S::PPW;
   constexpr int STAGE = (BM + BN) * SLAB, RING = 2 * STAGE;
@@ -210,14 +236,8 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
   uint64_t ts_k0, ts_d = 0, ts_e = 0, ts_c0 = 0;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_k0));
 #endif
-#if defined(OSUD_PH_TIMING) && OSUD_PH_TIMING >= 2   // (level 1: kernel and epilogue totals only -- the main loop runs unperturbed)
-#define OSUD_PH_STAMP(x) asm volatile("s_memtime %0" : "=s"(x))
-#define OSUD_PH_SEGMENTS 1
-#else
-#define OSUD_PH_STAMP(x)
-#endif
   uint32_t r_buf = 0;  // the consumer's slab buffer
-  float q_amax = 0.f;  // (fp8 training only: unused by 2-byte operands)
+  float q_amax = 0.f;  // fp8 training: running max |value| of this lane's share of the e4m3 output
   for (int t_cur = first; t_cur < ntiles; t_cur += G8) {
     const int ty = t_cur / ntx, tx = t_cur - ty * ntx;
     f32x16 acc[RY][RX];
@@ -227,7 +247,9 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
       for (int j = 0; j < RX; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    u32x4 fy[2][4], fx[2][4];  // fragments: two Y blocks x 4 sub-steps; X block(s) x 4 sub-steps (GEO 1 uses fx[0] only)
+    // fragments.  Plain: fy[i][s] two Y blocks x 4 sub-steps, fx[j][s] X block(s) x 4 sub-steps.  K-blocked: fy[i][h] up to four Y blocks x
+    // two chunk sets, fx[j][h] up to three X blocks x two chunk sets.
+    u32x4 fy[4][4], fx[3][4];
     if constexpr ((OSUD_PH_EXP & 16) != 0) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) asm volatile("" : "=v"(fy[0][s]), "=v"(fy[1][s]), "=v"(fx[0][s]), "=v"(fx[1][s]));
@@ -235,37 +257,28 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
     if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger
 
     for (int k = 0; k < nk; ++k) {
-      const bool counted = k > 0;  // slab 0's pieces were waited for before the previous epilogue (or by the prologue)
-      const bool last = k == nk - 1;
+      const bool first_slab = k == 0, last = k == nk - 1;
       static_for<NPH>([&](auto PH) {
         constexpr int P = decltype(PH)::value;
 #ifdef OSUD_PH_SEGMENTS
         uint64_t ts_a, ts_b, ts_c;
         OSUD_PH_STAMP(ts_a);
 #endif
-        // ---- reads of this phase's cluster, this phase's share of the stream, and the counted wait for what the NEXT phase reads
-        auto reads = [&]() {
-          if constexpr ((OSUD_PH_EXP & 16) != 0) return;
-        if constexpr (GEO == 0) {
-          if constexpr (P == 0) {
+        // ---- the fragment reads of this phase's cluster
+        if constexpr ((OSUD_PH_EXP & 16) != 0) {
+        } else if constexpr (kPlain && GEO == 0) {
+          if constexpr (P == 0 || P == 2) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-              fy[0][s] = ds_read16<S::Y_OFF[0]>(ya[s] + r_buf);
-              fy[1][s] = ds_read16<S::Y_OFF[1]>(ya[s] + r_buf);
-            }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) fx[0][s] = ds_read16<S::X_OFF[0]>(xa[s] + r_buf);
-          } else if constexpr (P == 1) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) fx[1][s] = ds_read16<S::X_OFF[1]>(xa[s] + r_buf);
-          } else if constexpr (P == 2) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-              fy[0][s] = ds_read16<S::Y_OFF[2]>(ya[s] + r_buf);
-              fy[1][s] = ds_read16<S::Y_OFF[3]>(ya[s] + r_buf);
+              fy[0][s] = ds_read16<S::Y_OFF[P]>(ya[s] + r_buf);
+              fy[1][s] = ds_read16<S::Y_OFF[P + 1]>(ya[s] + r_buf);
             }
           }
-        } else {
+          if constexpr (P == 0 || P == 1) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fx[P][s] = ds_read16<S::X_OFF[P]>(xa[s] + r_buf);
+          }
+        } else if constexpr (kPlain) {
           if constexpr (P == 0) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -275,15 +288,48 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
           }
 #pragma unroll
           for (int s = 0; s < 4; ++s) fx[0][s] = ds_read16<S::X_OFF[P]>(xa[s] + r_buf);
+        } else if constexpr (kH8 && P < 2) {  // fp16 values of k sub-step P: every block
+          static_for<RY>([&](auto I) { fy[decltype(I)::value][0] = ds_read16<S::Y_OFF[decltype(I)::value]>(ya[P] + r_buf); });
+          static_for<RX>([&](auto J) { fx[decltype(J)::value][0] = ds_read16<S::X_OFF[decltype(J)::value]>(xa[P] + r_buf); });
+        } else {  // a K = 64 block-scaled cluster: chunk sets (c0, c0 + 1) = sub-steps (2, 3) for h8_t, (0, 1) / (2, 3) for the e4m3 halves
+          constexpr int c0 = kH8 ? 2 : (P < 2 ? 0 : 2);
+          constexpr bool second = (P & 1) != 0;  // the second cluster of a pair: GEO 0 the other two Y blocks, GEO 1 the third X block
+          if constexpr (GEO == 0) {
+            constexpr int ib = second ? 2 : 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              fy[0][h] = ds_read16<S::Y_OFF[ib]>(ya[c0 + h] + r_buf);
+              fy[1][h] = ds_read16<S::Y_OFF[ib + 1]>(ya[c0 + h] + r_buf);
+            }
+            if constexpr (!second) {
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                fx[0][h] = ds_read16<S::X_OFF[0]>(xa[c0 + h] + r_buf);
+                fx[1][h] = ds_read16<S::X_OFF[1]>(xa[c0 + h] + r_buf);
+              }
+            }
+          } else {
+            if constexpr (!second) {
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                fy[0][h] = ds_read16<S::Y_OFF[0]>(ya[c0 + h] + r_buf);
+                fy[1][h] = ds_read16<S::Y_OFF[1]>(ya[c0 + h] + r_buf);
+                fx[0][h] = ds_read16<S::X_OFF[0]>(xa[c0 + h] + r_buf);
+                fx[1][h] = ds_read16<S::X_OFF[1]>(xa[c0 + h] + r_buf);
+              }
+            } else {
+#pragma unroll
+              for (int h = 0; h < 2; ++h) fx[2][h] = ds_read16<S::X_OFF[2]>(xa[c0 + h] + r_buf);
+            }
+          }
         }
-        };
-        if constexpr ((OSUD_PH_EXP & 8) == 0) reads();
-        if constexpr ((OSUD_PH_EXP & 1) == 0) stage_run(std::integral_constant<int, S::AHEAD + ph_issued_before<S>(P)>{}, std::integral_constant<int, S::cnt[P]>{});
-        if constexpr ((OSUD_PH_EXP & 8) != 0) reads();
+        // ---- this phase's share of the stream, and the counted wait for what the NEXT phase reads
+        if constexpr ((OSUD_PH_EXP & 1) == 0)
+          stage_run(std::integral_constant<int, S::AHEAD + ph_issued_before<S>(P)>{}, std::integral_constant<int, S::cnt[P]>{});
         constexpr int W = ph_wait<S>(P);
         if constexpr (W >= 0) {
           if (!c_live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the stream has ended: nothing younger to count on
-          else if (counted && (OSUD_PH_EXP & 2) == 0) wait_vmcnt<W>();
+          else if ((!first_slab || !ph_wait_predrained<S>(P)) && (OSUD_PH_EXP & 2) == 0) wait_vmcnt<W>();
         }
         __builtin_amdgcn_sched_barrier(0);
         OSUD_PH_STAMP(ts_b);
@@ -297,23 +343,49 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
         __builtin_amdgcn_sched_barrier(0);
 #endif
         // ---- the cluster
-        if (OSUD_PHASED_SETPRIO) __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
         if constexpr ((OSUD_PH_EXP & 32) != 0) {
-        } else if constexpr (GEO == 0) {
+        } else if constexpr (kPlain && GEO == 0) {
           constexpr int jb = (P == 0 || P == 3) ? 0 : 1, ib = P < 2 ? 0 : 2;
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             mma<TE>(acc[ib][jb], fx[jb][s], fy[0][s]);
             mma<TE>(acc[ib + 1][jb], fx[jb][s], fy[1][s]);
           }
-        } else {
+        } else if constexpr (kPlain) {
 #pragma unroll
           for (int s = 0; s < 4; ++s) {
             mma<TE>(acc[0][P], fx[0][s], fy[0][s]);
             mma<TE>(acc[1][P], fx[0][s], fy[1][s]);
           }
+        } else if constexpr (kH8 && P < 2) {
+#pragma unroll
+          for (int i = 0; i < RY; ++i)
+#pragma unroll
+            for (int j = 0; j < RX; ++j) mma_f16(acc[i][j], fx[j][0], fy[i][0]);
+        } else {
+          constexpr bool second = (P & 1) != 0;
+          auto mm = [&](f32x16& a, const u32x4& x0, const u32x4& x1, const u32x4& y0, const u32x4& y1) {
+            if constexpr (kH8) mma_f8_lo(a, x0, x1, y0, y1);
+            else mma_f8(a, x0, x1, y0, y1);
+          };
+          if constexpr (GEO == 0) {
+            constexpr int ib = second ? 2 : 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) mm(acc[ib + i][j], fx[j][0], fx[j][1], fy[i][0], fy[i][1]);
+          } else if constexpr (!second) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int j = 0; j < 2; ++j) mm(acc[i][j], fx[j][0], fx[j][1], fy[i][0], fy[i][1]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) mm(acc[i][2], fx[2][0], fx[2][1], fy[i][0], fy[i][1]);
+          }
         }
-        if (OSUD_PHASED_SETPRIO) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         OSUD_PH_STAMP(ts_d);
         if (P != NPH - 1 || !last || grp == 0) __builtin_amdgcn_s_barrier();
@@ -321,7 +393,7 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
       });
       r_buf = STAGE - r_buf;
     }
-    // everything in flight is the next tile's first slab and a half: landed before the epilogue's stores queue behind it
+    // everything in flight is the next tile's first slab (and a half): landed before the epilogue's stores queue behind it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifdef OSUD_PH_TIMING
     uint64_t ts_f, ts_g;
@@ -339,6 +411,20 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
 #endif
     __builtin_amdgcn_s_barrier();  // group 0 pays the stagger back; both groups: the next tile's first slab has landed everywhere
   }
+  if constexpr (kF8) {
+    if (p.out8 != nullptr && p.out8_slot != nullptr) {  // one amax atomic per workgroup (through LDS: the ring is idle by now)
+      q_amax = wave_max(q_amax);
+      __syncthreads();
+      volatile float* red = reinterpret_cast<volatile float*>(smem);
+      if (lane == 0) red[wave] = q_amax;
+      __syncthreads();
+      if (tid == 0) {
+        float mx = 0.f;
+        for (int w2 = 0; w2 < 8; ++w2) mx = fmaxf(mx, red[w2]);
+        if (mx > 0.f) atomicMax(reinterpret_cast<unsigned*>(p.out8_slot) + 2, __float_as_uint(mx));
+      }
+    }
+  }
 #ifdef OSUD_PH_TIMING
   {
     uint64_t ts_end;
@@ -353,9 +439,9 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
 }
 
 template <typename TE, int EPI, int GEO> int launch_phased(const GemmP& p_in, hipStream_t st) {
-  using S = PhSched<GEO>;
+  using G = PhGeo<GEO>;
   GemmP p = p_in;
-  constexpr int STAGE = (256 + S::BN) * SLAB;
+  constexpr int STAGE = (256 + G::BN) * SLAB;
   const size_t lds = 2 * (size_t)STAGE + 8 * 4096;
   static bool attr_set = false;
   if (!attr_set) {
@@ -363,8 +449,8 @@ template <typename TE, int EPI, int GEO> int launch_phased(const GemmP& p_in, hi
                                  (int)lds));
     attr_set = true;
   }
-  if (p.colpart_rows != nullptr) *p.colpart_rows = p.My / (S::RY * 32);
-  const int ntiles = (p.My / 256) * (p.Nx / S::BN);
+  if (p.colpart_rows != nullptr) *p.colpart_rows = p.My / (G::RY * 32);
+  const int ntiles = (p.My / 256) * (p.Nx / G::BN);
   int grid = gemm_num_cus();
   if (grid > ntiles) grid = ntiles;
   p.sched = nullptr;
@@ -376,7 +462,7 @@ template <typename TE, int EPI, int GEO> int launch_phased(const GemmP& p_in, hi
 // launch_t's hook (pick: its geometry choice; 2 = 256 x 256, 1 = 256 x 192): takes the launch where the phased loop is built for it
 template <typename TE, int EPI> int launch_phased_or(const GemmP& p, int pick, hipStream_t st, bool& taken) {
   taken = false;
-  if constexpr (sizeof(TE) == 2 && Planes<TE>::k == 1) {
+  if constexpr ((sizeof(TE) == 2 && Planes<TE>::k == 1) || std::is_same<TE, h8_t>::value || sizeof(TE) == 1) {
     if (opt(OPT_GEMM_LOOP) != 0 && (pick == 1 || pick == 2) && p.split_k <= 1 && !gemm_dynamic_tiles_wanted() &&
         (size_t)p.K * sizeof(TE) / SLAB >= 2) {
       taken = true;

@@ -26,6 +26,14 @@ template <typename S> constexpr int ph_wait(int p) {
   const int needpos = (p + 1 == S::NPH ? S::PPW : 0) + S::need[nxt];
   return S::AHEAD + ph_issued_before<S>(p + 1) - (needpos + 1);
 }
+// ... and whether that wait, in the FIRST stage of a tile, only covers pieces issued before the tile began -- all of which the wait
+// in front of the previous tile's epilogue (or the prologue) has retired already, so it can be skipped (it would otherwise sit behind
+// the epilogue's stores, which share the counter)
+template <typename S> constexpr bool ph_wait_predrained(int p) {
+  const int nxt = (p + 1) % S::NPH;
+  if (S::need[nxt] < 0) return true;
+  return (p + 1 == S::NPH ? S::PPW : 0) + S::need[nxt] < S::AHEAD;
+}
 template <typename S> constexpr bool sched_ok() {
   int total = 0;
   for (int p = 0; p < S::NPH; ++p) total += S::cnt[p];
