@@ -463,7 +463,11 @@ template <typename TE, int EPI, int GEO> int launch_phased(const GemmP& p_in, hi
 template <typename TE, int EPI> int launch_phased_or(const GemmP& p, int pick, hipStream_t st, bool& taken) {
   taken = false;
   if constexpr ((sizeof(TE) == 2 && Planes<TE>::k == 1) || std::is_same<TE, h8_t>::value || sizeof(TE) == 1) {
-    if (opt(OPT_GEMM_LOOP) != 0 && (pick == 1 || pick == 2) && p.split_k <= 1 && !gemm_dynamic_tiles_wanted() &&
+    // option gemm_loop: 1 (default) = plain operands only; 2 = the K-blocked forms too.  Measured on those (profiles/r05_gemm_phase_stamps.md):
+    // the half-length lead costs what the overlap gains -- fp16f8 sampling step 7.53 -> 7.87 ms, DiT-XL fp8 step 85.9 -> 91.4 ms -- so they
+    // stay on the slab loop unless asked for (tests/test_gpu_phased.py holds both schedules to the same bits in every form).
+    constexpr bool kPlain = sizeof(TE) == 2 && Planes<TE>::k == 1;
+    if (opt(OPT_GEMM_LOOP) >= (kPlain ? 1 : 2) && (pick == 1 || pick == 2) && p.split_k <= 1 && !gemm_dynamic_tiles_wanted() &&
         (size_t)p.K * sizeof(TE) / SLAB >= 2) {
       taken = true;
       return pick == 2 ? launch_phased<TE, EPI, 0>(p, st) : launch_phased<TE, EPI, 1>(p, st);

@@ -12,13 +12,32 @@ LOOP = int(os.environ.get("LOOP", "1"))
 _lib.set_option("gemm_loop", LOOP)
 SH = [("fc2 fwd  256x192", _lib.EPI_BIAS_TE, M, D, 4 * D), ("fc1 fwd  256x256 gelu", _lib.EPI_BIAS_GELU_TE, M, 4 * D, D),
       ("qkv dgrad 256x192", _lib.EPI_NONE_TE, M, D, 3 * D), ("fc2 dgrad 256x256", _lib.EPI_NONE_TE, M, 4 * D, D), ("4096^3 256x256", _lib.EPI_NONE_TE, 4096, 4096, 4096)]
+H8 = os.environ.get("PREC") == "h8"  # the tolerance tier's operand form (fp16 + e4m3 rows), sampling shapes
+if H8:
+    M = int(os.environ.get("M", "16384"))
+    SH = [("h8 fc2 256x192", _lib.EPI_NONE_F32, M, D, 4 * D), ("h8 fc1 256x256", _lib.EPI_BIAS_GELU_TE, M, 4 * D, D), ("h8 qkv 256x192", _lib.EPI_NONE_F32, M, 3 * D, D)]
+
+
+def pack_h8(t, weight):
+    R, C = t.shape
+    o = torch.empty(R, 4 * C, dtype=torch.uint8, device=dev)
+    _lib.check(L.osud_op_pack_h8(_lib.ptr(t), C, C, _lib.ptr(o), C, R, 1 if weight else 0, None))
+    return o
+
+
 for name, epi, My, Nx, K in SH:
-    Y = torch.randn(My, K, device=dev).to(torch.bfloat16); X = (torch.randn(Nx, K, device=dev) / K ** 0.5).to(torch.bfloat16)
+    Yf = torch.randn(My, K, device=dev); Xf = torch.randn(Nx, K, device=dev) / K ** 0.5
     if os.environ.get("ZERO") == "1":  # all-zero operands: what the same instruction stream costs when nothing toggles
-        Y.zero_(); X.zero_()
-    out = torch.zeros(My, Nx, dtype=torch.bfloat16, device=dev); bias = torch.randn(max(My, Nx), device=dev) * 0.02
+        Yf.zero_(); Xf.zero_()
+    if H8:
+        Y, X = pack_h8(Yf, False), pack_h8(Xf, True)
+        out = torch.zeros(My, 4 * Nx if epi == _lib.EPI_BIAS_GELU_TE else Nx, dtype=torch.uint8 if epi == _lib.EPI_BIAS_GELU_TE else torch.float32, device=dev)
+    else:
+        Y, X = Yf.to(torch.bfloat16), Xf.to(torch.bfloat16)
+        out = torch.zeros(My, Nx, dtype=torch.bfloat16, device=dev)
+    bias = torch.randn(max(My, Nx), device=dev) * 0.02
     dbg = torch.zeros(32 * 8 * 8, device=dev)
-    go = lambda: _lib.check(L.osud_op_gemm(0, epi, _lib.ptr(Y), K, _lib.ptr(X), K, My, Nx, K, _lib.ptr(out), Nx, _lib.ptr(bias), _lib.ptr(dbg), 0, 0, 0, None))
+    go = lambda: _lib.check(L.osud_op_gemm(_lib.PREC_F16F8 if H8 else 0, epi, _lib.ptr(Y), K, _lib.ptr(X), K, My, Nx, K, _lib.ptr(out), Nx, _lib.ptr(bias), _lib.ptr(dbg), 0, 0, 0, None))
     for _ in range(10): go()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
