@@ -143,7 +143,8 @@ def barrier(world):
         import torch.distributed as dist
 
         dist.barrier()
-    torch.cuda.synchronize()
+    if torch.cuda.is_available():  # (the world-8 schema test of multi_gpu_report runs this file's exchange report on CPU tensors over gloo)
+        torch.cuda.synchronize()
 
 
 def max_over_ranks(value, world, dev):
@@ -260,6 +261,53 @@ def wgrad_roofline(M, D, dev, iters=8):
             "flop_per_launch": flops, "avg_launch_us": round(avg_us, 2), "per_shape_us": {k: round(v, 2) for k, v in per_us.items()}}
 
 
+def train_roofline(wg_alone, fc1_alone, pf):
+    """The bench line's `roofline` of a training run.  Top level = the kernel with the largest share of the step's device time (the
+    weight-gradient kernel with the fixed-order combine of its partial slabs) at its IN-STEP duration: the mean device duration of its
+    launches inside training steps of this very run (torch.profiler / roctracer over steps behind the timed region, single-stream
+    schedule) -- the figure a `rocprofv3 --kernel-trace` of the same command reproduces (profiles/r05_train_kernel_trace.md: FLOP per
+    launch / (avg of the wgrad kernel + avg of splitk_reduce_kernel)).  The stand-alone, HIP-event-timed launch on cold operands that
+    earlier rounds reported here stays as `stand_alone`.  `lowest_fraction_top_family` names the family with the largest distance to its
+    roofline among those with >= 10 % of the step (the forward GEMMs), with its heaviest kernel (fc1 + GELU) at its in-step duration."""
+    out = dict(wg_alone)
+    stand = {k: out.pop(k) for k in ("achieved", "frac", "frac_of_random_operand_ceiling", "avg_launch_us", "per_shape_us") if k in out}
+    stand["what"] = "each launch alone between its own pair of HIP events, operands not cache-warm (bench.py: wgrad_roofline)"
+    fc1 = dict(fc1_alone)
+    fc1_stand = {k: fc1.pop(k) for k in ("achieved", "frac", "frac_of_random_operand_ceiling", "avg_launch_us") if k in fc1}
+    ok = isinstance(pf, dict) and "mfma_kernels" in pf
+    wg_us, wg_name = in_step_kernel(pf, r"^wgrad(_phased)?_kernel") if ok else (None, None)
+    sk_us, _ = in_step_kernel(pf, r"splitk_reduce") if ok else (None, None)
+    if wg_us:
+        us = wg_us + (sk_us or 0.0)
+        ach = out["flop_per_launch"] / (us * 1e-6) / 1e12
+        out.update(achieved=round(ach, 2), frac=round(ach / PEAK_BF16_TFLOPS, 4), frac_of_random_operand_ceiling=round(ach / MFMA_RANDOM_OPERAND_CEILING_TFLOPS, 4),
+                   avg_launch_us=round(us, 2), avg_launch_us_parts={wg_name: wg_us, "splitk_reduce_kernel": sk_us},
+                   measured="in-step: mean device duration of the kernel's launches inside training steps of this run (torch.profiler / roctracer, "
+                            "3 steps behind the timed region, single-stream schedule)")
+    else:
+        out.update(stand, measured="stand-alone launches (no per-kernel table in this run: --no-family-table)")
+    out["stand_alone"] = stand
+    f1_us, f1_name = in_step_kernel(pf, r"^gemm(_phased)?_kernel<bf16, 4,") if ok else (None, None)
+    if f1_us:
+        a = fc1["flop_per_launch"] / (f1_us * 1e-6) / 1e12
+        fc1.update(achieved=round(a, 2), frac=round(a / PEAK_BF16_TFLOPS, 4), avg_launch_us=f1_us, kernel_in_step=f1_name,
+                   measured="in-step (as the top level; the launch also writes the saved GELU derivative: 201 MB more than the stand-alone launch)")
+    else:
+        fc1.update(fc1_stand, measured="stand-alone")
+    fc1["stand_alone"] = fc1_stand
+    out["fc1_forward"] = fc1
+    if ok:
+        big = {k: v for k, v in pf["families"].items() if v.get("bound") == "mfma" and v.get("share", 0) >= 0.10}
+        if big:
+            fam = min(big, key=lambda k: big[k]["frac"])
+            out["lowest_fraction_top_family"] = {"family": fam, "ms_per_step": big[fam]["ms_per_step"], "share": big[fam]["share"], "frac": big[fam]["frac"],
+                                                 "heaviest_kernel": fc1.get("kernel_in_step") if fam == "gemm_fwd" else big[fam]["top_kernel"],
+                                                 "heaviest_kernel_frac": fc1.get("frac") if fam == "gemm_fwd" else None}
+    if pf is not None:
+        out["per_family"] = pf
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------------------------
 # Per-family roofline table.  A few steps AFTER the timed region are run under torch.profiler (roctracer sees every kernel
 # the process launches, libosud's included); kernel device times are summed per family and set against the family's
@@ -273,13 +321,13 @@ _EPI_FWD = {"0", "1", "2", "3", "4", "5"}  # csrc/gemm.h: bias / silu / gelu / g
 def _family_of(name):
     import re
 
-    if "gemm_kernel<" in name:
-        m = re.search(r"gemm_kernel<[^,]+,\s*\(?(?:osud::)?(?:GemmEpilogue\)?)?\s*(\d+)", name)
+    if "gemm_kernel<" in name or "gemm_phased_kernel<" in name:
+        m = re.search(r"gemm(?:_phased)?_kernel<[^,]+,\s*\(?(?:osud::)?(?:GemmEpilogue\)?)?\s*(\d+)", name)
         epi = m.group(1) if m else "?"
         if epi in _EPI_FWD:
             return "gemm_fwd"
         return "gemm_dgrad" if epi in ("7", "9") else "gemm_other"
-    if "wgrad_kernel" in name:
+    if "wgrad_kernel" in name or "wgrad_phased_kernel" in name:
         return "gemm_wgrad"
     if "attn_bwd" in name:
         return "attention_bwd"
@@ -297,6 +345,26 @@ def _family_of(name):
     return "other"
 
 
+def _short_kernel(name):
+    import re
+
+    name = re.sub(r"\(anonymous namespace\)::|osud::|^void ", "", name).replace("unsigned short", "bf16")
+    return re.sub(r"\(.*$", "", name)[:80]
+
+
+def in_step_kernel(pf, pattern):
+    """(avg_us, name) of the kernel of the family table's per-kernel rows whose short name matches `pattern` with the most device time."""
+    import re
+
+    best = None
+    for k, v in (pf.get("mfma_kernels") or {}).items():
+        if re.search(pattern, k):
+            t = v["avg_us"] * v["calls_per_step"]
+            if best is None or t > best[2]:
+                best = (v["avg_us"], k, t)
+    return (best[0], best[1]) if best else (None, None)
+
+
 def family_table(run_steps, n_steps, work, dev):
     """run_steps(n) executes n steps; work = {family: (amount per step, "flop" | "byte")}.  Returns the table or an
     {"error": ...} stub (the profiler is best effort: the headline numbers never depend on it)."""
@@ -307,7 +375,7 @@ def family_table(run_steps, n_steps, work, dev):
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
             run_steps(n_steps)
             torch.cuda.synchronize()
-        fam, top = {}, {}
+        fam, top, kern = {}, {}, {}
         for ev in prof.key_averages():
             t_us = getattr(ev, "device_time_total", None)
             if t_us is None:
@@ -316,6 +384,8 @@ def family_table(run_steps, n_steps, work, dev):
                 continue
             f = _family_of(ev.key)
             fam[f] = fam.get(f, 0.0) + t_us
+            if f.startswith("gemm") or "splitk_reduce" in ev.key:  # per-kernel rows of the MFMA kernels (and the split-K combine): `roofline` is made from them
+                kern[_short_kernel(ev.key)] = {"family": f, "calls_per_step": round(ev.count / n_steps, 2), "avg_us": round(t_us / max(1, ev.count), 2)}
             if t_us > top.get(f, ("", 0.0))[1]:
                 top[f] = (ev.key[:96], t_us)
         if not fam:
@@ -337,7 +407,7 @@ def family_table(run_steps, n_steps, work, dev):
         return {"source": f"torch.profiler (roctracer) over {n_steps} steps after the timed region", "kernel_ms_per_step": round(total / n_steps / 1e3, 4),
                 "mfma_ms_per_step": round(sum(v for k, v in fam.items() if k.startswith("gemm") or k.startswith("attention")) / n_steps / 1e3, 4),
                 "non_mfma_ms_per_step": round(sum(v for k, v in fam.items() if not (k.startswith("gemm") or k.startswith("attention"))) / n_steps / 1e3, 4),
-                "top_family": next(iter(rows)), "families": rows}
+                "top_family": next(iter(rows)), "families": rows, "mfma_kernels": kern}
     except Exception as e:  # noqa: BLE001
         return {"error": f"{type(e).__name__}: {e}"[:200]}
 
@@ -421,7 +491,7 @@ def cpu_baseline_train(model, args, batch, steps=1, cpu_batch=32):
                       f"torch-CPU oracle + autograd + AdamW + EMA, {dt:.1f} s"}
 
 
-def multi_gpu_report(args, world, rank, dev, model, diffusion, batches, timed_ms, timed_name):
+def multi_gpu_report(args, world, rank, dev, model, diffusion, batches, timed_ms, timed_name, trainer_factory=None):
     """What the first multi-GPU run needs to be read (no such node was available while this was written): did RCCL see every rank,
     how much of the step is exposed communication, how many bytes travel, and which exchange schedule is fastest -- measured in this
     very run, every schedule on the same model, batches and boxes:
@@ -430,25 +500,35 @@ def multi_gpu_report(args, world, rank, dev, model, diffusion, batches, timed_ms
       zero1_no_overlap the same, all-gathers joined before the next step
       native_comm      the all-reduce schedule through the library's own RCCL communicator (C ABI: osud_allreduce_grads)
       no_exchange      the all-reduce schedule with every collective left out (NOT a training run: the compute floor)
-    exposed_comm_ms_per_step = allreduce - no_exchange."""
+    exposed_comm_ms_per_step = allreduce - no_exchange.
+    `trainer_factory` (default: NativeTrainer) is what a leg builds its trainer with: tests/test_distributed_cpu.py runs this report at
+    world size 8 over gloo on CPU tensors with a trainer whose compute is a sleep and whose exchange is the real slice schedule."""
     import torch.distributed as dist
 
-    from osu_diffusion_amd import _lib
-    from osu_diffusion_amd.training import NativeTrainer, overlap_slices
+    from osu_diffusion_amd.training import overlap_slices
+
+    on_gpu = torch.device(dev).type == "cuda"
+    if trainer_factory is None:
+        from osu_diffusion_amd.training import NativeTrainer as trainer_factory
 
     if args.simulate_hang:
         time.sleep(1e9)
     backend = dist.get_backend()
     ones = torch.ones(1, device=dev)
     dist.all_reduce(ones)
+    rccl_version = None
+    if on_gpu:
+        from osu_diffusion_amd import _lib
+
+        rccl_version = int(_lib.lib().osud_comm_rccl_version())
     rep = {"rccl": {"backend": backend + (" (RCCL)" if backend == "nccl" else ""), "world_size": world, "ranks_seen": int(round(float(ones.item()))),
-                    "version": int(_lib.lib().osud_comm_rccl_version()),
+                    "version": rccl_version,
                     "torch_nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None}}
     B, T = args.batch, args.seq_len
     K, W = (6, 2) if args.precision == "fp32" else (max(4, min(args.steps or 20, 20)), 3)
 
     def leg(**kw):
-        tr = NativeTrainer(model, diffusion, lr=1e-4, **kw)
+        tr = trainer_factory(model, diffusion, lr=1e-4, **kw)
         for i in range(W):
             (x, o, c), y = batches[i % 4]
             tr.step(x, o, c, y)
@@ -461,7 +541,8 @@ def multi_gpu_report(args, world, rank, dev, model, diffusion, batches, timed_ms
         barrier(world)
         ms = max_over_ranks(time.perf_counter() - t0, world, dev) / K * 1e3
         del tr
-        torch.cuda.empty_cache()
+        if on_gpu:
+            torch.cuda.empty_cache()
         return round(ms, 3)
 
     legs = {"allreduce": dict(), "zero1": dict(shard_optimizer=True), "zero1_no_overlap": dict(shard_optimizer=True, overlap_gather=False),
@@ -497,7 +578,28 @@ def multi_gpu_report(args, world, rank, dev, model, diffusion, batches, timed_ms
                                   "class_table_dense_would_be": int(next(hi - lo for kind, _, lo, hi in tail if kind == "table") * 4),
                                   "ring_bytes_sent_per_gpu": int(2 * (world - 1) / world * dense * 4 + (world - 1) / world * rows_bytes),
                                   "slices": len(blocks) + 1 + sum(1 for kind, *_ in tail if kind == "tail")}
+    rep["predicted_comm_ms_per_step"] = predicted_comm_ms(dense * 4, rows_bytes, world)
     return rep
+
+
+XGMI_LINK_GBS = 153.0  # per link and direction; 7 links per GPU, point to point (MI355X_MICROARCH.md / the task's hardware sheet)
+
+
+def predicted_comm_ms(dense_bytes, rows_bytes, world):
+    """What the gradient exchange of one step costs ON THE WIRE if nothing overlaps, from the payload and the xGMI link rate -- the number
+    the first 8-GPU run's `exposed_comm_ms_per_step` is to be judged against (DESIGN.md section 6 has the derivation):
+      ring all-reduce          2 (W - 1) / W x payload over ONE link per direction (a ring uses one outgoing link per GPU)
+      direct (mesh) exchange   reduce-scatter + all-gather with every peer at once: each of the W - 1 links carries payload / W per phase,
+                               two phases -> 2 x payload / W per link
+    With the phased backward the exchange of all but the last slice runs under compute: exposed = what is left behind the first block's
+    backward (the last slice to be reduced), so both figures are upper bounds of `exposed_comm_ms_per_step`."""
+    if world < 2:
+        return None
+    link = XGMI_LINK_GBS * 1e9
+    ring = (2.0 * (world - 1) / world * dense_bytes + (world - 1) / world * rows_bytes) / link * 1e3
+    mesh = (2.0 * dense_bytes / world + rows_bytes / world) / link * 1e3
+    return {"link_GBps": XGMI_LINK_GBS, "ring_allreduce_unoverlapped": round(ring, 3), "mesh_reduce_scatter_allgather_unoverlapped": round(mesh, 3),
+            "note": "upper bounds of exposed_comm_ms_per_step: the phased backward hides every slice but the last under compute"}
 
 
 def bench_train(args, world, rank, dev):
@@ -573,9 +675,9 @@ def bench_train(args, world, rank, dev):
         # The dominant kernel of a training step by device time is the weight-gradient kernel (19 % of the step): it is
         # the top-level `roofline`; the forward fc1 GEMM -- the heaviest single forward launch, round 1's and 2's entry -- stays
         # next to it.  Both are timed live with HIP events at the step's shapes.
-        fc1 = gemm_roofline(B * T, 4 * D, D, dev)
-        res["roofline"] = wgrad_roofline(B * T, D, dev)
-        res["roofline"]["fc1_forward"] = fc1
+        fc1_alone = gemm_roofline(B * T, 4 * D, D, dev)
+        wg_alone = wgrad_roofline(B * T, D, dev)
+        pf = None
         if not args.no_family_table and world == 1:
             def more(n):
                 for i in range(n):
@@ -586,12 +688,12 @@ def bench_train(args, world, rank, dev):
             from osu_diffusion_amd import _lib as _l
             with _l.option("wgrad_side_stream", 0):
                 more(1)
-                res["roofline"]["per_family"] = family_table(more, 3, dit_work(D, model.depth, B * T, T, training=True,
-                                                                               n_params=trainer.arena.total), dev)
-            if isinstance(res["roofline"]["per_family"], dict) and "source" in res["roofline"]["per_family"]:
-                res["roofline"]["per_family"]["source"] += ("; single-stream schedule (option wgrad_side_stream = 0): the timed region overlaps a block's weight "
-                                                            "gradients with its data-gradient chain on a second stream, which stretches the durations of "
-                                                            "kernels that run side by side")
+                pf = family_table(more, 3, dit_work(D, model.depth, B * T, T, training=True, n_params=trainer.arena.total), dev)
+            if isinstance(pf, dict) and "source" in pf:
+                pf["source"] += ("; single-stream schedule (option wgrad_side_stream = 0): the timed region overlaps a block's weight "
+                                 "gradients with its data-gradient chain on a second stream, which stretches the durations of "
+                                 "kernels that run side by side")
+        res["roofline"] = train_roofline(wg_alone, fc1_alone, pf)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_train(model, args, batches[0])
     if world > 1 and not args.no_exchange_ab:  # (every rank takes part: the legs are collective)
@@ -665,10 +767,22 @@ def bench_sample(args, world, rank, dev):
                              "mfma_frac": round(steps_per_s * flop_step / 1e12 / PEAK_BF16_TFLOPS, 4)}
     if rank == 0 and not args.no_roofline and args.precision == "bf16":
         D = model.hidden_size
-        res["roofline"] = gemm_roofline(M, 4 * D, D, dev)
-        if not args.no_family_table and world == 1:
-            res["roofline"]["per_family"] = family_table(lambda k: run(k, z.clone()), 20,
-                                                         dit_work(D, model.depth, M, T, training=False), dev)
+        alone = gemm_roofline(M, 4 * D, D, dev)
+        pf = family_table(lambda k: run(k, z.clone()), 20, dit_work(D, model.depth, M, T, training=False), dev) if (not args.no_family_table and world == 1) else None
+        rf = dict(alone)
+        stand = {k: rf.pop(k) for k in ("achieved", "frac", "frac_of_random_operand_ceiling", "avg_launch_us") if k in rf}
+        us, kname = in_step_kernel(pf, r"^gemm(_phased)?_kernel<bf16, 4,") if isinstance(pf, dict) and "mfma_kernels" in pf else (None, None)
+        if us:
+            a = rf["flop_per_launch"] / (us * 1e-6) / 1e12
+            rf.update(achieved=round(a, 2), frac=round(a / PEAK_BF16_TFLOPS, 4), frac_of_random_operand_ceiling=round(a / MFMA_RANDOM_OPERAND_CEILING_TFLOPS, 4),
+                      avg_launch_us=us, kernel_in_step=kname,
+                      measured="in-step: mean device duration of the kernel's launches inside sampler steps of this run (torch.profiler / roctracer, 20 steps behind the timed region)")
+        else:
+            rf.update(stand, measured="stand-alone launches (no per-kernel table in this run)")
+        rf["stand_alone"] = stand
+        if pf is not None:
+            rf["per_family"] = pf
+        res["roofline"] = rf
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_sample(model, args, windows)
     return res
@@ -817,11 +931,12 @@ def parity_tier_and_drift(args, dev):
 
 XL_TIERS = ["bf16", "fp8"]
 PEAK_FP8_TFLOPS = 5000.0
-# share of a DiT block's GEMM FLOPs (forward + data gradients + weight gradients = 3 x 24 M D^2) the fp8 training tier runs on e4m3
-# operands: in_proj, out_proj, fc1, fc2 -- forward, data-gradient AND weight-gradient products (round 3) = all of them; the attention
-# core, the adaLN product and the first linear (2 % of the FLOPs) stay bf16 and are not counted in the share
-F8_SHARE = 1.0
+# share of the step's algorithmic FLOPs the fp8 training tier runs on e4m3 operands: in_proj, out_proj, fc1, fc2 -- forward, data-gradient AND
+# weight-gradient products; the attention core, the adaLN product, the embedders and the final layer stay bf16
 FLOP_PER_TOKEN_TRAIN_XL = 2783.5e6  # DiT-XL, T=256
+# the four Linear products of a block are 24 D^2 FLOP per token and block forward (x 3 for training, like everything else): 24 x 1152^2 x 28 =
+# 891.8 of DiT-XL's 927.84 MFLOP per token; the rest -- attention core 33.0, adaLN 1.7, first linear 1.2, final layer -- runs in bf16
+F8_SHARE = round(3 * 24 * 1152 ** 2 * 28 / FLOP_PER_TOKEN_TRAIN_XL, 4)
 
 
 def bench_xl(args, world, rank, dev, precision="bf16", steps=None, warmup=None):
@@ -872,23 +987,34 @@ def main():
         if world == 1 and args.precision == "bf16" and not args.no_parity_tier:
             res["parity_tier"], res["bf16_drift"] = parity_tier_and_drift(args, dev)
             tt = res["parity_tier"].pop("tolerance_tier")
-            res["sampling"]["tolerance_tier"] = tt
-            res["sampling"]["fp16_tier"] = res["parity_tier"].pop("fp16_tier")
-            # which number answers "1000-step CFG sampling steps/s, matching the reference within 1e-3": the fastest tier whose
-            # 1000-step drift from the exact-f32 tier stays below the bound on this very workload
+            fp16_tier = res["parity_tier"].pop("fp16_tier")
+            # Which number answers "1000-step CFG sampling steps/s, matching the reference within 1e-3": the fastest tier whose 1000-step
+            # drift from the exact-f32 tier stays below the bound on this very workload AND whose claim is held by every reference fixture
+            # of the test suite.  THAT is `sampling.value`; the bf16 tier's (faster, outside the tolerance) line moves to `also.bf16`.
             bd = res["bf16_drift"]
-            res["sampling"]["tolerance"] = {
-                "bound": 1e-3, "unit": "normalised playfield coordinates, max over the conditional rows after the full loop",
-                "this_line": {"tier": "bf16", "max_drift_vs_fp32_tier": bd["max"], "p99": bd["p99"], "meets": bool(bd["max"] <= 1e-3)},
-                "fastest_tier_meeting_it": ({"tier": tt.get("name", "bf16x3"), "value": tt["value"], "unit": "steps/s", "max_drift_vs_fp32_tier": tt["drift_vs_fp32_tier"]["max"]}
-                                            if tt["meets_1e-3"] else {"tier": "fp32", "value": res["parity_tier"]["sample"]["value"], "unit": "steps/s"}),
-                "reference_fixture": "tests/golden/g6_loop_p1000_dit_b.npz: the reference's own 1000-step CFG-4 DiT-B loop; tests/test_gpu_x3.py, "
-                                     "tests/test_gpu_h8.py (fp32 tier 9.8e-5, bf16x3 1.2e-4, fp16f8 1.2e-4, bf16 8.8e-3 from it)"}
+            bf16_line = res["sampling"]
+            bf16_line["tolerance"] = {"max_drift_vs_fp32_tier": bd["max"], "p99": bd["p99"], "meets_1e-3": bool(bd["max"] <= 1e-3)}
+            credited = tt if tt["meets_1e-3"] else dict(res["parity_tier"]["sample"], name="fp32", dtype="f32", **{"meets_1e-3": True})
+            res["sampling"] = {
+                "metric": bf16_line["metric"], "value": credited["value"], "unit": "steps/s", "steps": credited["steps"], "warmup": 2,
+                "ms_per_step": credited["ms_per_step"], "tier": credited.get("name"), "dtype": credited.get("dtype"),
+                "config": bf16_line["config"],
+                "tolerance": {
+                    "bound": 1e-3, "unit": "normalised playfield coordinates, max over the conditional rows after the full loop",
+                    "this_line": {"tier": credited.get("name"), "max_drift_vs_fp32_tier": (credited.get("drift_vs_fp32_tier") or {}).get("max", 0.0), "meets": True,
+                                  "held_by_every_reference_fixture": credited.get("held_by_every_reference_fixture", True)},
+                    "reference_fixture": "tests/golden/g6_loop_p1000_dit_b.npz: the reference's own 1000-step CFG-4 DiT-B loop; tests/test_gpu_x3.py, "
+                                         "tests/test_gpu_h8.py (fp32 tier 9.8e-5, bf16x3 1.2e-4, fp16f8 1.2e-4, bf16 8.8e-3 from it)"},
+                "end_to_end": {"flop_per_step": bf16_line.get("end_to_end", {}).get("flop_per_step"), "achieved_tflops": credited.get("algorithmic_tflops"),
+                               "mfma_frac": credited.get("mfma_frac_algorithmic"), "mfma_frac_issued_passes": credited.get("mfma_frac_issued")},
+                "tolerance_tier": tt,
+                "also": {"bf16": bf16_line, "fp16": fp16_tier},
+            }
             # the fp8 inference tier on the same sampling workload (reduced precision: 0.7 % rms from the fp32 oracle, tests/test_gpu_fp8.py)
             fargs = argparse.Namespace(**vars(args))
             fargs.precision, fargs.steps, fargs.warmup, fargs.no_roofline, fargs.no_cpu_baseline = "fp8", 300, 30, True, True
             f8 = bench_sample(fargs, world, rank, dev)
-            res["sampling"]["fp8_tier"] = {"value": f8["value"], "unit": "steps/s", "ms_per_step": f8["ms_per_step"], "steps": f8["steps"], "dtype": f8["dtype"]}
+            res["sampling"]["also"]["fp8"] = {"value": f8["value"], "unit": "steps/s", "ms_per_step": f8["ms_per_step"], "steps": f8["steps"], "dtype": f8["dtype"]}
         if not args.no_xl and args.precision == "bf16":
             WATCHDOG.stage = "xl"
             res["xl"] = {p: bench_xl(args, world, rank, dev, p) for p in ([args.xl_precision] if args.xl_precision else XL_TIERS)}
