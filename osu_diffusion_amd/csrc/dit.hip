@@ -137,7 +137,9 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
     OSUD_TRY(dev_alloc(W, &b.rowpart, (size_t)(2 * m->L + 2) * (Mp / 64) * (6 * D + 64) * 4, false));
     b.b1part_stride = (size_t)(Mp / 32) * 4 * D;
     b.bqkvpart_stride = (size_t)(nN > (Mp + 255) / 256 ? nN : (Mp + 255) / 256) * 3 * D;  // one row per sample (streamed kernel) or per 256-token row block (column-sum pass)
-    OSUD_TRY(dev_alloc(W, &b.b1part, (size_t)m->L * b.b1part_stride * 4, false));
+    // (fc1's bias gradient rides in the GELU' epilogue in the bf16 tier only -- train.hip: fused_b1 -- the fp32 tier never touches these rows;
+    //  DiT-XL at 32 768 tokens: 528 MB here + 829 MB of rowpart, stated in DESIGN.md section 3)
+    if (m->prec == OSUD_PREC_BF16) OSUD_TRY(dev_alloc(W, &b.b1part, (size_t)m->L * b.b1part_stride * 4, false));
     OSUD_TRY(dev_alloc(W, &b.bqkvpart, (size_t)m->L * b.bqkvpart_stride * 4, false));
     {  // the widest column sum: a transpose's (rows / 64) shares of 4 D (or the padded first-layer width) columns, or (Np / 64) x AC
       const size_t a = (size_t)(Mp / 64) * tcols, c = (size_t)(Np / 64) * AC;

@@ -302,7 +302,7 @@ __device__ __forceinline__ void compute_slab_w8(f32x16 (&acc)[RY][RX], const uin
 // in flight while one is consumed).  (Built, measured slower and removed: 64-byte half slabs in a ring of four with the epilogue
 // patches behind the ring -- fc1 183 vs 168 us, the doubled barrier count costs more than the extra lead buys; a role-split main
 // loop in which the two waves of a SIMD alternate between MFMAs and LDS-DMA issue -- equal time at a proportionally lower clock.
-// DESIGN.md section 4 has both write-ups.)
+// HISTORY.md section 4 has both write-ups.)
 template <int WY, int WX, int RY, int RX> struct Geo {
   static constexpr int SB = SLAB;
   static constexpr int BM = WY * RY * 32, BN = WX * RX * 32, NW = WY * WX, NT = 64 * NW;

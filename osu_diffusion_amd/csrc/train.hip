@@ -261,14 +261,14 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     // area), each as soon as its gradient operand exists; the chain -- data-gradient GEMMs with the HBM-bound LayerNorm / attention
     // backward kernels between them -- goes on at once, and waits for the side stream only before the kernel that overwrites the
     // branch gradients (the LN1 backward).  The weight gradients then run under the chain's HBM-bound kernels, which leave the
-    // matrix pipe -- and the power budget, section 4 of DESIGN.md -- idle: 12 blocks of the pattern with device copies standing in
+    // matrix pipe -- and the power budget, DESIGN.md section 4.1 -- idle: 12 blocks of the pattern with device copies standing in
     // for the HBM-bound kernels 14.2 -> 13.2 ms (tools/overlap_wgrad_probe.py); the real step 26.2 -> 25.7 ms on one box, 26.0 -> 25.8
     // on another (five alternating pairs, every one in favour).  Less than the stand-in promised: a LayerNorm backward fills every
     // compute unit's registers, so a weight-gradient workgroup only starts where its blocks have finished -- the gain is kernel
     // heads and tails filling each other, not two kernels sharing compute units.  osud_set_option("wgrad_side_stream", 0) restores
     // the single stream (same bits: tests/test_gpu_train.py; bench.py takes its per-kernel table there).
     // (Built, gradients equal to 2e-7, measured neutral and removed: the four products of a block in one or two GROUPED launches --
-    //  equal runs of stages per workgroup, one combine pass per group; DESIGN.md section 4 "round 3".)
+    //  equal runs of stages per workgroup, one combine pass per group; HISTORY.md section 4 "round 3".)
     const bool side_env = opt(OPT_WGRAD_SIDE_STREAM) != 0;  // (read per block)
     bool side_on = side_env && prec == OSUD_PREC_BF16 && !f8_train;
     // (fp8 training, live steps: the same for the e4m3 weight gradients, with one more join -- the twin of dqkv re-uses the staging

@@ -121,7 +121,7 @@ struct WgradP {
   unsigned* queue;  // shared-GPU mode (256x256 geometry, splits > 1): [tile] chunk tickets, [63] finished workgroups; else null
   int chunk;        // chunks per tile (a multiple of split_k)
   // (built, the same bits, measured slower and removed: the split-K combine inside this launch -- the workgroups of a tile meeting
-  //  on an arrival counter -- 29.99 vs 28.73 ms per training step: DESIGN.md section 4 "round 2")
+  //  on an arrival counter -- 29.99 vs 28.73 ms per training step: HISTORY.md section 4 "round 2")
   // one (tile, split) unit per workgroup, plain mode: units in split-major order, one contiguous run per XCD (workgroup L runs on
   // XCD L % 8), so that the ~32 workgroups of an XCD walk the SAME token rows -- one or two splits, all of their tiles -- and share
   // every stage's operand rows through that XCD's L2.  With blockIdx = (tile, split) an XCD held 4-5 tiles of each of the splits

@@ -675,7 +675,7 @@ def g12_cli_toy():
     torch.manual_seed(seed); z = randn(n, 2, T); doubled [cond; null] batch; banded mask; p_sample_loop with randn_like per
     step) on the toy beatmap's window tensors.  The reference's sample.py cannot be imported (`slider`), so its few lines of
     setup are re-enacted here around the REFERENCE model and diffusion objects; the window tensors come from this repository's
-    `.osu` reader (parsing itself is unpinned, DESIGN.md 7b) and are stored in the fixture."""
+    `.osu` reader (parsing itself is unpinned, DESIGN.md section 8) and are stored in the fixture."""
     print("G12 CLI: reference sampling flow on the toy beatmap")
     from osu_diffusion_amd.beatmap import Beatmap, beatmap_to_sequence
     from osu_diffusion_amd.windows import split_and_process_sequence_no_augment

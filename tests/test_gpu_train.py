@@ -298,6 +298,21 @@ def test_training_rejects_padded_shapes():
         tr.step(x, o, c, y)
 
 
+def test_training_without_learned_sigma_is_rejected_with_a_message():
+    """learn_sigma=False (2 output channels) runs forward and sampling; the backward pass is built for the 4 output channels every script
+    of the reference trains (models.py:243-254): asking for a training workspace says so instead of failing inside the final layer's backward."""
+    from osu_diffusion_amd import _lib
+    from osu_diffusion_amd.models import DiT
+
+    m = DiT(depth=1, hidden_size=128, num_heads=2, context_size=144, num_classes=4, learn_sigma=False, precision="fp32").to(DEV)
+    (x, o, c), y = synthetic_windows(2, 64, 4, seed=0)
+    with torch.no_grad():
+        out = m(x, torch.tensor([3, 900]), o, c, y)
+    assert out.shape == (2, 2, 64) and torch.isfinite(out).all()
+    with pytest.raises(AssertionError, match="learn_sigma=True"):
+        _lib.check(_lib.lib().osud_dit_reserve(m.native_handle(), 2, 64, 1))
+
+
 @pytest.mark.selfcheck
 def test_phased_backward_equals_single_call():
     """The phased backward (used to overlap the gradient all-reduce) against the single call: the same kernels except for the adaLN

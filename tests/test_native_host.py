@@ -60,6 +60,23 @@ def test_option_table_is_the_only_switchboard():
         assert names <= {"OSUD_LIB", "OSUD_PRECISION"}, (path, names)  # where the library file is; the default tier of DiT(...)
 
 
+def test_osud_options_environment_values_must_be_numbers():
+    """OSUD_OPTIONS="name=value,...": a value that is not a number ("off", the empty string) is reported on stderr and leaves the default in
+    place -- it must not be read as 0 (atoi would); a numeric one in range is taken; the phased GEMM loop's option exists with default 1."""
+    import subprocess
+    import sys
+
+    code = ("from osu_diffusion_amd import _lib; "
+            "print(_lib.get_option('sample_graph'), _lib.get_option('gemm_tile'), _lib.get_option('embed_const'), _lib.get_option('gemm_loop'))")
+    env = dict(os.environ, OSUD_OPTIONS="sample_graph=off,gemm_tile=,embed_const=0,gemm_loop=2", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split() == ["1", "0", "0", "2"], r.stdout
+    assert "ignoring 'sample_graph=off'" in r.stderr and "ignoring 'gemm_tile='" in r.stderr, r.stderr[-1000:]
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=ROOT, OSUD_OPTIONS=""), cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.stdout.split() == ["1", "0", "1", "1"], r.stdout + r.stderr[-500:]
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "g1_schedule_*.npz"))))
 def test_native_schedule_tables_match_reference(path):
     """osud_sched_create (C++ host code) vs the reference's numpy tables: bit-equal up to libm's

@@ -6,7 +6,7 @@ after a chained CFG-4 p_sample loop with identical noise.
 
     python tools/analysis/bf16_error_budget.py [--model tiny|small] [--steps 20] [--pos-gain 0.1]
 
-Result (committed in DESIGN.md §2): every GEMM class injects about the same ~2^-9 relative error, the loop amplifies whatever
+Result (committed in HISTORY.md §2): every GEMM class injects about the same ~2^-9 relative error, the loop amplifies whatever
 is injected; no single layer is "the" source.
 """
 import argparse

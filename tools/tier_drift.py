@@ -5,7 +5,7 @@ bench.py's `parity_tier_and_drift`: same windows, noise and seeded weights), nex
     python tools/tier_drift.py fp16f8 fp16w8 fp16m8:3 fp16m8:7 ...      # fp16m8:<mask> sets option f16m8_forms (bit i = GEMM i on w8_t)
     SEEDS=3 python tools/tier_drift.py ...                               # more than one (windows, noise) draw: the max is a tail statistic
 
-Used to choose which of a block's four GEMMs may drop the activation's residual (DESIGN.md section 2 "fp16w8")."""
+Used to choose which of a block's four GEMMs may drop the activation's residual (HISTORY.md section 2 "fp16w8")."""
 import os
 import sys
 import time
