@@ -185,3 +185,59 @@ def test_training_step_gradients_are_bit_identical_under_both_loops(osud_option,
     for k in res[0][1]:
         assert torch.equal(res[0][1][k], res[1][1][k]), k
     assert torch.equal(res[0][2], res[1][2])
+
+
+def test_race_screen_under_memory_load(osud_option):
+    """The staging rules of the phased loops (a piece is read one phase after the wait that retires it; a region is restaged two phases after
+    its last read) are checked at compile time, but what they guard against -- a fragment read that overtakes its LDS-DMA piece, a piece
+    that overwrites rows still being read -- only shows when a piece lands late or early.  So: 150 launches of the GEMM and of the
+    weight-gradient kernel while a second stream keeps HBM and the L2s busy with device copies of changing size (DMA latencies move by
+    factors), every result compared with the slab loop's bits; shapes with many rounds, odd slab counts and ragged splits."""
+    g = torch.Generator(device=DEV).manual_seed(21)
+    side = torch.cuda.Stream()
+    junk_a = torch.empty(96 << 20, dtype=torch.uint8, device=DEV)
+    junk_b = torch.empty_like(junk_a)
+    cases = []
+    for M, N, K, tile in ((4096, 3072, 768, 256), (4096, 768, 3072, 192), (2048, 2304, 192, 192), (1024, 512, 320, 256)):
+        Y = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+        X = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+        bias = torch.randn(N, device=DEV, generator=g)
+        cases.append((M, N, K, tile, Y, X, bias))
+    P = torch.randn(8192, 768, device=DEV, generator=g).to(torch.bfloat16)
+    Q = torch.randn(8192, 1024, device=DEV, generator=g).to(torch.bfloat16)
+    ws = torch.empty(32 * 768 * 1024, device=DEV)
+
+    def gemm(case):
+        M, N, K, tile, Y, X, bias = case
+        out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+        _gemm(_lib.PREC_BF16, "gelu", Y, K, X, K, M, N, K, out, bias, None)
+        return out
+
+    def wgrad():
+        out = torch.empty(768, 1024, device=DEV)
+        _lib.check(_lib.lib().osud_op_wgrad(_lib.ptr(P), 768, _lib.ptr(Q), 1024, 768, 1024, 8192, _lib.ptr(out), _lib.ptr(ws), ws.numel(), None))
+        return out
+
+    osud_option("gemm_loop", 0)
+    want = []
+    for case in cases:
+        osud_option("gemm_tile", case[3])
+        want.append(gemm(case))
+    want_w = wgrad()
+    torch.cuda.synchronize()
+    osud_option("gemm_loop", 1)
+    bad = 0
+    for it in range(150):
+        n = (1 + (it * 7) % 13) << 22  # 4 .. 52 MiB per copy, a different size every iteration
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                junk_b[:n].copy_(junk_a[:n], non_blocking=True)
+        k = it % len(cases)
+        osud_option("gemm_tile", cases[k][3])
+        got = gemm(cases[k])
+        got_w = wgrad() if it % 3 == 0 else None
+        bad += int(not torch.equal(got, want[k]))
+        if got_w is not None:
+            bad += int(not torch.equal(got_w, want_w))
+    torch.cuda.synchronize()
+    assert bad == 0, f"{bad} launches of the phased loops differ from the slab loop under memory load"
