@@ -89,8 +89,8 @@ enum Opt {
   OPT_DEBUG_SYNC,             // 1: synchronise and name every stage of the backward pass (fault triage)
   OPT_F16M8_FORMS,            // OSUD_PREC_F16M8: bit i = 1 puts GEMM i of a block (0 in_proj, 1 out_proj, 2 fc1, 3 fc2) on fp16-activation operands (w8_t),
                               // 0 on fp16 + e4m3 operands (h8_t); read by osud_dit_create
-  OPT_GEMM_LOOP,              // 1: the 256-row tile geometries of bf16 / fp16 operands (and the 256 x 256 weight gradients) run the phased main loop
-                              // (gemm_phased.h); 2: the fp16 + e4m3 and e4m3 operand forms too (slower there: measured); 0: the slab loop.  Same bits.
+  OPT_GEMM_LOOP,              // 1: the 256-row GEMM tiles (bf16 / fp16 / fp16 + e4m3 / e4m3 operands) and the 256 x 256 weight-gradient kernel run the
+                              // phased main loop (gemm_phased.h: the two waves of a SIMD one barrier apart); 0: one barrier per K slab.  Same bits.
   OPT_COUNT
 };
 int opt(Opt o);

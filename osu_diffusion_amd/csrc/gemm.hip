@@ -77,7 +77,7 @@ struct OptDef {
 constexpr OptDef kOpts[OPT_COUNT] = {
     {"wgrad_side_stream", 1, 0, 1}, {"sample_graph", 1, 0, 1},    {"embed_const", 1, 0, 1},  {"tvec_table", 1, 0, 1},
     {"split_first", 1, 0, 1},       {"attn_fwd_kernel", 0, 0, 2}, {"attn_bwd_kernel", 0, 0, 2}, {"gemm_tile", 0, 0, 1256},
-    {"f8_twins_only", 1, 0, 1},     {"debug_sync", 0, 0, 1},      {"f16m8_forms", 11, 0, 15},    {"gemm_loop", 1, 0, 2},
+    {"f8_twins_only", 1, 0, 1},     {"debug_sync", 0, 0, 1},      {"f16m8_forms", 11, 0, 15},    {"gemm_loop", 1, 0, 1},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<unsigned> g_opt_epoch{0};

@@ -21,17 +21,19 @@
 //
 // Staging is a stream of 1 KiB pieces in the order the phases need them (the LDS image of a slab is laid out in that order:
 // PhGeo::src_row), two slab buffers, AHEAD pieces per wave in flight in front of the consumer, cnt[p] more issued per phase.
-// Loads return in order, so `vmcnt(W[p])` before the first barrier of phase p retires exactly what phase p + 1 reads; with plain
-// operands it is never 0 in steady state (8 pieces = a whole slab stay in flight).  The rules a table is checked against at
+// Loads return in order, so `vmcnt(W[p])` before the first barrier of phase p retires exactly what phase p + 1 reads; it is never 0 in steady state (7-8 pieces = a whole slab stay in flight).  The rules a table is checked against at
 // compile time (phased.h: sched_ok):
 //   RAW  a piece is read one phase AFTER the phase whose counted wait (+ barrier, which every wave passes after its own wait)
 //        retires it -- one barrier more than lock step needs, because group 1 waits one barrier later than group 0;
 //   WAR  a region of a buffer is restaged at the earliest two phases after the phase that read it.
-// Plain operands: a cluster is one quadrant of the wave's block grid over the slab's four k sub-steps, so each phase needs only the
-// rows of its quadrant and a region is free again two phases later: a slab and a half in flight.  K-blocked rows (h8_t: fp16 | e4m3
-// planes of 32 k per 128-byte row; e4m3: 128 k per row) put every k sub-step of a row into the same piece, every phase touches most
-// rows, and a buffer is refilled only while the other one is consumed: all of a slab's pieces are issued in its predecessor's first
-// two phases and waited for (vmcnt(0)) in its last -- the overlap of the two wave groups is the same, the lead is half.
+// A cluster is one quadrant of the wave's block grid -- two Y blocks against one X block -- over the WHOLE slab (its four 32-byte chunk
+// pairs), so each phase needs only the rows of its quadrant and a region is free again two phases later: a slab and a half in flight.
+// That holds for every operand form, because a form only decides what the chunk pairs of a row mean: bf16 / fp16: four k sub-steps
+// of 16 (4 MFMAs per block); h8_t (fp16 | e4m3 planes of 32 k per row): two fp16 MFMAs + one block-scaled K = 64 MFMA per block; e4m3
+// (128 k per row): two K = 64 MFMAs per block -- 128 pipe cycles per block and slab in all three, 256 per cluster.  (A first version cut
+// the K-blocked forms by k sub-step instead: every phase then touches every row, a buffer can only be refilled while the other is
+// consumed, the lead halves -- and it measured SLOWER than the slab loop: fp16f8 sampling 7.53 -> 7.87 ms, DiT-XL fp8 85.9 -> 91.4 ms.
+// By quadrant: 7.60 -> 7.28 ms and 86.0 -> 86.2: profiles/r05_ab_runs.md.)
 // Tiles: persistent workgroups, static XCD-contiguous order as in gemm_kernel; the stream runs across tile boundaries, everything in
 // flight is waited for once before the epilogue's stores join the queue, and waits of a tile's first slab that only cover pieces
 // issued before that drain are skipped.  The stagger is per tile: group 1 enters a tile with one extra barrier, group 0 pays it
@@ -80,39 +82,22 @@ template <> struct PhGeo<1> {
 };
 
 // ---- phase tables (phased.h has the field meanings) -----------------------------------------------------------------------------
-template <int GEO, bool BLK> struct PhSched;
-// plain operands, 256 x 256: phases (Ya, X0) (Ya, X1) (Yb, X1) (Yb, X0) over the four k sub-steps; the Yb fragments take Ya's registers.
+template <int GEO> struct PhSched;
+// 256 x 256: phases (Ya, X0) (Ya, X1) (Yb, X1) (Yb, X0), each over the slab's four 32-byte chunk pairs; the Yb fragments take Ya's registers.
 // (Tuning builds measured {0, 2, 2, 4} / AHEAD 14 and {1, 2, 2, 3} / 13 -- nothing beside the 12 reads of phase 0 -- within +-1 %.)
-template <> struct PhSched<0, false> : PhGeo<0> {
+template <> struct PhSched<0> : PhGeo<0> {
   static constexpr int NPH = 4, AHEAD = 12;
   static constexpr int cnt[NPH] = {2, 2, 2, 2};
   static constexpr int need[NPH] = {3, 5, 7, -1};
   static constexpr int read_phase[PPW] = {0, 0, 0, 0, 1, 1, 2, 2};
 };
-// plain operands, 256 x 192: phases (Y, X0) (Y, X1) (Y, X2); all of Y is read in phase 0, so its five slots can only be restaged in phase 2
-template <> struct PhSched<1, false> : PhGeo<1> {
+// 256 x 192: phases (Y, X0) (Y, X1) (Y, X2); all of Y is read in phase 0, so its five slots can only be restaged in phase 2
+template <> struct PhSched<1> : PhGeo<1> {
   static constexpr int NPH = 3, AHEAD = 12;
   static constexpr int cnt[NPH] = {1, 1, 5};
   static constexpr int need[NPH] = {4, 5, 6};
   static constexpr int read_phase[PPW] = {0, 0, 0, 0, 0, 1, 2};
 };
-// K-blocked rows, 256 x 256.  h8_t: phases (fp16 k 0-15, all blocks) (fp16 k 16-31, all blocks) (e4m3 planes, Ya x X) (e4m3, Yb x X);
-// e4m3: (k 0-63, Ya x X) (k 0-63, Yb x X) (k 64-127, Ya x X) (k 64-127, Yb x X).  X fragments of the last cluster pair stay in registers.
-template <> struct PhSched<0, true> : PhGeo<0> {
-  static constexpr int NPH = 4, AHEAD = 8;
-  static constexpr int cnt[NPH] = {6, 2, 0, 0};
-  static constexpr int need[NPH] = {7, 7, 5, 7};
-  static constexpr int read_phase[PPW] = {2, 2, 2, 2, 2, 2, 3, 3};
-};
-// K-blocked rows, 256 x 192.  h8_t: (fp16 k 0-15) (fp16 k 16-31) (e4m3, Y x X0, X1) (e4m3, Y x X2); e4m3: (k 0-63, Y x X0, X1) (k 0-63, Y x X2)
-// (k 64-127, Y x X0, X1) (k 64-127, Y x X2): the Y fragments of a half stay in registers for its second cluster
-template <> struct PhSched<1, true> : PhGeo<1> {
-  static constexpr int NPH = 4, AHEAD = 7;
-  static constexpr int cnt[NPH] = {6, 1, 0, 0};
-  static constexpr int need[NPH] = {6, 6, 6, 6};
-  static constexpr int read_phase[PPW] = {2, 2, 2, 2, 2, 2, 3};
-};
-
 // timing builds (tools/build_gemm_variants.sh, tools/gemm_phase_stamps.py): -DOSUD_PH_TIMING=1 stamps the kernel and its epilogues
 // (the main loop runs unperturbed), =2 every segment of every phase.  -DOSUD_PH_EXP=<bits> leaves parts out (results meaningless):
 // 1 no LDS-DMA after the prologue, 2 no counted waits, 16 no fragment reads, 32 no MFMAs.
@@ -130,7 +115,7 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
   constexpr bool kPlain = sizeof(TE) == 2 && Planes<TE>::k == 1;
   constexpr bool kH8 = std::is_same<TE, h8_t>::value, kF8 = sizeof(TE) == 1;
   static_assert(kPlain || kH8 || kF8, "operand forms of the phased loop: bf16, fp16, fp16 + e4m3 rows, e4m3");
-  using S = PhSched<GEO, !kPlain>;
+  using S = PhSched<GEO>;
   static_assert(sched_ok<S>(), "phase table breaks a staging rule");
   constexpr int WY = S::WY, WX = S::WX, RY = S::RY, RX = S::RX, BM = 256, BN = S::BN, NPH = S::NPH, PPW = S::PPW;
   constexpr int STAGE = (BM + BN) * SLAB, RING = 2 * STAGE;
@@ -247,9 +232,8 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
       for (int j = 0; j < RX; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // fragments.  Plain: fy[i][s] two Y blocks x 4 sub-steps, fx[j][s] X block(s) x 4 sub-steps.  K-blocked: fy[i][h] up to four Y blocks x
-    // two chunk sets, fx[j][h] up to three X blocks x two chunk sets.
-    u32x4 fy[4][4], fx[3][4];
+    // fragments: fy[i][s] two Y blocks x the slab's four 32-byte chunk pairs, fx[j][s] one or two X blocks (GEO 1 uses fx[0] only)
+    u32x4 fy[2][4], fx[2][4];
     if constexpr ((OSUD_PH_EXP & 16) != 0) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) asm volatile("" : "=v"(fy[0][s]), "=v"(fy[1][s]), "=v"(fx[0][s]), "=v"(fx[1][s]));
@@ -266,7 +250,7 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
 #endif
         // ---- the fragment reads of this phase's cluster
         if constexpr ((OSUD_PH_EXP & 16) != 0) {
-        } else if constexpr (kPlain && GEO == 0) {
+        } else if constexpr (GEO == 0) {
           if constexpr (P == 0 || P == 2) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -278,7 +262,7 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
 #pragma unroll
             for (int s = 0; s < 4; ++s) fx[P][s] = ds_read16<S::X_OFF[P]>(xa[s] + r_buf);
           }
-        } else if constexpr (kPlain) {
+        } else {
           if constexpr (P == 0) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
@@ -288,40 +272,6 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
           }
 #pragma unroll
           for (int s = 0; s < 4; ++s) fx[0][s] = ds_read16<S::X_OFF[P]>(xa[s] + r_buf);
-        } else if constexpr (kH8 && P < 2) {  // fp16 values of k sub-step P: every block
-          static_for<RY>([&](auto I) { fy[decltype(I)::value][0] = ds_read16<S::Y_OFF[decltype(I)::value]>(ya[P] + r_buf); });
-          static_for<RX>([&](auto J) { fx[decltype(J)::value][0] = ds_read16<S::X_OFF[decltype(J)::value]>(xa[P] + r_buf); });
-        } else {  // a K = 64 block-scaled cluster: chunk sets (c0, c0 + 1) = sub-steps (2, 3) for h8_t, (0, 1) / (2, 3) for the e4m3 halves
-          constexpr int c0 = kH8 ? 2 : (P < 2 ? 0 : 2);
-          constexpr bool second = (P & 1) != 0;  // the second cluster of a pair: GEO 0 the other two Y blocks, GEO 1 the third X block
-          if constexpr (GEO == 0) {
-            constexpr int ib = second ? 2 : 0;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              fy[0][h] = ds_read16<S::Y_OFF[ib]>(ya[c0 + h] + r_buf);
-              fy[1][h] = ds_read16<S::Y_OFF[ib + 1]>(ya[c0 + h] + r_buf);
-            }
-            if constexpr (!second) {
-#pragma unroll
-              for (int h = 0; h < 2; ++h) {
-                fx[0][h] = ds_read16<S::X_OFF[0]>(xa[c0 + h] + r_buf);
-                fx[1][h] = ds_read16<S::X_OFF[1]>(xa[c0 + h] + r_buf);
-              }
-            }
-          } else {
-            if constexpr (!second) {
-#pragma unroll
-              for (int h = 0; h < 2; ++h) {
-                fy[0][h] = ds_read16<S::Y_OFF[0]>(ya[c0 + h] + r_buf);
-                fy[1][h] = ds_read16<S::Y_OFF[1]>(ya[c0 + h] + r_buf);
-                fx[0][h] = ds_read16<S::X_OFF[0]>(xa[c0 + h] + r_buf);
-                fx[1][h] = ds_read16<S::X_OFF[1]>(xa[c0 + h] + r_buf);
-              }
-            } else {
-#pragma unroll
-              for (int h = 0; h < 2; ++h) fx[2][h] = ds_read16<S::X_OFF[2]>(xa[c0 + h] + r_buf);
-            }
-          }
         }
         // ---- this phase's share of the stream, and the counted wait for what the NEXT phase reads
         if constexpr ((OSUD_PH_EXP & 1) == 0)
@@ -344,46 +294,35 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
 #endif
         // ---- the cluster
         __builtin_amdgcn_s_setprio(1);
+        // two accumulator blocks (Y blocks y0, y1 of the wave against one X block) over the slab's four chunk pairs, the two accumulators
+        // alternating; per accumulator the products come in the slab loop's order (compute_slab / _h8 / the e4m3 halves): same bits
+        auto pair = [&](f32x16& a0, f32x16& a1, const u32x4 (&x)[4], const u32x4 (&y0)[4], const u32x4 (&y1)[4]) {
+          if constexpr (kPlain) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+              mma<TE>(a0, x[s], y0[s]);
+              mma<TE>(a1, x[s], y1[s]);
+            }
+          } else if constexpr (kH8) {  // chunk pairs 0, 1: the fp16 values of k 0-15 / 16-31; 2 | 3: the e4m3 planes P | Q of all 32 k
+            mma_f16(a0, x[0], y0[0]);
+            mma_f16(a1, x[0], y1[0]);
+            mma_f16(a0, x[1], y0[1]);
+            mma_f16(a1, x[1], y1[1]);
+            mma_f8_lo(a0, x[2], x[3], y0[2], y0[3]);
+            mma_f8_lo(a1, x[2], x[3], y1[2], y1[3]);
+          } else {  // e4m3: chunk pairs 0 | 1 = k 0-63, 2 | 3 = k 64-127
+            mma_f8(a0, x[0], x[1], y0[0], y0[1]);
+            mma_f8(a1, x[0], x[1], y1[0], y1[1]);
+            mma_f8(a0, x[2], x[3], y0[2], y0[3]);
+            mma_f8(a1, x[2], x[3], y1[2], y1[3]);
+          }
+        };
         if constexpr ((OSUD_PH_EXP & 32) != 0) {
-        } else if constexpr (kPlain && GEO == 0) {
+        } else if constexpr (GEO == 0) {
           constexpr int jb = (P == 0 || P == 3) ? 0 : 1, ib = P < 2 ? 0 : 2;
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            mma<TE>(acc[ib][jb], fx[jb][s], fy[0][s]);
-            mma<TE>(acc[ib + 1][jb], fx[jb][s], fy[1][s]);
-          }
-        } else if constexpr (kPlain) {
-#pragma unroll
-          for (int s = 0; s < 4; ++s) {
-            mma<TE>(acc[0][P], fx[0][s], fy[0][s]);
-            mma<TE>(acc[1][P], fx[0][s], fy[1][s]);
-          }
-        } else if constexpr (kH8 && P < 2) {
-#pragma unroll
-          for (int i = 0; i < RY; ++i)
-#pragma unroll
-            for (int j = 0; j < RX; ++j) mma_f16(acc[i][j], fx[j][0], fy[i][0]);
+          pair(acc[ib][jb], acc[ib + 1][jb], fx[jb], fy[0], fy[1]);
         } else {
-          constexpr bool second = (P & 1) != 0;
-          auto mm = [&](f32x16& a, const u32x4& x0, const u32x4& x1, const u32x4& y0, const u32x4& y1) {
-            if constexpr (kH8) mma_f8_lo(a, x0, x1, y0, y1);
-            else mma_f8(a, x0, x1, y0, y1);
-          };
-          if constexpr (GEO == 0) {
-            constexpr int ib = second ? 2 : 0;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int j = 0; j < 2; ++j) mm(acc[ib + i][j], fx[j][0], fx[j][1], fy[i][0], fy[i][1]);
-          } else if constexpr (!second) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-              for (int j = 0; j < 2; ++j) mm(acc[i][j], fx[j][0], fx[j][1], fy[i][0], fy[i][1]);
-          } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) mm(acc[i][2], fx[2][0], fx[2][1], fy[i][0], fy[i][1]);
-          }
+          pair(acc[0][P], acc[1][P], fx[0], fy[0], fy[1]);
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
@@ -463,11 +402,7 @@ template <typename TE, int EPI, int GEO> int launch_phased(const GemmP& p_in, hi
 template <typename TE, int EPI> int launch_phased_or(const GemmP& p, int pick, hipStream_t st, bool& taken) {
   taken = false;
   if constexpr ((sizeof(TE) == 2 && Planes<TE>::k == 1) || std::is_same<TE, h8_t>::value || sizeof(TE) == 1) {
-    // option gemm_loop: 1 (default) = plain operands only; 2 = the K-blocked forms too.  Measured on those (profiles/r05_gemm_phase_stamps.md):
-    // the half-length lead costs what the overlap gains -- fp16f8 sampling step 7.53 -> 7.87 ms, DiT-XL fp8 step 85.9 -> 91.4 ms -- so they
-    // stay on the slab loop unless asked for (tests/test_gpu_phased.py holds both schedules to the same bits in every form).
-    constexpr bool kPlain = sizeof(TE) == 2 && Planes<TE>::k == 1;
-    if (opt(OPT_GEMM_LOOP) >= (kPlain ? 1 : 2) && (pick == 1 || pick == 2) && p.split_k <= 1 && !gemm_dynamic_tiles_wanted() &&
+    if (opt(OPT_GEMM_LOOP) != 0 && (pick == 1 || pick == 2) && p.split_k <= 1 && !gemm_dynamic_tiles_wanted() &&
         (size_t)p.K * sizeof(TE) / SLAB >= 2) {
       taken = true;
       return pick == 2 ? launch_phased<TE, EPI, 0>(p, st) : launch_phased<TE, EPI, 1>(p, st);

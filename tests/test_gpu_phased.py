@@ -1,5 +1,5 @@
-"""GPU (-m gpu): the phased main loops (csrc/gemm_phased.h, csrc/wgrad.hip: wgrad_phased_kernel; option gemm_loop: 1 = the default, plain operands;
-2 = every operand form the loop is built for) against the slab loops they re-schedule (gemm_loop = 0).
+"""GPU (-m gpu): the phased main loops (csrc/gemm_phased.h, csrc/wgrad.hip: wgrad_phased_kernel; option gemm_loop = 1, the default)
+against the slab loops they re-schedule (gemm_loop = 0).
 
 The phased kernels run the same staging, fragment reads, MFMAs and epilogue; every accumulator sees its k in the same order.  So the
 bar is BIT equality -- of single launches in every operand form the loop is built for (bf16, fp16, fp16 + e4m3 rows, e4m3), on both
@@ -34,7 +34,7 @@ def _gemm(prec, epi, Y, ldy, X, ldx, M, N, K, out, bias, gate):
 
 def _both_loops(osud_option, run):
     res = []
-    for loop in (0, 2):  # (2: the phased loop in every operand form it is built for; the default 1 keeps the K-blocked forms on the slab loop)
+    for loop in (0, 1):
         osud_option("gemm_loop", loop)
         res.append(run())
         torch.cuda.synchronize()
@@ -131,7 +131,7 @@ def test_forward_of_every_tier_is_bit_identical_under_both_loops(osud_option, pr
     outs = []
     for tile in (256, 192):
         osud_option("gemm_tile", tile)
-        for loop in (0, 2):
+        for loop in (0, 1):
             osud_option("gemm_loop", loop)
             m = _model(shape, sd, precision)
             with torch.no_grad():
@@ -155,7 +155,7 @@ def test_sampler_loop_is_bit_identical_under_both_loops(osud_option):
     kw = dict(o=torch.cat([o, o]).to(DEV), c=torch.cat([c, c]).to(DEV), y=torch.cat([y, torch.full_like(y, shape.num_classes)]).to(DEV), cfg_scale=4.0)
     noise = torch.randn(20, 8, 2, 128, generator=torch.Generator().manual_seed(10)).to(DEV)
     res = []
-    for loop in (0, 2, 0):
+    for loop in (0, 1, 0):
         osud_option("gemm_loop", loop)
         res.append(diff.p_sample_loop(m.forward_with_cfg, z.shape, z.clone(), clip_denoised=True, model_kwargs=kw, device=DEV, step_noise=noise).clone())
         torch.cuda.synchronize()
@@ -174,7 +174,7 @@ def test_training_step_gradients_are_bit_identical_under_both_loops(osud_option,
     noise = torch.randn(8, 2, 128, generator=torch.Generator().manual_seed(3))
     osud_option("gemm_tile", 256)
     res = []
-    for loop in (0, 2):
+    for loop in (0, 1):
         osud_option("gemm_loop", loop)
         tr = NativeTrainer(_model(shape, sd, precision, train=True), create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True))
         for _ in range(2):  # (fp8: the second step runs on the first one's delayed scales)

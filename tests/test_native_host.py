@@ -68,10 +68,10 @@ def test_osud_options_environment_values_must_be_numbers():
 
     code = ("from osu_diffusion_amd import _lib; "
             "print(_lib.get_option('sample_graph'), _lib.get_option('gemm_tile'), _lib.get_option('embed_const'), _lib.get_option('gemm_loop'))")
-    env = dict(os.environ, OSUD_OPTIONS="sample_graph=off,gemm_tile=,embed_const=0,gemm_loop=2", PYTHONPATH=ROOT)
+    env = dict(os.environ, OSUD_OPTIONS="sample_graph=off,gemm_tile=,embed_const=0,gemm_loop=0", PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
-    assert r.stdout.split() == ["1", "0", "0", "2"], r.stdout
+    assert r.stdout.split() == ["1", "0", "0", "0"], r.stdout
     assert "ignoring 'sample_graph=off'" in r.stderr and "ignoring 'gemm_tile='" in r.stderr, r.stderr[-1000:]
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PYTHONPATH=ROOT, OSUD_OPTIONS=""), cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.stdout.split() == ["1", "0", "1", "1"], r.stdout + r.stderr[-500:]
