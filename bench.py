@@ -283,7 +283,7 @@ def train_roofline(wg_alone, fc1_alone, pf):
         out.update(achieved=round(ach, 2), frac=round(ach / PEAK_BF16_TFLOPS, 4), frac_of_random_operand_ceiling=round(ach / MFMA_RANDOM_OPERAND_CEILING_TFLOPS, 4),
                    avg_launch_us=round(us, 2), avg_launch_us_parts={wg_name: wg_us, "splitk_reduce_kernel": sk_us},
                    measured="in-step: mean device duration of the kernel's launches inside training steps of this run (torch.profiler / roctracer, "
-                            "3 steps behind the timed region, single-stream schedule)")
+                            "8 steps behind the timed region, single-stream schedule)")
     else:
         out.update(stand, measured="stand-alone launches (no per-kernel table in this run: --no-family-table)")
     out["stand_alone"] = stand
@@ -687,8 +687,8 @@ def bench_train(args, world, rank, dev):
             #  run side by side report stretched durations, so the per-kernel table is taken on the single-stream schedule)
             from osu_diffusion_amd import _lib as _l
             with _l.option("wgrad_side_stream", 0):
-                more(1)
-                pf = family_table(more, 3, dit_work(D, model.depth, B * T, T, training=True, n_params=trainer.arena.total), dev)
+                more(3)  # (the schedule has just changed: let the clocks settle before the profiled steps)
+                pf = family_table(more, 8, dit_work(D, model.depth, B * T, T, training=True, n_params=trainer.arena.total), dev)
             if isinstance(pf, dict) and "source" in pf:
                 pf["source"] += ("; single-stream schedule (option wgrad_side_stream = 0): the timed region overlaps a block's weight "
                                  "gradients with its data-gradient chain on a second stream, which stretches the durations of "
