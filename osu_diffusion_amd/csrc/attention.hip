@@ -604,6 +604,187 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const bf16_t* __re
   }
 }
 
+// ---------------------------------------------------------------- the same shape on split-bf16 operands (the tolerance tiers' attention)
+// attn_bf16_kernel<64, 64, 1, true> pays a memory round trip per 64-key block behind two barriers: 60 us per launch at the sampling
+// batch where its 201 MB need 37 at the rate of a device copy.  This is the streamed structure of attn_fwd_stream_kernel for plane
+// pairs: one eight-wave workgroup per CU walks PAIRS of heads (waves 0-3 the first, 4-7 the second; a wave owns 32 queries) in
+// STAGES of 64 keys -- K_hi | K_lo | V_hi | V_lo of both heads = eight 8 KiB tiles = 64 KiB, one tile per wave by LDS-DMA -- into the
+// other half of a 128 KiB double buffer while this stage is computed, with the online softmax of the general kernel across a head's
+// two stages.  The arithmetic -- three-term products with the small terms first, the rescale, the order of the key blocks -- is the
+// general kernel's, instruction for instruction: the results are bit-identical (tests/test_gpu_x3.py).  Output forms as there:
+// plane pairs (bf16x3), fp16 + e4m3 rows (fp16f8: mode -1) or fp16 + e4m3(v) rows (fp16w8: mode -2).
+template <int T>
+__global__ __launch_bounds__(512) void attn_fwd_stream_x3_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int D, int H,
+                                                                 int items, float c1, float mode) {
+  constexpr int HD = 64, HDP = 64, KS = 4, DT = 2, KB = 64;
+  using TL = AttnTile<HDP>;
+  constexpr int TILE = KB * TL::RS;  // 8 KiB
+  static_assert(T == 128, "four waves x 32 queries per head, two 64-key stages");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][2 heads][K_hi | K_lo | V_hi | V_lo][TILE]
+  const uint32_t lds0 = (uint32_t)(size_t)(const __attribute__((address_space(3))) void*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const size_t ld3 = 3 * (size_t)D, ldrow = 2 * ld3;  // a row is [hi plane | lo plane], each 3 D long
+  const int npairs = (items + 1) / 2;
+  // LDS-DMA: wave w fetches tile w of a stage: head w / 4 of the pair, K or V = (w / 2) % 2, plane w % 2; 8 pieces of 8 rows
+  const int thead = wave >> 2, tkv = (wave >> 1) & 1, tpl = wave & 1;
+  const uint32_t ldb = (uint32_t)(ldrow * 2);
+  const int lr = lane >> 3, pc = lane & 7;
+  const uint32_t voff_even = (uint32_t)lr * ldb + (uint32_t)((pc ^ (lr >> 1)) << 4);
+  const uint32_t voff_odd = (uint32_t)lr * ldb + (uint32_t)((pc ^ (4 + (lr >> 1))) << 4);
+  auto issue = [&](int pair, int half, int buf) {
+    const int item = 2 * pair + thead;
+    if (item >= items) return;  // odd head count: the last pair is half empty
+    const int n = item / H, h = item - n * H;
+    const char* base = reinterpret_cast<const char*>(qkv + ((size_t)n * T + half * KB) * ldrow + (size_t)tpl * ld3 + (size_t)(1 + tkv) * D + h * HD);
+    const uint32_t dst0 = lds0 + (uint32_t)((buf * 8 + wave) * TILE);
+#pragma unroll
+    for (int pp = 0; pp < KB / 8; ++pp) {
+      const char* sb = base + (size_t)pp * 8 * ldb;
+      const uint32_t dst = dst0 + pp * 1024;
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"((pp & 1) ? voff_odd : voff_even), "s"(sb), "s"(dst) : "memory");
+    }
+  };
+  const int hw = wave >> 2, own = (wave & 3) * 32;  // which head of the pair, first query of this wave
+  auto fetch_q = [&](int pair, u32x4 (&qh)[KS], u32x4 (&ql)[KS]) {
+    int item = 2 * pair + hw;
+    if (item >= items) item = items - 1;  // (the empty half of an odd last pair reads a valid head and stores nothing)
+    const int n = item / H, h = item - n * H;
+    const bf16_t* src = qkv + ((size_t)n * T + own + frow) * ldrow + h * HD + fhalf * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qh[ks] = *reinterpret_cast<const u32x4*>(src + ks * 16);
+      ql[ks] = *reinterpret_cast<const u32x4*>(src + ld3 + ks * 16);
+    }
+  };
+  const int G = gridDim.x;
+  int it = blockIdx.x;
+  u32x4 qf[KS], qlo[KS], qn[KS], qnl[KS];
+  if (it < npairs) {
+    issue(it, 0, 0);
+    fetch_q(it, qf, qlo);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) asm volatile("" : "+v"(qf[ks]), "+v"(qlo[ks]));  // (the compiler's wait for these registers: here)
+  }
+  int buf = 0;
+  for (; it < npairs; it += G) {
+    const int nx = it + G;
+    const int item = 2 * it + hw;
+    f32x16 o[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+    for (int half = 0; half < 2; ++half, buf ^= 1) {
+      __syncthreads();  // every wave has waited for its tile of this stage; the other buffer is free from here on
+      if (half == 0) issue(it, 1, buf ^ 1);
+      else if (nx < npairs) {
+        issue(nx, 0, buf ^ 1);
+        fetch_q(nx, qn, qnl);
+      }
+      if (item < items) {
+        const char* Ks = smem + (size_t)((buf * 8 + hw * 4) * TILE);
+        const char* Vs = Ks + 2 * TILE;
+        // ---- S^T tiles: s[kt][4g+i] = score(key = half*64 + kt*32 + 8g + 4*fhalf + i, query own + frow)
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const u32x4 kh = rowfrag<HDP>(Ks, kt * 32 + frow, 2 * ks + fhalf);
+            s[kt] = mfma_h<false>(rowfrag<HDP>(Ks + TILE, kt * 32 + frow, 2 * ks + fhalf), qf[ks], s[kt]);  // small terms first
+            s[kt] = mfma_h<false>(kh, qlo[ks], s[kt]);
+            s[kt] = mfma_h<false>(kh, qf[ks], s[kt]);
+          }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float v = s[kt][r] * c1;
+            asm("" : "+v"(v));  // (the ROUNDED product, as in the general kernel, whose select on the mask keeps the compiler from contracting
+            s[kt][r] = v;       //  it into the subtraction below; here it would -- __fmul_rn is a plain multiply to it -- and the bits would differ)
+            mx = fmaxf(mx, v);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;
+        const float alpha = fast_exp2(m_run - m_use);  // m_run = -inf -> 0
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float pv = fast_exp2(s[kt][r] - m_use);
+            s[kt][r] = pv;
+            psum += pv;
+          }
+        psum += __shfl_xor(psum, 32, 64);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        // ---- O^T += V^T . P^T (V^T fragments = transposing reads of the row-major V tiles)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int ss = 0; ss < 2; ++ss) {
+            const u32x4 pf = pack8_h<false>(s[kt], 8 * ss);
+            const u32x4 pl = pack8_lo(s[kt], 8 * ss, pf);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+              const u32x4 vh = trfrag<HDP>(Vs, kt * 32 + 16 * ss, dt * 32, lane);
+              o[dt] = mfma_h<false>(trfrag<HDP>(Vs + TILE, kt * 32 + 16 * ss, dt * 32, lane), pf, o[dt]);
+              o[dt] = mfma_h<false>(vh, pl, o[dt]);
+              o[dt] = mfma_h<false>(vh, pf, o[dt]);
+            }
+          }
+      }
+      // everything issued in this stage -- the next stage's tiles, the next pair's Q rows -- has had the whole stage to land: wait for
+      // it HERE, before the pair's stores are issued, so that the stores drain under the next stage
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (half == 1 && nx < npairs) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          asm volatile("" : "+v"(qn[ks]), "+v"(qnl[ks]));
+          qf[ks] = qn[ks];
+          qlo[ks] = qnl[ks];
+        }
+      }
+    }
+    if (item < items) {
+      const int n = item / H, h = item - n * H;
+      const size_t row = (size_t)n * T + own + frow;
+      const float inv = 1.0f / l_run;
+      const bool h8_out = mode < 0.f && mode > -1.5f, w8_out = mode <= -1.5f;
+      bf16_t* orow = out + row * D * 2 + h * HD;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = dt * 32 + 8 * g + 4 * fhalf;
+          // (the products are written inside the calls, as in the general kernel: the compiler contracts o * inv - hi into one fma when it
+          //  forms the lo / residual part there, and the bits only agree if it may do the same here; tests/test_gpu_x3.py holds both to it)
+          if (w8_out)
+            store4_w8<false>(reinterpret_cast<w8_t*>(out) + row * D, h * HD + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv,
+                             o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+          else if (h8_out)
+            store4_h8<false>(reinterpret_cast<h8_t*>(out) + row * D, h * HD + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv,
+                             o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+          else store4_x3(orow + d, (size_t)D, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+        }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- T == Tp == 256, head_dim 72 (DiT-XL), no mask: persistent, streamed
 // One eight-wave workgroup per CU walks heads (a wave owns 32 of the 256 queries); the K | V tile pairs of 128 keys (52 KiB, rows of
 // 208 bytes, pad columns read from a zero chunk) arrive by LDS-DMA in a two-stage ring, one step ahead, across head boundaries;
@@ -920,6 +1101,16 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
     // (F16F8: the split-bf16 kernel on split-bf16 q | k | v, its output written as fp16 + e4m3 rows for out_proj: flag = scale < 0)
     OSUD_CHECK_ARG(lse == nullptr && fp8_scale <= 0.f, "attention: the split-bf16 tier is inference only");
     const float flag = prec == OSUD_PREC_F16F8 ? -1.0f : (prec == OSUD_PREC_F16W8 ? -2.0f : 0.f);  // (the output form of the split-bf16 kernel)
+    if (head_dim == 64 && T == 128 && Tp == 128 && mask == nullptr && ld_qk == 3 * D && opt(OPT_ATTN_FWD_KERNEL) == 0) {  // the window shape: streamed
+      constexpr size_t slds = (size_t)16 * 64 * AttnTile<64>::RS;
+      OSUD_BIG_LDS_ONCE(attn_fwd_stream_x3_kernel<128>);
+      const int cus = device_cus();
+      const int items = N * heads, npairs = (items + 1) / 2;
+      hipLaunchKernelGGL((attn_fwd_stream_x3_kernel<128>), dim3(npairs < cus ? npairs : cus), dim3(512), slds, st, (const bf16_t*)qk, (bf16_t*)out, D,
+                         heads, items, scale * 1.4426950408889634f, flag);
+      OSUD_HIP(hipGetLastError());
+      return OSUD_OK;
+    }
     dim3 grid((Tp + 127) / 128, heads, N);
     if (head_dim == 64)
       hipLaunchKernelGGL((attn_bf16_kernel<64, 64, 1, true>), grid, dim3(256), 0, st, (const bf16_t*)qk, mask, (bf16_t*)out, lse, T, Tp,

@@ -205,3 +205,25 @@ def test_dit_b_1000_step_cfg4_loop_matches_the_reference(precision, bound):
 
 
 BF16_P1000_BOUND = 2.6e-2  # bf16 tier, 1000 steps: 3x the measured 8.75e-3 (fp32 tier 9.8e-5, split-bf16 tier 1.18e-4, round 3)
+
+
+@pytest.mark.parametrize("prec,N,H", [("bf16x3", 41, 13), ("bf16x3", 128, 12), ("fp16f8", 7, 3), ("fp16w8", 6, 12)])
+def test_streamed_window_kernel_equals_the_general_kernel_bit_for_bit(osud_option, prec, N, H):
+    """T = Tp = 128, head_dim 64, no mask -- the shape of window sampling -- runs `attn_fwd_stream_x3_kernel` (pairs of heads, 64-key stages
+    by LDS-DMA into a double buffer) instead of the general kernel; the arithmetic is the same instruction for instruction, so the
+    outputs are equal BIT FOR BIT in all three output forms (plane pairs, fp16 + e4m3 rows, fp16 + e4m3(v) rows), odd head counts (a
+    half-empty last pair) and more pairs than compute units included."""
+    hd, T_ = 64, 128
+    D, Mp = H * hd, N * T_
+    torch.manual_seed(N * 100 + H)
+    qkc = to_x3(torch.randn(Mp, 3 * D, device=DEV) * 1.7)
+    code = {"bf16x3": _lib.PREC_BF16X3, "fp16f8": _lib.PREC_F16F8, "fp16w8": _lib.PREC_F16W8}[prec]
+    outs = []
+    for general in (1, 0):
+        osud_option("attn_fwd_kernel", general)
+        out = torch.zeros(Mp, 4 * D, dtype=torch.uint8, device=DEV)  # (4 bytes per element in the plane-pair and fp16 + e4m3 forms, 3 in fp16w8)
+        _lib.check(_lib.lib().osud_op_attention(code, _lib.ptr(qkc), 3 * D, None, _lib.ptr(out), N, T_, T_, Mp, H, hd, None))
+        torch.cuda.synchronize()
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert int((outs[1] != 0).sum()) > Mp * D  # (something was written)
