@@ -830,7 +830,9 @@ extern "C" int osud_adamw_ema_step(float* params, const float* grads, float* exp
   if (!same || head > n) head = n;  // differently aligned buffers: everything on the one-element-per-thread path
   // (the grid follows whichever path carries the elements: a misaligned call must still use the whole chip)
   const size_t work = head == n ? n : (n - head) / 4 + 8;
-  const int grid = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
+  // two workgroups per CU, long strides (130 M elements, same box: 512 blocks 787-800 us, 256: 821-845, 1024: 831-846, 4096: 820-844;
+  // non-temporal loads / stores and two 16-byte sets per lane in flight were slower -- tools/adam_bench.py, profiles/r05_ab_runs.md)
+  const int grid = (int)((work + 255) / 256 > 512 ? 512 : (work + 255) / 256);
   const AdamC c{lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, ema_decay, grad_scale};
   hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, ema, n, c,
                      skip_begin, skip_end, head);
