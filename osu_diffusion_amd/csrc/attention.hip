@@ -254,13 +254,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((HD == 64 &
         const int d = dt * 32 + 8 * g + 4 * fhalf;
         if (d < HD) {
           if constexpr (X3) {
-            if (w8_out)
-              store4_w8<false>(reinterpret_cast<w8_t*>(out) + ((size_t)n * Tp + q) * D, h * HD + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv,
-                               o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-            else if (h8_out)  // (OSUD_PREC_F16F8: out_proj reads fp16 + e4m3 rows)
-              store4_h8<false>(reinterpret_cast<h8_t*>(out) + ((size_t)n * Tp + q) * D, h * HD + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv,
-                               o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-            else store4_x3(orow + d, (size_t)D, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+            // (mul_rn: the streamed kernel of the window shape must produce the same bits, see attn_frag.h)
+            const float v0 = mul_rn(o[dt][4 * g + 0], inv), v1 = mul_rn(o[dt][4 * g + 1], inv), v2 = mul_rn(o[dt][4 * g + 2], inv),
+                        v3 = mul_rn(o[dt][4 * g + 3], inv);
+            if (w8_out) store4_w8<false>(reinterpret_cast<w8_t*>(out) + ((size_t)n * Tp + q) * D, h * HD + d, v0, v1, v2, v3);
+            else if (h8_out) store4_h8<false>(reinterpret_cast<h8_t*>(out) + ((size_t)n * Tp + q) * D, h * HD + d, v0, v1, v2, v3);  // (OSUD_PREC_F16F8: out_proj reads fp16 + e4m3 rows)
+            else store4_x3(orow + d, (size_t)D, v0, v1, v2, v3);
           }
           else if (fp8_scale > 0.f) store4(orow8 + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
           else if (F16) store4(reinterpret_cast<f16_t*>(orow) + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
@@ -612,7 +611,8 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const bf16_t* __re
 // other half of a 128 KiB double buffer while this stage is computed, with the online softmax of the general kernel across a head's
 // two stages.  The arithmetic -- three-term products with the small terms first, the rescale, the order of the key blocks -- is the
 // general kernel's, instruction for instruction: the results are bit-identical (tests/test_gpu_x3.py).  Output forms as there:
-// plane pairs (bf16x3), fp16 + e4m3 rows (fp16f8: mode -1) or fp16 + e4m3(v) rows (fp16w8: mode -2).
+// plane pairs (bf16x3), fp16 + e4m3 rows (fp16f8: mode -1) or fp16 + e4m3(v) rows (fp16w8: mode -2).  Rows leave through per-wave
+// LDS patches as whole 64- / 128-byte segments (see the end of the kernel).
 template <int T>
 __global__ __launch_bounds__(512) void attn_fwd_stream_x3_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int D, int H,
                                                                  int items, float c1, float mode) {
@@ -707,9 +707,8 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_x3_kernel(const bf16_t* _
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            float v = s[kt][r] * c1;
-            asm("" : "+v"(v));  // (the ROUNDED product, as in the general kernel, whose select on the mask keeps the compiler from contracting
-            s[kt][r] = v;       //  it into the subtraction below; here it would -- __fmul_rn is a plain multiply to it -- and the bits would differ)
+            const float v = mul_rn(s[kt][r], c1);  // (the ROUNDED product, as in the general kernel, whose select on the mask keeps the compiler
+            s[kt][r] = v;                           //  from contracting it into the subtraction below; here it would, and the bits would differ)
             mx = fmaxf(mx, v);
           }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -761,26 +760,62 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_x3_kernel(const bf16_t* _
       }
     }
     if (item < items) {
+      // Output rows through the wave's 4 KiB LDS patch, one 32-column half (dt) at a time: a lane owns a ROW of the accumulators, so direct
+      // stores touch 32 rows with 4-16 bytes each per instruction -- 16-22 of the kernel's 46-52 us (tools/attn_x3_bench.py, stores
+      // compiled out: 29-30 us).  The half-row image is 128 bytes in every form -- plane pairs: hi 64 | lo 64; fp16 + e4m3 rows: exactly one
+      // K-blocked group of 32 (fp16 64 | e4m3 32 | e4m3 32); fp16 + e4m3(v) rows: fp16 64 | e4m3 32 -- its 16-byte chunks XOR-swizzled
+      // with (row >> 1) & 7, and leaves as 16 bytes per lane, eight lanes per row: whole 64- / 128-byte segments per store instruction.
+      // (mul_rn: the rounded product, as in the general kernel -- attn_frag.h; tests/test_gpu_x3.py holds the two kernels to the same bits.)
       const int n = item / H, h = item - n * H;
-      const size_t row = (size_t)n * T + own + frow;
+      const size_t row0 = (size_t)n * T + own;
       const float inv = 1.0f / l_run;
       const bool h8_out = mode < 0.f && mode > -1.5f, w8_out = mode <= -1.5f;
-      bf16_t* orow = out + row * D * 2 + h * HD;
+      char* const patch = smem + 2 * 8 * TILE + wave * 4096;
+      char* const prow = patch + frow * 128;
+      const int sw = (frow >> 1) & 7;
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
+      for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int d = dt * 32 + 8 * g + 4 * fhalf;
-          // (the products are written inside the calls, as in the general kernel: the compiler contracts o * inv - hi into one fma when it
-          //  forms the lo / residual part there, and the bits only agree if it may do the same here; tests/test_gpu_x3.py holds both to it)
-          if (w8_out)
-            store4_w8<false>(reinterpret_cast<w8_t*>(out) + row * D, h * HD + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv,
-                             o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-          else if (h8_out)
-            store4_h8<false>(reinterpret_cast<h8_t*>(out) + row * D, h * HD + d, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv,
-                             o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
-          else store4_x3(orow + d, (size_t)D, o[dt][4 * g + 0] * inv, o[dt][4 * g + 1] * inv, o[dt][4 * g + 2] * inv, o[dt][4 * g + 3] * inv);
+          const float v0 = mul_rn(o[dt][4 * g + 0], inv), v1 = mul_rn(o[dt][4 * g + 1], inv), v2 = mul_rn(o[dt][4 * g + 2], inv),
+                      v3 = mul_rn(o[dt][4 * g + 3], inv);
+          uint2 hi;
+          if (w8_out) {
+            uint32_t p8;
+            pack4_w8<false>(v0, v1, v2, v3, hi, p8);
+            *reinterpret_cast<uint32_t*>(prow + (((4 + (g >> 1)) ^ sw) << 4) + 8 * (g & 1) + 4 * fhalf) = p8;
+          } else if (h8_out) {
+            uint32_t p64, p96;
+            pack4_h8<false>(v0, v1, v2, v3, hi, p64, p96);
+            *reinterpret_cast<uint32_t*>(prow + (((4 + (g >> 1)) ^ sw) << 4) + 8 * (g & 1) + 4 * fhalf) = p64;
+            *reinterpret_cast<uint32_t*>(prow + (((6 + (g >> 1)) ^ sw) << 4) + 8 * (g & 1) + 4 * fhalf) = p96;
+          } else {
+            uint2 lo;
+            pack4_x3(v0, v1, v2, v3, hi, lo);
+            *reinterpret_cast<uint2*>(prow + (((4 + g) ^ sw) << 4) + 8 * fhalf) = lo;
+          }
+          *reinterpret_cast<uint2*>(prow + ((g ^ sw) << 4) + 8 * fhalf) = hi;
         }
+        asm volatile("" ::: "memory");  // (LDS operations of a wave execute in order; this only pins the compiler's order)
+        const int x0 = h * HD + dt * 32;  // first logical column of this half
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int rr = 8 * k + (lane >> 3), c = lane & 7;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(patch + rr * 128 + ((c ^ ((rr >> 1) & 7)) << 4));
+          const size_t row = row0 + rr;
+          if (w8_out) {
+            char* gsg = reinterpret_cast<char*>(out) + row * D * 3 + (size_t)(x0 >> 7) * 384;
+            const int i = x0 & 127;
+            if (c < 4) *reinterpret_cast<u32x4*>(gsg + 2 * i + c * 16) = v;
+            else if (c < 6) *reinterpret_cast<u32x4*>(gsg + 256 + i + (c - 4) * 16) = v;
+          } else if (h8_out) {
+            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(out) + row * D * 4 + (size_t)(x0 >> 5) * 128 + c * 16) = v;
+          } else {
+            *reinterpret_cast<u32x4*>(out + row * D * 2 + (c < 4 ? 0 : D) + x0 + (c & 3) * 8) = v;
+          }
+        }
+        asm volatile("" ::: "memory");
+      }
     }
   }
 }
@@ -1102,7 +1137,7 @@ int launch_attention(int prec, const void* qk, int ld_qk, const uint8_t* mask, v
     OSUD_CHECK_ARG(lse == nullptr && fp8_scale <= 0.f, "attention: the split-bf16 tier is inference only");
     const float flag = prec == OSUD_PREC_F16F8 ? -1.0f : (prec == OSUD_PREC_F16W8 ? -2.0f : 0.f);  // (the output form of the split-bf16 kernel)
     if (head_dim == 64 && T == 128 && Tp == 128 && mask == nullptr && ld_qk == 3 * D && opt(OPT_ATTN_FWD_KERNEL) == 0) {  // the window shape: streamed
-      constexpr size_t slds = (size_t)16 * 64 * AttnTile<64>::RS;
+      constexpr size_t slds = (size_t)16 * 64 * AttnTile<64>::RS + 8 * 4096;  // double buffer + a 4 KiB output patch per wave = 160 KiB
       OSUD_BIG_LDS_ONCE(attn_fwd_stream_x3_kernel<128>);
       const int cus = device_cus();
       const int items = N * heads, npairs = (items + 1) / 2;

@@ -79,6 +79,15 @@ template <bool F16> __device__ __forceinline__ u32x4 pack8_h(const f32x16& v, in
   return r;
 }
 
+// a * b ROUNDED to fp32 before anything consumes it: an output split into hi + lo (or fp16 + residual) parts subtracts the hi part from the
+// product, and the compiler contracts that into one fma in some kernels and not in others (it depends on how many uses the product
+// has after inlining) -- two kernels that must produce the same bits pin the product with this
+__device__ __forceinline__ float mul_rn(float a, float b) {
+  float v = a * b;
+  asm("" : "+v"(v));
+  return v;
+}
+
 // split-bf16 tier: the lo halves of the same 8 values, given their packed hi halves: bf16(v - float(hi))
 __device__ __forceinline__ u32x4 pack8_lo(const f32x16& v, int base, const u32x4& hi) {
   u32x4 r;

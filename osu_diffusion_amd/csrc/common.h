@@ -214,10 +214,13 @@ __device__ __forceinline__ void store2_x3(bf16_t* p, size_t ld, float a, float b
   *reinterpret_cast<uint32_t*>(p) = hi;
   *reinterpret_cast<uint32_t*>(p + ld) = lo;
 }
-__device__ __forceinline__ void store4_x3(bf16_t* p, size_t ld, float a, float b, float c, float d) {
-  uint2 hi, lo;
+__device__ __forceinline__ void pack4_x3(float a, float b, float c, float d, uint2& hi, uint2& lo) {
   split_hi_lo(a, b, hi.x, lo.x);
   split_hi_lo(c, d, hi.y, lo.y);
+}
+__device__ __forceinline__ void store4_x3(bf16_t* p, size_t ld, float a, float b, float c, float d) {
+  uint2 hi, lo;
+  pack4_x3(a, b, c, d, hi, lo);
   *reinterpret_cast<uint2*>(p) = hi;
   *reinterpret_cast<uint2*>(p + ld) = lo;
 }
@@ -246,17 +249,24 @@ __device__ __forceinline__ uint32_t pack_h2(float a, float b, float& ra, float& 
   rb = b - (float)h[1];
   return __builtin_bit_cast(uint32_t, h);
 }
+// (the bytes of 4 consecutive elements: `hi` for byte 2 i of the group, `p64` / `p96` for bytes 64 + i / 96 + i)
+template <bool WEIGHT> __device__ __forceinline__ void pack4_h8(float a, float b, float c, float d, uint2& hi, uint32_t& p64, uint32_t& p96) {
+  float r0, r1, r2, r3;
+  hi.x = pack_h2(a, b, r0, r1);
+  hi.y = pack_h2(c, d, r2, r3);
+  const uint32_t lo8 = pack_fp8x4(r0 * kH8LoScale, r1 * kH8LoScale, r2 * kH8LoScale, r3 * kH8LoScale), hi8 = pack_fp8x4(a, b, c, d);
+  p64 = WEIGHT ? hi8 : lo8;
+  p96 = WEIGHT ? lo8 : hi8;
+}
 template <bool WEIGHT> __device__ __forceinline__ void store4_h8(h8_t* row, int x, float a, float b, float c, float d) {
   char* g = reinterpret_cast<char*>(row) + (size_t)(x >> 5) * 128;
   const int i = x & 31;
-  float r0, r1, r2, r3;
   uint2 hi;
-  hi.x = pack_h2(a, b, r0, r1);
-  hi.y = pack_h2(c, d, r2, r3);
+  uint32_t p64, p96;
+  pack4_h8<WEIGHT>(a, b, c, d, hi, p64, p96);
   *reinterpret_cast<uint2*>(g + 2 * i) = hi;
-  const uint32_t lo8 = pack_fp8x4(r0 * kH8LoScale, r1 * kH8LoScale, r2 * kH8LoScale, r3 * kH8LoScale), hi8 = pack_fp8x4(a, b, c, d);
-  *reinterpret_cast<uint32_t*>(g + 64 + i) = WEIGHT ? hi8 : lo8;
-  *reinterpret_cast<uint32_t*>(g + 96 + i) = WEIGHT ? lo8 : hi8;
+  *reinterpret_cast<uint32_t*>(g + 64 + i) = p64;
+  *reinterpret_cast<uint32_t*>(g + 96 + i) = p96;
 }
 template <bool WEIGHT> __device__ __forceinline__ void store8_h8(h8_t* row, int x, const float (&v)[8]) {
   char* g = reinterpret_cast<char*>(row) + (size_t)(x >> 5) * 128;
@@ -286,16 +296,20 @@ template <bool WEIGHT> __device__ __forceinline__ void store2_h8(h8_t* row, int 
   *reinterpret_cast<uint16_t*>(g + 96 + i) = WEIGHT ? lo8 : hi8;
 }
 // ---- fp16 + one e4m3 plane rows (w8_t): 8 / 4 / 2 consecutive logical elements at column x of the row starting at `row`
+template <bool WEIGHT> __device__ __forceinline__ void pack4_w8(float a, float b, float c, float d, uint2& hi, uint32_t& p8) {
+  float r0, r1, r2, r3;
+  hi.x = pack_h2(a, b, r0, r1);
+  hi.y = pack_h2(c, d, r2, r3);
+  p8 = WEIGHT ? pack_fp8x4(r0 * kH8LoScale, r1 * kH8LoScale, r2 * kH8LoScale, r3 * kH8LoScale) : pack_fp8x4(a, b, c, d);
+}
 template <bool WEIGHT> __device__ __forceinline__ void store4_w8(w8_t* row, int x, float a, float b, float c, float d) {
   char* g = reinterpret_cast<char*>(row) + (size_t)(x >> 7) * 384;
   const int i = x & 127;
-  float r0, r1, r2, r3;
   uint2 hi;
-  hi.x = pack_h2(a, b, r0, r1);
-  hi.y = pack_h2(c, d, r2, r3);
+  uint32_t p8;
+  pack4_w8<WEIGHT>(a, b, c, d, hi, p8);
   *reinterpret_cast<uint2*>(g + 2 * i) = hi;
-  *reinterpret_cast<uint32_t*>(g + 256 + i) =
-      WEIGHT ? pack_fp8x4(r0 * kH8LoScale, r1 * kH8LoScale, r2 * kH8LoScale, r3 * kH8LoScale) : pack_fp8x4(a, b, c, d);
+  *reinterpret_cast<uint32_t*>(g + 256 + i) = p8;
 }
 template <bool WEIGHT> __device__ __forceinline__ void store8_w8(w8_t* row, int x, const float (&v)[8]) {
   char* g = reinterpret_cast<char*>(row) + (size_t)(x >> 7) * 384;
