@@ -584,7 +584,17 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x16 (&acc)[RY][
           float dg[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) gelu_tanh_both_t<FAST>(v[e], w[e], dg[e]);
-          store8_out<TO>(p.out2, orow, p.ldo, x, dg);
+          // The derivative is read again a whole forward pass later: a streaming (non-temporal) store keeps its 201 MB from displacing
+          // the GELU output next to it, which the fc2 forward GEMM reads right away.  Same box, in-step: this launch 184 -> 173 us, the
+          // GEMM after it 103 -> 97 us, the training step -0.3 ms.  (Measured and not taken: the same hint on the GELU output itself
+          // 180 us; on the backward's loads of the derivative +5 us; on that launch's output +20 us -- profiles/r05_ab_runs.md.)
+          if constexpr (std::is_same<TO, bf16_t>::value) {
+            typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+            const u4v u = {pack_bf2(dg[0], dg[1]), pack_bf2(dg[2], dg[3]), pack_bf2(dg[4], dg[5]), pack_bf2(dg[6], dg[7])};
+            __builtin_nontemporal_store(u, reinterpret_cast<u4v*>(reinterpret_cast<bf16_t*>(p.out2) + orow * (size_t)p.ldo + x));
+          } else {
+            store8_out<TO>(p.out2, orow, p.ldo, x, dg);
+          }
           if constexpr (kOut8) {
             if (out8_on) {
               float q8[8];
