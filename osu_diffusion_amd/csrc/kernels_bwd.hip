@@ -234,10 +234,23 @@ __global__ __launch_bounds__(256, OSUD_LNB_OCC(VPL)) void ln_mod_bwd_kernel(cons
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int d = W * lane + 64 * W * g;
-      loadw<W>(h + row + d, R.hv + g * W);
+      // h (the forward's saved residual stream) and br_next (the saved branch output) are read here for the last time: streaming
+      // loads, so that they do not displace what the next launches read (training step -0.1 ... -0.2 ms in three same-box
+      // alternations; the same hint on dh_skip as well: no further gain -- profiles/r05_ab_runs.md)
+      if constexpr (W == 4) {
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(h + row + d));
+        R.hv[g * W + 0] = t[0]; R.hv[g * W + 1] = t[1]; R.hv[g * W + 2] = t[2]; R.hv[g * W + 3] = t[3];
+      } else loadw<W>(h + row + d, R.hv + g * W);
       R.dv[g].load(du + row + d);
       loadw<W>(dh_skip + row + d, R.sk + g * W);
-      if constexpr (GATE) R.bn[g].load(br_next + row + d);
+      if constexpr (GATE) {
+        if constexpr (W == 4 && sizeof(TE) == 2) {
+          typedef uint32_t u2v __attribute__((ext_vector_type(2)));
+          const u2v t = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(br_next + row + d));
+          R.bn[g].u[0] = t[0]; R.bn[g].u[1] = t[1];
+        } else R.bn[g].load(br_next + row + d);
+      }
     }
     R.mu = stats[2 * (size_t)m];
     R.rstd = stats[2 * (size_t)m + 1];
