@@ -298,7 +298,13 @@ __global__ __launch_bounds__(256, OSUD_LNB_OCC(VPL)) void ln_mod_bwd_kernel(cons
           b[e] = gt[e] * o[e];
         }
       }
-      storew<W>(dh_out + row + d, o);
+      if constexpr (W == 4) {  // (streaming store, as ln_mod_kernel's residual stream: its next reader is the LayerNorm backward after next)
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v t = {o[0], o[1], o[2], o[3]};
+        __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(dh_out + row + d));
+      } else {
+        storew<W>(dh_out + row + d, o);
+      }
       if constexpr (GATE) {
         if (dbr != nullptr) storew<W>(dbr + row + d, b);  // (null: only the e4m3 twin is consumed this step)
         if (twin) {

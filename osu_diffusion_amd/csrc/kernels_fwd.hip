@@ -183,7 +183,17 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* h, const float
     }
     if (h_out != nullptr) {
 #pragma unroll
-      for (int g = 0; g < NG; ++g) storew<W>(h_out + (size_t)m * D + W * lane + 64 * W * g, v + g * W);
+      for (int g = 0; g < NG; ++g) {
+        // (streaming store: the updated residual stream is read again four launches later, behind 300 MB of other outputs -- stored
+        //  normally it only displaces the rows the next GEMM reads; training step -0.10 ms, profiles/r05_ab_runs.md)
+        if constexpr (W == 4) {
+          typedef float f4v __attribute__((ext_vector_type(4)));
+          const f4v t = {v[g * W + 0], v[g * W + 1], v[g * W + 2], v[g * W + 3]};
+          __builtin_nontemporal_store(t, reinterpret_cast<f4v*>(h_out + (size_t)m * D + W * lane + 64 * W * g));
+        } else {
+          storew<W>(h_out + (size_t)m * D + W * lane + 64 * W * g, v + g * W);
+        }
+      }
     }
   }
 #pragma unroll
