@@ -224,10 +224,24 @@ __global__ void splitk_reduce_kernel(const float4* __restrict__ part, int splits
       const f4v t = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(part + k));
       return make_float4(t[0], t[1], t[2], t[3]);
     };
+    // eight slabs in flight per lane, added in slab order (the order of the sum is part of the result: gradients are bit-reproducible)
     float4 a = ld(i);
-    for (int s = 1; s < splits; ++s) {
-      const float4 b = ld((size_t)s * stride4 + i);
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    int s = 1;
+    for (; s + 8 <= splits; s += 8) {
+      float4 b[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[j] = ld((size_t)(s + j) * stride4 + i);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a.x += b[j].x; a.y += b[j].y; a.z += b[j].z; a.w += b[j].w; }
+    }
+    if (s < splits) {
+      float4 b[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (s + j < splits) b[j] = ld((size_t)(s + j) * stride4 + i);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (s + j < splits) { a.x += b[j].x; a.y += b[j].y; a.z += b[j].z; a.w += b[j].w; }
     }
     out[i] = a;
   }
