@@ -4,8 +4,9 @@
     python bench.py --gpus N --steps K --warmup W [--mode sample|train]
 
 N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`
-(one rank per GPU).  Prints ONE JSON line on rank 0 (contract in the task description; DESIGN.md §5
-says how each number is obtained).
+(one rank per GPU).  Prints ONE JSON line on rank 0, at most 4 KB (`compact_line`: the contract fields, `roofline`,
+`cpu_baseline`, a `sampling` summary); the full report goes to bench_detail.json next to this file and to stderr
+(DESIGN.md §5 says how each number is obtained).
 
 mode train (BASELINE.json configs[1], the configuration the headline metric is quoted on): DiT-B,
   seq-len 128, per-GPU batch 256 synthetic windows, bf16 MFMA tier, one "step" = everything in the
@@ -109,7 +110,7 @@ class Watchdog:
                 out = {k: v for k, v in self.res.items()}
                 out["diagnostics_incomplete"] = {"stage": self.stage, "after_s": self.seconds,
                                                  "note": "a diagnostic after the timed region did not return; value / ms_per_step are the completed timed region"}
-                print(json.dumps(out, default=str), flush=True)
+                emit(out)
             else:
                 time.sleep(2.0)  # (rank 0's line first)
             os._exit(WATCHDOG_EXIT)
@@ -250,7 +251,7 @@ def wgrad_roofline(M, D, dev, iters=8):
                    "read side x2 per the gfx950 note)")
     except Exception:
         pass
-    return {"bound": "mfma", "kernel": "wgrad_kernel<2,4,4,2> + splitk_reduce_kernel (the four weight gradients of a block, %d tokens, D = %d)" % (M, D),
+    return {"bound": "mfma", "kernel": "wgrad_phased_kernel + splitk_reduce_kernel (a block's four weight gradients, %d tokens, D = %d)" % (M, D),
             "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
             "frac_of_random_operand_ceiling": round(ach / MFMA_RANDOM_OPERAND_CEILING_TFLOPS, 4),
             "random_operand_ceiling": {"value": MFMA_RANDOM_OPERAND_CEILING_TFLOPS, "unit": "TFLOP/s",
@@ -965,6 +966,118 @@ def bench_xl(args, world, rank, dev, precision="bf16", steps=None, warmup=None):
     return out
 
 
+LINE_LIMIT = 4000  # bytes: the driver reads the LAST stdout line from a bounded tail (round 5's 22.5 KB report was not parsed)
+DETAIL_FILE = os.path.join(ROOT, "bench_detail.json")
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def _cut(s, n):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 1] + "~"
+
+
+def compact_line(res):
+    """The ONE stdout line: the contract fields + `roofline` + `cpu_baseline` + a six-field `sampling` summary (+ `multi_gpu` for
+    N > 1), every string cut short, <= LINE_LIMIT bytes by construction (tests/test_bench_line.py).  Everything else a run measures
+    (per-family table, per-kernel rows, stand-alone timings, the other tiers, drift tables, the fp32 tier, DiT-XL) is written to
+    bench_detail.json next to this file and echoed on stderr."""
+    out = _pick(res, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    out["vs_baseline"] = res.get("vs_baseline")
+    out.update(_pick(res, ("dtype", "data")))
+    out["metric"] = _cut(out.get("metric"), 80)
+    out["dtype"] = _cut(out.get("dtype"), 24)
+    cfg = dict(res.get("config") or {})
+    for k, n in (("workload", 170), ("parallelism", 150), ("sharding", 40)):
+        if k in cfg:
+            cfg[k] = _cut(cfg[k], n)
+    out["config"] = cfg
+    if "end_to_end" in res:
+        out["end_to_end"] = _pick(res["end_to_end"], ("achieved_tflops_per_gpu", "achieved_tflops", "mfma_frac", "mfma_frac_of_mixed_peak"))
+    rf = res.get("roofline")
+    if isinstance(rf, dict):
+        r = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes", "flop_per_launch", "avg_launch_us", "measured"))
+        r["kernel"] = _cut(r.get("kernel"), 90)
+        r["measured"] = _cut(r.get("measured"), 60)
+        r.setdefault("traffic", None)
+        low = rf.get("lowest_fraction_top_family")
+        if isinstance(low, dict):
+            r["lowest_fraction_top_family"] = _pick(low, ("family", "ms_per_step", "share", "frac", "heaviest_kernel", "heaviest_kernel_frac"))
+        pf = rf.get("per_family")
+        if isinstance(pf, dict) and "families" in pf:
+            r["non_mfma_ms_per_step"] = pf.get("non_mfma_ms_per_step")
+            r["family_frac"] = {k: v["frac"] for k, v in pf["families"].items() if "frac" in v and v.get("share", 0) >= 0.04}
+        fc1 = rf.get("fc1_forward")
+        if isinstance(fc1, dict):
+            r["fc1_forward"] = _pick(fc1, ("avg_launch_us", "frac", "traffic", "algorithmic_bytes"))
+        out["roofline"] = r
+    if "cpu_baseline" in res:
+        cb = dict(res["cpu_baseline"])
+        cb["sample"] = _cut(cb.get("sample"), 150)
+        out["cpu_baseline"] = cb
+    sp = res.get("sampling")
+    if isinstance(sp, dict):
+        tol = (sp.get("tolerance") or {}).get("this_line") or {}
+        s = _pick(sp, ("value", "unit", "tier", "ms_per_step", "steps"))
+        s["meets_1e-3"] = tol.get("meets", (sp.get("tolerance") or {}).get("meets_1e-3"))
+        if "held_by_every_reference_fixture" in tol:
+            s["held_by_every_reference_fixture"] = tol["held_by_every_reference_fixture"]
+            s["max_drift_vs_fp32_tier"] = tol.get("max_drift_vs_fp32_tier")
+        s["mfma_frac"] = (sp.get("end_to_end") or {}).get("mfma_frac")
+        cb = sp.get("cpu_baseline") or ((sp.get("also") or {}).get("bf16") or {}).get("cpu_baseline")
+        if cb:
+            s["cpu_baseline"] = dict(_pick(cb, ("value", "unit", "cores", "kind")), sample=_cut(cb.get("sample"), 90))
+        also = {}
+        for name, v in (sp.get("also") or {}).items():
+            if isinstance(v, dict) and "value" in v:
+                m = v.get("meets_1e-3", (v.get("tolerance") or {}).get("meets_1e-3"))
+                also[name] = {"value": v["value"], "meets_1e-3": m} if m is not None else {"value": v["value"]}
+        if also:
+            s["also"] = also
+        out["sampling"] = s
+    if "parity_tier" in res:
+        pt = res["parity_tier"]
+        out["parity_tier"] = {k: _pick(pt[k], ("value", "unit", "mfma_frac_of_f32_peak")) for k in ("train", "sample") if k in pt}
+    if "xl" in res:
+        out["xl"] = {p: dict(_pick(v, ("value", "unit", "ms_per_step")), mfma_frac=(v.get("end_to_end") or {}).get("mfma_frac")) for p, v in res["xl"].items()}
+    if "pcie_inclusive" in res:
+        out["pcie_inclusive"] = _pick(res["pcie_inclusive"], ("value", "unit", "ms_per_step"))
+    mg = res.get("multi_gpu")
+    if isinstance(mg, dict):
+        m = _pick(mg, ("rccl", "fastest_schedule", "schedule_selected", "exposed_comm_ms_per_step", "timed_schedule", "wire_bytes_per_step", "multi_gpu_schedule_compute_floor_ms"))
+        m["schedules"] = {k: ({kk: _cut(vv, 80) for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in (mg.get("schedules") or {}).items()}
+        pc = mg.get("predicted_comm_ms_per_step")
+        if isinstance(pc, dict):
+            m["predicted_comm_ms_per_step"] = {k: v for k, v in pc.items() if k != "note"}
+        out["multi_gpu"] = m
+    if "multi_gpu_schedule_compute_floor_ms" in res:
+        out["multi_gpu_schedule_compute_floor_ms"] = res["multi_gpu_schedule_compute_floor_ms"]
+    if "diagnostics_incomplete" in res:
+        out["diagnostics_incomplete"] = _pick(res["diagnostics_incomplete"], ("stage", "after_s"))
+    out["detail"] = "bench_detail.json (next to bench.py; also echoed on stderr)"
+    line = json.dumps(out, default=str)
+    # by construction the line is well below the limit; should a future field outgrow it, drop the optional objects, never the contract fields
+    for k in ("pcie_inclusive", "parity_tier", "xl", "end_to_end", "multi_gpu"):
+        if len(line) <= LINE_LIMIT:
+            break
+        out.pop(k, None)
+        line = json.dumps(out, default=str)
+    return line
+
+
+def emit(res):
+    """Rank 0: the full report to bench_detail.json and stderr, the compact line LAST on stdout."""
+    full = json.dumps(res, default=str)
+    try:
+        with open(DETAIL_FILE, "w") as f:
+            f.write(full + "\n")
+    except OSError as e:  # (a read-only tree must not cost the line)
+        print(f"bench_detail.json not written: {e}", file=sys.stderr, flush=True)
+    print("bench_detail " + full, file=sys.stderr, flush=True)
+    print(compact_line(res), flush=True)
+
+
 def main():
     args = parse()
     world, rank, local = dist_setup(args)
@@ -1020,7 +1133,7 @@ def main():
             res["xl"] = {p: bench_xl(args, world, rank, dev, p) for p in ([args.xl_precision] if args.xl_precision else XL_TIERS)}
     WATCHDOG.disarm()
     if rank == 0:
-        print(json.dumps(res), flush=True)
+        emit(res)
     if world > 1:
         import torch.distributed as dist
 
