@@ -297,9 +297,12 @@ int osud_set_gemm_dynamic_tiles(int on);
  *   debug_sync          0        1: synchronise after every stage of the backward pass and name it on stderr (fault triage)
  *   f16m8_forms         11       OSUD_PREC_F16M8: bit i = 1 puts GEMM i of a block (0 in_proj, 1 out_proj, 2 fc1, 3 fc2) on fp16-activation operands;
  *                                read by osud_dit_create
- *   gemm_loop           1        main loop of the 256-row GEMM tiles (every operand form) and of the 256 x 256 weight-gradient kernel: 1: the phased
+ *   gemm_loop           1        main loop of the 256-row GEMM tiles (bf16, fp16, fp16 + e4m3 and e4m3 operands) and of the 256 x 256 weight-gradient kernel: 1: the phased
  *                                schedule (the two waves of a SIMD one barrier apart, counted vmcnt: csrc/gemm_phased.h); 0: one barrier per K
- *                                slab.  Same bits. */
+ *                                slab.  Same bits.
+ *   gelu_code           1        bf16 / fp8 training tiers: the GELU derivative saved by the fc1 epilogue for the backward pass is an 8-bit code
+ *                                (step 1 / 200, absolute error <= 2.5e-3, 0 and 1 exact; 32 x 32 blocks of 1 KiB) instead of bf16 rows: half the
+ *                                bytes out of fc1's epilogue and into the fc2 data gradient's.  0: bf16 rows.  Read by osud_dit_create. */
 int osud_set_option(const char* name, int value);
 int osud_get_option(const char* name, int* value);
 

@@ -520,6 +520,26 @@ template <bool FAST> __device__ __forceinline__ void gelu_tanh_both_t(float z, f
   }
 }
 
+// The saved GELU derivative as an 8-bit code (option gelu_code): tanh-GELU's derivative lies in [-0.1289, 1.1289]; code c = rne(200 dg) + 26,
+// dg' = (c - 26) / 200: absolute error <= 2.5e-3 (bf16 near 1: 2e-3), 0 and 1 -- the saturated ends -- exact.  A tensor of codes is a grid of
+// 32 x 32 blocks of 1 KiB, block (y / 32, x / 32) at ((y / 32) * (ld / 32) + x / 32) * 1024; inside a block the GEMM epilogue's lane l = 4 * (row & 15)
+// + (col >> 3) holds 16 bytes at 16 l: columns (col & ~7) .. + 7 of row (row & 15), then of row 16 + (row & 15) -- one 1 KiB store / load per wave.
+constexpr float kGeluCodeScale = 200.0f, kGeluCodeZero = 26.0f;
+__device__ __forceinline__ uint32_t gelu_code4(float a, float b, float c, float d) {  // four derivatives -> four code bytes (a lowest)
+  // (v + 2^23: the integer nearest to v, ties to even, sits in the low mantissa bits; 0 <= v <= 252 for every finite z)
+  const uint32_t ua = __float_as_uint(fmaf(a, kGeluCodeScale, kGeluCodeZero + 8388608.0f)), ub = __float_as_uint(fmaf(b, kGeluCodeScale, kGeluCodeZero + 8388608.0f));
+  const uint32_t uc = __float_as_uint(fmaf(c, kGeluCodeScale, kGeluCodeZero + 8388608.0f)), ud = __float_as_uint(fmaf(d, kGeluCodeScale, kGeluCodeZero + 8388608.0f));
+  const uint32_t lo = __builtin_amdgcn_perm(ub, ua, 0x0c0c0400u), hi = __builtin_amdgcn_perm(ud, uc, 0x0c0c0400u);
+  return lo | (hi << 16);
+}
+__device__ __forceinline__ void gelu_decode4(uint32_t w, float* o) {
+  constexpr float s = 1.0f / kGeluCodeScale, z = -kGeluCodeZero / kGeluCodeScale;
+  o[0] = fmaf((float)(w & 0xffu), s, z);
+  o[1] = fmaf((float)((w >> 8) & 0xffu), s, z);
+  o[2] = fmaf((float)((w >> 16) & 0xffu), s, z);
+  o[3] = fmaf((float)(w >> 24), s, z);
+}
+
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 // bytes per LOGICAL element (the split-bf16 tier stores two bf16 planes)
 static inline size_t elem_size(int prec) {

@@ -99,6 +99,7 @@ struct osud_dit {
   int D = 0, L = 0, H = 0, hd = 0, E = 0, C = 0, C2 = 0, Kp = 0, prec = 0, esz = 0, ada_cols = 0;
   int Ke = 0;                // row length of e0 / w_e: Kp, or 3 * Kp in the split form of the bf16 tier's first linear
   bool split_first = false;
+  bool z1_code = false;  // the saved GELU derivative (saved[l].z1) is the 8-bit block code of common.h (option gelu_code at create; bf16 / fp8 training tiers)
   int device = -1;
   bool training = false;
   bool h8 = false;   // OSUD_PREC_F16F8: prec == BF16X3 (x3 set), and the four big GEMMs of every block on fp16 + e4m3 operands (h8_t): their
@@ -210,6 +211,7 @@ inline int gemm(osud_dit* m, int epi, const void* Y, int ldy, const void* X, int
   p.Y = Y; p.X = X; p.ldy = ldy; p.ldx = ldx; p.My = My; p.Nx = Nx; p.K = K;
   p.out = out; p.out2 = out2; p.ldo = ldo; p.bias = bias; p.gate = gate; p.ld_gate = ld_gate;
   p.rows_per_sample = Tp; p.n_samples = N; p.res = res; p.aux = aux;
+  p.aux_code = (m->z1_code && ((epi == EPI_BIAS_GELU_TE && out2 != nullptr) || (epi == EPI_GELUGRAD_TE && aux != nullptr))) ? 1 : 0;
   return launch_gemm(prec >= 0 ? prec : m->prec, epi, p, st);
 }
 // one of the four big GEMMs of a block (in_proj, out_proj, fc1, fc2): OSUD_PREC_F16F8 runs these -- and only these -- on fp16 + e4m3
@@ -234,7 +236,7 @@ inline int gemm8(osud_dit* m, int epi, const void* Y, const void* X, int My, int
   p.rows_per_sample = Tp; p.n_samples = N; p.colscale = dequant; p.out_scale = out_scale;
   p.act_inv_host = act_inv_host; p.act_inv = act_inv_dev; p.out2 = out2; p.aux = aux; p.colpart = colpart; p.colpart_rows = colpart_rows;
   p.out8 = out8; p.out8_slot = out8_slot;
-  (void)m;
+  p.aux_code = (m->z1_code && ((epi == EPI_BIAS_GELU_BF && out2 != nullptr) || (epi == EPI_GELUGRAD_TE && aux != nullptr))) ? 1 : 0;
   return launch_gemm(OSUD_PREC_FP8, epi, p, st);
 }
 

@@ -79,7 +79,7 @@ int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
       OSUD_TRY(dev_alloc(W, &s.qk, (size_t)Mp * 3 * D * es));
       OSUD_TRY(dev_alloc(W, &s.ao, (size_t)Mp * D * es));
       OSUD_TRY(dev_alloc(W, &s.u2, (size_t)Mp * D * es));
-      OSUD_TRY(dev_alloc(W, &s.z1, (size_t)Mp * 4 * D * es));
+      OSUD_TRY(dev_alloc(W, &s.z1, (size_t)Mp * 4 * D * (m->z1_code ? 1 : es)));  // (Mp % 128 == 0: whole 32 x 32 code blocks)
       OSUD_TRY(dev_alloc(W, &s.g, (size_t)Mp * 4 * D * es));
       OSUD_TRY(dev_alloc(W, &s.br1, (size_t)Mp * D * es));
       OSUD_TRY(dev_alloc(W, &s.br2, (size_t)Mp * D * es));
@@ -430,6 +430,7 @@ extern "C" int osud_dit_create(const osud_dit_cfg* cfg, osud_dit** out) {
     m->split_first = (m->prec == OSUD_PREC_BF16 || m->prec == OSUD_PREC_F16) && opt(OPT_SPLIT_FIRST) != 0 && (size_t)16 * m->Kp * 6 <= 64 * 1024;
   }
   m->Ke = m->split_first ? 3 * m->Kp : m->Kp;
+  m->z1_code = m->prec == OSUD_PREC_BF16 && opt(OPT_GELU_CODE) != 0 && (4 * m->D) % 32 == 0;
   m->ada_cols = 6 * m->D * m->L + 2 * m->D;
   if (hipGetDevice(&m->device) != hipSuccess) {
     delete m;

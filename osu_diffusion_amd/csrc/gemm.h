@@ -51,6 +51,8 @@ struct GemmP {
   int rows_per_sample;  // Tp
   int n_samples;
   const void* aux;   // TE [My][ldo] (EPI_GELUGRAD_TE: saved GELU derivative)
+  int aux_code;      // 1 (bf16-typed outputs only): the saved GELU derivative -- out2 of the GELU epilogues, aux of EPI_GELUGRAD_TE -- is the 8-bit
+                     // block code of common.h (gelu_code: one byte per element, 32 x 32 blocks of 1 KiB in the epilogue's lane order) instead of TE rows
   const float* res;  // EPI_GATE_RES: residual input [My][ldo]; nullptr = update `out` in place
   const float* colscale;  // fp8 operands only: out = epilogue(acc * colscale[x]) -- the product of the activation and per-output-channel
                           // weight de-quantisation factors
@@ -91,6 +93,8 @@ enum Opt {
                               // 0 on fp16 + e4m3 operands (h8_t); read by osud_dit_create
   OPT_GEMM_LOOP,              // 1: the 256-row GEMM tiles (bf16 / fp16 / fp16 + e4m3 / e4m3 operands) and the 256 x 256 weight-gradient kernel run the
                               // phased main loop (gemm_phased.h: the two waves of a SIMD one barrier apart); 0: one barrier per K slab.  Same bits.
+  OPT_GELU_CODE,              // 1: bf16 / fp8 training tiers save the GELU derivative for the backward pass as an 8-bit code (step 1 / 200 over [-0.13, 1.145]:
+                              // absolute error <= 2.5e-3, 0 and 1 exact) in 32 x 32 blocks: half the bytes of the bf16 rows.  Read by osud_dit_create.
   OPT_COUNT
 };
 int opt(Opt o);

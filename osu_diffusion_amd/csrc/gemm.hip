@@ -78,6 +78,7 @@ constexpr OptDef kOpts[OPT_COUNT] = {
     {"wgrad_side_stream", 1, 0, 1}, {"sample_graph", 1, 0, 1},    {"embed_const", 1, 0, 1},  {"tvec_table", 1, 0, 1},
     {"split_first", 1, 0, 1},       {"attn_fwd_kernel", 0, 0, 2}, {"attn_bwd_kernel", 0, 0, 2}, {"gemm_tile", 0, 0, 1256},
     {"f8_twins_only", 1, 0, 1},     {"debug_sync", 0, 0, 1},      {"f16m8_forms", 11, 0, 15},    {"gemm_loop", 1, 0, 1},
+    {"gelu_code", 1, 0, 1},
 };
 std::atomic<int> g_opt[OPT_COUNT];
 std::atomic<unsigned> g_opt_epoch{0};
@@ -183,6 +184,11 @@ int launch_gemm(int prec, int epi, const GemmP& p_in, hipStream_t st) {
       epi == EPI_BIAS_GELU_TE || epi == EPI_BIAS_GELU_BF || epi == EPI_BIAS_GELU_ALT)
     OSUD_CHECK_ARG(p.bias != nullptr, "gemm: epilogue %d needs a bias", epi);
   if (epi == EPI_GELUGRAD_TE) OSUD_CHECK_ARG(p.aux != nullptr, "gemm: epilogue %d needs aux", epi);
+  if (p.aux_code)
+    OSUD_CHECK_ARG((prec == OSUD_PREC_BF16 || prec == OSUD_PREC_FP8) && p.ldo % 32 == 0 &&
+                       (epi == EPI_BIAS_GELU_TE || epi == EPI_BIAS_GELU_BF || epi == EPI_GELUGRAD_TE),
+                   "gemm: the 8-bit code of the saved GELU derivative exists for the bf16-output GELU epilogues and ldo %% 32 == 0 (prec %d, epilogue %d, ldo %d)",
+                   prec, epi, p.ldo);
   if (p.split_k > 1) {
     OSUD_CHECK_ARG(epi == EPI_NONE_F32 || epi == EPI_NONE_TE, "gemm: split-K needs a plain epilogue");
     OSUD_CHECK_ARG((size_t)p.K * esz / SLAB >= (size_t)p.split_k, "gemm: K=%d does not split %d ways", p.K, p.split_k);

@@ -481,7 +481,16 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x16 (&acc)[RY][
   constexpr bool kPfAux = EPI == EPI_GELUGRAD_TE && sizeof(TO) == 2;
   constexpr int PF = NB < 2 ? NB : 2;
   uint4 praw[kPfAux ? PF : 1][2];
+  // (8-bit block code of the derivative, p.aux_code: block (y / 32, x / 32) is 1 KiB, this lane's 16 bytes at 16 * lane: common.h)
+  auto code_block = [&](int b) -> size_t {
+    const int yb32 = (ty * BM + wy * RY * 32 + (b / RX) * 32) >> 5, xb32 = (tx * BN + wx * RX * 32 + (b % RX) * 32) >> 5;
+    return ((size_t)yb32 * (size_t)(p.ldo >> 5) + (size_t)xb32) * 1024 + (size_t)lane * 16;
+  };
   auto aux_issue = [&](int b) {
+    if (p.aux_code) {
+      praw[b % PF][0] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(p.aux) + code_block(b));
+      return;
+    }
     const size_t row = (size_t)(ty * BM + wy * RY * 32 + (b / RX) * 32 + lrow);
     const int x = xw + (b % RX) * 32;
 #pragma unroll
@@ -506,6 +515,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x16 (&acc)[RY][
     }
     f32x4 (&t)[4] = tq[b & 1];
     const int x = xw + j * 32;
+    uint32_t dcode[4];  // (8-bit derivative code: the lane's two rows of this block)
     float gv[8], rv[2][8];
     float rb[2];
     if (EPI == EPI_GATE_RES) {
@@ -532,7 +542,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x16 (&acc)[RY][
     } else {
       OSUD_LGKM_WAIT(0);
     }
-    if constexpr (kPfAux) {  // this block's rows out of the ring (bf16 pairs -> floats), its slot refilled for block b + PF
+    if constexpr (kPfAux) {  // this block's rows out of the ring (bf16 pairs / code bytes -> floats), its slot refilled for block b + PF
+      if (p.aux_code) {
+        const uint4 u = praw[b % PF][0];
+        gelu_decode4(u.x, rv[0]); gelu_decode4(u.y, rv[0] + 4);
+        gelu_decode4(u.z, rv[1]); gelu_decode4(u.w, rv[1] + 4);
+      } else
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const uint4 u = praw[b % PF][q];
@@ -590,8 +605,17 @@ __device__ __forceinline__ void tile_epilogue(const GemmP& p, f32x16 (&acc)[RY][
           // 180 us; on the backward's loads of the derivative +5 us; on that launch's output +20 us -- profiles/r05_ab_runs.md.)
           if constexpr (std::is_same<TO, bf16_t>::value) {
             typedef uint32_t u4v __attribute__((ext_vector_type(4)));
+            if (p.aux_code) {  // 8-bit code: this row's eight bytes wait for the other row of the lane, one 16-byte store per block (below)
+              dcode[2 * q] = gelu_code4(dg[0], dg[1], dg[2], dg[3]);
+              dcode[2 * q + 1] = gelu_code4(dg[4], dg[5], dg[6], dg[7]);
+              if (q == 1) {
+                const u4v u = {dcode[0], dcode[1], dcode[2], dcode[3]};
+                __builtin_nontemporal_store(u, reinterpret_cast<u4v*>(reinterpret_cast<char*>(p.out2) + code_block(b)));
+              }
+            } else {
             const u4v u = {pack_bf2(dg[0], dg[1]), pack_bf2(dg[2], dg[3]), pack_bf2(dg[4], dg[5]), pack_bf2(dg[6], dg[7])};
             __builtin_nontemporal_store(u, reinterpret_cast<u4v*>(reinterpret_cast<bf16_t*>(p.out2) + orow * (size_t)p.ldo + x));
+            }
           } else {
             store8_out<TO>(p.out2, orow, p.ldo, x, dg);
           }

@@ -309,7 +309,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
       } else {
       GemmP gp{};
       gp.Y = w.dbr; gp.X = bw.w2_t; gp.ldy = D; gp.ldx = D; gp.My = Mp; gp.Nx = 4 * D; gp.K = D;
-      gp.out = w.dz1; gp.ldo = 4 * D; gp.aux = sv.z1;
+      gp.out = w.dz1; gp.ldo = 4 * D; gp.aux = sv.z1; gp.aux_code = m->z1_code ? 1 : 0;
       if (fused_b1) {
         gp.colpart = b1part;
         gp.colpart_rows = &part_rows;

@@ -229,6 +229,8 @@ def test_forward_matches_reference_golden(tag, precision):
         cfg4 = m.forward_with_cfg(*args, 4.0, attn_mask=mask)
         cfg1 = m.forward_with_cfg(*args, 1.0, attn_mask=mask)
     scale = float(np.abs(fx["out"]).max())
+    # fp32: a fixed bound.  bf16: 3 x the error this implementation measured on the fixture (BF16_FWD_MEASURED) -- a REGRESSION bound fitted to
+    # the implementation, not an accuracy claim: the bf16 tier is outside the 1e-3 end-to-end tolerance and says so.
     tol = 2e-4 * max(scale, 1.0) if precision == "fp32" else 3 * BF16_FWD_MEASURED[tag][0] * scale
     assert out.shape == (len(args[0]), 4, args[0].shape[2]) and out.dtype == torch.float32
     e_out, e_cfg4, e_cfg1 = maxdiff(out.cpu(), fx["out"]), maxdiff(cfg4.cpu(), fx["out_cfg4"]), maxdiff(cfg1.cpu(), fx["out_cfg1"])
@@ -357,39 +359,42 @@ def test_chained_loop_final_coordinates_fp32(tag):
     assert torch.equal(finals["graph"], finals["eager"])  # graph replay == eager launches, bit for bit
 
 
-def test_p250_loop_on_undamped_weights_fp32():
+@pytest.mark.parametrize("precision", ["fp32", "fp16f8", "bf16x3"])
+def test_p250_loop_on_undamped_weights(precision):
     """The same 250-step CFG-4 loop on reference-like UNDAMPED weights (pos_gain 1: position features at 512 rad per unit x).
     The fixture holds the reference's fp32 result and an fp64 evaluation of the same loop; their distance (3.8e-4) is what any
-    fp32 implementation can claim here.  The parity tier must stay within 1e-3 of the reference and is reported against both."""
+    fp32 implementation can claim here.  The parity tier AND the two tolerance tiers (fp16f8 = sample.py's default, bf16x3) must stay
+    within 1e-3 of the reference's fp32 result; each is reported against the fp64 evaluation next to the reference's own distance."""
     fx = load("g6_loop_p250_undamped")
     shape = mo.DitShape(*(int(v) for v in fx["shape"][:3]), num_classes=int(fx["shape"][3]))
     sd = mo.seeded_state_dict(shape, int(fx["wseed"]), pos_gain=float(fx["pos_gain"]))
-    m = native_model(shape, sd, "fp32")
+    m = native_model(shape, sd, precision)
     d = create_diffusion("250", noise_schedule="squaredcos_cap_v2")
     z = T(fx["z"]).to(DEV)
     kw = dict(o=T(fx["o"]).to(DEV), c=T(fx["c"]).to(DEV), y=T(fx["y"]).to(DEV), cfg_scale=4.0, attn_mask=None)
     fin = d.p_sample_loop(m.forward_with_cfg, z.shape, z, model_kwargs=kw, step_noise=T(fx["noises"])).cpu()
     d_ref, d_64, spread = maxdiff(fin, fx["final"]), maxdiff(fin, fx["final_fp64"]), maxdiff(fx["final"], fx["final_fp64"])
-    print(f"undamped p250: native fp32 vs reference fp32 {d_ref:.3e}, vs fp64 evaluation {d_64:.3e} (reference fp32 vs fp64 {spread:.3e})")
+    print(f"MEASURED undamped p250 [{precision}]: native vs reference fp32 {d_ref:.3e}, vs fp64 evaluation {d_64:.3e} (reference fp32 vs fp64 {spread:.3e})")
     assert d_ref < 1e-3
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fp16f8", "bf16x3"])
 @pytest.mark.parametrize("damping", ["", "_undamped"])
 @pytest.mark.parametrize("part", ["head", "tail"])
-def test_1000_step_schedule_head_and_tail_fp32(part, damping):
+def test_1000_step_schedule_head_and_tail(part, damping, precision):
     """the first five steps of the 1000-step schedule (t = 999..995: sqrt(1/ac - 1) ~ 2e4 multiplies eps, the
     clamp decides x0) and the last five (t = 4..0, the t = 0 step adds no noise), against reference p_sample calls."""
     fx = load("g6_steps_1000" + damping)
     shape = mo.DitShape(*(int(v) for v in fx["shape"][:3]), num_classes=int(fx["shape"][3]))
     sd = mo.seeded_state_dict(shape, int(fx["wseed"]), pos_gain=float(fx["pos_gain"]))
-    m = native_model(shape, sd, "fp32")
+    m = native_model(shape, sd, precision)
     d = create_diffusion("1000", noise_schedule="squaredcos_cap_v2")
     kw = dict(o=T(fx["o"]).to(DEV), c=T(fx["c"]).to(DEV), y=T(fx["y"]).to(DEV), cfg_scale=4.0, attn_mask=None)
     x = T(fx[part + "_start"]).to(DEV).clone()
     d.run_steps(m.forward_with_cfg, x, kw, first_step=int(fx[part + "_first"]), last_step=int(fx[part + "_last"]),
                 step_noise=T(fx[part + "_noises"]))
     err = maxdiff(x.cpu(), fx[part + "_final"])
-    print(f"1000-step {part}{damping}: native fp32 vs reference {err:.3e}")
+    print(f"MEASURED 1000-step {part}{damping} [{precision}]: native vs reference {err:.3e}")
     assert err < 1e-3
 
 

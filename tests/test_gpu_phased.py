@@ -18,7 +18,8 @@ from osu_diffusion_amd.models import DiT
 from osu_diffusion_amd.synthetic import synthetic_windows
 from osu_diffusion_amd.training import NativeTrainer
 
-pytestmark = pytest.mark.gpu
+# every test here compares two schedules of THIS library with each other: `selfcheck` (collected behind every reference / oracle test, tests/conftest.py)
+pytestmark = [pytest.mark.gpu, pytest.mark.selfcheck]
 DEV = "cuda:0"
 EPI = {"bias_f32": _lib.EPI_BIAS_F32, "bias": _lib.EPI_BIAS_TE, "silu": _lib.EPI_BIAS_SILU_TE, "rowbias": _lib.EPI_ROWBIAS_TE,
        "gelu": _lib.EPI_BIAS_GELU_TE, "gate": _lib.EPI_GATE_RES, "none_f32": _lib.EPI_NONE_F32, "none": _lib.EPI_NONE_TE,
@@ -45,7 +46,9 @@ def _both_loops(osud_option, run):
 @pytest.mark.parametrize("epi", sorted(EPI))
 @pytest.mark.parametrize("prec", ["bf16", "fp16"])
 def test_plain_operand_gemm_is_bit_identical_to_the_slab_loop(osud_option, prec, epi, tile):
-    """512 x 768 outputs (2 x 3 / 2 x 4 tiles), K = 768 (12 slabs) and K = 192 (3 slabs: odd -- the consumer's buffer parity flips from tile to tile)."""
+    """512 x 768 outputs (2 x 3 / 2 x 4 tiles: one tile per workgroup), K = 768 (12 slabs) and K = 192 (3 slabs).  A workgroup that crosses a tile
+    boundary with an odd slab count -- where the stream cursor and the consumer's buffer parity continue flipped into the next tile -- is in
+    test_many_rounds_and_the_shortest_stream."""
     dt, pc = (torch.bfloat16, _lib.PREC_BF16) if prec == "bf16" else (torch.float16, _lib.PREC_F16)
     if prec == "fp16" and epi in ("accum", "rowbias", "none"):
         pytest.skip("the fp16 tier builds the forward pass's epilogues only (csrc/gemm_f16.hip)")
@@ -73,9 +76,11 @@ def test_plain_operand_gemm_is_bit_identical_to_the_slab_loop(osud_option, prec,
 
 def test_many_rounds_and_the_shortest_stream(osud_option):
     """More tiles than compute units (the stream runs across tile boundaries: 2048 x 3072 = 96 / 128 tiles on <= 256 workgroups is one round, so
-    also 8192 x 3072 = 384 tiles), and K = 128 = two slabs, the shortest stream the loop takes."""
+    also 8192 x 3072 = 384 tiles), and K = 128 = two slabs, the shortest stream the loop takes;
+    also K = 192 / 320 (3 / 5 slabs: odd) on multi-round grids, where a workgroup enters its next tile with the buffer parity flipped."""
     g = torch.Generator(device=DEV).manual_seed(6)
-    for M, N, K, tile in ((8192, 3072, 768, 256), (8192, 2304, 256, 192), (256, 768, 128, 256), (256, 768, 128, 192), (1024, 256, 320, 256)):
+    for M, N, K, tile in ((8192, 3072, 768, 256), (8192, 2304, 256, 192), (256, 768, 128, 256), (256, 768, 128, 192), (1024, 256, 320, 256),
+                          (8192, 3072, 192, 256), (8192, 2304, 320, 192), (16384, 3072, 320, 256)):
         osud_option("gemm_tile", tile)
         Y = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
         X = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)

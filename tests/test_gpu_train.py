@@ -140,6 +140,39 @@ def test_training_step_at_dit_b_width_matches_reference(precision):
         print(f"MEASURED train_dit_b[bf16]: worst per-tensor relative gradient error {worst:.3e}, worst norm deviation {worst_n:.3e}")
 
 
+def test_saved_gelu_derivative_code_against_the_reference_and_the_bf16_rows(osud_option):
+    """Option gelu_code (default 1): the fc1 epilogue saves the GELU derivative for the backward pass as an 8-bit code (step 1 / 200: absolute
+    error <= 2.5e-3, 0 and 1 exact) instead of bf16 rows.  Both forms must hold the bf16 tier's bounds against the REFERENCE's gradients
+    (fixture g7_train_dit_b, the geometry bench.py times), and the two forms must differ -- the code path is really taken -- by no more
+    than the bf16 tier's own distance from the reference."""
+    fx = load("g7_train_dit_b")
+    shape, sd = weights_for(fx)
+    keys = [str(k) for k in fx["grad_keys"]]
+    grads, worst = {}, {}
+    for code in (1, 0):
+        osud_option("gelu_code", code)  # (read when the handle is created)
+        tr = NativeTrainer(native_model(shape, sd, "bf16"), create_diffusion("", noise_schedule="squaredcos_cap_v2", use_l1=True))
+        tr.step(T(fx["x"]), T(fx["o"]), T(fx["c"]), T(fx["y"]), t=T(fx["t"]), noise=T(fx["noise"]), drop_ids=T(fx["drop"]).long())
+        gv = tr.arena.grad_views()
+        grads[code] = {k: gv[k].detach().clone() for k in keys}
+        w = 0.0
+        for k, n_ref in zip(keys, fx["grad_norms"]):
+            n, _, smp = _probe(k, gv[k])
+            ref = T(fx["sample:" + k])
+            rel = float((smp - ref).norm() / ref.norm().clamp_min(1e-12))
+            w = max(w, rel)
+            assert rel < BF16_GRAD_REL, (code, k, rel)
+            assert abs(n - n_ref) <= BF16_NORM_REL * max(n_ref, 1e-4), (code, k, n, n_ref)
+        worst[code] = w
+        del tr
+    between = max(float((grads[1][k] - grads[0][k]).norm() / grads[0][k].norm().clamp_min(1e-12)) for k in keys)
+    changed = [k for k in keys if not torch.equal(grads[1][k], grads[0][k])]
+    print(f"MEASURED gelu_code: worst relative gradient error vs reference {worst[1]:.3e} (8-bit code) / {worst[0]:.3e} (bf16 rows); "
+          f"between the two forms {between:.3e}; {len(changed)} of {len(keys)} tensors differ")
+    assert any("mlp.fc1" in k for k in changed), "the coded derivative was not used"
+    assert between < BF16_GRAD_REL
+
+
 def _check_first_adam_step(after, before, ref_after, ref_grad, key):
     """The first Adam step is lr * g / (|g| + eps): +-1e-4 wherever |g| >> eps = 1e-8, and ill-conditioned
     where |g| ~ eps (a 1e-9 gradient difference moves it by percents).  Compare the step tightly where the
