@@ -66,6 +66,7 @@ def parse():
     ap.add_argument("--watchdog-s", type=float, default=900.0, help="N > 1: if the collective diagnostics after the timed region have not returned after this "
                                                                     "many seconds, rank 0 prints the line with what is measured and every rank exits")
     ap.add_argument("--simulate-hang", action="store_true", help=argparse.SUPPRESS)  # (test of the watchdog: the first diagnostic never returns)
+    ap.add_argument("--no-compute-floor", action="store_true", help="N = 1: skip the compute floor of the multi-GPU schedule (phased backward, queued tiles, stubbed exchange)")
     ap.add_argument("--no-family-table", action="store_true", help="skip the torch.profiler pass (use under rocprofv3)")
     ap.add_argument("--no-parity-tier", action="store_true", help="skip the fp32 parity-tier throughput and the bf16-vs-fp32 drift run")
     ap.add_argument("--drift-steps", type=int, default=1000, help="length of the CFG-4 loop the bf16 drift is measured on")
@@ -695,6 +696,36 @@ def bench_train(args, world, rank, dev):
                                  "gradients with its data-gradient chain on a second stream, which stretches the durations of "
                                  "kernels that run side by side")
         res["roofline"] = train_roofline(wg_alone, fc1_alone, pf)
+    if world == 1 and args.precision == "bf16" and not args.no_compute_floor:
+        # What the data-parallel schedule costs in compute alone, on this one GPU: the phased backward (a slice per block, as under the
+        # exchange), early AdamW on finished slices, GEMM tiles / weight-gradient K-chunks / attention heads drawn from the ticket queues
+        # (osud_set_gemm_dynamic_tiles(1), what a trainer switches on when world > 1), every collective left out.  To be read against
+        # ms_per_step: the first multi-GPU run starts from THIS compute floor, not from the single-GPU step.
+        from osu_diffusion_amd import _lib as _l
+        del trainer
+        torch.cuda.empty_cache()
+        _l.check(_l.lib().osud_set_gemm_dynamic_tiles(1))
+        try:
+            tr2 = NativeTrainer(model, diffusion, lr=1e-4, force_phased=True, stub_exchange=True)
+            for i in range(min(W, 5) or 1):
+                (x, o, c), y = batches[i % 4]
+                tr2.step(x, o, c, y)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(K):
+                (x, o, c), y = batches[i % 4]
+                tr2.step(x, o, c, y)
+            tr2.finish_exchange()
+            torch.cuda.synchronize()
+            floor_ms = (time.perf_counter() - t0) / K * 1e3
+            res["multi_gpu_schedule_compute_floor_ms"] = round(floor_ms, 3)
+            res["multi_gpu_schedule_compute_floor"] = {
+                "ms_per_step": round(floor_ms, 3), "vs_single_gpu_step": round(floor_ms / (dt / K * 1e3), 4), "steps": K,
+                "what": "phased backward + early AdamW + ticket-queued tiles / K-chunks / heads (dynamic tiles on), collectives stubbed, one GPU"}
+            del tr2
+        finally:
+            _l.check(_l.lib().osud_set_gemm_dynamic_tiles(-1))
+        trainer = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_train(model, args, batches[0])
     if world > 1 and not args.no_exchange_ab:  # (every rank takes part: the legs are collective)
@@ -802,6 +833,7 @@ def parity_tier_and_drift(args, dev):
     # (1a) training tokens/s
     targs = argparse.Namespace(**vars(args))
     targs.precision, targs.steps, targs.warmup, targs.no_roofline, targs.no_cpu_baseline, targs.h2d = "fp32", 4, 1, True, True, False
+    targs.no_compute_floor = True
     tr = bench_train(targs, 1, 0, dev)
     out["train"] = {"value": tr["value"], "unit": "tokens/s", "ms_per_step": tr["ms_per_step"], "steps": tr["steps"],
                     "mfma_frac_of_f32_peak": round(tr["value"] * FLOP_PER_TOKEN_TRAIN / 1e12 / 157.3, 4) if args.model == "DiT-B" and args.seq_len == 128 else None}
@@ -946,7 +978,7 @@ def bench_xl(args, world, rank, dev, precision="bf16", steps=None, warmup=None):
     xa = argparse.Namespace(**vars(args))
     xa.model, xa.seq_len, xa.batch, xa.precision = "DiT-XL", 256, 128, precision
     xa.steps, xa.warmup = (steps if steps is not None else 6), (warmup if warmup is not None else 2)
-    xa.no_roofline, xa.no_cpu_baseline, xa.h2d, xa.no_family_table = True, True, False, True
+    xa.no_roofline, xa.no_cpu_baseline, xa.h2d, xa.no_family_table, xa.no_compute_floor = True, True, False, True, True
     r = bench_train(xa, world, rank, dev)
     per_gpu = r["value"] / world
     # Peaks (MI355X_MICROARCH.md): bf16 2.5 PFLOP/s dense, fp8 5 PFLOP/s dense (block-scaled K = 64 MFMA).  The fp8 tier runs the

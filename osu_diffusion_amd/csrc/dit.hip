@@ -25,6 +25,10 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
 }
 
 int dit_ensure_ws(osud_dit* m, int N, int T, bool training) {
+  // the final layer's backward writes its weight / bias gradient through a fixed-order column pass built for 4 output channels
+  // (learn_sigma = True: what every script of the reference trains, models.py:243-254); learn_sigma = False runs forward / sampling only.
+  // Checked HERE so that every training entry point (reserve, forward_train) rejects such a handle before anything is allocated or run.
+  OSUD_CHECK_ARG(!training || m->C2 == 4, "the backward pass is built for learn_sigma=True (4 output channels), this handle has %d", m->C2);
   OSUD_TRY(gemm_sched_init());  // tile-queue counters: must exist before any launch is captured into a graph
   if (N <= m->cap_N && T <= m->cap_T && (!training || m->training)) return OSUD_OK;
   // grow: free the old set, allocate for the max of old/new
@@ -622,9 +626,6 @@ extern "C" int osud_dit_set_param(osud_dit* m, const char* key, const float* src
 
 extern "C" int osud_dit_reserve(osud_dit* m, int max_N, int max_T, int training) {
   OSUD_CHECK_ARG(m && max_N > 0 && max_T > 0, "reserve: bad argument");
-  // the final layer's backward writes its weight / bias gradient through a fixed-order column pass built for 4 output channels
-  // (learn_sigma = True: what every script of the reference trains, models.py:243-254); learn_sigma = False runs forward / sampling only
-  OSUD_CHECK_ARG(!training || m->C2 == 4, "reserve: the backward pass is built for learn_sigma=True (4 output channels), this handle has %d", m->C2);
   return dit_ensure_ws(m, max_N, max_T, training != 0);
 }
 

@@ -73,6 +73,7 @@ struct GemmP {
 };
 
 int launch_gemm(int prec, int epi, const GemmP& p, hipStream_t st);
+int gemm_num_cus();                     // compute units of the current device
 bool gemm_dynamic_tiles_on();            // the effective setting
 void gemm_set_dynamic_tiles(int on);  // 1 / 0 (default off; -1 = back to the default)
 

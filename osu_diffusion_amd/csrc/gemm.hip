@@ -129,7 +129,9 @@ int opt_set(const char* name, int value) {
       OSUD_CHECK_ARG(value == -1 || (value >= kOpts[i].lo && value <= kOpts[i].hi), "set_option: %s takes %d..%d (or -1 = default), got %d", name,
                      kOpts[i].lo, kOpts[i].hi, value);
       g_opt[i].store(value == -1 ? kOpts[i].def : value, std::memory_order_relaxed);
-      g_opt_epoch.fetch_add(1, std::memory_order_relaxed);
+      // (the epoch invalidates captured sampler steps: only options a captured step reads move it -- not the training / triage switches)
+      if (i != OPT_WGRAD_SIDE_STREAM && i != OPT_DEBUG_SYNC && i != OPT_F8_TWINS_ONLY && i != OPT_GELU_CODE)
+        g_opt_epoch.fetch_add(1, std::memory_order_relaxed);
       return OSUD_OK;
     }
   set_error("set_option: unknown option '%s'", name);

@@ -34,7 +34,8 @@
 // the K-blocked forms by k sub-step instead: every phase then touches every row, a buffer can only be refilled while the other is
 // consumed, the lead halves -- and it measured SLOWER than the slab loop: fp16f8 sampling 7.53 -> 7.87 ms, DiT-XL fp8 85.9 -> 91.4 ms.
 // By quadrant: 7.60 -> 7.28 ms and 86.0 -> 86.2: profiles/r05_ab_runs.md.)
-// Tiles: persistent workgroups, static XCD-contiguous order as in gemm_kernel; the stream runs across tile boundaries, everything in
+// Tiles: persistent workgroups, static XCD-contiguous order as in gemm_kernel or -- shared-GPU mode -- its per-XCD ticket queues (see
+// "tile sequence" below); the stream runs across tile boundaries, everything in
 // flight is waited for once before the epilogue's stores join the queue, and waits of a tile's first slab that only cover pieces
 // issued before that drain are skipped.  The stagger is per tile: group 1 enters a tile with one extra barrier, group 0 pays it
 // back after its epilogue; the epilogues of both groups run side by side (patches live behind the ring: no barrier inside).
@@ -168,6 +169,32 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
     voff[m] = (uint32_t)((size_t)gr * (isy ? ldy_b : ldx_b) + (size_t)c * 16);
   }
 
+  // ---- tile sequence.  Static: first, first + G8, ...  Queued (p.sched != nullptr: osud_set_gemm_dynamic_tiles, multi-round launches): every
+  // later tile is drawn from the ticket counter of this workgroup's XCD, two tiles ahead of the arithmetic, exactly as in gemm_kernel
+  // (same counters, same ticket -> tile map: an undisturbed launch walks the static order; every tile is computed the same way whoever
+  // takes it, so the results are bit-identical).  The ticket for tile j + 2 is requested at the top of tile j, has returned by the drain
+  // in front of tile j's epilogue -- the only vmcnt(0) of the loop: the compiler's own wait for the returned value costs nothing there
+  // -- and is published behind the epilogue through the first word of wave 0's epilogue patch (free again by then; the 256 x 256
+  // geometry fills the LDS to the last byte), across the tile's closing barrier.  The staging cursor crosses into the next tile once per
+  // tile, 1.5 slabs ahead of the consumer, and takes the tile id the consumer already holds (t_nxt).
+  const bool dyn = p.sched != nullptr;
+  volatile __attribute__((address_space(3))) uint32_t* const sched_word =
+      reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>((lds_void*)smem) + RING / 4;
+  const bool ticket_lane = dyn && wave == 0 && lane == 0;
+  const int xcd = blockIdx.x & 7, per = G8 >> 3;
+  auto resolve = [&](uint32_t word) -> int {  // one queue per XCD: 16-bit fields of p.sched[0..3] (gemm_kernel.h has the design notes)
+    const uint32_t k = (word >> (16 * (xcd & 1))) & 0xffffu;
+    const int id = (int)((uint32_t)G8 * (1u + k / (uint32_t)per) + (uint32_t)(xcd * per) + k % (uint32_t)per);
+    return id < ntiles ? id : 0x7fffffff;
+  };
+  auto take_ticket = [&](uint32_t& dst) {
+    if (ticket_lane)
+      dst = __hip_atomic_fetch_add(p.sched + (xcd >> 1), 1u << (16 * (xcd & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  uint32_t tk_start = 0, tk = 0;
+  take_ticket(tk_start);  // the second tile's (older than every LDS-DMA piece: back by the prologue's wait)
+  int t_nxt = dyn ? 0x7fffffff : first + G8;
+
   // ---- the staging stream: a cursor over (tile, slab, slot) in issue order ----------------------------------------------------
   int c_tile = first, c_kt = 0;
   uint32_t c_buf = 0;  // byte offset of the cursor's slab buffer
@@ -184,7 +211,7 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
     const char* sb = S::is_y(m) ? c_gy : c_gx;
     const uint32_t dst = lds0 + c_buf + (uint32_t)((8 * m + wave) * 1024);
     const uint32_t vo = voff[m];  // (named outside the asm statement: an asm operand alone does not capture in a generic lambda)
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(sb), "s"(dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(sb), "s"(dst) : "memory", "m0");
   };
   auto advance = [&]() {
     c_buf = STAGE - c_buf;
@@ -192,7 +219,7 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
     c_gx += SLAB;
     if (++c_kt == nk) {
       c_kt = 0;
-      c_tile += G8;
+      c_tile = t_nxt;  // (the consumer is in the tile the cursor leaves: its next tile is the cursor's)
       c_live = c_tile < ntiles;
       if (c_live) tile_base(c_tile, c_gy, c_gx);
     }
@@ -211,7 +238,12 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
   // prologue: AHEAD pieces, all landed, everywhere
   stage_run(std::integral_constant<int, 0>{}, std::integral_constant<int, S::AHEAD>{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (dyn) {
+    if (ticket_lane) sched_word[0] = (uint32_t)resolve(tk_start);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
+  if (dyn) t_nxt = __builtin_amdgcn_readfirstlane((int)sched_word[0]);
 
 #ifdef OSUD_PH_TIMING
   // cycle stamps (shader clock, s_memtime) of this wave: [0] read + DMA issue + counted wait, [1] first barrier, [2] lgkmcnt + cluster issue,
@@ -223,8 +255,9 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
 #endif
   uint32_t r_buf = 0;  // the consumer's slab buffer
   float q_amax = 0.f;  // fp8 training: running max |value| of this lane's share of the e4m3 output
-  for (int t_cur = first; t_cur < ntiles; t_cur += G8) {
+  for (int t_cur = first; t_cur < ntiles;) {
     const int ty = t_cur / ntx, tx = t_cur - ty * ntx;
+    take_ticket(tk);  // for the tile after next
     f32x16 acc[RY][RX];
 #pragma unroll
     for (int i = 0; i < RY; ++i)
@@ -334,6 +367,11 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
     }
     // everything in flight is the next tile's first slab (and a half): landed before the epilogue's stores queue behind it
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int t_nxt2 = t_nxt + G8, t_pub = 0;  // (t_pub: the ticket lane's own value -- per-lane, so that the tile ids themselves stay wave-uniform)
+    if (ticket_lane) {  // the ticket has returned with the drain above: resolve it HERE (pinned: behind the epilogue the compiler's wait for it would drain the stores)
+      t_pub = resolve(tk);
+      asm volatile("" : "+v"(t_pub)::"memory");
+    }
 #ifdef OSUD_PH_TIMING
     uint64_t ts_f, ts_g;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_f));
@@ -348,7 +386,21 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ts_g));
     tsum[5] += ts_g - ts_f;
 #endif
+    if (dyn) {  // wave 0's patch is idle again: the id of the tile after next, for every wave behind the closing barrier
+      if (ticket_lane) sched_word[0] = (uint32_t)t_pub;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();  // group 0 pays the stagger back; both groups: the next tile's first slab has landed everywhere
+    if (dyn) t_nxt2 = __builtin_amdgcn_readfirstlane((int)sched_word[0]);
+    t_cur = t_nxt;
+    t_nxt = t_nxt2;
+  }
+  if (ticket_lane) {  // the last workgroup out re-arms the counters for the next launch that borrows this slot
+    const unsigned done = __hip_atomic_fetch_add(p.sched + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x - 1) {
+#pragma unroll
+      for (int y = 0; y < 9; ++y) __hip_atomic_store(p.sched + y, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
   if constexpr (kF8) {
     if (p.out8 != nullptr && p.out8_slot != nullptr) {  // one amax atomic per workgroup (through LDS: the ring is idle by now)
@@ -392,7 +444,8 @@ template <typename TE, int EPI, int GEO> int launch_phased(const GemmP& p_in, hi
   const int ntiles = (p.My / 256) * (p.Nx / G::BN);
   int grid = gemm_num_cus();
   if (grid > ntiles) grid = ntiles;
-  p.sched = nullptr;
+  // shared-GPU mode (collectives on the same compute units): multi-round launches draw their tiles from the per-XCD ticket queues
+  p.sched = (gemm_dynamic_tiles_wanted() && ntiles > grid && grid % 8 == 0 && ntiles / 8 + 2 * grid < 60000) ? gemm_sched_slot() : nullptr;
   hipLaunchKernelGGL((gemm_phased_kernel<TE, EPI, GEO>), dim3(grid), dim3(512), lds, st, p);
   OSUD_HIP(hipGetLastError());
   return OSUD_OK;
@@ -402,8 +455,7 @@ template <typename TE, int EPI, int GEO> int launch_phased(const GemmP& p_in, hi
 template <typename TE, int EPI> int launch_phased_or(const GemmP& p, int pick, hipStream_t st, bool& taken) {
   taken = false;
   if constexpr ((sizeof(TE) == 2 && Planes<TE>::k == 1) || std::is_same<TE, h8_t>::value || sizeof(TE) == 1) {
-    if (opt(OPT_GEMM_LOOP) != 0 && (pick == 1 || pick == 2) && p.split_k <= 1 && !gemm_dynamic_tiles_wanted() &&
-        (size_t)p.K * sizeof(TE) / SLAB >= 2) {
+    if (opt(OPT_GEMM_LOOP) != 0 && (pick == 1 || pick == 2) && p.split_k <= 1 && (size_t)p.K * sizeof(TE) / SLAB >= 2) {
       taken = true;
       return pick == 2 ? launch_phased<TE, EPI, 0>(p, st) : launch_phased<TE, EPI, 1>(p, st);
     }

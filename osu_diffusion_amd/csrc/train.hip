@@ -243,7 +243,7 @@ int dit_backward_impl(osud_dit* m, const float* dout, int phase_lo, int phase_hi
     // dz1 = (dbr . W2) * gelu'(z1); in the bf16 tier the fc1 bias gradient (column sums of dz1) rides in the same epilogue
     // as per-wave-row partial sums (scratch: the split-K slab area, free until the weight gradients below)
     const bool fused_b1 = prec == OSUD_PREC_BF16;
-    float* b1part = w.b1part + (size_t)l * w.b1part_stride;        // this layer's partial rows (summed at the end of the call)
+    float* b1part = fused_b1 ? w.b1part + (size_t)l * w.b1part_stride : nullptr;  // this layer's partial rows (summed at the end of the call; allocated where fused_b1 holds: dit.hip)
     float* bqkvpart = w.bqkvpart + (size_t)l * w.bqkvpart_stride;
     // fp8 training: the data-gradient products of fc2, fc1 and in_proj run on e4m3 operands (gradient tensors quantised with the
     // scale from their previous step's amax, transposed weights per row); the very first step only records (see dit_forward_impl)
@@ -776,7 +776,7 @@ extern "C" int osud_dit_forward_train(osud_dit* m, const float* x, const int64_t
   OSUD_CHECK_ARG(m, "forward_train: null handle");
   OSUD_CHECK_ARG(T % 64 == 0 && (N * T) % 128 == 0,
                  "training needs seq_len %% 64 == 0 and batch*seq_len %% 128 == 0 (got N=%d, T=%d)", N, T);
-  OSUD_TRY(dit_ensure_ws(m, N, T, true));
+  OSUD_TRY(dit_ensure_ws(m, N, T, true));  // (rejects learn_sigma = False handles up front)
   return dit_forward_impl(m, x, t, o, c, y, nullptr, N, T, -1.0f, false, out, true, (hipStream_t)stream);
 }
 
@@ -830,9 +830,10 @@ extern "C" int osud_adamw_ema_step(float* params, const float* grads, float* exp
   if (!same || head > n) head = n;  // differently aligned buffers: everything on the one-element-per-thread path
   // (the grid follows whichever path carries the elements: a misaligned call must still use the whole chip)
   const size_t work = head == n ? n : (n - head) / 4 + 8;
-  // two workgroups per CU, long strides (130 M elements, same box: 512 blocks 787-800 us, 256: 821-845, 1024: 831-846, 4096: 820-844;
+  // two workgroups per compute unit (512 on this part), long strides (130 M elements, same box: 512 blocks 787-800 us, 256: 821-845, 1024: 831-846, 4096: 820-844;
   // non-temporal loads / stores and two 16-byte sets per lane in flight were slower -- tools/adam_bench.py, profiles/r05_ab_runs.md)
-  const int grid = (int)((work + 255) / 256 > 512 ? 512 : (work + 255) / 256);
+  const size_t cap = 2 * (size_t)gemm_num_cus();
+  const int grid = (int)((work + 255) / 256 > cap ? cap : (work + 255) / 256);
   const AdamC c{lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, ema_decay, grad_scale};
   hipLaunchKernelGGL(adamw_ema_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params, grads, exp_avg, exp_avg_sq, ema, n, c,
                      skip_begin, skip_end, head);

@@ -72,7 +72,7 @@ __device__ __forceinline__ void stage_tokens(const char* gp, const char* gq, uin
     const int piece = wave * G::PPW + q;  // wave-uniform
     const char* sbase = (piece * 1024 < G::YB) ? gp : gq;
     const uint32_t dst = stage_lds + (uint32_t)__builtin_amdgcn_readfirstlane(piece * 1024);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff[q]), "s"(sbase), "s"(dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff[q]), "s"(sbase), "s"(dst) : "memory", "m0");
   }
 }
 
@@ -384,6 +384,18 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
   const int frow = lane & 31, fhalf = lane >> 5;
   const int ntx = (p.Nx + G::BN - 1) / G::BN, ntiles = ((p.Ny + G::BM - 1) / G::BM) * ntx;
   const int st_total = p.M / BKT;
+  // Shared-GPU mode (p.queue != nullptr: one (tile, split) unit per workgroup, blockIdx = (tile, split)): the token axis of the tile is cut
+  // into p.chunk chunks, workgroup `split` starts on chunk `split` and draws every later chunk from the tile's ticket counter, accumulating in
+  // registers -- wgrad_kernel's queue mode in the phased schedule.  A run of stages ("segment") is a tile's share of the token axis in the
+  // plain mode and one chunk in the queue mode; the staging stream runs from segment to segment, the epilogue follows a TILE.
+  // The ticket is a SCALAR atomic (s_atomic_add ... glc: the value before the add comes back in an SGPR and is tracked by lgkmcnt -- gfx950
+  // executes it, tools/probes/satomic_probe.hip), so it never enters the vector-memory queue whose counted waits the stream lives on: wave 0
+  // requests it in phase 0 of a chunk's first stage, the value is back behind that phase's own lgkmcnt(0), goes to the first word of wave 0's
+  // (idle) epilogue patch in phase 1 and is read by every wave in phase 2 -- one and a half stages before the cursor needs it at the
+  // earliest (chunks have at least four stages: the launcher's condition).
+  const bool dyn = p.queue != nullptr;
+  const int nch = dyn ? p.chunk : 1;
+  auto chunk_begin = [&](int c) { return (int)((long)c * st_total / nch); };  // (lengths differ by at most one stage)
   int sidx = blockIdx.y, bx = blockIdx.x;
   if (p.xcd_units) {  // (tile, split) units in split-major order, one contiguous run per XCD: see WgradP::xcd_units
     const int total = gridDim.x * gridDim.y, L = blockIdx.x + blockIdx.y * gridDim.x;
@@ -392,8 +404,8 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
     sidx = u / (int)gridDim.x;
     bx = u - sidx * (int)gridDim.x;
   }
-  const int st_begin = (int)((long)sidx * st_total / p.split_k);
-  const int nst = (int)((long)(sidx + 1) * st_total / p.split_k) - st_begin;
+  const int st_begin = dyn ? 0 : (int)((long)sidx * st_total / p.split_k);
+  const int nst = dyn ? 0 : (int)((long)(sidx + 1) * st_total / p.split_k) - st_begin;
   const size_t ldp_b = (size_t)p.ldp * 2, ldq_b = (size_t)p.ldq * 2;
   const char* const gp0 = reinterpret_cast<const char*>(p.P) + (size_t)st_begin * BKT * ldp_b;
   const char* const gq0 = reinterpret_cast<const char*>(p.Q) + (size_t)st_begin * BKT * ldq_b;
@@ -404,6 +416,7 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
     const int b = blockIdx.x, q = G8 >> 3, r = G8 & 7, xcd = b & 7, idx = b >> 3;
     first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     if (p.xcd_units) first = bx;
+    if (dyn) first = blockIdx.x;
   }
 
   // fragment addresses (stage 0, sub-step 0), exactly wgrad_kernel's
@@ -432,34 +445,49 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
 #pragma unroll
   for (int g = 0; g < 4; ++g) pw[g] = patch + frow * 128 + (((2 * g + fhalf) ^ (frow & 7)) << 4);
   const uint32_t pr = patch + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+  volatile __attribute__((address_space(3))) uint32_t* const q_word =
+      reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>((lds_void*)smem) + RING / 4;  // (wave 0's patch: idle until the tile's store)
+
+  // ---- segments: (first stage, stages).  Plain: one per tile, the same range for every tile.  Queue: the chunks this workgroup draws.
+  int s_cur = dyn ? (int)blockIdx.y : 0, s_nxt = 0x7fffffff;  // queue mode: the consumer's chunk and the one after it (known from phase 2 of s_cur's first stage on)
+  auto seg_first = [&](int c) { return dyn ? chunk_begin(c) : 0; };
+  auto seg_len = [&](int c) { return dyn ? chunk_begin(c + 1) - chunk_begin(c) : nst; };
 
   // ---- the staging stream
-  int c_tile = first, c_st = 0;
+  int c_tile = first, c_st = 0, c_len = seg_len(s_cur);
   uint32_t c_buf = 0;
-  bool c_live = c_tile < ntiles && nst > 0;
+  bool c_live = c_tile < ntiles && c_len > 0;
   const char *c_gp, *c_gq;
-  auto tile_base = [&](int t, const char*& gp, const char*& gq) {
+  auto seg_base = [&](int t, int stage0, const char*& gp, const char*& gq) {
     const int ty = t / ntx, tx = t - ty * ntx;
-    gp = gp0 + (size_t)ty * G::BM * 2;
-    gq = gq0 + (size_t)tx * G::BN * 2;
+    gp = gp0 + (size_t)ty * G::BM * 2 + (size_t)stage0 * BKT * ldp_b;
+    gq = gq0 + (size_t)tx * G::BN * 2 + (size_t)stage0 * BKT * ldq_b;
   };
-  tile_base(c_tile, c_gp, c_gq);
+  seg_base(c_tile, seg_first(s_cur), c_gp, c_gq);
   auto stage_slot = [&](auto M) {
     constexpr int m = decltype(M)::value;
     const char* sb = (m & 1) == 0 ? c_gp : c_gq;
     const uint32_t dst = lds0 + c_buf + (uint32_t)(((m & 1) ? G::YB : 0) + (8 * (m >> 1) + wave) * 1024);
     const uint32_t vo = voff[m];
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(sb), "s"(dst) : "memory");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(sb), "s"(dst) : "memory", "m0");
   };
   auto advance = [&]() {
     c_buf = STAGE - c_buf;
     c_gp += (size_t)BKT * ldp_b;
     c_gq += (size_t)BKT * ldq_b;
-    if (++c_st == nst) {
+    if (++c_st == c_len) {
       c_st = 0;
-      c_tile += G8;
-      c_live = c_tile < ntiles;
-      if (c_live) tile_base(c_tile, c_gp, c_gq);
+      if (dyn) {  // the consumer is in the chunk the cursor leaves: its next chunk is the cursor's
+        c_live = s_nxt < nch;
+        if (c_live) {
+          c_len = seg_len(s_nxt);
+          seg_base(c_tile, seg_first(s_nxt), c_gp, c_gq);
+        }
+      } else {
+        c_tile += G8;
+        c_live = c_tile < ntiles;
+        if (c_live) seg_base(c_tile, 0, c_gp, c_gq);
+      }
     }
   };
   auto stage_run = [&](auto P0, auto N) {
@@ -476,6 +504,8 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
   __builtin_amdgcn_s_barrier();
 
   uint32_t r_buf = 0;
+  uint32_t tkq = 0;  // queue mode, wave 0: the increment on the way in, the tile's ticket (chunks drawn so far) on the way out
+  const unsigned* const q_ctr = dyn ? p.queue + blockIdx.x : nullptr;
   for (int tile = first; tile < ntiles; tile += G8) {
     const int ty = tile / ntx, tx = tile - ty * ntx;
     f32x16 acc[RY][RX];
@@ -487,26 +517,54 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     TFrag<RY, RX> f;
     if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger
-    for (int st = 0; st < nst; ++st) {
-      const bool counted = st > 0, last = st == nst - 1;
-      static_for<NPH>([&](auto PH) {
-        constexpr int P = decltype(PH)::value;
-        read_frags<RY, RX, P, G::ROWY, G::ROWX>(f, ya, xa, r_buf);
-        stage_run(std::integral_constant<int, S::AHEAD + ph_issued_before<S>(P)>{}, std::integral_constant<int, S::cnt[P]>{});
-        constexpr int W = ph_wait<S>(P);
-        if (!c_live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (counted) wait_vmcnt<W>();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        OSUD_WG_WAIT(0);
-        __builtin_amdgcn_s_setprio(1);
-        mma_frags<RY, RX>(acc, f);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (P != NPH - 1 || !last || grp == 0) __builtin_amdgcn_s_barrier();
-      });
-      r_buf = STAGE - r_buf;
-    }
+    bool tile_first = true;
+    do {  // the tile's segments (plain mode: one)
+      const int len = seg_len(s_cur);
+      for (int st = 0; st < len; ++st) {
+        const bool counted = st > 0 || !tile_first;
+        const bool draw = dyn && st == 0;  // this chunk's first stage: the ticket for the chunk after it
+        static_for<NPH>([&](auto PH) {
+          constexpr int P = decltype(PH)::value;
+          if constexpr (P == 0) {
+            if (draw && wave == 0) {
+              tkq = 1u;
+              asm volatile("s_atomic_add %0, %1, 0x0 glc" : "+s"(tkq) : "s"(q_ctr) : "memory");
+            }
+          }
+          if constexpr (P == 1) {  // (the ticket came back with phase 0's lgkmcnt(0))
+            if (draw && wave == 0) {
+              asm volatile("" : "+s"(tkq));
+              if (lane == 0) q_word[0] = (uint32_t)p.split_k + tkq;
+            }
+          }
+          read_frags<RY, RX, P, G::ROWY, G::ROWX>(f, ya, xa, r_buf);
+          stage_run(std::integral_constant<int, S::AHEAD + ph_issued_before<S>(P)>{}, std::integral_constant<int, S::cnt[P]>{});
+          constexpr int W = ph_wait<S>(P);
+          if (!c_live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else if (counted) wait_vmcnt<W>();
+          __builtin_amdgcn_sched_barrier(0);
+          __builtin_amdgcn_s_barrier();
+          OSUD_WG_WAIT(0);
+          if constexpr (P == 2) {  // (wave 0 wrote the word in front of phase 1's first barrier and waited for it behind that barrier: two barriers ago at the latest)
+            if (draw) {
+              const int c = __builtin_amdgcn_readfirstlane((int)q_word[0]);
+              s_nxt = c < nch ? c : 0x7fffffff;
+            }
+          }
+          __builtin_amdgcn_s_setprio(1);
+          mma_frags<RY, RX>(acc, f);
+          __builtin_amdgcn_s_setprio(0);
+          __builtin_amdgcn_sched_barrier(0);
+          const bool last = st == len - 1 && (!dyn || s_nxt >= nch);  // (the tile's last stage)
+          if (P != NPH - 1 || !last || grp == 0) __builtin_amdgcn_s_barrier();
+        });
+        r_buf = STAGE - r_buf;
+      }
+      tile_first = false;
+      s_cur = dyn ? s_nxt : 0x7fffffff;
+      s_nxt = 0x7fffffff;
+    } while (dyn && s_cur < nch);
+    s_cur = 0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     // ---- the tile's partial slab (as wgrad_kernel's store_tile)
 #pragma unroll
@@ -536,6 +594,12 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
     }
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
+    if (dyn) break;  // (one tile per workgroup)
+  }
+  if (dyn && wave == 0 && lane == 0) {  // the last workgroup out re-arms the counters
+    const unsigned done = __hip_atomic_fetch_add(p.queue + 63, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == gridDim.x * gridDim.y - 1)
+      for (int i = 0; i < 64; ++i) __hip_atomic_store(p.queue + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -638,7 +702,7 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(Wgrad8P p) {
       const int piece = wave * PPW + q;
       const char* sbase = (piece * 1024 < YB) ? gp : gq;
       const uint32_t dst = stage_lds + (uint32_t)__builtin_amdgcn_readfirstlane(piece * 1024);
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(dma_off[q]), "s"(sbase), "s"(dst) : "memory");
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(dma_off[q]), "s"(sbase), "s"(dst) : "memory", "m0");
     }
     ++issued;
     ++ic_st;
@@ -889,7 +953,8 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
   }
   // one unit per workgroup in the plain mode: XCD-contiguous unit order (WgradP::xcd_units)
   p.xcd_units = (S > 1 && p.queue == nullptr) ? 1 : 0;
-  if (geo == 0 && p.queue == nullptr && opt(OPT_GEMM_LOOP) != 0 && stages / S >= 2) {  // the phased schedule (same bits)
+  // the phased schedule (same bits; queue mode: chunks of at least four stages, so that a chunk's ticket is known before the stream needs it)
+  if (geo == 0 && opt(OPT_GEMM_LOOP) != 0 && stages / S >= 2 && (p.queue == nullptr || stages / p.chunk >= 4)) {
     constexpr size_t lds = 2 * (size_t)WGeo<2, 4, 4, 2>::STAGE + 8 * 4096;
     static bool attr_set = false;
     if (!attr_set) {

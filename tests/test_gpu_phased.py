@@ -117,6 +117,50 @@ def test_weight_gradient_kernel_is_bit_identical_to_the_slab_loop(osud_option, s
     assert float((b - ref).abs().max()) < 1e-3 * float(ref.abs().max())
 
 
+def test_ticket_queues_in_the_phased_loops(osud_option):
+    """Shared-GPU mode (osud_set_gemm_dynamic_tiles(1), what a data-parallel trainer switches on) INSIDE the phased loops: multi-round GEMM
+    launches draw their tiles from the per-XCD ticket queues (every tile is computed the same way whoever takes it: bit-identical to the
+    static order, in both loops, also with an odd slab count), and the split-K weight-gradient kernel draws K-chunks per tile through a
+    scalar atomic (the partial sums then depend on who took which chunk: equal to rounding).  Each case twice: the second launch runs on
+    counters the first one re-armed."""
+    L = _lib.lib()
+    g = torch.Generator(device=DEV).manual_seed(11)
+    osud_option("gemm_loop", 1)
+    try:
+        for M, N, K, tile, epi in ((8192, 3072, 768, 256, "gelu"), (8192, 2304, 320, 192, "bias"), (16384, 768, 3072, 192, "bias"), (16384, 3072, 192, 256, "gelu")):
+            osud_option("gemm_tile", tile)
+            Y = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+            X = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5).to(torch.bfloat16)
+            bias = torch.randn(N, device=DEV, generator=g)
+            outs = []
+            for mode in (0, 1, 1):
+                _lib.check(L.osud_set_gemm_dynamic_tiles(mode))
+                out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+                _gemm(_lib.PREC_BF16, epi, Y, K, X, K, M, N, K, out, bias, None)
+                torch.cuda.synchronize()
+                outs.append(out)
+            assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), (M, N, K, tile)
+        osud_option("gemm_tile", 0)
+        for Ny, Nx, M in ((768, 768, 32768), (3072, 768, 32768), (768, 2304, 16384)):  # chunks of >= 4 stages: the phased kernel takes the queued launch
+            P = torch.randn(M, Ny, device=DEV, generator=g).to(torch.bfloat16)
+            Q = torch.randn(M, Nx, device=DEV, generator=g).to(torch.bfloat16)
+            ws = torch.empty(32 * Ny * Nx, device=DEV)
+            outs = []
+            for mode in (0, 1, 1):
+                _lib.check(L.osud_set_gemm_dynamic_tiles(mode))
+                out = torch.full((Ny, Nx), float("nan"), device=DEV)
+                ws.fill_(float("nan"))
+                _lib.check(L.osud_op_wgrad(_lib.ptr(P), Ny, _lib.ptr(Q), Nx, Ny, Nx, M, _lib.ptr(out), _lib.ptr(ws), ws.numel(), None))
+                torch.cuda.synchronize()
+                outs.append(out)
+            scale = float(outs[0].abs().max())
+            assert float((outs[1] - outs[0]).abs().max()) < 2e-5 * scale and float((outs[2] - outs[0]).abs().max()) < 2e-5 * scale, (Ny, Nx, M)
+            ref = P.float().t() @ Q.float()
+            assert float((outs[2] - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+    finally:
+        _lib.check(L.osud_set_gemm_dynamic_tiles(-1))
+
+
 def _model(shape, sd, precision, train=False):
     m = DiT(depth=shape.depth, hidden_size=shape.hidden, num_heads=shape.heads, context_size=shape.context, num_classes=shape.num_classes,
             class_dropout_prob=0.2, precision=precision)
