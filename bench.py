@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--zero1", action="store_true", help="N > 1: sharded optimizer between reduce-scatter and all-gather instead of all-reduce")
     ap.add_argument("--grad-wire", choices=["fp32", "bf16"], default="fp32", help="--zero1: dtype of the gradients on the wire")
     ap.add_argument("--native-comm", action="store_true", help="N > 1: the timed exchange goes through the library's own RCCL communicator (C ABI)")
+    ap.add_argument("--no-schedule-selection", action="store_true", help="N > 1: time the all-reduce schedule as given instead of measuring both exchange schedules first and keeping the faster")
     ap.add_argument("--no-exchange-ab", action="store_true", help="N > 1: skip the in-run A/B of the exchange schedules (multi_gpu.schedules)")
     ap.add_argument("--watchdog-s", type=float, default=900.0, help="N > 1: if the collective diagnostics after the timed region have not returned after this "
                                                                     "many seconds, rank 0 prints the line with what is measured and every rank exits")
@@ -90,9 +91,12 @@ class Watchdog:
         self.lock = threading.Lock()
         self.res, self.rank, self.deadline, self.done, self.stage = None, 0, None, False, "after the timed region"
 
-    def arm(self, res, rank, seconds):
+    def arm(self, res, rank, seconds, stage=None):
         self.res, self.rank, self.deadline = res, rank, time.monotonic() + seconds
         self.seconds = seconds
+        self.done = False
+        if stage is not None:
+            self.stage = stage
         threading.Thread(target=self._run, daemon=True).start()
 
     def disarm(self):
@@ -118,6 +122,7 @@ class Watchdog:
 
 
 WATCHDOG = Watchdog()
+WATCHDOG_PRE = Watchdog()  # (the schedule selection in FRONT of the timed region is collective too: a hang there must still end the run)
 
 
 def dist_setup(args):
@@ -624,6 +629,17 @@ def bench_train(args, world, rank, dev):
     for i in range(4):  # a few distinct resident batches, cycled
         (x, o, c), y = synthetic_windows(B, T, num_classes, seed=10_000 * rank + i, train_offsets=True)
         batches.append(((x.to(dev), o.to(dev), c.to(dev)), y.to(dev)))
+    # N > 1: the exchange schedule of the timed region is MEASURED first (3 steps each of the all-reduce and the sharded-optimizer form, the
+    # faster one is kept on every rank) unless a flag names it: the first multi-GPU line must not depend on RCCL's own algorithm choice
+    selected = None
+    if world > 1 and not args.zero1 and not args.native_comm and not args.no_schedule_selection:
+        from osu_diffusion_amd.training import select_exchange_schedule
+        WATCHDOG_PRE.arm({"metric": f"{args.model} seq{args.seq_len} train tokens/sec", "value": None, "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None},
+                         rank, args.watchdog_s, stage="schedule selection (before the timed region)")
+        selected = select_exchange_schedule(lambda shard_optimizer: NativeTrainer(model, diffusion, lr=1e-4, shard_optimizer=shard_optimizer),
+                                            batches, steps=3, warmup=1, device=dev)
+        WATCHDOG_PRE.disarm()
+        args.zero1 = selected["name"] == "zero1"
     trainer = NativeTrainer(model, diffusion, lr=1e-4, shard_optimizer=args.zero1,
                             wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None, native_comm=args.native_comm)
     terms = None
@@ -728,12 +744,16 @@ def bench_train(args, world, rank, dev):
         trainer = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_train(model, args, batches[0])
+    if world > 1 and args.no_exchange_ab and selected is not None:
+        res["multi_gpu"] = {"schedule_selected": selected}
     if world > 1 and not args.no_exchange_ab:  # (every rank takes part: the legs are collective)
         timed_name = ("zero1" if args.zero1 else "allreduce") + (" + native_comm" if args.native_comm else "")
         del trainer
         trainer = None
         torch.cuda.empty_cache()
         res["multi_gpu"] = multi_gpu_report(args, world, rank, dev, model, diffusion, batches, dt / K * 1e3, timed_name)
+        if selected is not None:
+            res["multi_gpu"]["schedule_selected"] = selected
     del trainer, model
     torch.cuda.empty_cache()
     from osu_diffusion_amd import _lib

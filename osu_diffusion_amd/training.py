@@ -278,6 +278,56 @@ def backward_with_overlapped_allreduce(model, dout, group=None, force=False, on_
     return world_scale
 
 
+def select_exchange_schedule(make_trainer, batches, group=None, steps=3, warmup=1, device=None):
+    """world > 1: which gradient exchange this job should run -- decided by MEASUREMENT at start-up, on this node, this RCCL build and
+    this topology, instead of by RCCL's per-call algorithm choice: `steps` training steps each of `allreduce` (per-slice all-reduces under
+    the phased backward) and `zero1` (reduce-scatter -> AdamW / EMA on the own shard -> all-gather of the masters), each behind `warmup`
+    untimed steps and bracketed by barriers; a schedule's time is the MAX over ranks, so that every rank keeps the same one.  On xGMI a ring
+    all-reduce moves 2 (W - 1) / W of the payload over ONE link per direction, the mesh form payload / W per link over all of them
+    (5.98 ms vs 0.85 ms per DiT-B step at 8 ranks, unoverlapped) -- the first multi-GPU run must not land on the
+    slow one by default.  `make_trainer(shard_optimizer=...)` builds a trainer (the steps run on the caller's model: a few real
+    optimisation steps, like a warm-up); `batches`: [((x, o, c), y), ...].
+    Returns {"name": "allreduce" | "zero1", "allreduce_ms": ..., "zero1_ms": ..., "steps": ..., "world_size": ...}; world 1:
+    {"name": "allreduce", "skipped": ...} without running anything."""
+    import time
+
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        return {"name": "allreduce", "skipped": "one rank: nothing to exchange"}
+    world = dist.get_world_size(group)
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+
+    def fence():
+        dist.barrier(group=group)
+        if on_gpu:
+            torch.cuda.synchronize(device)
+
+    out = {"steps": int(steps), "world_size": world}
+    for name, shard in (("allreduce", False), ("zero1", True)):
+        tr = make_trainer(shard_optimizer=shard)
+        for i in range(warmup):
+            (x, o, c), y = batches[i % len(batches)]
+            tr.step(x, o, c, y)
+        tr.finish_exchange()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            (x, o, c), y = batches[i % len(batches)]
+            tr.step(x, o, c, y)
+        tr.finish_exchange()
+        fence()
+        ms = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64, device=device if on_gpu else "cpu")
+        dist.all_reduce(ms, op=dist.ReduceOp.MAX, group=group)
+        out[name + "_ms"] = round(float(ms.item()), 3)
+        del tr
+        if on_gpu:
+            torch.cuda.empty_cache()
+    # (ties and near-ties -- within 2 % -- keep the all-reduce: same results to the last bit as the single-call reference path)
+    out["name"] = "zero1" if out["zero1_ms"] < 0.98 * out["allreduce_ms"] else "allreduce"
+    return out
+
+
 # ------------------------------------------------------------------------------ ZeRO-1 exchange (reduce-scatter / all-gather)
 def shard_plan(lo, hi, world, align=4):
     """How one contiguous gradient slice [lo, hi) of the flat arena is exchanged when the optimizer is sharded: a bulk of

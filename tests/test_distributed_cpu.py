@@ -1,6 +1,7 @@
 """CPU, world_size 2 over gloo: the N > 1 pieces of the training path that do not need a GPU — the
 per-rank data sharding rule (train.py:165-170, data_loading.py:366-376) and the flat-arena gradient
 averaging that replaces DDP's bucketed all-reduce (train.py:152,257)."""
+import json
 import os
 import socket
 
@@ -397,6 +398,10 @@ def _bench_report_worker(rank, world, port, out):
         args = argparse.Namespace(batch=4, seq_len=64, precision="bf16", steps=4, simulate_hang=False)
         batches = [((None, None, None), None)] * 4
         rep = bench.multi_gpu_report(args, world, rank, torch.device("cpu"), m, None, batches, 12.5, "allreduce", trainer_factory=_StubTrainer)
+        # ... and the start-up choice of the exchange schedule, as bench_train records it (multi_gpu.schedule_selected)
+        from osu_diffusion_amd.training import select_exchange_schedule
+
+        rep["schedule_selected"] = select_exchange_schedule(lambda shard_optimizer: _StubTrainer(m, None, shard_optimizer=shard_optimizer), batches, steps=3, warmup=1)
         out[rank] = rep
     finally:
         dist.destroy_process_group()
@@ -443,5 +448,63 @@ def test_bench_multi_gpu_report_schema_at_world_8():
 
     p = bench.predicted_comm_ms(4 * (170_370_054 - 52_671 * 768), 8 * 256 * (768 * 4 + 8), 8)
     assert abs(p["ring_allreduce_unoverlapped"] - 5.98) < 0.03 and abs(p["mesh_reduce_scatter_allgather_unoverlapped"] - 0.854) < 0.01
-    for r in range(1, world):  # every rank computed the same report skeleton
+    sel = rep["schedule_selected"]
+    assert sel["name"] in ("allreduce", "zero1") and sel["allreduce_ms"] > 0 and sel["zero1_ms"] > 0 and sel["steps"] == 3 and sel["world_size"] == world
+    for r in range(1, world):  # every rank computed the same report skeleton -- and KEPT THE SAME SCHEDULE (the times are maxima over ranks)
         assert res[r]["rccl"]["ranks_seen"] == world and set(res[r]["schedules"]) == set(sched)
+        assert res[r]["schedule_selected"] == sel
+    line = json.loads(bench.compact_line({"metric": "m", "value": 1.0, "unit": "tokens/s", "n_gpus": world, "steps": 4, "warmup": 1, "ms_per_step": 12.5,
+                                          "config": {"workload": "w"}, "multi_gpu": rep}))
+    assert line["multi_gpu"]["schedule_selected"] == sel and len(json.dumps(line)) < bench.LINE_LIMIT
+
+
+class _SlowExchangeTrainer:
+    """A trainer whose step costs `base` seconds plus `extra[schedule]`: the selection logic must keep the faster schedule, the same on every rank
+    -- also when the ranks disagree about which one was faster locally (rank 1's all-reduce steps are made slow: the MAX over ranks decides)."""
+
+    def __init__(self, shard_optimizer, extra):
+        self.delay = 0.004 + extra["zero1" if shard_optimizer else "allreduce"]
+        self.t = torch.zeros(4)
+
+    def step(self, x, o, c, y):
+        import time
+
+        time.sleep(self.delay)
+        dist.all_reduce(self.t)
+
+    def finish_exchange(self):
+        pass
+
+
+def _selection_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from osu_diffusion_amd.training import select_exchange_schedule
+
+        batches = [((None, None, None), None)] * 2
+        res = {}
+        # (a) the sharded form is slower everywhere -> allreduce; (b) the all-reduce is slow on rank 1 only -> zero1, on BOTH ranks;
+        # (c) a near-tie (1 %) keeps the all-reduce
+        for case, extra in (("a", {"allreduce": 0.0, "zero1": 0.02}), ("b", {"allreduce": 0.03 if rank == 1 else 0.0, "zero1": 0.01}),
+                            ("c", {"allreduce": 0.0500, "zero1": 0.0495})):
+            res[case] = select_exchange_schedule(lambda shard_optimizer, e=extra: _SlowExchangeTrainer(shard_optimizer, e), batches, steps=3, warmup=1)
+        out[rank] = res
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_schedule_is_selected_by_measurement_and_agreed_by_every_rank():
+    world = 2
+    port = _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_selection_worker, args=(world, port, out), nprocs=world, join=True)
+        res = dict(out)
+    assert res[0] == res[1]  # same times (maxima over ranks), same choice
+    assert res[0]["a"]["name"] == "allreduce" and res[0]["a"]["zero1_ms"] > res[0]["a"]["allreduce_ms"]
+    assert res[0]["b"]["name"] == "zero1" and res[0]["b"]["allreduce_ms"] > 30.0  # rank 1's slow steps decide for both
+    assert res[0]["c"]["name"] == "allreduce"
+    from osu_diffusion_amd.training import select_exchange_schedule
+
+    assert select_exchange_schedule(None, [])["name"] == "allreduce"  # no process group: nothing is run

@@ -204,7 +204,14 @@ def test_bench_two_ranks_over_gloo():
         assert "skipped" in mg["schedules"]["native_comm"]
         assert mg["fastest_schedule"] in ("allreduce", "zero1", "zero1_no_overlap")
         assert isinstance(mg["exposed_comm_ms_per_step"], float)
-        assert mg["timed_schedule"]["name"] == ("zero1" if extra else "allreduce") and mg["timed_schedule"]["ms_per_step"] > 0
+        # without a flag the timed schedule is the one MEASURED faster at start-up (training.select_exchange_schedule), the same on both ranks
+        if extra:
+            assert mg["timed_schedule"]["name"] == "zero1" and "schedule_selected" not in mg
+        else:
+            sel = mg["schedule_selected"]
+            assert sel["name"] in ("allreduce", "zero1") and sel["allreduce_ms"] > 0 and sel["zero1_ms"] > 0 and sel["world_size"] == 2
+            assert mg["timed_schedule"]["name"] == sel["name"]
+        assert mg["timed_schedule"]["ms_per_step"] > 0
         wb = mg["wire_bytes_per_step"]
         assert wb["dense_slices_payload"] > 0 and wb["class_table_rows_allgather"] < wb["class_table_dense_would_be"] and wb["ring_bytes_sent_per_gpu"] > 0
 

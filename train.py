@@ -73,6 +73,21 @@ def main(args):
                                                          "operands, delayed per-tensor scaling; attention / adaLN / embedders bf16; fp32 masters)"
                                                          if args.precision == "fp8" else ""))
     # AdamW(lr, wd=0) + EMA 0.9999 + init broadcast; the exchange options are flags of this script (--zero1, --grad-wire, --native-comm)
+    if args.select_exchange and world_size > 1 and not args.zero1 and not args.native_comm:
+        # which exchange this node runs faster is MEASURED -- 3 steps each on synthetic windows of the run's shape, with lr = 0 on throw-away
+        # trainers (the weights the run starts from are not touched; moments and EMA copies die with the probe) -- and agreed by all ranks
+        from osu_diffusion_amd.synthetic import synthetic_windows
+        from osu_diffusion_amd.training import select_exchange_schedule
+
+        probe = []
+        for i in range(2):
+            (px, po, pc), py = synthetic_windows(args.global_batch_size // world_size, args.seq_len, args.num_classes, seed=977 * rank + i, train_offsets=True)
+            probe.append(((px.to(device), po.to(device), pc.to(device)), py.to(device)))
+        model.train()
+        sel = select_exchange_schedule(lambda shard_optimizer: NativeTrainer(model, diffusion, lr=0.0, shard_optimizer=shard_optimizer, broadcast_init=False),
+                                       probe, steps=3, warmup=1, device=device)
+        args.zero1 = sel["name"] == "zero1"
+        logger.info(f"exchange schedule selected by measurement: {sel}")
     trainer = NativeTrainer(model, diffusion, lr=args.lr, shard_optimizer=args.zero1,
                             wire_dtype=torch.bfloat16 if args.grad_wire == "bf16" else None, native_comm=args.native_comm)
     model.train()
@@ -188,6 +203,8 @@ def parse_args(argv=None):
                         "(BASELINE config 5: DiT-XL, seq-len 256)")
     p.add_argument("--zero1", action="store_true",
                    help="multi-GPU: reduce-scatter / sharded AdamW + EMA / all-gather instead of the gradient all-reduce")
+    p.add_argument("--select-exchange", action="store_true",
+                   help="multi-GPU: time 3 steps each of the all-reduce and the --zero1 exchange at start-up and keep the faster (every rank the same)")
     p.add_argument("--grad-wire", choices=["fp32", "bf16"], default="fp32", help="--zero1: dtype of the gradients on the wire")
     p.add_argument("--native-comm", action="store_true",
                    help="multi-GPU: the exchange through the library's own RCCL communicator (C ABI) instead of torch.distributed")
