@@ -934,8 +934,11 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
     int t0 = 0, t1 = 0, t2 = 0;
     const double s0 = score(256, 256, &t0);
     const double s1 = Nx % 192 == 0 ? score(256, 192, &t1) : 0.0, s2 = Ny % 192 == 0 ? score(192, 256, &t2) : 0.0;
-    if (s1 >= s2 && s1 > 1.12 * s0) { geo = 1; tiles = t1; }
-    else if (s2 > s1 && s2 > 1.12 * s0) { geo = 2; tiles = t2; }
+    // (the 256 x 256 geometry runs the phased schedule -- 10-12 % faster per useful FLOP than the 192-wide slab kernels at DiT-XL's four shapes
+    //  although it fills the chip a third worse there: 1112 vs 1223 us for a block's weight gradients, profiles/r06_wgrad_xl_geometry.txt)
+    const double margin = opt(OPT_GEMM_LOOP) != 0 ? 1.5 : 1.12;
+    if (s1 >= s2 && s1 > margin * s0) { geo = 1; tiles = t1; }
+    else if (s2 > s1 && s2 > margin * s0) { geo = 2; tiles = t2; }
   }
   const int stages = M / BKT;
   // fill the chip in ONE round: splits = CUs / tiles, each split at least 8 stages (512 tokens)
