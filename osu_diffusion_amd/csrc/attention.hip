@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
       const int p = 4 * wave + i, t = p >> 3, pp = p & 7;  // tile (K, V), piece inside the tile
       const char* sb = reinterpret_cast<const char*>(qk + ((size_t)n * Tp + kb * 64 + pp * 8) * ldq + (size_t)(1 + t) * D + h * HD);
       const uint32_t dst = lds0 + (uint32_t)(stage * STAGE + t * TILE + pp * 1024);
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"((pp & 1) ? voff_odd : voff_even), "s"(sb), "s"(dst) : "memory", "m0");
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"((pp & 1) ? voff_odd : voff_even), "s"(sb), "s"(dst) : "memory");
     }
   };
   bool chk_cur = false, chk_nxt = false;
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_kernel(const bf16_t* __re
     for (int pp = 0; pp < T / 16; ++pp) {
       const char* sb = base + (size_t)pp * 8 * ldb;
       const uint32_t dst = dst0 + pp * 1024;
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"((pp & 1) ? voff_odd : voff_even), "s"(sb), "s"(dst) : "memory", "m0");
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"((pp & 1) ? voff_odd : voff_even), "s"(sb), "s"(dst) : "memory");
     }
   };
   const int hw = wave >> 2, own = (wave & 3) * 32;  // which head of the pair, first query of this wave
@@ -642,7 +642,7 @@ __global__ __launch_bounds__(512) void attn_fwd_stream_x3_kernel(const bf16_t* _
     for (int pp = 0; pp < KB / 8; ++pp) {
       const char* sb = base + (size_t)pp * 8 * ldb;
       const uint32_t dst = dst0 + pp * 1024;
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"((pp & 1) ? voff_odd : voff_even), "s"(sb), "s"(dst) : "memory", "m0");
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"((pp & 1) ? voff_odd : voff_even), "s"(sb), "s"(dst) : "memory");
     }
   };
   const int hw = wave >> 2, own = (wave & 3) * 32;  // which head of the pair, first query of this wave
@@ -861,7 +861,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_stream72_kernel(const bf16_t*
         const int gi = pp * 64 + lane_o, row = (gi * 5042) >> 16, c = gi - 13 * row;
         const char* src = c < 9 ? (t ? yb : xb) + (size_t)row * ldb + c * 16 : zsrc;
         const uint32_t dst = lds0 + (uint32_t)(stage * STAGE + t * TILE + pp * 1024);
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory");
       }
     }
   };

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512) void attn_bwd_stream_kernel(const bf16_t* __re
     for (int pp = 0; pp < T / 16; ++pp) {  // (T / 16 is even: piece parity = pp parity)
       const char* sb = base + (size_t)pp * 8 * ldb;
       const uint32_t dst = dst0 + pp * 1024;
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"((pp & 1) ? voff_odd : voff_even), "s"(sb), "s"(dst) : "memory", "m0");
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"((pp & 1) ? voff_odd : voff_even), "s"(sb), "s"(dst) : "memory");
     }
   };
   // delta = rowsum(dO . O) and lse of the NEXT head are made while this head's stores drain: thread (row r = tid / 4, quarter =
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_stream72_kernel(const bf16_t*
         const int gi = pp * 64 + lane_o, row = (gi * 5042) >> 16, c = gi - 13 * row;
         const char* src = c < 9 ? (t ? yb + (size_t)row * yld : xb + (size_t)row * xld) + c * 16 : zsrc;
         const uint32_t dst = lds0 + (uint32_t)(stage * STAGE + t * TILE + pp * 1024);
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(dst) : "memory");
       }
     }
   };

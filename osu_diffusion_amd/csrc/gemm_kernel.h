@@ -336,7 +336,7 @@ __device__ __forceinline__ void stage_slab(const char* gy, const char* gx, uint3
     const int piece = wave * G::PPW + q;  // wave-uniform
     const char* sbase = (piece * G::RPP < G::BM) ? gy : gx;
     const uint32_t dst = stage_lds + (uint32_t)__builtin_amdgcn_readfirstlane(piece * 1024);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff[q]), "s"(sbase), "s"(dst) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff[q]), "s"(sbase), "s"(dst) : "memory");
   }
 }
 

@@ -211,7 +211,7 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
     const char* sb = S::is_y(m) ? c_gy : c_gx;
     const uint32_t dst = lds0 + c_buf + (uint32_t)((8 * m + wave) * 1024);
     const uint32_t vo = voff[m];  // (named outside the asm statement: an asm operand alone does not capture in a generic lambda)
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(sb), "s"(dst) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(sb), "s"(dst) : "memory");
   };
   auto advance = [&]() {
     c_buf = STAGE - c_buf;

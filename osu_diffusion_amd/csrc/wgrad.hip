@@ -29,6 +29,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
 
 template <int OFF> __device__ __forceinline__ u32x2 ds_read_tr(uint32_t addr) {
   u32x2 v;
@@ -72,7 +73,7 @@ __device__ __forceinline__ void stage_tokens(const char* gp, const char* gq, uin
     const int piece = wave * G::PPW + q;  // wave-uniform
     const char* sbase = (piece * 1024 < G::YB) ? gp : gq;
     const uint32_t dst = stage_lds + (uint32_t)__builtin_amdgcn_readfirstlane(piece * 1024);
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff[q]), "s"(sbase), "s"(dst) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff[q]), "s"(sbase), "s"(dst) : "memory");
   }
 }
 
@@ -384,17 +385,29 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
   const int frow = lane & 31, fhalf = lane >> 5;
   const int ntx = (p.Nx + G::BN - 1) / G::BN, ntiles = ((p.Ny + G::BM - 1) / G::BM) * ntx;
   const int st_total = p.M / BKT;
-  // Shared-GPU mode (p.queue != nullptr: one (tile, split) unit per workgroup, blockIdx = (tile, split)): the token axis of the tile is cut
-  // into p.chunk chunks, workgroup `split` starts on chunk `split` and draws every later chunk from the tile's ticket counter, accumulating in
-  // registers -- wgrad_kernel's queue mode in the phased schedule.  A run of stages ("segment") is a tile's share of the token axis in the
-  // plain mode and one chunk in the queue mode; the staging stream runs from segment to segment, the epilogue follows a TILE.
-  // The ticket is a SCALAR atomic (s_atomic_add ... glc: the value before the add comes back in an SGPR and is tracked by lgkmcnt -- gfx950
-  // executes it, tools/probes/satomic_probe.hip), so it never enters the vector-memory queue whose counted waits the stream lives on: wave 0
-  // requests it in phase 0 of a chunk's first stage, the value is back behind that phase's own lgkmcnt(0), goes to the first word of wave 0's
-  // (idle) epilogue patch in phase 1 and is read by every wave in phase 2 -- one and a half stages before the cursor needs it at the
-  // earliest (chunks have at least four stages: the launcher's condition).
+  // Shared-GPU mode (p.queue != nullptr; one (tile, split) unit per workgroup, placed as in the plain mode): the split's share of the token
+  // axis is cut into per_wg = p.chunk / split_k chunks.  The workgroup OWNS its split's chunks and walks them front to back -- in an undisturbed
+  // launch exactly the plain mode's stages in the plain mode's order: the same L2 locality (WgradP::xcd_units) and the same bits -- but it
+  // has to CLAIM every chunk after the first from the split's counter word, because a workgroup that has run out of chunks (its own compute
+  // unit was free while another's was held by a collective) steals from the BACK of the other splits of its tile:
+  //     word = {low 16 bits: chunks the owner has claimed beyond chunk 0 | high 16 bits: chunks stolen from the back}
+  //     owner: old = add(word, 1)        -> chunk 1 + old.lo, valid while 1 + old.lo <= per_wg - 1 - old.hi
+  //     thief: old = add(word, 1 << 16)  -> chunk per_wg - 1 - old.hi, valid under the same condition
+  // (an invalid claim only pushes a counter further past the other: the range stays empty).  A stolen chunk is accumulated in the thief's
+  // registers and leaves in the thief's partial slab: the combine adds the slabs in a fixed order, so only WHICH slab holds a chunk's sum
+  // -- rounding -- depends on who was held.  A run of stages ("segment") is a tile's share of the token axis in the plain mode and one
+  // chunk here; the staging stream runs from segment to segment, the epilogue follows a TILE.
+  // The claims are SCALAR atomics (s_atomic_add ... glc: the value before the add comes back in an SGPR and is tracked by lgkmcnt -- gfx950
+  // executes it, tools/probes/satomic_probe.hip), so they never enter the vector-memory queue whose counted waits the stream lives on.
+  // Wave 0 runs the protocol in the phases of a chunk's first two stages, one scalar memory operation per phase, issued at the phase's top and
+  // found back behind the phase's own barrier + lgkmcnt(0) (~300 ns on an idle chip, tools/probes/satomic_latency.hip: the price of a chunk): the
+  // claim on the own word; once the own share is used up, a LOOK at eight words of the tile's row (s_load_dwordx8 ... glc) for the split with the
+  // most unclaimed chunks, then the claim on that split's word.  An undisturbed launch pays one claim per chunk and, at its end, one failed
+  // claim and one look that finds nothing.  The chunk goes out through the first word of wave 0's (idle) epilogue patch (six operations at most:
+  // up to phase 1 of the second stage); all waves read it in phase 3 of the second stage -- the cursor of a four-stage chunk, the shortest
+  // the launcher allows, moves on in phase 1 of the third.
   const bool dyn = p.queue != nullptr;
-  const int nch = dyn ? p.chunk : 1;
+  const int nch = dyn ? p.chunk : 1, per_wg = dyn ? p.chunk / p.split_k : 1;
   auto chunk_begin = [&](int c) { return (int)((long)c * st_total / nch); };  // (lengths differ by at most one stage)
   int sidx = blockIdx.y, bx = blockIdx.x;
   if (p.xcd_units) {  // (tile, split) units in split-major order, one contiguous run per XCD: see WgradP::xcd_units
@@ -416,7 +429,7 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
     const int b = blockIdx.x, q = G8 >> 3, r = G8 & 7, xcd = b & 7, idx = b >> 3;
     first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     if (p.xcd_units) first = bx;
-    if (dyn) first = blockIdx.x;
+    if (dyn) first = bx;
   }
 
   // fragment addresses (stage 0, sub-step 0), exactly wgrad_kernel's
@@ -449,7 +462,7 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
       reinterpret_cast<volatile __attribute__((address_space(3))) uint32_t*>((lds_void*)smem) + RING / 4;  // (wave 0's patch: idle until the tile's store)
 
   // ---- segments: (first stage, stages).  Plain: one per tile, the same range for every tile.  Queue: the chunks this workgroup draws.
-  int s_cur = dyn ? (int)blockIdx.y : 0, s_nxt = 0x7fffffff;  // queue mode: the consumer's chunk and the one after it (known from phase 2 of s_cur's first stage on)
+  int s_cur = dyn ? sidx * per_wg : 0, s_nxt = 0x7fffffff;  // queue mode: the consumer's chunk and the one after it (known from phase 3 of s_cur's second stage on)
   auto seg_first = [&](int c) { return dyn ? chunk_begin(c) : 0; };
   auto seg_len = [&](int c) { return dyn ? chunk_begin(c + 1) - chunk_begin(c) : nst; };
 
@@ -469,7 +482,7 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
     const char* sb = (m & 1) == 0 ? c_gp : c_gq;
     const uint32_t dst = lds0 + c_buf + (uint32_t)(((m & 1) ? G::YB : 0) + (8 * (m >> 1) + wave) * 1024);
     const uint32_t vo = voff[m];
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(sb), "s"(dst) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(sb), "s"(dst) : "memory");
   };
   auto advance = [&]() {
     c_buf = STAGE - c_buf;
@@ -504,8 +517,44 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
   __builtin_amdgcn_s_barrier();
 
   uint32_t r_buf = 0;
-  uint32_t tkq = 0;  // queue mode, wave 0: the increment on the way in, the tile's ticket (chunks drawn so far) on the way out
-  const unsigned* const q_ctr = dyn ? p.queue + blockIdx.x : nullptr;
+  // ---- queue mode, wave 0: the claim protocol (see the top of the kernel).  The SGPR an atomic returns into is defined at the top of a phase and
+  // consumed behind that SAME phase's barrier + lgkmcnt(0): one variable per phase body, no join of two claims, no loop back-edge in between.
+  // The compiler believes an asm result is there at once and is free to copy the register before the value has landed (a version that let a
+  // claim fly into the next phase got exactly such copies): tools/check_satomic.py holds the listing to it -- no path from an s_atomic_add
+  // reads or writes its destination in front of an s_waitcnt lgkmcnt(0); run it after touching this kernel or the toolchain.
+  const unsigned* const q_row = dyn ? p.queue + 1 + bx * p.split_k : nullptr;  // this tile's words, one per split ([0] of the slot counts finished workgroups)
+  bool q_need = false, own_done = false;  // this chunk's successor is still to be found; the own share is used up (persistent)
+  int q_pick = -1, q_win = 0;             // the split to steal from next (-1: look first); the window of eight words the next look covers (persistent)
+  auto q_publish = [&](int chunk) {
+    q_word[0] = (uint32_t)chunk;  // (every lane of wave 0 stores the same word: no per-lane branch inside the scalar protocol)
+    q_need = false;
+  };
+  // what this phase does for the search: 0 claim on the own word, 1 claim on q_pick's, 2 look at window q_win, -1 nothing left anywhere
+  auto q_action = [&]() -> int {
+    if (!own_done) return 0;
+    if (q_pick >= 0) return 1;
+    return q_win * 8 < p.split_k ? 2 : -1;
+  };
+  auto q_land_claim = [&](int on, uint32_t word) {  // the word before the add
+    const int lo = (int)(word & 0xffffu), hi = (int)(word >> 16);
+    if (1 + lo <= per_wg - 1 - hi) q_publish(on * per_wg + (on == sidx ? 1 + lo : per_wg - 1 - hi));
+    else if (on == sidx) own_done = true;
+    else q_pick = -1;  // emptied meanwhile: look again
+  };
+  auto q_land_look = [&](const u32x8& w) {  // eight words of the tile's row from split 8 * q_win: the split with the most unclaimed chunks
+    int best = -1, most = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int split = 8 * q_win + j;
+      const int left = per_wg - 1 - (int)(w[j] >> 16) - (int)(w[j] & 0xffffu);
+      if (split < p.split_k && split != sidx && left > most) {
+        most = left;
+        best = split;
+      }
+    }
+    if (best >= 0) q_pick = best;
+    else ++q_win;  // nothing in these eight, for good (counters only grow)
+  };
   for (int tile = first; tile < ntiles; tile += G8) {
     const int ty = tile / ntx, tx = tile - ty * ntx;
     f32x16 acc[RY][RX];
@@ -522,21 +571,32 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
       const int len = seg_len(s_cur);
       for (int st = 0; st < len; ++st) {
         const bool counted = st > 0 || !tile_first;
-        const bool draw = dyn && st == 0;  // this chunk's first stage: the ticket for the chunk after it
+        const bool draw = dyn && st < 2 && wave == 0;  // wave 0, this chunk's first two stages: the claim for the chunk after it
+        if (draw && st == 0) q_need = true;
         static_for<NPH>([&](auto PH) {
           constexpr int P = decltype(PH)::value;
-          if constexpr (P == 0) {
-            if (draw && wave == 0) {
-              tkq = 1u;
-              asm volatile("s_atomic_add %0, %1, 0x0 glc" : "+s"(tkq) : "s"(q_ctr) : "memory");
+          // queue mode, wave 0: this phase's claim, issued here and found back behind this phase's own barrier + lgkmcnt(0)
+          int q_on = -1;
+          uint32_t q_ret = 0;
+          int q_act = -1;
+          u32x8 q_look;
+#ifndef OSUD_WGQ_NOCLAIM
+          if (draw && q_need) {
+            q_act = q_action();
+            if (q_act < 0) q_publish(0x7fffffff);
+            else if (q_act == 2) {
+              const unsigned* a = q_row + 8 * q_win;
+              asm volatile("s_load_dwordx8 %0, %1, 0x0 glc" : "=s"(q_look) : "s"(a) : "memory");
+            } else {
+              q_on = q_act == 0 ? sidx : q_pick;
+              q_ret = q_act == 0 ? 1u : 0x10000u;
+              const unsigned* a = q_row + q_on;
+              asm volatile("s_atomic_add %0, %1, 0x0 glc" : "+s"(q_ret) : "s"(a) : "memory");
             }
           }
-          if constexpr (P == 1) {  // (the ticket came back with phase 0's lgkmcnt(0))
-            if (draw && wave == 0) {
-              asm volatile("" : "+s"(tkq));
-              if (lane == 0) q_word[0] = (uint32_t)p.split_k + tkq;
-            }
-          }
+#else  // (tuning builds: every workgroup walks its own chunks, no claims, no steals -- what the chunking alone costs)
+          if (draw && q_need) q_publish((s_cur + 1) % per_wg != 0 ? s_cur + 1 : 0x7fffffff);
+#endif
           read_frags<RY, RX, P, G::ROWY, G::ROWX>(f, ya, xa, r_buf);
           stage_run(std::integral_constant<int, S::AHEAD + ph_issued_before<S>(P)>{}, std::integral_constant<int, S::cnt[P]>{});
           constexpr int W = ph_wait<S>(P);
@@ -545,8 +605,18 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
           __builtin_amdgcn_sched_barrier(0);
           __builtin_amdgcn_s_barrier();
           OSUD_WG_WAIT(0);
-          if constexpr (P == 2) {  // (wave 0 wrote the word in front of phase 1's first barrier and waited for it behind that barrier: two barriers ago at the latest)
-            if (draw) {
+          if (q_act >= 0) {  // (wave 0, a claim or a look in flight: back with the wait above)
+            if (q_act == 2) {
+              asm volatile("" : "+s"(q_look));
+              q_land_look(q_look);
+            } else {
+              asm volatile("" : "+s"(q_ret));
+              q_land_claim(q_on, q_ret);
+            }
+            if (q_need && ((P >= 1 && st == 1) || q_action() < 0)) q_publish(0x7fffffff);  // out of time (six operations), or nothing left anywhere
+          }
+          if constexpr (P == 3) {  // (wave 0 published behind the wait of the second stage's phase 1 at the latest: two phases = four barriers ago)
+            if (dyn && st == 1) {
               const int c = __builtin_amdgcn_readfirstlane((int)q_word[0]);
               s_nxt = c < nch ? c : 0x7fffffff;
             }
@@ -597,9 +667,9 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
     if (dyn) break;  // (one tile per workgroup)
   }
   if (dyn && wave == 0 && lane == 0) {  // the last workgroup out re-arms the counters
-    const unsigned done = __hip_atomic_fetch_add(p.queue + 63, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned done = __hip_atomic_fetch_add(p.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (done == gridDim.x * gridDim.y - 1)
-      for (int i = 0; i < 64; ++i) __hip_atomic_store(p.queue + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int i = 0; i < 1 + (int)(gridDim.x * gridDim.y); ++i) __hip_atomic_store(p.queue + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -702,7 +772,7 @@ __global__ __launch_bounds__(512) void wgrad8_kernel(Wgrad8P p) {
       const int piece = wave * PPW + q;
       const char* sbase = (piece * 1024 < YB) ? gp : gq;
       const uint32_t dst = stage_lds + (uint32_t)__builtin_amdgcn_readfirstlane(piece * 1024);
-      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(dma_off[q]), "s"(sbase), "s"(dst) : "memory", "m0");
+      asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(dma_off[q]), "s"(sbase), "s"(dst) : "memory");
     }
     ++issued;
     ++ic_st;
@@ -869,19 +939,20 @@ int num_cus_w() {
   return n[dev];
 }
 
-// counter sets of the chunk queues (64 words each: [tile] tickets, [63] finished workgroups), re-armed by the last workgroup out
-constexpr int kQueueSlots = 64;
+// counter sets of the chunk queues, re-armed by the last workgroup out.  wgrad_kernel's queue mode: [tile] tickets, [63] finished workgroups;
+// wgrad_phased_kernel's: [0] finished workgroups, [1 + tile * splits + split] the split's claim word (tiles x splits <= compute units)
+constexpr int kQueueSlots = 64, kQueueWords = 576;
 unsigned* g_queue_pool[kMaxDevices] = {};
 unsigned* queue_slot() {
   static std::atomic<unsigned> seq{0};
   const int dev = cur_device_w();
   if (!g_queue_pool[dev]) {
     unsigned* pool = nullptr;
-    if (hipMalloc(&pool, kQueueSlots * 64 * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemset(pool, 0, kQueueSlots * 64 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMalloc(&pool, kQueueSlots * kQueueWords * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipMemset(pool, 0, kQueueSlots * kQueueWords * sizeof(unsigned)) != hipSuccess) return nullptr;
     g_queue_pool[dev] = pool;
   }
-  return g_queue_pool[dev] + 64 * (seq.fetch_add(1) % kQueueSlots);
+  return g_queue_pool[dev] + kQueueWords * (seq.fetch_add(1) % kQueueSlots);
 }
 
 template <int WY, int WX, int RY, int RX> int launch_wg(const WgradP& p, hipStream_t st) {
@@ -949,15 +1020,24 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
   WgradP p{};
   p.P = (const bf16_t*)P; p.Q = (const bf16_t*)Q; p.ldp = ldp; p.ldq = ldq; p.Ny = Ny; p.Nx = Nx; p.M = M;
   p.split_k = S; p.split_stride = (size_t)Ny * Nx; p.out = S > 1 ? ws : out;
-  if (geo == 0 && S > 1 && tiles <= 62 && gemm_dynamic_tiles_on()) {  // the GPU is shared with collectives: queue the K-chunks per tile
-    const int share = stages / S, per_wg = share / 4 < 16 ? (share / 4 < 1 ? 1 : share / 4) : 16;  // chunks of >= 4 stages
-    p.chunk = S * per_wg;
-    p.queue = queue_slot();
+  // the phased schedule (same bits) where it exists; its queue mode needs chunks of at least four stages (a chunk's claim is settled in its
+  // first two stages and the stream needs the next chunk a stage and a half before the current one ends)
+  bool phased = geo == 0 && opt(OPT_GEMM_LOOP) != 0 && stages / S >= 2;
+  if (geo == 0 && S > 1 && gemm_dynamic_tiles_on()) {  // the GPU is shared with collectives: queue the K-chunks
+#ifndef OSUD_WGQ_PERWG
+#define OSUD_WGQ_PERWG 8
+#endif
+    const int share = stages / S, per_wg = share / 4 < OSUD_WGQ_PERWG ? (share / 4 < 1 ? 1 : share / 4) : OSUD_WGQ_PERWG;  // chunks of >= 4 stages, at most 8 per workgroup (a claim costs a scalar-memory round trip)
+    const bool ph_q = phased && per_wg >= 2 && stages / (S * per_wg) >= 4 && 1 + tiles * S <= kQueueWords;
+    if (ph_q || tiles <= 62) {  // (wgrad_kernel's per-tile ticket queue has room for 62 tiles)
+      p.chunk = S * per_wg;
+      p.queue = queue_slot();
+      phased = ph_q;
+    }
   }
-  // one unit per workgroup in the plain mode: XCD-contiguous unit order (WgradP::xcd_units)
-  p.xcd_units = (S > 1 && p.queue == nullptr) ? 1 : 0;
-  // the phased schedule (same bits; queue mode: chunks of at least four stages, so that a chunk's ticket is known before the stream needs it)
-  if (geo == 0 && opt(OPT_GEMM_LOOP) != 0 && stages / S >= 2 && (p.queue == nullptr || stages / p.chunk >= 4)) {
+  // one unit per workgroup: XCD-contiguous unit order (WgradP::xcd_units) in the plain mode and in the phased kernel's queue mode
+  p.xcd_units = (S > 1 && (p.queue == nullptr || phased)) ? 1 : 0;
+  if (phased) {
     constexpr size_t lds = 2 * (size_t)WGeo<2, 4, 4, 2>::STAGE + 8 * 4096;
     static bool attr_set = false;
     if (!attr_set) {
