@@ -372,7 +372,9 @@ struct WgSched {
   static constexpr int read_phase[PPW] = {0, 0, 1, 1, 2, 2, 3, 3};
 };
 
-__global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
+// (DYN: the queue mode is its own instantiation -- with the claim protocol compiled into the one kernel the plain mode's launches ran 13 % longer,
+//  109.5 -> 123.8 us in the training step on the same box: profiles/r06_ab_runs.md)
+template <bool DYN> __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
   using G = WGeo<2, 4, 4, 2>;
   using S = WgSched;
   static_assert(sched_ok<S>(), "phase table breaks a staging rule");
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
   // claim and one look that finds nothing.  The chunk goes out through the first word of wave 0's (idle) epilogue patch (six operations at most:
   // up to phase 1 of the second stage); all waves read it in phase 3 of the second stage -- the cursor of a four-stage chunk, the shortest
   // the launcher allows, moves on in phase 1 of the third.
-  const bool dyn = p.queue != nullptr;
+  constexpr bool dyn = DYN;
   const int nch = dyn ? p.chunk : 1, per_wg = dyn ? p.chunk / p.split_k : 1;
   auto chunk_begin = [&](int c) { return (int)((long)c * st_total / nch); };  // (lengths differ by at most one stage)
   int sidx = blockIdx.y, bx = blockIdx.x;
@@ -532,6 +534,9 @@ __global__ __launch_bounds__(512) void wgrad_phased_kernel(WgradP p) {
   // what this phase does for the search: 0 claim on the own word, 1 claim on q_pick's, 2 look at window q_win, -1 nothing left anywhere
   auto q_action = [&]() -> int {
     if (!own_done) return 0;
+#ifdef OSUD_WGQ_NOSTEAL
+    return -1;
+#endif
     if (q_pick >= 0) return 1;
     return q_win * 8 < p.split_k ? 2 : -1;
   };
@@ -1041,13 +1046,15 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
     constexpr size_t lds = 2 * (size_t)WGeo<2, 4, 4, 2>::STAGE + 8 * 4096;
     static bool attr_set = false;
     if (!attr_set) {
-      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_phased_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_phased_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_phased_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr_set = true;
     }
     int grid = cus / p.split_k;
     if (grid < 1) grid = 1;
     if (grid > tiles || p.split_k > 1) grid = tiles;
-    hipLaunchKernelGGL(wgrad_phased_kernel, dim3(grid, p.split_k), dim3(512), lds, st, p);
+    if (p.queue != nullptr) hipLaunchKernelGGL(wgrad_phased_kernel<true>, dim3(grid, p.split_k), dim3(512), lds, st, p);
+    else hipLaunchKernelGGL(wgrad_phased_kernel<false>, dim3(grid, p.split_k), dim3(512), lds, st, p);
     OSUD_HIP(hipGetLastError());
   } else if (geo == 0) OSUD_TRY((launch_wg<2, 4, 4, 2>(p, st)));
   else if (geo == 1) OSUD_TRY((launch_wg<4, 2, 2, 3>(p, st)));

@@ -24,78 +24,85 @@ for i, l in enumerate(lines):
         labels[m.group(1)] = i
 
 
-def walk(start, reg):
-    """Every path from line `start` to the first lgkmcnt(0) wait: returns a list of offending (line, text).  Both sides of a conditional branch
-    are followed unless its direction is known: hipcc guards the "no claim this slot" code that sits between the asm and the join with
-    `s_mov_b64 s[a:b], 0 | -1` ... `s_andn2_b64 vcc, exec, s[a:b]` ... `s_cbranch_vccnz / vccz`, so pairs set to 0 / -1 on the path and the vcc made
-    from them are tracked.  Bounded: a path that has not met a wait after 3000 instructions counts as offending."""
-    bad, seen, work = [], set(), [(start, 0, {}, None)]
+ALL_SOURCES = ("s_cmp", "s_bitcmp", "s_cbranch", "global_store", "ds_write", "buffer_store", "scratch_store", "s_waitcnt", "s_barrier", "s_setprio", "s_nop")
+
+
+def touches(t, hit):
+    """How instruction text `t` uses the register(s) `hit` matches: "read" (a source operand), "write" (destination only) or None."""
+    ops = t.split(None, 1)
+    if len(ops) < 2:
+        return None
+    operands = [o.strip() for o in ops[1].split(",")]
+    srcs = operands if ops[0].startswith(ALL_SOURCES) else operands[1:]
+    if any(hit(o) for o in srcs):
+        return "read"
+    return "write" if hit(operands[0]) else None
+
+
+def walk(start, hit, landing=None):
+    """Every path from line `start` until the result has landed: a scalar result with the first s_waitcnt lgkmcnt(0), a vector claim (landing =
+    its register name) with the asm statement `s_waitcnt vmcnt(N)` + `v_readfirstlane_b32 sX, vN`.  The compiler believes an asm result is
+    there at once, so the hazard is a COPY: any instruction that READS the register in front of the landing fails (a spill, a v_mov / s_mov
+    of it -- also one that is copied back later).  A path on which the register is WRITTEN first is a path on which no operation is in
+    flight (both sides of the protocol's branches are laid out between the two statements; the compiler never overwrites a value it
+    holds live) and ends there.  Both sides of conditional branches are followed."""
+    bad, seen, work = [], set(), [start]
     while work:
-        j, depth, pairs, vcc = work.pop()
-        pairs = dict(pairs)
+        j = work.pop()
+        steps = 0
         while j < len(lines):
-            if (j, vcc) in seen:
+            if j in seen:
                 break
-            seen.add((j, vcc))
+            seen.add(j)
             t = lines[j].strip()
             j += 1
             if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
                 continue
-            depth += 1
-            if depth > 3000:
-                bad.append((j, "no wait within 3000 instructions"))
+            steps += 1
+            if steps > 8000:
+                bad.append((j, "no landing within 8000 instructions"))
                 break
-            if "s_waitcnt" in t and "lgkmcnt(0)" in t:
+            if landing is None and "s_waitcnt" in t and "lgkmcnt(0)" in t:
                 break
-            if reg(t):
+            if landing is not None and re.match(r"v_readfirstlane_b32 s\d+, " + landing + r"$", t):
+                k = j - 2
+                while k >= 0 and (not lines[k].strip() or lines[k].strip().startswith(";")):
+                    k -= 1
+                if not re.match(r"s_waitcnt vmcnt\((\d+)\)", lines[k].strip()):
+                    bad.append((j, "read without its counted wait: " + t))
+                break
+            use = touches(t, hit)
+            if use == "read":
                 bad.append((j, t))
                 break
-            m = re.match(r"s_mov_b64 (s\[\d+:\d+\]), (0|-1)$", t)
-            if m:
-                pairs[m.group(1)] = int(m.group(2))
-            else:
-                m = re.match(r"s_andn2_b64 vcc, exec, (s\[\d+:\d+\])$", t)
-                if m:
-                    vcc = {0: "nz", -1: "z"}.get(pairs.get(m.group(1)))
-                elif re.match(r"\S+\s+(s\[\d+:\d+\]|vcc)\b", t):  # any other write to a tracked pair / vcc: forget it
-                    w = re.match(r"\S+\s+(s\[\d+:\d+\]|vcc)\b", t).group(1)
-                    if w == "vcc":
-                        vcc = None
-                    else:
-                        pairs.pop(w, None)
+            if use == "write":
+                break
             m = re.match(r"(s_cbranch_\w+|s_branch)\s+(\S+)", t)
             if m:
                 tgt = labels.get(m.group(2))
                 if tgt is None:
                     bad.append((j, "unknown branch target " + t))
                     break
-                kind = m.group(1)
-                taken = None
-                if kind == "s_cbranch_vccnz" and vcc is not None:
-                    taken = vcc == "nz"
-                if kind == "s_cbranch_vccz" and vcc is not None:
-                    taken = vcc == "z"
-                if kind == "s_branch" or taken is True:
+                if m.group(1) == "s_branch":
                     j = tgt
                     continue
-                if taken is None:
-                    work.append((tgt, depth, pairs, vcc))
+                work.append(tgt)
             if t.startswith(("s_endpgm", "s_setpc")):
-                bad.append((j, "leaves the kernel before a wait: " + t))
                 break
     return bad
 
 
 def reg_pattern(dest):
-    """A regex matching any mention of the SGPRs in `dest` ("s37" or "s[8:15]"), alone or inside a range operand."""
-    m = re.match(r"s\[(\d+):(\d+)\]", dest)
+    """A predicate matching any mention of the registers in `dest` ("s37", "s[8:15]", "v131"), alone or inside a range operand."""
+    kind = dest[0]
+    m = re.match(kind + r"\[(\d+):(\d+)\]", dest)
     lo, hi = (int(m.group(1)), int(m.group(2))) if m else (int(dest[1:]), int(dest[1:]))
-    singles = "|".join(f"s{r}" for r in range(lo, hi + 1))
+    singles = "|".join(f"{kind}{r}" for r in range(lo, hi + 1))
 
     def hits(text):
         if re.search(r"\b(" + singles + r")\b", text):
             return True
-        for a, b in re.findall(r"s\[(\d+):(\d+)\]", text):
+        for a, b in re.findall(kind + r"\[(\d+):(\d+)\]", text):
             if int(a) <= hi and int(b) >= lo:
                 return True
         return False
@@ -103,17 +110,31 @@ def reg_pattern(dest):
 
 
 n = bad = 0
+in_phased = False
 for i, l in enumerate(lines):
+    if re.match(r"^_ZN.*wgrad_phased_kernel.*:", l):
+        in_phased = True
+    if ".end_amdhsa_kernel" in l:
+        in_phased = False
     m = re.search(r"(s_atomic_add|s_load_dwordx8) (s\d+|s\[\d+:\d+\]),", l)
-    if not m or "glc" not in l:
-        continue
-    n += 1
-    off = walk(i + 1, reg_pattern(m.group(2)))
-    if off:
-        bad += 1
-        for j, t in off:
-            print(f"line {i + 1}: {l.strip()} -- before the wait, line {j}: {t}")
-    else:
-        print(f"line {i + 1}: {l.strip()} -- no path touches {m.group(2)} before an s_waitcnt lgkmcnt(0)")
-print(f"{n} scalar memory operations with late results, {bad} unsafe")
+    if m and "glc" in l:
+        n += 1
+        off = walk(i + 1, reg_pattern(m.group(2)))
+        if off:
+            bad += 1
+            for j, t in off:
+                print(f"line {i + 1}: {l.strip()} -- before the wait, line {j}: {t}")
+        else:
+            print(f"line {i + 1}: {l.strip()} -- no path touches {m.group(2)} before an s_waitcnt lgkmcnt(0)")
+    m = re.search(r"global_atomic_add (v\d+), v\d+, v\d+, s\[\d+:\d+\] sc0$", l.strip())
+    if m and in_phased and lines[i - 1].strip() == "s_mov_b64 exec, 1":  # (the protocol's own: the compiler's atomics carry the compiler's waits)
+        n += 1
+        off = walk(i + 1, reg_pattern(m.group(1)), landing=m.group(1))
+        if off:
+            bad += 1
+            for j, t in off:
+                print(f"line {i + 1}: {l.strip()} -- line {j}: {t}")
+        else:
+            print(f"line {i + 1}: {l.strip()} -- {m.group(1)} is not read before its s_waitcnt vmcnt(N) + v_readfirstlane")
+print(f"{n} operations with late results, {bad} unsafe")
 sys.exit(1 if bad or n == 0 else 0)

@@ -76,12 +76,12 @@ def main(args):
     if args.select_exchange and world_size > 1 and not args.zero1 and not args.native_comm:
         # which exchange this node runs faster is MEASURED -- 3 steps each on synthetic windows of the run's shape, with lr = 0 on throw-away
         # trainers (the weights the run starts from are not touched; moments and EMA copies die with the probe) -- and agreed by all ranks
-        from osu_diffusion_amd.synthetic import synthetic_windows
+        from osu_diffusion_amd.synthetic import synthetic_windows as probe_windows  # (a local name: `synthetic_windows` is the module-level import the batch generator below closes over)
         from osu_diffusion_amd.training import select_exchange_schedule
 
         probe = []
         for i in range(2):
-            (px, po, pc), py = synthetic_windows(args.global_batch_size // world_size, args.seq_len, args.num_classes, seed=977 * rank + i, train_offsets=True)
+            (px, po, pc), py = probe_windows(args.global_batch_size // world_size, args.seq_len, args.num_classes, seed=977 * rank + i, train_offsets=True)
             probe.append(((px.to(device), po.to(device), pc.to(device)), py.to(device)))
         model.train()
         sel = select_exchange_schedule(lambda shard_optimizer: NativeTrainer(model, diffusion, lr=0.0, shard_optimizer=shard_optimizer, broadcast_init=False),
