@@ -197,8 +197,8 @@ def gemm_roofline(M, N, K, dev, iters=50):
     traffic, src = None, None
     try:  # HBM bytes per launch of this kernel from the committed rocprofv3 --pmc passes (not measurable in-process)
         if M == 32768:
-            traffic = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))["fc1_forward"]["hbm_bytes_per_launch"]
-            src = "profiles/r05_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2 per the gfx950 note)"
+            traffic = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")))["fc1_forward"]["hbm_bytes_per_launch"]
+            src = "profiles/r06_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2 per the gfx950 note)"
         else:
             traffic = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_fc1.json")))[f"M={M}"]["hbm_bytes_per_launch"]
             src = "profiles/r02_pmc_fc1.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2 per the gfx950 note)"
@@ -250,10 +250,10 @@ def wgrad_roofline(M, D, dev, iters=8):
     ach = flops / (avg_us * 1e-6) / 1e12
     traffic, src = None, None
     try:  # HBM bytes per launch (kernel + combine pass, fc1's shape) from the committed rocprofv3 --pmc passes (not measurable in-process)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")))["wgrad_fc1"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")))["wgrad_fc1"]
         if pmc["M"] == M and D == 768:
             traffic = pmc["hbm_bytes_per_launch"]
-            src = ("profiles/r05_pmc_traffic.json (fc1's shape: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/wgrad_only.py, separate passes, "
+            src = ("profiles/r06_pmc_traffic.json (fc1's shape: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/wgrad_only.py, separate passes, "
                    "read side x2 per the gfx950 note)")
     except Exception:
         pass
