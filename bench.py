@@ -739,6 +739,8 @@ def bench_train(args, world, rank, dev):
                 "ms_per_step": round(floor_ms, 3), "vs_single_gpu_step": round(floor_ms / (dt / K * 1e3), 4), "steps": K,
                 "what": "phased backward + early AdamW + ticket-queued tiles / K-chunks / heads (dynamic tiles on), collectives stubbed, one GPU"}
             del tr2
+        except Exception as e:  # noqa: BLE001  (a diagnostic leg must not cost the line its headline)
+            res["multi_gpu_schedule_compute_floor"] = {"error": f"{type(e).__name__}: {e}"[:200]}
         finally:
             _l.check(_l.lib().osud_set_gemm_dynamic_tiles(-1))
         trainer = None

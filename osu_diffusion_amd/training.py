@@ -305,26 +305,35 @@ def select_exchange_schedule(make_trainer, batches, group=None, steps=3, warmup=
 
     out = {"steps": int(steps), "world_size": world}
     for name, shard in (("allreduce", False), ("zero1", True)):
-        tr = make_trainer(shard_optimizer=shard)
-        for i in range(warmup):
-            (x, o, c), y = batches[i % len(batches)]
-            tr.step(x, o, c, y)
-        tr.finish_exchange()
-        fence()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            (x, o, c), y = batches[i % len(batches)]
-            tr.step(x, o, c, y)
-        tr.finish_exchange()
-        fence()
-        ms = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64, device=device if on_gpu else "cpu")
-        dist.all_reduce(ms, op=dist.ReduceOp.MAX, group=group)
-        out[name + "_ms"] = round(float(ms.item()), 3)
-        del tr
-        if on_gpu:
-            torch.cuda.empty_cache()
+        tr = None
+        try:
+            tr = make_trainer(shard_optimizer=shard)
+            for i in range(warmup):
+                (x, o, c), y = batches[i % len(batches)]
+                tr.step(x, o, c, y)
+            tr.finish_exchange()
+            fence()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                (x, o, c), y = batches[i % len(batches)]
+                tr.step(x, o, c, y)
+            tr.finish_exchange()
+            fence()
+            ms = torch.tensor([(time.perf_counter() - t0) / steps * 1e3], dtype=torch.float64, device=device if on_gpu else "cpu")
+            dist.all_reduce(ms, op=dist.ReduceOp.MAX, group=group)
+            out[name + "_ms"] = round(float(ms.item()), 3)
+        except Exception as e:  # noqa: BLE001
+            # a schedule that does not run on this node (raised on every rank alike: a missing library, an unsupported collective) must not take
+            # the job with it: the other one is kept.  (A failure on ONE rank leaves the others inside a collective: the caller's watchdog.)
+            if name == "allreduce":
+                raise
+            out[name + "_error"] = f"{type(e).__name__}: {e}"[:200]
+        finally:
+            del tr
+            if on_gpu:
+                torch.cuda.empty_cache()
     # (ties and near-ties -- within 2 % -- keep the all-reduce: same results to the last bit as the single-call reference path)
-    out["name"] = "zero1" if out["zero1_ms"] < 0.98 * out["allreduce_ms"] else "allreduce"
+    out["name"] = "zero1" if "zero1_ms" in out and out["zero1_ms"] < 0.98 * out["allreduce_ms"] else "allreduce"
     return out
 
 

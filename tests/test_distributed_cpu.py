@@ -489,6 +489,14 @@ def _selection_worker(rank, world, port, out):
         for case, extra in (("a", {"allreduce": 0.0, "zero1": 0.02}), ("b", {"allreduce": 0.03 if rank == 1 else 0.0, "zero1": 0.01}),
                             ("c", {"allreduce": 0.0500, "zero1": 0.0495})):
             res[case] = select_exchange_schedule(lambda shard_optimizer, e=extra: _SlowExchangeTrainer(shard_optimizer, e), batches, steps=3, warmup=1)
+
+        # (d) the sharded form cannot be built on this node (raised on every rank alike): the all-reduce is kept, the error is on record
+        def only_allreduce(shard_optimizer):
+            if shard_optimizer:
+                raise RuntimeError("no reduce-scatter here")
+            return _SlowExchangeTrainer(False, {"allreduce": 0.0, "zero1": 0.0})
+
+        res["d"] = select_exchange_schedule(only_allreduce, batches, steps=2, warmup=1)
         out[rank] = res
     finally:
         dist.destroy_process_group()
@@ -505,6 +513,7 @@ def test_exchange_schedule_is_selected_by_measurement_and_agreed_by_every_rank()
     assert res[0]["a"]["name"] == "allreduce" and res[0]["a"]["zero1_ms"] > res[0]["a"]["allreduce_ms"]
     assert res[0]["b"]["name"] == "zero1" and res[0]["b"]["allreduce_ms"] > 30.0  # rank 1's slow steps decide for both
     assert res[0]["c"]["name"] == "allreduce"
+    assert res[0]["d"]["name"] == "allreduce" and "no reduce-scatter here" in res[0]["d"]["zero1_error"] and "zero1_ms" not in res[0]["d"]
     from osu_diffusion_amd.training import select_exchange_schedule
 
     assert select_exchange_schedule(None, [])["name"] == "allreduce"  # no process group: nothing is run
