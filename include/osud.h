@@ -312,6 +312,14 @@ int osud_get_option(const char* name, int* value);
 int osud_op_gemm(int precision, int epilogue, const void* Y, int ldy, const void* X, int ldx, int My, int Nx, int K,
                  void* out, int ldo, const float* bias, const float* gate, int ld_gate, int rows_per_sample,
                  int n_samples, osud_stream stream);
+/* osud_op_gemm with the second tensor of the TRAINING epilogues (csrc/gemm.h): out2 = what the epilogue saves for the backward pass
+ * (4 bias + GELU: the GELU derivative; 2 bias + SiLU: the pre-activation), aux = what epilogue 9 multiplies the product with (the saved GELU
+ * derivative), colpart (epilogue 9, optional) = [My / 128 or My / 64][Nx] partial column sums of the output.  aux_code = 1: the derivative
+ * is the 8-bit block code of option gelu_code (one byte per element; 32 x 32 blocks of 1 KiB, block (y / 32, x / 32) at ((y / 32) * (ldo / 32)
+ * + x / 32) * 1024, lane l = 4 * (row & 15) + ((col & 31) >> 3) holds 16 bytes at 16 l: columns (col & ~7) .. + 7 of row (row & 15), then of row
+ * 16 + (row & 15); value = (code - 26) / 200) instead of rows of the tier's element type.  bf16 and fp32 tiers (fp32: aux_code = 0). */
+int osud_op_gemm_ex(int precision, int epilogue, const void* Y, int ldy, const void* X, int ldx, int My, int Nx, int K, void* out, int ldo,
+                    const float* bias, void* out2, const void* aux, int aux_code, float* colpart, osud_stream stream);
 /* fp16 + e4m3 operand form of OSUD_PREC_F16F8 (csrc/common.h: h8_t): src fp32 [rows][ld_src] (cols_src used, zero padded to cols_dst,
  * a multiple of 32) -> dst [rows][4 * cols_dst bytes], K-blocked groups of 32; weight = 1 for the weight flavour (planes swapped). */
 int osud_op_pack_h8(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, int weight, osud_stream stream);

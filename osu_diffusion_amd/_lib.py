@@ -89,6 +89,7 @@ _SIGNATURES = {
     "osud_table_rows_pack": (_i, [_vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "osud_table_rows_apply": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp]),
     "osud_op_gemm": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _i, _i, _i, _vp]),
+    "osud_op_gemm_ex": (_i, [_i, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "osud_op_convert": (_i, [_i, _vp, _vp, _sz, _vp]),
     "osud_op_pack_h8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp]),
     "osud_op_pack_w8": (_i, [_vp, _i, _i, _vp, _i, _i, _i, _vp]),

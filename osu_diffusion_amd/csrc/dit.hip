@@ -823,6 +823,19 @@ extern "C" int osud_op_gemm(int precision, int epilogue, const void* Y, int ldy,
   p.gate = gate; p.ld_gate = ld_gate; p.rows_per_sample = rows_per_sample; p.n_samples = n_samples;
   return launch_gemm(precision, epilogue, p, (hipStream_t)stream);
 }
+extern "C" int osud_op_gemm_ex(int precision, int epilogue, const void* Y, int ldy, const void* X, int ldx, int My, int Nx, int K, void* out,
+                               int ldo, const float* bias, void* out2, const void* aux, int aux_code, float* colpart, osud_stream stream) {
+  OSUD_CHECK_ARG(precision == OSUD_PREC_BF16 || precision == OSUD_PREC_F32, "op_gemm_ex: the training epilogues exist in the bf16 and fp32 tiers");
+  GemmP p{};
+  p.Y = Y; p.X = X; p.ldy = ldy; p.ldx = ldx; p.My = My; p.Nx = Nx; p.K = K; p.out = out; p.ldo = ldo; p.bias = bias;
+  p.out2 = out2; p.aux = aux; p.aux_code = aux_code;
+  int rows = 0;
+  if (colpart != nullptr) {
+    p.colpart = colpart;
+    p.colpart_rows = &rows;
+  }
+  return launch_gemm(precision, epilogue, p, (hipStream_t)stream);
+}
 extern "C" int osud_op_pack_w8(const float* src, int ld_src, int cols_src, void* dst, int cols_dst, int rows, int weight, osud_stream stream) {
   OSUD_CHECK_ARG(src && dst, "op_pack_w8: null argument");
   return launch_pack_rows_w8(src, ld_src, cols_src, dst, cols_dst, rows, weight != 0, (hipStream_t)stream);

@@ -22,7 +22,7 @@ def pytest_configure(config):
 # another (`selfcheck`) come last: one of those failing must never hide a parity test again.
 _FILE_ORDER = ["test_oracle_golden", "test_bench_line", "test_native_host", "test_windows", "test_curves", "test_beatmap", "test_toy_dataset",
                "test_distributed_cpu", "test_gpu_forward", "test_gpu_x3", "test_gpu_h8", "test_gpu_f16", "test_inpaint", "test_gpu_refine",
-               "test_gpu_train", "test_gpu_fullsize", "test_gpu_w8", "test_gpu_fp8", "test_gpu_configs", "test_gpu_exchange", "test_gpu_scripts", "test_gpu_multiproc",
+               "test_gpu_train", "test_gpu_gelu_code", "test_gpu_fullsize", "test_gpu_w8", "test_gpu_fp8", "test_gpu_configs", "test_gpu_exchange", "test_gpu_scripts", "test_gpu_multiproc",
                "test_gpu_phased"]
 
 
