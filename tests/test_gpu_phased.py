@@ -95,6 +95,32 @@ def test_many_rounds_and_the_shortest_stream(osud_option):
         assert torch.equal(a, b), (M, N, K, tile)
 
 
+def test_e4m3_operands_on_a_multi_round_grid_with_an_odd_slab_count(osud_option):
+    """DiT-XL's fp8 shape class: e4m3 operands (128 k per 128-byte slab), K = 1152 = 9 slabs, 16384 x 1152 outputs = 384 tiles of 256 x 192 on
+    <= 256 workgroups: a workgroup enters its second tile with the stream cursor and the consumer's buffer parity flipped.  Bit equality of
+    the two loops, static and queued tile order."""
+    g = torch.Generator(device=DEV).manual_seed(8)
+    M, N, K = 16384, 1152, 1152
+    Y = torch.randn(M, K, device=DEV, generator=g).to(torch.float8_e4m3fn)
+    X = (torch.randn(N, K, device=DEV, generator=g) / K ** 0.5 * 8).to(torch.float8_e4m3fn)
+    bias = torch.randn(N, device=DEV, generator=g)
+    L = _lib.lib()
+    outs = []
+    try:
+        for loop, dyn in ((0, 0), (1, 0), (1, 1)):
+            osud_option("gemm_loop", loop)
+            _lib.check(L.osud_set_gemm_dynamic_tiles(dyn))
+            out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+            _gemm(_lib.PREC_FP8, "bias", Y, K, X, K, M, N, K, out, bias, None)
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        _lib.check(L.osud_set_gemm_dynamic_tiles(-1))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ref = Y.float() @ X.float().t() + bias
+    assert float((outs[1].float() - ref).abs().max()) < 1e-2 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("shape", [(256, 256, 128), (512, 256, 1024), (768, 3072, 8192), (1152, 1152, 4096), (384, 256, 2048)])
 def test_weight_gradient_kernel_is_bit_identical_to_the_slab_loop(osud_option, shape):
     """out = P^T Q over M tokens: split over the token axis into partial slabs + the fixed-order combine; odd multiples of 128 (half-empty edge
