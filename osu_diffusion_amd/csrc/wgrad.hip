@@ -25,6 +25,13 @@ namespace osud {
 namespace {
 
 constexpr int BKT = 64;  // tokens per stage
+#ifndef OSUD_WG192_MARGIN
+// how much better a 192-wide geometry has to fill the chip (useful tile area x occupied compute units) than the padded 256 x 256 one to be
+// taken.  At DiT-XL's shapes the ratio is 1.27-1.34 and the two phased kernels are a wash: a block's four weight gradients 1127 us
+// (192-wide) vs 1172 us (padded 256 x 256) stand-alone, but 111.2 vs 110.7 ms per XL bf16 training step -- the 256 x 256 geometry stays the
+// choice there (profiles/r06_wgrad_xl_geometry.txt); the slab loop's 192-wide kernels were 5 % behind both
+#define OSUD_WG192_MARGIN 1.5
+#endif
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -680,6 +687,194 @@ template <bool DYN> __global__ __launch_bounds__(512) void wgrad_phased_kernel(W
 
 
 // ---------------------------------------------------------------------------------------------------------------------------
+// The 256 x 192 (NARROW_Y = false) and 192 x 256 (NARROW_Y = true) geometries in the phased schedule: DiT-XL's widths (1152 = 6 x 192,
+// 3456 = 18 x 192, 4608 = 24 x 192) tile exactly with a 192-wide side, where the 256 x 256 kernel pads 10 % of its tiles' area and fills
+// two thirds of the chip.  Same staging image, transposing reads and MFMAs as wgrad_kernel<4, 2, 2, 3> / <2, 4, 3, 2>, every accumulator
+// sees its tokens in the same order: bit-identical partial slabs.  A phase is one k sub-step (16 tokens of both operands: 10 transposing
+// reads, 6 MFMAs = 192 pipe cycles per wave).  The wide part (512-byte token rows) splits into one 8-piece slot per sub-step; the narrow part
+// (384-byte rows: 24 pieces per stage, 6 per sub-step) into three 8-piece slots Na Nb Nc, whose pieces straddle token rows -- the per-lane
+// source offsets are computed per 16-byte chunk -- so sub-step s reads Na | Na Nb | Nb Nc | Nc.  Stream order W0 Na W1 Nb W2 Nc W3: need
+// {1, 3, 5, 6}; seven pieces per wave and stage, ten in flight, vmcnt(8) per phase.
+struct Wg192Sched {
+  static constexpr int NPH = 4, PPW = 7, AHEAD = 10;
+  static constexpr int cnt[NPH] = {2, 2, 1, 2};
+  static constexpr int need[NPH] = {1, 3, 5, 6};
+  static constexpr int read_phase[PPW] = {0, 1, 1, 2, 2, 3, 3};
+};
+
+template <bool NARROW_Y> __global__ __launch_bounds__(512) void wgrad_phased192_kernel(WgradP p) {
+  using G = typename std::conditional<NARROW_Y, WGeo<2, 4, 3, 2>, WGeo<4, 2, 2, 3>>::type;
+  using S = Wg192Sched;
+  static_assert(sched_ok<S>(), "phase table breaks a staging rule");
+  constexpr int WX = NARROW_Y ? 4 : 2, RY = NARROW_Y ? 3 : 2, RX = NARROW_Y ? 2 : 3, NPH = S::NPH, PPW = S::PPW, STAGE = G::STAGE, RING = 2 * STAGE;
+  static_assert(G::NSTAGE == 2 && G::PPW == PPW && G::ROWY == (NARROW_Y ? 384 : 512) && G::ROWX == (NARROW_Y ? 512 : 384) && RING + 8 * 4096 <= 160 * 1024, "geometry");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wy = wave / WX, wx = wave % WX, grp = wave >> 2;
+  const int frow = lane & 31, fhalf = lane >> 5;
+  const int ntx = (p.Nx + G::BN - 1) / G::BN, ntiles = ((p.Ny + G::BM - 1) / G::BM) * ntx;
+  const int st_total = p.M / BKT;
+  int sidx = blockIdx.y, bx = blockIdx.x;
+  if (p.xcd_units) {  // (tile, split) units in split-major order, one contiguous run per XCD: see WgradP::xcd_units
+    const int total = gridDim.x * gridDim.y, L = blockIdx.x + blockIdx.y * gridDim.x;
+    const int q = total >> 3, r = total & 7, xcd = L & 7, idx = L >> 3;
+    const int u = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    sidx = u / (int)gridDim.x;
+    bx = u - sidx * (int)gridDim.x;
+  }
+  const int st_begin = (int)((long)sidx * st_total / p.split_k);
+  const int nst = (int)((long)(sidx + 1) * st_total / p.split_k) - st_begin;
+  const size_t ldp_b = (size_t)p.ldp * 2, ldq_b = (size_t)p.ldq * 2;
+  const char* const gp0 = reinterpret_cast<const char*>(p.P) + (size_t)st_begin * BKT * ldp_b;
+  const char* const gq0 = reinterpret_cast<const char*>(p.Q) + (size_t)st_begin * BKT * ldq_b;
+  float* const outp = p.out + (size_t)sidx * p.split_stride;
+  const int G8 = gridDim.x;
+  int first;
+  {
+    const int b = blockIdx.x, q = G8 >> 3, r = G8 & 7, xcd = b & 7, idx = b >> 3;
+    first = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    if (p.xcd_units) first = bx;
+  }
+
+  // fragment addresses (stage 0, sub-step 0), exactly wgrad_kernel's for this geometry
+  const uint32_t lds0 = (uint32_t)(size_t)(lds_void*)smem;
+  const int tok0 = 8 * fhalf + ((lane & 15) >> 2);
+  const int swy = G::swz(G::ROWY, tok0), swx = G::swz(G::ROWX, tok0);
+  const int fbyte = 32 * ((lane >> 4) & 1) + 8 * (lane & 3);
+  uint32_t ya[RY], xa[RX];
+#pragma unroll
+  for (int i = 0; i < RY; ++i) ya[i] = lds0 + tok0 * G::ROWY + (((wy * RY + i) ^ swy) * 64) + fbyte;
+#pragma unroll
+  for (int j = 0; j < RX; ++j) xa[j] = lds0 + G::YB + tok0 * G::ROWX + (((wx * RX + j) ^ swx) * 64) + fbyte;
+  // LDS-DMA: stream order W0 Na W1 Nb W2 Nc W3.  Even slot m = 2 s: piece 8 s + w of the WIDE part (token rows 16 s + 2 w, + 1); odd slot
+  // m = 2 j + 1: piece 8 j + w of the NARROW part (1 KiB of 384-byte rows: per-chunk token / position).  P is the wide part unless NARROW_Y.
+  uint32_t voff[PPW];
+#pragma unroll
+  for (int m = 0; m < PPW; ++m) {
+    const bool wide = (m & 1) == 0;
+    const bool isY = wide != NARROW_Y;                      // this slot belongs to the P part
+    const int rowb = wide ? 512 : 384, lpr = rowb / 16;
+    const int pb = (8 * (m >> 1) + wave) * 1024;            // byte offset inside the part
+    const int cidx = pb / 16 + lane;
+    const int tok = cidx / lpr, pos = cidx - tok * lpr;
+    const int c = pos ^ (G::swz(rowb, tok) << 2);
+    voff[m] = (uint32_t)((size_t)tok * (isY ? ldp_b : ldq_b) + (size_t)c * 16);
+  }
+  const uint32_t patch = lds0 + RING + wave * 4096;
+  uint32_t pw[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) pw[g] = patch + frow * 128 + (((2 * g + fhalf) ^ (frow & 7)) << 4);
+  const uint32_t pr = patch + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+
+  // ---- the staging stream
+  int c_tile = first, c_st = 0;
+  uint32_t c_buf = 0;
+  bool c_live = c_tile < ntiles && nst > 0;
+  const char *c_gp, *c_gq;
+  auto tile_base = [&](int t, const char*& gp, const char*& gq) {
+    const int ty = t / ntx, tx = t - ty * ntx;
+    gp = gp0 + (size_t)ty * G::BM * 2;
+    gq = gq0 + (size_t)tx * G::BN * 2;
+  };
+  tile_base(c_tile, c_gp, c_gq);
+  auto stage_slot = [&](auto M) {
+    constexpr int m = decltype(M)::value;
+    constexpr bool wide = (m & 1) == 0, isY = wide != NARROW_Y;
+    const char* sb = isY ? c_gp : c_gq;
+    const uint32_t dst = lds0 + c_buf + (uint32_t)((isY ? 0 : G::YB) + (8 * (m >> 1) + wave) * 1024);
+    const uint32_t vo = voff[m];
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(sb), "s"(dst) : "memory");
+  };
+  auto advance = [&]() {
+    c_buf = STAGE - c_buf;
+    c_gp += (size_t)BKT * ldp_b;
+    c_gq += (size_t)BKT * ldq_b;
+    if (++c_st == nst) {
+      c_st = 0;
+      c_tile += G8;
+      c_live = c_tile < ntiles;
+      if (c_live) tile_base(c_tile, c_gp, c_gq);
+    }
+  };
+  auto stage_run = [&](auto P0, auto N) {
+    static_for<decltype(N)::value>([&](auto I) {
+      constexpr int m = (decltype(P0)::value + decltype(I)::value) % PPW;
+      if (c_live) stage_slot(std::integral_constant<int, m>{});
+      if constexpr (m == PPW - 1) {
+        if (c_live) advance();
+      }
+    });
+  };
+  stage_run(std::integral_constant<int, 0>{}, std::integral_constant<int, S::AHEAD>{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  uint32_t r_buf = 0;
+  for (int tile = first; tile < ntiles; tile += G8) {
+    const int ty = tile / ntx, tx = tile - ty * ntx;
+    f32x16 acc[RY][RX];
+#pragma unroll
+    for (int i = 0; i < RY; ++i)
+#pragma unroll
+      for (int j = 0; j < RX; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    TFrag<RY, RX> f;
+    if (grp == 1) __builtin_amdgcn_s_barrier();  // the stagger
+    for (int st = 0; st < nst; ++st) {
+      const bool last = st == nst - 1;
+      static_for<NPH>([&](auto PH) {
+        constexpr int P = decltype(PH)::value;
+        read_frags<RY, RX, P, G::ROWY, G::ROWX>(f, ya, xa, r_buf);
+        stage_run(std::integral_constant<int, S::AHEAD + ph_issued_before<S>(P)>{}, std::integral_constant<int, S::cnt[P]>{});
+        constexpr int W = ph_wait<S>(P);
+        if (!c_live) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (st > 0 || !ph_wait_predrained<S>(P)) wait_vmcnt<W>();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        OSUD_WG_WAIT(0);
+        __builtin_amdgcn_s_setprio(1);
+        mma_frags<RY, RX>(acc, f);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (P != NPH - 1 || !last || grp == 0) __builtin_amdgcn_s_barrier();
+      });
+      r_buf = STAGE - r_buf;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- the tile's partial slab (as wgrad_kernel's store_tile)
+#pragma unroll
+    for (int i = 0; i < RY; ++i) {
+      const int y0 = ty * G::BM + wy * RY * 32 + i * 32 + (lane >> 3);
+#pragma unroll
+      for (int j = 0; j < RX; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+          v[0] = acc[i][j][4 * g + 0]; v[1] = acc[i][j][4 * g + 1]; v[2] = acc[i][j][4 * g + 2]; v[3] = acc[i][j][4 * g + 3];
+          ds_write16(pw[g], v);
+        }
+        f32x4 t[4];
+        t[0] = ds_read16f<0>(pr);
+        t[1] = ds_read16f<1024>(pr);
+        t[2] = ds_read16f<2048>(pr);
+        t[3] = ds_read16f<3072>(pr);
+        OSUD_WG_WAIT(0);
+        const int x = tx * G::BN + wx * RX * 32 + j * 32 + 4 * (lane & 7);
+        if (x < p.Nx) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (y0 + 8 * q < p.Ny) store4(outp + (size_t)(y0 + 8 * q) * p.Nx + x, t[q][0], t[q][1], t[q][2], t[q][3]);
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
 // Weight gradients on e4m3 operands (fp8 training, BASELINE config 5):  out[y][x] = inv_p * inv_q * sum_m P8[m][y0 + y] * Q8[m][x0 + x]
 // P8 / Q8 are the e4m3 twins of the gradient / activation tensors (token-major, one byte per element, each quantised with its
 // slot's delayed scale; inv_p / inv_q = the slots' 1 / scale, device scalars).  Same structure as wgrad_kernel -- stages by
@@ -1010,9 +1205,7 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
     int t0 = 0, t1 = 0, t2 = 0;
     const double s0 = score(256, 256, &t0);
     const double s1 = Nx % 192 == 0 ? score(256, 192, &t1) : 0.0, s2 = Ny % 192 == 0 ? score(192, 256, &t2) : 0.0;
-    // (the 256 x 256 geometry runs the phased schedule -- 10-12 % faster per useful FLOP than the 192-wide slab kernels at DiT-XL's four shapes
-    //  although it fills the chip a third worse there: 1112 vs 1223 us for a block's weight gradients, profiles/r06_wgrad_xl_geometry.txt)
-    const double margin = opt(OPT_GEMM_LOOP) != 0 ? 1.5 : 1.12;
+    const double margin = OSUD_WG192_MARGIN;
     if (s1 >= s2 && s1 > margin * s0) { geo = 1; tiles = t1; }
     else if (s2 > s1 && s2 > margin * s0) { geo = 2; tiles = t2; }
   }
@@ -1057,7 +1250,22 @@ int launch_wgrad_tr(const void* P, int ldp, const void* Q, int ldq, int Ny, int 
     else hipLaunchKernelGGL(wgrad_phased_kernel<false>, dim3(grid, p.split_k), dim3(512), lds, st, p);
     OSUD_HIP(hipGetLastError());
   } else if (geo == 0) OSUD_TRY((launch_wg<2, 4, 4, 2>(p, st)));
-  else if (geo == 1) OSUD_TRY((launch_wg<4, 2, 2, 3>(p, st)));
+  else if ((geo == 1 || geo == 2) && opt(OPT_GEMM_LOOP) != 0 && stages / S >= 2) {  // the 192-wide geometries in the phased schedule (same bits)
+    constexpr size_t lds = 2 * (size_t)WGeo<4, 2, 2, 3>::STAGE + 8 * 4096;
+    static_assert(WGeo<4, 2, 2, 3>::STAGE == WGeo<2, 4, 3, 2>::STAGE, "one LDS size for both");
+    static bool attr_set = false;
+    if (!attr_set) {
+      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_phased192_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      OSUD_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_phased192_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_set = true;
+    }
+    int grid = cus / p.split_k;
+    if (grid < 1) grid = 1;
+    if (grid > tiles || p.split_k > 1) grid = tiles;
+    if (geo == 1) hipLaunchKernelGGL(wgrad_phased192_kernel<false>, dim3(grid, p.split_k), dim3(512), lds, st, p);
+    else hipLaunchKernelGGL(wgrad_phased192_kernel<true>, dim3(grid, p.split_k), dim3(512), lds, st, p);
+    OSUD_HIP(hipGetLastError());
+  } else if (geo == 1) OSUD_TRY((launch_wg<4, 2, 2, 3>(p, st)));
   else if (geo == 2) OSUD_TRY((launch_wg<2, 4, 3, 2>(p, st)));
   else OSUD_TRY((launch_wg<2, 2, 2, 2>(p, st)));
   if (S > 1) OSUD_TRY(launch_splitk_reduce(ws, S, (size_t)Ny * Nx, out, (size_t)Ny * Nx, st));
