@@ -312,7 +312,8 @@ int osud_get_option(const char* name, int* value);
 int osud_op_gemm(int precision, int epilogue, const void* Y, int ldy, const void* X, int ldx, int My, int Nx, int K,
                  void* out, int ldo, const float* bias, const float* gate, int ld_gate, int rows_per_sample,
                  int n_samples, osud_stream stream);
-/* osud_op_gemm with the second tensor of the TRAINING epilogues (csrc/gemm.h): out2 = what the epilogue saves for the backward pass
+/* osud_op_gemm with the second tensor of the TRAINING epilogues (csrc/gemm.h; reference: Mlp.forward models.py:112-119 with nn.GELU(approximate="tanh")
+ * :138 -- fc1 -> GELU -> fc2 -- and autograd's derivative of that GELU in train.py:257's backward): out2 = what the epilogue saves for the backward pass
  * (4 bias + GELU: the GELU derivative; 2 bias + SiLU: the pre-activation), aux = what epilogue 9 multiplies the product with (the saved GELU
  * derivative), colpart (epilogue 9, optional) = [My / 128 or My / 64][Nx] partial column sums of the output.  aux_code = 1: the derivative
  * is the 8-bit block code of option gelu_code (one byte per element; 32 x 32 blocks of 1 KiB, block (y / 32, x / 32) at ((y / 32) * (ldo / 32)
