@@ -829,6 +829,10 @@ extern "C" int osud_op_gemm_ex(int precision, int epilogue, const void* Y, int l
   GemmP p{};
   p.Y = Y; p.X = X; p.ldy = ldy; p.ldx = ldx; p.My = My; p.Nx = Nx; p.K = K; p.out = out; p.ldo = ldo; p.bias = bias;
   p.out2 = out2; p.aux = aux; p.aux_code = aux_code;
+#ifdef OSUD_PH_TIMING  // (timing builds, tools/gemm_phase_stamps.py: the cycle stamps leave through the gate pointer, which these epilogues do not use)
+  p.gate = colpart;
+  colpart = nullptr;
+#endif
   int rows = 0;
   if (colpart != nullptr) {
     p.colpart = colpart;

@@ -6,8 +6,8 @@ root=$(cd "$(dirname "$0")/.." && pwd); cs=$root/osu_diffusion_amd/csrc
 mkdir -p $root/ab
 build_one() {
   name=$1; flags=$2; b=$cs/build_v_$name
-  rm -rf $b && mkdir -p $b && cp $cs/build/*.o $b/ && rm -f $b/gemm_bf16.o $b/gemm_h8.o
-  for tu in gemm_bf16 gemm_h8; do
+  rm -rf $b && mkdir -p $b && cp $cs/build/*.o $b/ && rm -f $b/gemm_bf16.o $b/gemm_h8.o $b/dit.o
+  for tu in gemm_bf16 gemm_h8 dit; do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-gpu-rdc $flags -mllvm -amdgpu-atomic-optimizer-strategy=None \
        -c $cs/$tu.hip -o $b/$tu.o 2> $b/log_$tu.txt || { tail $b/log_$tu.txt; exit 1; }
   done

@@ -25,6 +25,9 @@ def pack_h8(t, weight):
     return o
 
 
+TRAIN = os.environ.get("TRAIN")  # "code" / "rows": the fc1 launch of a TRAINING step -- bias + GELU with the saved derivative as the 8-bit code / as bf16 rows
+if TRAIN:
+    SH = [("fc1 fwd 256x256 gelu + derivative (" + TRAIN + ")", _lib.EPI_BIAS_GELU_TE, M, 4 * D, D)]
 for name, epi, My, Nx, K in SH:
     Yf = torch.randn(My, K, device=dev); Xf = torch.randn(Nx, K, device=dev) / K ** 0.5
     if os.environ.get("ZERO") == "1":  # all-zero operands: what the same instruction stream costs when nothing toggles
@@ -38,6 +41,10 @@ for name, epi, My, Nx, K in SH:
     bias = torch.randn(max(My, Nx), device=dev) * 0.02
     dbg = torch.zeros(32 * 8 * 8, device=dev)
     go = lambda: _lib.check(L.osud_op_gemm(_lib.PREC_F16F8 if H8 else 0, epi, _lib.ptr(Y), K, _lib.ptr(X), K, My, Nx, K, _lib.ptr(out), Nx, _lib.ptr(bias), _lib.ptr(dbg), 0, 0, 0, None))
+    if TRAIN:  # (a timing build of dit.hip hands the stamps out through osud_op_gemm_ex's colpart pointer)
+        out2 = torch.zeros(My * Nx, dtype=torch.uint8, device=dev) if TRAIN == "code" else torch.zeros(My, Nx, dtype=torch.bfloat16, device=dev)
+        go = lambda: _lib.check(L.osud_op_gemm_ex(0, epi, _lib.ptr(Y), K, _lib.ptr(X), K, My, Nx, K, _lib.ptr(out), Nx, _lib.ptr(bias), _lib.ptr(out2), None,
+                                                  1 if TRAIN == "code" else 0, _lib.ptr(dbg), None))
     for _ in range(10): go()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
