@@ -211,6 +211,9 @@ template <typename TE, int EPI, int GEO> __global__ __launch_bounds__(512) void 
     const char* sb = S::is_y(m) ? c_gy : c_gx;
     const uint32_t dst = lds0 + c_buf + (uint32_t)((8 * m + wave) * 1024);
     const uint32_t vo = voff[m];  // (named outside the asm statement: an asm operand alone does not capture in a generic lambda)
+    // (M0 is written and consumed inside ONE asm statement.  It cannot be named as a clobber: hipcc treats M0 as a reserved register and rejects it
+    //  from clobber lists with a warning ("may not be preserved across the asm statement") -- the compiler never keeps a value of its own in M0
+    //  across an asm statement on this target: it re-materialises M0 in front of each of its own uses (s_movrel, LDS-DMA builtins, sendmsg).)
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(sb), "s"(dst) : "memory");
   };
   auto advance = [&]() {
